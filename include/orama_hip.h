@@ -1,0 +1,234 @@
+/*
+ * orama_hip.h — C ABI of liborama_hip.so: the MI355X (gfx950) implementation of OramaCore's
+ * hybrid-search scoring hot path.  This header IS the drop-in boundary: every entry point cites
+ * the reference interface it replaces (paths relative to the oramacore repository root), and
+ * INTEGRATION.md shows the Rust `extern "C"` shim that binds it inside the reference's wrappers.
+ *
+ * Conventions (mirroring the reference's seams — SURVEY.md §8b):
+ *   - plain pointers + sizes, no C++/torch types; every function returns an `int` status
+ *     (ORAMA_OK == 0) and never throws/aborts across the boundary;  the message of the last
+ *     failure on the calling thread is available from orama_last_error() — the shim turns it into
+ *     `anyhow::Error` (→ ReadError::Generic → HTTP 500, src/collection_manager/sides/read/mod.rs:136-138).
+ *   - borrowed inputs: query / filter / posting pointers are only read during the call;
+ *     outputs are caller-allocated buffers with the documented capacity.
+ *   - handles are owned by the wrapper struct that created them and are destroyed with it.
+ *   - re-entrancy: `*_search*` may be called concurrently from many threads on one handle and
+ *     concurrently with insert/delete (the reference calls search(&self) from many tokio workers
+ *     under a read lock — src/collection_manager/sides/read/collection.rs:846-884); the library
+ *     serialises mutation internally and gives each search its own stream + scratch.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with
+ *     ORAMA_ERR_HIP.
+ */
+#ifndef ORAMA_HIP_H
+#define ORAMA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORAMA_ABI_VERSION 1
+
+/* status codes */
+#define ORAMA_OK 0
+#define ORAMA_ERR_INVALID 1     /* bad argument (null handle, dim mismatch, k == 0 where illegal …) */
+#define ORAMA_ERR_HIP 2         /* HIP runtime failure / no device */
+#define ORAMA_ERR_OOM 3         /* device or host allocation failed */
+#define ORAMA_ERR_UNSUPPORTED 4 /* valid request outside the implemented envelope */
+
+/* DistanceMetric — oramacore_fields::embedding::DistanceMetric; the reference hard-codes Cosine
+ * (src/collection_manager/sides/read/index/embedding_field.rs:66,88).  L2 is a build-side extension. */
+#define ORAMA_METRIC_COSINE 0 /* distance = 1 - cos(q, x) */
+#define ORAMA_METRIC_L2SQ 1   /* distance = |q - x|^2 */
+
+/* storage element type of the HBM-resident corpus.  The reference stores f32 (Vec<f32> end to
+ * end, src/collection_manager/sides/operation/op.rs:144); f16 is a build-side extension. */
+#define ORAMA_DTYPE_F32 0
+#define ORAMA_DTYPE_F16 1
+
+typedef struct orama_ctx orama_ctx;   /* one per GPU: device ordinal, stream + scratch pools */
+typedef struct orama_vec orama_vec;   /* one per embedding field  (EmbeddingFieldStorage) */
+typedef struct orama_post orama_post; /* one per index: resident postings of its string fields */
+
+int orama_abi_version(void);
+/* Thread-local message of the last failing call on this thread ("" if none). Never NULL. */
+const char* orama_last_error(void);
+
+/* ------------------------------------------------------------------ context */
+int orama_ctx_create(int device_ordinal, orama_ctx** out);
+void orama_ctx_destroy(orama_ctx* ctx);
+int orama_ctx_synchronize(orama_ctx* ctx);
+/* Device facts for reports: name (<= 255 chars), CU count, HBM bytes. Any pointer may be NULL. */
+int orama_ctx_device_info(orama_ctx* ctx, char* name256, int* compute_units, uint64_t* hbm_bytes);
+
+/* Per-kernel HIP-event timing (used by bench.py's roofline leg).  When enabled, the library
+ * brackets each launch of the named hot kernels with hipEvents on the launching stream.
+ * kernels: "vec_scan_f32", "vec_scan_f16", "topk_select", "bm25_accumulate", "bm25_finalize". */
+int orama_prof_enable(orama_ctx* ctx, int on);
+int orama_prof_reset(orama_ctx* ctx);
+int orama_prof_get(orama_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
+
+/* ------------------------------------------------------------------ vector store
+ * Replaces oramacore_fields::embedding::EmbeddingStorage behind
+ * EmbeddingFieldStorage (src/collection_manager/sides/read/index/embedding_field.rs:63-320). */
+
+/* EmbeddingFieldStorage::new — embedding_field.rs:65-76 (EmbeddingConfig::new(dim, Cosine)). */
+int orama_vec_create(orama_ctx* ctx, uint32_t dim, int metric, int dtype, uint64_t reserve_rows,
+                     orama_vec** out);
+void orama_vec_destroy(orama_vec* v);
+
+/* EmbeddingFieldStorage::insert — embedding_field.rs:232-237 (N vectors per doc allowed).
+ * `rows` is n_rows x dim f32 row-major (host); doc_ids[i] is the DocumentId of row i.
+ * Rows that are non-finite or have zero norm are rejected (index_vec_vec -> None);
+ * *accepted (nullable) receives the number of rows stored. */
+int orama_vec_insert(orama_vec* v, const uint64_t* doc_ids, const float* rows, uint64_t n_rows,
+                     uint64_t* accepted);
+/* EmbeddingFieldStorage::delete — embedding_field.rs:240-242: tombstones every row of each doc. */
+int orama_vec_delete(orama_vec* v, const uint64_t* doc_ids, uint64_t n);
+/* EmbeddingFieldStorage::compact — embedding_field.rs:286-290: drops tombstoned rows and
+ * re-packs the HBM matrix. `version` is recorded (current_version_number, :298-300). */
+int orama_vec_compact(orama_vec* v, uint64_t version);
+/* EmbeddingFieldStorage::{stats,has_pending_ops,current_version_number} — :281-310. */
+typedef struct {
+    uint32_t dimensions;
+    uint64_t num_embeddings; /* live rows */
+    uint64_t num_rows;       /* live + tombstoned rows resident in HBM */
+    uint64_t pending_ops;    /* tombstones not yet compacted */
+    uint64_t version;
+    uint64_t hbm_bytes;      /* bytes of HBM held by this store */
+} orama_vec_info_t;
+int orama_vec_info(orama_vec* v, orama_vec_info_t* out);
+
+/* EmbeddingStorage::search / search_with_filter — call site embedding_field.rs:255-266.
+ *   queries      : q x dim f32 row-major (host). q == 1 is the reference's shape; q > 1 is the
+ *                  batch extension and returns q independent result lists.
+ *   k            : `limit` (VectorSearchParams.limit, committed_field/vector.rs:10-15).
+ *   allow_bitmap : NULL, or the materialised DocumentFilter (embedding_field.rs:54-61): bit d of the
+ *                  little-endian u64 array set <=> doc id d passes; ids >= bitmap_bits never pass.
+ *   out_ids/out_dist : q x k (host); out_n : q counts. Row-level results, distance ascending
+ *                  (ties: doc id asc), several rows of one doc may appear — the caller sums them
+ *                  (embedding_field.rs:268-276), exactly as with the reference's storage. */
+int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
+                     const uint64_t* allow_bitmap, uint64_t bitmap_bits, uint64_t* out_ids,
+                     float* out_dist, uint32_t* out_n);
+
+/* Same, with every buffer already in HBM and work enqueued on `hip_stream` (a hipStream_t, NULL =
+ * the default stream) without host synchronisation — used by the sharded path so that RCCL can
+ * consume the candidates in place.  d_out_rows (nullable) receives store row indices; out ids are
+ * DocumentIds.  Unused tail entries (i >= d_out_n[q]) are (UINT64_MAX, +inf). */
+int orama_vec_search_device(orama_vec* v, const float* d_queries, uint32_t q, uint32_t k,
+                            const uint64_t* d_allow_bitmap, uint64_t bitmap_bits,
+                            uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n,
+                            void* hip_stream);
+
+/* K6 — merge per-shard candidate lists after the RCCL all-gather: for each of q
+ * queries, `lists` shards x k candidates laid out [shard][query][k] -> best k by (distance asc,
+ * id asc). All pointers are device memory; enqueued on hip_stream. */
+int orama_merge_candidates_device(orama_ctx* ctx, const uint64_t* d_ids, const float* d_dist,
+                                  uint32_t lists, uint32_t q, uint32_t k, uint64_t* d_out_ids,
+                                  float* d_out_dist, uint32_t* d_out_n, void* hip_stream);
+
+/* Test/bench utilities (no reference counterpart). */
+/* Fill the store with n synthetic rows generated in HBM: x = u * g/|g|,
+ * g ~ N(0,1)^dim, u ~ U(0.5, 2), counter-based RNG keyed by (seed, row, col); doc id = first_doc_id + row. */
+int orama_vec_fill_synthetic(orama_vec* v, uint64_t n_rows, uint64_t seed, uint64_t first_doc_id);
+/* Read back stored rows (as f32) by store row index. */
+int orama_vec_get_rows(orama_vec* v, const uint64_t* row_idx, uint64_t n, float* out_rows,
+                       uint64_t* out_doc_ids);
+
+/* ------------------------------------------------------------------ BM25F full-text scoring
+ * Replaces the in-tree hot loop search_full_text + BM25Scorer + top_n:
+ *   src/collection_manager/sides/read/index/token_score.rs:257-302,
+ *   src/collection_manager/bm25.rs:325-525, src/collection_manager/sides/read/sort.rs:260-279. */
+
+/* One posting-list entry = the per_doc_ntf vector returned by one field for one query token
+ * (ContributionsResult.token_contributions[i].per_doc_ntf, token_score.rs:264-271). */
+typedef struct {
+    uint32_t token;      /* query token index (term_index) */
+    const uint64_t* doc; /* host, `len` DocumentIds, unique inside the entry */
+    const float* ntf;    /* host, `len` normalised TFs (boost + length norm already folded in) */
+    uint64_t len;
+} orama_ntf_entry;
+
+typedef struct {
+    float total_documents;  /* N: index document_count as f32 — token_score.rs:221 */
+    float k;                /* 1.2 — token_score.rs:283 */
+    uint32_t n_tokens;
+    int use_threshold;      /* 0: BM25Scorer::plain, 1: with_threshold — token_score.rs:211-218 */
+    uint32_t threshold;     /* floor(n_tokens * threshold) */
+    uint32_t top_k;         /* limit + offset (sort.rs:24-34) */
+} orama_bm25_params;
+
+/* Seam (i): host-provided contributions (exact inputs of the in-tree loop) -> BM25F scores,
+ * optional OMC multiply (search.rs:39-48; omc_* nullable, doc ids ascending), match count
+ * (token_score_results.len(), search.rs:482) and top-k (score desc, doc id asc; NaN dropped).
+ * Entries are consumed in array order inside each token.  out_* hold top_k entries. */
+int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_entries,
+                     const orama_bm25_params* params, const uint64_t* omc_doc, const float* omc_mul,
+                     uint64_t n_omc, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
+                     uint64_t* out_count);
+
+/* Seam (ii): HBM-resident postings (SURVEY §8b option ii).  The store mirrors what
+ * StringFieldStorage holds per field (src/collection_manager/sides/read/index/string_field.rs):
+ * for each (field, term) a doc-sorted list of (doc, tf, field_length).  Term dictionary lookup /
+ * prefix / fuzzy expansion stay on the host (third-party a5); the caller passes term ids. */
+int orama_post_create(orama_ctx* ctx, orama_post** out);
+void orama_post_destroy(orama_post* p);
+/* Bulk build.  docs: n_docs DocumentIds ascending (the index's live documents; N = n_docs).
+ * For list l in [0, n_lists): field_of_list[l], postings [list_off[l], list_off[l+1]) of
+ * (post_doc, post_tf, post_len) with post_doc ascending and present in docs.
+ * avg_field_len[f] for f in [0, n_fields) — StringStorage::info().avg_field_length. */
+int orama_post_build(orama_post* p, const uint64_t* docs, uint64_t n_docs, uint32_t n_fields,
+                     const float* avg_field_len, uint32_t n_lists, const uint32_t* field_of_list,
+                     const uint64_t* list_off, const uint64_t* post_doc, const uint32_t* post_tf,
+                     const uint32_t* post_len);
+/* OMC multipliers of the index (Index::get_all_omc, index/mod.rs:1720-1739); doc ids ascending. */
+int orama_post_set_omc(orama_post* p, const uint64_t* omc_doc, const float* omc_mul, uint64_t n);
+
+/* One (token, list) reference of a query: token `token` expands to posting list `list`
+ * scored with field boost `boost` (SearchParams.boost, token_score.rs:234-238). */
+typedef struct {
+    uint32_t token;
+    uint32_t list;
+    float boost;
+} orama_term_ref;
+
+/* search_full_text over resident postings: ntf = boost * (tf / (1 - b + b * (len / avglen)))
+ * (bm25.rs:99-110 with Bm25Params::default b = 0.75 passed in `b`), then exactly as seam (i).
+ * allow_bitmap as in orama_vec_search (the filter is applied to postings, so df counts only
+ * allowed docs — collect_contributions_with_filter, string_field.rs:215-225). */
+int orama_post_search(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, float b,
+                      const orama_bm25_params* params, const uint64_t* allow_bitmap,
+                      uint64_t bitmap_bits, int apply_omc, uint64_t* out_ids, float* out_scores,
+                      uint32_t* out_n, uint64_t* out_count);
+
+/* ------------------------------------------------------------------ hybrid
+ * search_hybrid + normalize_and_combine — token_score.rs:357-422, then OMC + count + top-k.
+ * vec_doc/vec_score: the vector result MAP after the a2 epilogue (<= limit entries, any order,
+ * unique docs).  Full-text side as orama_post_search.  min/max fold from 0.0 over both maps;
+ * out = fulltext' (+ vector'), max == min yields NaN scores which top-k drops (sort.rs:264-268)
+ * while `out_count` still counts them (search.rs:482). */
+int orama_post_search_hybrid(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, float b,
+                             const orama_bm25_params* params, const uint64_t* allow_bitmap,
+                             uint64_t bitmap_bits, const uint64_t* vec_doc, const float* vec_score,
+                             uint32_t n_vec, int apply_omc, uint64_t* out_ids, float* out_scores,
+                             uint32_t* out_n, uint64_t* out_count);
+
+/* Standalone normalize_and_combine on host-provided maps (both sides small or large) — the
+ * literal replacement of token_score.rs:393-422 + top_n for callers that keep seam (i). */
+int orama_hybrid_combine(orama_ctx* ctx, const uint64_t* vec_doc, const float* vec_score,
+                         uint64_t n_vec, const uint64_t* ft_doc, const float* ft_score,
+                         uint64_t n_ft, uint32_t top_k, uint64_t* out_ids, float* out_scores,
+                         uint32_t* out_n, uint64_t* out_count);
+
+/* ------------------------------------------------------------------ top-n
+ * top_n — sort.rs:260-279 over an explicit (doc, score) list: NaN dropped, score desc, doc asc. */
+int orama_top_n(orama_ctx* ctx, const uint64_t* doc, const float* score, uint64_t n, uint32_t top_k,
+                uint64_t* out_ids, float* out_scores, uint32_t* out_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORAMA_HIP_H */

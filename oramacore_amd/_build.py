@@ -1,0 +1,109 @@
+"""In-tree build of liborama_hip.so (hipcc, gfx950 only) and of the CPU oracle.
+
+`build_native()` compiles every .hip translation unit under oramacore_amd/csrc with
+`hipcc --offload-arch=gfx950` and links them into oramacore_amd/csrc/liborama_hip.so.  The shared
+object is git-ignored but travels to the GPU box with the repo snapshot.  hipcc cross-compiles
+without a GPU, so this is also the CPU-side "does it build" check.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "oramacore_amd" / "csrc"
+INCLUDE = ROOT / "include"
+LIB = CSRC / "liborama_hip.so"
+OBJ_DIR = CSRC / "build"
+ORACLE_DIR = ROOT / "oracle"
+ORACLE_LIB = ORACLE_DIR / "liborama_oracle.so"
+
+ARCH = "gfx950"
+COMMON_FLAGS = [
+    f"--offload-arch={ARCH}",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-Wall",
+    "-Wno-unused-result",
+    f"-I{INCLUDE}",
+    f"-I{CSRC}",
+]
+# Translation units whose f32 arithmetic must round exactly like the scalar reference
+# (BM25F scoring is compared bit-for-bit with the oracle): no FMA contraction.
+EXACT_FP = {"fulltext.hip", "bm25_kernels.hip"}
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found — liborama_hip.so cannot be built (no CPU fallback exists)")
+
+
+def _sources() -> list[Path]:
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _fingerprint() -> str:
+    h = hashlib.sha256()
+    for p in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + list(INCLUDE.glob("*.h"))):
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    h.update(" ".join(COMMON_FLAGS).encode())
+    return h.hexdigest()
+
+
+def native_is_fresh() -> bool:
+    stamp = OBJ_DIR / "fingerprint"
+    return LIB.exists() and stamp.exists() and stamp.read_text() == _fingerprint()
+
+
+def build_native(force: bool = False, verbose: bool = True) -> Path:
+    if not force and native_is_fresh():
+        return LIB
+    hipcc = _hipcc()
+    OBJ_DIR.mkdir(exist_ok=True)
+
+    def compile_one(src: Path) -> Path:
+        obj = OBJ_DIR / (src.stem + ".o")
+        flags = list(COMMON_FLAGS)
+        flags.append("-ffp-contract=off" if src.name in EXACT_FP else "-ffp-contract=fast")
+        cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, _sources()))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs), "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    (OBJ_DIR / "fingerprint").write_text(_fingerprint())
+    return LIB
+
+
+def build_oracle(force: bool = False) -> Path:
+    """Compile the CPU oracle (test infrastructure; never loaded by the product path)."""
+    src = ORACLE_DIR / "orama_oracle.c"
+    if force or not ORACLE_LIB.exists() or ORACLE_LIB.stat().st_mtime < max(
+        src.stat().st_mtime, (ORACLE_DIR / "orama_oracle.h").stat().st_mtime
+    ):
+        r = subprocess.run(["make", "-C", str(ORACLE_DIR), "-B"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"oracle build failed:\n{r.stdout}\n{r.stderr}")
+    return ORACLE_LIB
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in sys.argv))
+    print(build_oracle())

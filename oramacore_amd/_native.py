@@ -1,0 +1,159 @@
+"""ctypes binding of liborama_hip.so (the C ABI declared in include/orama_hip.h).
+
+This is plumbing only: every function here forwards to one `extern "C"` entry point.  There is no
+CPU fallback — if the shared object is missing and cannot be built, or no HIP device is present,
+the calls raise `OramaError` / `RuntimeError` loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+from . import _build
+
+ORAMA_OK = 0
+ORAMA_ERR_INVALID = 1
+ORAMA_ERR_HIP = 2
+ORAMA_ERR_OOM = 3
+ORAMA_ERR_UNSUPPORTED = 4
+
+METRIC_COSINE = 0
+METRIC_L2SQ = 1
+DTYPE_F32 = 0
+DTYPE_F16 = 1
+
+HEADER = Path(__file__).resolve().parent.parent / "include" / "orama_hip.h"
+
+
+class OramaError(RuntimeError):
+    """A non-zero status from liborama_hip (mirrors the reference's anyhow::Error → ReadError::Generic)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"liborama_hip status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+class VecInfo(C.Structure):
+    _fields_ = [
+        ("dimensions", C.c_uint32),
+        ("num_embeddings", C.c_uint64),
+        ("num_rows", C.c_uint64),
+        ("pending_ops", C.c_uint64),
+        ("version", C.c_uint64),
+        ("hbm_bytes", C.c_uint64),
+    ]
+
+
+class NtfEntry(C.Structure):
+    _fields_ = [
+        ("token", C.c_uint32),
+        ("doc", C.POINTER(C.c_uint64)),
+        ("ntf", C.POINTER(C.c_float)),
+        ("len", C.c_uint64),
+    ]
+
+
+class Bm25Params(C.Structure):
+    _fields_ = [
+        ("total_documents", C.c_float),
+        ("k", C.c_float),
+        ("n_tokens", C.c_uint32),
+        ("use_threshold", C.c_int),
+        ("threshold", C.c_uint32),
+        ("top_k", C.c_uint32),
+    ]
+
+
+class TermRef(C.Structure):
+    _fields_ = [("token", C.c_uint32), ("list", C.c_uint32), ("boost", C.c_float)]
+
+
+def declared_symbols() -> list[str]:
+    """Every function name declared in include/orama_hip.h (used by the ABI export test)."""
+    text = HEADER.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(orama_[a-z0-9_]+)\s*\(", text)
+    seen, out = set(), []
+    for n in names:
+        if n not in seen:
+            seen.add(n)
+            out.append(n)
+    return out
+
+
+_lib = None
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load liborama_hip.so from the source tree (building it with hipcc when stale/missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if build_if_missing and not _build.native_is_fresh():
+        try:
+            _build.build_native()
+        except Exception as e:  # noqa: BLE001
+            if not path.exists():
+                raise RuntimeError(
+                    f"liborama_hip.so is missing and could not be built ({e}); the HIP path has no fallback"
+                ) from e
+    if not path.exists():
+        raise RuntimeError(f"{path} not found — run `python __graft_entry__.py` (build) first; no CPU fallback exists")
+    lib = C.CDLL(str(path))
+    _declare(lib)
+    if lib.orama_abi_version() != 1:
+        raise RuntimeError("liborama_hip ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _declare(lib: C.CDLL) -> None:
+    vp, u64p, u32p, f32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+    lib.orama_abi_version.restype = C.c_int
+    lib.orama_last_error.restype = C.c_char_p
+    sig = {
+        "orama_ctx_create": [C.c_int, C.POINTER(vp)],
+        "orama_ctx_synchronize": [vp],
+        "orama_ctx_device_info": [vp, C.c_char_p, C.POINTER(C.c_int), u64p],
+        "orama_prof_enable": [vp, C.c_int],
+        "orama_prof_reset": [vp],
+        "orama_prof_get": [vp, C.c_char_p, C.POINTER(C.c_double), u64p],
+        "orama_vec_create": [vp, C.c_uint32, C.c_int, C.c_int, C.c_uint64, C.POINTER(vp)],
+        "orama_vec_insert": [vp, vp, vp, C.c_uint64, u64p],
+        "orama_vec_delete": [vp, vp, C.c_uint64],
+        "orama_vec_compact": [vp, C.c_uint64],
+        "orama_vec_info": [vp, C.POINTER(VecInfo)],
+        "orama_vec_search": [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, vp],
+        "orama_vec_search_device": [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp],
+        "orama_merge_candidates_device": [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp],
+        "orama_vec_fill_synthetic": [vp, C.c_uint64, C.c_uint64, C.c_uint64],
+        "orama_vec_get_rows": [vp, vp, C.c_uint64, vp, vp],
+        "orama_bm25_score": [vp, C.POINTER(NtfEntry), C.c_uint32, C.POINTER(Bm25Params), vp, vp, C.c_uint64,
+                             vp, vp, u32p, u64p],
+        "orama_post_create": [vp, C.POINTER(vp)],
+        "orama_post_build": [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_uint32, vp, vp, vp, vp, vp],
+        "orama_post_set_omc": [vp, vp, vp, C.c_uint64],
+        "orama_post_search": [vp, C.POINTER(TermRef), C.c_uint32, C.c_float, C.POINTER(Bm25Params), vp,
+                              C.c_uint64, C.c_int, vp, vp, u32p, u64p],
+        "orama_post_search_hybrid": [vp, C.POINTER(TermRef), C.c_uint32, C.c_float, C.POINTER(Bm25Params), vp,
+                                     C.c_uint64, vp, vp, C.c_uint32, C.c_int, vp, vp, u32p, u64p],
+        "orama_hybrid_combine": [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u32p, u64p],
+        "orama_top_n": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u32p],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    for name in ("orama_ctx_destroy", "orama_vec_destroy", "orama_post_destroy"):
+        fn = getattr(lib, name)
+        fn.argtypes = [vp]
+        fn.restype = None
+
+
+def check(status: int) -> None:
+    if status != ORAMA_OK:
+        msg = load().orama_last_error().decode("utf-8", "replace")
+        raise OramaError(status, msg)

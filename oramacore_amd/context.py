@@ -1,0 +1,61 @@
+"""Per-GPU context (orama_ctx) — owns the device ordinal, stream/scratch pools and the profiler."""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import _native as N
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self._lib = N.load()
+        h = C.c_void_p()
+        N.check(self._lib.orama_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    @property
+    def handle(self) -> C.c_void_p:
+        if not self._h:
+            raise RuntimeError("context already closed")
+        return self._h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.orama_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def synchronize(self) -> None:
+        N.check(self._lib.orama_ctx_synchronize(self.handle))
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cu = C.c_int()
+        hbm = C.c_uint64()
+        N.check(self._lib.orama_ctx_device_info(self.handle, name, C.byref(cu), C.byref(hbm)))
+        return {"name": name.value.decode(), "compute_units": cu.value, "hbm_bytes": hbm.value}
+
+    # --- HIP-event profiler (bench.py roofline leg)
+    def prof_enable(self, on: bool = True) -> None:
+        N.check(self._lib.orama_prof_enable(self.handle, 1 if on else 0))
+
+    def prof_reset(self) -> None:
+        N.check(self._lib.orama_prof_reset(self.handle))
+
+    def prof_get(self, kernel: str) -> tuple[float, int]:
+        ms = C.c_double()
+        n = C.c_uint64()
+        N.check(self._lib.orama_prof_get(self.handle, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,181 @@
+// common.hpp — shared host-side plumbing of liborama_hip.so (errors, device buffers, the per-GPU
+// context with its stream/scratch pools and the HIP-event profiler).  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "orama_hip.h"
+
+namespace orama {
+
+// ---------------------------------------------------------------- errors
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+void clear_error();
+
+#define ORAMA_HIP_TRY(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            ::orama::set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,    \
+                               __LINE__);                                                    \
+            return e__ == hipErrorOutOfMemory ? ORAMA_ERR_OOM : ORAMA_ERR_HIP;               \
+        }                                                                                    \
+    } while (0)
+
+#define ORAMA_TRY(expr)                  \
+    do {                                 \
+        int s__ = (expr);                \
+        if (s__ != ORAMA_OK) return s__; \
+    } while (0)
+
+#define ORAMA_REQUIRE(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::orama::set_error(__VA_ARGS__); \
+            return ORAMA_ERR_INVALID;       \
+        }                                   \
+    } while (0)
+
+// ---------------------------------------------------------------- device / pinned buffers
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    // Ensure capacity (contents NOT preserved when it grows).
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return ORAMA_OK;
+        release();
+        size_t want = bytes < 256 ? 256 : bytes;
+        ORAMA_HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return ORAMA_OK;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return ORAMA_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes < 4096 ? 4096 : bytes;
+        ORAMA_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return ORAMA_OK;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---------------------------------------------------------------- profiler
+// Brackets launches of the named hot kernels with hipEvents on the launching stream; the pairs
+// are resolved lazily in orama_prof_get (after the caller synchronised).
+struct Profiler {
+    std::mutex mu;
+    bool on = false;
+    struct Acc {
+        double ms = 0.0;
+        uint64_t n = 0;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    };
+    std::map<std::string, Acc> acc;
+    std::vector<hipEvent_t> free_events;
+
+    hipEvent_t get_event();
+    void begin(const char* name, hipStream_t s, hipEvent_t* start);
+    void end(const char* name, hipStream_t s, hipEvent_t start);
+    int resolve();
+    void reset();
+    ~Profiler();
+};
+
+struct ProfScope {
+    Profiler* prof;
+    const char* name;
+    hipStream_t stream;
+    hipEvent_t start = nullptr;
+    ProfScope(Profiler* p, const char* n, hipStream_t s) : prof(p), name(n), stream(s) {
+        if (prof && prof->on) prof->begin(name, stream, &start);
+    }
+    ~ProfScope() {
+        if (start) prof->end(name, stream, start);
+    }
+};
+
+// ---------------------------------------------------------------- per-call scratch
+// One set per in-flight search: its own stream, device scratch and pinned staging, so that
+// concurrent orama_*_search calls never share mutable state (re-entrancy contract of the ABI).
+struct Scratch {
+    hipStream_t stream = nullptr;
+    DevBuf query;      // q x dim f32
+    DevBuf dist;       // per-row distances / dense scores
+    DevBuf sel_state;  // SelectState[q]
+    DevBuf sel_keys;   // collected composite keys
+    DevBuf out_idx, out_val, out_n, out_ids;
+    DevBuf bitmap;     // uploaded allow bitmap
+    DevBuf misc0, misc1, misc2, misc3, misc4, misc5;
+    PinnedBuf h_in, h_out, h_misc;
+    ~Scratch() {
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+}  // namespace orama
+
+struct orama_ctx {
+    int device = 0;
+    int compute_units = 0;
+    uint64_t hbm_bytes = 0;
+    char name[256] = {0};
+    orama::Profiler prof;
+    std::mutex pool_mu;
+    std::vector<std::unique_ptr<orama::Scratch>> pool;
+
+    // Borrow a scratch set (creates one when the pool is empty).
+    int acquire(std::unique_ptr<orama::Scratch>* out);
+    void release(std::unique_ptr<orama::Scratch> s);
+};
+
+namespace orama {
+struct ScratchLease {
+    orama_ctx* ctx;
+    std::unique_ptr<Scratch> s;
+    explicit ScratchLease(orama_ctx* c) : ctx(c) {}
+    int init() { return ctx->acquire(&s); }
+    ~ScratchLease() {
+        if (s) ctx->release(std::move(s));
+    }
+    Scratch* operator->() { return s.get(); }
+};
+
+inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+}  // namespace orama

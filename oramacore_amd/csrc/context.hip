@@ -1,0 +1,189 @@
+// context.hip — error channel, per-GPU context, scratch pool, HIP-event profiler.
+#include "common.hpp"
+
+namespace orama {
+
+static thread_local char g_err[1024] = {0};
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+void clear_error() { g_err[0] = 0; }
+
+// ---------------------------------------------------------------- profiler
+hipEvent_t Profiler::get_event() {
+    if (!free_events.empty()) {
+        hipEvent_t e = free_events.back();
+        free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void Profiler::begin(const char*, hipStream_t s, hipEvent_t* start) {
+    std::lock_guard<std::mutex> g(mu);
+    hipEvent_t e = get_event();
+    if (e && hipEventRecord(e, s) == hipSuccess) *start = e;
+}
+
+void Profiler::end(const char* name, hipStream_t s, hipEvent_t start) {
+    std::lock_guard<std::mutex> g(mu);
+    hipEvent_t e = get_event();
+    if (!e) return;
+    (void)hipEventRecord(e, s);
+    acc[name].pending.emplace_back(start, e);
+}
+
+int Profiler::resolve() {
+    std::lock_guard<std::mutex> g(mu);
+    for (auto& kv : acc) {
+        for (auto& pr : kv.second.pending) {
+            (void)hipEventSynchronize(pr.second);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                kv.second.ms += (double)ms;
+                kv.second.n += 1;
+            }
+            free_events.push_back(pr.first);
+            free_events.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+    return ORAMA_OK;
+}
+
+void Profiler::reset() {
+    resolve();
+    std::lock_guard<std::mutex> g(mu);
+    for (auto& kv : acc) {
+        kv.second.ms = 0.0;
+        kv.second.n = 0;
+    }
+}
+
+Profiler::~Profiler() {
+    for (auto& kv : acc)
+        for (auto& pr : kv.second.pending) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    for (hipEvent_t e : free_events) (void)hipEventDestroy(e);
+}
+
+}  // namespace orama
+
+int orama_ctx::acquire(std::unique_ptr<orama::Scratch>* out) {
+    {
+        std::lock_guard<std::mutex> g(pool_mu);
+        if (!pool.empty()) {
+            *out = std::move(pool.back());
+            pool.pop_back();
+            return ORAMA_OK;
+        }
+    }
+    std::unique_ptr<orama::Scratch> s(new orama::Scratch());
+    ORAMA_HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    *out = std::move(s);
+    return ORAMA_OK;
+}
+
+void orama_ctx::release(std::unique_ptr<orama::Scratch> s) {
+    std::lock_guard<std::mutex> g(pool_mu);
+    pool.push_back(std::move(s));
+}
+
+extern "C" {
+
+int orama_abi_version(void) { return ORAMA_ABI_VERSION; }
+
+const char* orama_last_error(void) { return orama::g_err; }
+
+int orama_ctx_create(int device_ordinal, orama_ctx** out) {
+    ORAMA_REQUIRE(out != nullptr, "orama_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        orama::set_error("no HIP device available (%s) — liborama_hip has no CPU fallback",
+                         e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return ORAMA_ERR_HIP;
+    }
+    ORAMA_REQUIRE(device_ordinal >= 0 && device_ordinal < count, "device %d out of range [0,%d)",
+                  device_ordinal, count);
+    ORAMA_HIP_TRY(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    ORAMA_HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    orama_ctx* c = new (std::nothrow) orama_ctx();
+    if (!c) {
+        orama::set_error("out of host memory");
+        return ORAMA_ERR_OOM;
+    }
+    c->device = device_ordinal;
+    c->compute_units = prop.multiProcessorCount;
+    c->hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+    *out = c;
+    return ORAMA_OK;
+}
+
+void orama_ctx_destroy(orama_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    delete ctx;
+}
+
+int orama_ctx_synchronize(orama_ctx* ctx) {
+    ORAMA_REQUIRE(ctx, "null ctx");
+    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_HIP_TRY(hipDeviceSynchronize());
+    return ORAMA_OK;
+}
+
+int orama_ctx_device_info(orama_ctx* ctx, char* name256, int* compute_units, uint64_t* hbm_bytes) {
+    ORAMA_REQUIRE(ctx, "null ctx");
+    if (name256) {
+        strncpy(name256, ctx->name, 255);
+        name256[255] = 0;
+    }
+    if (compute_units) *compute_units = ctx->compute_units;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return ORAMA_OK;
+}
+
+int orama_prof_enable(orama_ctx* ctx, int on) {
+    ORAMA_REQUIRE(ctx, "null ctx");
+    ctx->prof.on = on != 0;
+    return ORAMA_OK;
+}
+
+int orama_prof_reset(orama_ctx* ctx) {
+    ORAMA_REQUIRE(ctx, "null ctx");
+    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ctx->prof.reset();
+    return ORAMA_OK;
+}
+
+int orama_prof_get(orama_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches) {
+    ORAMA_REQUIRE(ctx && kernel, "null argument");
+    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ctx->prof.resolve();
+    std::lock_guard<std::mutex> g(ctx->prof.mu);
+    auto it = ctx->prof.acc.find(kernel);
+    double ms = 0.0;
+    uint64_t n = 0;
+    if (it != ctx->prof.acc.end()) {
+        ms = it->second.ms;
+        n = it->second.n;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    return ORAMA_OK;
+}
+
+}  // extern "C"

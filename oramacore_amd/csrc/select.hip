@@ -1,0 +1,412 @@
+// select.hip — K4 / K6: exact, deterministic top-k on gfx950.
+//
+// Algorithm: MSB-first radix select on a 64-bit composite key
+//     key = ordered(value) << 32 | ~idx          ("larger key wins")
+// so that equal values are ordered by ascending idx and every key is unique.  Three histogram
+// passes (11/11/10 bits) fix the value threshold; three more passes over the idx bits run only
+// when several equal values straddle the k boundary (they early-exit on `done` otherwise).  A
+// collect pass appends exactly k' = min(k, #non-NaN) keys, and one workgroup sorts them in LDS
+// with the full tie order (value, 64-bit id asc, idx asc).
+//
+// Roofline: HBM — each pass streams the value array once (4 B/element); the final sort is
+// LDS-resident.  For the dense single-query vector path this is 4 x N x 4 B on top of the
+// N x D x 4 B corpus pass (0.5 % at D = 768).
+#include "select.hpp"
+
+#include "device_utils.hpp"
+
+namespace orama {
+
+namespace {
+
+__constant__ const uint32_t kShift[6] = {53, 42, 32, 21, 10, 0};
+__constant__ const uint32_t kBits[6] = {11, 11, 10, 11, 11, 10};
+
+constexpr int kHistThreads = 256;
+constexpr int kSortThreads = 1024;
+
+__device__ __forceinline__ unsigned long long make_key(float v, uint32_t idx, bool descending) {
+    uint32_t o = f32_to_ordered(v);
+    uint32_t hi = descending ? o : ~o;
+    return ((unsigned long long)hi << 32) | (unsigned long long)(uint32_t)(~idx);
+}
+
+// ---------------------------------------------------------------- histogram pass
+__global__ __launch_bounds__(kHistThreads) void select_hist_kernel(
+    const float* __restrict__ vals, const uint32_t* __restrict__ idx, uint64_t stride,
+    const uint32_t* __restrict__ n_dev, uint32_t n_max, bool descending, SelectState* state,
+    int pass) {
+    const uint32_t qi = blockIdx.y;
+    SelectState* st = state + qi;
+    if (st->done) return;
+    const uint32_t n = n_dev ? min(n_dev[qi], n_max) : n_max;
+    const float* v = vals + (uint64_t)qi * stride;
+    const uint32_t* ix = idx ? idx + (uint64_t)qi * stride : nullptr;
+
+    __shared__ uint32_t hist[2048];
+    for (int i = threadIdx.x; i < 2048; i += kHistThreads) hist[i] = 0;
+    __syncthreads();
+
+    const uint32_t shift = kShift[pass];
+    const uint32_t mask = (1u << kBits[pass]) - 1u;
+    const unsigned long long prefix = st->prefix;
+    const uint32_t pshift = shift + kBits[pass];
+
+    auto visit = [&](float x, uint32_t id) {
+        if (x != x) return;
+        unsigned long long key = make_key(x, id, descending);
+        if (pass > 0 && (key >> pshift) != prefix) return;
+        atomicAdd(&hist[(uint32_t)(key >> shift) & mask], 1u);
+    };
+
+    const uint32_t tid = blockIdx.x * kHistThreads + threadIdx.x;
+    const uint32_t nthreads = gridDim.x * kHistThreads;
+    const bool vec = (ix == nullptr) && ((stride & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(vals) & 15) == 0);
+    if (vec) {
+        const uint32_t n4 = n >> 2;
+        const float4* v4 = reinterpret_cast<const float4*>(v);
+        for (uint32_t i = tid; i < n4; i += nthreads) {
+            float4 x = v4[i];
+            visit(x.x, 4 * i + 0);
+            visit(x.y, 4 * i + 1);
+            visit(x.z, 4 * i + 2);
+            visit(x.w, 4 * i + 3);
+        }
+        for (uint32_t i = (n4 << 2) + tid; i < n; i += nthreads) visit(v[i], i);
+    } else {
+        for (uint32_t i = tid; i < n; i += nthreads) visit(v[i], ix ? ix[i] : i);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += kHistThreads) {
+        uint32_t c = hist[i];
+        if (c) atomicAdd(&st->hist[pass][i], c);
+    }
+}
+
+// ---------------------------------------------------------------- pick the bin
+__global__ __launch_bounds__(256) void select_scan_kernel(SelectState* state, uint32_t k, int pass) {
+    SelectState* st = state + blockIdx.x;
+    if (st->done) return;
+    const uint32_t* h = st->hist[pass];
+    __shared__ uint32_t suffix[257];
+    const int t = threadIdx.x;
+    uint32_t local[8];
+    uint32_t s = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        local[b] = h[t * 8 + b];
+        s += local[b];
+    }
+    suffix[t] = s;
+    if (t == 0) suffix[256] = 0;
+    __syncthreads();
+    // inclusive suffix sum over threads (Hillis–Steele)
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t add = (t + off < 256) ? suffix[t + off] : 0;
+        __syncthreads();
+        suffix[t] += add;
+        __syncthreads();
+    }
+    __shared__ uint32_t rem_s;
+    if (t == 0) {
+        if (pass == 0) {
+            uint32_t valid = suffix[0];
+            st->valid = valid;
+            st->kprime = valid < k ? valid : k;
+            st->remaining = st->kprime;
+        }
+        rem_s = st->remaining;
+    }
+    __syncthreads();
+    const uint32_t rem = rem_s;
+    if (rem == 0) {  // nothing to select (k' == 0)
+        if (t == 0) {
+            st->done = 1;
+            st->sel_shift = 0;
+            st->prefix = ~0ull;
+        }
+        return;
+    }
+    const uint32_t above = suffix[t + 1];  // elements in bins owned by higher threads
+    if (suffix[t] >= rem && above < rem) {
+        uint32_t cum = above;
+#pragma unroll
+        for (int b = 7; b >= 0; --b) {
+            if (cum + local[b] >= rem) {
+                const uint32_t bin = (uint32_t)(t * 8 + b);
+                const uint32_t r2 = rem - cum;
+                st->prefix = (st->prefix << kBits[pass]) | (unsigned long long)bin;
+                st->remaining = r2;
+                st->sel_shift = kShift[pass];
+                if (local[b] == r2 || pass == 5) st->done = 1;
+                break;
+            }
+            cum += local[b];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- collect the k' winners
+__global__ __launch_bounds__(kHistThreads) void select_collect_kernel(
+    const float* __restrict__ vals, const uint32_t* __restrict__ idx, uint64_t stride,
+    const uint32_t* __restrict__ n_dev, uint32_t n_max, bool descending, SelectState* state,
+    unsigned long long* __restrict__ keys, uint32_t kcap) {
+    const uint32_t qi = blockIdx.y;
+    SelectState* st = state + qi;
+    const uint32_t kprime = st->kprime;
+    if (kprime == 0) return;
+    const uint32_t n = n_dev ? min(n_dev[qi], n_max) : n_max;
+    const float* v = vals + (uint64_t)qi * stride;
+    const uint32_t* ix = idx ? idx + (uint64_t)qi * stride : nullptr;
+    unsigned long long* out = keys + (uint64_t)qi * kcap;
+    const unsigned long long prefix = st->prefix;
+    const uint32_t shift = st->sel_shift;
+
+    auto visit = [&](float x, uint32_t id) {
+        if (x != x) return;
+        unsigned long long key = make_key(x, id, descending);
+        if ((key >> shift) >= prefix) {
+            uint32_t pos = atomicAdd(&st->out_count, 1u);
+            if (pos < kcap) out[pos] = key;
+        }
+    };
+    const uint32_t tid = blockIdx.x * kHistThreads + threadIdx.x;
+    const uint32_t nthreads = gridDim.x * kHistThreads;
+    const bool vec = (ix == nullptr) && ((stride & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(vals) & 15) == 0);
+    if (vec) {
+        const uint32_t n4 = n >> 2;
+        const float4* v4 = reinterpret_cast<const float4*>(v);
+        for (uint32_t i = tid; i < n4; i += nthreads) {
+            float4 x = v4[i];
+            visit(x.x, 4 * i + 0);
+            visit(x.y, 4 * i + 1);
+            visit(x.z, 4 * i + 2);
+            visit(x.w, 4 * i + 3);
+        }
+        for (uint32_t i = (n4 << 2) + tid; i < n; i += nthreads) visit(v[i], i);
+    } else {
+        for (uint32_t i = tid; i < n; i += nthreads) visit(v[i], ix ? ix[i] : i);
+    }
+}
+
+// ---------------------------------------------------------------- LDS bitonic sort
+// Sort record: hi (ordered value key, larger first), id (64-bit, smaller first), idx (smaller first).
+struct SortLds {
+    uint32_t hi[kSelectMaxK];
+    uint32_t idx[kSelectMaxK];
+    uint64_t id[kSelectMaxK];
+};
+
+__device__ __forceinline__ bool rec_before(uint32_t ha, uint64_t ia, uint32_t xa, uint32_t hb,
+                                           uint64_t ib, uint32_t xb) {
+    if (ha != hb) return ha > hb;
+    if (ia != ib) return ia < ib;
+    return xa < xb;
+}
+
+__device__ void lds_bitonic_sort(SortLds& s, uint32_t p2) {
+    for (uint32_t size = 2; size <= p2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (p2 >> 1); t += blockDim.x) {
+                uint32_t lo = 2 * t - (t & (stride - 1));
+                uint32_t hi = lo + stride;
+                bool up = ((lo & size) == 0);  // "up" block: best first
+                uint32_t ha = s.hi[lo], hb = s.hi[hi];
+                uint64_t ia = s.id[lo], ib = s.id[hi];
+                uint32_t xa = s.idx[lo], xb = s.idx[hi];
+                bool b_first = rec_before(hb, ib, xb, ha, ia, xa);
+                if (b_first == up) {
+                    s.hi[lo] = hb; s.hi[hi] = ha;
+                    s.id[lo] = ib; s.id[hi] = ia;
+                    s.idx[lo] = xb; s.idx[hi] = xa;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t next_pow2(uint32_t v) {
+    uint32_t p = 2;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+__device__ void write_sorted(const SortLds& s, uint32_t count, uint32_t k, bool descending,
+                             uint32_t* out_idx, uint64_t* out_ids, float* out_val, uint32_t* out_n) {
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        if (i < count) {
+            if (out_idx) out_idx[i] = s.idx[i];
+            if (out_ids) out_ids[i] = s.id[i];
+            out_val[i] = ordered_to_f32(descending ? s.hi[i] : ~s.hi[i]);
+        } else {
+            if (out_idx) out_idx[i] = 0xffffffffu;
+            if (out_ids) out_ids[i] = ~0ull;
+            out_val[i] = descending ? -__builtin_huge_valf() : __builtin_huge_valf();
+        }
+    }
+    if (threadIdx.x == 0 && out_n) *out_n = count;
+}
+
+// Final ordering of the k' collected keys.
+__global__ __launch_bounds__(kSortThreads) void select_sort_kernel(
+    const SelectState* __restrict__ state, const unsigned long long* __restrict__ keys,
+    uint32_t kcap, uint32_t k, bool descending, const uint64_t* __restrict__ id_map,
+    uint32_t* out_idx, uint64_t* out_ids, float* out_val, uint32_t* out_n) {
+    __shared__ SortLds s;
+    const uint32_t qi = blockIdx.x;
+    const uint32_t count = min(state[qi].kprime, kcap);
+    const uint32_t p2 = next_pow2(count);
+    const unsigned long long* in = keys + (uint64_t)qi * kcap;
+    for (uint32_t i = threadIdx.x; i < p2; i += blockDim.x) {
+        if (i < count) {
+            unsigned long long key = in[i];
+            uint32_t ix = ~(uint32_t)key;
+            s.hi[i] = (uint32_t)(key >> 32);
+            s.idx[i] = ix;
+            s.id[i] = id_map ? id_map[ix] : (uint64_t)ix;
+        } else {
+            s.hi[i] = 0;
+            s.idx[i] = 0xffffffffu;
+            s.id[i] = ~0ull;
+        }
+    }
+    __syncthreads();
+    lds_bitonic_sort(s, p2);
+    write_sorted(s, count, k, descending, out_idx ? out_idx + (uint64_t)qi * k : nullptr,
+                 out_ids ? out_ids + (uint64_t)qi * k : nullptr, out_val + (uint64_t)qi * k,
+                 out_n ? out_n + qi : nullptr);
+}
+
+// Whole selection in one workgroup when the list fits LDS (n <= kSelectMaxK).
+__global__ __launch_bounds__(kSortThreads) void select_small_kernel(
+    const float* __restrict__ vals, const uint32_t* __restrict__ idx, uint64_t stride,
+    const uint32_t* __restrict__ n_dev, uint32_t n_max, uint32_t k, bool descending,
+    const uint64_t* __restrict__ id_map, uint32_t* out_idx, uint64_t* out_ids, float* out_val,
+    uint32_t* out_n) {
+    __shared__ SortLds s;
+    __shared__ uint32_t valid_s;
+    const uint32_t qi = blockIdx.x;
+    const uint32_t n = n_dev ? min(n_dev[qi], n_max) : n_max;
+    const float* v = vals + (uint64_t)qi * stride;
+    const uint32_t* ix = idx ? idx + (uint64_t)qi * stride : nullptr;
+    const uint32_t p2 = next_pow2(n);
+    if (threadIdx.x == 0) valid_s = 0;
+    __syncthreads();
+    uint32_t my_valid = 0;
+    for (uint32_t i = threadIdx.x; i < p2; i += blockDim.x) {
+        float x = i < n ? v[i] : __builtin_nanf("");
+        if (x == x) {
+            uint32_t id = ix ? ix[i] : i;
+            uint32_t o = f32_to_ordered(x);
+            s.hi[i] = descending ? o : ~o;
+            s.idx[i] = id;
+            s.id[i] = id_map ? id_map[id] : (uint64_t)id;
+            ++my_valid;
+        } else {
+            s.hi[i] = 0;
+            s.idx[i] = 0xffffffffu;
+            s.id[i] = ~0ull;
+        }
+    }
+    if (my_valid) atomicAdd(&valid_s, my_valid);
+    __syncthreads();
+    lds_bitonic_sort(s, p2);
+    const uint32_t count = min(valid_s, k);
+    write_sorted(s, count, k, descending, out_idx ? out_idx + (uint64_t)qi * k : nullptr,
+                 out_ids ? out_ids + (uint64_t)qi * k : nullptr, out_val + (uint64_t)qi * k,
+                 out_n ? out_n + qi : nullptr);
+}
+
+// K6: merge `lists` x k candidates per query (ids are already 64-bit DocumentIds).
+__global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(
+    const uint64_t* __restrict__ ids, const float* __restrict__ dist, uint32_t lists, uint32_t q,
+    uint32_t k, uint64_t* out_ids, float* out_dist, uint32_t* out_n) {
+    __shared__ SortLds s;
+    __shared__ uint32_t valid_s;
+    const uint32_t qi = blockIdx.x;
+    const uint32_t n = lists * k;
+    const uint32_t p2 = next_pow2(n);
+    if (threadIdx.x == 0) valid_s = 0;
+    __syncthreads();
+    uint32_t my_valid = 0;
+    for (uint32_t i = threadIdx.x; i < p2; i += blockDim.x) {
+        bool ok = false;
+        if (i < n) {
+            uint32_t l = i / k, j = i - l * k;
+            uint64_t src = ((uint64_t)l * q + qi) * k + j;
+            uint64_t id = ids[src];
+            float x = dist[src];
+            if (id != ~0ull && x == x) {
+                s.hi[i] = ~f32_to_ordered(x);
+                s.idx[i] = i;
+                s.id[i] = id;
+                ok = true;
+                ++my_valid;
+            }
+        }
+        if (!ok) {
+            s.hi[i] = 0;
+            s.idx[i] = 0xffffffffu;
+            s.id[i] = ~0ull;
+        }
+    }
+    if (my_valid) atomicAdd(&valid_s, my_valid);
+    __syncthreads();
+    lds_bitonic_sort(s, p2);
+    const uint32_t count = min(valid_s, k);
+    write_sorted(s, count, k, false, nullptr, out_ids + (uint64_t)qi * k, out_dist + (uint64_t)qi * k,
+                 out_n ? out_n + qi : nullptr);
+}
+
+}  // namespace
+
+int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
+    ORAMA_REQUIRE(p.k >= 1 && p.k <= kSelectMaxK, "top-k: k=%u outside [1, %u]", p.k, kSelectMaxK);
+    ORAMA_REQUIRE(p.q >= 1 && p.vals && p.out_val, "top-k: bad plan");
+    ProfScope prof(&ctx->prof, "topk_select", stream);
+    if (p.n <= kSelectMaxK) {
+        if (p.n == 0) {
+            // empty list: emit padding + zero counts through the small kernel with n = 0
+        }
+        hipLaunchKernelGGL(select_small_kernel, dim3(p.q), dim3(kSortThreads), 0, stream, p.vals,
+                           p.idx, p.stride, p.n_dev, p.n, p.k, p.descending, p.id_map, p.out_idx,
+                           p.out_ids, p.out_val, p.out_n);
+        ORAMA_HIP_TRY(hipGetLastError());
+        return ORAMA_OK;
+    }
+    ORAMA_REQUIRE(p.state && p.keys, "top-k: scratch missing");
+    ORAMA_HIP_TRY(hipMemsetAsync(p.state, 0, sizeof(SelectState) * (size_t)p.q, stream));
+    uint32_t blocks = ceil_div_u32(p.n, kHistThreads * 16);
+    uint32_t max_blocks = (uint32_t)ctx->compute_units * 8u;
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks < 1) blocks = 1;
+    for (int pass = 0; pass < 6; ++pass) {
+        hipLaunchKernelGGL(select_hist_kernel, dim3(blocks, p.q), dim3(kHistThreads), 0, stream,
+                           p.vals, p.idx, p.stride, p.n_dev, p.n, p.descending, p.state, pass);
+        hipLaunchKernelGGL(select_scan_kernel, dim3(p.q), dim3(256), 0, stream, p.state, p.k, pass);
+    }
+    hipLaunchKernelGGL(select_collect_kernel, dim3(blocks, p.q), dim3(kHistThreads), 0, stream,
+                       p.vals, p.idx, p.stride, p.n_dev, p.n, p.descending, p.state, p.keys, p.k);
+    hipLaunchKernelGGL(select_sort_kernel, dim3(p.q), dim3(kSortThreads), 0, stream, p.state, p.keys,
+                       p.k, p.k, p.descending, p.id_map, p.out_idx, p.out_ids, p.out_val, p.out_n);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_merge_candidates(orama_ctx* ctx, const uint64_t* d_ids, const float* d_dist,
+                            uint32_t lists, uint32_t q, uint32_t k, uint64_t* d_out_ids,
+                            float* d_out_dist, uint32_t* d_out_n, hipStream_t stream) {
+    (void)ctx;
+    ORAMA_REQUIRE(lists >= 1 && q >= 1 && k >= 1, "merge: empty shape");
+    ORAMA_REQUIRE((uint64_t)lists * k <= kSelectMaxK, "merge: lists*k=%llu exceeds %u",
+                  (unsigned long long)lists * k, kSelectMaxK);
+    hipLaunchKernelGGL(merge_candidates_kernel, dim3(q), dim3(kSortThreads), 0, stream, d_ids, d_dist,
+                       lists, q, k, d_out_ids, d_out_dist, d_out_n);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+}  // namespace orama

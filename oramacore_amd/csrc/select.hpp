@@ -1,0 +1,56 @@
+// select.hpp — K4: top-k selection over dense or candidate score arrays (device side of
+// `top_n`, src/collection_manager/sides/read/sort.rs:260-279, and of the k-NN cut in the
+// third-party EmbeddingStorage::search).
+#pragma once
+
+#include "common.hpp"
+
+namespace orama {
+
+constexpr uint32_t kSelectMaxK = 4096;  // LDS-resident final sort (16 B x 4096 = 64 KiB)
+
+// Per-query selection state in HBM (zeroed by launch_select with one hipMemsetAsync).
+struct SelectState {
+    uint32_t hist[6][2048];
+    unsigned long long prefix;  // selected high bits of the 64-bit composite key so far
+    uint32_t remaining;         // how many elements must still be taken inside `prefix`
+    uint32_t done;              // selection threshold fully determined
+    uint32_t sel_shift;         // select  (key >> sel_shift) >= prefix
+    uint32_t valid;             // non-NaN elements
+    uint32_t kprime;            // min(k, valid)
+    uint32_t out_count;         // collect cursor
+    uint32_t pad;
+};
+
+struct SelectPlan {
+    // input: q independent lists. List i starts at vals + i*stride (and idx + i*stride).
+    const float* vals = nullptr;
+    const uint32_t* idx = nullptr;    // nullable: implicit position index
+    uint64_t stride = 0;
+    const uint32_t* n_dev = nullptr;  // nullable: per-list length in HBM (<= n)
+    uint32_t n = 0;                   // (max) list length
+    uint32_t q = 1;
+    uint32_t k = 0;
+    bool descending = true;           // true: larger value is better (scores); false: distances
+    const uint64_t* id_map = nullptr; // nullable: idx -> 64-bit id used for tie order + out_ids
+    // scratch (HBM)
+    SelectState* state = nullptr;     // q entries
+    unsigned long long* keys = nullptr;  // q x k
+    // output (HBM): q x k each, out_n: q
+    uint32_t* out_idx = nullptr;      // nullable
+    uint64_t* out_ids = nullptr;      // nullable (id_map[idx] or idx)
+    float* out_val = nullptr;
+    uint32_t* out_n = nullptr;
+};
+
+// Enqueue the selection on `stream`. Order of the result: value (best first), then id asc, then
+// idx asc. NaN values are never selected. Requires 1 <= k <= kSelectMaxK.
+int launch_select(orama_ctx* ctx, const SelectPlan& plan, hipStream_t stream);
+
+// K6: merge `lists` candidate lists of k (id, dist) pairs per query ([list][query][k] layout);
+// entries with id == UINT64_MAX are padding. Result per query: best k by (dist asc, id asc).
+int launch_merge_candidates(orama_ctx* ctx, const uint64_t* d_ids, const float* d_dist,
+                            uint32_t lists, uint32_t q, uint32_t k, uint64_t* d_out_ids,
+                            float* d_out_dist, uint32_t* d_out_n, hipStream_t stream);
+
+}  // namespace orama

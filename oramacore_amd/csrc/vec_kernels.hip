@@ -1,0 +1,386 @@
+// vec_kernels.hip — K1: brute-force distance scan over the HBM-resident embedding matrix.
+//
+// Mapping (gfx950): one 64-lane wave owns a row at a time; lane l loads the 16-byte pieces
+// l, l+64, l+128 … of the row, so every wave-wide load instruction fetches one contiguous 1 KiB
+// run of the row (full 128-B lines, no re-reads).  The query never goes through LDS: with this
+// mapping lane l only ever needs query elements 4l…4l+3 (+256·c), so they sit in 4·NCHUNK VGPRs
+// for the whole kernel.  Each wave keeps ROWS rows (ROWS·NCHUNK independent 16-B loads per lane)
+// in flight; rows are dealt to waves round-robin so that the chip reads one contiguous window of
+// the matrix at any moment.  Per row: 4·NCHUNK FMAs/lane, a DPP wave reduction, one scalar
+// epilogue → VALU load is a few % of the HBM time; the kernel is bound by HBM bandwidth
+// (algorithmic bytes = n · dim · 4 per pass; distances written back are 4 B/row, < 0.2 %).
+#include "vec_kernels.hpp"
+
+#include <cstdlib>
+
+#include "device_utils.hpp"
+
+namespace orama {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+const ScanTuning& scan_tuning() {
+    static ScanTuning t = [] {
+        ScanTuning x;
+        if (const char* e = std::getenv("ORAMA_SCAN_ROWS")) x.rows_per_wave = std::atoi(e);
+        if (const char* e = std::getenv("ORAMA_SCAN_BLOCKS_PER_CU")) x.blocks_per_cu = std::atoi(e);
+        if (const char* e = std::getenv("ORAMA_SCAN_NT")) x.nontemporal = std::atoi(e);
+        if (x.rows_per_wave != 1 && x.rows_per_wave != 2 && x.rows_per_wave != 4 &&
+            x.rows_per_wave != 8)
+            x.rows_per_wave = 4;
+        if (x.blocks_per_cu < 1 || x.blocks_per_cu > 16) x.blocks_per_cu = 8;
+        return x;
+    }();
+    return t;
+}
+
+namespace {
+
+constexpr int kScanThreads = 256;
+constexpr int kWavesPerBlock = kScanThreads / kWave;
+
+template <bool NT>
+__device__ __forceinline__ f32x4 load16(const f32x4* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+__device__ __forceinline__ bool row_excluded(uint64_t row, const uint32_t* dead,
+                                             const uint64_t* row_doc, const uint64_t* allow,
+                                             uint64_t allow_bits) {
+    if (dead && ((dead[row >> 5] >> (row & 31)) & 1u)) return true;
+    if (allow) {
+        uint64_t doc = row_doc[row];
+        if (doc >= allow_bits) return true;
+        if (!((allow[doc >> 6] >> (doc & 63)) & 1ull)) return true;
+    }
+    return false;
+}
+
+// NCHUNK = ceil(dim/4 / 64) 16-byte pieces per lane per row; EXACT: dim/4 == 64*NCHUNK.
+template <int NCHUNK, bool EXACT, int ROWS, bool NT, int METRIC>
+__global__ __launch_bounds__(kScanThreads) void vec_scan_f32_kernel(ScanArgs a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform_u32(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    const uint32_t d4 = a.dim >> 2;
+    const f32x4* __restrict__ base = reinterpret_cast<const f32x4*>(a.corpus);
+
+    // query → registers; |q| from the same registers (no extra launch)
+    f32x4 qv[NCHUNK];
+    float qq = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const uint32_t f = c * kWave + lane;
+        if (EXACT || f < d4) {
+            qv[c] = reinterpret_cast<const f32x4*>(a.query)[f];
+        } else {
+            qv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        qq = fmaf(qv[c].x, qv[c].x, qq);
+        qq = fmaf(qv[c].y, qv[c].y, qq);
+        qq = fmaf(qv[c].z, qv[c].z, qq);
+        qq = fmaf(qv[c].w, qv[c].w, qq);
+    }
+    float qscale = 0.0f;
+    if (METRIC == ORAMA_METRIC_COSINE) {
+        qq = wave_sum(qq);
+        qscale = qq > 0.0f ? 1.0f / sqrtf(qq) : 0.0f;  // zero-norm query: similarity 0
+    }
+    const bool filtered = (a.dead != nullptr) || (a.allow != nullptr);
+
+    for (uint64_t r0 = (uint64_t)wave * ROWS; r0 < a.n; r0 += (uint64_t)nwaves * ROWS) {
+        f32x4 x[ROWS][NCHUNK];
+        bool live[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint64_t row = r0 + r;
+            live[r] = row < a.n;
+            if (filtered && live[r])
+                live[r] = !row_excluded(row, a.dead, a.row_doc, a.allow, a.allow_bits);
+            const f32x4* p = base + row * d4 + lane;
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c) {
+                const bool ok = live[r] && (EXACT || (uint32_t)(c * kWave + lane) < d4);
+                x[r][c] = ok ? load16<NT>(p + c * kWave) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        float mine = 0.0f;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c) {
+                if (METRIC == ORAMA_METRIC_COSINE) {
+                    acc = fmaf(x[r][c].x, qv[c].x, acc);
+                    acc = fmaf(x[r][c].y, qv[c].y, acc);
+                    acc = fmaf(x[r][c].z, qv[c].z, acc);
+                    acc = fmaf(x[r][c].w, qv[c].w, acc);
+                } else {
+                    float t0 = x[r][c].x - qv[c].x, t1 = x[r][c].y - qv[c].y;
+                    float t2 = x[r][c].z - qv[c].z, t3 = x[r][c].w - qv[c].w;
+                    acc = fmaf(t0, t0, acc);
+                    acc = fmaf(t1, t1, acc);
+                    acc = fmaf(t2, t2, acc);
+                    acc = fmaf(t3, t3, acc);
+                }
+            }
+            const float tot = wave_sum(acc);
+            float dist;
+            if (METRIC == ORAMA_METRIC_COSINE) {
+                const float inv = live[r] ? a.inv_norm[r0 + r] : 0.0f;
+                dist = 1.0f - tot * (inv * qscale);
+            } else {
+                dist = tot;
+            }
+            if (!live[r]) dist = __builtin_nanf("");
+            if (lane == r) mine = dist;
+        }
+        if (lane < ROWS && r0 + lane < a.n) a.out_dist[r0 + lane] = mine;
+    }
+}
+
+// Any dim (also dim % 4 != 0): scalar loads, one row per wave iteration.
+template <int METRIC>
+__global__ __launch_bounds__(kScanThreads) void vec_scan_f32_generic_kernel(ScanArgs a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform_u32(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    float qq = 0.0f;
+    for (uint32_t c = lane; c < a.dim; c += kWave) qq = fmaf(a.query[c], a.query[c], qq);
+    float qscale = 0.0f;
+    if (METRIC == ORAMA_METRIC_COSINE) {
+        qq = wave_sum(qq);
+        qscale = qq > 0.0f ? 1.0f / sqrtf(qq) : 0.0f;
+    }
+    for (uint64_t row = wave; row < a.n; row += nwaves) {
+        const bool live = !row_excluded(row, a.dead, a.row_doc, a.allow, a.allow_bits);
+        float acc = 0.0f;
+        if (live) {
+            const float* p = a.corpus + row * (uint64_t)a.dim;
+            for (uint32_t c = lane; c < a.dim; c += kWave) {
+                if (METRIC == ORAMA_METRIC_COSINE) {
+                    acc = fmaf(p[c], a.query[c], acc);
+                } else {
+                    float t = p[c] - a.query[c];
+                    acc = fmaf(t, t, acc);
+                }
+            }
+        }
+        const float tot = wave_sum(acc);
+        float dist = METRIC == ORAMA_METRIC_COSINE ? 1.0f - tot * (a.inv_norm[row] * qscale) : tot;
+        if (!live) dist = __builtin_nanf("");
+        if (lane == 0) a.out_dist[row] = dist;
+    }
+}
+
+template <int NCHUNK, bool EXACT, int ROWS, bool NT>
+void launch_scan_metric(const ScanArgs& a, dim3 grid, hipStream_t s) {
+    if (a.metric == ORAMA_METRIC_COSINE)
+        hipLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_COSINE>), grid,
+                           dim3(kScanThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_L2SQ>), grid,
+                           dim3(kScanThreads), 0, s, a);
+}
+
+template <int NCHUNK, bool EXACT>
+void launch_scan_rows(const ScanArgs& a, const ScanTuning& t, dim3 grid, hipStream_t s) {
+    const bool nt = t.nontemporal != 0;
+    // register budget: ROWS * NCHUNK * 4 data VGPRs — cap ROWS for wide rows
+    int rows = t.rows_per_wave;
+    while (rows * NCHUNK > 16) rows >>= 1;
+    switch (rows) {
+        case 8:
+            nt ? launch_scan_metric<NCHUNK, EXACT, 8, true>(a, grid, s)
+               : launch_scan_metric<NCHUNK, EXACT, 8, false>(a, grid, s);
+            break;
+        case 4:
+            nt ? launch_scan_metric<NCHUNK, EXACT, 4, true>(a, grid, s)
+               : launch_scan_metric<NCHUNK, EXACT, 4, false>(a, grid, s);
+            break;
+        case 2:
+            nt ? launch_scan_metric<NCHUNK, EXACT, 2, true>(a, grid, s)
+               : launch_scan_metric<NCHUNK, EXACT, 2, false>(a, grid, s);
+            break;
+        default:
+            nt ? launch_scan_metric<NCHUNK, EXACT, 1, true>(a, grid, s)
+               : launch_scan_metric<NCHUNK, EXACT, 1, false>(a, grid, s);
+            break;
+    }
+}
+
+// ---------------------------------------------------------------- row norms
+__global__ __launch_bounds__(kScanThreads) void row_inv_norm_kernel(const float* __restrict__ corpus,
+                                                                    uint64_t first, uint64_t n,
+                                                                    uint32_t dim,
+                                                                    float* __restrict__ inv_norm) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+    for (uint64_t i = wave; i < n; i += nwaves) {
+        const float* p = corpus + (first + i) * (uint64_t)dim;
+        float ss = 0.0f;
+        for (uint32_t c = lane; c < dim; c += kWave) ss = fmaf(p[c], p[c], ss);
+        ss = wave_sum(ss);
+        if (lane == 0) inv_norm[first + i] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------- synthetic data
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float u01(uint32_t bits) {  // (0, 1]
+    return ((float)(bits >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(kScanThreads) void synth_fill_kernel(float* __restrict__ corpus,
+                                                                  uint64_t first, uint64_t n,
+                                                                  uint32_t dim, uint64_t seed) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+    for (uint64_t i = wave; i < n; i += nwaves) {
+        const uint64_t row = first + i;
+        float* p = corpus + row * (uint64_t)dim;
+        float ss = 0.0f;
+        // pass 1: norm of the gaussian row (values are regenerated in pass 2 — pure ALU, no HBM)
+        for (uint32_t c = lane * 2; c < dim; c += 2 * kWave) {
+            uint64_t h = splitmix64(seed ^ (row * 0xD1342543DE82EF95ull + (uint64_t)(c >> 1)));
+            float r = sqrtf(-2.0f * __logf(u01((uint32_t)h)));
+            float th = 6.28318530718f * u01((uint32_t)(h >> 32));
+            float g0 = r * __cosf(th), g1 = r * __sinf(th);
+            ss = fmaf(g0, g0, ss);
+            if (c + 1 < dim) ss = fmaf(g1, g1, ss);
+        }
+        ss = wave_sum(ss);
+        uint64_t hs = splitmix64(seed ^ 0xA5A5A5A55A5A5A5Aull ^ (row * 0x2545F4914F6CDD1Dull));
+        const float u = 0.5f + 1.5f * u01((uint32_t)hs);
+        const float scale = ss > 0.0f ? u / sqrtf(ss) : 0.0f;
+        for (uint32_t c = lane * 2; c < dim; c += 2 * kWave) {
+            uint64_t h = splitmix64(seed ^ (row * 0xD1342543DE82EF95ull + (uint64_t)(c >> 1)));
+            float r = sqrtf(-2.0f * __logf(u01((uint32_t)h)));
+            float th = 6.28318530718f * u01((uint32_t)(h >> 32));
+            float g0 = r * __cosf(th), g1 = r * __sinf(th);
+            p[c] = g0 * scale;
+            if (c + 1 < dim) p[c + 1] = g1 * scale;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void gather_rows_kernel(const float* __restrict__ corpus,
+                                                                   const uint64_t* __restrict__ idx,
+                                                                   uint64_t n, uint32_t dim,
+                                                                   float* __restrict__ out) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+    for (uint64_t i = wave; i < n; i += nwaves) {
+        const float* p = corpus + idx[i] * (uint64_t)dim;
+        float* o = out + i * (uint64_t)dim;
+        for (uint32_t c = lane; c < dim; c += kWave) o[c] = p[c];
+    }
+}
+
+__global__ void iota_u64_kernel(uint64_t* ids, uint64_t n, uint64_t first) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        ids[i] = first + i;
+}
+
+uint32_t grid_for_rows(uint64_t n_rows_per_wave_units, uint32_t cap) {
+    uint64_t blocks = (n_rows_per_wave_units + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks < 1) blocks = 1;
+    if (blocks > cap) blocks = cap;
+    return (uint32_t)blocks;
+}
+
+}  // namespace
+
+int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a, hipStream_t stream) {
+    ORAMA_REQUIRE(a.corpus && a.query && a.out_dist && a.dim > 0, "vec_scan: bad arguments");
+    ORAMA_REQUIRE(a.metric != ORAMA_METRIC_COSINE || a.inv_norm, "vec_scan: cosine needs inv_norm");
+    ORAMA_REQUIRE(!a.allow || a.row_doc, "vec_scan: filter needs row_doc");
+    if (a.n == 0) return ORAMA_OK;
+    const ScanTuning& t = scan_tuning();
+    ProfScope prof(&ctx->prof, "vec_scan_f32", stream);
+    const uint32_t cap = (uint32_t)ctx->compute_units * (uint32_t)t.blocks_per_cu;
+    const uint32_t d4 = a.dim >> 2;
+    if ((a.dim & 3) == 0 && d4 <= 4 * kWave) {
+        const int nchunk = (int)((d4 + kWave - 1) / kWave);
+        const bool exact = (d4 == (uint32_t)nchunk * kWave);
+        int rows = t.rows_per_wave;
+        while (rows * nchunk > 16) rows >>= 1;
+        dim3 grid(grid_for_rows((a.n + rows - 1) / rows, cap));
+        switch (nchunk) {
+            case 1:
+                exact ? launch_scan_rows<1, true>(a, t, grid, stream)
+                      : launch_scan_rows<1, false>(a, t, grid, stream);
+                break;
+            case 2:
+                exact ? launch_scan_rows<2, true>(a, t, grid, stream)
+                      : launch_scan_rows<2, false>(a, t, grid, stream);
+                break;
+            case 3:
+                exact ? launch_scan_rows<3, true>(a, t, grid, stream)
+                      : launch_scan_rows<3, false>(a, t, grid, stream);
+                break;
+            default:
+                exact ? launch_scan_rows<4, true>(a, t, grid, stream)
+                      : launch_scan_rows<4, false>(a, t, grid, stream);
+                break;
+        }
+    } else {
+        dim3 grid(grid_for_rows(a.n, cap));
+        if (a.metric == ORAMA_METRIC_COSINE)
+            hipLaunchKernelGGL((vec_scan_f32_generic_kernel<ORAMA_METRIC_COSINE>), grid,
+                               dim3(kScanThreads), 0, stream, a);
+        else
+            hipLaunchKernelGGL((vec_scan_f32_generic_kernel<ORAMA_METRIC_L2SQ>), grid,
+                               dim3(kScanThreads), 0, stream, a);
+    }
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_row_inv_norm_f32(const float* corpus, uint64_t first, uint64_t n, uint32_t dim,
+                            float* inv_norm, hipStream_t stream) {
+    if (n == 0) return ORAMA_OK;
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3(grid_for_rows(n, 4096)), dim3(kScanThreads), 0,
+                       stream, corpus, first, n, dim, inv_norm);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_synth_fill_f32(float* corpus, uint64_t first, uint64_t n, uint32_t dim, uint64_t seed,
+                          hipStream_t stream) {
+    if (n == 0) return ORAMA_OK;
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(grid_for_rows(n, 8192)), dim3(kScanThreads), 0, stream,
+                       corpus, first, n, dim, seed);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_gather_rows_f32(const float* corpus, const uint64_t* d_row_idx, uint64_t n, uint32_t dim,
+                           float* d_out, hipStream_t stream) {
+    if (n == 0) return ORAMA_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for_rows(n, 4096)), dim3(kScanThreads), 0,
+                       stream, corpus, d_row_idx, n, dim, d_out);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_iota_u64(uint64_t* d_ids, uint64_t n, uint64_t first, hipStream_t stream) {
+    if (n == 0) return ORAMA_OK;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(iota_u64_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_ids, n, first);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+}  // namespace orama

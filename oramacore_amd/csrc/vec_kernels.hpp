@@ -1,0 +1,50 @@
+// vec_kernels.hpp — launchers of the vector-store kernels (K1 scan, row norms, synthetic fill,
+// row gather).  Device side of oramacore_fields::embedding::EmbeddingStorage::search as called at
+// src/collection_manager/sides/read/index/embedding_field.rs:255-266.
+#pragma once
+
+#include "common.hpp"
+
+namespace orama {
+
+struct ScanTuning {
+    int rows_per_wave = 4;    // rows each wave keeps in flight per iteration (1, 2, 4, 8)
+    int blocks_per_cu = 8;    // persistent grid = CUs x this
+    int nontemporal = 1;      // stream the corpus with `nt` loads
+};
+// Reads ORAMA_SCAN_ROWS / ORAMA_SCAN_BLOCKS_PER_CU / ORAMA_SCAN_NT once (tuning sweeps).
+const ScanTuning& scan_tuning();
+
+struct ScanArgs {
+    const float* corpus = nullptr;    // n x dim f32 row-major, rows 16-B aligned when dim % 4 == 0
+    const float* inv_norm = nullptr;  // n: 1/|x| (cosine only)
+    const float* query = nullptr;     // dim f32 (HBM)
+    uint64_t n = 0;
+    uint32_t dim = 0;
+    int metric = ORAMA_METRIC_COSINE;
+    const uint64_t* row_doc = nullptr;   // n DocumentIds (needed when `allow` is set)
+    const uint32_t* dead = nullptr;      // nullable bitmap over rows, bit set = tombstoned
+    const uint64_t* allow = nullptr;     // nullable bitmap over doc ids
+    uint64_t allow_bits = 0;
+    float* out_dist = nullptr;           // n distances; NaN for excluded rows
+};
+
+// K1: one corpus pass, one query.  Algorithmic HBM traffic: n * dim * 4 bytes.
+int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a, hipStream_t stream);
+
+// 1/|x| per row (cosine) for rows [first, first + n).
+int launch_row_inv_norm_f32(const float* corpus, uint64_t first, uint64_t n, uint32_t dim,
+                            float* inv_norm, hipStream_t stream);
+
+// Synthetic rows generated in HBM: x = u * g/|g|, g ~ N(0,1), u ~ U(0.5, 2).
+int launch_synth_fill_f32(float* corpus, uint64_t first, uint64_t n, uint32_t dim, uint64_t seed,
+                          hipStream_t stream);
+
+// out[i] = corpus[row_idx[i]]  (f32 rows).
+int launch_gather_rows_f32(const float* corpus, const uint64_t* d_row_idx, uint64_t n, uint32_t dim,
+                           float* d_out, hipStream_t stream);
+
+// ids[i] = first + i
+int launch_iota_u64(uint64_t* d_ids, uint64_t n, uint64_t first, hipStream_t stream);
+
+}  // namespace orama
