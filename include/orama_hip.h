@@ -63,6 +63,10 @@ int orama_ctx_synchronize(orama_ctx* ctx);
 /* Device facts for reports: name (<= 255 chars), CU count, HBM bytes. Any pointer may be NULL. */
 int orama_ctx_device_info(orama_ctx* ctx, char* name256, int* compute_units, uint64_t* hbm_bytes);
 
+/* Launch geometry of the K1 scan (tuning sweeps; defaults are the measured best on MI355X):
+ * rows each wave keeps in flight (1/2/4/8), persistent workgroups per CU, nontemporal corpus loads. */
+int orama_ctx_set_scan_tuning(orama_ctx* ctx, int rows_per_wave, int blocks_per_cu, int nontemporal);
+
 /* Per-kernel HIP-event timing (used by bench.py's roofline leg).  When enabled, the library
  * brackets each launch of the named hot kernels with hipEvents on the launching stream.
  * kernels: "vec_scan_f32", "vec_scan_f16", "topk_select", "bm25_accumulate", "bm25_finalize". */
@@ -129,6 +133,19 @@ int orama_vec_search_device(orama_vec* v, const float* d_queries, uint32_t q, ui
 int orama_merge_candidates_device(orama_ctx* ctx, const uint64_t* d_ids, const float* d_dist,
                                   uint32_t lists, uint32_t q, uint32_t k, uint64_t* d_out_ids,
                                   float* d_out_dist, uint32_t* d_out_n, void* hip_stream);
+
+/* Packed exchange block for the sharded path: one rank's candidates for q queries laid out as
+ * [q*k u64 ids][q*k f32 distances] and padded to a multiple of 8 bytes, so that ONE all-gather moves
+ * ids and distances together.  orama_packed_block_bytes gives the block size;
+ * orama_vec_search_packed_device writes the local block (same semantics as
+ * orama_vec_search_device); orama_merge_packed_device merges `lists` consecutive blocks. */
+uint64_t orama_packed_block_bytes(uint32_t q, uint32_t k);
+int orama_vec_search_packed_device(orama_vec* v, const float* d_queries, uint32_t q, uint32_t k,
+                                   const uint64_t* d_allow_bitmap, uint64_t bitmap_bits,
+                                   void* d_packed_block, uint32_t* d_out_n, void* hip_stream);
+int orama_merge_packed_device(orama_ctx* ctx, const void* d_packed_blocks, uint32_t lists, uint32_t q,
+                              uint32_t k, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n,
+                              void* hip_stream);
 
 /* Test/bench utilities (no reference counterpart). */
 /* Fill the store with n synthetic rows generated in HBM: x = u * g/|g|,

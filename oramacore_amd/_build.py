@@ -1,4 +1,4 @@
-"""In-tree build of liborama_hip.so (hipcc, gfx950 only) and of the CPU oracle.
+"""In-tree build of liborama_hip.so (hipcc, gfx950 only).
 
 `build_native()` compiles every .hip translation unit under oramacore_amd/csrc with
 `hipcc --offload-arch=gfx950` and links them into oramacore_amd/csrc/liborama_hip.so.  The shared
@@ -20,8 +20,6 @@ CSRC = ROOT / "oramacore_amd" / "csrc"
 INCLUDE = ROOT / "include"
 LIB = CSRC / "liborama_hip.so"
 OBJ_DIR = CSRC / "build"
-ORACLE_DIR = ROOT / "oracle"
-ORACLE_LIB = ORACLE_DIR / "liborama_oracle.so"
 
 ARCH = "gfx950"
 COMMON_FLAGS = [
@@ -35,7 +33,7 @@ COMMON_FLAGS = [
     f"-I{CSRC}",
 ]
 # Translation units whose f32 arithmetic must round exactly like the scalar reference
-# (BM25F scoring is compared bit-for-bit with the oracle): no FMA contraction.
+# (BM25F scores must be bit-identical to the scalar f32 evaluation): no FMA contraction.
 EXACT_FP = {"fulltext.hip", "bm25_kernels.hip"}
 
 
@@ -92,18 +90,5 @@ def build_native(force: bool = False, verbose: bool = True) -> Path:
     return LIB
 
 
-def build_oracle(force: bool = False) -> Path:
-    """Compile the CPU oracle (test infrastructure; never loaded by the product path)."""
-    src = ORACLE_DIR / "orama_oracle.c"
-    if force or not ORACLE_LIB.exists() or ORACLE_LIB.stat().st_mtime < max(
-        src.stat().st_mtime, (ORACLE_DIR / "orama_oracle.h").stat().st_mtime
-    ):
-        r = subprocess.run(["make", "-C", str(ORACLE_DIR), "-B"], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"oracle build failed:\n{r.stdout}\n{r.stderr}")
-    return ORACLE_LIB
-
-
 if __name__ == "__main__":
     print(build_native(force="--force" in sys.argv))
-    print(build_oracle())

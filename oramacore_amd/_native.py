@@ -118,6 +118,7 @@ def _declare(lib: C.CDLL) -> None:
         "orama_ctx_create": [C.c_int, C.POINTER(vp)],
         "orama_ctx_synchronize": [vp],
         "orama_ctx_device_info": [vp, C.c_char_p, C.POINTER(C.c_int), u64p],
+        "orama_ctx_set_scan_tuning": [vp, C.c_int, C.c_int, C.c_int],
         "orama_prof_enable": [vp, C.c_int],
         "orama_prof_reset": [vp],
         "orama_prof_get": [vp, C.c_char_p, C.POINTER(C.c_double), u64p],
@@ -129,6 +130,8 @@ def _declare(lib: C.CDLL) -> None:
         "orama_vec_search": [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, vp],
         "orama_vec_search_device": [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp],
         "orama_merge_candidates_device": [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp],
+        "orama_vec_search_packed_device": [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, vp],
+        "orama_merge_packed_device": [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp],
         "orama_vec_fill_synthetic": [vp, C.c_uint64, C.c_uint64, C.c_uint64],
         "orama_vec_get_rows": [vp, vp, C.c_uint64, vp, vp],
         "orama_bm25_score": [vp, C.POINTER(NtfEntry), C.c_uint32, C.POINTER(Bm25Params), vp, vp, C.c_uint64,
@@ -147,6 +150,8 @@ def _declare(lib: C.CDLL) -> None:
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.orama_packed_block_bytes.argtypes = [C.c_uint32, C.c_uint32]
+    lib.orama_packed_block_bytes.restype = C.c_uint64
     for name in ("orama_ctx_destroy", "orama_vec_destroy", "orama_post_destroy"):
         fn = getattr(lib, name)
         fn.argtypes = [vp]

@@ -47,6 +47,9 @@ class Context:
         N.check(self._lib.orama_ctx_device_info(self.handle, name, C.byref(cu), C.byref(hbm)))
         return {"name": name.value.decode(), "compute_units": cu.value, "hbm_bytes": hbm.value}
 
+    def set_scan_tuning(self, rows_per_wave: int, blocks_per_cu: int, nontemporal: bool) -> None:
+        N.check(self._lib.orama_ctx_set_scan_tuning(self.handle, rows_per_wave, blocks_per_cu, 1 if nontemporal else 0))
+
     # --- HIP-event profiler (bench.py roofline leg)
     def prof_enable(self, on: bool = True) -> None:
         N.check(self._lib.orama_prof_enable(self.handle, 1 if on else 0))

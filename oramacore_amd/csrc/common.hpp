@@ -151,8 +151,17 @@ struct Scratch {
 
 }  // namespace orama
 
+namespace orama {
+struct ScanTuning {
+    int rows_per_wave = 4;  // rows each wave keeps in flight per iteration (1, 2, 4, 8)
+    int blocks_per_cu = 8;  // persistent grid = CUs x this
+    int nontemporal = 1;    // stream the corpus with `nt` loads
+};
+}  // namespace orama
+
 struct orama_ctx {
     int device = 0;
+    orama::ScanTuning scan_tuning;  // defaults from ORAMA_SCAN_* env, see orama_ctx_set_scan_tuning
     int compute_units = 0;
     uint64_t hbm_bytes = 0;
     char name[256] = {0};

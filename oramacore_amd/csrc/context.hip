@@ -1,5 +1,6 @@
 // context.hip — error channel, per-GPU context, scratch pool, HIP-event profiler.
 #include "common.hpp"
+#include "vec_kernels.hpp"
 
 namespace orama {
 
@@ -123,6 +124,7 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
         orama::set_error("out of host memory");
         return ORAMA_ERR_OOM;
     }
+    c->scan_tuning = orama::default_scan_tuning();
     c->device = device_ordinal;
     c->compute_units = prop.multiProcessorCount;
     c->hbm_bytes = (uint64_t)prop.totalGlobalMem;
@@ -153,6 +155,17 @@ int orama_ctx_device_info(orama_ctx* ctx, char* name256, int* compute_units, uin
     }
     if (compute_units) *compute_units = ctx->compute_units;
     if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return ORAMA_OK;
+}
+
+int orama_ctx_set_scan_tuning(orama_ctx* ctx, int rows_per_wave, int blocks_per_cu, int nontemporal) {
+    ORAMA_REQUIRE(ctx, "null ctx");
+    orama::ScanTuning t;
+    t.rows_per_wave = rows_per_wave;
+    t.blocks_per_cu = blocks_per_cu;
+    t.nontemporal = nontemporal;
+    ORAMA_REQUIRE(orama::scan_tuning_valid(t), "scan tuning out of range (rows in {1,2,4,8}, blocks/CU in [1,32])");
+    ctx->scan_tuning = t;
     return ORAMA_OK;
 }
 

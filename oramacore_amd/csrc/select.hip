@@ -321,9 +321,12 @@ __global__ __launch_bounds__(kSortThreads) void select_small_kernel(
 }
 
 // K6: merge `lists` x k candidates per query (ids are already 64-bit DocumentIds).
+// List l of the ids lives at ids + l*ids_stride bytes, of the distances at dist + l*dist_stride bytes
+// (separate arrays: stride = q*k elements; packed all-gather blocks: stride = block size).
 __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(
-    const uint64_t* __restrict__ ids, const float* __restrict__ dist, uint32_t lists, uint32_t q,
-    uint32_t k, uint64_t* out_ids, float* out_dist, uint32_t* out_n) {
+    const char* __restrict__ ids, uint64_t ids_stride, const char* __restrict__ dist,
+    uint64_t dist_stride, uint32_t lists, uint32_t q, uint32_t k, uint64_t* out_ids, float* out_dist,
+    uint32_t* out_n) {
     __shared__ SortLds s;
     __shared__ uint32_t valid_s;
     const uint32_t qi = blockIdx.x;
@@ -336,9 +339,9 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(
         bool ok = false;
         if (i < n) {
             uint32_t l = i / k, j = i - l * k;
-            uint64_t src = ((uint64_t)l * q + qi) * k + j;
-            uint64_t id = ids[src];
-            float x = dist[src];
+            const uint64_t src = (uint64_t)qi * k + j;
+            const uint64_t id = reinterpret_cast<const uint64_t*>(ids + (uint64_t)l * ids_stride)[src];
+            const float x = reinterpret_cast<const float*>(dist + (uint64_t)l * dist_stride)[src];
             if (id != ~0ull && x == x) {
                 s.hi[i] = ~f32_to_ordered(x);
                 s.idx[i] = i;
@@ -403,8 +406,29 @@ int launch_merge_candidates(orama_ctx* ctx, const uint64_t* d_ids, const float* 
     ORAMA_REQUIRE(lists >= 1 && q >= 1 && k >= 1, "merge: empty shape");
     ORAMA_REQUIRE((uint64_t)lists * k <= kSelectMaxK, "merge: lists*k=%llu exceeds %u",
                   (unsigned long long)lists * k, kSelectMaxK);
-    hipLaunchKernelGGL(merge_candidates_kernel, dim3(q), dim3(kSortThreads), 0, stream, d_ids, d_dist,
-                       lists, q, k, d_out_ids, d_out_dist, d_out_n);
+    hipLaunchKernelGGL(merge_candidates_kernel, dim3(q), dim3(kSortThreads), 0, stream,
+                       reinterpret_cast<const char*>(d_ids), (uint64_t)q * k * 8,
+                       reinterpret_cast<const char*>(d_dist), (uint64_t)q * k * 4, lists, q, k, d_out_ids,
+                       d_out_dist, d_out_n);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+uint64_t packed_block_bytes(uint32_t q, uint32_t k) {
+    return (((uint64_t)q * k * 12) + 7) & ~7ull;
+}
+
+int launch_merge_packed(orama_ctx* ctx, const void* d_packed, uint32_t lists, uint32_t q, uint32_t k,
+                        uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n,
+                        hipStream_t stream) {
+    (void)ctx;
+    ORAMA_REQUIRE(lists >= 1 && q >= 1 && k >= 1, "merge: empty shape");
+    ORAMA_REQUIRE((uint64_t)lists * k <= kSelectMaxK, "merge: lists*k=%llu exceeds %u",
+                  (unsigned long long)lists * k, kSelectMaxK);
+    const uint64_t block = packed_block_bytes(q, k);
+    const char* base = reinterpret_cast<const char*>(d_packed);
+    hipLaunchKernelGGL(merge_candidates_kernel, dim3(q), dim3(kSortThreads), 0, stream, base, block,
+                       base + (uint64_t)q * k * 8, block, lists, q, k, d_out_ids, d_out_dist, d_out_n);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

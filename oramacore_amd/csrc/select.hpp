@@ -53,4 +53,10 @@ int launch_merge_candidates(orama_ctx* ctx, const uint64_t* d_ids, const float* 
                             uint32_t lists, uint32_t q, uint32_t k, uint64_t* d_out_ids,
                             float* d_out_dist, uint32_t* d_out_n, hipStream_t stream);
 
+// Packed exchange block of one rank: [q*k u64 ids][q*k f32 distances], padded to 8 bytes.
+uint64_t packed_block_bytes(uint32_t q, uint32_t k);
+// K6 over `lists` consecutive packed blocks (the output of one all-gather).
+int launch_merge_packed(orama_ctx* ctx, const void* d_packed, uint32_t lists, uint32_t q, uint32_t k,
+                        uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n, hipStream_t stream);
+
 }  // namespace orama

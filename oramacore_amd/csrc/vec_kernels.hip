@@ -19,19 +19,18 @@ namespace orama {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-const ScanTuning& scan_tuning() {
-    static ScanTuning t = [] {
-        ScanTuning x;
-        if (const char* e = std::getenv("ORAMA_SCAN_ROWS")) x.rows_per_wave = std::atoi(e);
-        if (const char* e = std::getenv("ORAMA_SCAN_BLOCKS_PER_CU")) x.blocks_per_cu = std::atoi(e);
-        if (const char* e = std::getenv("ORAMA_SCAN_NT")) x.nontemporal = std::atoi(e);
-        if (x.rows_per_wave != 1 && x.rows_per_wave != 2 && x.rows_per_wave != 4 &&
-            x.rows_per_wave != 8)
-            x.rows_per_wave = 4;
-        if (x.blocks_per_cu < 1 || x.blocks_per_cu > 16) x.blocks_per_cu = 8;
-        return x;
-    }();
-    return t;
+bool scan_tuning_valid(const ScanTuning& t) {
+    const int r = t.rows_per_wave;
+    return (r == 1 || r == 2 || r == 4 || r == 8) && t.blocks_per_cu >= 1 && t.blocks_per_cu <= 32;
+}
+
+ScanTuning default_scan_tuning() {
+    ScanTuning x;
+    if (const char* e = std::getenv("ORAMA_SCAN_ROWS")) x.rows_per_wave = std::atoi(e);
+    if (const char* e = std::getenv("ORAMA_SCAN_BLOCKS_PER_CU")) x.blocks_per_cu = std::atoi(e);
+    if (const char* e = std::getenv("ORAMA_SCAN_NT")) x.nontemporal = std::atoi(e);
+    if (!scan_tuning_valid(x)) x = ScanTuning();
+    return x;
 }
 
 namespace {
@@ -306,7 +305,7 @@ int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a, hipStream_t stream) {
     ORAMA_REQUIRE(a.metric != ORAMA_METRIC_COSINE || a.inv_norm, "vec_scan: cosine needs inv_norm");
     ORAMA_REQUIRE(!a.allow || a.row_doc, "vec_scan: filter needs row_doc");
     if (a.n == 0) return ORAMA_OK;
-    const ScanTuning& t = scan_tuning();
+    const ScanTuning& t = ctx->scan_tuning;
     ProfScope prof(&ctx->prof, "vec_scan_f32", stream);
     const uint32_t cap = (uint32_t)ctx->compute_units * (uint32_t)t.blocks_per_cu;
     const uint32_t d4 = a.dim >> 2;

@@ -7,13 +7,10 @@
 
 namespace orama {
 
-struct ScanTuning {
-    int rows_per_wave = 4;    // rows each wave keeps in flight per iteration (1, 2, 4, 8)
-    int blocks_per_cu = 8;    // persistent grid = CUs x this
-    int nontemporal = 1;      // stream the corpus with `nt` loads
-};
-// Reads ORAMA_SCAN_ROWS / ORAMA_SCAN_BLOCKS_PER_CU / ORAMA_SCAN_NT once (tuning sweeps).
-const ScanTuning& scan_tuning();
+// Initial tuning: built-in defaults overridden by ORAMA_SCAN_ROWS / ORAMA_SCAN_BLOCKS_PER_CU /
+// ORAMA_SCAN_NT (read once).
+ScanTuning default_scan_tuning();
+bool scan_tuning_valid(const ScanTuning& t);
 
 struct ScanArgs {
     const float* corpus = nullptr;    // n x dim f32 row-major, rows 16-B aligned when dim % 4 == 0

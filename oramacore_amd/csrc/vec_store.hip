@@ -420,6 +420,28 @@ int orama_merge_candidates_device(orama_ctx* ctx, const uint64_t* d_ids, const f
                                    (hipStream_t)hip_stream);
 }
 
+uint64_t orama_packed_block_bytes(uint32_t q, uint32_t k) { return packed_block_bytes(q, k); }
+
+int orama_vec_search_packed_device(orama_vec* v, const float* d_queries, uint32_t q, uint32_t k,
+                                   const uint64_t* d_allow_bitmap, uint64_t bitmap_bits,
+                                   void* d_packed_block, uint32_t* d_out_n, void* hip_stream) {
+    ORAMA_REQUIRE(d_packed_block, "null argument");
+    char* base = reinterpret_cast<char*>(d_packed_block);
+    return orama_vec_search_device(v, d_queries, q, k, d_allow_bitmap, bitmap_bits,
+                                   reinterpret_cast<uint64_t*>(base),
+                                   reinterpret_cast<float*>(base + (uint64_t)q * k * 8), d_out_n,
+                                   hip_stream);
+}
+
+int orama_merge_packed_device(orama_ctx* ctx, const void* d_packed_blocks, uint32_t lists, uint32_t q,
+                              uint32_t k, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n,
+                              void* hip_stream) {
+    ORAMA_REQUIRE(ctx && d_packed_blocks && d_out_ids && d_out_dist, "null argument");
+    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_merge_packed(ctx, d_packed_blocks, lists, q, k, d_out_ids, d_out_dist, d_out_n,
+                               (hipStream_t)hip_stream);
+}
+
 int orama_vec_fill_synthetic(orama_vec* v, uint64_t n_rows, uint64_t seed, uint64_t first_doc_id) {
     ORAMA_REQUIRE(v, "null handle");
     if (n_rows == 0) return ORAMA_OK;

@@ -1,0 +1,243 @@
+"""GPU parity tests of the vector path (K1 scan + K4 top-k) through the C ABI.
+
+Bar (BASELINE.json north_star): cosine scores within 1e-4 of the reference's fp32 arithmetic; ids
+identical wherever scores are separated by more than the fp32 summation-order noise.
+"""
+import numpy as np
+import pytest
+
+import oramacore_amd as oa
+import util
+from oracle import oracle as orc
+from test_oracle_golden import multirow_inputs
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north_star: "cosine scores within 1e-4 fp32"
+
+
+def make_store(ctx, corpus, row_doc=None, metric=oa.METRIC_COSINE):
+    n, d = corpus.shape
+    st = oa.EmbeddingFieldStorage(ctx, dimensions=d, metric=metric)
+    ids = np.arange(n, dtype=np.uint64) if row_doc is None else row_doc
+    assert st.insert_rows(ids, corpus) == n
+    return st
+
+
+@pytest.mark.parametrize("d", [384, 768])
+def test_cosine_small_vs_golden_and_oracle(ctx, d):
+    g = np.load(util.GOLDEN / "cosine_small.npz")
+    n, nq, k = 4096, 8, 100
+    corpus = util.det_matrix(n, d, seed=1000 + d)
+    queries = util.det_matrix(nq, d, seed=2000 + d)
+    st = make_store(ctx, corpus)
+    ids, dist, cnt = st.storage_search(queries, k)  # batch entry: 8 independent queries
+    assert cnt.tolist() == [k] * nq
+    for qi in range(nq):
+        util.assert_ranked_equal(ids[qi], dist[qi], g[f"ids_{d}"][qi], g[f"dist32_{d}"][qi], TOL, f"q{qi}")
+        assert np.max(np.abs(dist[qi].astype(np.float64) - g[f"dist64_{d}"][qi])) < TOL
+        full = orc.distances(corpus, queries[qi])
+        util.assert_topk_sound(ids[qi], dist[qi], full, k, TOL, f"q{qi}")
+    # single-query entry (the reference's shape) gives the same answer as the batch entry
+    ids1, dist1, cnt1 = st.storage_search(queries[3], k)
+    assert np.array_equal(ids1[0], ids[3]) and np.array_equal(dist1[0], dist[3])
+    st.close()
+
+
+@pytest.mark.parametrize("d,n", [(1024, 3000), (384, 1), (768, 63), (100, 777), (7, 50), (2048, 130), (96, 5000)])
+def test_dims_and_ragged_sizes(ctx, d, n):
+    """Every reference model dimension (384/768/1024, src/python/embeddings.rs:52-63) plus odd dims that
+    take the generic kernel, and row counts that do not fill the last wave group."""
+    corpus = util.gaussian_rows(n, d, seed=d * 7 + n)
+    q = util.gaussian_rows(1, d, seed=d + 1)[0]
+    st = make_store(ctx, corpus)
+    for k in (1, 10, 100):
+        ids, dist, cnt = st.storage_search(q, k)
+        m = int(cnt[0])
+        assert m == min(k, n)
+        full = orc.distances(corpus, q)
+        util.assert_topk_sound(ids[0, :m], dist[0, :m], full, k, TOL, f"d={d} n={n} k={k}")
+    st.close()
+
+
+def test_empty_store_and_limit_zero(ctx):
+    st = oa.EmbeddingFieldStorage(ctx, oa.Model.BGESmall)
+    q = np.ones(384, dtype=np.float32)
+    ids, dist, cnt = st.storage_search(q, 10)
+    assert cnt[0] == 0
+    st.insert(5, q)
+    ids, dist, cnt = st.storage_search(q, 0)
+    assert cnt[0] == 0
+    ids, dist, cnt = st.storage_search(q, 10)
+    assert cnt[0] == 1 and ids[0, 0] == 5 and abs(dist[0, 0]) < 1e-6
+    st.close()
+
+
+def test_insert_rejects_invalid_rows(ctx):
+    """EmbeddingIndexer::index_vec_vec -> None (embedding_field.rs:232-237): zero / non-finite rows."""
+    d = 384
+    rows = util.gaussian_rows(6, d, seed=3)
+    rows[1] = 0.0
+    rows[3, 17] = np.nan
+    rows[4, 0] = np.inf
+    st = oa.EmbeddingFieldStorage(ctx, dimensions=d)
+    assert st.insert_rows(np.arange(6, dtype=np.uint64), rows) == 3
+    assert st.info()["num_embeddings"] == 3
+    ids, dist, cnt = st.storage_search(rows[0], 10)
+    assert sorted(ids[0, :cnt[0]].tolist()) == [0, 2, 5]
+    for j in range(6):
+        assert orc.row_is_valid(rows[j]) == (j in (0, 2, 5))
+    st.close()
+
+
+def test_tie_rule_matches_oracle_exactly(ctx):
+    """Duplicated rows under shuffled doc ids: equal distances are ordered by doc id, and the cut at k
+    keeps the lowest rows (declared rule; reference unpinned — SURVEY F6)."""
+    g = util.load_json("cosine_ties.json")
+    d, base_n = 384, 64
+    base = util.det_matrix(base_n, d, seed=77)
+    order = np.argsort(util.hash_u64(np.arange(base_n * 4, dtype=np.uint64) + np.uint64(5)), kind="stable")
+    corpus = np.concatenate([base] * 4, axis=0)[order]
+    row_doc = (np.arange(base_n * 4, dtype=np.uint64) * np.uint64(3) + np.uint64(7))[
+        np.argsort(util.hash_u64(np.arange(base_n * 4, dtype=np.uint64) + np.uint64(11)), kind="stable")]
+    q = util.det_matrix(1, d, seed=78)[0]
+    st = make_store(ctx, corpus, row_doc)
+    for k, exp in g.items():
+        ids, dist, cnt = st.storage_search(q, int(k))
+        m = int(cnt[0])
+        assert m == len(exp["ids"])
+        exp_dist = np.array(exp["dist_bits"], dtype=np.uint32).view(np.float32)
+        assert np.max(np.abs(dist[0, :m] - exp_dist)) <= TOL
+        # duplicates are bit-identical rows => bit-identical device distances => exact tie groups:
+        # within each group of 4 the ids must come out ascending, like the oracle's.
+        got = ids[0, :m].tolist()
+        dd = dist[0, :m]
+        i = 0
+        while i < m:
+            j = i
+            while j < m and dd[j] == dd[i]:
+                j += 1
+            assert got[i:j] == sorted(got[i:j])
+            i = j
+        util.assert_ranked_equal(ids[0, :m], dist[0, :m], exp["ids"], exp_dist, TOL, f"ties k={k}")
+    st.close()
+
+
+def test_multirow_delete_filter_epilogue(ctx):
+    """N rows per doc, tombstones, allow-bitmap, then the in-tree epilogue (embedding_field.rs:268-276)
+    with and without the E5 rescale (python/embeddings.rs:71-92)."""
+    g = util.load_json("cosine_multirow.json")
+    corpus, row_doc, q, dead, allow, dead_docs = multirow_inputs()
+    bm = oa.AllowBitmap.from_mask(allow)
+    for name, use_dead, use_filter in (("plain", 0, 0), ("dead", 1, 0), ("filter", 0, 1), ("dead_filter", 1, 1)):
+        st = make_store(ctx, corpus, row_doc)
+        if use_dead:
+            for dd in dead_docs:
+                st.delete(dd)
+            assert st.has_pending_ops()
+        for k in (5, 10, 50):
+            exp = g[f"{name}_k{k}"]
+            ids, dist, cnt = st.storage_search(q, k, bm if use_filter else None)
+            m = int(cnt[0])
+            util.assert_ranked_equal(ids[0, :m], dist[0, :m], exp["ids"], exp["dist"], TOL, f"{name} k={k}")
+            for model, is_e5 in ((oa.Model.BGESmall, 0), (oa.Model.MultilingualE5Small, 1)):
+                for ms in (0.0, 0.7):
+                    st._model = model
+                    out = {}
+                    st.search(oa.VectorSearchParams(target=q, similarity=ms, limit=k,
+                                                    filtered_doc_ids=bm if use_filter else None), out)
+                    expm = exp[f"map_e5{is_e5}_min{ms}"]
+                    # scores near the cut-off may flip with 1e-4 noise: compare docs clearly inside/outside
+                    for dk, v in expm.items():
+                        if v > ms + 5 * TOL or ms == 0.0:
+                            assert int(dk) in out and abs(float(out[int(dk)]) - v) <= 20 * TOL, (name, k, dk)
+                    for dk, v in out.items():
+                        assert str(dk) in expm or float(v) <= ms + 5 * TOL
+        if use_dead:
+            # compaction drops the tombstones and must not change results
+            before = st.storage_search(q, 50, bm if use_filter else None)
+            st.compact(7)
+            assert not st.has_pending_ops() and st.current_version_number() == 7
+            after = st.storage_search(q, 50, bm if use_filter else None)
+            assert np.array_equal(before[0], after[0]) and np.array_equal(before[2], after[2])
+            assert np.allclose(before[1], after[1], atol=1e-6)
+        st.close()
+
+
+def test_l2_extension(ctx):
+    """Squared-L2 metric (build-side extension) against the oracle's direct form."""
+    n, d = 5000, 384
+    corpus = util.gaussian_rows(n, d, seed=11)
+    q = util.gaussian_rows(1, d, seed=12)[0]
+    st = make_store(ctx, corpus, metric=oa.METRIC_L2SQ)
+    ids, dist, cnt = st.storage_search(q, 100)
+    full = orc.distances(corpus, q, metric=1)
+    util.assert_topk_sound(ids[0], dist[0], full, 100, 1e-4, "l2")
+    st.close()
+
+
+def test_zero_query_declared_rule(ctx):
+    corpus = util.gaussian_rows(100, 384, seed=5)
+    st = make_store(ctx, corpus)
+    ids, dist, cnt = st.storage_search(np.zeros(384, dtype=np.float32), 5)
+    assert cnt[0] == 5 and np.all(dist[0] == 1.0) and ids[0].tolist() == [0, 1, 2, 3, 4]
+    st.close()
+
+
+def test_search_is_idempotent_and_incremental(ctx):
+    """Appending rows keeps earlier rows' distances; repeated searches are bit-identical."""
+    d = 768
+    a = util.gaussian_rows(3000, d, seed=21)
+    b = util.gaussian_rows(2000, d, seed=22)
+    q = util.gaussian_rows(1, d, seed=23)[0]
+    st = make_store(ctx, a)
+    r1 = st.storage_search(q, 50)
+    r2 = st.storage_search(q, 50)
+    assert all(np.array_equal(x, y) for x, y in zip(r1, r2))
+    st.insert_rows(np.arange(3000, 5000, dtype=np.uint64), b)
+    ids, dist, cnt = st.storage_search(q, 50)
+    full = orc.distances(np.concatenate([a, b]), q)
+    util.assert_topk_sound(ids[0], dist[0], full, 50, TOL, "after append")
+    st.close()
+
+
+def test_synthetic_fill_properties_1m(ctx):
+    """BASELINE configs[1] shape (1 M x 384 fp32, k = 100) through size-independent properties:
+    sortedness, planted exact matches on top, top-k soundness on the rows read back, and
+    merge-of-halves == whole (the shard/merge identity used by the multi-GPU path)."""
+    n, d, k = 1_000_000, 384, 100
+    st = oa.EmbeddingFieldStorage(ctx, oa.Model.BGESmall, reserve_rows=n + 16)
+    st.fill_synthetic(n, seed=0xC0FFEE, first_doc_id=0)
+    q = util.gaussian_rows(1, d, seed=0xBEEF)[0]
+    # plant 3 scaled copies of the query at the end: cosine distance ~ 0
+    plant = np.stack([q * np.float32(s) for s in (0.5, 1.0, 3.0)])
+    st.insert_rows(np.arange(n, n + 3, dtype=np.uint64), plant)
+    ids, dist, cnt = st.storage_search(q, k)
+    assert cnt[0] == k
+    assert sorted(ids[0, :3].tolist()) == [n, n + 1, n + 2] and np.all(np.abs(dist[0, :3]) < 1e-6)
+    assert np.all(np.diff(dist[0]) >= 0)
+    # reported distances agree with the oracle on the rows themselves (doc id == row here)
+    rows, docs = st.get_rows(ids[0])
+    assert np.array_equal(docs, ids[0])
+    od = np.array([orc.distances(rows[i:i + 1], q)[0] for i in range(k)])
+    assert np.max(np.abs(od - dist[0])) <= TOL
+    # rows have the declared norm distribution U(0.5, 2)
+    norms = np.linalg.norm(rows[3:], axis=1)
+    assert norms.min() >= 0.49 and norms.max() <= 2.01
+    # a random sample of other rows must not beat the k-th distance
+    rng = np.random.default_rng(1)
+    sample = rng.choice(n, size=20000, replace=False).astype(np.uint64)
+    srows, _ = st.get_rows(sample)
+    sd = orc.distances(srows, q)
+    inside = set(ids[0].tolist())
+    for r, v in zip(sample.tolist(), sd.tolist()):
+        assert r in inside or v >= dist[0, -1] - 2 * TOL
+    # shard/merge identity: top-k(all) == merge(top-k(even docs), top-k(odd docs))
+    even = oa.AllowBitmap.from_mask(np.arange(n + 3) % 2 == 0)
+    odd = oa.AllowBitmap.from_mask(np.arange(n + 3) % 2 == 1)
+    ie, de, ce = st.storage_search(q, k, even)
+    io, do, co = st.storage_search(q, k, odd)
+    assert np.all(ie[0] % 2 == 0) and np.all(io[0] % 2 == 1)
+    md, ms = orc.top_n(np.concatenate([ie[0], io[0]]), -np.concatenate([de[0], do[0]]), k)
+    assert np.array_equal(md, ids[0]) and np.array_equal(-ms, dist[0])
+    st.close()
