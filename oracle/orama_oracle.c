@@ -313,7 +313,7 @@ uint64_t orc_search_full_text(const orc_entry* entries, uint32_t n_entries, uint
                     float final_score = term_score * 1.0f; /* phrase boost */
                     applied[n_applied].doc = buf[i].doc;
                     applied[n_applied].score = final_score;
-                    applied[n_applied].mask = t < 32 ? (1u << t) : 0u; /* 1 << term_index (u32) */
+                    applied[n_applied].mask = 1u << (t & 31u); /* 1 << term_index on u32: release-mode Rust masks the shift amount */
                     ++n_applied;
                 }
             }

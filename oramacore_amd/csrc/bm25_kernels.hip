@@ -1,0 +1,314 @@
+// bm25_kernels.hip — K3: postings accumulate → BM25F finalise; K5: hybrid min-max combine.
+//
+// Compiled with -ffp-contract=off: every f32 operation below rounds once, in the order the
+// reference's scalar Rust evaluates it, so scores are bit-identical to the CPU restatement
+// (idf comes from the host's libm log1pf — the function Rust's f32::ln_1p lowers to — through a
+// table or a per-token array, never from the device math library).
+//
+// Data flow per query (all HBM-resident, no host round trip in the resident mode):
+//   accumulate (one launch per entry rank; rank-0 covers every token's first posting list):
+//       for each posting (doc, tf|len) of each (token, list) reference, coalesced 2 x 4-byte loads,
+//       S[token][doc] (+)= boost * tf / (1 - b + b*len/avglen); first touch of (token, doc) bumps
+//       df[token]; first touch of doc appends it to the touched list.  Inside one launch a
+//       (token, doc) cell is written by at most one thread (docs are unique inside a list), so the
+//       f32 accumulation order across a token's lists is the list order — deterministic, no atomics
+//       on the accumulators.
+//   finalise: one thread per touched doc walks the tokens IN ORDER:
+//       score += idf_t * (k+1) * S / (k+S)  (skipped unless S.is_normal(), bm25.rs:387/501),
+//       token mask, threshold filter (bm25.rs:416-428), OMC multiply (search.rs:39-48), and emits
+//       the doc into the candidate list = the score map (its length is `count`, search.rs:482).
+//   [hybrid] normalise / add vector scores / OMC on the candidate list (token_score.rs:393-422).
+//   K4 top-k over the candidate list.
+// Roofline: HBM (gather/scatter): algorithmic bytes = 8 B per posting + 4 B per touched doc.
+#include "bm25_kernels.hpp"
+
+#include "device_utils.hpp"
+
+namespace orama {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ bool f32_is_normal(float x) {
+    const uint32_t e = (__builtin_bit_cast(uint32_t, x) >> 23) & 0xffu;
+    return e != 0u && e != 0xffu;
+}
+
+template <bool PRE>
+__global__ __launch_bounds__(kThreads) void bm25_accumulate_kernel(Bm25Accum a) {
+    __shared__ Bm25Seg segs[kMaxTokens];
+    __shared__ uint32_t df_lds[kMaxTokens];
+    for (uint32_t i = threadIdx.x; i < a.n_segs; i += kThreads) segs[i] = a.segs[i];
+    for (uint32_t i = threadIdx.x; i < kMaxTokens; i += kThreads) df_lds[i] = 0;
+    __syncthreads();
+    const float one_minus_b = 1.0f - a.b;
+    for (uint64_t v = (uint64_t)blockIdx.x * kThreads + threadIdx.x; v < a.total;
+         v += (uint64_t)gridDim.x * kThreads) {
+        // segment lookup: segs are sorted by virt_begin (<= 64 entries)
+        uint32_t lo = 0, hi = a.n_segs;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (segs[mid].virt_begin <= v) lo = mid; else hi = mid;
+        }
+        const Bm25Seg& s = segs[lo];
+        const uint64_t p = s.post_begin + (v - s.virt_begin);
+        const uint32_t doc = a.post_doc[p];
+        const uint32_t val = a.post_val[p];
+        if (a.allow) {  // collect_contributions_with_filter: filtered docs never reach the scorer
+            const uint64_t id = a.docs[doc];
+            if (id >= a.allow_bits || !((a.allow[id >> 6] >> (id & 63)) & 1ull)) continue;
+        }
+        float ntf;
+        if (PRE) {
+            ntf = __builtin_bit_cast(float, val);
+        } else {
+            const float tf = (float)(val >> 16);
+            const float len = (float)(val & 0xffffu);
+            ntf = s.boost * (tf / (one_minus_b + a.b * (len / s.avg_len)));
+        }
+        unsigned long long* w = a.acc + (uint64_t)s.token * a.n_docs + doc;
+        const unsigned long long old = *w;
+        float sum;
+        if ((uint32_t)(old >> 32) != a.epoch) {
+            sum = 0.0f + 1.0f * ntf;  // Iterator::sum() from 0.0, weight = 1.0
+            atomicAdd(&df_lds[s.token], 1u);
+            if (atomicExch(&a.seen[doc], a.epoch) != a.epoch) {
+                const uint32_t pos = atomicAdd(&a.state->touched_count, 1u);
+                a.touched[pos] = doc;
+            }
+        } else {
+            sum = __builtin_bit_cast(float, (uint32_t)old) + 1.0f * ntf;
+        }
+        *w = ((unsigned long long)a.epoch << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, sum);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kMaxTokens; i += kThreads)
+        if (df_lds[i]) atomicAdd(&a.state->df[i], df_lds[i]);
+}
+
+template <bool TRACK_MINMAX>
+__global__ __launch_bounds__(kThreads) void bm25_finalize_kernel(Bm25Finalize f) {
+    __shared__ float idf[kMaxTokens];
+    for (uint32_t t = threadIdx.x; t < f.n_tokens; t += kThreads) {
+        if (f.idf_table) {
+            uint32_t df = f.state->df[t];
+            if (df < 1) df = 1;  // corpus_docs.len().max(1), token_score.rs:275
+            idf[t] = f.idf_table[df];
+        } else {
+            idf[t] = f.idf_vals[t];
+        }
+    }
+    __syncthreads();
+    const uint32_t n = f.state->touched_count;
+    const float k1 = f.k + 1.0f;
+    uint32_t my_max = 0u, my_min = 0xffffffffu;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const uint32_t doc = f.touched[i];
+        float score = 0.0f;  // entry(key).or_insert(0.0)
+        uint32_t mask = 0u;
+        bool applied = false;
+        for (uint32_t t = 0; t < f.n_tokens; ++t) {
+            const unsigned long long w = f.acc[(uint64_t)t * f.n_docs + doc];
+            if ((uint32_t)(w >> 32) != f.epoch) continue;
+            const float s = __builtin_bit_cast(float, (uint32_t)w);
+            if (!f32_is_normal(s)) continue;
+            const float term = idf[t] * k1 * s / (f.k + s);  // bm25f_score, bm25.rs:124-126
+            if (term != term) continue;
+            score = score + term * 1.0f;  // phrase boost 1.0
+            mask |= 1u << (t & 31u);      // 1 << term_index on u32 (wrapping shift)
+            applied = true;
+        }
+        if (!applied) continue;
+        if (f.use_threshold && (uint32_t)__popc(mask) < f.threshold) continue;
+        if (f.omc_dense) score = score * f.omc_dense[doc];
+        const uint32_t pos = atomicAdd(&f.state->cand_count, 1u);
+        f.cand_score[pos] = score;
+        f.cand_idx[pos] = doc;
+        f.emit[doc] = ((unsigned long long)f.epoch << 32) | (unsigned long long)pos;
+        if (TRACK_MINMAX && score == score) {
+            const uint32_t key = f32_to_ordered(score);
+            my_max = max(my_max, key);
+            my_min = min(my_min, key);
+        }
+    }
+    if (TRACK_MINMAX) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, off, 64));
+            my_min = min(my_min, (uint32_t)__shfl_xor((int)my_min, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (my_max != 0u) atomicMax(&f.state->max_key, my_max);
+            if (my_min != 0xffffffffu) atomicMin(&f.state->min_key, my_min);
+        }
+    }
+}
+
+// fold(0.0, f32::max) / fold(0.0, f32::min) over both maps — token_score.rs:398-401
+__device__ __forceinline__ void hybrid_min_max(const HybridCombine& h, float& mn, float& mx) {
+    mx = 0.0f;
+    mn = 0.0f;
+    if (h.vec_max > mx) mx = h.vec_max;
+    if (h.vec_min < mn) mn = h.vec_min;
+    const uint32_t kmax = h.state->max_key, kmin = h.state->min_key;
+    if (kmax != 0u) {
+        const float v = ordered_to_f32(kmax);
+        if (v > mx) mx = v;
+    }
+    if (kmin != 0xffffffffu) {
+        const float v = ordered_to_f32(kmin);
+        if (v < mn) mn = v;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void hybrid_normalize_kernel(HybridCombine h) {
+    float mn, mx;
+    hybrid_min_max(h, mn, mx);
+    const float den = mx - mn;
+    const uint32_t n = h.state->cand_count;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
+        h.cand_score[i] = (h.cand_score[i] - mn) / den;
+}
+
+__global__ __launch_bounds__(kThreads) void hybrid_add_vector_kernel(HybridCombine h) {
+    float mn, mx;
+    hybrid_min_max(h, mn, mx);
+    const float den = mx - mn;
+    for (uint32_t j = blockIdx.x * kThreads + threadIdx.x; j < h.n_vec; j += gridDim.x * kThreads) {
+        const uint32_t doc = h.vec_idx[j];
+        const float v = (h.vec_score[j] - mn) / den;
+        const unsigned long long e = h.emit[doc];
+        if ((uint32_t)(e >> 32) == h.epoch) {
+            const uint32_t pos = (uint32_t)e;
+            h.cand_score[pos] = h.cand_score[pos] + v;  // *e += v
+        } else {
+            const uint32_t pos = atomicAdd(&h.state->cand_count, 1u);
+            h.cand_score[pos] = 0.0f + v;  // entry(k).or_default() += v
+            h.cand_idx[pos] = doc;
+            h.emit[doc] = ((unsigned long long)h.epoch << 32) | (unsigned long long)pos;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void hybrid_ingest_kernel(uint32_t n, uint32_t epoch,
+                                                                 const uint32_t* __restrict__ cand_idx,
+                                                                 const float* __restrict__ cand_score,
+                                                                 unsigned long long* __restrict__ emit,
+                                                                 Bm25State* state) {
+    uint32_t my_max = 0u, my_min = 0xffffffffu;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        emit[cand_idx[i]] = ((unsigned long long)epoch << 32) | (unsigned long long)i;
+        const float s = cand_score[i];
+        if (s == s) {
+            const uint32_t key = f32_to_ordered(s);
+            my_max = max(my_max, key);
+            my_min = min(my_min, key);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, off, 64));
+        my_min = min(my_min, (uint32_t)__shfl_xor((int)my_min, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (my_max != 0u) atomicMax(&state->max_key, my_max);
+        if (my_min != 0xffffffffu) atomicMin(&state->min_key, my_min);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) state->cand_count = n;
+}
+
+__global__ __launch_bounds__(kThreads) void omc_dense_kernel(const float* __restrict__ omc,
+                                                             const Bm25State* __restrict__ state,
+                                                             const uint32_t* __restrict__ cand_idx,
+                                                             float* __restrict__ cand_score) {
+    const uint32_t n = state->cand_count;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
+        cand_score[i] = cand_score[i] * omc[cand_idx[i]];
+}
+
+__global__ __launch_bounds__(kThreads) void omc_sparse_kernel(const uint32_t* __restrict__ idx,
+                                                              const float* __restrict__ mul, uint32_t n,
+                                                              uint32_t epoch,
+                                                              const unsigned long long* __restrict__ emit,
+                                                              float* __restrict__ cand_score) {
+    for (uint32_t j = blockIdx.x * kThreads + threadIdx.x; j < n; j += gridDim.x * kThreads) {
+        const unsigned long long e = emit[idx[j]];
+        if ((uint32_t)(e >> 32) == epoch) {
+            const uint32_t pos = (uint32_t)e;
+            cand_score[pos] = cand_score[pos] * mul[j];
+        }
+    }
+}
+
+uint32_t grid_for(uint64_t items, orama_ctx* ctx, uint32_t per_thread = 4) {
+    uint64_t blocks = (items + (uint64_t)kThreads * per_thread - 1) / ((uint64_t)kThreads * per_thread);
+    const uint64_t cap = (uint64_t)ctx->compute_units * 8u;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (uint32_t)blocks;
+}
+
+}  // namespace
+
+int launch_bm25_accumulate(orama_ctx* ctx, const Bm25Accum& a, hipStream_t stream) {
+    if (a.total == 0 || a.n_segs == 0) return ORAMA_OK;
+    ORAMA_REQUIRE(a.n_segs <= kMaxTokens, "bm25: too many segments in one launch");
+    ProfScope prof(&ctx->prof, "bm25_accumulate", stream);
+    const dim3 grid(grid_for(a.total, ctx));
+    if (a.precomputed)
+        hipLaunchKernelGGL(bm25_accumulate_kernel<true>, grid, dim3(kThreads), 0, stream, a);
+    else
+        hipLaunchKernelGGL(bm25_accumulate_kernel<false>, grid, dim3(kThreads), 0, stream, a);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_bm25_finalize(orama_ctx* ctx, const Bm25Finalize& f, hipStream_t stream) {
+    ORAMA_REQUIRE(f.n_tokens >= 1 && f.n_tokens <= kMaxTokens, "bm25: n_tokens %u outside [1, %u]",
+                  f.n_tokens, kMaxTokens);
+    ORAMA_REQUIRE(f.idf_table || f.idf_vals, "bm25: idf source missing");
+    ProfScope prof(&ctx->prof, "bm25_finalize", stream);
+    const dim3 grid(grid_for(f.touched_cap ? f.touched_cap : 1, ctx, 1));
+    if (f.track_minmax)
+        hipLaunchKernelGGL(bm25_finalize_kernel<true>, grid, dim3(kThreads), 0, stream, f);
+    else
+        hipLaunchKernelGGL(bm25_finalize_kernel<false>, grid, dim3(kThreads), 0, stream, f);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_hybrid_ingest(orama_ctx* ctx, uint32_t n, uint32_t epoch, const uint32_t* cand_idx,
+                         const float* cand_score, unsigned long long* emit, Bm25State* state,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(hybrid_ingest_kernel, dim3(grid_for(n ? n : 1, ctx, 1)), dim3(kThreads), 0, stream, n,
+                       epoch, cand_idx, cand_score, emit, state);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_hybrid_combine(orama_ctx* ctx, const HybridCombine& h, hipStream_t stream) {
+    hipLaunchKernelGGL(hybrid_normalize_kernel, dim3(grid_for(h.cand_cap ? h.cand_cap : 1, ctx, 1)),
+                       dim3(kThreads), 0, stream, h);
+    if (h.n_vec)
+        hipLaunchKernelGGL(hybrid_add_vector_kernel, dim3(grid_for(h.n_vec, ctx, 1)), dim3(kThreads), 0,
+                           stream, h);
+    if (h.omc_dense)
+        hipLaunchKernelGGL(omc_dense_kernel, dim3(grid_for(h.cand_cap + h.n_vec, ctx, 1)), dim3(kThreads),
+                           0, stream, h.omc_dense, h.state, h.cand_idx, h.cand_score);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_omc_sparse(const uint32_t* d_idx, const float* d_mul, uint32_t n, uint32_t epoch,
+                      const unsigned long long* emit, float* cand_score, hipStream_t stream) {
+    if (n == 0) return ORAMA_OK;
+    uint32_t blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(omc_sparse_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_idx, d_mul, n, epoch,
+                       emit, cand_score);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+}  // namespace orama

@@ -1,0 +1,103 @@
+// bm25_kernels.hpp — K3 (postings accumulate → BM25F finalise) and K5 (hybrid min-max combine).
+// Device side of search_full_text / BM25Scorer / normalize_and_combine:
+//   src/collection_manager/sides/read/index/token_score.rs:257-302, 393-422
+//   src/collection_manager/bm25.rs:369-428, 484-524
+#pragma once
+
+#include "common.hpp"
+
+namespace orama {
+
+constexpr uint32_t kMaxTokens = 64;  // query tokens per search (mask bit = 1 << (t % 32), see below)
+
+// One (token, posting list) reference processed by the accumulate kernel.
+struct Bm25Seg {
+    uint64_t post_begin;  // first posting of the list inside the postings arrays
+    uint64_t virt_begin;  // first virtual index of this segment inside its launch
+    uint32_t len;
+    uint32_t token;
+    float boost;   // SearchParams.boost of the field (resident mode)
+    float inv_avg_unused;
+    float avg_len; // field average length (resident mode)
+    uint32_t pad;
+};
+
+// Query-scoped device state (zeroed per query with one memset).
+struct Bm25State {
+    uint32_t df[kMaxTokens];   // distinct docs per token (corpus_docs.len(), token_score.rs:262-275)
+    uint32_t touched_count;    // docs touched by any token
+    uint32_t cand_count;       // docs in the score map (== `count`, search.rs:482)
+    uint32_t max_key;          // ordered(max score) over non-NaN candidates, 0 if none
+    uint32_t min_key;          // ordered(min score), 0xffffffff if none
+};
+
+struct Bm25Accum {
+    // postings: word0 = local doc index; word1 = (tf << 16 | field_len) [resident] or f32 ntf bits [PRE]
+    const uint32_t* post_doc = nullptr;
+    const uint32_t* post_val = nullptr;
+    const Bm25Seg* segs = nullptr;  // segments of THIS launch (device)
+    uint32_t n_segs = 0;
+    uint64_t total = 0;             // virtual postings in this launch
+    bool precomputed = false;       // post_val holds ntf
+    float b = 0.75f;                // Bm25Params::default().b
+    const uint64_t* docs = nullptr;   // local idx -> DocumentId (needed with `allow`)
+    const uint64_t* allow = nullptr;  // nullable bitmap over DocumentIds
+    uint64_t allow_bits = 0;
+    uint32_t epoch = 0;
+    uint64_t n_docs = 0;
+    unsigned long long* acc = nullptr;  // [n_tokens][n_docs] {epoch:32 | S:f32}
+    uint32_t* seen = nullptr;           // [n_docs] epoch of the last query that touched the doc
+    uint32_t* touched = nullptr;        // list of touched local docs
+    Bm25State* state = nullptr;
+};
+int launch_bm25_accumulate(orama_ctx* ctx, const Bm25Accum& a, hipStream_t stream);
+
+struct Bm25Finalize {
+    uint32_t n_tokens = 0;
+    float k = 1.2f;
+    const float* idf_table = nullptr;  // nullable: idf[df] for df in [0, n_docs]
+    const float* idf_vals = nullptr;   // else: idf per token (device, n_tokens)
+    bool use_threshold = false;
+    uint32_t threshold = 0;
+    bool track_minmax = false;         // hybrid: reduce min/max of the emitted scores into `state`
+    const float* omc_dense = nullptr;  // nullable: multiplier per local doc (applied to the final score)
+    uint32_t epoch = 0;
+    uint64_t n_docs = 0;
+    const unsigned long long* acc = nullptr;
+    const uint32_t* touched = nullptr;
+    uint32_t touched_cap = 0;          // host-side upper bound of touched_count (grid sizing)
+    Bm25State* state = nullptr;
+    // outputs: the score map as a candidate list + dense position index
+    float* cand_score = nullptr;
+    uint32_t* cand_idx = nullptr;
+    unsigned long long* emit = nullptr;  // [n_docs] {epoch:32 | position:32} for docs in the map
+};
+int launch_bm25_finalize(orama_ctx* ctx, const Bm25Finalize& f, hipStream_t stream);
+
+// K5 — normalize_and_combine on the candidate list (token_score.rs:393-422).
+struct HybridCombine {
+    float vec_min = 0.0f, vec_max = 0.0f;  // fold(0.0, min/max) over the vector map (host, <= k entries)
+    const uint32_t* vec_idx = nullptr;     // local doc of each vector entry (device)
+    const float* vec_score = nullptr;
+    uint32_t n_vec = 0;
+    const float* omc_dense = nullptr;      // nullable, applied after the combine (search.rs:342-343)
+    uint32_t epoch = 0;
+    uint32_t cand_cap = 0;
+    Bm25State* state = nullptr;
+    float* cand_score = nullptr;
+    uint32_t* cand_idx = nullptr;
+    unsigned long long* emit = nullptr;
+};
+int launch_hybrid_combine(orama_ctx* ctx, const HybridCombine& h, hipStream_t stream);
+
+// Register an uploaded (idx, score) list as the candidate list (standalone orama_hybrid_combine):
+// fills `emit`, cand_count and the min/max keys.
+int launch_hybrid_ingest(orama_ctx* ctx, uint32_t n, uint32_t epoch, const uint32_t* cand_idx,
+                         const float* cand_score, unsigned long long* emit, Bm25State* state,
+                         hipStream_t stream);
+
+// Sparse OMC multiply (seam i): for each (local doc, multiplier): score[pos(doc)] *= multiplier.
+int launch_omc_sparse(const uint32_t* d_idx, const float* d_mul, uint32_t n, uint32_t epoch,
+                      const unsigned long long* emit, float* cand_score, hipStream_t stream);
+
+}  // namespace orama

@@ -144,6 +144,9 @@ struct Scratch {
     DevBuf bitmap;     // uploaded allow bitmap
     DevBuf misc0, misc1, misc2, misc3, misc4, misc5;
     PinnedBuf h_in, h_out, h_misc;
+    // BM25 accumulators: epoch-stamped, zeroed only when (re)allocated (see bm25_kernels.hip)
+    DevBuf bm25_acc, bm25_seen, bm25_emit;
+    uint32_t bm25_epoch = 0;
     ~Scratch() {
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -154,7 +157,7 @@ struct Scratch {
 namespace orama {
 struct ScanTuning {
     int rows_per_wave = 4;  // rows each wave keeps in flight per iteration (1, 2, 4, 8)
-    int blocks_per_cu = 8;  // persistent grid = CUs x this
+    int blocks_per_cu = 2;  // persistent grid = CUs x this (measured best on MI355X: profiles/r01_sweep_ns_v1.json)
     int nontemporal = 1;    // stream the corpus with `nt` loads
 };
 }  // namespace orama

@@ -1,0 +1,270 @@
+"""Host-side mirror of the reference's full-text / hybrid scoring interfaces over the C ABI.
+
+Reference interfaces mirrored (names, argument meaning, error behaviour):
+  * `BM25Scorer` — src/collection_manager/bm25.rs:135-323 (plain / with_threshold, add_precomputed_field,
+    finalize_term, get_scores).  The reference scores on the CPU while contributions are added; here the
+    calls only record the contributions and `get_scores()/top_n()` runs K3 (+K4) on the GPU through
+    `orama_bm25_score`.
+  * `normalize_and_combine` — token_score.rs:393-422  → `orama_hybrid_combine`
+  * `top_n` — sort.rs:260-279                          → `orama_top_n`
+  * `PostingsStore` — the HBM-resident replacement of what `StringFieldStorage`
+    (index/string_field.rs) holds, searched with `search_full_text` / `search_hybrid`
+    (token_score.rs:186-303, 357-387) semantics through `orama_post_search[_hybrid]`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _native as N
+from .context import Context
+from .embedding_field import AllowBitmap
+
+K1_DEFAULT = 1.2  # token_score.rs:283
+B_DEFAULT = 0.75  # Bm25Params::default()
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _params(total_documents: float, n_tokens: int, threshold, top_k: int, k: float = K1_DEFAULT) -> N.Bm25Params:
+    p = N.Bm25Params()
+    p.total_documents = float(total_documents)
+    p.k = float(k)
+    p.n_tokens = int(n_tokens)
+    p.use_threshold = 0 if threshold is None else 1
+    p.threshold = 0 if threshold is None else int(threshold)
+    p.top_k = int(top_k)
+    return p
+
+
+def threshold_tokens(n_tokens: int, threshold: float) -> int:
+    """token_score.rs:213-214 — floor(tokens.len() as f32 * threshold) as u32."""
+    return int(np.floor(np.float32(n_tokens) * np.float32(threshold)))
+
+
+def bm25_score(ctx: Context, entries, n_tokens: int, total_documents: float, top_k: int, threshold=None,
+               omc: dict | None = None, k: float = K1_DEFAULT):
+    """Seam (i). entries: list of (token, doc_ids, ntf). Returns (ids, scores, count)."""
+    lib = N.load()
+    keep = []
+    arr = (N.NtfEntry * max(len(entries), 1))()
+    for i, (tok, docs, ntf) in enumerate(entries):
+        docs, ntf = _u64(docs), _f32(ntf)
+        keep.append((docs, ntf))
+        arr[i].token = int(tok)
+        arr[i].doc = docs.ctypes.data_as(C.POINTER(C.c_uint64))
+        arr[i].ntf = ntf.ctypes.data_as(C.POINTER(C.c_float))
+        arr[i].len = docs.shape[0]
+    params = _params(total_documents, n_tokens, threshold, top_k, k)
+    out_ids = np.zeros(max(top_k, 1), dtype=np.uint64)
+    out_sc = np.zeros(max(top_k, 1), dtype=np.float32)
+    out_n = C.c_uint32()
+    out_count = C.c_uint64()
+    omc_doc = omc_mul = None
+    n_omc = 0
+    if omc:
+        items = sorted(omc.items())
+        omc_doc = _u64([d for d, _ in items])
+        omc_mul = _f32([m for _, m in items])
+        n_omc = len(items)
+    N.check(lib.orama_bm25_score(ctx.handle, arr, len(entries), C.byref(params),
+                                 omc_doc.ctypes.data if n_omc else None, omc_mul.ctypes.data if n_omc else None,
+                                 n_omc, out_ids.ctypes.data, out_sc.ctypes.data, C.byref(out_n), C.byref(out_count)))
+    return out_ids[: out_n.value], out_sc[: out_n.value], out_count.value
+
+
+def hybrid_combine(ctx: Context, vector: dict, fulltext: dict, top_k: int):
+    """normalize_and_combine (token_score.rs:393-422) + count + top_n. Returns (ids, scores, count)."""
+    lib = N.load()
+    v_doc, v_sc = _u64(list(vector.keys())), _f32(list(vector.values()))
+    f_doc, f_sc = _u64(list(fulltext.keys())), _f32(list(fulltext.values()))
+    out_ids = np.zeros(max(top_k, 1), dtype=np.uint64)
+    out_sc = np.zeros(max(top_k, 1), dtype=np.float32)
+    out_n = C.c_uint32()
+    out_count = C.c_uint64()
+    N.check(lib.orama_hybrid_combine(ctx.handle, v_doc.ctypes.data, v_sc.ctypes.data, v_doc.shape[0],
+                                     f_doc.ctypes.data, f_sc.ctypes.data, f_doc.shape[0], top_k,
+                                     out_ids.ctypes.data, out_sc.ctypes.data, C.byref(out_n), C.byref(out_count)))
+    return out_ids[: out_n.value], out_sc[: out_n.value], out_count.value
+
+
+def top_n(ctx: Context, token_scores: dict | tuple, n: int):
+    """sort.rs:260-279 over a {DocumentId: score} map (or a (docs, scores) pair)."""
+    lib = N.load()
+    if isinstance(token_scores, dict):
+        doc, sc = _u64(list(token_scores.keys())), _f32(list(token_scores.values()))
+    else:
+        doc, sc = _u64(token_scores[0]), _f32(token_scores[1])
+    out_ids = np.zeros(max(n, 1), dtype=np.uint64)
+    out_sc = np.zeros(max(n, 1), dtype=np.float32)
+    out_n = C.c_uint32()
+    N.check(lib.orama_top_n(ctx.handle, doc.ctypes.data, sc.ctypes.data, doc.shape[0], n, out_ids.ctypes.data,
+                            out_sc.ctypes.data, C.byref(out_n)))
+    return out_ids[: out_n.value], out_sc[: out_n.value]
+
+
+class BM25Scorer:
+    """Mirror of bm25.rs `BM25Scorer<K>` restricted to the calls search_full_text makes
+    (token_score.rs:211-302): plain()/with_threshold(), reset_term(), add_precomputed_field(),
+    finalize_term[_plain](), next_term(), get_scores()."""
+
+    def __init__(self, ctx: Context, threshold: int | None):
+        self.ctx = ctx
+        self.threshold = threshold
+        self._entries = []      # finalised (token, docs, ntf*weight)
+        self._cur_docs, self._cur_ntf = [], []
+        self._term_index = 0
+        self._finalized = []    # (df, total_documents, k) per term, as passed by the caller
+
+    @classmethod
+    def plain(cls, ctx: Context) -> "BM25Scorer":
+        return cls(ctx, None)
+
+    @classmethod
+    def with_threshold(cls, ctx: Context, threshold: int) -> "BM25Scorer":
+        return cls(ctx, int(threshold))
+
+    def reset_term(self) -> None:
+        self._cur_docs, self._cur_ntf = [], []
+
+    def add_precomputed_field(self, key: int, normalized_tf, weight=1.0) -> None:
+        self._cur_docs.append(int(key))
+        self._cur_ntf.append(np.float32(np.float32(weight) * np.float32(normalized_tf)))
+
+    def current_term_document_count(self) -> int:
+        return len(set(self._cur_docs))
+
+    def finalize_term(self, corpus_term_frequency: int, total_documents: float, k: float, phrase_boost: float = 1.0,
+                      token_indexes: int = 0) -> None:
+        if phrase_boost != 1.0:
+            raise N.OramaError(N.ORAMA_ERR_UNSUPPORTED, "phrase_boost != 1.0 (the reference always passes 1.0)")
+        # One entry per field push: a doc may appear several times inside a term (one per field); split the
+        # stream into runs with unique docs so that each run is a valid posting-list entry, in push order.
+        runs, seen = [], set()
+        cur_d, cur_v = [], []
+        for d, v in zip(self._cur_docs, self._cur_ntf):
+            if d in seen:
+                runs.append((cur_d, cur_v))
+                cur_d, cur_v, seen = [], [], set()
+            seen.add(d)
+            cur_d.append(d)
+            cur_v.append(v)
+        runs.append((cur_d, cur_v))
+        for d, v in runs:
+            self._entries.append((self._term_index, d, v))
+        self._finalized.append((corpus_term_frequency, float(total_documents), float(k)))
+
+    finalize_term_plain = finalize_term
+
+    def next_term(self) -> None:
+        self._term_index += 1
+        self.reset_term()
+
+    def _n_tokens(self) -> int:
+        return max(self._term_index, len(self._finalized), 1)
+
+    def top_n(self, n: int, omc: dict | None = None):
+        """get_scores() + apply_omc_multipliers + count + top_n in one GPU pass."""
+        total_documents = self._finalized[0][1] if self._finalized else 1.0
+        k = self._finalized[0][2] if self._finalized else K1_DEFAULT
+        return bm25_score(self.ctx, self._entries, self._n_tokens(), total_documents, n, self.threshold, omc, k)
+
+    def get_scores(self) -> dict:
+        total = sum(len(e[1]) for e in self._entries)
+        ids, sc, count = self.top_n(min(max(total, 1), 4096))
+        if count > len(ids):
+            raise N.OramaError(N.ORAMA_ERR_UNSUPPORTED, "get_scores(): map larger than 4096 entries; use top_n()")
+        return {int(d): np.float32(s) for d, s in zip(ids, sc)}
+
+
+@dataclass
+class PostingList:
+    field: int
+    docs: np.ndarray   # DocumentIds ascending
+    tf: np.ndarray
+    field_len: np.ndarray
+
+
+class PostingsStore:
+    """HBM-resident postings of one index (seam ii)."""
+
+    def __init__(self, ctx: Context):
+        self._lib = N.load()
+        self.ctx = ctx
+        h = C.c_void_p()
+        N.check(self._lib.orama_post_create(ctx.handle, C.byref(h)))
+        self._h = h
+        self.n_docs = 0
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.orama_post_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def build(self, docs, avg_field_len, lists: list[PostingList]) -> None:
+        docs = _u64(docs)
+        avg = _f32(avg_field_len)
+        n_lists = len(lists)
+        fol = np.ascontiguousarray([l.field for l in lists], dtype=np.uint32)
+        off = np.zeros(n_lists + 1, dtype=np.uint64)
+        for i, l in enumerate(lists):
+            off[i + 1] = off[i] + np.uint64(len(l.docs))
+        if n_lists:
+            pdoc = _u64(np.concatenate([_u64(l.docs) for l in lists]))
+            ptf = np.ascontiguousarray(np.concatenate([np.asarray(l.tf) for l in lists]), dtype=np.uint32)
+            plen = np.ascontiguousarray(np.concatenate([np.asarray(l.field_len) for l in lists]), dtype=np.uint32)
+        else:
+            pdoc, ptf, plen = _u64([]), np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+        N.check(self._lib.orama_post_build(self._h, docs.ctypes.data, docs.shape[0], avg.shape[0], avg.ctypes.data,
+                                           n_lists, fol.ctypes.data, off.ctypes.data, pdoc.ctypes.data,
+                                           ptf.ctypes.data, plen.ctypes.data))
+        self.n_docs = int(docs.shape[0])
+
+    def set_omc(self, omc: dict) -> None:
+        items = sorted(omc.items())
+        d, m = _u64([x for x, _ in items]), _f32([y for _, y in items])
+        N.check(self._lib.orama_post_set_omc(self._h, d.ctypes.data, m.ctypes.data, len(items)))
+
+    def _refs(self, refs):
+        arr = (N.TermRef * max(len(refs), 1))()
+        for i, (tok, lst, boost) in enumerate(refs):
+            arr[i].token, arr[i].list, arr[i].boost = int(tok), int(lst), float(boost)
+        return arr
+
+    def search(self, refs, n_tokens: int, total_documents: float, top_k: int, threshold=None,
+               allow: AllowBitmap | None = None, apply_omc: bool = True, b: float = B_DEFAULT,
+               k: float = K1_DEFAULT, vector: dict | None = None):
+        """refs: list of (token, list, boost). With `vector` (the map after the a2 epilogue) runs the hybrid
+        combine. Returns (ids, scores, count)."""
+        arr = self._refs(refs)
+        params = _params(total_documents, n_tokens, threshold, top_k, k)
+        out_ids = np.zeros(max(top_k, 1), dtype=np.uint64)
+        out_sc = np.zeros(max(top_k, 1), dtype=np.float32)
+        out_n = C.c_uint32()
+        out_count = C.c_uint64()
+        bm_ptr, bm_bits = (allow.words.ctypes.data, allow.n_bits) if allow is not None else (None, 0)
+        if vector is None:
+            N.check(self._lib.orama_post_search(self._h, arr, len(refs), b, C.byref(params), bm_ptr, bm_bits,
+                                                1 if apply_omc else 0, out_ids.ctypes.data, out_sc.ctypes.data,
+                                                C.byref(out_n), C.byref(out_count)))
+        else:
+            v_doc, v_sc = _u64(list(vector.keys())), _f32(list(vector.values()))
+            N.check(self._lib.orama_post_search_hybrid(self._h, arr, len(refs), b, C.byref(params), bm_ptr, bm_bits,
+                                                       v_doc.ctypes.data, v_sc.ctypes.data, v_doc.shape[0],
+                                                       1 if apply_omc else 0, out_ids.ctypes.data,
+                                                       out_sc.ctypes.data, C.byref(out_n), C.byref(out_count)))
+        return out_ids[: out_n.value], out_sc[: out_n.value], out_count.value

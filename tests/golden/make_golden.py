@@ -139,7 +139,7 @@ def search_full_text(entries, n_tokens, n_docs, k=1.2, threshold=None):
             if np.isnan(ts):
                 continue
             scores[d] = F(scores.get(d, F(0.0)) + F(ts * F(1.0)))
-            masks[d] = masks.get(d, 0) | ((1 << t) & 0xFFFFFFFF)
+            masks[d] = masks.get(d, 0) | (1 << (t % 32))  # u32 shift, amount masked (release-mode Rust)
     if threshold is not None:
         scores = {d: s for d, s in scores.items() if bin(masks[d]).count("1") >= threshold}
     return scores

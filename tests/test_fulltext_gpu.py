@@ -1,0 +1,274 @@
+"""GPU parity of the BM25F path (K3 + K4) and the hybrid combine (K5) through the C ABI.
+
+Bar (north_star): bit-exact docID ordering and scores for pure BM25 — the HIP path must reproduce the
+oracle's f32 arithmetic exactly (same operation order, libm idf), not approximately.
+"""
+import numpy as np
+import pytest
+
+import oramacore_amd as oa
+import util
+from oracle import oracle as orc
+from oramacore_amd import fulltext as ft
+from test_oracle_golden import bm25_synth_entries
+
+pytestmark = pytest.mark.gpu
+
+F = np.float32
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def oracle_topk(entries, n_tokens, n_docs, top_k, threshold=None, omc=None):
+    docs, scores = orc.search_full_text(entries, n_tokens, float(n_docs), 1.2, threshold)
+    if omc:
+        scores = orc.apply_omc(docs, scores, list(omc), list(omc.values()))
+    td, ts = orc.top_n(docs, scores, top_k)
+    return td, ts, len(docs)
+
+
+# ----------------------------------------------------------------------------- reference known answers
+def test_reference_kat_two_fields_through_scorer_mirror(ctx):
+    """bm25.rs:911-983 (test_canonical_bm25f_single_term_two_fields) driven through the BM25Scorer mirror:
+    expected value from the reference test body, tolerance 1e-5 as in the reference; and bit-equal to the oracle."""
+    case = [c for c in util.load_json("bm25_kat.json")["cases"]
+            if c["name"] == "test_canonical_bm25f_single_term_two_fields"][0]
+    f0, f1 = case["fields"]
+    scorer = ft.BM25Scorer.plain(ctx)
+    scorer.reset_term()
+    # the in-tree caller derives df from the postings (token_score.rs:262-275): 10 docs hold the term
+    for d in range(1, 11):
+        scorer.add_precomputed_field(d, orc.bm25f_normalized_tf(f0["tf"], f0["len"], f0["avglen"], f0["b"]), f0["weight"])
+    scorer.add_precomputed_field(1, orc.bm25f_normalized_tf(f1["tf"], f1["len"], f1["avglen"], f1["b"]), f1["weight"])
+    scorer.finalize_term_plain(10, 100.0, 1.2, 1.0)
+    scorer.next_term()
+    scores = scorer.get_scores()
+    assert len(scores) == 10
+    assert abs(float(scores[1]) - case["expect"]["1"]) <= case["tol"]
+    n0 = F(F(f0["weight"]) * orc.bm25f_normalized_tf(f0["tf"], f0["len"], f0["avglen"], f0["b"]))
+    n1 = F(F(f1["weight"]) * orc.bm25f_normalized_tf(f1["tf"], f1["len"], f1["avglen"], f1["b"]))
+    od, os_ = orc.search_full_text([(0, list(range(1, 11)), [n0] * 10), (0, [1], [n1])], 1, 100.0)
+    assert {int(d): int(bits([s])[0]) for d, s in zip(od, os_)} == {d: int(bits([s])[0]) for d, s in scores.items()}
+
+
+def test_reference_kat_basic_legacy_formula(ctx):
+    """bm25.rs:533-563: single field, tf=5, len=avglen=100, N=100, df=10 → idf*(k+1)*5/(k+5) within 1e-6."""
+    case = util.load_json("bm25_kat.json")["cases"][0]
+    a = case["adds"][0]
+    ntf = orc.bm25f_normalized_tf(a["tf"], a["len"], a["avglen"], a["b"])
+    ids, sc, count = ft.bm25_score(ctx, [(0, list(range(1, 11)), [ntf] * 10)], 1, a["total_docs"], 10)
+    assert count == 10 and ids.tolist() == list(range(1, 11))  # equal scores → doc id ascending
+    assert abs(float(sc[0]) - case["expect"]["1"]) <= case["tol"]
+    assert len(set(bits(sc).tolist())) == 1
+
+
+# ----------------------------------------------------------------------------- synthetic corpus, both seams
+@pytest.fixture(scope="module")
+def synth():
+    meta = util.load_json("bm25_synth.json")
+    fields = util.mg.zipf_corpus(meta["n_docs"], meta["vocab"], meta["n_fields"], seed=meta["seed"])
+    doc_ids = np.arange(meta["n_docs"], dtype=np.uint64) * np.uint64(meta["doc_id_mul"]) + np.uint64(meta["doc_id_add"])
+    allow = (util.hash_u64(doc_ids + np.uint64(5)) % np.uint64(3)) != 0
+    return meta, fields, doc_ids, allow
+
+
+def build_store(ctx, meta, fields, doc_ids):
+    """Resident postings: list id = field * vocab + term."""
+    lists = []
+    list_id = {}
+    for f in range(meta["n_fields"]):
+        for term in sorted(fields[f]["postings"]):
+            pl = fields[f]["postings"][term]
+            dix = np.array([p[0] for p in pl], dtype=np.int64)
+            list_id[(f, term)] = len(lists)
+            lists.append(ft.PostingList(field=f, docs=doc_ids[dix], tf=np.array([p[1] for p in pl]),
+                                        field_len=fields[f]["lens"][dix]))
+    store = ft.PostingsStore(ctx)
+    store.build(doc_ids, [fields[f]["avg"] for f in range(meta["n_fields"])], lists)
+    return store, list_id
+
+
+def test_bm25_synth_seam_i_bit_exact(ctx, synth):
+    meta, fields, doc_ids, allow = synth
+    for case in meta["cases"]:
+        entries = bm25_synth_entries(meta, fields, case, doc_ids, allow)
+        n_tok = len(case["terms"])
+        for top_k in (1, 20, 500):
+            ids, sc, count = ft.bm25_score(ctx, entries, n_tok, float(meta["n_docs"]), top_k, case["threshold"])
+            od, os_, ocount = oracle_topk(entries, n_tok, meta["n_docs"], top_k, case["threshold"])
+            assert count == ocount == case["count"]
+            assert ids.tolist() == od.tolist(), (case["query"], case["threshold"], case["filter"], top_k)
+            assert np.array_equal(bits(sc), bits(os_))
+        if case["threshold"] is None and not case["filter"]:
+            assert ids[:20].tolist() == od[:20].tolist()
+
+
+def test_bm25_synth_resident_bit_exact(ctx, synth):
+    """Seam (ii): ntf computed on the device from (tf, len) + field boost, filter applied to postings, df counted
+    on the device, idf from the host-built table — still bit-identical to the oracle fed with host ntf."""
+    meta, fields, doc_ids, allow = synth
+    store, list_id = build_store(ctx, meta, fields, doc_ids)
+    bm = oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[allow])
+    for case in meta["cases"]:
+        refs = []
+        for ti, term in enumerate(case["terms"]):
+            for f in range(meta["n_fields"]):
+                if (f, term) in list_id:
+                    refs.append((ti, list_id[(f, term)], meta["boosts"][f]))
+        entries = bm25_synth_entries(meta, fields, case, doc_ids, allow)
+        n_tok = len(case["terms"])
+        ids, sc, count = store.search(refs, n_tok, float(meta["n_docs"]), 50, case["threshold"],
+                                      allow=bm if case["filter"] else None)
+        od, os_, ocount = oracle_topk(entries, n_tok, meta["n_docs"], 50, case["threshold"])
+        assert count == ocount
+        assert ids.tolist() == od.tolist(), (case["query"], case["threshold"], case["filter"])
+        assert np.array_equal(bits(sc), bits(os_))
+    # golden cross-check (independent numpy restatement): count + top ids where scores are isolated
+    case = meta["cases"][0]
+    refs = [(ti, list_id[(f, t)], meta["boosts"][f]) for ti, t in enumerate(case["terms"])
+            for f in range(meta["n_fields"]) if (f, t) in list_id]
+    ids, sc, count = store.search(refs, len(case["terms"]), float(meta["n_docs"]), 20, None)
+    assert count == case["count"]
+    assert np.allclose(sc, np.array(case["top_scores"], dtype=np.float32), rtol=2e-6, atol=1e-6)
+    store.close()
+
+
+def test_omc_multipliers(ctx, synth):
+    """apply_omc_multipliers (search.rs:39-48): ratios 0.25/0.5/2/5/10 as in src/tests/omc_test.rs:485-553."""
+    meta, fields, doc_ids, allow = synth
+    case = meta["cases"][12]  # 3-token query
+    entries = bm25_synth_entries(meta, fields, {**case, "filter": False}, doc_ids, allow)
+    n_tok = len(case["terms"])
+    base_ids, base_sc, count = ft.bm25_score(ctx, entries, n_tok, float(meta["n_docs"]), 200)
+    mult = [0.25, 0.5, 2.0, 5.0, 10.0]
+    omc = {int(base_ids[i]): m for i, m in enumerate(mult)}
+    omc[10**12] = 3.0  # multiplier of a doc that is not in the result: ignored
+    ids, sc, count2 = ft.bm25_score(ctx, entries, n_tok, float(meta["n_docs"]), 200, omc=omc)
+    od, os_, _ = oracle_topk(entries, n_tok, meta["n_docs"], 200, omc=omc)
+    assert count2 == count and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
+    got = dict(zip(ids.tolist(), sc.tolist()))
+    for i, m in enumerate(mult):
+        assert abs(got[int(base_ids[i])] / float(base_sc[i]) - m) < 1e-3
+    # resident store: dense OMC
+    store, list_id = build_store(ctx, meta, fields, doc_ids)
+    store.set_omc(omc)
+    refs = [(ti, list_id[(f, t)], meta["boosts"][f]) for ti, t in enumerate(case["terms"])
+            for f in range(meta["n_fields"]) if (f, t) in list_id]
+    ids2, sc2, _ = store.search(refs, n_tok, float(meta["n_docs"]), 200)
+    assert ids2.tolist() == od.tolist() and np.array_equal(bits(sc2), bits(os_))
+    ids3, sc3, _ = store.search(refs, n_tok, float(meta["n_docs"]), 200, apply_omc=False)
+    assert ids3.tolist() == base_ids.tolist()
+    store.close()
+
+
+def test_fulltext_ordinal_replica(ctx):
+    """src/tests/fulltext_search.rs:192-251 through the resident store: 100 docs, doc i holds "text " x (i+1);
+    query "text" → ranking 99, 98, 97 …, limit 10, count 100."""
+    g = util.load_json("fulltext_ordinal.json")
+    n = g["n"]
+    docs = np.arange(n, dtype=np.uint64)
+    lens = np.arange(1, n + 1)
+    store = ft.PostingsStore(ctx)
+    store.build(docs, [g["avg"]], [ft.PostingList(field=0, docs=docs, tf=lens, field_len=lens)])
+    ids, sc, count = store.search([(0, 0, 1.0)], 1, float(n), 10)
+    assert count == 100 and ids.tolist() == list(range(99, 89, -1)) == g["top_ids"]
+    assert np.allclose(sc, g["top_scores"], rtol=1e-6)
+    # offset paging (fulltext_search.rs:254-335): top (limit+offset) then skip(offset).take(limit)
+    ids2, _, _ = store.search([(0, 0, 1.0)], 1, float(n), 25)
+    assert ids2[20:25].tolist() == [79, 78, 77, 76, 75]
+    store.close()
+
+
+def test_all_scores_equal_large_tie(ctx):
+    """benches/fulltext_simple.rs shape: every doc holds the query term once with the same length → all scores
+    equal; the top-10 must be the 10 lowest doc ids (declared tie rule) and count = N."""
+    n = 200_000
+    docs = np.arange(n, dtype=np.uint64) + np.uint64(1)
+    ntf = np.full(n, orc.bm25f_normalized_tf(1, 7, 7.0, 0.75), dtype=np.float32)
+    ids, sc, count = ft.bm25_score(ctx, [(0, docs, ntf)], 1, float(n), 10)
+    assert count == n and ids.tolist() == list(range(1, 11)) and len(set(bits(sc).tolist())) == 1
+    od, os_, _ = oracle_topk([(0, docs, ntf)], 1, n, 10)
+    assert np.array_equal(bits(sc), bits(os_))
+
+
+def test_edge_cases(ctx):
+    # token without postings contributes nothing; empty query → empty result
+    ids, sc, count = ft.bm25_score(ctx, [(0, [], [])], 1, 100.0, 10)
+    assert count == 0 and len(ids) == 0
+    # subnormal / zero / negative-zero S are skipped (is_normal), NaN term scores are skipped
+    docs = [1, 2, 3, 4, 5]
+    ntf = np.array([1e-45, 0.0, -0.0, 1.0, np.inf], dtype=np.float32)
+    ids, sc, count = ft.bm25_score(ctx, [(0, docs, ntf)], 1, 100.0, 10)
+    od, os_, ocount = oracle_topk([(0, docs, ntf)], 1, 100, 10)
+    assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
+    # top_k = 0 still returns the match count
+    ids, sc, count = ft.bm25_score(ctx, [(0, [1, 2, 3], [1.0, 2.0, 3.0])], 1, 100.0, 0)
+    assert count == 3 and len(ids) == 0
+    # non-dense 64-bit doc ids take the sorted-set path
+    big = np.array([5, 2**40, 2**41 + 7, 2**63 + 11], dtype=np.uint64)
+    ids, sc, count = ft.bm25_score(ctx, [(0, big, [1.0, 3.0, 2.0, 3.0]), (1, big[1:3], [0.5, 0.25])], 2, 1000.0, 4)
+    od, os_, ocount = oracle_topk([(0, big, [1.0, 3.0, 2.0, 3.0]), (1, big[1:3], [0.5, 0.25])], 2, 1000, 4)
+    assert count == ocount == 4 and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
+
+
+def test_many_tokens_and_three_entries_per_token(ctx):
+    """40 tokens (mask wraps at 32 like Rust's `1 << term_index` on u32 in release builds) and 3 entries per token
+    hitting the same docs: the f32 accumulation order (entry order) must match the oracle."""
+    rng = np.random.default_rng(3)
+    entries = []
+    n_tok = 40
+    for t in range(n_tok):
+        for e in range(3):
+            docs = np.sort(rng.choice(300, size=120, replace=False)).astype(np.uint64)
+            entries.append((t, docs, rng.random(120).astype(np.float32) * 3))
+    for thr in (None, 5, 33):
+        ids, sc, count = ft.bm25_score(ctx, entries, n_tok, 300.0, 50, thr)
+        od, os_, ocount = oracle_topk(entries, n_tok, 300, 50, thr)
+        assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
+
+
+# ----------------------------------------------------------------------------- hybrid
+@pytest.mark.parametrize("case", util.load_json("hybrid_kat.json")["cases"], ids=lambda c: c["name"])
+def test_hybrid_combine_golden(ctx, case):
+    vec = {int(k): v for k, v in case["vec"].items()}
+    ftm = {int(k): v for k, v in case["ft"].items()}
+    if case["omc"]:
+        pytest.skip("OMC on the hybrid path is covered by test_hybrid_resident")
+    ids, sc, count = ft.hybrid_combine(ctx, vec, ftm, case["k"])
+    assert count == case["count"]
+    assert ids.tolist() == case["top_ids"]
+    assert bits(sc).tolist() == [e["bits"] for e in case["top_scores"]]
+
+
+def test_hybrid_resident(ctx, synth):
+    """search_hybrid (token_score.rs:357-387) on the resident store: vector map (after the a2 epilogue) +
+    BM25F over postings → min-max normalise over both → sum → OMC → count → top-k; bit-exact vs the oracle."""
+    meta, fields, doc_ids, allow = synth
+    store, list_id = build_store(ctx, meta, fields, doc_ids)
+    rng = np.random.default_rng(9)
+    for ci in (0, 12, 24, 30):
+        case = {**meta["cases"][ci], "filter": False}
+        refs = [(ti, list_id[(f, t)], meta["boosts"][f]) for ti, t in enumerate(case["terms"])
+                for f in range(meta["n_fields"]) if (f, t) in list_id]
+        entries = bm25_synth_entries(meta, fields, case, doc_ids, allow)
+        n_tok = len(case["terms"])
+        fd, fs = orc.search_full_text(entries, n_tok, float(meta["n_docs"]), 1.2, case["threshold"])
+        # vector map: some docs inside the fulltext result, some outside, incl. a negative score
+        inside = rng.choice(fd, size=min(5, len(fd)), replace=False) if len(fd) else np.array([], dtype=np.uint64)
+        outside = np.setdiff1d(doc_ids[:50], fd)[:4]
+        vec = {int(d): float(s) for d, s in zip(np.concatenate([inside, outside]),
+                                                 rng.uniform(-0.2, 1.0, size=len(inside) + len(outside)))}
+        for omc in (None, {int(doc_ids[3]): 2.0, int(fd[0]) if len(fd) else 1: 0.5}):
+            od, os_ = orc.normalize_and_combine(list(vec), list(vec.values()), fd, fs)
+            if omc:
+                os_ = orc.apply_omc(od, os_, list(omc), list(omc.values()))
+                store.set_omc(omc)
+            td, ts = orc.top_n(od, os_, 30)
+            ids, sc, count = store.search(refs, n_tok, float(meta["n_docs"]), 30, case["threshold"], vector=vec,
+                                          apply_omc=omc is not None)
+            assert count == len(od)
+            assert ids.tolist() == td.tolist(), (ci, omc)
+            assert np.array_equal(bits(sc), bits(ts))
+    store.close()
