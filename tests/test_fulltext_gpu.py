@@ -141,12 +141,12 @@ def test_omc_multipliers(ctx, synth):
     case = meta["cases"][12]  # 3-token query
     entries = bm25_synth_entries(meta, fields, {**case, "filter": False}, doc_ids, allow)
     n_tok = len(case["terms"])
-    base_ids, base_sc, count = ft.bm25_score(ctx, entries, n_tok, float(meta["n_docs"]), 200)
+    base_ids, base_sc, count = ft.bm25_score(ctx, entries, n_tok, float(meta["n_docs"]), 2000)
     mult = [0.25, 0.5, 2.0, 5.0, 10.0]
     omc = {int(base_ids[i]): m for i, m in enumerate(mult)}
     omc[10**12] = 3.0  # multiplier of a doc that is not in the result: ignored
-    ids, sc, count2 = ft.bm25_score(ctx, entries, n_tok, float(meta["n_docs"]), 200, omc=omc)
-    od, os_, _ = oracle_topk(entries, n_tok, meta["n_docs"], 200, omc=omc)
+    ids, sc, count2 = ft.bm25_score(ctx, entries, n_tok, float(meta["n_docs"]), 2000, omc=omc)
+    od, os_, _ = oracle_topk(entries, n_tok, meta["n_docs"], 2000, omc=omc)
     assert count2 == count and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
     got = dict(zip(ids.tolist(), sc.tolist()))
     for i, m in enumerate(mult):
@@ -156,9 +156,9 @@ def test_omc_multipliers(ctx, synth):
     store.set_omc(omc)
     refs = [(ti, list_id[(f, t)], meta["boosts"][f]) for ti, t in enumerate(case["terms"])
             for f in range(meta["n_fields"]) if (f, t) in list_id]
-    ids2, sc2, _ = store.search(refs, n_tok, float(meta["n_docs"]), 200)
+    ids2, sc2, _ = store.search(refs, n_tok, float(meta["n_docs"]), 2000)
     assert ids2.tolist() == od.tolist() and np.array_equal(bits(sc2), bits(os_))
-    ids3, sc3, _ = store.search(refs, n_tok, float(meta["n_docs"]), 200, apply_omc=False)
+    ids3, sc3, _ = store.search(refs, n_tok, float(meta["n_docs"]), 2000, apply_omc=False)
     assert ids3.tolist() == base_ids.tolist()
     store.close()
 
