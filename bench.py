@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="ns")
     ap.add_argument("--rows", type=int, default=0, help="override the corpus size (debug only; marks the run invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the RCCL all-gather + merge even with one rank (plumbing test)")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     return ap.parse_args()
 
@@ -110,9 +112,15 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_exchange
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     n_total, dim, k, desc = WORKLOADS[args.workload]
     if args.rows:
@@ -131,11 +139,11 @@ def main():
     rng = np.random.default_rng(0xBEEF)
     queries_h = rng.standard_normal((total_q, dim)).astype(np.float32)
     queries = torch.from_numpy(queries_h).to(device)
-    searcher = ShardedSearcher(HipOps(ctx, store), rank, world, device)
+    searcher = ShardedSearcher(HipOps(ctx, store), rank, world, device, always_exchange=args.force_exchange)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -151,7 +159,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -175,6 +183,14 @@ def main():
     avg_scan_s = scan_ms / max(scan_n, 1) / 1e3
     achieved = alg_bytes / avg_scan_s / 1e9 if scan_n else 0.0
 
+    traffic, traffic_src = None, None
+    pmc_files = sorted((ROOT / "profiles").glob(f"r*_pmc_{args.workload}_vec_scan.json"))
+    if pmc_files and not args.rows and world == 1:
+        rec = json.loads(pmc_files[-1].read_text())
+        traffic = rec.get("traffic_bytes_per_launch")
+        traffic_src = f"profiles/{pmc_files[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
+                      "FETCH_SIZE x2 per MI355X_MICROARCH.md)"
+
     out = {
         "metric": "queries/sec, single-query cosine top-100 scan (10M x 768 fp32) — HBM GB/s vs peak in `roofline`",
         "value": args.steps / elapsed,
@@ -192,7 +208,8 @@ def main():
                    "queries_per_step": 1, "parallelism": f"row-shard x{world} + all-gather(top-k) over RCCL"
                    if world > 1 else "single GPU", "valid": not bool(args.rows)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                      "kernel": "vec_scan_f32_kernel", "alg_bytes_per_launch": alg_bytes,
                      "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_n,
                      "topk_select_avg_ms": sel_ms / max(sel_n, 1)},
@@ -214,7 +231,7 @@ def main():
         out["device"] = ctx.device_info()["name"]
         print(json.dumps(out), flush=True)
     store.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
