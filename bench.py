@@ -13,7 +13,7 @@ PCIe hop, is timed separately and reported as `latency_ms_p50_host_api`).
 Strong scaling: the 10 M rows are split statically over the N ranks, so queries/sec
 should grow ~linearly with N.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|c2] [--rows R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|c2|c3] [--rows R]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 from __future__ import annotations
@@ -33,9 +33,11 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 WORKLOADS = {
-    # name: (rows, dim, k, description)
-    "ns": (10_000_000, 768, 100, "10M x 768 fp32 embeddings, single-query cosine top-100 (north-star)"),
-    "c2": (1_000_000, 384, 100, "1M x 384 fp32 embeddings, single-query cosine top-100 (BASELINE configs[1])"),
+    # name: (rows, dim, k, queries per step, storage dtype, description)
+    "ns": (10_000_000, 768, 100, 1, "f32", "10M x 768 fp32 embeddings, single-query cosine top-100 (north-star)"),
+    "c2": (1_000_000, 384, 100, 1, "f32", "1M x 384 fp32 embeddings, single-query cosine top-100 (BASELINE configs[1])"),
+    "c3": (10_000_000, 768, 100, 64, "f16", "10M x 768 fp16 embeddings, batch-64 queries, MFMA scan + top-100 "
+                                            "(BASELINE configs[2])"),
 }
 
 
@@ -122,22 +124,24 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=device)
 
-    n_total, dim, k, desc = WORKLOADS[args.workload]
+    n_total, dim, k, qb, dtype, desc = WORKLOADS[args.workload]
     if args.rows:
         n_total = args.rows
     plan = ShardPlan(n_total, world)
     lo, hi = plan.range(rank)
     n_local = hi - lo
+    f16 = dtype == "f16"
 
     ctx = oa.Context(local_rank)
-    store = oa.EmbeddingFieldStorage(ctx, dimensions=dim, reserve_rows=n_local)
+    store = oa.EmbeddingFieldStorage(ctx, dimensions=dim, reserve_rows=n_local,
+                                     dtype=oa.DTYPE_F16 if f16 else oa.DTYPE_F32)
     t_fill = time.perf_counter()
     store.fill_synthetic(n_local, seed=0xC0FFEE + rank, first_doc_id=lo)
     t_fill = time.perf_counter() - t_fill
 
-    total_q = args.warmup + args.steps
+    total_b = args.warmup + args.steps  # batches
     rng = np.random.default_rng(0xBEEF)
-    queries_h = rng.standard_normal((total_q, dim)).astype(np.float32)
+    queries_h = rng.standard_normal((total_b * qb, dim)).astype(np.float32)
     queries = torch.from_numpy(queries_h).to(device)
     searcher = ShardedSearcher(HipOps(ctx, store), rank, world, device, always_exchange=args.force_exchange)
 
@@ -147,15 +151,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # keep per-step results (ids/dist of the last step are checked after the timed region)
     for i in range(args.warmup):
-        searcher.search(queries[i:i + 1], k)
+        searcher.search(queries[i * qb:(i + 1) * qb], k)
     barrier()
     ctx.prof_reset()
     ctx.prof_enable(True)
     t0 = time.perf_counter()
-    for i in range(args.warmup, total_q):
-        ids, dst, cnt = searcher.search(queries[i:i + 1], k)
+    for i in range(args.warmup, total_b):
+        ids, dst, cnt = searcher.search(queries[i * qb:(i + 1) * qb], k)
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
@@ -165,21 +168,31 @@ def main():
         elapsed = float(t.item())
 
     # ---- sanity of the last step (outside the timed region): sorted, and exact on re-computation
-    ids_h = ids.cpu().numpy().view(np.uint64)[0]
-    dst_h = dst.cpu().numpy()[0]
-    assert int(cnt.cpu()[0]) == k and np.all(np.diff(dst_h) >= 0), "bench result not sorted"
-    mine = (ids_h >= lo) & (ids_h < hi)
-    if mine.any():
-        from oracle import oracle as orc  # checker only
+    ids_all = ids.cpu().numpy().view(np.uint64)
+    dst_all = dst.cpu().numpy()
+    assert np.all(cnt.cpu().numpy() == k), "bench result incomplete"
+    from oracle import oracle as orc  # checker only
 
-        rows, _ = store.get_rows((ids_h[mine] - np.uint64(lo)).astype(np.uint64))
-        od = orc.distances(rows, queries_h[-1])
-        err = float(np.max(np.abs(od - dst_h[mine])))
-        assert err <= 1e-4, f"bench parity check failed: {err}"
+    for qi in sorted({0, qb - 1}):
+        ids_h, dst_h = ids_all[qi], dst_all[qi]
+        assert np.all(np.diff(dst_h) >= 0), "bench result not sorted"
+        mine = (ids_h >= lo) & (ids_h < hi)
+        if mine.any():
+            rows, _ = store.get_rows((ids_h[mine] - np.uint64(lo)).astype(np.uint64))
+            qv = queries_h[(total_b - 1) * qb + qi]
+            if f16:  # the fp16 path scores the fp16-rounded query against the stored fp16 rows
+                qv = qv.astype(np.float16).astype(np.float32)
+            od = orc.distances(rows, qv)
+            err = float(np.max(np.abs(od - dst_h[mine])))
+            assert err <= 1e-4, f"bench parity check failed: {err}"
 
-    scan_ms, scan_n = ctx.prof_get("vec_scan_f32")
+    kern = "vec_scan_f16" if f16 else "vec_scan_f32"
+    scan_ms, scan_n = ctx.prof_get(kern)
     sel_ms, sel_n = ctx.prof_get("topk_select")
-    alg_bytes = n_local * dim * 4
+    kpad = (dim + 127) // 128 * 128
+    bytes_per_step = n_local * (kpad * 2 if f16 else dim * 4)  # one corpus pass per step
+    launches_per_step = max(scan_n, 1) / args.steps
+    alg_bytes = bytes_per_step / launches_per_step
     avg_scan_s = scan_ms / max(scan_n, 1) / 1e3
     achieved = alg_bytes / avg_scan_s / 1e9 if scan_n else 0.0
 
@@ -192,8 +205,8 @@ def main():
                       "FETCH_SIZE x2 per MI355X_MICROARCH.md)"
 
     out = {
-        "metric": "queries/sec, single-query cosine top-100 scan (10M x 768 fp32) — HBM GB/s vs peak in `roofline`",
-        "value": args.steps / elapsed,
+        "metric": "queries/sec, cosine top-100 scan (10M x 768) — HBM GB/s vs peak in `roofline`",
+        "value": args.steps * qb / elapsed,
         "unit": "queries/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -202,30 +215,35 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": dtype,
         "data": "synthetic",
         "config": {"workload": desc, "rows_total": n_total, "rows_per_gpu": n_local, "dim": dim, "k": k,
-                   "queries_per_step": 1, "parallelism": f"row-shard x{world} + all-gather(top-k) over RCCL"
+                   "queries_per_step": qb, "parallelism": f"row-shard x{world} + all-gather(top-k) over RCCL"
                    if world > 1 else "single GPU", "valid": not bool(args.rows)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                     "kernel": "vec_scan_f32_kernel", "alg_bytes_per_launch": alg_bytes,
+                     "kernel": kern + "_kernel", "alg_bytes_per_launch": alg_bytes,
                      "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_n,
-                     "topk_select_avg_ms": sel_ms / max(sel_n, 1)},
+                     "scan_launches_per_step": launches_per_step,
+                     "topk_select_ms_per_step": sel_ms / args.steps},
         "fill_seconds": t_fill,
     }
+    if f16:
+        flops = 2.0 * qb * n_local * kpad * args.steps
+        out["roofline"]["mfma_tflops"] = flops / (scan_ms / 1e3) / 1e12 if scan_ms else 0.0
+        out["roofline"]["mfma_peak_tflops_dense_f16"] = 2500.0
 
     if rank == 0 and world == 1:
         # host-buffer API latency (adds the PCIe hop for the query and the k results)
         lat = []
-        for i in range(min(50, total_q)):
+        for i in range(min(50, total_b)):
             t1 = time.perf_counter()
-            store.storage_search(queries_h[i], k)
+            store.storage_search(queries_h[i * qb:(i + 1) * qb], k)
             lat.append((time.perf_counter() - t1) * 1e3)
         out["latency_ms_p50_host_api"] = float(np.percentile(lat, 50))
         out["latency_ms_p95_host_api"] = float(np.percentile(lat, 95))
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not f16:
             out["cpu_baseline"] = cpu_baseline(store, dim, n_total, k, args.cpu_sample_rows)
     if rank == 0:
         out["device"] = ctx.device_info()["name"]

@@ -66,6 +66,8 @@ int orama_ctx_device_info(orama_ctx* ctx, char* name256, int* compute_units, uin
 /* Launch geometry of the K1 scan (tuning sweeps; defaults are the measured best on MI355X):
  * rows each wave keeps in flight (1/2/4/8), persistent workgroups per CU, nontemporal corpus loads. */
 int orama_ctx_set_scan_tuning(orama_ctx* ctx, int rows_per_wave, int blocks_per_cu, int nontemporal);
+/* Register-ring geometry of the K2 fp16 scan: k-steps per chunk (8/12/16) and chunks in the ring (2..4). */
+int orama_ctx_set_f16_tuning(orama_ctx* ctx, int ksteps_per_chunk, int ring_chunks);
 
 /* Per-kernel HIP-event timing (used by bench.py's roofline leg).  When enabled, the library
  * brackets each launch of the named hot kernels with hipEvents on the launching stream.

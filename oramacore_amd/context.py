@@ -50,6 +50,9 @@ class Context:
     def set_scan_tuning(self, rows_per_wave: int, blocks_per_cu: int, nontemporal: bool) -> None:
         N.check(self._lib.orama_ctx_set_scan_tuning(self.handle, rows_per_wave, blocks_per_cu, 1 if nontemporal else 0))
 
+    def set_f16_tuning(self, ksteps_per_chunk: int, ring_chunks: int) -> None:
+        N.check(self._lib.orama_ctx_set_f16_tuning(self.handle, ksteps_per_chunk, ring_chunks))
+
     # --- HIP-event profiler (bench.py roofline leg)
     def prof_enable(self, on: bool = True) -> None:
         N.check(self._lib.orama_prof_enable(self.handle, 1 if on else 0))

@@ -1,4 +1,6 @@
 // context.hip — error channel, per-GPU context, scratch pool, HIP-event profiler.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "vec_kernels.hpp"
 
@@ -125,6 +127,8 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
         return ORAMA_ERR_OOM;
     }
     c->scan_tuning = orama::default_scan_tuning();
+    if (const char* e = std::getenv("ORAMA_F16_KC")) c->f16_kc = std::atoi(e);
+    if (const char* e = std::getenv("ORAMA_F16_NBUF")) c->f16_nbuf = std::atoi(e);
     c->device = device_ordinal;
     c->compute_units = prop.multiProcessorCount;
     c->hbm_bytes = (uint64_t)prop.totalGlobalMem;
@@ -166,6 +170,16 @@ int orama_ctx_set_scan_tuning(orama_ctx* ctx, int rows_per_wave, int blocks_per_
     t.nontemporal = nontemporal;
     ORAMA_REQUIRE(orama::scan_tuning_valid(t), "scan tuning out of range (rows in {1,2,4,8}, blocks/CU in [1,32])");
     ctx->scan_tuning = t;
+    return ORAMA_OK;
+}
+
+int orama_ctx_set_f16_tuning(orama_ctx* ctx, int ksteps_per_chunk, int ring_chunks) {
+    ORAMA_REQUIRE(ctx, "null ctx");
+    ORAMA_REQUIRE((ksteps_per_chunk == 8 || ksteps_per_chunk == 12 || ksteps_per_chunk == 16) && ring_chunks >= 2 &&
+                      ring_chunks <= 4,
+                  "f16 tuning out of range (k-steps per chunk in {8,12,16}, ring chunks in [2,4])");
+    ctx->f16_kc = ksteps_per_chunk;
+    ctx->f16_nbuf = ring_chunks;
     return ORAMA_OK;
 }
 

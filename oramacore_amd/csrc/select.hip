@@ -382,7 +382,7 @@ int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
     }
     ORAMA_REQUIRE(p.state && p.keys, "top-k: scratch missing");
     ORAMA_HIP_TRY(hipMemsetAsync(p.state, 0, sizeof(SelectState) * (size_t)p.q, stream));
-    uint32_t blocks = ceil_div_u32(p.n, kHistThreads * 16);
+    uint32_t blocks = ceil_div_u32(p.n_hint ? p.n_hint : p.n, kHistThreads * 16);
     uint32_t max_blocks = (uint32_t)ctx->compute_units * 8u;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;

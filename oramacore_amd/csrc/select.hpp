@@ -29,6 +29,7 @@ struct SelectPlan {
     uint64_t stride = 0;
     const uint32_t* n_dev = nullptr;  // nullable: per-list length in HBM (<= n)
     uint32_t n = 0;                   // (max) list length
+    uint32_t n_hint = 0;              // expected length when n_dev is set (grid sizing only; 0 = n)
     uint32_t q = 1;
     uint32_t k = 0;
     bool descending = true;           // true: larger value is better (scores); false: distances

@@ -1,0 +1,375 @@
+// vec_f16.hip — K2: batched-query cosine scan over an fp16 corpus on the gfx950 matrix cores.
+//
+// GEMM shape per launch: scores[rows x Q] = corpus[rows x K] · queriesᵀ[K x Q], Q <= 64, never
+// materialised: each wave owns 32-row tiles, streams the tile's A fragments straight from HBM into
+// VGPRs (the HBM layout IS the fragment layout — one contiguous 1 KiB per wave-load, no LDS staging of
+// the corpus), multiplies against the query fragments that sit in LDS (converted to fp16 once per
+// block, conflict-free ds_read_b128: lane-linear 16 B), accumulates in f32 with
+// v_mfma_f32_32x32x16_f16 and applies the epilogue (1 - s/|x||q|, filter, per-query threshold test)
+// directly on the accumulator registers.
+//
+// Roofline: HBM.  Arithmetic intensity = Q flop/B (64 at C3) against a ridge of ~312 flop/B, so at
+// the HBM roof the matrix pipe is ~Q/312 busy (20 % at Q = 64).  Algorithmic bytes = rows·kpad·2 per
+// launch (one pass serves the whole batch).  Per CU: 8 waves (2/SIMD), each with two 8-KiB chunks of
+// A fragments in flight (double-buffered across tile boundaries) → 128 KiB of loads outstanding.
+//
+// The A/B element order inside a 16-wide k-step only has to be the SAME for both operands (the dot
+// product is invariant under a common permutation of k), and it is: both are filled with
+// lane = (kgrp << 5) | (row or query), element e ↔ k = 16·kstep + 8·kgrp + e.
+#include "vec_f16.hpp"
+
+#include "device_utils.hpp"
+
+namespace orama {
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBlock = 512;          // 8 waves: 2 per SIMD
+constexpr int kWavesPerBlock = kBlock / 64;
+// KC = k-steps per register chunk (KC x 1 KiB per wave-load group), NBUF = chunks in the register ring
+// (NBUF-1 chunks stay in flight while one is being multiplied).
+
+__device__ __forceinline__ h8 as_h8(f4 v) { return __builtin_bit_cast(h8, v); }
+
+template <int NQT, int KC, int NBUF>
+__global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uint32_t ksteps) {
+    constexpr int kChunk = KC;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t frag_total = ksteps * NQT * 64;
+    float* qinv = reinterpret_cast<float*>(lds + (size_t)frag_total * 16);
+
+    // ---- prologue: queries (f32, HBM/L2) → fp16 B fragments in LDS
+    for (uint32_t idx = tid; idx < frag_total; idx += kBlock) {
+        const uint32_t ks = idx / (NQT * 64);
+        const uint32_t rem = idx - ks * (NQT * 64);
+        const uint32_t qt = rem >> 6, l = rem & 63;
+        const uint32_t j = qt * 32 + (l & 31);
+        const uint32_t k0 = ks * 16 + (l >> 5) * 8;
+        h8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t k = k0 + e;
+            const float x = (j < a.q && k < a.dim) ? a.queries[(size_t)j * a.dim + k] : 0.0f;
+            v[e] = (_Float16)x;
+        }
+        *reinterpret_cast<h8*>(lds + (size_t)idx * 16) = v;
+    }
+    __syncthreads();
+    if (tid < NQT * 32) {  // |q| of the fp16-rounded query, f32 accumulation, fixed order
+        const uint32_t j = tid;
+        float ss = 0.0f;
+        for (uint32_t k = 0; k < ksteps * 16; ++k) {
+            const uint32_t ks = k >> 4, g = (k >> 3) & 1, e = k & 7;
+            const uint32_t l = g * 32 + (j & 31), qt = j >> 5;
+            const float x = (float)reinterpret_cast<const _Float16*>(lds + (size_t)((ks * NQT + qt) * 64 + l) * 16)[e];
+            ss = fmaf(x, x, ss);
+        }
+        qinv[j] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+    }
+    __syncthreads();
+
+    // ---- tiles of this wave
+    const uint32_t gw = uniform_u32(blockIdx.x * kWavesPerBlock + (tid >> 6));
+    const uint32_t gwaves = gridDim.x * kWavesPerBlock;
+    const uint64_t t_first = a.row_begin >> 5;
+    const uint64_t t_end = (a.row_end + 31) >> 5;
+    if (t_first + gw >= t_end) return;
+    const uint64_t my_tiles = (t_end - t_first - gw + gwaves - 1) / gwaves;
+    const uint32_t nc = ksteps / kChunk;  // chunks per tile
+    const uint64_t tile_bytes = (uint64_t)ksteps * 1024;
+    const char* base = reinterpret_cast<const char*>(a.tiled);
+
+    f16v acc[NQT];
+    f4 buf[NBUF][KC];
+    uint64_t ld_tile = t_first + gw;  // (tile, chunk) cursor of the NEXT load
+    uint32_t ld_c = 0;
+    uint64_t ld_left = my_tiles * nc;
+    uint64_t cp_tile = t_first + gw;  // cursor of the NEXT compute
+    uint32_t cp_c = 0;
+
+    auto load_chunk = [&](f4* buf) {
+        const f4* p = reinterpret_cast<const f4*>(base + ld_tile * tile_bytes + (uint64_t)ld_c * kChunk * 1024) + lane;
+#pragma unroll
+        for (int s = 0; s < kChunk; ++s) buf[s] = __builtin_nontemporal_load(p + s * 64);
+        if (++ld_c == nc) {
+            ld_c = 0;
+            ld_tile += gwaves;
+        }
+        --ld_left;
+    };
+
+    // per-lane constants of the epilogue: this lane's query column per tile, its 1/|q| and threshold
+    float qi_reg[NQT], tau_reg[NQT];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        const uint32_t j = qt * 32 + (lane & 31);
+        qi_reg[qt] = qinv[j];
+        tau_reg[qt] = (a.tau && j < a.q) ? a.tau[j] : 0.0f;
+    }
+    // 1/|x| of the 16 accumulator rows of this lane, fetched at tile START (4 x 16 B: rows 8g+4h+0..3)
+    // so that the epilogue never waits on memory behind the prefetched corpus chunks
+    f4 nrm[4];
+    uint32_t dead_word = 0;
+    auto prefetch_tile_meta = [&](uint64_t tile) {
+        const f4* np = reinterpret_cast<const f4*>(a.inv_norm + tile * 32 + 4 * (lane >> 5));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nrm[g] = np[2 * g];
+        dead_word = a.dead ? a.dead[tile] : 0u;
+    };
+
+    auto epilogue = [&](uint64_t tile) {
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            const uint32_t j = qt * 32 + (lane & 31);
+            const bool jok = j < a.q;
+            const float qi = qi_reg[qt];
+            const float tau = tau_reg[qt];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const uint64_t row = tile * 32 + i;
+                if (row >= a.row_end || !jok) continue;
+                bool excluded = (dead_word >> i) & 1u;
+                if (!excluded && a.allow) {
+                    const uint64_t doc = a.row_doc[row];
+                    excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
+                }
+                const float dist = 1.0f - acc[qt][r] * (nrm[r >> 2][r & 3] * qi);
+                if (a.out_dense) {
+                    a.out_dense[(uint64_t)j * a.dense_stride + (row - a.row_begin)] =
+                        excluded ? __builtin_nanf("") : dist;
+                } else if (!excluded && dist < tau) {
+                    const uint32_t pos = atomicAdd(&a.cand_count[j], 1u);
+                    a.cand_dist[(uint64_t)j * a.cand_stride + pos] = dist;
+                    a.cand_row[(uint64_t)j * a.cand_stride + pos] = (uint32_t)row;
+                }
+            }
+        }
+    };
+
+    auto compute_chunk = [&](const f4* buf) {
+        if (cp_c == 0) {
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[qt][r] = 0.0f;
+            prefetch_tile_meta(cp_tile);
+        }
+        const char* bl = lds + ((size_t)cp_c * kChunk * NQT * 64 + lane) * 16;
+#pragma unroll
+        for (int s = 0; s < kChunk; ++s) {
+            const h8 av = as_h8(buf[s]);
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) {
+                const h8 bv = *reinterpret_cast<const h8*>(bl + (size_t)(s * NQT + qt) * 1024);
+                acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[qt], 0, 0, 0);
+            }
+        }
+        if (++cp_c == nc) {
+            epilogue(cp_tile);
+            cp_c = 0;
+            cp_tile += gwaves;
+        }
+    };
+
+    uint64_t todo = my_tiles * nc;
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+        if (ld_left) load_chunk(buf[b]);
+    while (todo) {
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) {
+            if (ld_left) load_chunk(buf[(b + NBUF - 1) % NBUF]);
+            compute_chunk(buf[b]);
+            if (--todo == 0) break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- store / norms / gather
+__global__ __launch_bounds__(256) void f16_store_rows_kernel(char* __restrict__ tiled,
+                                                             const float* __restrict__ src, uint64_t first,
+                                                             uint64_t n, uint32_t dim, uint32_t kpad) {
+    const uint32_t pieces = kpad / 8;
+    const uint64_t total = n * pieces;
+    const uint64_t tile_bytes = (uint64_t)kpad * 64;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = t / pieces;
+        const uint32_t p = (uint32_t)(t - r * pieces);
+        const uint32_t k0 = p * 8;
+        h8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)((k0 + e < dim) ? src[r * dim + k0 + e] : 0.0f);
+        const uint64_t row = first + r;
+        const uint32_t ks = k0 >> 4, g = (k0 >> 3) & 1;
+        const uint32_t lane = g * 32 + (uint32_t)(row & 31);
+        *reinterpret_cast<h8*>(tiled + (row >> 5) * tile_bytes + ((uint64_t)ks * 64 + lane) * 16) = v;
+    }
+}
+
+__device__ __forceinline__ h8 f16_piece(const char* tiled, uint64_t row, uint32_t p, uint64_t tile_bytes) {
+    const uint32_t k0 = p * 8;
+    const uint32_t ks = k0 >> 4, g = (k0 >> 3) & 1;
+    const uint32_t lane = g * 32 + (uint32_t)(row & 31);
+    return *reinterpret_cast<const h8*>(tiled + (row >> 5) * tile_bytes + ((uint64_t)ks * 64 + lane) * 16);
+}
+
+__global__ __launch_bounds__(256) void f16_inv_norm_kernel(const char* __restrict__ tiled, uint64_t first,
+                                                           uint64_t n, uint32_t kpad,
+                                                           float* __restrict__ inv_norm) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint32_t pieces = kpad / 8;
+    const uint64_t tile_bytes = (uint64_t)kpad * 64;
+    for (uint64_t i = wave; i < n; i += nwaves) {
+        const uint64_t row = first + i;
+        float ss = 0.0f;
+        for (uint32_t p = lane; p < pieces; p += 64) {
+            const h8 v = f16_piece(tiled, row, p, tile_bytes);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = fmaf((float)v[e], (float)v[e], ss);
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) inv_norm[row] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void f16_gather_rows_kernel(const char* __restrict__ tiled,
+                                                              const uint64_t* __restrict__ idx, uint64_t n,
+                                                              uint32_t dim, uint32_t kpad,
+                                                              float* __restrict__ out) {
+    const uint32_t pieces = kpad / 8;
+    const uint64_t total = n * pieces;
+    const uint64_t tile_bytes = (uint64_t)kpad * 64;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = t / pieces;
+        const uint32_t p = (uint32_t)(t - r * pieces);
+        const h8 v = f16_piece(tiled, idx[r], p, tile_bytes);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (p * 8 + e < dim) out[r * dim + p * 8 + e] = (float)v[e];
+    }
+}
+
+__global__ void f16_seed_candidates_kernel(const float* __restrict__ best_dist,
+                                           const uint32_t* __restrict__ best_row,
+                                           const uint32_t* __restrict__ best_n, uint32_t k, float* tau,
+                                           float* cand_dist, uint32_t* cand_row, uint32_t* cand_count,
+                                           uint64_t cand_stride) {
+    const uint32_t j = blockIdx.x;
+    const uint32_t n = best_n[j];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        cand_dist[(uint64_t)j * cand_stride + i] = best_dist[(uint64_t)j * k + i];
+        cand_row[(uint64_t)j * cand_stride + i] = best_row[(uint64_t)j * k + i];
+    }
+    if (threadIdx.x == 0) {
+        cand_count[j] = n;
+        // strict '<' against the k-th best: a later row with an equal distance has a higher row index
+        // and can never displace it (tie rule: distance asc, row asc)
+        tau[j] = (n == k) ? best_dist[(uint64_t)j * k + (k - 1)] : __builtin_huge_valf();
+    }
+}
+
+uint32_t blocks_for(uint64_t items, uint32_t per_block, uint32_t cap) {
+    uint64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (uint32_t)b;
+}
+
+}  // namespace
+
+int launch_f16_store_rows(void* tiled, const float* src, uint64_t first, uint64_t n, uint32_t dim,
+                          hipStream_t stream) {
+    if (n == 0) return ORAMA_OK;
+    const uint32_t kpad = f16_kpad(dim);
+    hipLaunchKernelGGL(f16_store_rows_kernel, dim3(blocks_for(n * (kpad / 8), 256, 16384)), dim3(256), 0,
+                       stream, reinterpret_cast<char*>(tiled), src, first, n, dim, kpad);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_f16_inv_norm(const void* tiled, uint64_t first, uint64_t n, uint32_t dim, float* inv_norm,
+                        hipStream_t stream) {
+    if (n == 0) return ORAMA_OK;
+    hipLaunchKernelGGL(f16_inv_norm_kernel, dim3(blocks_for(n, 4, 8192)), dim3(256), 0, stream,
+                       reinterpret_cast<const char*>(tiled), first, n, f16_kpad(dim), inv_norm);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_f16_gather_rows(const void* tiled, const uint64_t* d_row_idx, uint64_t n, uint32_t dim,
+                           float* d_out, hipStream_t stream) {
+    if (n == 0) return ORAMA_OK;
+    const uint32_t kpad = f16_kpad(dim);
+    hipLaunchKernelGGL(f16_gather_rows_kernel, dim3(blocks_for(n * (kpad / 8), 256, 16384)), dim3(256), 0,
+                       stream, reinterpret_cast<const char*>(tiled), d_row_idx, n, dim, kpad, d_out);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream) {
+    ORAMA_REQUIRE(a.tiled && a.inv_norm && a.queries, "vec_scan_f16: bad arguments");
+    ORAMA_REQUIRE(a.q >= 1 && a.q <= kF16MaxQ, "vec_scan_f16: q=%u outside [1, %u]", a.q, kF16MaxQ);
+    ORAMA_REQUIRE((a.row_begin & 31) == 0 && a.row_begin <= a.row_end, "vec_scan_f16: bad row range");
+    ORAMA_REQUIRE(a.out_dense || (a.tau && a.cand_dist && a.cand_row && a.cand_count),
+                  "vec_scan_f16: no output mode");
+    ORAMA_REQUIRE(!a.allow || a.row_doc, "vec_scan_f16: filter needs row_doc");
+    if (a.row_begin == a.row_end) return ORAMA_OK;
+    const uint32_t kpad = f16_kpad(a.dim);
+    const uint32_t ksteps = kpad / 16;
+    const int nqt = a.q <= 32 ? 1 : 2;
+    const size_t lds_bytes = (size_t)ksteps * nqt * 1024 + 64 * sizeof(float);
+    ORAMA_REQUIRE(lds_bytes <= 160 * 1024, "vec_scan_f16: dim %u too large for the LDS query tile", a.dim);
+    ProfScope prof(&ctx->prof, "vec_scan_f16", stream);
+    const uint64_t tiles = ((a.row_end + 31) >> 5) - (a.row_begin >> 5);
+    const dim3 grid(blocks_for(tiles, kWavesPerBlock, (uint32_t)ctx->compute_units));
+    // chunk geometry: preferred (KC, NBUF) from the context tuning, constrained by ksteps % KC == 0
+    int kc = ctx->f16_kc, nbuf = ctx->f16_nbuf;
+    if (ksteps % (uint32_t)kc != 0) kc = 8;
+#define ORAMA_F16_LAUNCH(NQT_, KC_, NB_)                                                                   \
+    do {                                                                                                   \
+        static bool attr_done = false;                                                                     \
+        if (!attr_done) {                                                                                  \
+            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_kernel<NQT_, KC_, NB_>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
+            attr_done = true;                                                                              \
+        }                                                                                                  \
+        hipLaunchKernelGGL((vec_scan_f16_kernel<NQT_, KC_, NB_>), grid, dim3(kBlock), lds_bytes, stream, a, ksteps); \
+    } while (0)
+#define ORAMA_F16_DISPATCH(NQT_)                                  \
+    do {                                                          \
+        if (kc == 16 && nbuf == 2) ORAMA_F16_LAUNCH(NQT_, 16, 2); \
+        else if (kc == 12 && nbuf == 3) ORAMA_F16_LAUNCH(NQT_, 12, 3); \
+        else if (kc == 12) ORAMA_F16_LAUNCH(NQT_, 12, 2);         \
+        else if (nbuf == 4) ORAMA_F16_LAUNCH(NQT_, 8, 4);         \
+        else if (nbuf == 3) ORAMA_F16_LAUNCH(NQT_, 8, 3);         \
+        else ORAMA_F16_LAUNCH(NQT_, 8, 2);                        \
+    } while (0)
+    if (nqt == 1) ORAMA_F16_DISPATCH(1);
+    else ORAMA_F16_DISPATCH(2);
+#undef ORAMA_F16_DISPATCH
+#undef ORAMA_F16_LAUNCH
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_f16_seed_candidates(const float* best_dist, const uint32_t* best_row, const uint32_t* best_n,
+                               uint32_t q, uint32_t k, float* tau, float* cand_dist, uint32_t* cand_row,
+                               uint32_t* cand_count, uint64_t cand_stride, hipStream_t stream) {
+    hipLaunchKernelGGL(f16_seed_candidates_kernel, dim3(q), dim3(256), 0, stream, best_dist, best_row, best_n,
+                       k, tau, cand_dist, cand_row, cand_count, cand_stride);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+}  // namespace orama

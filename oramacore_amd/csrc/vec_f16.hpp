@@ -1,0 +1,62 @@
+// vec_f16.hpp — K2: fp16 corpus in an MFMA-fragment-tiled HBM layout + batched-query scan on the
+// matrix cores with a fused per-query threshold filter (build-side extension: SURVEY F4, configs C3/C5).
+#pragma once
+
+#include "common.hpp"
+
+namespace orama {
+
+// HBM layout of the fp16 corpus: [row_tile = row/32][k_step = k/16][lane 0..63][8 halves], where lane
+// l = (kgrp << 5) | (row & 31) holds elements k = 16*k_step + 8*kgrp + 0..7 of its row — exactly the
+// A-operand fragment of v_mfma_f32_32x32x16_f16, so every wave-wide 16 B/lane load is one contiguous
+// 1 KiB and a row tile (32 rows) is one contiguous run of kpad*64 bytes.  kpad = dim rounded up to 128.
+inline uint32_t f16_kpad(uint32_t dim) { return (dim + 127u) & ~127u; }
+inline uint64_t f16_tile_bytes(uint32_t dim) { return (uint64_t)f16_kpad(dim) * 64u; }  // 32 rows x kpad x 2 B
+inline uint64_t f16_tiles(uint64_t rows) { return (rows + 31) / 32; }
+
+constexpr uint32_t kF16MaxQ = 64;  // queries per corpus pass (2 MFMA column tiles); larger batches loop
+
+// rows [first, first+n) of `src` (f32 row-major [n][dim]) → fp16 (RNE) into the tiled store.
+int launch_f16_store_rows(void* tiled, const float* src, uint64_t first, uint64_t n, uint32_t dim,
+                          hipStream_t stream);
+// 1/|x| of the STORED (fp16-rounded) rows, accumulated in f32.
+int launch_f16_inv_norm(const void* tiled, uint64_t first, uint64_t n, uint32_t dim, float* inv_norm,
+                        hipStream_t stream);
+// out[i] = row row_idx[i] converted back to f32.
+int launch_f16_gather_rows(const void* tiled, const uint64_t* d_row_idx, uint64_t n, uint32_t dim,
+                           float* d_out, hipStream_t stream);
+// zero the padding rows of the last tile / whole tiles in [first_row, cap_rows)
+int launch_f16_zero_rows(void* tiled, uint64_t first_row, uint64_t end_row, uint32_t dim, hipStream_t stream);
+
+struct F16ScanArgs {
+    const void* tiled = nullptr;
+    const float* inv_norm = nullptr;
+    const float* queries = nullptr;  // q x dim f32 (HBM); converted to fp16 fragments in LDS by every block
+    uint32_t q = 0;                  // 1..64
+    uint32_t dim = 0;
+    uint64_t n_rows = 0;             // rows in the store
+    uint64_t row_begin = 0, row_end = 0;  // rows scanned by this launch (row_begin % 32 == 0)
+    const uint64_t* row_doc = nullptr;
+    const uint32_t* dead = nullptr;
+    const uint64_t* allow = nullptr;
+    uint64_t allow_bits = 0;
+    // dense mode: out_dense[j * dense_stride + (row - row_begin)] = distance (NaN when excluded)
+    float* out_dense = nullptr;
+    uint64_t dense_stride = 0;
+    // filter mode: rows with distance < tau[j] are appended to (cand_dist, cand_row)[j * cand_stride + pos]
+    const float* tau = nullptr;
+    float* cand_dist = nullptr;
+    uint32_t* cand_row = nullptr;
+    uint32_t* cand_count = nullptr;  // q counters (pre-seeded by the caller)
+    uint64_t cand_stride = 0;
+};
+// K2. Algorithmic HBM traffic: (row_end - row_begin) * kpad * 2 bytes per launch (serves all q queries).
+int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream);
+
+// tau[j] = k-th best distance of list j when the list is full, else +inf; and seed the candidate lists
+// with the current best entries: cand[j][0..n_j) = (dist, row), cand_count[j] = n_j.
+int launch_f16_seed_candidates(const float* best_dist, const uint32_t* best_row, const uint32_t* best_n,
+                               uint32_t q, uint32_t k, float* tau, float* cand_dist, uint32_t* cand_row,
+                               uint32_t* cand_count, uint64_t cand_stride, hipStream_t stream);
+
+}  // namespace orama

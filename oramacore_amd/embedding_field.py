@@ -101,14 +101,15 @@ class VectorSearchParams:
 
 class EmbeddingFieldStorage:
     def __init__(self, ctx: Context, model: Model | None = None, *, dimensions: int | None = None,
-                 metric: int = N.METRIC_COSINE, reserve_rows: int = 0):
+                 metric: int = N.METRIC_COSINE, reserve_rows: int = 0, dtype: int = N.DTYPE_F32):
         self._lib = N.load()
         self.ctx = ctx
         self._model = model
         self.dim = int(dimensions if dimensions is not None else model.dimensions())
         h = C.c_void_p()
-        N.check(self._lib.orama_vec_create(ctx.handle, self.dim, metric, N.DTYPE_F32, int(reserve_rows),
+        N.check(self._lib.orama_vec_create(ctx.handle, self.dim, metric, int(dtype), int(reserve_rows),
                                            C.byref(h)))
+        self.dtype = int(dtype)
         self._h = h
 
     def close(self) -> None:

@@ -1,0 +1,131 @@
+"""GPU parity of K2: fp16 storage + batched-query MFMA scan with the fused threshold filter.
+
+The fp16 path is a build-side extension (the reference stores f32 and takes one query — SURVEY F4); its
+parity is defined against the f32 restatement evaluated on the fp16-ROUNDED vectors: the kernel computes the
+exact cosine of the quantised vectors with f32 accumulation, so the 1e-4 bar applies unchanged.
+"""
+import numpy as np
+import pytest
+
+import oramacore_amd as oa
+import util
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def q16(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32))
+
+
+def make_store(ctx, corpus, row_doc=None):
+    n, d = corpus.shape
+    st = oa.EmbeddingFieldStorage(ctx, dimensions=d, dtype=oa.DTYPE_F16)
+    ids = np.arange(n, dtype=np.uint64) if row_doc is None else row_doc
+    assert st.insert_rows(ids, corpus) == n
+    return st
+
+
+def check(st, corpus16, queries, k, allow=None, dead_rows=None, what=""):
+    ids, dist, cnt = st.storage_search(queries, k, allow)
+    for qi in range(queries.shape[0]):
+        full = orc.distances(corpus16, q16(queries[qi])).astype(np.float64)
+        if dead_rows is not None:
+            full[dead_rows] = np.nan
+        if allow is not None:
+            mask = np.array([allow.contains(int(d)) for d in range(corpus16.shape[0])])
+            full[~mask] = np.nan
+        m = int(cnt[qi])
+        util.assert_topk_sound(ids[qi, :m], dist[qi, :m], full, k, TOL, f"{what} q{qi}")
+
+
+@pytest.mark.parametrize("d", [384, 768, 1024, 100])
+@pytest.mark.parametrize("nq", [1, 5, 33, 64, 70])
+def test_head_only_batches(ctx, d, nq):
+    """N below the dense head: every reference model dimension + a padded odd one; batch sizes that hit one and
+    two MFMA column tiles, a ragged tile and the two-pass (> 64 queries) loop."""
+    n = 3000 + d
+    corpus = util.gaussian_rows(n, d, seed=d)
+    queries = util.gaussian_rows(nq, d, seed=d + nq)
+    st = make_store(ctx, corpus)
+    check(st, q16(corpus), queries, 100, what=f"d={d} nq={nq}")
+    # storage round trip: rows come back as the fp16-rounded values
+    rows, docs = st.get_rows(np.array([0, 31, 32, n - 1], dtype=np.uint64))
+    assert np.array_equal(rows, q16(corpus[[0, 31, 32, n - 1]]))
+    st.close()
+
+
+def test_filter_path_random_and_adversarial_order(ctx):
+    """N above the dense head (131072 rows): the rest goes through the threshold filter.  The second corpus is
+    ordered by INCREASING similarity to query 0, so every later row beats the running threshold — the
+    worst case for the candidate lists — and the result must still be exact."""
+    n, d, k = 200_000, 384, 100
+    corpus = util.gaussian_rows(n, d, seed=7)
+    queries = util.gaussian_rows(64, d, seed=8)
+    st = make_store(ctx, corpus)
+    check(st, q16(corpus), queries, k, what="random order")
+    check(st, q16(corpus), queries[:3], 7, what="random order small k")
+    st.close()
+    sim = q16(corpus) @ q16(queries[0]) / np.linalg.norm(q16(corpus), axis=1)
+    order = np.argsort(sim, kind="stable")
+    corpus2 = corpus[order]
+    st = make_store(ctx, corpus2)
+    check(st, q16(corpus2), queries[:4], k, what="adversarial order")
+    st.close()
+
+
+def test_deletes_filter_and_compaction(ctx):
+    n, d, k = 140_000, 384, 50
+    corpus = util.gaussian_rows(n, d, seed=17)
+    queries = util.gaussian_rows(6, d, seed=18)
+    st = make_store(ctx, corpus)
+    dead = np.array([3, 64, 65, 131071, 131072, 139_999], dtype=np.int64)
+    for r in dead:
+        st.delete(int(r))
+    allow = oa.AllowBitmap.from_mask(np.arange(n) % 3 != 0)
+    check(st, q16(corpus), queries, k, dead_rows=dead, what="dead")
+    check(st, q16(corpus), queries, k, allow=allow, dead_rows=dead, what="dead+filter")
+    before = st.storage_search(queries, k)
+    st.compact(3)
+    assert st.info()["num_rows"] == n - len(dead) and not st.has_pending_ops()
+    after = st.storage_search(queries, k)
+    assert np.array_equal(before[0], after[0]) and np.allclose(before[1], after[1], atol=1e-6)
+    st.close()
+
+
+def test_matches_f32_store_up_to_quantisation(ctx):
+    """Same vectors in an f32 store and an fp16 store: distances agree to fp16 quantisation (~1e-3) and the
+    top-10 of well-separated neighbours are identical."""
+    n, d = 20_000, 768
+    corpus = util.gaussian_rows(n, d, seed=27)
+    q = util.gaussian_rows(1, d, seed=28)[0]
+    corpus[:10] = (q[None, :] * np.linspace(1.0, 0.3, 10, dtype=np.float32)[:, None]
+                   + util.gaussian_rows(10, d, seed=29) * np.linspace(0.05, 2.0, 10, dtype=np.float32)[:, None])
+    s32 = oa.EmbeddingFieldStorage(ctx, dimensions=d)
+    s32.insert_rows(np.arange(n, dtype=np.uint64), corpus)
+    s16 = make_store(ctx, corpus)
+    i32, d32, _ = s32.storage_search(q, 10)
+    i16, d16, _ = s16.storage_search(q, 10)
+    assert np.array_equal(i32, i16)
+    assert np.max(np.abs(d32 - d16)) < 2e-3
+    s32.close()
+    s16.close()
+
+
+def test_synthetic_fill_f16_1m(ctx):
+    """1 M x 768 fp16 generated in HBM, batch of 64: planted copies on top, sorted, exact on read-back rows."""
+    n, d, k = 1_000_000, 768, 100
+    st = oa.EmbeddingFieldStorage(ctx, dimensions=d, dtype=oa.DTYPE_F16, reserve_rows=n + 64)
+    st.fill_synthetic(n, seed=0xC0FFEE)
+    queries = util.gaussian_rows(64, d, seed=0xBEEF)
+    st.insert_rows(np.arange(n, n + 64, dtype=np.uint64), queries * np.float32(1.7))
+    ids, dist, cnt = st.storage_search(queries, k)
+    assert np.all(cnt == k)
+    for qi in range(64):
+        assert ids[qi, 0] == n + qi and abs(dist[qi, 0]) < 2e-4
+        assert np.all(np.diff(dist[qi]) >= 0)
+    rows, _ = st.get_rows(ids[5])
+    od = orc.distances(rows, q16(queries[5]))
+    assert np.max(np.abs(od - dist[5])) <= TOL
+    st.close()
