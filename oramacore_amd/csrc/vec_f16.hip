@@ -18,6 +18,8 @@
 // lane = (kgrp << 5) | (row or query), element e ↔ k = 16·kstep + 8·kgrp + e.
 #include "vec_f16.hpp"
 
+#include <cstdlib>
+
 #include "device_utils.hpp"
 
 namespace orama {
@@ -36,7 +38,7 @@ constexpr int kWavesPerBlock = kBlock / 64;
 __device__ __forceinline__ h8 as_h8(f4 v) { return __builtin_bit_cast(h8, v); }
 
 template <int NQT, int KC, int NBUF>
-__global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uint32_t ksteps) {
+__global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uint32_t ksteps, uint64_t tile_bytes) {
     constexpr int kChunk = KC;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
@@ -82,7 +84,6 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
     if (t_first + gw >= t_end) return;
     const uint64_t my_tiles = (t_end - t_first - gw + gwaves - 1) / gwaves;
     const uint32_t nc = ksteps / kChunk;  // chunks per tile
-    const uint64_t tile_bytes = (uint64_t)ksteps * 1024;
     const char* base = reinterpret_cast<const char*>(a.tiled);
 
     f16v acc[NQT];
@@ -195,10 +196,10 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
 // ---------------------------------------------------------------- store / norms / gather
 __global__ __launch_bounds__(256) void f16_store_rows_kernel(char* __restrict__ tiled,
                                                              const float* __restrict__ src, uint64_t first,
-                                                             uint64_t n, uint32_t dim, uint32_t kpad) {
+                                                             uint64_t n, uint32_t dim, uint32_t kpad,
+                                                             uint64_t tile_bytes) {
     const uint32_t pieces = kpad / 8;
     const uint64_t total = n * pieces;
-    const uint64_t tile_bytes = (uint64_t)kpad * 64;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = t / pieces;
@@ -222,13 +223,12 @@ __device__ __forceinline__ h8 f16_piece(const char* tiled, uint64_t row, uint32_
 }
 
 __global__ __launch_bounds__(256) void f16_inv_norm_kernel(const char* __restrict__ tiled, uint64_t first,
-                                                           uint64_t n, uint32_t kpad,
+                                                           uint64_t n, uint32_t kpad, uint64_t tile_bytes,
                                                            float* __restrict__ inv_norm) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     const uint32_t pieces = kpad / 8;
-    const uint64_t tile_bytes = (uint64_t)kpad * 64;
     for (uint64_t i = wave; i < n; i += nwaves) {
         const uint64_t row = first + i;
         float ss = 0.0f;
@@ -244,11 +244,10 @@ __global__ __launch_bounds__(256) void f16_inv_norm_kernel(const char* __restric
 
 __global__ __launch_bounds__(256) void f16_gather_rows_kernel(const char* __restrict__ tiled,
                                                               const uint64_t* __restrict__ idx, uint64_t n,
-                                                              uint32_t dim, uint32_t kpad,
+                                                              uint32_t dim, uint32_t kpad, uint64_t tile_bytes,
                                                               float* __restrict__ out) {
     const uint32_t pieces = kpad / 8;
     const uint64_t total = n * pieces;
-    const uint64_t tile_bytes = (uint64_t)kpad * 64;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = t / pieces;
@@ -279,6 +278,19 @@ __global__ void f16_seed_candidates_kernel(const float* __restrict__ best_dist,
     }
 }
 
+}  // namespace
+
+uint64_t f16_tile_pad() {
+    static const uint64_t pad = [] {
+        uint64_t v = 0;  // measured: no effect on MI355X (profiles/r01_f16_tile_pad_sweep.md), so no padding
+        if (const char* e = std::getenv("ORAMA_F16_TILE_PAD")) v = (uint64_t)std::strtoull(e, nullptr, 10);
+        return (v + 15) & ~15ull;
+    }();
+    return pad;
+}
+
+namespace {
+
 uint32_t blocks_for(uint64_t items, uint32_t per_block, uint32_t cap) {
     uint64_t b = (items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -293,7 +305,7 @@ int launch_f16_store_rows(void* tiled, const float* src, uint64_t first, uint64_
     if (n == 0) return ORAMA_OK;
     const uint32_t kpad = f16_kpad(dim);
     hipLaunchKernelGGL(f16_store_rows_kernel, dim3(blocks_for(n * (kpad / 8), 256, 16384)), dim3(256), 0,
-                       stream, reinterpret_cast<char*>(tiled), src, first, n, dim, kpad);
+                       stream, reinterpret_cast<char*>(tiled), src, first, n, dim, kpad, f16_tile_bytes(dim));
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }
@@ -302,7 +314,7 @@ int launch_f16_inv_norm(const void* tiled, uint64_t first, uint64_t n, uint32_t 
                         hipStream_t stream) {
     if (n == 0) return ORAMA_OK;
     hipLaunchKernelGGL(f16_inv_norm_kernel, dim3(blocks_for(n, 4, 8192)), dim3(256), 0, stream,
-                       reinterpret_cast<const char*>(tiled), first, n, f16_kpad(dim), inv_norm);
+                       reinterpret_cast<const char*>(tiled), first, n, f16_kpad(dim), f16_tile_bytes(dim), inv_norm);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }
@@ -312,7 +324,7 @@ int launch_f16_gather_rows(const void* tiled, const uint64_t* d_row_idx, uint64_
     if (n == 0) return ORAMA_OK;
     const uint32_t kpad = f16_kpad(dim);
     hipLaunchKernelGGL(f16_gather_rows_kernel, dim3(blocks_for(n * (kpad / 8), 256, 16384)), dim3(256), 0,
-                       stream, reinterpret_cast<const char*>(tiled), d_row_idx, n, dim, kpad, d_out);
+                       stream, reinterpret_cast<const char*>(tiled), d_row_idx, n, dim, kpad, f16_tile_bytes(dim), d_out);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }
@@ -344,7 +356,8 @@ int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
             attr_done = true;                                                                              \
         }                                                                                                  \
-        hipLaunchKernelGGL((vec_scan_f16_kernel<NQT_, KC_, NB_>), grid, dim3(kBlock), lds_bytes, stream, a, ksteps); \
+        hipLaunchKernelGGL((vec_scan_f16_kernel<NQT_, KC_, NB_>), grid, dim3(kBlock), lds_bytes, stream, a, ksteps, \
+                           f16_tile_bytes(a.dim));                                                         \
     } while (0)
 #define ORAMA_F16_DISPATCH(NQT_)                                  \
     do {                                                          \

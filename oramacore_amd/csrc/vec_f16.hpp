@@ -11,7 +11,11 @@ namespace orama {
 // A-operand fragment of v_mfma_f32_32x32x16_f16, so every wave-wide 16 B/lane load is one contiguous
 // 1 KiB and a row tile (32 rows) is one contiguous run of kpad*64 bytes.  kpad = dim rounded up to 128.
 inline uint32_t f16_kpad(uint32_t dim) { return (dim + 127u) & ~127u; }
-inline uint64_t f16_tile_bytes(uint32_t dim) { return (uint64_t)f16_kpad(dim) * 64u; }  // 32 rows x kpad x 2 B
+// Bytes between consecutive row tiles: 32 rows x kpad x 2 B of fragments + an optional skew pad
+// (ORAMA_F16_TILE_PAD, bytes).  The pad was an experiment against HBM channel camping (all tiles start at
+// multiples of 48 KiB at dim 768); it measured neutral on MI355X, so the default is 0.
+uint64_t f16_tile_pad();
+inline uint64_t f16_tile_bytes(uint32_t dim) { return (uint64_t)f16_kpad(dim) * 64u + f16_tile_pad(); }
 inline uint64_t f16_tiles(uint64_t rows) { return (rows + 31) / 32; }
 
 constexpr uint32_t kF16MaxQ = 64;  // queries per corpus pass (2 MFMA column tiles); larger batches loop
