@@ -1,0 +1,224 @@
+"""Host-side mirror of the scoring dispatcher and of the minimal index state it reads.
+
+Mirrors (names / argument meaning) `TokenScoreContext` — src/collection_manager/sides/read/index/token_score.rs:
+`search_full_text` :186-303, `search_vector` :309-351, `search_hybrid` :357-387, `execute` :460-509 — and the
+hot part of `search_on_indexes` (src/collection_manager/sides/read/search.rs:297-343, 481-500): filter →
+token scores → OMC → count → top-(limit+offset) → skip/take.
+
+Difference by design: the reference materialises the whole `HashMap<DocumentId, f32>` and selects later;
+here scoring, OMC, count and top-k are one fused device pass, so `execute` returns `(hits, count)`.
+
+What is NOT mirrored (third-party / out of scope): the real tokenizer + stemmer
+(`oramacore_lib::nlp::TextParser`), the FST dictionary with Levenshtein expansion, the embedding model
+(PyO3 service) — `SimpleTokenizer`, `StringFieldStorage`'s prefix lookup and the injected `embed` callable
+are test-scale stand-ins that feed the same interfaces.
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+from typing import Callable, Optional
+
+import numpy as np
+
+from .context import Context
+from .embedding_field import AllowBitmap, EmbeddingFieldStorage, VectorSearchParams
+from .fulltext import B_DEFAULT, K1_DEFAULT, PostingList, PostingsStore, threshold_tokens
+
+
+# ----------------------------------------------------------------------------- modes (src/types.rs:838-940)
+@dataclass
+class FulltextMode:
+    term: str
+    threshold: Optional[float] = None  # Threshold(f32), types.rs:860
+    exact: bool = False
+    tolerance: Optional[int] = None
+
+
+@dataclass
+class VectorMode:
+    term: str
+    similarity: float = 0.7  # Similarity default, types.rs:879-885
+
+
+@dataclass
+class HybridMode:
+    term: str
+    similarity: float = 0.7
+    threshold: Optional[float] = None
+    exact: bool = False
+    tolerance: Optional[int] = None
+
+
+class SimpleTokenizer:
+    """Stand-in for nlp::TextParser::tokenize_and_stem: lowercase alphanumeric runs, no stemming
+    (returns (token, None) pairs like the reference's (String, Option<String>))."""
+
+    _re = re.compile(r"[0-9a-z]+")
+
+    def tokenize_and_stem(self, text: str):
+        return [(t, None) for t in self._re.findall(text.lower())]
+
+
+class StringFieldStorage:
+    """Host-side builder of one string field's postings (what `StringFieldStorage::insert`,
+    index/string_field.rs:155-176, feeds the third-party store): term → (doc, tf), field_length per doc."""
+
+    def __init__(self, tokenizer=None):
+        self.tokenizer = tokenizer or SimpleTokenizer()
+        self.postings: dict[str, dict[int, int]] = {}
+        self.field_len: dict[int, int] = {}
+
+    def insert(self, doc_id: int, text: str) -> None:
+        toks = [t for t, _ in self.tokenizer.tokenize_and_stem(text)]
+        self.field_len[doc_id] = min(len(toks), 0xFFFF)  # field_length: u16
+        for t in toks:
+            d = self.postings.setdefault(t, {})
+            d[doc_id] = min(d.get(doc_id, 0) + 1, 0xFFFF)
+
+    def delete(self, doc_id: int) -> None:
+        self.field_len.pop(doc_id, None)
+        for d in self.postings.values():
+            d.pop(doc_id, None)
+
+    def avg_field_length(self) -> float:
+        return float(np.float32(np.mean(list(self.field_len.values())))) if self.field_len else 1.0
+
+
+@dataclass
+class Index:
+    """The slice of the read-side `Index` the hot path reads (IndexSearchStore, index/mod.rs:88-105):
+    document_count, string fields, embedding fields, OMC map."""
+
+    ctx: Context
+    string_fields: dict[int, StringFieldStorage] = field(default_factory=dict)
+    embedding_fields: dict[int, EmbeddingFieldStorage] = field(default_factory=dict)
+    omc: dict[int, float] = field(default_factory=dict)
+    document_ids: set = field(default_factory=set)
+    _post: Optional[PostingsStore] = None
+    _lists: dict = field(default_factory=dict)      # (field_id, term) -> list id
+    _terms: dict = field(default_factory=dict)      # field_id -> sorted term list
+
+    @property
+    def document_count(self) -> int:
+        return len(self.document_ids)
+
+    def commit(self) -> None:
+        """Export the committed postings to HBM (the GPU side of `compact`, INTEGRATION.md §3 ii)."""
+        docs = np.array(sorted(self.document_ids), dtype=np.uint64)
+        field_ids = sorted(self.string_fields)
+        lists, self._lists, self._terms = [], {}, {}
+        for fi, fid in enumerate(field_ids):
+            sf = self.string_fields[fid]
+            self._terms[fid] = sorted(sf.postings)
+            for term in self._terms[fid]:
+                pl = sorted((d, tf) for d, tf in sf.postings[term].items() if d in self.document_ids)
+                if not pl:
+                    continue
+                d = np.array([x[0] for x in pl], dtype=np.uint64)
+                self._lists[(fid, term)] = len(lists)
+                lists.append(PostingList(field=fi, docs=d, tf=np.array([x[1] for x in pl]),
+                                         field_len=np.array([sf.field_len[int(x)] for x in d])))
+        if self._post is None:
+            self._post = PostingsStore(self.ctx)
+        self._post.build(docs, [self.string_fields[f].avg_field_length() for f in field_ids], lists)
+        if self.omc:
+            self._post.set_omc(self.omc)
+        self._field_order = field_ids
+
+    def lookup(self, field_id: int, token: str, exact: bool) -> list[int]:
+        """Dictionary step of collect_contributions: exact term, or (non-exact) every term with the token as
+        prefix — evidenced by src/tests/fulltext_search.rs:603-753 ("christoph" matches "christopher")."""
+        if exact:
+            l = self._lists.get((field_id, token))
+            return [] if l is None else [l]
+        import bisect
+
+        terms = self._terms.get(field_id, [])
+        i = bisect.bisect_left(terms, token)
+        out = []
+        while i < len(terms) and terms[i].startswith(token):
+            l = self._lists.get((field_id, terms[i]))
+            if l is not None:
+                out.append(l)
+            i += 1
+        return out
+
+
+@dataclass
+class TokenScoreParams:
+    mode: object
+    properties: Optional[list[int]] = None       # string field ids; None = all (Properties::None | Star)
+    boost: dict = field(default_factory=dict)    # field_id -> boost
+    limit: int = 10                              # Limit default 10, types.rs:748-754
+    offset: int = 0
+    filtered_doc_ids: Optional[AllowBitmap] = None
+
+
+class TokenScoreContext:
+    def __init__(self, index: Index, embed: Callable[[str, object], np.ndarray] | None = None, tokenizer=None):
+        self.index = index
+        self.embed = embed
+        self.text_parser = tokenizer or SimpleTokenizer()
+
+    # token_score.rs:196-209
+    def _tokens(self, term: str, exact: bool) -> list[str]:
+        toks = self.text_parser.tokenize_and_stem(term)
+        out = [t for t, _ in toks] if exact else [x for t, s in toks for x in ((t,) if s is None else (t, s))]
+        return out or [""]
+
+    def _refs(self, tokens, properties, boost, exact):
+        fields = sorted(self.index.string_fields) if properties is None else sorted(
+            f for f in properties if f in self.index.string_fields)  # canonical order: ascending FieldId
+        refs = []
+        for ti, tok in enumerate(tokens):
+            for fid in fields:
+                for l in self.index.lookup(fid, tok, exact):
+                    refs.append((ti, l, float(boost.get(fid, 1.0))))
+        return refs
+
+    # token_score.rs:186-303 (+ OMC, count, top-(limit+offset) fused)
+    def search_full_text(self, mode: FulltextMode, params: TokenScoreParams, vector: dict | None = None):
+        if mode.tolerance not in (None, 0):
+            raise NotImplementedError("Levenshtein expansion lives in the third-party dictionary (SURVEY §8f rank 4)")
+        tokens = self._tokens(mode.term, mode.exact)
+        thr = None if mode.threshold is None else threshold_tokens(len(tokens), mode.threshold)
+        refs = self._refs(tokens, params.properties, params.boost, mode.exact)
+        return self.index._post.search(refs, len(tokens), float(self.index.document_count),
+                                       params.limit + params.offset, thr, allow=params.filtered_doc_ids,
+                                       apply_omc=bool(self.index.omc), b=B_DEFAULT, k=K1_DEFAULT, vector=vector)
+
+    # token_score.rs:309-351 — returns the map after the a2 epilogue
+    def search_vector(self, mode, params: TokenScoreParams) -> dict:
+        output: dict = {}
+        for fid in sorted(self.index.embedding_fields):
+            ef = self.index.embedding_fields[fid]
+            target = self.embed(mode.term, ef.model())
+            ef.search(VectorSearchParams(target=target, similarity=mode.similarity, limit=params.limit,
+                                         filtered_doc_ids=params.filtered_doc_ids), output)
+        return output
+
+    # token_score.rs:460-509 + search.rs:342-343, 481-500
+    def execute(self, params: TokenScoreParams):
+        """Returns (hits [(doc_id, score)] after skip(offset).take(limit), count)."""
+        from . import fulltext as ft
+
+        m = params.mode
+        top = params.limit + params.offset
+        if isinstance(m, FulltextMode):
+            ids, sc, count = self.search_full_text(m, params)
+        elif isinstance(m, VectorMode):
+            vec = self.search_vector(m, params)
+            if self.index.omc:
+                vec = {d: np.float32(s * np.float32(self.index.omc[d])) if d in self.index.omc else s
+                       for d, s in vec.items()}
+            ids, sc = ft.top_n(self.index.ctx, vec, top) if vec else (np.zeros(0, np.uint64), np.zeros(0, np.float32))
+            count = len(vec)
+        elif isinstance(m, HybridMode):
+            vec = self.search_vector(m, params)
+            ids, sc, count = self.search_full_text(
+                FulltextMode(m.term, m.threshold, m.exact, m.tolerance), params, vector=vec)
+        else:
+            raise TypeError(f"unknown score mode {type(m)}")
+        hits = list(zip(ids.tolist(), sc.tolist()))[params.offset: params.offset + params.limit]
+        return hits, count

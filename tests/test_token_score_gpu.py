@@ -1,0 +1,200 @@
+"""End-to-end replicas of the reference's search tests on the scoring dispatcher mirror (GPU).
+
+The reference's tests are ordinal/cardinal (src/tests/fulltext_search.rs, vector_search.rs) and run a real
+tokenizer + embedding model; here `SimpleTokenizer` and a deterministic fake `embed` stand in for those
+(out-of-scope) components, and every result is additionally compared with the oracle pipeline.
+"""
+import numpy as np
+import pytest
+
+import oramacore_amd as oa
+import util
+from oracle import oracle as orc
+from oramacore_amd.token_score import (FulltextMode, HybridMode, Index, StringFieldStorage, TokenScoreContext,
+                                       TokenScoreParams, VectorMode)
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def make_index(ctx, docs: dict, fields=("text",)):
+    idx = Index(ctx)
+    for fi, name in enumerate(fields):
+        idx.string_fields[fi] = StringFieldStorage()
+    for doc_id, doc in docs.items():
+        idx.document_ids.add(doc_id)
+        for fi, name in enumerate(fields):
+            if name in doc:
+                idx.string_fields[fi].insert(doc_id, doc[name])
+    idx.commit()
+    return idx
+
+
+def oracle_fulltext(idx: Index, tokens, exact, boost=None, threshold=None, allow=None):
+    """The same query through the oracle: entries built on the host from the index's postings."""
+    entries = []
+    for ti, tok in enumerate(tokens):
+        for fid in sorted(idx.string_fields):
+            sf = idx.string_fields[fid]
+            terms = [tok] if exact else [t for t in sorted(sf.postings) if t.startswith(tok)]
+            for term in terms:
+                if term not in sf.postings:
+                    continue
+                pl = sorted(sf.postings[term].items())
+                if allow is not None:
+                    pl = [(d, tf) for d, tf in pl if allow.contains(d)]
+                docs = [d for d, _ in pl]
+                ntf = [F(F((boost or {}).get(fid, 1.0)) * orc.bm25f_normalized_tf(tf, sf.field_len[d],
+                                                                                  sf.avg_field_length(), 0.75))
+                       for d, tf in pl]
+                entries.append((ti, docs, ntf))
+    return orc.search_full_text(entries, len(tokens), float(idx.document_count), 1.2, threshold)
+
+
+def test_search_documents_order(ctx):
+    """src/tests/fulltext_search.rs:146-189 — the shorter document ranks first."""
+    idx = make_index(ctx, {1: {"text": "This is a long text with a lot of words"}, 2: {"text": "This is a smaller text"}})
+    hits, count = TokenScoreContext(idx).execute(TokenScoreParams(mode=FulltextMode("text")))
+    assert count == 2 and [h[0] for h in hits] == [2, 1] and hits[0][1] > hits[1][1]
+
+
+def test_fulltext_threshold(ctx):
+    """src/tests/fulltext_search.rs:478-600 — threshold = fraction of query tokens a document must match."""
+    idx = make_index(ctx, {1: {"text": "The pen is on the table"},
+                           2: {"text": "the pen", "text2": "is on the table"},
+                           3: {"text": "the pen"}}, fields=("text", "text2"))
+    tsc = TokenScoreContext(idx)
+
+    def n_hits(term, thr):
+        hits, count = tsc.execute(TokenScoreParams(mode=FulltextMode(term, threshold=thr)))
+        assert count == len(hits)
+        return len(hits)
+
+    assert n_hits("the pen is on the table", 0.7) == 2
+    assert n_hits("the pen is on the table", 1.0) == 2
+    assert n_hits("pen", 0.0) == 3
+    assert n_hits("pen", 1.0) == 3
+
+
+def test_prefix_vs_exact(ctx):
+    """src/tests/fulltext_search.rs:603-753 — "christoph" matches "Christopher" unless `exact`."""
+    idx = make_index(ctx, {1: {"text": "Christopher Nolan"}, 2: {"text": "Christoph Waltz"}, 3: {"text": "Someone else"}})
+    tsc = TokenScoreContext(idx)
+    hits, count = tsc.execute(TokenScoreParams(mode=FulltextMode("christoph")))
+    assert count == 2 and {h[0] for h in hits} == {1, 2}
+    hits, count = tsc.execute(TokenScoreParams(mode=FulltextMode("christoph", exact=True)))
+    assert count == 1 and hits[0][0] == 2
+    # the exact token outranks the prefix match (src/tests/boost_integration.rs:449-491 in spirit)
+    hits, _ = tsc.execute(TokenScoreParams(mode=FulltextMode("christoph")))
+    od, os_ = oracle_fulltext(idx, ["christoph"], exact=False)
+    td, ts = orc.top_n(od, os_, 10)
+    assert [h[0] for h in hits] == td.tolist()
+    assert np.array_equal(np.array([h[1] for h in hits], dtype=np.float32).view(np.uint32), ts.view(np.uint32))
+
+
+def test_empty_term_and_paging(ctx):
+    idx = make_index(ctx, {i: {"text": "text " * (i + 1)} for i in range(100)})
+    tsc = TokenScoreContext(idx)
+    # src/tests/fulltext_search.rs:192-251: 99, 98, … with limit 10, count 100
+    hits, count = tsc.execute(TokenScoreParams(mode=FulltextMode("text"), limit=10))
+    assert count == 100 and [h[0] for h in hits] == list(range(99, 89, -1))
+    # :254-335 offset paging
+    hits, count = tsc.execute(TokenScoreParams(mode=FulltextMode("text"), limit=5, offset=20))
+    assert count == 100 and [h[0] for h in hits] == [79, 78, 77, 76, 75]
+    # unknown term: nothing
+    hits, count = tsc.execute(TokenScoreParams(mode=FulltextMode("absent")))
+    assert count == 0 and hits == []
+
+
+@pytest.mark.parametrize("n", [1000, 5000])
+def test_fulltext_simple_bench_workload(ctx, n):
+    """BASELINE configs[0] (plumbing): the benches/fulltext_simple.rs:383-400 corpus and queries
+    ("technology", "technology software", "development", limit 10) — results identical to the oracle."""
+    docs = {i: {"text": f"document content technology software development number {i}"} for i in range(n)}
+    idx = make_index(ctx, docs)
+    tsc = TokenScoreContext(idx)
+    for term in ("technology", "technology software", "development", "number 7"):
+        hits, count = tsc.execute(TokenScoreParams(mode=FulltextMode(term), limit=10))
+        toks = [t for t, _ in tsc.text_parser.tokenize_and_stem(term)]
+        od, os_ = oracle_fulltext(idx, toks, exact=False)
+        td, ts = orc.top_n(od, os_, 10)
+        assert count == len(od)
+        assert [h[0] for h in hits] == td.tolist(), term
+        assert np.array_equal(np.array([h[1] for h in hits], dtype=np.float32).view(np.uint32), ts.view(np.uint32))
+    assert count >= 1
+
+
+def test_boost_and_filter_and_omc(ctx):
+    docs = {i: {"title": f"alpha beta {'gamma ' * (i % 3)}", "body": f"beta {'alpha ' * (i % 5)} delta"} for i in range(200)}
+    idx = make_index(ctx, docs, fields=("title", "body"))
+    idx.omc = {3: 2.0, 7: 0.25, 150: 10.0}
+    idx.commit()
+    tsc = TokenScoreContext(idx)
+    allow = oa.AllowBitmap.from_mask(np.arange(200) % 4 != 1)
+    for boost in ({}, {0: 2.0}, {1: 0.5, 0: 3.0}):
+        for flt in (None, allow):
+            hits, count = tsc.execute(TokenScoreParams(mode=FulltextMode("alpha gamma"), boost=boost, limit=15,
+                                                       filtered_doc_ids=flt))
+            od, os_ = oracle_fulltext(idx, ["alpha", "gamma"], exact=False, boost=boost, allow=flt)
+            os_ = orc.apply_omc(od, os_, list(idx.omc), list(idx.omc.values()))
+            td, ts = orc.top_n(od, os_, 15)
+            assert count == len(od) and [h[0] for h in hits] == td.tolist()
+            assert np.array_equal(np.array([h[1] for h in hits], dtype=np.float32).view(np.uint32), ts.view(np.uint32))
+
+
+def fake_embed(dim):
+    def embed(term: str, model):
+        seed = sum(ord(c) * (i + 1) for i, c in enumerate(term)) % 100000
+        return util.gaussian_rows(1, dim, seed=seed, scale_rows=False)[0]
+    return embed
+
+
+def test_vector_and_hybrid_modes(ctx):
+    """search_vector + search_hybrid (token_score.rs:309-387): a fake deterministic embedder, multi-row docs
+    (chunked long text → several vectors per doc, src/tests/vector_search.rs:638-679), similarity cut-off, then
+    the full oracle pipeline: scan → epilogue → min-max combine with BM25F → OMC → top-n."""
+    dim, n = 384, 400
+    docs = {i: {"text": ("red " * (i % 4 + 1)) + ("blue " if i % 3 else "") + f"item{i}"} for i in range(n)}
+    idx = make_index(ctx, docs)
+    ef = oa.EmbeddingFieldStorage(ctx, oa.Model.BGESmall)
+    embed = fake_embed(dim)
+    q = embed("red blue", None)
+    rng = np.random.default_rng(5)
+    rows, row_doc = [], []
+    for i in range(n):
+        for c in range(1 + i % 3):  # 1-3 chunks per doc
+            noise = rng.standard_normal(dim).astype(np.float32)
+            w = np.float32(0.95 if i % 10 == 0 else 0.2)
+            rows.append(w * q / np.linalg.norm(q) + (1 - w) * noise / np.linalg.norm(noise))
+            row_doc.append(i)
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    row_doc = np.array(row_doc, dtype=np.uint64)
+    ef.insert_rows(row_doc, rows)
+    idx.embedding_fields[0] = ef
+    idx.omc = {0: 3.0, 10: 0.5}
+    idx.commit()
+    tsc = TokenScoreContext(idx, embed=embed)
+
+    # vector mode: hits are docs, chunk scores summed; cut-off 0.7 keeps only the near-duplicates
+    # (limit counts ROWS, like the reference's storage: 200 covers every chunk of the ~40 near-duplicate docs)
+    hits, count = tsc.execute(TokenScoreParams(mode=VectorMode("red blue", similarity=0.7), limit=200))
+    o_ids, o_dist, _ = orc.vector_search(rows, row_doc, q, 200)
+    omap = orc.embedding_epilogue(o_ids, o_dist, False, 0.7)
+    assert count == len(omap) and {h[0] for h in hits} == set(omap)
+    assert all(h[0] % 10 == 0 for h in hits)
+    for d, s in hits:
+        exp = float(omap[d]) * idx.omc.get(d, 1.0)
+        assert abs(s - exp) <= 1e-3
+
+    # hybrid mode, bit-exact combine given the device's own vector map
+    for sim in (0.0, 0.7):
+        params = TokenScoreParams(mode=HybridMode("red blue", similarity=sim), limit=20)
+        hits, count = tsc.execute(params)
+        vec = tsc.search_vector(params.mode, params)
+        fd, fs = oracle_fulltext(idx, ["red", "blue"], exact=False)
+        cd, cs = orc.normalize_and_combine(list(vec), list(vec.values()), fd, fs)
+        cs = orc.apply_omc(cd, cs, list(idx.omc), list(idx.omc.values()))
+        td, ts = orc.top_n(cd, cs, 20)
+        assert count == len(cd) and [h[0] for h in hits] == td.tolist()
+        assert np.array_equal(np.array([h[1] for h in hits], dtype=np.float32).view(np.uint32), ts.view(np.uint32))
+    ef.close()

@@ -241,3 +241,52 @@ def test_synthetic_fill_properties_1m(ctx):
     md, ms = orc.top_n(np.concatenate([ie[0], io[0]]), -np.concatenate([de[0], do[0]]), k)
     assert np.array_equal(md, ids[0]) and np.array_equal(-ms, dist[0])
     st.close()
+
+
+def test_concurrent_searches_with_inserts_and_deletes(ctx):
+    """Re-entrancy contract of the ABI (the reference calls search(&self) from many tokio workers while
+    update_data(&self) inserts — collection.rs:846-884, index/mod.rs:1436): 8 threads search while another
+    thread appends rows and tombstones documents that are far from the queries; every search must return the
+    same exact answer."""
+    import threading
+
+    d, n = 384, 60_000
+    corpus = util.gaussian_rows(n, d, seed=101)
+    queries = util.gaussian_rows(8, d, seed=102)
+    for qi in range(8):  # plant clear winners so that appended noise never enters the top-10
+        for j in range(10):
+            corpus[qi * 100 + j] = queries[qi] * np.float32(1 + j) + util.gaussian_rows(1, d, seed=qi * 31 + j)[0] * np.float32(0.05 * (j + 1))
+    st = make_store(ctx, corpus)
+    expected = [st.storage_search(queries[qi], 10) for qi in range(8)]
+    errors = []
+    stop = threading.Event()
+
+    def searcher(qi):
+        try:
+            for _ in range(25):
+                ids, dist, cnt = st.storage_search(queries[qi], 10)
+                assert np.array_equal(ids, expected[qi][0]) and np.array_equal(dist, expected[qi][1])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def mutator():
+        try:
+            i = 0
+            while not stop.is_set() and i < 15:
+                extra = util.gaussian_rows(500, d, seed=500 + i)
+                st.insert_rows(np.arange(n + i * 500, n + (i + 1) * 500, dtype=np.uint64), extra)
+                st.delete(n - 1 - i)  # rows far from every planted winner
+                i += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=searcher, args=(qi,)) for qi in range(8)] + [threading.Thread(target=mutator)]
+    for t in threads:
+        t.start()
+    for t in threads[:-1]:
+        t.join()
+    stop.set()
+    threads[-1].join()
+    assert not errors, errors
+    assert st.info()["num_rows"] > n
+    st.close()
