@@ -203,6 +203,18 @@ int orama_post_build(orama_post* p, const uint64_t* docs, uint64_t n_docs, uint3
                      const float* avg_field_len, uint32_t n_lists, const uint32_t* field_of_list,
                      const uint64_t* list_off, const uint64_t* post_doc, const uint32_t* post_tf,
                      const uint32_t* post_len);
+/* Bench utility (no reference counterpart): synthetic postings generated in HBM.  n_docs documents
+ * with dense ids [first_doc_id, first_doc_id + n_docs), one field, field length ~ LogNormal(4.0, 0.6) clipped to
+ * [4, 2000]; list l models the term of Zipf(1.07) rank ranks[l] over a 2^20 vocabulary:
+ * df = n_docs * (1 - exp(-avg_len * rank^-1.07 / H)), docs stratified-uniform, tf in 1..3. */
+int orama_post_fill_synthetic(orama_post* p, uint64_t n_docs, uint64_t first_doc_id, uint32_t n_lists,
+                              const uint32_t* ranks, uint64_t seed, uint64_t* out_total_postings);
+
+/* Read back one posting list (test/bench checker) and the store's shape (StringStorage::info()). */
+int orama_post_get_list(orama_post* p, uint32_t list, uint64_t capacity, uint64_t* out_doc, uint32_t* out_tf,
+                        uint32_t* out_len, uint64_t* out_n);
+int orama_post_info(orama_post* p, uint64_t* n_docs, uint32_t* n_lists, uint64_t* n_postings, float* avg_len0);
+
 /* OMC multipliers of the index (Index::get_all_omc, index/mod.rs:1720-1739); doc ids ascending. */
 int orama_post_set_omc(orama_post* p, const uint64_t* omc_doc, const float* omc_mul, uint64_t n);
 
@@ -234,6 +246,16 @@ int orama_post_search_hybrid(orama_post* p, const orama_term_ref* refs, uint32_t
                              uint64_t bitmap_bits, const uint64_t* vec_doc, const float* vec_score,
                              uint32_t n_vec, int apply_omc, uint64_t* out_ids, float* out_scores,
                              uint32_t* out_n, uint64_t* out_count);
+
+/* search_hybrid as ONE call (token_score.rs:357-387): the vector leg (scan + top-`limit` rows of `query` in `v`)
+ * and the full-text leg over `p` run concurrently on two HIP streams; the in-tree epilogue of
+ * EmbeddingFieldStorage::search (embedding_field.rs:268-276: similarity = 1 - distance, Model::rescale_score when
+ * rescale_e5 != 0, `>= min_similarity` cut-off, per-document sum) is applied to the <= limit hits, then
+ * normalize_and_combine + OMC + count + top-k run on the device. `v` and `p` must belong to the same context. */
+int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_t limit, float min_similarity,
+                        int rescale_e5, const orama_term_ref* refs, uint32_t n_refs, float b,
+                        const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits,
+                        int apply_omc, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count);
 
 /* Standalone normalize_and_combine on host-provided maps (both sides small or large) — the
  * literal replacement of token_score.rs:393-422 + top_n for callers that keep seam (i). */

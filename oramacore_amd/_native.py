@@ -140,10 +140,15 @@ def _declare(lib: C.CDLL) -> None:
         "orama_post_create": [vp, C.POINTER(vp)],
         "orama_post_build": [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_uint32, vp, vp, vp, vp, vp],
         "orama_post_set_omc": [vp, vp, vp, C.c_uint64],
+        "orama_post_get_list": [vp, C.c_uint32, C.c_uint64, vp, vp, vp, u64p],
+        "orama_post_info": [vp, u64p, u32p, u64p, f32p],
+        "orama_post_fill_synthetic": [vp, C.c_uint64, C.c_uint64, C.c_uint32, vp, C.c_uint64, u64p],
         "orama_post_search": [vp, C.POINTER(TermRef), C.c_uint32, C.c_float, C.POINTER(Bm25Params), vp,
                               C.c_uint64, C.c_int, vp, vp, u32p, u64p],
         "orama_post_search_hybrid": [vp, C.POINTER(TermRef), C.c_uint32, C.c_float, C.POINTER(Bm25Params), vp,
                                      C.c_uint64, vp, vp, C.c_uint32, C.c_int, vp, vp, u32p, u64p],
+        "orama_hybrid_search": [vp, vp, vp, C.c_uint32, C.c_float, C.c_int, C.POINTER(TermRef), C.c_uint32, C.c_float,
+                                C.POINTER(Bm25Params), vp, C.c_uint64, C.c_int, vp, vp, u32p, u64p],
         "orama_hybrid_combine": [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u32p, u64p],
         "orama_top_n": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u32p],
     }

@@ -132,15 +132,26 @@ __global__ __launch_bounds__(kThreads) void bm25_finalize_kernel(Bm25Finalize f)
             my_min = min(my_min, key);
         }
     }
-    if (TRACK_MINMAX) {
+    if (TRACK_MINMAX) {  // wave reduce → LDS block reduce → ONE pair of atomics per block
+        __shared__ uint32_t blk_max, blk_min;
+        if (threadIdx.x == 0) {
+            blk_max = 0u;
+            blk_min = 0xffffffffu;
+        }
+        __syncthreads();
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, off, 64));
             my_min = min(my_min, (uint32_t)__shfl_xor((int)my_min, off, 64));
         }
         if ((threadIdx.x & 63) == 0) {
-            if (my_max != 0u) atomicMax(&f.state->max_key, my_max);
-            if (my_min != 0xffffffffu) atomicMin(&f.state->min_key, my_min);
+            atomicMax(&blk_max, my_max);
+            atomicMin(&blk_min, my_min);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (blk_max != 0u) atomicMax(&f.state->max_key, blk_max);
+            if (blk_min != 0xffffffffu) atomicMin(&f.state->min_key, blk_min);
         }
     }
 }
@@ -241,6 +252,52 @@ __global__ __launch_bounds__(kThreads) void omc_sparse_kernel(const uint32_t* __
     }
 }
 
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(kThreads) void synth_doc_len_kernel(uint16_t* __restrict__ len, uint64_t n_docs,
+                                                                 uint64_t seed) {
+    for (uint64_t d = (uint64_t)blockIdx.x * kThreads + threadIdx.x; d < n_docs;
+         d += (uint64_t)gridDim.x * kThreads) {
+        const uint64_t h = mix64(seed ^ (d * 0xD1342543DE82EF95ull));
+        const float u1 = ((float)((uint32_t)h >> 8) + 1.0f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)((uint32_t)(h >> 32) >> 8) + 1.0f) * (1.0f / 16777216.0f);
+        const float z = sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2);
+        float l = __expf(4.0f + 0.6f * z);
+        l = fminf(fmaxf(rintf(l), 4.0f), 2000.0f);
+        len[d] = (uint16_t)l;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void synth_postings_kernel(uint32_t* __restrict__ post_doc,
+                                                                  uint32_t* __restrict__ post_val,
+                                                                  const uint64_t* __restrict__ list_off,
+                                                                  uint32_t n_lists, uint64_t n_docs,
+                                                                  const uint16_t* __restrict__ len, uint64_t seed,
+                                                                  uint64_t total) {
+    for (uint64_t p = (uint64_t)blockIdx.x * kThreads + threadIdx.x; p < total;
+         p += (uint64_t)gridDim.x * kThreads) {
+        uint32_t lo = 0, hi = n_lists;  // list_off[lo] <= p < list_off[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (list_off[mid] <= p) lo = mid; else hi = mid;
+        }
+        const uint64_t i = p - list_off[lo];
+        const uint64_t df = list_off[lo + 1] - list_off[lo];
+        // integer strata: doc in [i*N/df, (i+1)*N/df) — ascending and unique because df <= N
+        const uint64_t base = (i * n_docs) / df, next = ((i + 1) * n_docs) / df;
+        const uint64_t h = mix64(seed ^ ((uint64_t)lo * 0x2545F4914F6CDD1Dull) ^ (i * 0x9E3779B97F4A7C15ull));
+        const uint64_t doc = base + (h >> 11) % (next - base);
+        const uint32_t tf = ((h & 3u) == 0u) ? 2u + (uint32_t)((h >> 2) & 1u) : 1u;
+        post_doc[p] = (uint32_t)doc;
+        post_val[p] = (tf << 16) | (uint32_t)len[doc];
+    }
+}
+
 uint32_t grid_for(uint64_t items, orama_ctx* ctx, uint32_t per_thread = 4) {
     uint64_t blocks = (items + (uint64_t)kThreads * per_thread - 1) / ((uint64_t)kThreads * per_thread);
     const uint64_t cap = (uint64_t)ctx->compute_units * 8u;
@@ -269,7 +326,8 @@ int launch_bm25_finalize(orama_ctx* ctx, const Bm25Finalize& f, hipStream_t stre
                   f.n_tokens, kMaxTokens);
     ORAMA_REQUIRE(f.idf_table || f.idf_vals, "bm25: idf source missing");
     ProfScope prof(&ctx->prof, "bm25_finalize", stream);
-    const dim3 grid(grid_for(f.touched_cap ? f.touched_cap : 1, ctx, 1));
+    dim3 grid(grid_for(f.touched_cap ? f.touched_cap : 1, ctx, 1));
+    if (f.track_minmax && grid.x > (uint32_t)ctx->compute_units * 2u) grid.x = (uint32_t)ctx->compute_units * 2u;
     if (f.track_minmax)
         hipLaunchKernelGGL(bm25_finalize_kernel<true>, grid, dim3(kThreads), 0, stream, f);
     else
@@ -296,6 +354,27 @@ int launch_hybrid_combine(orama_ctx* ctx, const HybridCombine& h, hipStream_t st
     if (h.omc_dense)
         hipLaunchKernelGGL(omc_dense_kernel, dim3(grid_for(h.cand_cap + h.n_vec, ctx, 1)), dim3(kThreads),
                            0, stream, h.omc_dense, h.state, h.cand_idx, h.cand_score);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_synth_doc_len(uint16_t* d_len, uint64_t n_docs, uint64_t seed, hipStream_t stream) {
+    if (n_docs == 0) return ORAMA_OK;
+    uint64_t blocks = (n_docs + kThreads - 1) / kThreads;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(synth_doc_len_kernel, dim3((uint32_t)blocks), dim3(kThreads), 0, stream, d_len, n_docs, seed);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_synth_postings(uint32_t* post_doc, uint32_t* post_val, const uint64_t* d_list_off, uint32_t n_lists,
+                          uint64_t n_docs, const uint16_t* d_len, uint64_t seed, uint64_t total,
+                          hipStream_t stream) {
+    if (total == 0) return ORAMA_OK;
+    uint64_t blocks = (total + kThreads - 1) / kThreads;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(synth_postings_kernel, dim3((uint32_t)blocks), dim3(kThreads), 0, stream, post_doc, post_val,
+                       d_list_off, n_lists, n_docs, d_len, seed, total);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -100,4 +100,13 @@ int launch_hybrid_ingest(orama_ctx* ctx, uint32_t n, uint32_t epoch, const uint3
 int launch_omc_sparse(const uint32_t* d_idx, const float* d_mul, uint32_t n, uint32_t epoch,
                       const unsigned long long* emit, float* cand_score, hipStream_t stream);
 
+// ---- synthetic postings generated in HBM (bench utility)
+// len[doc] ~ LogNormal(4.0, 0.6) clipped to [4, 2000]
+int launch_synth_doc_len(uint16_t* d_len, uint64_t n_docs, uint64_t seed, hipStream_t stream);
+// list l = postings [list_off[l], list_off[l+1]): docs stratified-uniform over [0, n_docs) (ascending, unique),
+// tf in 1..3, field length from d_len.
+int launch_synth_postings(uint32_t* post_doc, uint32_t* post_val, const uint64_t* d_list_off, uint32_t n_lists,
+                          uint64_t n_docs, const uint16_t* d_len, uint64_t seed, uint64_t total,
+                          hipStream_t stream);
+
 }  // namespace orama

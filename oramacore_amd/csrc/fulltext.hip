@@ -15,6 +15,7 @@
 #include "bm25_kernels.hpp"
 #include "common.hpp"
 #include "select.hpp"
+#include "vec_internal.hpp"
 
 using namespace orama;
 
@@ -154,7 +155,21 @@ struct orama_post {
     uint32_t n_fields = 0;
     uint32_t n_lists = 0;
     uint64_t n_postings = 0;
-    std::vector<uint64_t> h_docs;
+    std::vector<uint64_t> h_docs;  // empty when the ids are dense (docs[i] = dense_base + i)
+    bool dense = false;
+    uint64_t dense_base = 0;
+    // DocumentId -> local index (rank of the id); false when the id is not a document of this index
+    bool local_of(uint64_t id, uint32_t* out) const {
+        if (dense) {
+            if (id < dense_base || id - dense_base >= n_docs) return false;
+            *out = (uint32_t)(id - dense_base);
+            return true;
+        }
+        auto it = std::lower_bound(h_docs.begin(), h_docs.end(), id);
+        if (it == h_docs.end() || *it != id) return false;
+        *out = (uint32_t)(it - h_docs.begin());
+        return true;
+    }
     std::vector<float> avg_len;
     std::vector<uint32_t> field_of_list;
     std::vector<uint64_t> list_off;
@@ -184,22 +199,25 @@ int ensure_idf_table(orama_post* p, float total_documents, hipStream_t s) {
     return ORAMA_OK;
 }
 
-int post_search_impl(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, float b,
-                     const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits,
-                     const uint64_t* vec_doc, const float* vec_score, uint32_t n_vec, bool hybrid,
-                     int apply_omc, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
-                     uint64_t* out_count) {
-    ORAMA_REQUIRE(p && out_n, "null argument");
-    *out_n = 0;
-    if (out_count) *out_count = 0;
+// State of one resident-postings query between its two stages.
+struct PostQuery {
+    QueryBuffers qb;
+    uint64_t touched_cap = 0;
+    uint64_t cand_cap = 0;
+    size_t vec_stage_off = 0;  // byte offset of the stage-2 staging area inside sc->h_in (after the segments)
+    uint32_t n_vec_cap = 0;
+    bool hybrid = false;
+    const float* omc = nullptr;
+};
+
+// Stage 1 (independent of the vector leg): descriptor upload, K3 accumulate (one launch per entry rank),
+// K3 finalise (+ min/max of the full-text scores when hybrid).  Everything is enqueued on sc->stream.
+int post_stage1(orama_post* p, Scratch* sc, const orama_term_ref* refs, uint32_t n_refs, float b,
+                const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits, bool hybrid,
+                int apply_omc, uint32_t n_vec_cap, PostQuery* st) {
     ORAMA_TRY(check_params(params));
     ORAMA_REQUIRE(n_refs == 0 || refs, "null refs");
-    ORAMA_REQUIRE(params->top_k == 0 || (out_ids && out_scores), "null output");
-    ORAMA_REQUIRE(!hybrid || n_vec == 0 || (vec_doc && vec_score), "null vector map");
-    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
-    std::shared_lock<std::shared_mutex> lk(p->mu);
     ORAMA_REQUIRE(p->n_docs > 0 || n_refs == 0, "postings store is empty (orama_post_build not called)");
-
     // group references by entry rank (position inside their token); rank r of every token forms one launch
     std::vector<uint32_t> rank(n_refs, 0), per_token(kMaxTokens, 0);
     uint32_t max_rank = 0;
@@ -213,24 +231,13 @@ int post_search_impl(orama_post* p, const orama_term_ref* refs, uint32_t n_refs,
         total_postings += p->list_off[refs[i].list + 1] - p->list_off[refs[i].list];
     }
     ORAMA_REQUIRE(total_postings < 0xffffffffull, "query touches too many postings");
-
-    // map the vector map to local doc indices (host, <= limit entries)
-    std::vector<uint32_t> vidx(n_vec);
-    for (uint32_t j = 0; j < n_vec; ++j) {
-        auto it = std::lower_bound(p->h_docs.begin(), p->h_docs.end(), vec_doc[j]);
-        ORAMA_REQUIRE(it != p->h_docs.end() && *it == vec_doc[j],
-                      "hybrid: vector hit doc %llu is not a document of this index", (unsigned long long)vec_doc[j]);
-        vidx[j] = (uint32_t)(it - p->h_docs.begin());
-    }
-
-    ScratchLease sc(p->ctx);
-    ORAMA_TRY(sc.init());
     hipStream_t s = sc->stream;
-    const uint64_t touched_cap = std::min<uint64_t>(total_postings, p->n_docs);
-    const uint64_t cand_cap = touched_cap + n_vec;
-    QueryBuffers qb;
-    ORAMA_TRY(prepare_query(sc.s.get(), p->n_docs ? p->n_docs : 1, params->n_tokens, cand_cap, &qb));
+    st->hybrid = hybrid;
+    st->touched_cap = std::min<uint64_t>(total_postings, p->n_docs);
+    st->cand_cap = st->touched_cap + n_vec_cap;
+    ORAMA_TRY(prepare_query(sc, p->n_docs ? p->n_docs : 1, params->n_tokens, st->cand_cap, &st->qb));
     ORAMA_TRY(ensure_idf_table(p, params->total_documents, s));
+    const QueryBuffers& qb = st->qb;
 
     // segments, grouped by rank
     std::vector<Bm25Seg> segs;
@@ -265,20 +272,16 @@ int post_search_impl(orama_post* p, const orama_term_ref* refs, uint32_t n_refs,
         if (words) ORAMA_HIP_TRY(hipMemcpyAsync(sc->bitmap.p, allow_bitmap, words * 8, hipMemcpyHostToDevice, s));
         d_allow = sc->bitmap.as<uint64_t>();
     }
-    // one H2D for the query descriptor: segments + vector entries
     const size_t seg_bytes = segs.size() * sizeof(Bm25Seg);
-    const size_t vec_off = (seg_bytes + 15) & ~(size_t)15;
-    const size_t desc_bytes = vec_off + (size_t)n_vec * 8;
-    ORAMA_TRY(sc->h_in.reserve(desc_bytes + 16));
-    ORAMA_TRY(sc->misc0.reserve(desc_bytes + 16));
-    char* hd = sc->h_in.as<char>();
-    if (seg_bytes) memcpy(hd, segs.data(), seg_bytes);
-    if (n_vec) {
-        memcpy(hd + vec_off, vidx.data(), (size_t)n_vec * 4);
-        memcpy(hd + vec_off + (size_t)n_vec * 4, vec_score, (size_t)n_vec * 4);
+    // pinned staging: [segments | stage-2 vector entries] — stage 2 must not touch bytes an in-flight copy reads
+    st->vec_stage_off = (seg_bytes + 63) & ~(size_t)63;
+    st->n_vec_cap = n_vec_cap;
+    ORAMA_TRY(sc->h_in.reserve(st->vec_stage_off + (size_t)n_vec_cap * 8 + 64));
+    ORAMA_TRY(sc->misc0.reserve(seg_bytes + 16));
+    if (seg_bytes) {
+        memcpy(sc->h_in.p, segs.data(), seg_bytes);
+        ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, sc->h_in.p, seg_bytes, hipMemcpyHostToDevice, s));
     }
-    if (desc_bytes) ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, hd, desc_bytes, hipMemcpyHostToDevice, s));
-
     for (uint32_t r = 0; r < max_rank; ++r) {
         Bm25Accum a;
         a.post_doc = p->d_post_doc.as<uint32_t>();
@@ -299,7 +302,7 @@ int post_search_impl(orama_post* p, const orama_term_ref* refs, uint32_t n_refs,
         a.state = qb.state;
         ORAMA_TRY(launch_bm25_accumulate(p->ctx, a, s));
     }
-    const float* omc = (apply_omc && p->has_omc) ? p->d_omc.as<float>() : nullptr;
+    st->omc = (apply_omc && p->has_omc) ? p->d_omc.as<float>() : nullptr;
     Bm25Finalize f;
     f.n_tokens = params->n_tokens;
     f.k = params->k;
@@ -307,34 +310,73 @@ int post_search_impl(orama_post* p, const orama_term_ref* refs, uint32_t n_refs,
     f.use_threshold = params->use_threshold != 0;
     f.threshold = params->threshold;
     f.track_minmax = hybrid;
-    f.omc_dense = hybrid ? nullptr : omc;  // hybrid: OMC after the combine
+    f.omc_dense = hybrid ? nullptr : st->omc;  // hybrid: OMC after the combine
     f.epoch = qb.epoch;
     f.n_docs = p->n_docs;
     f.acc = qb.acc;
     f.touched = qb.touched;
-    f.touched_cap = (uint32_t)touched_cap;
+    f.touched_cap = (uint32_t)st->touched_cap;
     f.state = qb.state;
     f.cand_score = qb.cand_score;
     f.cand_idx = qb.cand_idx;
     f.emit = qb.emit;
-    ORAMA_TRY(launch_bm25_finalize(p->ctx, f, s));
-    if (hybrid) {
+    return launch_bm25_finalize(p->ctx, f, s);
+}
+
+// Stage 2: [hybrid: K5 combine with the vector map +] OMC, K4 top-k, download (synchronises sc->stream).
+int post_stage2(orama_post* p, Scratch* sc, const PostQuery& st, const orama_bm25_params* params,
+                const uint64_t* vec_doc, const float* vec_score, uint32_t n_vec, uint64_t* out_ids,
+                float* out_scores, uint32_t* out_n, uint64_t* out_count) {
+    hipStream_t s = sc->stream;
+    const QueryBuffers& qb = st.qb;
+    if (st.hybrid) {
+        ORAMA_REQUIRE(st.touched_cap + n_vec <= st.cand_cap, "hybrid: vector map larger than announced");
+        // map the vector map to local doc indices (host, <= limit entries) and upload it
+        ORAMA_REQUIRE(n_vec <= st.n_vec_cap, "hybrid: vector map larger than announced");
+        ORAMA_TRY(sc->misc1.reserve((size_t)n_vec * 8 + 16));
+        uint32_t* h_idx = reinterpret_cast<uint32_t*>(sc->h_in.as<char>() + st.vec_stage_off);
+        float* h_sc = reinterpret_cast<float*>(h_idx + n_vec);
+        for (uint32_t j = 0; j < n_vec; ++j) {
+            ORAMA_REQUIRE(p->local_of(vec_doc[j], &h_idx[j]),
+                          "hybrid: vector hit doc %llu is not a document of this index", (unsigned long long)vec_doc[j]);
+            h_sc[j] = vec_score[j];
+        }
+        if (n_vec) ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc1.p, h_idx, (size_t)n_vec * 8, hipMemcpyHostToDevice, s));
         HybridCombine h;
         vec_min_max(vec_score, n_vec, &h.vec_min, &h.vec_max);
-        h.vec_idx = reinterpret_cast<const uint32_t*>(sc->misc0.as<char>() + vec_off);
-        h.vec_score = reinterpret_cast<const float*>(sc->misc0.as<char>() + vec_off + (size_t)n_vec * 4);
+        h.vec_idx = sc->misc1.as<uint32_t>();
+        h.vec_score = reinterpret_cast<const float*>(sc->misc1.as<uint32_t>() + n_vec);
         h.n_vec = n_vec;
-        h.omc_dense = omc;
+        h.omc_dense = st.omc;
         h.epoch = qb.epoch;
-        h.cand_cap = (uint32_t)touched_cap;
+        h.cand_cap = (uint32_t)st.touched_cap;
         h.state = qb.state;
         h.cand_score = qb.cand_score;
         h.cand_idx = qb.cand_idx;
         h.emit = qb.emit;
         ORAMA_TRY(launch_hybrid_combine(p->ctx, h, s));
     }
-    return select_and_download(p->ctx, sc.s.get(), qb, p->d_docs.as<uint64_t>(), (uint32_t)cand_cap, params->top_k,
-                               out_ids, out_scores, out_n, out_count);
+    return select_and_download(p->ctx, sc, qb, p->d_docs.as<uint64_t>(), (uint32_t)st.cand_cap, params->top_k, out_ids,
+                               out_scores, out_n, out_count);
+}
+
+int post_search_impl(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, float b,
+                     const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits,
+                     const uint64_t* vec_doc, const float* vec_score, uint32_t n_vec, bool hybrid,
+                     int apply_omc, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
+                     uint64_t* out_count) {
+    ORAMA_REQUIRE(p && out_n && params, "null argument");
+    *out_n = 0;
+    if (out_count) *out_count = 0;
+    ORAMA_REQUIRE(params->top_k == 0 || (out_ids && out_scores), "null output");
+    ORAMA_REQUIRE(!hybrid || n_vec == 0 || (vec_doc && vec_score), "null vector map");
+    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    std::shared_lock<std::shared_mutex> lk(p->mu);
+    ScratchLease sc(p->ctx);
+    ORAMA_TRY(sc.init());
+    PostQuery st;
+    ORAMA_TRY(post_stage1(p, sc.s.get(), refs, n_refs, b, params, allow_bitmap, bitmap_bits, hybrid, apply_omc, n_vec, &st));
+    return post_stage2(p, sc.s.get(), st, params, vec_doc, vec_score, n_vec, out_ids, out_scores, out_n, out_count);
 }
 
 }  // namespace
@@ -415,13 +457,115 @@ int orama_post_build(orama_post* p, const uint64_t* docs, uint64_t n_docs, uint3
     p->n_fields = n_fields;
     p->n_lists = n_lists;
     p->n_postings = n_post;
-    p->h_docs.assign(docs, docs + n_docs);
+    p->dense = dense;
+    p->dense_base = n_docs ? docs[0] : 0;
+    if (dense) {
+        p->h_docs.clear();
+        p->h_docs.shrink_to_fit();
+    } else {
+        p->h_docs.assign(docs, docs + n_docs);
+    }
     p->avg_len.assign(avg_field_len, avg_field_len + n_fields);
     p->field_of_list.assign(field_of_list, field_of_list + n_lists);
     p->list_off.assign(list_off, list_off + (n_lists ? n_lists + 1 : 0));
     if (!n_lists) p->list_off.assign(1, 0);
     p->has_omc = false;
     p->idf_total_docs = -1.0f;
+    return ORAMA_OK;
+}
+
+int orama_post_fill_synthetic(orama_post* p, uint64_t n_docs, uint64_t first_doc_id, uint32_t n_lists,
+                              const uint32_t* ranks, uint64_t seed, uint64_t* out_total_postings) {
+    ORAMA_REQUIRE(p, "null handle");
+    ORAMA_REQUIRE(n_docs >= 1 && n_docs < 0xffffffffull, "n_docs out of range");
+    ORAMA_REQUIRE(n_lists >= 1 && ranks, "null ranks");
+    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    std::unique_lock<std::shared_mutex> lk(p->mu);
+    ScratchLease sc(p->ctx);
+    ORAMA_TRY(sc.init());
+    hipStream_t s = sc->stream;
+    // document lengths (device) → average field length (host, f64 mean → f32 like StringStorage::info())
+    ORAMA_TRY(sc->misc1.reserve((size_t)n_docs * 2));
+    ORAMA_TRY(launch_synth_doc_len(sc->misc1.as<uint16_t>(), n_docs, seed ^ 0xB25ull, s));
+    std::vector<uint16_t> h_len((size_t)n_docs);
+    ORAMA_HIP_TRY(hipMemcpyAsync(h_len.data(), sc->misc1.p, (size_t)n_docs * 2, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    double sum = 0.0;
+    for (uint16_t l : h_len) sum += l;
+    const double avg = sum / (double)n_docs;
+    // Zipf(1.07) over V = 2^20 ranks: term frequency f_r = r^-1.07 / H; df_r = N * (1 - exp(-avg_len * f_r))
+    double H = 0.0;
+    for (uint32_t r = 1; r <= (1u << 20); ++r) H += std::pow((double)r, -1.07);
+    std::vector<uint64_t> off((size_t)n_lists + 1, 0);
+    for (uint32_t l = 0; l < n_lists; ++l) {
+        ORAMA_REQUIRE(ranks[l] >= 1, "rank must be >= 1");
+        const double f = std::pow((double)ranks[l], -1.07) / H;
+        uint64_t df = (uint64_t)std::llround((double)n_docs * (1.0 - std::exp(-avg * f)));
+        df = std::min<uint64_t>(std::max<uint64_t>(df, 1), n_docs);
+        off[l + 1] = off[l] + df;
+    }
+    const uint64_t total = off[n_lists];
+    ORAMA_TRY(p->d_docs.reserve((size_t)n_docs * 8));
+    ORAMA_TRY(p->d_post_doc.reserve((size_t)total * 4));
+    ORAMA_TRY(p->d_post_val.reserve((size_t)total * 4));
+    ORAMA_TRY(sc->misc0.reserve(off.size() * 8));
+    ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, s));
+    {   // docs[i] = first_doc_id + i
+        std::vector<uint64_t> ids((size_t)std::min<uint64_t>(n_docs, 1u << 22));
+        for (uint64_t i0 = 0; i0 < n_docs; i0 += ids.size()) {
+            const uint64_t cnt = std::min<uint64_t>(ids.size(), n_docs - i0);
+            for (uint64_t i = 0; i < cnt; ++i) ids[(size_t)i] = first_doc_id + i0 + i;
+            ORAMA_HIP_TRY(hipMemcpy(p->d_docs.as<uint64_t>() + i0, ids.data(), (size_t)cnt * 8, hipMemcpyHostToDevice));
+        }
+    }
+    ORAMA_TRY(launch_synth_postings(p->d_post_doc.as<uint32_t>(), p->d_post_val.as<uint32_t>(),
+                                    sc->misc0.as<uint64_t>(), n_lists, n_docs, sc->misc1.as<uint16_t>(), seed, total, s));
+    ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    p->n_docs = n_docs;
+    p->n_fields = 1;
+    p->n_lists = n_lists;
+    p->n_postings = total;
+    p->dense = true;
+    p->dense_base = first_doc_id;
+    p->h_docs.clear();
+    p->avg_len.assign(1, (float)avg);
+    p->field_of_list.assign(n_lists, 0u);
+    p->list_off = off;
+    p->has_omc = false;
+    p->idf_total_docs = -1.0f;
+    if (out_total_postings) *out_total_postings = total;
+    return ORAMA_OK;
+}
+
+int orama_post_get_list(orama_post* p, uint32_t list, uint64_t capacity, uint64_t* out_doc, uint32_t* out_tf,
+                        uint32_t* out_len, uint64_t* out_n) {
+    ORAMA_REQUIRE(p && out_n, "null argument");
+    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    std::shared_lock<std::shared_mutex> lk(p->mu);
+    ORAMA_REQUIRE(list < p->n_lists, "list %u out of range", list);
+    const uint64_t b = p->list_off[list], n = p->list_off[list + 1] - b;
+    *out_n = n;
+    if (n == 0 || capacity == 0) return ORAMA_OK;
+    ORAMA_REQUIRE(capacity >= n && out_doc && out_tf && out_len, "capacity %llu < list length %llu",
+                  (unsigned long long)capacity, (unsigned long long)n);
+    std::vector<uint32_t> pd((size_t)n), pv((size_t)n);
+    ORAMA_HIP_TRY(hipMemcpy(pd.data(), p->d_post_doc.as<uint32_t>() + b, (size_t)n * 4, hipMemcpyDeviceToHost));
+    ORAMA_HIP_TRY(hipMemcpy(pv.data(), p->d_post_val.as<uint32_t>() + b, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) {
+        out_doc[i] = p->dense ? p->dense_base + pd[(size_t)i] : p->h_docs[pd[(size_t)i]];
+        out_tf[i] = pv[(size_t)i] >> 16;
+        out_len[i] = pv[(size_t)i] & 0xffffu;
+    }
+    return ORAMA_OK;
+}
+
+int orama_post_info(orama_post* p, uint64_t* n_docs, uint32_t* n_lists, uint64_t* n_postings, float* avg_len0) {
+    ORAMA_REQUIRE(p, "null handle");
+    std::shared_lock<std::shared_mutex> lk(p->mu);
+    if (n_docs) *n_docs = p->n_docs;
+    if (n_lists) *n_lists = p->n_lists;
+    if (n_postings) *n_postings = p->n_postings;
+    if (avg_len0) *avg_len0 = p->avg_len.empty() ? 0.0f : p->avg_len[0];
     return ORAMA_OK;
 }
 
@@ -436,9 +580,9 @@ int orama_post_set_omc(orama_post* p, const uint64_t* omc_doc, const float* omc_
     }
     std::vector<float> dense((size_t)p->n_docs, 1.0f);  // x * 1.0 == x bit-for-bit: absent docs untouched
     for (uint64_t i = 0; i < n; ++i) {
-        auto it = std::lower_bound(p->h_docs.begin(), p->h_docs.end(), omc_doc[i]);
-        if (it == p->h_docs.end() || *it != omc_doc[i]) continue;  // multiplier of a doc not in this index
-        dense[(size_t)(it - p->h_docs.begin())] = omc_mul[i];
+        uint32_t local;
+        if (!p->local_of(omc_doc[i], &local)) continue;  // multiplier of a doc not in this index
+        dense[local] = omc_mul[i];
     }
     ORAMA_TRY(p->d_omc.reserve(std::max<size_t>(4, dense.size() * 4)));
     if (!dense.empty())
@@ -462,6 +606,92 @@ int orama_post_search_hybrid(orama_post* p, const orama_term_ref* refs, uint32_t
                              uint32_t* out_n, uint64_t* out_count) {
     return post_search_impl(p, refs, n_refs, b, params, allow_bitmap, bitmap_bits, vec_doc, vec_score, n_vec, true,
                             apply_omc, out_ids, out_scores, out_n, out_count);
+}
+
+// search_hybrid (token_score.rs:357-387) as ONE call: the vector leg (K1/K2 + K4 on its own HIP stream) and
+// the full-text leg (K3 on a second stream) run concurrently; the host applies the in-tree epilogue
+// (embedding_field.rs:268-276) to the <= limit vector hits and stage 2 combines on the device.
+int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_t limit, float min_similarity,
+                        int rescale_e5, const orama_term_ref* refs, uint32_t n_refs, float b,
+                        const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits,
+                        int apply_omc, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count) {
+    ORAMA_REQUIRE(v && p && query && out_n && params, "null argument");
+    *out_n = 0;
+    if (out_count) *out_count = 0;
+    ORAMA_REQUIRE(params->top_k == 0 || (out_ids && out_scores), "null output");
+    ORAMA_REQUIRE(limit <= kSelectMaxK, "limit %u exceeds the supported maximum %u", limit, kSelectMaxK);
+    orama_ctx* ctx = p->ctx;
+    ORAMA_REQUIRE(vec_ctx(v) == ctx, "vector store and postings store live on different contexts");
+    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    VecSharedLock vlk(v);
+    std::shared_lock<std::shared_mutex> lk(p->mu);
+    ScratchLease a(ctx), bsc(ctx);
+    ORAMA_TRY(a.init());
+    ORAMA_TRY(bsc.init());
+    // ---- leg A: vector scan + top-`limit` rows
+    const uint32_t dim = vec_dim(v);
+    const bool have_rows = vec_rows(v) > 0 && limit > 0;
+    const uint32_t kk = limit ? limit : 1;
+    hipStream_t sa = a->stream;
+    char* ha = nullptr;
+    if (have_rows) {
+        ORAMA_TRY(a->query.reserve((size_t)dim * 4));
+        ORAMA_TRY(a->h_in.reserve((size_t)dim * 4));
+        memcpy(a->h_in.p, query, (size_t)dim * 4);
+        ORAMA_HIP_TRY(hipMemcpyAsync(a->query.p, a->h_in.p, (size_t)dim * 4, hipMemcpyHostToDevice, sa));
+        const uint64_t* d_allow = nullptr;
+        if (allow_bitmap) {
+            const size_t words = (size_t)((bitmap_bits + 63) / 64);
+            ORAMA_TRY(a->bitmap.reserve(std::max<size_t>(8, words * 8)));
+            if (words) ORAMA_HIP_TRY(hipMemcpyAsync(a->bitmap.p, allow_bitmap, words * 8, hipMemcpyHostToDevice, sa));
+            d_allow = a->bitmap.as<uint64_t>();
+        }
+        ORAMA_TRY(a->out_ids.reserve((size_t)kk * 8));
+        ORAMA_TRY(a->out_val.reserve((size_t)kk * 4));
+        ORAMA_TRY(a->out_n.reserve(4));
+        ORAMA_TRY(vec_search_enqueue(v, a.s.get(), a->query.as<float>(), 1, limit, d_allow, bitmap_bits,
+                                     a->out_ids.as<uint64_t>(), a->out_val.as<float>(), a->out_n.as<uint32_t>(), sa));
+        ORAMA_TRY(a->h_out.reserve((size_t)kk * 12 + 4));
+        ha = a->h_out.as<char>();
+        ORAMA_HIP_TRY(hipMemcpyAsync(ha, a->out_ids.p, (size_t)kk * 8, hipMemcpyDeviceToHost, sa));
+        ORAMA_HIP_TRY(hipMemcpyAsync(ha + (size_t)kk * 8, a->out_val.p, (size_t)kk * 4, hipMemcpyDeviceToHost, sa));
+        ORAMA_HIP_TRY(hipMemcpyAsync(ha + (size_t)kk * 12, a->out_n.p, 4, hipMemcpyDeviceToHost, sa));
+    }
+    // ---- leg B, stage 1: BM25F accumulate + finalise (overlaps leg A)
+    PostQuery st;
+    ORAMA_TRY(post_stage1(p, bsc.s.get(), refs, n_refs, b, params, allow_bitmap, bitmap_bits, true, apply_omc, limit, &st));
+    // ---- join A; in-tree epilogue on the host: similarity, rescale, cut-off, per-doc sum (hit order)
+    std::vector<uint64_t> vdoc;
+    std::vector<float> vsc;
+    if (have_rows) {
+        ORAMA_HIP_TRY(hipStreamSynchronize(sa));
+        const uint64_t* ids = reinterpret_cast<const uint64_t*>(ha);
+        const float* dist = reinterpret_cast<const float*>(ha + (size_t)kk * 8);
+        const uint32_t n = *reinterpret_cast<const uint32_t*>(ha + (size_t)kk * 12);
+        for (uint32_t i = 0; i < n; ++i) {
+            const float similarity = 1.0f - dist[i];
+            float score = similarity;
+            if (rescale_e5) {  // Model::rescale_score, src/python/embeddings.rs:71-92
+                const float MIN = 0.7f, MAX = 1.0f, DELTA = MAX - MIN;
+                float c = similarity;
+                if (c < MIN) c = MIN;
+                if (c > MAX) c = MAX;
+                score = (c - MIN) / DELTA;
+            }
+            if (!(score >= min_similarity)) continue;
+            size_t j = 0;
+            for (; j < vdoc.size(); ++j)
+                if (vdoc[j] == ids[i]) break;
+            if (j == vdoc.size()) {
+                vdoc.push_back(ids[i]);
+                vsc.push_back(0.0f);
+            }
+            vsc[j] = vsc[j] + score;
+        }
+    }
+    // ---- leg B, stage 2: combine + OMC + count + top-k
+    return post_stage2(p, bsc.s.get(), st, params, vdoc.data(), vsc.data(), (uint32_t)vdoc.size(), out_ids, out_scores,
+                       out_n, out_count);
 }
 
 // ================================================================= seam (i): host-provided contributions
@@ -600,7 +830,8 @@ int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_
         ORAMA_TRY(launch_bm25_accumulate(ctx, a, s));
     }
     // df → host → idf (libm log1pf, bm25.rs:78-82) → device
-    ORAMA_TRY(sc->h_out.reserve(sizeof(Bm25State) + kMaxTokens * 4));
+    // sized for the later result download too: the buffer must not be re-allocated while the idf upload reads it
+    ORAMA_TRY(sc->h_out.reserve((size_t)kSelectMaxK * 12 + 64 + 2 * sizeof(Bm25State) + kMaxTokens * 4));
     Bm25State* hst = sc->h_out.as<Bm25State>();
     ORAMA_HIP_TRY(hipMemcpyAsync(hst, qb.state, sizeof(Bm25State), hipMemcpyDeviceToHost, s));
     ORAMA_HIP_TRY(hipStreamSynchronize(s));

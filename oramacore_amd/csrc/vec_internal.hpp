@@ -1,0 +1,30 @@
+// vec_internal.hpp — what the fused hybrid entry point needs from the vector store (library-internal).
+#pragma once
+
+#include "common.hpp"
+
+struct orama_vec;
+
+namespace orama {
+
+// Shared (read) lock on a vector store for the lifetime of the object.
+class VecSharedLock {
+   public:
+    explicit VecSharedLock(orama_vec* v);
+    ~VecSharedLock();
+    VecSharedLock(const VecSharedLock&) = delete;
+    VecSharedLock& operator=(const VecSharedLock&) = delete;
+
+   private:
+    orama_vec* v_;
+};
+
+orama_ctx* vec_ctx(orama_vec* v);
+uint32_t vec_dim(orama_vec* v);
+uint64_t vec_rows(orama_vec* v);
+// Enqueue scan + top-k for q queries resident at d_queries on stream s (caller holds a VecSharedLock).
+int vec_search_enqueue(orama_vec* v, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
+                       const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
+                       uint32_t* d_out_n, hipStream_t s);
+
+}  // namespace orama

@@ -17,6 +17,7 @@
 #include "common.hpp"
 #include "select.hpp"
 #include "vec_f16.hpp"
+#include "vec_internal.hpp"
 #include "vec_kernels.hpp"
 
 using namespace orama;
@@ -320,6 +321,19 @@ int search_enqueue(orama_vec* v, Scratch* sc, const float* d_queries, uint32_t q
 }
 
 }  // namespace
+
+namespace orama {
+VecSharedLock::VecSharedLock(orama_vec* v) : v_(v) { v_->mu.lock_shared(); }
+VecSharedLock::~VecSharedLock() { v_->mu.unlock_shared(); }
+orama_ctx* vec_ctx(orama_vec* v) { return v->ctx; }
+uint32_t vec_dim(orama_vec* v) { return v->dim; }
+uint64_t vec_rows(orama_vec* v) { return v->n_rows; }
+int vec_search_enqueue(orama_vec* v, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
+                       const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
+                       uint32_t* d_out_n, hipStream_t s) {
+    return search_enqueue(v, sc, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, s);
+}
+}  // namespace orama
 
 extern "C" {
 

@@ -234,6 +234,50 @@ class PostingsStore:
                                            ptf.ctypes.data, plen.ctypes.data))
         self.n_docs = int(docs.shape[0])
 
+    def fill_synthetic(self, n_docs: int, ranks, seed: int, first_doc_id: int = 0) -> int:
+        """Bench utility: Zipf(1.07) posting lists generated in HBM. Returns the number of postings."""
+        r = np.ascontiguousarray(ranks, dtype=np.uint32)
+        total = C.c_uint64()
+        N.check(self._lib.orama_post_fill_synthetic(self._h, int(n_docs), int(first_doc_id), r.shape[0],
+                                                    r.ctypes.data, int(seed), C.byref(total)))
+        self.n_docs = int(n_docs)
+        return total.value
+
+    def hybrid_search(self, vec_store, query, limit: int, similarity: float, refs, n_tokens: int,
+                      total_documents: float, top_k: int, threshold=None, allow: AllowBitmap | None = None,
+                      apply_omc: bool = True, rescale_e5: bool = False, b: float = B_DEFAULT, k: float = K1_DEFAULT):
+        """search_hybrid (token_score.rs:357-387) in one call: vector leg and full-text leg overlap on two HIP
+        streams; epilogue, combine, OMC, count and top-k inside the library. Returns (ids, scores, count)."""
+        arr = self._refs(refs)
+        params = _params(total_documents, n_tokens, threshold, top_k, k)
+        qv = _f32(query)
+        out_ids = np.zeros(max(top_k, 1), dtype=np.uint64)
+        out_sc = np.zeros(max(top_k, 1), dtype=np.float32)
+        out_n = C.c_uint32()
+        out_count = C.c_uint64()
+        bm_ptr, bm_bits = (allow.words.ctypes.data, allow.n_bits) if allow is not None else (None, 0)
+        N.check(self._lib.orama_hybrid_search(vec_store.handle, self._h, qv.ctypes.data, int(limit), float(similarity),
+                                              1 if rescale_e5 else 0, arr, len(refs), b, C.byref(params), bm_ptr,
+                                              bm_bits, 1 if apply_omc else 0, out_ids.ctypes.data, out_sc.ctypes.data,
+                                              C.byref(out_n), C.byref(out_count)))
+        return out_ids[: out_n.value], out_sc[: out_n.value], out_count.value
+
+    def info(self) -> dict:
+        nd, nl, npst, avg = C.c_uint64(), C.c_uint32(), C.c_uint64(), C.c_float()
+        N.check(self._lib.orama_post_info(self._h, C.byref(nd), C.byref(nl), C.byref(npst), C.byref(avg)))
+        return {"n_docs": nd.value, "n_lists": nl.value, "n_postings": npst.value, "avg_field_length": avg.value}
+
+    def get_list(self, lst: int):
+        """(docs, tf, field_len) of one posting list (checker utility)."""
+        n = C.c_uint64()
+        N.check(self._lib.orama_post_get_list(self._h, int(lst), 0, None, None, None, C.byref(n)))
+        d = np.zeros(max(n.value, 1), dtype=np.uint64)
+        tf = np.zeros(max(n.value, 1), dtype=np.uint32)
+        ln = np.zeros(max(n.value, 1), dtype=np.uint32)
+        N.check(self._lib.orama_post_get_list(self._h, int(lst), n.value, d.ctypes.data, tf.ctypes.data,
+                                              ln.ctypes.data, C.byref(n)))
+        return d[: n.value], tf[: n.value], ln[: n.value]
+
     def set_omc(self, omc: dict) -> None:
         items = sorted(omc.items())
         d, m = _u64([x for x, _ in items]), _f32([y for _, y in items])
@@ -262,7 +306,10 @@ class PostingsStore:
                                                 1 if apply_omc else 0, out_ids.ctypes.data, out_sc.ctypes.data,
                                                 C.byref(out_n), C.byref(out_count)))
         else:
-            v_doc, v_sc = _u64(list(vector.keys())), _f32(list(vector.values()))
+            if isinstance(vector, dict):
+                v_doc, v_sc = _u64(list(vector.keys())), _f32(list(vector.values()))
+            else:
+                v_doc, v_sc = _u64(vector[0]), _f32(vector[1])
             N.check(self._lib.orama_post_search_hybrid(self._h, arr, len(refs), b, C.byref(params), bm_ptr, bm_bits,
                                                        v_doc.ctypes.data, v_sc.ctypes.data, v_doc.shape[0],
                                                        1 if apply_omc else 0, out_ids.ctypes.data,

@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""C4 bench (BASELINE configs[3]): hybrid = 10 M-doc BM25F (12-token queries) + 10 M x 768 fp32 vector scan,
+min-max merge, top-100, on one MI355X.  Also times the BM25-only path.  Same JSON schema as bench.py.
+
+Per hybrid query (the reference's order, token_score.rs:357-387): vector scan + top-k (K1 + K4) → host
+epilogue (a2) → BM25F over HBM-resident postings + combine + OMC + count + top-k (K3 + K5 + K4).
+Synthetic inputs per SURVEY §8d: Zipf(1.07) term ranks in [100, 100000] over a 2^20 vocabulary, field length
+~ LogNormal(4.0, 0.6) clipped to [4, 2000], N = 10 M documents, 12 distinct tokens per query.
+
+    python scripts/bench_hybrid.py [--docs 10000000] [--steps 50] [--warmup 5] [--lists 2048]
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+import oramacore_amd as oa  # noqa: E402
+from oramacore_amd import fulltext as ft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--lists", type=int, default=2048)
+    ap.add_argument("--tokens", type=int, default=12)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+    n, dim, k, T = args.docs, args.dim, args.k, args.tokens
+
+    ctx = oa.Context(0)
+    vec = oa.EmbeddingFieldStorage(ctx, dimensions=dim, reserve_rows=n)
+    vec.fill_synthetic(n, seed=0xC0FFEE, first_doc_id=0)
+    rng = np.random.default_rng(0xB26)
+    ranks = np.unique(np.exp(rng.uniform(np.log(100), np.log(100000), size=args.lists)).astype(np.uint32))
+    post = ft.PostingsStore(ctx)
+    t0 = time.perf_counter()
+    n_post = post.fill_synthetic(n, ranks, seed=0xB25)
+    t_fill = time.perf_counter() - t0
+    info = post.info()
+
+    total = args.warmup + args.steps
+    qv = np.random.default_rng(0xBEEF).standard_normal((total, dim)).astype(np.float32)
+    qlists = [rng.choice(len(ranks), size=T, replace=False) for _ in range(total)]
+    refs = [[(t, int(l), 1.0) for t, l in enumerate(ql)] for ql in qlists]
+
+    def hybrid_two_calls(i):
+        ids, dist, cnt = vec.storage_search(qv[i], k)
+        m = int(cnt[0])
+        sim = (np.float32(1.0) - dist[0, :m]).astype(np.float32)  # a2: similarity = 1 - distance, no rescale (BGE)
+        keep = sim >= np.float32(0.0)                              # similarity cut-off disabled for perf
+        return post.search(refs[i], T, float(n), k, vector=(ids[0, :m][keep], sim[keep]))
+
+    def hybrid(i):  # one call: vector leg and BM25 leg overlap on two HIP streams
+        return post.hybrid_search(vec, qv[i], k, 0.0, refs[i], T, float(n), k)
+
+    def bm25(i):
+        return post.search(refs[i], T, float(n), k)
+
+    for i in range(args.warmup):
+        hybrid(i)
+        bm25(i)
+    ctx.synchronize()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        h_ids, h_sc, h_count = hybrid(i)
+    ctx.synchronize()
+    el_h = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    scan_ms, scan_n = ctx.prof_get("vec_scan_f32")
+    acc_ms, acc_n = ctx.prof_get("bm25_accumulate")
+    fin_ms, fin_n = ctx.prof_get("bm25_finalize")
+    sel_ms, sel_n = ctx.prof_get("topk_select")
+
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        hybrid_two_calls(i)
+    ctx.synchronize()
+    el_h2 = time.perf_counter() - t0
+
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        b_ids, b_sc, b_count = bm25(i)
+    ctx.synchronize()
+    el_b = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    bacc_ms, bacc_n = ctx.prof_get("bm25_accumulate")
+    bfin_ms, bfin_n = ctx.prof_get("bm25_finalize")
+    bsel_ms, bsel_n = ctx.prof_get("topk_select")
+
+    # postings touched per query (algorithmic bytes of K3 = 8 B per posting + 4 B per touched doc)
+    lens = {}
+    touched_postings = []
+    for i in range(args.warmup, total):
+        for l in qlists[i]:
+            if l not in lens:
+                lens[l] = len(post.get_list(int(l))[0])
+        touched_postings.append(sum(lens[l] for l in qlists[i]))
+    avg_postings = float(np.mean(touched_postings))
+
+    # ---- parity of the last BM25 and hybrid query against the oracle (checker only)
+    check = None
+    if not args.no_check:
+        from oracle import oracle as orc
+
+        i = total - 1
+        entries = []
+        for t, l in enumerate(qlists[i]):
+            d, tf, ln = post.get_list(int(l))
+            b_, avg_ = np.float32(0.75), np.float32(info["avg_field_length"])  # bm25.rs:99-110 in f32, vectorised
+            ntf = np.float32(1.0) * (tf.astype(np.float32) / ((np.float32(1.0) - b_) + b_ * (ln.astype(np.float32) / avg_)))
+            entries.append((t, d, ntf))
+        od, os_ = orc.search_full_text(entries, T, float(n), 1.2, None)
+        td, ts = orc.top_n(od, os_, k)
+        assert b_count == len(od) and b_ids.tolist() == td.tolist(), "BM25 ids differ from the oracle"
+        assert np.array_equal(b_sc.view(np.uint32), ts.view(np.uint32)), "BM25 scores differ from the oracle"
+        ids, dist, cnt = vec.storage_search(qv[i], k)
+        sim = (np.float32(1.0) - dist[0]).astype(np.float32)
+        cd, cs = orc.normalize_and_combine(ids[0], sim, od, os_)
+        hd, hs = orc.top_n(cd, cs, k)
+        assert h_count == len(cd) and h_ids.tolist() == hd.tolist(), "hybrid ids differ from the oracle"
+        assert np.array_equal(h_sc.view(np.uint32), hs.view(np.uint32)), "hybrid scores differ from the oracle"
+        check = "bit-exact vs oracle (last query): BM25 ids/scores/count, hybrid ids/scores/count"
+
+    alg_vec = n * dim * 4
+    avg_scan_s = scan_ms / max(scan_n, 1) / 1e3
+    achieved = alg_vec / avg_scan_s / 1e9 if scan_n else 0.0
+    acc_s = bacc_ms / max(bacc_n, 1) / 1e3
+    out = {
+        "metric": "queries/sec, hybrid search: 10M-doc BM25F (12 tokens) + 10M x 768 fp32 cosine scan, min-max merge, top-100",
+        "value": args.steps / el_h, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": el_h / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Hybrid: 10M docs BM25 (12 terms/query) + 10M x 768 vector, min-max merge (BASELINE configs[3])",
+                   "docs": n, "dim": dim, "k": k, "tokens_per_query": T, "posting_lists": int(len(ranks)),
+                   "postings_resident": int(n_post), "avg_postings_per_query": avg_postings,
+                   "avg_field_length": info["avg_field_length"], "valid": n == 10_000_000 and dim == 768},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "vec_scan_f32_kernel",
+                     "alg_bytes_per_launch": alg_vec, "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_n},
+        "hybrid_breakdown_ms_per_query": {"vec_scan": scan_ms / args.steps, "bm25_accumulate": acc_ms / args.steps,
+                                          "bm25_finalize": fin_ms / args.steps, "topk_select(all)": sel_ms / args.steps},
+        "hybrid_two_call_path": {"value": args.steps / el_h2, "unit": "queries/s",
+                                 "note": "vector search, host epilogue, then orama_post_search_hybrid (sequential legs)"},
+        "bm25_only": {"value": args.steps / el_b, "unit": "queries/s", "ms_per_query": el_b / args.steps * 1e3,
+                      "accumulate_ms": bacc_ms / args.steps, "finalize_ms": bfin_ms / args.steps,
+                      "topk_select_ms": bsel_ms / args.steps,
+                      "k3_alg_bytes_per_query": avg_postings * 8,
+                      "k3_accumulate_GBps": avg_postings * 8 / acc_s / 1e9 if bacc_n else 0.0,
+                      "k3_postings_per_s": avg_postings / acc_s if bacc_n else 0.0},
+        "postings_fill_seconds": t_fill, "parity_check": check, "device": ctx.device_info()["name"],
+    }
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

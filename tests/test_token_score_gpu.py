@@ -198,3 +198,41 @@ def test_vector_and_hybrid_modes(ctx):
         assert count == len(cd) and [h[0] for h in hits] == td.tolist()
         assert np.array_equal(np.array([h[1] for h in hits], dtype=np.float32).view(np.uint32), ts.view(np.uint32))
     ef.close()
+
+
+def test_fused_hybrid_search_equals_two_call_path(ctx):
+    """orama_hybrid_search (two HIP streams, epilogue inside the library) == vector search + host epilogue +
+    orama_post_search_hybrid, for BGE and E5 (rescale) models, with and without a filter / OMC."""
+    dim, n = 384, 600
+    docs = {i: {"text": ("red " * (i % 4 + 1)) + ("blue " if i % 3 else "") + f"item{i}"} for i in range(n)}
+    idx = make_index(ctx, docs)
+    rng = np.random.default_rng(11)
+    q = util.gaussian_rows(1, dim, seed=77, scale_rows=False)[0]
+    rows, row_doc = [], []
+    for i in range(n):
+        for c in range(1 + i % 3):
+            noise = rng.standard_normal(dim).astype(np.float32)
+            w = np.float32(0.97 if i % 7 == 0 else 0.3)
+            rows.append(w * q / np.linalg.norm(q) + (1 - w) * noise / np.linalg.norm(noise))
+            row_doc.append(i)
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    row_doc = np.array(row_doc, dtype=np.uint64)
+    idx.omc = {0: 3.0, 7: 0.5, 14: 2.0}
+    idx.commit()
+    allow = oa.AllowBitmap.from_mask(np.arange(n) % 5 != 2)
+    tsc = TokenScoreContext(idx)
+    refs = tsc._refs(["red", "blue"], None, {}, False)
+    for model in (oa.Model.BGESmall, oa.Model.MultilingualE5Small):
+        ef = oa.EmbeddingFieldStorage(ctx, model)
+        ef.insert_rows(row_doc, rows)
+        for sim in (0.0, 0.7):
+            for flt in (None, allow):
+                for limit in (10, 300):
+                    vec = {}
+                    ef.search(oa.VectorSearchParams(target=q, similarity=sim, limit=limit, filtered_doc_ids=flt), vec)
+                    e_ids, e_sc, e_cnt = idx._post.search(refs, 2, float(n), 25, None, allow=flt, vector=vec)
+                    f_ids, f_sc, f_cnt = idx._post.hybrid_search(ef, q, limit, sim, refs, 2, float(n), 25, None,
+                                                                 allow=flt, rescale_e5=model.is_e5())
+                    assert f_cnt == e_cnt and f_ids.tolist() == e_ids.tolist(), (model, sim, limit)
+                    assert np.array_equal(f_sc.view(np.uint32), e_sc.view(np.uint32))
+        ef.close()
