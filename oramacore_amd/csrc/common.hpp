@@ -165,6 +165,11 @@ struct ScanTuning {
 struct orama_ctx {
     int device = 0;
     orama::ScanTuning scan_tuning;  // defaults from ORAMA_SCAN_* env, see orama_ctx_set_scan_tuning
+    // Experimental: K1 keeps per-wave top-k lists (k <= 128) in registers instead of writing dense distances
+    // (ORAMA_FUSED_TOPK=1).  Exact and tested, but measured SLOWER on MI355X (profiles/r01_fused_topk_experiment.md):
+    // the 64-bit shuffle re-reduction per insert lengthens each wave's latency-bound critical path and the LDS
+    // bitonic reduction of the wave lists costs more than the dense radix select — so it is off by default.
+    int fused_topk = 0;
     int f16_kc = 8, f16_nbuf = 3;   // K2 register ring: k-steps per chunk, chunks (ORAMA_F16_KC / ORAMA_F16_NBUF)
     int compute_units = 0;
     uint64_t hbm_bytes = 0;

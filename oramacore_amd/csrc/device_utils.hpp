@@ -55,4 +55,48 @@ __device__ __forceinline__ float ordered_to_f32(uint32_t k) {
     return __builtin_bit_cast(float, u);
 }
 
+// ---------------------------------------------------------------- per-wave running top-k (k <= 128)
+// 64-bit keys, "larger is better", 0 = empty slot.  The list lives in REGISTERS: lane l holds entries l and
+// l + 64.  `thr` (wave-uniform) is the smallest kept key once the list is full, so the hot-path test is one
+// scalar compare per candidate; an insert replaces the minimum and re-reduces (rare: ~k·ln(n/k) per wave).
+struct WaveTopK {
+    unsigned long long s0 = 0ull, s1 = 0ull;
+    unsigned long long thr = 0ull;
+    uint32_t count = 0;
+    uint32_t min_pos = 0;
+
+    __device__ __forceinline__ void recompute_min(uint32_t k, int lane) {
+        unsigned long long m = ~0ull;
+        if ((uint32_t)lane < k) m = s0;
+        if ((uint32_t)lane + 64u < k && s1 < m) m = s1;
+        unsigned long long w = m;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(w, off, 64);
+            w = o < w ? o : w;
+        }
+        thr = w;
+        const unsigned long long owners = __ballot(m == w);
+        const int fl = __ffsll((long long)owners) - 1;
+        const uint32_t which = ((uint32_t)lane < k && s0 == w) ? 0u : 1u;
+        min_pos = (uint32_t)fl + 64u * (uint32_t)__shfl((int)which, fl, 64);
+    }
+    __device__ __forceinline__ void set_slot(uint32_t pos, unsigned long long key, int lane) {
+        if ((uint32_t)lane == (pos & 63u)) {
+            if (pos < 64u) s0 = key; else s1 = key;
+        }
+    }
+    // key must be wave-uniform; call only when (count < k || key > thr)
+    __device__ __forceinline__ void insert(unsigned long long key, uint32_t k, int lane) {
+        if (count < k) {
+            set_slot(count, key, lane);
+            ++count;
+            if (count == k) recompute_min(k, lane);
+        } else {
+            set_slot(min_pos, key, lane);
+            recompute_min(k, lane);
+        }
+    }
+};
+
 }  // namespace orama

@@ -364,7 +364,106 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(
                  out_n ? out_n + qi : nullptr);
 }
 
+// ---------------------------------------------------------------- key lists (fused per-wave top-k of K1)
+// One workgroup per (chunk, list): bitonic-sort up to 8192 u64 keys in LDS (descending), keep the best k.
+__global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigned long long* __restrict__ keys,
+                                                                   uint32_t n_keys, uint64_t in_stride,
+                                                                   uint32_t k, unsigned long long* __restrict__ out,
+                                                                   uint64_t out_stride) {
+    __shared__ unsigned long long s[kKeysChunk];
+    const uint32_t qi = blockIdx.y;
+    const unsigned long long* in = keys + (uint64_t)qi * in_stride;
+    const uint32_t begin = blockIdx.x * kKeysChunk;
+    const uint32_t cnt = min(kKeysChunk, n_keys - begin);
+    uint32_t p2 = 2;
+    while (p2 < cnt) p2 <<= 1;
+    for (uint32_t i = threadIdx.x; i < p2; i += blockDim.x) s[i] = i < cnt ? in[begin + i] : 0ull;
+    __syncthreads();
+    for (uint32_t size = 2; size <= p2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (p2 >> 1); t += blockDim.x) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = s[lo], b = s[hi];
+                if ((b > a) == up) {
+                    s[lo] = b;
+                    s[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    unsigned long long* o = out + (uint64_t)qi * out_stride + (uint64_t)blockIdx.x * k;
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = i < p2 ? s[i] : 0ull;
+}
+
+// Final ordering of <= 4096 keys: (value, 64-bit id asc, idx asc), empties (0) dropped.
+__global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned long long* __restrict__ keys,
+                                                                  uint32_t n_keys, uint64_t in_stride, uint32_t k,
+                                                                  bool descending,
+                                                                  const uint64_t* __restrict__ id_map,
+                                                                  uint32_t* out_idx, uint64_t* out_ids, float* out_val,
+                                                                  uint32_t* out_n) {
+    __shared__ SortLds s;
+    __shared__ uint32_t valid_s;
+    const uint32_t qi = blockIdx.x;
+    const unsigned long long* in = keys + (uint64_t)qi * in_stride;
+    const uint32_t p2 = next_pow2(n_keys);
+    if (threadIdx.x == 0) valid_s = 0;
+    __syncthreads();
+    uint32_t my_valid = 0;
+    for (uint32_t i = threadIdx.x; i < p2; i += blockDim.x) {
+        const unsigned long long key = i < n_keys ? in[i] : 0ull;
+        if (key != 0ull) {
+            const uint32_t ix = ~(uint32_t)key;
+            s.hi[i] = (uint32_t)(key >> 32);
+            s.idx[i] = ix;
+            s.id[i] = id_map ? id_map[ix] : (uint64_t)ix;
+            ++my_valid;
+        } else {
+            s.hi[i] = 0;
+            s.idx[i] = 0xffffffffu;
+            s.id[i] = ~0ull;
+        }
+    }
+    if (my_valid) atomicAdd(&valid_s, my_valid);
+    __syncthreads();
+    lds_bitonic_sort(s, p2);
+    const uint32_t count = min(valid_s, k);
+    write_sorted(s, count, k, descending, out_idx ? out_idx + (uint64_t)qi * k : nullptr,
+                 out_ids ? out_ids + (uint64_t)qi * k : nullptr, out_val + (uint64_t)qi * k,
+                 out_n ? out_n + qi : nullptr);
+}
+
 }  // namespace
+
+int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t n_keys, uint64_t stride,
+                     uint32_t q, uint32_t k, bool descending, const uint64_t* id_map,
+                     unsigned long long* d_tmp, uint32_t* out_idx, uint64_t* out_ids, float* out_val,
+                     uint32_t* out_n, hipStream_t stream) {
+    ORAMA_REQUIRE(k >= 1 && k <= kSelectMaxK && q >= 1 && d_keys && out_val, "keys top-k: bad arguments");
+    ProfScope prof(&ctx->prof, "topk_select", stream);
+    const unsigned long long* cur = d_keys;
+    uint64_t cur_stride = stride;
+    uint32_t n = n_keys;
+    unsigned long long* tmp = d_tmp;
+    while (n > kSelectMaxK) {
+        ORAMA_REQUIRE(tmp, "keys top-k: scratch missing");
+        const uint32_t chunks = (n + kKeysChunk - 1) / kKeysChunk;
+        const uint64_t out_stride = (uint64_t)chunks * k;
+        hipLaunchKernelGGL(keys_reduce_kernel, dim3(chunks, q), dim3(kSortThreads), 0, stream, cur, n, cur_stride, k,
+                           tmp, out_stride);
+        cur = tmp;
+        cur_stride = out_stride;
+        n = chunks * k;
+        tmp = tmp + (uint64_t)q * out_stride;  // next level (if any) writes behind this one
+    }
+    hipLaunchKernelGGL(keys_final_kernel, dim3(q), dim3(kSortThreads), 0, stream, cur, n, cur_stride, k, descending,
+                       id_map, out_idx, out_ids, out_val, out_n);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
 
 int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
     ORAMA_REQUIRE(p.k >= 1 && p.k <= kSelectMaxK, "top-k: k=%u outside [1, %u]", p.k, kSelectMaxK);

@@ -87,6 +87,8 @@ __global__ __launch_bounds__(kScanThreads) void vec_scan_f32_kernel(ScanArgs a) 
         qscale = qq > 0.0f ? 1.0f / sqrtf(qq) : 0.0f;  // zero-norm query: similarity 0
     }
     const bool filtered = (a.dead != nullptr) || (a.allow != nullptr);
+    const bool fused = a.wave_lists != nullptr;
+    WaveTopK best;
 
     for (uint64_t r0 = (uint64_t)wave * ROWS; r0 < a.n; r0 += (uint64_t)nwaves * ROWS) {
         f32x4 x[ROWS][NCHUNK];
@@ -133,9 +135,22 @@ __global__ __launch_bounds__(kScanThreads) void vec_scan_f32_kernel(ScanArgs a) 
                 dist = tot;
             }
             if (!live[r]) dist = __builtin_nanf("");
-            if (lane == r) mine = dist;
+            if (fused) {
+                if (live[r] && dist == dist) {  // smaller distance wins, then lower row: key = ~ordered(d) << 32 | ~row
+                    const unsigned long long key =
+                        ((unsigned long long)(~f32_to_ordered(dist)) << 32) | (unsigned long long)(uint32_t)(~(uint32_t)(r0 + r));
+                    if (best.count < a.topk || key > best.thr) best.insert(key, a.topk, lane);
+                }
+            } else if (lane == r) {
+                mine = dist;
+            }
         }
-        if (lane < ROWS && r0 + lane < a.n) a.out_dist[r0 + lane] = mine;
+        if (!fused && lane < ROWS && r0 + lane < a.n) a.out_dist[r0 + lane] = mine;
+    }
+    if (fused) {
+        unsigned long long* out = a.wave_lists + (uint64_t)wave * kWaveListKeys;
+        out[lane] = best.s0;
+        out[lane + 64] = best.s1;
     }
 }
 
@@ -152,6 +167,8 @@ __global__ __launch_bounds__(kScanThreads) void vec_scan_f32_generic_kernel(Scan
         qq = wave_sum(qq);
         qscale = qq > 0.0f ? 1.0f / sqrtf(qq) : 0.0f;
     }
+    const bool fused = a.wave_lists != nullptr;
+    WaveTopK best;
     for (uint64_t row = wave; row < a.n; row += nwaves) {
         const bool live = !row_excluded(row, a.dead, a.row_doc, a.allow, a.allow_bits);
         float acc = 0.0f;
@@ -169,7 +186,20 @@ __global__ __launch_bounds__(kScanThreads) void vec_scan_f32_generic_kernel(Scan
         const float tot = wave_sum(acc);
         float dist = METRIC == ORAMA_METRIC_COSINE ? 1.0f - tot * (a.inv_norm[row] * qscale) : tot;
         if (!live) dist = __builtin_nanf("");
-        if (lane == 0) a.out_dist[row] = dist;
+        if (fused) {
+            if (live && dist == dist) {
+                const unsigned long long key =
+                    ((unsigned long long)(~f32_to_ordered(dist)) << 32) | (unsigned long long)(uint32_t)(~(uint32_t)row);
+                if (best.count < a.topk || key > best.thr) best.insert(key, a.topk, lane);
+            }
+        } else if (lane == 0) {
+            a.out_dist[row] = dist;
+        }
+    }
+    if (fused) {
+        unsigned long long* out = a.wave_lists + (uint64_t)wave * kWaveListKeys;
+        out[lane] = best.s0;
+        out[lane + 64] = best.s1;
     }
 }
 
@@ -300,47 +330,74 @@ uint32_t grid_for_rows(uint64_t n_rows_per_wave_units, uint32_t cap) {
 
 }  // namespace
 
+namespace {
+// geometry shared by the launcher and vec_scan_f32_waves()
+struct ScanGeom {
+    bool vec4;
+    int nchunk;
+    bool exact;
+    int rows;
+    uint32_t blocks;
+};
+ScanGeom scan_geom(orama_ctx* ctx, const ScanArgs& a) {
+    const ScanTuning& t = ctx->scan_tuning;
+    const uint32_t cap = (uint32_t)ctx->compute_units * (uint32_t)t.blocks_per_cu;
+    const uint32_t d4 = a.dim >> 2;
+    ScanGeom g{};
+    g.vec4 = (a.dim & 3) == 0 && d4 <= 4 * kWave;
+    if (g.vec4) {
+        g.nchunk = (int)((d4 + kWave - 1) / kWave);
+        g.exact = (d4 == (uint32_t)g.nchunk * kWave);
+        g.rows = t.rows_per_wave;
+        while (g.rows * g.nchunk > 16) g.rows >>= 1;
+        g.blocks = grid_for_rows((a.n + g.rows - 1) / g.rows, cap);
+    } else {
+        g.rows = 1;
+        g.blocks = grid_for_rows(a.n, cap);
+    }
+    return g;
+}
+}  // namespace
+
+uint32_t vec_scan_f32_waves(orama_ctx* ctx, const ScanArgs& a) {
+    return a.n ? scan_geom(ctx, a).blocks * kWavesPerBlock : 0;
+}
+
 int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a, hipStream_t stream) {
-    ORAMA_REQUIRE(a.corpus && a.query && a.out_dist && a.dim > 0, "vec_scan: bad arguments");
+    ORAMA_REQUIRE(a.corpus && a.query && a.dim > 0, "vec_scan: bad arguments");
+    ORAMA_REQUIRE(a.out_dist || (a.wave_lists && a.topk >= 1 && a.topk <= kWaveListKeys), "vec_scan: no output mode");
     ORAMA_REQUIRE(a.metric != ORAMA_METRIC_COSINE || a.inv_norm, "vec_scan: cosine needs inv_norm");
     ORAMA_REQUIRE(!a.allow || a.row_doc, "vec_scan: filter needs row_doc");
+    ORAMA_REQUIRE(a.n < 0xffffffffull, "vec_scan: too many rows");
     if (a.n == 0) return ORAMA_OK;
     const ScanTuning& t = ctx->scan_tuning;
     ProfScope prof(&ctx->prof, "vec_scan_f32", stream);
-    const uint32_t cap = (uint32_t)ctx->compute_units * (uint32_t)t.blocks_per_cu;
-    const uint32_t d4 = a.dim >> 2;
-    if ((a.dim & 3) == 0 && d4 <= 4 * kWave) {
-        const int nchunk = (int)((d4 + kWave - 1) / kWave);
-        const bool exact = (d4 == (uint32_t)nchunk * kWave);
-        int rows = t.rows_per_wave;
-        while (rows * nchunk > 16) rows >>= 1;
-        dim3 grid(grid_for_rows((a.n + rows - 1) / rows, cap));
-        switch (nchunk) {
+    const ScanGeom g = scan_geom(ctx, a);
+    const dim3 grid(g.blocks);
+    if (g.vec4) {
+        switch (g.nchunk) {
             case 1:
-                exact ? launch_scan_rows<1, true>(a, t, grid, stream)
-                      : launch_scan_rows<1, false>(a, t, grid, stream);
+                g.exact ? launch_scan_rows<1, true>(a, t, grid, stream)
+                        : launch_scan_rows<1, false>(a, t, grid, stream);
                 break;
             case 2:
-                exact ? launch_scan_rows<2, true>(a, t, grid, stream)
-                      : launch_scan_rows<2, false>(a, t, grid, stream);
+                g.exact ? launch_scan_rows<2, true>(a, t, grid, stream)
+                        : launch_scan_rows<2, false>(a, t, grid, stream);
                 break;
             case 3:
-                exact ? launch_scan_rows<3, true>(a, t, grid, stream)
-                      : launch_scan_rows<3, false>(a, t, grid, stream);
+                g.exact ? launch_scan_rows<3, true>(a, t, grid, stream)
+                        : launch_scan_rows<3, false>(a, t, grid, stream);
                 break;
             default:
-                exact ? launch_scan_rows<4, true>(a, t, grid, stream)
-                      : launch_scan_rows<4, false>(a, t, grid, stream);
+                g.exact ? launch_scan_rows<4, true>(a, t, grid, stream)
+                        : launch_scan_rows<4, false>(a, t, grid, stream);
                 break;
         }
     } else {
-        dim3 grid(grid_for_rows(a.n, cap));
         if (a.metric == ORAMA_METRIC_COSINE)
-            hipLaunchKernelGGL((vec_scan_f32_generic_kernel<ORAMA_METRIC_COSINE>), grid,
-                               dim3(kScanThreads), 0, stream, a);
+            hipLaunchKernelGGL((vec_scan_f32_generic_kernel<ORAMA_METRIC_COSINE>), grid, dim3(kScanThreads), 0, stream, a);
         else
-            hipLaunchKernelGGL((vec_scan_f32_generic_kernel<ORAMA_METRIC_L2SQ>), grid,
-                               dim3(kScanThreads), 0, stream, a);
+            hipLaunchKernelGGL((vec_scan_f32_generic_kernel<ORAMA_METRIC_L2SQ>), grid, dim3(kScanThreads), 0, stream, a);
     }
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;

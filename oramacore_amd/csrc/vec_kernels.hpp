@@ -23,11 +23,18 @@ struct ScanArgs {
     const uint32_t* dead = nullptr;      // nullable bitmap over rows, bit set = tombstoned
     const uint64_t* allow = nullptr;     // nullable bitmap over doc ids
     uint64_t allow_bits = 0;
-    float* out_dist = nullptr;           // n distances; NaN for excluded rows
+    float* out_dist = nullptr;           // dense mode: n distances; NaN for excluded rows
+    // fused top-k mode (k <= 128): every wave keeps its own best-k of the rows it scans and writes them as
+    // 128 composite keys (~ordered(distance) << 32 | ~row, 0 = empty) to wave_lists[wave * 128 ...]
+    unsigned long long* wave_lists = nullptr;
+    uint32_t topk = 0;
 };
 
 // K1: one corpus pass, one query.  Algorithmic HBM traffic: n * dim * 4 bytes.
 int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a, hipStream_t stream);
+// Number of waves launch_vec_scan_f32 will use for `a` (= number of 128-key lists written in fused mode).
+uint32_t vec_scan_f32_waves(orama_ctx* ctx, const ScanArgs& a);
+constexpr uint32_t kWaveListKeys = 128;
 
 // 1/|x| per row (cosine) for rows [first, first + n).
 int launch_row_inv_norm_f32(const float* corpus, uint64_t first, uint64_t n, uint32_t dim,

@@ -144,6 +144,34 @@ int search_enqueue_f32(orama_vec* v, Scratch* sc, const float* d_queries, uint32
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
                        uint32_t* d_out_n, hipStream_t s) {
     const uint64_t n = v->n_rows;
+    if (k <= kWaveListKeys && v->ctx->fused_topk) {
+        // fused path: each K1 wave keeps its own best-k in registers; no dense distance array at all.
+        ScanArgs a;
+        a.corpus = v->rows.as<float>();
+        a.inv_norm = v->inv_norm.as<float>();
+        a.n = n;
+        a.dim = v->dim;
+        a.metric = v->metric;
+        a.row_doc = v->row_doc.as<uint64_t>();
+        a.dead = v->n_dead ? v->dead.as<uint32_t>() : nullptr;
+        a.allow = d_allow;
+        a.allow_bits = allow_bits;
+        a.topk = k;
+        const uint32_t waves = vec_scan_f32_waves(v->ctx, a);
+        const uint32_t n_keys = waves * kWaveListKeys;
+        const uint32_t chunks = (n_keys + kKeysChunk - 1) / kKeysChunk;
+        ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * (size_t)q * n_keys));
+        ORAMA_TRY(sc->dist.reserve(sizeof(unsigned long long) * (size_t)q * (size_t)(chunks + 1) * k * 2 + 64));
+        for (uint32_t j = 0; j < q; ++j) {
+            a.query = d_queries + (size_t)j * v->dim;
+            a.wave_lists = sc->sel_keys.as<unsigned long long>() + (size_t)j * n_keys;
+            ORAMA_TRY(launch_vec_scan_f32(v->ctx, a, s));
+        }
+        return launch_keys_topk(v->ctx, sc->sel_keys.as<unsigned long long>(), n_keys, n_keys, q, k, false,
+                                v->row_doc.as<uint64_t>(), sc->dist.as<unsigned long long>(), nullptr, d_out_ids,
+                                d_out_dist, d_out_n, s);
+    }
+    // dense path (k > 128): distances for every row, then K4 radix select.
     // queries are processed in groups so that the dense distance buffer stays <= ~1 GiB
     uint32_t group = q;
     if (n > 0) {

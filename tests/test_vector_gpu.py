@@ -290,3 +290,25 @@ def test_concurrent_searches_with_inserts_and_deletes(ctx):
     assert not errors, errors
     assert st.info()["num_rows"] > n
     st.close()
+
+
+def test_experimental_fused_topk_path_is_exact(monkeypatch):
+    """ORAMA_FUSED_TOPK=1 (per-wave register top-k inside K1; off by default because it measured slower) must
+    return exactly what the default dense path returns."""
+    n, d = 30_000, 768
+    corpus = util.gaussian_rows(n, d, seed=301)
+    corpus[100:104] = corpus[7]  # exact ties
+    queries = util.gaussian_rows(3, d, seed=302)
+    base_ctx = oa.Context(0)
+    st = make_store(base_ctx, corpus)
+    want = [st.storage_search(queries, k) for k in (1, 10, 100, 128)]
+    st.close()
+    base_ctx.close()
+    monkeypatch.setenv("ORAMA_FUSED_TOPK", "1")
+    fctx = oa.Context(0)
+    st = make_store(fctx, corpus)
+    for k, w in zip((1, 10, 100, 128), want):
+        got = st.storage_search(queries, k)
+        assert np.array_equal(got[0], w[0]) and np.array_equal(got[1], w[1]) and np.array_equal(got[2], w[2])
+    st.close()
+    fctx.close()
