@@ -1,0 +1,303 @@
+// orama/host.hpp — C++ host-side mirror of the reference's interfaces for the scoring hot path, header-only,
+// on top of the C ABI (orama_hip.h).  The reference is Rust; this image has no Rust toolchain, so this mirror
+// (same names, argument meaning and error behaviour) is what a C++ host — and the parity tests in
+// tests/host/ — program against; INTEGRATION.md shows the equivalent Rust shim.
+//
+//   reference item                                                        here
+//   --------------------------------------------------------------------  ---------------------------------
+//   EmbeddingFieldStorage  (sides/read/index/embedding_field.rs:63-320)   orama::host::EmbeddingFieldStorage
+//   VectorSearchParams     (index/committed_field/vector.rs:10-15)        orama::host::VectorSearchParams
+//   Model::{dimensions,rescale_score} (src/python/embeddings.rs:52-92)    orama::host::Model
+//   FilterResult<DocumentId> as a predicate (embedding_field.rs:54-61)    orama::host::DocBitmap
+//   BM25Scorer<DocumentId> (src/collection_manager/bm25.rs:135-323)       orama::host::BM25Scorer
+//   top_n                  (sides/read/sort.rs:260-279)                   orama::host::top_n
+//   normalize_and_combine  (index/token_score.rs:393-422)                 orama::host::normalize_and_combine
+//   apply_omc_multipliers  (sides/read/search.rs:39-48)                   folded into the scoring calls
+//   anyhow::Error                                                         orama::host::Error (status + message)
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../orama_hip.h"
+
+namespace orama {
+namespace host {
+
+using DocumentId = uint64_t;  // types.rs:112
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string& m) : std::runtime_error("liborama_hip status " + std::to_string(s) + ": " + m), status(s) {}
+};
+inline void check(int status) {
+    if (status != ORAMA_OK) throw Error(status, orama_last_error());
+}
+
+struct TokenScore {  // types.rs:363-366
+    DocumentId document_id;
+    float score;
+};
+
+class Context {
+   public:
+    explicit Context(int device = 0) { check(orama_ctx_create(device, &h_)); }
+    ~Context() { orama_ctx_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    orama_ctx* raw() const { return h_; }
+
+   private:
+    orama_ctx* h_ = nullptr;
+};
+
+enum class Model {  // src/python/embeddings.rs:13-63
+    BGESmall, BGEBase, BGELarge, JinaEmbeddingsV2BaseCode, MultilingualE5Small, MultilingualE5Base,
+    MultilingualE5Large, MultilingualMiniLML12V2
+};
+inline size_t dimensions(Model m) {
+    switch (m) {
+        case Model::BGESmall: case Model::MultilingualE5Small: case Model::MultilingualMiniLML12V2: return 384;
+        case Model::BGEBase: case Model::JinaEmbeddingsV2BaseCode: case Model::MultilingualE5Base: return 768;
+        default: return 1024;
+    }
+}
+inline bool is_e5(Model m) {
+    return m == Model::MultilingualE5Small || m == Model::MultilingualE5Base || m == Model::MultilingualE5Large;
+}
+inline float rescale_score(Model m, float score) {  // embeddings.rs:71-92
+    if (!is_e5(m)) return score;
+    const float MIN = 0.7f, MAX = 1.0f, DELTA = MAX - MIN;
+    float c = score;
+    if (c < MIN) c = MIN;
+    if (c > MAX) c = MAX;
+    return (c - MIN) / DELTA;
+}
+
+// FilterResult<DocumentId> materialised as a bitmap over document ids (bit d set <=> `contains(d)`).
+struct DocBitmap {
+    std::vector<uint64_t> words;
+    uint64_t bits = 0;
+    explicit DocBitmap(uint64_t n_bits = 0) : words((n_bits + 63) / 64, 0), bits(n_bits) {}
+    void insert(DocumentId d) {
+        if (d < bits) words[d >> 6] |= 1ull << (d & 63);
+    }
+    bool contains(DocumentId d) const { return d < bits && ((words[d >> 6] >> (d & 63)) & 1ull); }
+};
+
+struct VectorSearchParams {  // committed_field/vector.rs:10-15
+    const std::vector<float>* target = nullptr;
+    float similarity = 0.7f;  // Similarity default, types.rs:879-885
+    size_t limit = 10;        // Limit default, types.rs:748-754
+    const DocBitmap* filtered_doc_ids = nullptr;
+};
+
+class EmbeddingFieldStorage {
+   public:
+    EmbeddingFieldStorage(Context& ctx, Model model) : model_(model), dim_(dimensions(model)) {  // :65-76
+        check(orama_vec_create(ctx.raw(), (uint32_t)dim_, ORAMA_METRIC_COSINE, ORAMA_DTYPE_F32, 0, &h_));
+    }
+    ~EmbeddingFieldStorage() { orama_vec_destroy(h_); }
+    EmbeddingFieldStorage(const EmbeddingFieldStorage&) = delete;
+    EmbeddingFieldStorage& operator=(const EmbeddingFieldStorage&) = delete;
+    Model model() const { return model_; }
+
+    // insert — :232-237 (N vectors per document; vectors the indexer rejects are dropped silently)
+    void insert(DocumentId doc_id, const std::vector<std::vector<float>>& vectors) {
+        std::vector<float> flat;
+        std::vector<uint64_t> ids;
+        for (const auto& v : vectors) {
+            if (v.size() != dim_) continue;
+            flat.insert(flat.end(), v.begin(), v.end());
+            ids.push_back(doc_id);
+        }
+        if (!ids.empty()) check(orama_vec_insert(h_, ids.data(), flat.data(), ids.size(), nullptr));
+    }
+    void remove(DocumentId doc_id) { check(orama_vec_delete(h_, &doc_id, 1)); }  // delete — :240-242
+    void compact(uint64_t version) { check(orama_vec_compact(h_, version)); }    // :286-290
+    bool has_pending_ops() const { return info().pending_ops > 0; }              // :281-283
+    uint64_t current_version_number() const { return info().version; }           // :298-300
+    orama_vec_info_t info() const {
+        orama_vec_info_t i{};
+        check(orama_vec_info(h_, &i));
+        return i;
+    }
+
+    // search — :250-278.  The storage call returns (doc, cosine distance) per row; the epilogue below is the
+    // reference's own code: similarity = 1 - distance, rescale, cut-off, per-document sum.
+    void search(const VectorSearchParams& params, std::unordered_map<DocumentId, float>& output) const {
+        if (!params.target || params.target->size() != dim_) throw Error(ORAMA_ERR_INVALID, "target dimension mismatch");
+        const size_t k = params.limit;
+        std::vector<uint64_t> ids(k ? k : 1);
+        std::vector<float> dist(k ? k : 1);
+        uint32_t n = 0;
+        const uint64_t* bm = params.filtered_doc_ids ? params.filtered_doc_ids->words.data() : nullptr;
+        const uint64_t bits = params.filtered_doc_ids ? params.filtered_doc_ids->bits : 0;
+        check(orama_vec_search(h_, params.target->data(), 1, (uint32_t)k, bm, bits, ids.data(), dist.data(), &n));
+        for (uint32_t i = 0; i < n; ++i) {
+            const float similarity = 1.0f - dist[i];
+            const float score = rescale_score(model_, similarity);
+            if (score >= params.similarity) output[ids[i]] += score;
+        }
+    }
+    orama_vec* raw() const { return h_; }
+
+   private:
+    Model model_;
+    size_t dim_;
+    orama_vec* h_ = nullptr;
+};
+
+struct TopResult {
+    std::vector<TokenScore> hits;  // top-(limit+offset), score desc, DocumentId asc
+    uint64_t count = 0;            // token_score_results.len() — search.rs:482
+};
+
+// BM25Scorer<DocumentId> restricted to the calls search_full_text makes (token_score.rs:211-302).  The
+// reference scores while contributions arrive; here they are recorded and `top_n()/get_scores()` runs the
+// GPU pass (orama_bm25_score): accumulate per (token, doc), finalise with the Lucene idf, threshold mask,
+// OMC, count, top-k.
+class BM25Scorer {
+   public:
+    static BM25Scorer plain(Context& ctx) { return BM25Scorer(ctx, false, 0); }
+    static BM25Scorer with_threshold(Context& ctx, uint32_t threshold) { return BM25Scorer(ctx, true, threshold); }
+
+    void reset_term() { cur_.clear(); }
+    void add_precomputed_field(DocumentId key, float normalized_tf, float weight) {
+        cur_.emplace_back(key, weight * normalized_tf);
+    }
+    size_t current_term_document_count() const {
+        std::map<DocumentId, int> s;
+        for (auto& c : cur_) s[c.first] = 1;
+        return s.size();
+    }
+    // finalize_term / finalize_term_plain — bm25.rs:202-240.  corpus_term_frequency must be the number of
+    // distinct documents of the term (what the in-tree caller passes, token_score.rs:262-275).
+    void finalize_term(size_t corpus_term_frequency, float total_documents, float k, float phrase_boost = 1.0f,
+                       uint32_t /*token_indexes*/ = 0) {
+        if (phrase_boost != 1.0f) throw Error(ORAMA_ERR_UNSUPPORTED, "phrase_boost != 1.0");
+        if (corpus_term_frequency != std::max<size_t>(current_term_document_count(), 1))
+            throw Error(ORAMA_ERR_UNSUPPORTED, "corpus_term_frequency must equal the distinct documents of the term");
+        total_documents_ = total_documents;
+        k_ = k;
+        // split the push stream into runs with unique documents = posting-list entries, in push order
+        std::vector<uint64_t> d;
+        std::vector<float> v;
+        std::map<DocumentId, int> seen;
+        auto flush = [&] {
+            entries_.push_back(Entry{term_index_, d, v});
+            d.clear();
+            v.clear();
+            seen.clear();
+        };
+        for (auto& c : cur_) {
+            if (seen.count(c.first)) flush();
+            seen[c.first] = 1;
+            d.push_back(c.first);
+            v.push_back(c.second);
+        }
+        flush();
+    }
+    void finalize_term_plain(size_t df, float total_documents, float k, float phrase_boost = 1.0f) {
+        finalize_term(df, total_documents, k, phrase_boost, 0);
+    }
+    void next_term() {
+        ++term_index_;
+        cur_.clear();
+    }
+
+    // get_scores() + apply_omc_multipliers + count + top_n in one device pass.
+    TopResult top_n(size_t n, const std::map<DocumentId, float>& omc = {}) const {
+        std::vector<orama_ntf_entry> raw;
+        for (const auto& e : entries_)
+            raw.push_back(orama_ntf_entry{e.token, e.doc.data(), e.ntf.data(), (uint64_t)e.doc.size()});
+        orama_bm25_params p{};
+        p.total_documents = total_documents_;
+        p.k = k_;
+        p.n_tokens = std::max<uint32_t>(term_index_, 1);
+        p.use_threshold = with_threshold_ ? 1 : 0;
+        p.threshold = threshold_;
+        p.top_k = (uint32_t)n;
+        std::vector<uint64_t> od, ids(n ? n : 1);
+        std::vector<float> om, sc(n ? n : 1);
+        for (auto& kv : omc) {
+            od.push_back(kv.first);
+            om.push_back(kv.second);
+        }
+        uint32_t out_n = 0;
+        TopResult r;
+        check(orama_bm25_score(ctx_.raw(), raw.data(), (uint32_t)raw.size(), &p, od.data(), om.data(), od.size(),
+                               ids.data(), sc.data(), &out_n, &r.count));
+        for (uint32_t i = 0; i < out_n; ++i) r.hits.push_back(TokenScore{ids[i], sc[i]});
+        return r;
+    }
+    std::unordered_map<DocumentId, float> get_scores() const {
+        size_t total = 0;
+        for (const auto& e : entries_) total += e.doc.size();
+        TopResult r = top_n(std::min<size_t>(std::max<size_t>(total, 1), 4096));
+        if (r.count > r.hits.size()) throw Error(ORAMA_ERR_UNSUPPORTED, "get_scores(): more than 4096 entries; use top_n()");
+        std::unordered_map<DocumentId, float> m;
+        for (auto& h : r.hits) m[h.document_id] = h.score;
+        return m;
+    }
+
+   private:
+    struct Entry {
+        uint32_t token;
+        std::vector<uint64_t> doc;
+        std::vector<float> ntf;
+    };
+    BM25Scorer(Context& ctx, bool wt, uint32_t thr) : ctx_(ctx), with_threshold_(wt), threshold_(thr) {}
+    Context& ctx_;
+    bool with_threshold_;
+    uint32_t threshold_;
+    uint32_t term_index_ = 0;
+    float total_documents_ = 1.0f, k_ = 1.2f;
+    std::vector<std::pair<DocumentId, float>> cur_;
+    std::vector<Entry> entries_;
+};
+
+// top_n — sort.rs:260-279
+inline std::vector<TokenScore> top_n(Context& ctx, const std::unordered_map<DocumentId, float>& token_scores, size_t n) {
+    std::vector<uint64_t> d, ids(n ? n : 1);
+    std::vector<float> s, sc(n ? n : 1);
+    for (auto& kv : token_scores) {
+        d.push_back(kv.first);
+        s.push_back(kv.second);
+    }
+    uint32_t out_n = 0;
+    check(orama_top_n(ctx.raw(), d.data(), s.data(), d.size(), (uint32_t)n, ids.data(), sc.data(), &out_n));
+    std::vector<TokenScore> r;
+    for (uint32_t i = 0; i < out_n; ++i) r.push_back(TokenScore{ids[i], sc[i]});
+    return r;
+}
+
+// normalize_and_combine — token_score.rs:393-422 (+ count + top_n)
+inline TopResult normalize_and_combine(Context& ctx, const std::unordered_map<DocumentId, float>& vector,
+                                       const std::unordered_map<DocumentId, float>& fulltext, size_t n) {
+    std::vector<uint64_t> vd, fd, ids(n ? n : 1);
+    std::vector<float> vs, fs, sc(n ? n : 1);
+    for (auto& kv : vector) {
+        vd.push_back(kv.first);
+        vs.push_back(kv.second);
+    }
+    for (auto& kv : fulltext) {
+        fd.push_back(kv.first);
+        fs.push_back(kv.second);
+    }
+    uint32_t out_n = 0;
+    TopResult r;
+    check(orama_hybrid_combine(ctx.raw(), vd.data(), vs.data(), vd.size(), fd.data(), fs.data(), fd.size(),
+                               (uint32_t)n, ids.data(), sc.data(), &out_n, &r.count));
+    for (uint32_t i = 0; i < out_n; ++i) r.hits.push_back(TokenScore{ids[i], sc[i]});
+    return r;
+}
+
+}  // namespace host
+}  // namespace orama

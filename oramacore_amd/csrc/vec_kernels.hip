@@ -57,7 +57,7 @@ __device__ __forceinline__ bool row_excluded(uint64_t row, const uint32_t* dead,
 }
 
 // NCHUNK = ceil(dim/4 / 64) 16-byte pieces per lane per row; EXACT: dim/4 == 64*NCHUNK.
-template <int NCHUNK, bool EXACT, int ROWS, bool NT, int METRIC>
+template <int NCHUNK, bool EXACT, int ROWS, bool NT, int METRIC, bool FUSED>
 __global__ __launch_bounds__(kScanThreads) void vec_scan_f32_kernel(ScanArgs a) {
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform_u32(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kScanThreads) void vec_scan_f32_kernel(ScanArgs a) 
         qscale = qq > 0.0f ? 1.0f / sqrtf(qq) : 0.0f;  // zero-norm query: similarity 0
     }
     const bool filtered = (a.dead != nullptr) || (a.allow != nullptr);
-    const bool fused = a.wave_lists != nullptr;
+    constexpr bool fused = FUSED;  // compile-time: the dense kernel carries none of the list state
     WaveTopK best;
 
     for (uint64_t r0 = (uint64_t)wave * ROWS; r0 < a.n; r0 += (uint64_t)nwaves * ROWS) {
@@ -205,12 +205,22 @@ __global__ __launch_bounds__(kScanThreads) void vec_scan_f32_generic_kernel(Scan
 
 template <int NCHUNK, bool EXACT, int ROWS, bool NT>
 void launch_scan_metric(const ScanArgs& a, dim3 grid, hipStream_t s) {
-    if (a.metric == ORAMA_METRIC_COSINE)
-        hipLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_COSINE>), grid,
-                           dim3(kScanThreads), 0, s, a);
-    else
-        hipLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_L2SQ>), grid,
-                           dim3(kScanThreads), 0, s, a);
+    const bool fused = a.wave_lists != nullptr;
+    if (a.metric == ORAMA_METRIC_COSINE) {
+        if (fused)
+            hipLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_COSINE, true>), grid,
+                               dim3(kScanThreads), 0, s, a);
+        else
+            hipLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_COSINE, false>), grid,
+                               dim3(kScanThreads), 0, s, a);
+    } else {
+        if (fused)
+            hipLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_L2SQ, true>), grid,
+                               dim3(kScanThreads), 0, s, a);
+        else
+            hipLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_L2SQ, false>), grid,
+                               dim3(kScanThreads), 0, s, a);
+    }
 }
 
 template <int NCHUNK, bool EXACT>
