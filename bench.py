@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the RCCL all-gather + merge even with one rank (plumbing test)")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the steps are issued on round-robin (independent queries: the tiny top-k / "
+                         "all-gather / merge kernels of step i overlap the corpus scan of step i+1)")
     return ap.parse_args()
 
 
@@ -143,7 +146,20 @@ def main():
     rng = np.random.default_rng(0xBEEF)
     queries_h = rng.standard_normal((total_b * qb, dim)).astype(np.float32)
     queries = torch.from_numpy(queries_h).to(device)
-    searcher = ShardedSearcher(HipOps(ctx, store), rank, world, device, always_exchange=args.force_exchange)
+    # Stream plan: ONE scan stream (corpus scans of consecutive steps run back to back, never concurrently, so
+    # each keeps the whole HBM bandwidth) + `--streams` tail streams used round-robin for top-k / all-gather /
+    # merge, which are launch-bound and overlap the next step's scan.
+    n_streams = max(1, args.streams)
+    scan_stream = torch.cuda.Stream(device=device) if n_streams > 1 else None
+    # tail streams are HIGH priority: ROCm gives priority levels their own hardware queues, so the launch-bound
+    # tail never queues behind a scan in the same HW queue (observed with same-priority streams: profiles/).
+    streams = [torch.cuda.Stream(device=device, priority=-1 if n_streams > 1 else 0) for _ in range(n_streams)]
+    searchers = [ShardedSearcher(HipOps(ctx, store, scan_stream), rank, world, device,
+                                 always_exchange=args.force_exchange) for _ in range(n_streams)]
+
+    def step(i):
+        with torch.cuda.stream(streams[i % n_streams]):
+            return searchers[i % n_streams].search(queries[i * qb:(i + 1) * qb], k)
 
     def barrier():
         torch.cuda.synchronize()
@@ -152,13 +168,13 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        searcher.search(queries[i * qb:(i + 1) * qb], k)
+        step(i)
     barrier()
     ctx.prof_reset()
     ctx.prof_enable(True)
     t0 = time.perf_counter()
     for i in range(args.warmup, total_b):
-        ids, dst, cnt = searcher.search(queries[i * qb:(i + 1) * qb], k)
+        ids, dst, cnt = step(i)
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
@@ -219,7 +235,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": desc, "rows_total": n_total, "rows_per_gpu": n_local, "dim": dim, "k": k,
                    "queries_per_step": qb, "parallelism": f"row-shard x{world} + all-gather(top-k) over RCCL"
-                   if world > 1 else "single GPU", "valid": not bool(args.rows)},
+                   if world > 1 else "single GPU", "streams": n_streams, "valid": not bool(args.rows)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "bytes/launch", "traffic_source": traffic_src,

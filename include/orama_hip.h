@@ -145,6 +145,13 @@ uint64_t orama_packed_block_bytes(uint32_t q, uint32_t k);
 int orama_vec_search_packed_device(orama_vec* v, const float* d_queries, uint32_t q, uint32_t k,
                                    const uint64_t* d_allow_bitmap, uint64_t bitmap_bits,
                                    void* d_packed_block, uint32_t* d_out_n, void* hip_stream);
+/* Two-stream form: the corpus scan(s) are enqueued on `scan_stream`, the top-k tail on `tail_stream` (the
+ * library inserts the scan→tail and tail→next-scan event dependencies).  A caller that alternates between two
+ * tail streams keeps ONE scan in flight at all times while the launch-bound tail (top-k, all-gather, merge) of
+ * the previous query runs beside it — consecutive scans never share HBM bandwidth. */
+int orama_vec_search_packed_device2(orama_vec* v, const float* d_queries, uint32_t q, uint32_t k,
+                                    const uint64_t* d_allow_bitmap, uint64_t bitmap_bits, void* d_packed_block,
+                                    uint32_t* d_out_n, void* scan_stream, void* tail_stream);
 int orama_merge_packed_device(orama_ctx* ctx, const void* d_packed_blocks, uint32_t lists, uint32_t q,
                               uint32_t k, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n,
                               void* hip_stream);

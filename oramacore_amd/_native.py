@@ -132,6 +132,7 @@ def _declare(lib: C.CDLL) -> None:
         "orama_vec_search_device": [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp],
         "orama_merge_candidates_device": [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp],
         "orama_vec_search_packed_device": [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, vp],
+        "orama_vec_search_packed_device2": [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp],
         "orama_merge_packed_device": [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp],
         "orama_vec_fill_synthetic": [vp, C.c_uint64, C.c_uint64, C.c_uint64],
         "orama_vec_get_rows": [vp, vp, C.c_uint64, vp, vp],

@@ -147,8 +147,13 @@ struct Scratch {
     // BM25 accumulators: epoch-stamped, zeroed only when (re)allocated (see bm25_kernels.hip)
     DevBuf bm25_acc, bm25_seen, bm25_emit;
     uint32_t bm25_epoch = 0;
+    // two-stream search (scan on one stream, top-k tail on another): scan → tail and tail → next-scan ordering
+    hipEvent_t ev_scan = nullptr, ev_tail = nullptr;
+    bool tail_recorded = false;
     ~Scratch() {
         if (stream) (void)hipStreamDestroy(stream);
+        if (ev_scan) (void)hipEventDestroy(ev_scan);
+        if (ev_tail) (void)hipEventDestroy(ev_tail);
     }
 };
 

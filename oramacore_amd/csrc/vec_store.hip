@@ -140,9 +140,31 @@ int store_rows_from_device(orama_vec* v, void* rows_base, float* norm_base, cons
 }
 
 // ---------------------------------------------------------------- f32: K1 + dense K4
+// Stream ordering of the two-stream mode: scans run on `s_scan`, the top-k tail on `s`; the tail waits for its
+// scan, and a scan that reuses this scratch set waits for the previous tail (events in the scratch set).
+int scan_begin(Scratch* sc, hipStream_t s_scan, hipStream_t s) {
+    if (s_scan == s) return ORAMA_OK;
+    if (!sc->ev_scan) ORAMA_HIP_TRY(hipEventCreateWithFlags(&sc->ev_scan, hipEventDisableTiming));
+    if (!sc->ev_tail) ORAMA_HIP_TRY(hipEventCreateWithFlags(&sc->ev_tail, hipEventDisableTiming));
+    if (sc->tail_recorded) ORAMA_HIP_TRY(hipStreamWaitEvent(s_scan, sc->ev_tail, 0));
+    return ORAMA_OK;
+}
+int scan_end(Scratch* sc, hipStream_t s_scan, hipStream_t s) {
+    if (s_scan == s) return ORAMA_OK;
+    ORAMA_HIP_TRY(hipEventRecord(sc->ev_scan, s_scan));
+    ORAMA_HIP_TRY(hipStreamWaitEvent(s, sc->ev_scan, 0));
+    return ORAMA_OK;
+}
+int tail_end(Scratch* sc, hipStream_t s_scan, hipStream_t s) {
+    if (s_scan == s) return ORAMA_OK;
+    ORAMA_HIP_TRY(hipEventRecord(sc->ev_tail, s));
+    sc->tail_recorded = true;
+    return ORAMA_OK;
+}
+
 int search_enqueue_f32(orama_vec* v, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
-                       uint32_t* d_out_n, hipStream_t s) {
+                       uint32_t* d_out_n, hipStream_t s, hipStream_t s_scan) {
     const uint64_t n = v->n_rows;
     if (k <= kWaveListKeys && v->ctx->fused_topk) {
         // fused path: each K1 wave keeps its own best-k in registers; no dense distance array at all.
@@ -162,14 +184,17 @@ int search_enqueue_f32(orama_vec* v, Scratch* sc, const float* d_queries, uint32
         const uint32_t chunks = (n_keys + kKeysChunk - 1) / kKeysChunk;
         ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * (size_t)q * n_keys));
         ORAMA_TRY(sc->dist.reserve(sizeof(unsigned long long) * (size_t)q * (size_t)(chunks + 1) * k * 2 + 64));
+        ORAMA_TRY(scan_begin(sc, s_scan, s));
         for (uint32_t j = 0; j < q; ++j) {
             a.query = d_queries + (size_t)j * v->dim;
             a.wave_lists = sc->sel_keys.as<unsigned long long>() + (size_t)j * n_keys;
-            ORAMA_TRY(launch_vec_scan_f32(v->ctx, a, s));
+            ORAMA_TRY(launch_vec_scan_f32(v->ctx, a, s_scan));
         }
-        return launch_keys_topk(v->ctx, sc->sel_keys.as<unsigned long long>(), n_keys, n_keys, q, k, false,
+        ORAMA_TRY(scan_end(sc, s_scan, s));
+        ORAMA_TRY(launch_keys_topk(v->ctx, sc->sel_keys.as<unsigned long long>(), n_keys, n_keys, q, k, false,
                                 v->row_doc.as<uint64_t>(), sc->dist.as<unsigned long long>(), nullptr, d_out_ids,
-                                d_out_dist, d_out_n, s);
+                                d_out_dist, d_out_n, s));
+        return tail_end(sc, s_scan, s);
     }
     // dense path (k > 128): distances for every row, then K4 radix select.
     // queries are processed in groups so that the dense distance buffer stays <= ~1 GiB
@@ -183,6 +208,7 @@ int search_enqueue_f32(orama_vec* v, Scratch* sc, const float* d_queries, uint32
     ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * (size_t)group * k));
     for (uint32_t q0 = 0; q0 < q; q0 += group) {
         const uint32_t gq = (q - q0) < group ? (q - q0) : group;
+        ORAMA_TRY(scan_begin(sc, s_scan, s));
         for (uint32_t j = 0; j < gq; ++j) {
             ScanArgs a;
             a.corpus = v->rows.as<float>();
@@ -196,8 +222,9 @@ int search_enqueue_f32(orama_vec* v, Scratch* sc, const float* d_queries, uint32
             a.allow = d_allow;
             a.allow_bits = allow_bits;
             a.out_dist = sc->dist.as<float>() + (size_t)j * n;
-            ORAMA_TRY(launch_vec_scan_f32(v->ctx, a, s));
+            ORAMA_TRY(launch_vec_scan_f32(v->ctx, a, s_scan));
         }
+        ORAMA_TRY(scan_end(sc, s_scan, s));
         SelectPlan p;
         p.vals = sc->dist.as<float>();
         p.stride = n;
@@ -212,6 +239,7 @@ int search_enqueue_f32(orama_vec* v, Scratch* sc, const float* d_queries, uint32
         p.out_val = d_out_dist + (size_t)q0 * k;
         p.out_n = d_out_n + q0;
         ORAMA_TRY(launch_select(v->ctx, p, s));
+        ORAMA_TRY(tail_end(sc, s_scan, s));
     }
     return ORAMA_OK;
 }
@@ -339,13 +367,15 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
     return ORAMA_OK;
 }
 
+// `s_scan` (nullable = same as s): stream the corpus scans run on.  The f16 pipeline interleaves scans and
+// selections with dependencies in both directions, so it stays on `s`.
 int search_enqueue(orama_vec* v, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                    const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
-                   uint32_t* d_out_n, hipStream_t s) {
+                   uint32_t* d_out_n, hipStream_t s, hipStream_t s_scan = nullptr, bool two_streams = false) {
     return v->f16() ? search_enqueue_f16(v, sc, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist,
                                          d_out_n, s)
                     : search_enqueue_f32(v, sc, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist,
-                                         d_out_n, s);
+                                         d_out_n, s, two_streams ? s_scan : s);
 }
 
 }  // namespace
@@ -613,6 +643,27 @@ int orama_vec_search_device(orama_vec* v, const float* d_queries, uint32_t q, ui
         sc = slot.get();
     }
     return search_enqueue(v, sc, d_queries, q, k, d_allow_bitmap, bitmap_bits, d_out_ids, d_out_dist, d_out_n, s);
+}
+
+int orama_vec_search_packed_device2(orama_vec* v, const float* d_queries, uint32_t q, uint32_t k,
+                                    const uint64_t* d_allow_bitmap, uint64_t bitmap_bits, void* d_packed_block,
+                                    uint32_t* d_out_n, void* scan_stream, void* tail_stream) {
+    ORAMA_REQUIRE(v && d_packed_block, "null argument");
+    ORAMA_REQUIRE(q >= 1 && d_queries && d_out_n, "null argument");
+    ORAMA_REQUIRE(k >= 1 && k <= kSelectMaxK, "limit %u outside [1, %u]", k, kSelectMaxK);
+    ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
+    hipStream_t s = (hipStream_t)tail_stream, ss = (hipStream_t)scan_stream;
+    std::shared_lock<std::shared_mutex> lk(v->mu);
+    Scratch* sc = nullptr;
+    {
+        std::lock_guard<std::mutex> g(v->dev_mu);
+        auto& slot = v->dev_scratch[s];
+        if (!slot) slot.reset(new Scratch());
+        sc = slot.get();
+    }
+    char* base = reinterpret_cast<char*>(d_packed_block);
+    return search_enqueue(v, sc, d_queries, q, k, d_allow_bitmap, bitmap_bits, reinterpret_cast<uint64_t*>(base),
+                          reinterpret_cast<float*>(base + (uint64_t)q * k * 8), d_out_n, s, ss, true);
 }
 
 int orama_merge_candidates_device(orama_ctx* ctx, const uint64_t* d_ids, const float* d_dist,

@@ -50,15 +50,21 @@ class ShardPlan:
 class HipOps:
     """The product's compute steps: K1+K4 on the local shard, K6 merge — through the C ABI."""
 
-    def __init__(self, ctx, store):
+    def __init__(self, ctx, store, scan_stream=None):
         self.lib = N.load()
         self.ctx = ctx
         self.store = store
+        self.scan_stream = scan_stream  # torch.cuda.Stream shared by all searchers: corpus scans run there, in order
 
     def local_topk(self, queries: torch.Tensor, k: int, block: torch.Tensor, out_n: torch.Tensor) -> None:
         stream = torch.cuda.current_stream().cuda_stream
-        N.check(self.lib.orama_vec_search_packed_device(self.store.handle, queries.data_ptr(), queries.shape[0], k,
-                                                        None, 0, block.data_ptr(), out_n.data_ptr(), stream))
+        if self.scan_stream is None:
+            N.check(self.lib.orama_vec_search_packed_device(self.store.handle, queries.data_ptr(), queries.shape[0], k,
+                                                            None, 0, block.data_ptr(), out_n.data_ptr(), stream))
+        else:
+            N.check(self.lib.orama_vec_search_packed_device2(self.store.handle, queries.data_ptr(), queries.shape[0],
+                                                             k, None, 0, block.data_ptr(), out_n.data_ptr(),
+                                                             self.scan_stream.cuda_stream, stream))
 
     def merge(self, blocks: torch.Tensor, lists: int, q: int, k: int, out_ids: torch.Tensor,
               out_dist: torch.Tensor, out_n: torch.Tensor) -> None:
