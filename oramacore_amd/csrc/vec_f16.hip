@@ -81,28 +81,37 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
     const uint32_t gwaves = gridDim.x * kWavesPerBlock;
     const uint64_t t_first = a.row_begin >> 5;
     const uint64_t t_end = (a.row_end + 31) >> 5;
-    if (t_first + gw >= t_end) return;
-    const uint64_t my_tiles = (t_end - t_first - gw + gwaves - 1) / gwaves;
+    const uint64_t n_tiles = t_end - t_first;
+    if (gw >= n_tiles) return;
+    const uint64_t tile0 = t_first + gw;  // wave w takes tiles w, w + W, …: the chip sweeps one window
+    const uint64_t tile_step = gwaves;
+    const uint64_t my_tiles = (n_tiles - gw + gwaves - 1) / gwaves;
     const uint32_t nc = ksteps / kChunk;  // chunks per tile
     const char* base = reinterpret_cast<const char*>(a.tiled);
 
     f16v acc[NQT];
     f4 buf[NBUF][KC];
-    uint64_t ld_tile = t_first + gw;  // (tile, chunk) cursor of the NEXT load
+    uint64_t ld_tile = tile0;  // (tile, chunk) cursor of the NEXT load
     uint32_t ld_c = 0;
-    uint64_t ld_left = my_tiles * nc;
-    uint64_t cp_tile = t_first + gw;  // cursor of the NEXT compute
+    uint64_t ld_more = my_tiles * nc - 1;  // chunks still to load after the one under the cursor
+    uint64_t cp_tile = tile0;              // cursor of the NEXT compute
     uint32_t cp_c = 0;
 
-    auto load_chunk = [&](f4* buf) {
+    // The chunk loads are UNCONDITIONAL (past the end the cursor stays on the wave's last chunk and re-reads
+    // it): with a fixed number of loads between a chunk's issue and its use, the compiler's s_waitcnt pass
+    // emits counted vmcnt(N) waits that leave the NBUF-1 prefetched chunks in flight.  (Conditional loads made
+    // it fall back to vmcnt(<KC), which drained the ring before every chunk: 5.4 → see profiles/.)
+    auto load_chunk = [&](f4* b) {
         const f4* p = reinterpret_cast<const f4*>(base + ld_tile * tile_bytes + (uint64_t)ld_c * kChunk * 1024) + lane;
 #pragma unroll
-        for (int s = 0; s < kChunk; ++s) buf[s] = __builtin_nontemporal_load(p + s * 64);
-        if (++ld_c == nc) {
-            ld_c = 0;
-            ld_tile += gwaves;
+        for (int s = 0; s < kChunk; ++s) b[s] = __builtin_nontemporal_load(p + s * 64);
+        if (ld_more) {
+            --ld_more;
+            if (++ld_c == nc) {
+                ld_c = 0;
+                ld_tile += tile_step;
+            }
         }
-        --ld_left;
     };
 
     // per-lane constants of the epilogue: this lane's query column per tile, its 1/|q| and threshold
@@ -113,18 +122,19 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
         qi_reg[qt] = qinv[j];
         tau_reg[qt] = (a.tau && j < a.q) ? a.tau[j] : 0.0f;
     }
-    // 1/|x| of the 16 accumulator rows of this lane, fetched at tile START (4 x 16 B: rows 8g+4h+0..3)
-    // so that the epilogue never waits on memory behind the prefetched corpus chunks
-    f4 nrm[4];
-    uint32_t dead_word = 0;
-    auto prefetch_tile_meta = [&](uint64_t tile) {
-        const f4* np = reinterpret_cast<const f4*>(a.inv_norm + tile * 32 + 4 * (lane >> 5));
-#pragma unroll
-        for (int g = 0; g < 4; ++g) nrm[g] = np[2 * g];
-        dead_word = a.dead ? a.dead[tile] : 0u;
-    };
+    // Tile metadata (1/|x| of the 32 rows, tombstone word) comes through SCALAR loads (constant address space,
+    // wave-uniform address → s_load, counted by lgkmcnt): a vector load here would sit in the in-order vmcnt
+    // queue behind the prefetched corpus chunks and force them to drain at every tile.
+    typedef const float __attribute__((address_space(4))) cfloat;
+    typedef const uint32_t __attribute__((address_space(4))) cu32;
 
     auto epilogue = [&](uint64_t tile) {
+        cfloat* cn = (cfloat*)(uintptr_t)(a.inv_norm + tile * 32);
+        float nrm_s[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) nrm_s[i] = cn[i];
+        const uint32_t dead_word = a.dead ? ((cu32*)(uintptr_t)a.dead)[tile] : 0u;
+        const bool hi_half = (lane >> 5) != 0;
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) {
             const uint32_t j = qt * 32 + (lane & 31);
@@ -133,7 +143,8 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
             const float tau = tau_reg[qt];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int i0 = (r & 3) + 8 * (r >> 2);
+                const uint32_t i = (uint32_t)i0 + (hi_half ? 4u : 0u);
                 const uint64_t row = tile * 32 + i;
                 if (row >= a.row_end || !jok) continue;
                 bool excluded = (dead_word >> i) & 1u;
@@ -141,7 +152,8 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
                     const uint64_t doc = a.row_doc[row];
                     excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
                 }
-                const float dist = 1.0f - acc[qt][r] * (nrm[r >> 2][r & 3] * qi);
+                const float inv = hi_half ? nrm_s[i0 + 4] : nrm_s[i0];
+                const float dist = 1.0f - acc[qt][r] * (inv * qi);
                 if (a.out_dense) {
                     a.out_dense[(uint64_t)j * a.dense_stride + (row - a.row_begin)] =
                         excluded ? __builtin_nanf("") : dist;
@@ -154,18 +166,17 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
         }
     };
 
-    auto compute_chunk = [&](const f4* buf) {
+    auto compute_chunk = [&](const f4* b) {
         if (cp_c == 0) {
 #pragma unroll
             for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[qt][r] = 0.0f;
-            prefetch_tile_meta(cp_tile);
         }
         const char* bl = lds + ((size_t)cp_c * kChunk * NQT * 64 + lane) * 16;
 #pragma unroll
         for (int s = 0; s < kChunk; ++s) {
-            const h8 av = as_h8(buf[s]);
+            const h8 av = as_h8(b[s]);
 #pragma unroll
             for (int qt = 0; qt < NQT; ++qt) {
                 const h8 bv = *reinterpret_cast<const h8*>(bl + (size_t)(s * NQT + qt) * 1024);
@@ -175,20 +186,26 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
         if (++cp_c == nc) {
             epilogue(cp_tile);
             cp_c = 0;
-            cp_tile += gwaves;
+            cp_tile += tile_step;
         }
     };
 
-    uint64_t todo = my_tiles * nc;
+    const uint64_t total = my_tiles * nc;
 #pragma unroll
-    for (int b = 0; b < NBUF - 1; ++b)
-        if (ld_left) load_chunk(buf[b]);
-    while (todo) {
+    for (int b = 0; b < NBUF - 1; ++b) load_chunk(buf[b]);
+    uint64_t g = 0;
+    for (; g + NBUF <= total; g += NBUF) {
 #pragma unroll
         for (int b = 0; b < NBUF; ++b) {
-            if (ld_left) load_chunk(buf[(b + NBUF - 1) % NBUF]);
+            load_chunk(buf[(b + NBUF - 1) % NBUF]);
             compute_chunk(buf[b]);
-            if (--todo == 0) break;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) {  // tail: total - g < NBUF chunks, already in flight
+        if (g + b < total) {
+            load_chunk(buf[(b + NBUF - 1) % NBUF]);
+            compute_chunk(buf[b]);
         }
     }
 }

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Run a few K2 scans (C3 shape) — target for rocprofv3 --pmc passes."""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import oramacore_amd as oa  # noqa: E402
+
+ctx = oa.Context(0)
+n, d, q = 10_000_000, 768, 64
+st = oa.EmbeddingFieldStorage(ctx, dimensions=d, reserve_rows=n, dtype=oa.DTYPE_F16)
+st.fill_synthetic(n, seed=1)
+qs = np.random.default_rng(0).standard_normal((q, d)).astype(np.float32)
+for _ in range(4):
+    st.storage_search(qs, 100)
