@@ -8,7 +8,7 @@
 // Data flow per query (all HBM-resident, no host round trip in the resident mode):
 //   accumulate (one launch per entry rank; rank-0 covers every token's first posting list):
 //       for each posting (doc, tf|len) of each (token, list) reference, coalesced 2 x 4-byte loads,
-//       S[token][doc] (+)= boost * tf / (1 - b + b*len/avglen); first touch of (token, doc) bumps
+//       S[doc][token] (+)= boost * tf / (1 - b + b*len/avglen); first touch of (token, doc) bumps
 //       df[token]; first touch of doc appends it to the touched list.  Inside one launch a
 //       (token, doc) cell is written by at most one thread (docs are unique inside a list), so the
 //       f32 accumulation order across a token's lists is the list order — deterministic, no atomics
@@ -29,6 +29,7 @@ namespace orama {
 namespace {
 
 constexpr int kThreads = 256;
+constexpr uint32_t kNoDoc = 0xffffffffu;  // empty slot of the touched / candidate lists
 
 __device__ __forceinline__ bool f32_is_normal(float x) {
     const uint32_t e = (__builtin_bit_cast(uint32_t, x) >> 23) & 0xffu;
@@ -55,9 +56,13 @@ __global__ __launch_bounds__(kThreads) void bm25_accumulate_kernel(Bm25Accum a) 
         const uint64_t p = s.post_begin + (v - s.virt_begin);
         const uint32_t doc = a.post_doc[p];
         const uint32_t val = a.post_val[p];
+        uint32_t first_touch_doc = kNoDoc;
         if (a.allow) {  // collect_contributions_with_filter: filtered docs never reach the scorer
             const uint64_t id = a.docs[doc];
-            if (id >= a.allow_bits || !((a.allow[id >> 6] >> (id & 63)) & 1ull)) continue;
+            if (id >= a.allow_bits || !((a.allow[id >> 6] >> (id & 63)) & 1ull)) {
+                a.touched[a.virt_base + v] = kNoDoc;
+                continue;
+            }
         }
         float ntf;
         if (PRE) {
@@ -67,20 +72,24 @@ __global__ __launch_bounds__(kThreads) void bm25_accumulate_kernel(Bm25Accum a) 
             const float len = (float)(val & 0xffffu);
             ntf = s.boost * (tf / (one_minus_b + a.b * (len / s.avg_len)));
         }
-        unsigned long long* w = a.acc + (uint64_t)s.token * a.n_docs + doc;
+        unsigned long long* rec = a.acc + (uint64_t)doc * a.slots;
+        unsigned long long* w = rec + s.token;
         const unsigned long long old = *w;
         float sum;
         if ((uint32_t)(old >> 32) != a.epoch) {
             sum = 0.0f + 1.0f * ntf;  // Iterator::sum() from 0.0, weight = 1.0
             atomicAdd(&df_lds[s.token], 1u);
-            if (atomicExch(&a.seen[doc], a.epoch) != a.epoch) {
-                const uint32_t pos = atomicAdd(&a.state->touched_count, 1u);
-                a.touched[pos] = doc;
+            // first touch of the doc in this query: the stamp lives in the HIGH word of the record's last cell,
+            // the same position accumulator cells keep their epoch, so a scratch set shared by queries with
+            // different record sizes can never mistake stale float bits for a stamp
+            if (atomicExch(reinterpret_cast<uint32_t*>(rec + (a.slots - 1)) + 1, a.epoch) != a.epoch) {
+                first_touch_doc = doc;
             }
         } else {
             sum = __builtin_bit_cast(float, (uint32_t)old) + 1.0f * ntf;
         }
         *w = ((unsigned long long)a.epoch << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, sum);
+        a.touched[a.virt_base + v] = first_touch_doc;
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < kMaxTokens; i += kThreads)
@@ -100,16 +109,21 @@ __global__ __launch_bounds__(kThreads) void bm25_finalize_kernel(Bm25Finalize f)
         }
     }
     __syncthreads();
-    const uint32_t n = f.state->touched_count;
+    const uint32_t n = f.n_slots;
     const float k1 = f.k + 1.0f;
-    uint32_t my_max = 0u, my_min = 0xffffffffu;
+    uint32_t my_max = 0u, my_min = 0xffffffffu, my_count = 0u;
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         const uint32_t doc = f.touched[i];
+        // slot i of the candidate list mirrors slot i of the touched list; empty = (NaN, kNoDoc)
+        f.cand_idx[i] = kNoDoc;
+        f.cand_score[i] = __builtin_nanf("");
+        if (doc == kNoDoc) continue;
         float score = 0.0f;  // entry(key).or_insert(0.0)
         uint32_t mask = 0u;
         bool applied = false;
+        const unsigned long long* rec = f.acc + (uint64_t)doc * f.slots;
         for (uint32_t t = 0; t < f.n_tokens; ++t) {
-            const unsigned long long w = f.acc[(uint64_t)t * f.n_docs + doc];
+            const unsigned long long w = rec[t];
             if ((uint32_t)(w >> 32) != f.epoch) continue;
             const float s = __builtin_bit_cast(float, (uint32_t)w);
             if (!f32_is_normal(s)) continue;
@@ -122,34 +136,44 @@ __global__ __launch_bounds__(kThreads) void bm25_finalize_kernel(Bm25Finalize f)
         if (!applied) continue;
         if (f.use_threshold && (uint32_t)__popc(mask) < f.threshold) continue;
         if (f.omc_dense) score = score * f.omc_dense[doc];
-        const uint32_t pos = atomicAdd(&f.state->cand_count, 1u);
-        f.cand_score[pos] = score;
-        f.cand_idx[pos] = doc;
-        f.emit[doc] = ((unsigned long long)f.epoch << 32) | (unsigned long long)pos;
+        f.cand_score[i] = score;
+        f.cand_idx[i] = doc;
+        f.emit[doc] = ((unsigned long long)f.epoch << 32) | (unsigned long long)i;
+        ++my_count;
         if (TRACK_MINMAX && score == score) {
             const uint32_t key = f32_to_ordered(score);
             my_max = max(my_max, key);
             my_min = min(my_min, key);
         }
     }
-    if (TRACK_MINMAX) {  // wave reduce → LDS block reduce → ONE pair of atomics per block
-        __shared__ uint32_t blk_max, blk_min;
-        if (threadIdx.x == 0) {
-            blk_max = 0u;
-            blk_min = 0xffffffffu;
-        }
-        __syncthreads();
+    // wave reduce → LDS block reduce → ONE atomic per block and quantity (a hot word retires ~88 atomics/µs,
+    // so per-wave atomics on `cand_count` alone used to cost ~0.1 ms at 600K slots)
+    __shared__ uint32_t blk_max, blk_min, blk_count;
+    if (threadIdx.x == 0) {
+        blk_max = 0u;
+        blk_min = 0xffffffffu;
+        blk_count = 0u;
+    }
+    __syncthreads();
+    my_count = wave_sum_u32(my_count);
+    if (TRACK_MINMAX) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, off, 64));
             my_min = min(my_min, (uint32_t)__shfl_xor((int)my_min, off, 64));
         }
-        if ((threadIdx.x & 63) == 0) {
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (my_count) atomicAdd(&blk_count, my_count);
+        if (TRACK_MINMAX) {
             atomicMax(&blk_max, my_max);
             atomicMin(&blk_min, my_min);
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (blk_count) atomicAdd(&f.state->cand_count, blk_count);
+        if (TRACK_MINMAX) {
             if (blk_max != 0u) atomicMax(&f.state->max_key, blk_max);
             if (blk_min != 0xffffffffu) atomicMin(&f.state->min_key, blk_min);
         }
@@ -177,9 +201,9 @@ __global__ __launch_bounds__(kThreads) void hybrid_normalize_kernel(HybridCombin
     float mn, mx;
     hybrid_min_max(h, mn, mx);
     const float den = mx - mn;
-    const uint32_t n = h.state->cand_count;
+    const uint32_t n = h.state->list_len;
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
-        h.cand_score[i] = (h.cand_score[i] - mn) / den;
+        if (h.cand_idx[i] != kNoDoc) h.cand_score[i] = (h.cand_score[i] - mn) / den;
 }
 
 __global__ __launch_bounds__(kThreads) void hybrid_add_vector_kernel(HybridCombine h) {
@@ -194,7 +218,8 @@ __global__ __launch_bounds__(kThreads) void hybrid_add_vector_kernel(HybridCombi
             const uint32_t pos = (uint32_t)e;
             h.cand_score[pos] = h.cand_score[pos] + v;  // *e += v
         } else {
-            const uint32_t pos = atomicAdd(&h.state->cand_count, 1u);
+            const uint32_t pos = atomicAdd(&h.state->list_len, 1u);  // <= limit appends per query
+            atomicAdd(&h.state->cand_count, 1u);
             h.cand_score[pos] = 0.0f + v;  // entry(k).or_default() += v
             h.cand_idx[pos] = doc;
             h.emit[doc] = ((unsigned long long)h.epoch << 32) | (unsigned long long)pos;
@@ -226,16 +251,19 @@ __global__ __launch_bounds__(kThreads) void hybrid_ingest_kernel(uint32_t n, uin
         if (my_max != 0u) atomicMax(&state->max_key, my_max);
         if (my_min != 0xffffffffu) atomicMin(&state->min_key, my_min);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) state->cand_count = n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        state->cand_count = n;
+        state->list_len = n;
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void omc_dense_kernel(const float* __restrict__ omc,
                                                              const Bm25State* __restrict__ state,
                                                              const uint32_t* __restrict__ cand_idx,
                                                              float* __restrict__ cand_score) {
-    const uint32_t n = state->cand_count;
+    const uint32_t n = state->list_len;
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
-        cand_score[i] = cand_score[i] * omc[cand_idx[i]];
+        if (cand_idx[i] != kNoDoc) cand_score[i] = cand_score[i] * omc[cand_idx[i]];
 }
 
 __global__ __launch_bounds__(kThreads) void omc_sparse_kernel(const uint32_t* __restrict__ idx,
@@ -326,8 +354,8 @@ int launch_bm25_finalize(orama_ctx* ctx, const Bm25Finalize& f, hipStream_t stre
                   f.n_tokens, kMaxTokens);
     ORAMA_REQUIRE(f.idf_table || f.idf_vals, "bm25: idf source missing");
     ProfScope prof(&ctx->prof, "bm25_finalize", stream);
-    dim3 grid(grid_for(f.touched_cap ? f.touched_cap : 1, ctx, 1));
-    if (f.track_minmax && grid.x > (uint32_t)ctx->compute_units * 2u) grid.x = (uint32_t)ctx->compute_units * 2u;
+    dim3 grid(grid_for(f.n_slots ? f.n_slots : 1, ctx, 1));
+    if (grid.x > (uint32_t)ctx->compute_units * 4u) grid.x = (uint32_t)ctx->compute_units * 4u;
     if (f.track_minmax)
         hipLaunchKernelGGL(bm25_finalize_kernel<true>, grid, dim3(kThreads), 0, stream, f);
     else

@@ -25,7 +25,7 @@ struct Bm25Seg {
 // Query-scoped device state (zeroed per query with one memset).
 struct Bm25State {
     uint32_t df[kMaxTokens];   // distinct docs per token (corpus_docs.len(), token_score.rs:262-275)
-    uint32_t touched_count;    // docs touched by any token
+    uint32_t list_len;         // slots of the candidate list in use (host: one per posting; + appended vector docs)
     uint32_t cand_count;       // docs in the score map (== `count`, search.rs:482)
     uint32_t max_key;          // ordered(max score) over non-NaN candidates, 0 if none
     uint32_t min_key;          // ordered(min score), 0xffffffff if none
@@ -45,9 +45,17 @@ struct Bm25Accum {
     uint64_t allow_bits = 0;
     uint32_t epoch = 0;
     uint64_t n_docs = 0;
-    unsigned long long* acc = nullptr;  // [n_tokens][n_docs] {epoch:32 | S:f32}
-    uint32_t* seen = nullptr;           // [n_docs] epoch of the last query that touched the doc
-    uint32_t* touched = nullptr;        // list of touched local docs
+    // Per-document record of `slots` 8-byte cells (slots = pow2 >= n_tokens + 1, one or a few cache lines):
+    // cell t < n_tokens = {epoch:32 | S_t:f32}; the LAST cell's high word = epoch of the last query that touched
+    // the doc.  A posting's accumulator update and its first-touch test hit the same line, and finalise reads a
+    // document's token cells contiguously.
+    unsigned long long* acc = nullptr;  // [n_docs][slots]
+    uint32_t slots = 0;
+    // touched[virt_base + v] = doc when posting v is the doc's first touch in this query, else 0xffffffff:
+    // a slot per posting instead of a compacted list — no returning atomics on a shared cursor (one hot word
+    // saturates at ~88 atomics/us on MI355X, which was the whole cost of this kernel)
+    uint32_t* touched = nullptr;
+    uint64_t virt_base = 0;             // first slot of this launch (launches of one query are laid end to end)
     Bm25State* state = nullptr;
 };
 int launch_bm25_accumulate(orama_ctx* ctx, const Bm25Accum& a, hipStream_t stream);
@@ -63,9 +71,10 @@ struct Bm25Finalize {
     const float* omc_dense = nullptr;  // nullable: multiplier per local doc (applied to the final score)
     uint32_t epoch = 0;
     uint64_t n_docs = 0;
-    const unsigned long long* acc = nullptr;
+    const unsigned long long* acc = nullptr;  // [n_docs][slots]
+    uint32_t slots = 0;
     const uint32_t* touched = nullptr;
-    uint32_t touched_cap = 0;          // host-side upper bound of touched_count (grid sizing)
+    uint32_t n_slots = 0;              // slots written by the accumulate launches (= postings referenced)
     Bm25State* state = nullptr;
     // outputs: the score map as a candidate list + dense position index
     float* cand_score = nullptr;

@@ -145,7 +145,7 @@ struct Scratch {
     DevBuf misc0, misc1, misc2, misc3, misc4, misc5;
     PinnedBuf h_in, h_out, h_misc;
     // BM25 accumulators: epoch-stamped, zeroed only when (re)allocated (see bm25_kernels.hip)
-    DevBuf bm25_acc, bm25_seen, bm25_emit;
+    DevBuf bm25_acc, bm25_emit;
     uint32_t bm25_epoch = 0;
     // two-stream search (scan on one stream, top-k tail on another): scan → tail and tail → next-scan ordering
     hipEvent_t ev_scan = nullptr, ev_tail = nullptr;

@@ -35,23 +35,21 @@ struct QueryBuffers {
     float* cand_score = nullptr;
     uint32_t* cand_idx = nullptr;
     unsigned long long* acc = nullptr;
-    uint32_t* seen = nullptr;
+    uint32_t slots = 0;  // cells per document record: pow2 >= n_tokens + 1
     unsigned long long* emit = nullptr;
     uint32_t epoch = 0;
 };
 
 // Carve the per-query device buffers out of the scratch set and start a new epoch.
-int prepare_query(Scratch* sc, uint64_t n_docs, uint32_t n_tokens, uint64_t cand_cap, QueryBuffers* qb) {
+int prepare_query(Scratch* sc, uint64_t n_docs, uint32_t n_tokens, uint64_t cand_cap, uint32_t n_slots,
+                  QueryBuffers* qb) {
     hipStream_t s = sc->stream;
-    const bool grew = (size_t)n_tokens * n_docs * 8 > sc->bm25_acc.cap || (size_t)n_docs * 4 > sc->bm25_seen.cap ||
-                      (size_t)n_docs * 8 > sc->bm25_emit.cap;
-    ORAMA_TRY(reserve_zeroed(sc->bm25_acc, (size_t)n_tokens * n_docs * 8, s));
-    ORAMA_TRY(reserve_zeroed(sc->bm25_seen, (size_t)n_docs * 4, s));
+    uint32_t slots = 2;
+    while (slots < n_tokens + 1) slots <<= 1;
+    ORAMA_TRY(reserve_zeroed(sc->bm25_acc, (size_t)slots * n_docs * 8, s));
     ORAMA_TRY(reserve_zeroed(sc->bm25_emit, (size_t)n_docs * 8, s));
-    (void)grew;
     if (sc->bm25_epoch == 0xffffffffu) {  // wrap: forget every stamp
         ORAMA_HIP_TRY(hipMemsetAsync(sc->bm25_acc.p, 0, sc->bm25_acc.cap, s));
-        ORAMA_HIP_TRY(hipMemsetAsync(sc->bm25_seen.p, 0, sc->bm25_seen.cap, s));
         ORAMA_HIP_TRY(hipMemsetAsync(sc->bm25_emit.p, 0, sc->bm25_emit.cap, s));
         sc->bm25_epoch = 0;
     }
@@ -64,13 +62,14 @@ int prepare_query(Scratch* sc, uint64_t n_docs, uint32_t n_tokens, uint64_t cand
     Bm25State* hs = sc->h_misc.as<Bm25State>();
     memset(hs, 0, sizeof(Bm25State));
     hs->min_key = 0xffffffffu;
+    hs->list_len = n_slots;  // one candidate slot per referenced posting; hybrid appends behind them
     ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc2.p, hs, sizeof(Bm25State), hipMemcpyHostToDevice, s));
     qb->state = sc->misc2.as<Bm25State>();
     qb->touched = sc->misc3.as<uint32_t>();
     qb->cand_score = sc->misc4.as<float>();
     qb->cand_idx = sc->misc5.as<uint32_t>();
     qb->acc = sc->bm25_acc.as<unsigned long long>();
-    qb->seen = sc->bm25_seen.as<uint32_t>();
+    qb->slots = slots;
     qb->emit = sc->bm25_emit.as<unsigned long long>();
     return ORAMA_OK;
 }
@@ -91,7 +90,7 @@ int select_and_download(orama_ctx* ctx, Scratch* sc, const QueryBuffers& qb, con
         p.vals = qb.cand_score;
         p.idx = qb.cand_idx;
         p.stride = 0;
-        p.n_dev = &qb.state->cand_count;
+        p.n_dev = &qb.state->list_len;
         p.n = cand_cap;
         p.q = 1;
         p.k = top_k;
@@ -233,9 +232,10 @@ int post_stage1(orama_post* p, Scratch* sc, const orama_term_ref* refs, uint32_t
     ORAMA_REQUIRE(total_postings < 0xffffffffull, "query touches too many postings");
     hipStream_t s = sc->stream;
     st->hybrid = hybrid;
-    st->touched_cap = std::min<uint64_t>(total_postings, p->n_docs);
+    st->touched_cap = total_postings;  // one slot per posting (first touches hold the doc, the rest are empty)
     st->cand_cap = st->touched_cap + n_vec_cap;
-    ORAMA_TRY(prepare_query(sc, p->n_docs ? p->n_docs : 1, params->n_tokens, st->cand_cap, &st->qb));
+    ORAMA_TRY(prepare_query(sc, p->n_docs ? p->n_docs : 1, params->n_tokens, st->cand_cap, (uint32_t)total_postings,
+                            &st->qb));
     ORAMA_TRY(ensure_idf_table(p, params->total_documents, s));
     const QueryBuffers& qb = st->qb;
 
@@ -282,8 +282,11 @@ int post_stage1(orama_post* p, Scratch* sc, const orama_term_ref* refs, uint32_t
         memcpy(sc->h_in.p, segs.data(), seg_bytes);
         ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, sc->h_in.p, seg_bytes, hipMemcpyHostToDevice, s));
     }
+    uint64_t virt_base = 0;
     for (uint32_t r = 0; r < max_rank; ++r) {
         Bm25Accum a;
+        a.virt_base = virt_base;
+        virt_base += rank_total[r];
         a.post_doc = p->d_post_doc.as<uint32_t>();
         a.post_val = p->d_post_val.as<uint32_t>();
         a.segs = sc->misc0.as<Bm25Seg>() + rank_begin[r];
@@ -297,7 +300,7 @@ int post_stage1(orama_post* p, Scratch* sc, const orama_term_ref* refs, uint32_t
         a.epoch = qb.epoch;
         a.n_docs = p->n_docs;
         a.acc = qb.acc;
-        a.seen = qb.seen;
+        a.slots = qb.slots;
         a.touched = qb.touched;
         a.state = qb.state;
         ORAMA_TRY(launch_bm25_accumulate(p->ctx, a, s));
@@ -314,8 +317,9 @@ int post_stage1(orama_post* p, Scratch* sc, const orama_term_ref* refs, uint32_t
     f.epoch = qb.epoch;
     f.n_docs = p->n_docs;
     f.acc = qb.acc;
+    f.slots = qb.slots;
     f.touched = qb.touched;
-    f.touched_cap = (uint32_t)st->touched_cap;
+    f.n_slots = (uint32_t)st->touched_cap;
     f.state = qb.state;
     f.cand_score = qb.cand_score;
     f.cand_idx = qb.cand_idx;
@@ -729,9 +733,9 @@ int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_
     ScratchLease sc(ctx);
     ORAMA_TRY(sc.init());
     hipStream_t s = sc->stream;
-    const uint64_t touched_cap = std::min<uint64_t>(total, n_docs);
+    const uint64_t touched_cap = total;  // one slot per posting
     QueryBuffers qb;
-    ORAMA_TRY(prepare_query(sc.s.get(), n_docs, params->n_tokens, touched_cap, &qb));
+    ORAMA_TRY(prepare_query(sc.s.get(), n_docs, params->n_tokens, touched_cap, (uint32_t)total, &qb));
 
     // pack postings (local doc, ntf bits) + segments grouped by rank + doc table
     std::vector<uint32_t> rank(n_entries, 0), per_token(kMaxTokens, 0);
@@ -813,8 +817,11 @@ int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_
     }
     ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, hb, all_bytes, hipMemcpyHostToDevice, s));
     char* db = sc->misc0.as<char>();
+    uint64_t virt_base = 0;
     for (uint32_t r = 0; r < max_rank; ++r) {
         Bm25Accum a;
+        a.virt_base = virt_base;
+        virt_base += rank_total[r];
         a.post_doc = reinterpret_cast<const uint32_t*>(db);
         a.post_val = reinterpret_cast<const uint32_t*>(db + post_bytes);
         a.segs = reinterpret_cast<const Bm25Seg*>(db + seg_off) + rank_begin[r];
@@ -824,7 +831,7 @@ int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_
         a.epoch = qb.epoch;
         a.n_docs = n_docs;
         a.acc = qb.acc;
-        a.seen = qb.seen;
+        a.slots = qb.slots;
         a.touched = qb.touched;
         a.state = qb.state;
         ORAMA_TRY(launch_bm25_accumulate(ctx, a, s));
@@ -851,8 +858,9 @@ int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_
     f.epoch = qb.epoch;
     f.n_docs = n_docs;
     f.acc = qb.acc;
+    f.slots = qb.slots;
     f.touched = qb.touched;
-    f.touched_cap = (uint32_t)touched_cap;
+    f.n_slots = (uint32_t)touched_cap;
     f.state = qb.state;
     f.cand_score = qb.cand_score;
     f.cand_idx = qb.cand_idx;
@@ -892,7 +900,7 @@ int orama_hybrid_combine(orama_ctx* ctx, const uint64_t* vec_doc, const float* v
     hipStream_t s = sc->stream;
     const uint64_t cand_cap = n_ft + n_vec;
     QueryBuffers qb;
-    ORAMA_TRY(prepare_query(sc.s.get(), n_docs, 1, cand_cap, &qb));
+    ORAMA_TRY(prepare_query(sc.s.get(), n_docs, 1, cand_cap, (uint32_t)n_ft, &qb));
     const size_t ft_off = 0, vec_off = (size_t)n_ft * 8, doc_off = (vec_off + (size_t)n_vec * 8 + 15) & ~(size_t)15;
     const size_t all_bytes = doc_off + (size_t)n_docs * 8;
     ORAMA_TRY(sc->h_in.reserve(all_bytes + 16));
