@@ -264,6 +264,44 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
                         const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits,
                         int apply_omc, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count);
 
+/* ------------------------------------------------------------------ one index sharded over several GPUs
+ * shard g of an index holds the documents of one doc-id range — its rows in an orama_vec and its
+ * postings in an orama_post built from that range only (avg_field_len = the index-wide averages).  A query is the
+ * single-GPU search_full_text / search_hybrid (token_score.rs:186-387) cut at the three points where the
+ * reference reads index-wide quantities, with the caller running the collective (RCCL over xGMI) in between:
+ *
+ *   begin  : K3 accumulate over the local postings           d_df[n_tokens] (i32)  <- local df per token
+ *            -- all-reduce SUM of d_df:  corpus_docs.len() is index-wide (token_score.rs:262-275) --
+ *   score  : idf from the GLOBAL df and params->total_documents (the index's document_count,
+ *            token_score.rs:221), K3 finalise                 d_minmax[2] (i64)      <- hybrid only
+ *            -- hybrid: all-reduce MAX of d_minmax: min/max fold over the whole map (token_score.rs:398-401) --
+ *   finish : [hybrid: K5 with the reduced min/max; vector hits whose document lives on another shard are
+ *            skipped here and combined there] OMC, K4 local top-k
+ *                                                            d_block <- [k u64 ids][k f32 scores][pad][u64 count]
+ *            -- all-gather of the blocks, then orama_post_merge_blocks_device on every rank --
+ *
+ * Every stage is enqueued on `hip_stream` (the stream the collectives run on); only `score` touches the host
+ * (n_tokens log1pf).  df_global is a HOST array: the reduced d_df downloaded by the caller.  The query object
+ * holds the store's shared lock and one scratch set; all calls for one query must come from the same thread and
+ * end with orama_post_query_end (which waits for the stream).  Results are bit-identical to the single-store
+ * search over the union of the shards (tests/test_sharded_fulltext_gpu.py). */
+typedef struct orama_post_query orama_post_query;
+uint64_t orama_post_block_bytes(uint32_t top_k);
+int orama_post_query_begin(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, float b,
+                           const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits,
+                           int hybrid, int apply_omc, uint32_t n_vec_cap, void* hip_stream, int32_t* d_df,
+                           orama_post_query** out);
+int orama_post_query_score(orama_post_query* q, const uint32_t* df_global, int64_t* d_minmax);
+int orama_post_query_finish(orama_post_query* q, const int64_t* d_minmax_global, const uint64_t* vec_doc,
+                            const float* vec_score, uint32_t n_vec, void* d_block);
+void orama_post_query_end(orama_post_query* q);
+/* K6 over `lists` gathered blocks: global top-k (score desc, DocumentId asc) and the summed match count. */
+int orama_post_merge_blocks_device(orama_ctx* ctx, const void* d_blocks, uint32_t lists, uint32_t top_k,
+                                   uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_n,
+                                   uint64_t* d_out_count, void* hip_stream);
+/* Replace the per-field average lengths (index-wide averages for the shards of one index). */
+int orama_post_set_avg_len(orama_post* p, const float* avg_field_len, uint32_t n_fields);
+
 /* Standalone normalize_and_combine on host-provided maps (both sides small or large) — the
  * literal replacement of token_score.rs:393-422 + top_n for callers that keep seam (i). */
 int orama_hybrid_combine(orama_ctx* ctx, const uint64_t* vec_doc, const float* vec_score,

@@ -150,6 +150,12 @@ def _declare(lib: C.CDLL) -> None:
                                      C.c_uint64, vp, vp, C.c_uint32, C.c_int, vp, vp, u32p, u64p],
         "orama_hybrid_search": [vp, vp, vp, C.c_uint32, C.c_float, C.c_int, C.POINTER(TermRef), C.c_uint32, C.c_float,
                                 C.POINTER(Bm25Params), vp, C.c_uint64, C.c_int, vp, vp, u32p, u64p],
+        "orama_post_query_begin": [vp, C.POINTER(TermRef), C.c_uint32, C.c_float, C.POINTER(Bm25Params), vp, C.c_uint64,
+                                   C.c_int, C.c_int, C.c_uint32, vp, vp, C.POINTER(vp)],
+        "orama_post_query_score": [vp, vp, vp],
+        "orama_post_query_finish": [vp, vp, vp, vp, C.c_uint32, vp],
+        "orama_post_merge_blocks_device": [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp],
+        "orama_post_set_avg_len": [vp, vp, C.c_uint32],
         "orama_hybrid_combine": [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u32p, u64p],
         "orama_top_n": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u32p],
     }
@@ -159,7 +165,9 @@ def _declare(lib: C.CDLL) -> None:
         fn.restype = C.c_int
     lib.orama_packed_block_bytes.argtypes = [C.c_uint32, C.c_uint32]
     lib.orama_packed_block_bytes.restype = C.c_uint64
-    for name in ("orama_ctx_destroy", "orama_vec_destroy", "orama_post_destroy"):
+    lib.orama_post_block_bytes.argtypes = [C.c_uint32]
+    lib.orama_post_block_bytes.restype = C.c_uint64
+    for name in ("orama_ctx_destroy", "orama_vec_destroy", "orama_post_destroy", "orama_post_query_end"):
         fn = getattr(lib, name)
         fn.argtypes = [vp]
         fn.restype = None

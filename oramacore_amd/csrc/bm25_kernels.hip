@@ -280,6 +280,36 @@ __global__ __launch_bounds__(kThreads) void omc_sparse_kernel(const uint32_t* __
     }
 }
 
+// ---- sharded-index exchange words.  The all-reduce MAX runs on i64 lanes:
+//   lane 0 = ordered key of the largest full-text score (0 = none), lane 1 = 0xffffffff - smallest key.
+__global__ void minmax_export_kernel(const Bm25State* __restrict__ st, long long* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = (long long)st->max_key;
+        out[1] = (long long)(0xffffffffu - st->min_key);
+    }
+}
+__global__ void minmax_import_kernel(Bm25State* __restrict__ st, const long long* __restrict__ in) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        st->max_key = (uint32_t)in[0];
+        st->min_key = 0xffffffffu - (uint32_t)in[1];
+    }
+}
+__global__ void df_export_kernel(const Bm25State* __restrict__ st, uint32_t n_tokens, int* __restrict__ out) {
+    for (uint32_t t = threadIdx.x; t < n_tokens; t += blockDim.x) out[t] = (int)st->df[t];
+}
+__global__ void count_export_kernel(const Bm25State* __restrict__ st, unsigned long long* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (unsigned long long)st->cand_count;
+}
+__global__ void count_sum_kernel(const char* __restrict__ blocks, uint64_t stride, uint64_t off, uint32_t lists,
+                                 unsigned long long* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long c = 0;
+        for (uint32_t l = 0; l < lists; ++l)
+            c += *reinterpret_cast<const unsigned long long*>(blocks + (uint64_t)l * stride + off);
+        out[0] = c;
+    }
+}
+
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -382,6 +412,34 @@ int launch_hybrid_combine(orama_ctx* ctx, const HybridCombine& h, hipStream_t st
     if (h.omc_dense)
         hipLaunchKernelGGL(omc_dense_kernel, dim3(grid_for(h.cand_cap + h.n_vec, ctx, 1)), dim3(kThreads),
                            0, stream, h.omc_dense, h.state, h.cand_idx, h.cand_score);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_minmax_export(const Bm25State* st, long long* d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(minmax_export_kernel, dim3(1), dim3(64), 0, stream, st, d_out);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+int launch_minmax_import(Bm25State* st, const long long* d_in, hipStream_t stream) {
+    hipLaunchKernelGGL(minmax_import_kernel, dim3(1), dim3(64), 0, stream, st, d_in);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+int launch_df_export(const Bm25State* st, uint32_t n_tokens, int* d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(df_export_kernel, dim3(1), dim3(64), 0, stream, st, n_tokens, d_out);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+int launch_count_export(const Bm25State* st, unsigned long long* d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(count_export_kernel, dim3(1), dim3(64), 0, stream, st, d_out);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+int launch_count_sum(const void* d_blocks, uint64_t stride, uint64_t off, uint32_t lists, unsigned long long* d_out,
+                     hipStream_t stream) {
+    hipLaunchKernelGGL(count_sum_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const char*>(d_blocks), stride,
+                       off, lists, d_out);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

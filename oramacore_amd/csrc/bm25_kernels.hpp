@@ -109,6 +109,14 @@ int launch_hybrid_ingest(orama_ctx* ctx, uint32_t n, uint32_t epoch, const uint3
 int launch_omc_sparse(const uint32_t* d_idx, const float* d_mul, uint32_t n, uint32_t epoch,
                       const unsigned long long* emit, float* cand_score, hipStream_t stream);
 
+// ---- sharded index: the words exchanged between the stages of a staged query
+int launch_df_export(const Bm25State* st, uint32_t n_tokens, int* d_out, hipStream_t stream);
+int launch_minmax_export(const Bm25State* st, long long* d_out, hipStream_t stream);
+int launch_minmax_import(Bm25State* st, const long long* d_in, hipStream_t stream);
+int launch_count_export(const Bm25State* st, unsigned long long* d_out, hipStream_t stream);
+int launch_count_sum(const void* d_blocks, uint64_t stride, uint64_t off, uint32_t lists, unsigned long long* d_out,
+                     hipStream_t stream);
+
 // ---- synthetic postings generated in HBM (bench utility)
 // len[doc] ~ LogNormal(4.0, 0.6) clipped to [4, 2000]
 int launch_synth_doc_len(uint16_t* d_len, uint64_t n_docs, uint64_t seed, hipStream_t stream);

@@ -74,6 +74,29 @@ int prepare_query(Scratch* sc, uint64_t n_docs, uint32_t n_tokens, uint64_t cand
     return ORAMA_OK;
 }
 
+// K4 over the candidate list into caller-named device outputs
+int select_enqueue(orama_ctx* ctx, Scratch* sc, const QueryBuffers& qb, const uint64_t* d_docs, uint32_t cand_cap,
+                   uint32_t top_k, uint64_t* d_out_ids, float* d_out_val, uint32_t* d_out_n) {
+    ORAMA_TRY(sc->sel_state.reserve(sizeof(SelectState)));
+    ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * top_k));
+    SelectPlan p;
+    p.vals = qb.cand_score;
+    p.idx = qb.cand_idx;
+    p.stride = 0;
+    p.n_dev = &qb.state->list_len;
+    p.n = cand_cap;
+    p.q = 1;
+    p.k = top_k;
+    p.descending = true;
+    p.id_map = d_docs;
+    p.state = sc->sel_state.as<SelectState>();
+    p.keys = sc->sel_keys.as<unsigned long long>();
+    p.out_ids = d_out_ids;
+    p.out_val = d_out_val;
+    p.out_n = d_out_n;
+    return launch_select(ctx, p, sc->stream);
+}
+
 // top-k over the candidate list + download of (ids, scores, n, count)
 int select_and_download(orama_ctx* ctx, Scratch* sc, const QueryBuffers& qb, const uint64_t* d_docs,
                         uint32_t cand_cap, uint32_t top_k, uint64_t* out_ids, float* out_scores,
@@ -83,26 +106,9 @@ int select_and_download(orama_ctx* ctx, Scratch* sc, const QueryBuffers& qb, con
     ORAMA_TRY(sc->out_ids.reserve((size_t)kk * 8));
     ORAMA_TRY(sc->out_val.reserve((size_t)kk * 4));
     ORAMA_TRY(sc->out_n.reserve(4));
-    if (top_k) {
-        ORAMA_TRY(sc->sel_state.reserve(sizeof(SelectState)));
-        ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * kk));
-        SelectPlan p;
-        p.vals = qb.cand_score;
-        p.idx = qb.cand_idx;
-        p.stride = 0;
-        p.n_dev = &qb.state->list_len;
-        p.n = cand_cap;
-        p.q = 1;
-        p.k = top_k;
-        p.descending = true;
-        p.id_map = d_docs;
-        p.state = sc->sel_state.as<SelectState>();
-        p.keys = sc->sel_keys.as<unsigned long long>();
-        p.out_ids = sc->out_ids.as<uint64_t>();
-        p.out_val = sc->out_val.as<float>();
-        p.out_n = sc->out_n.as<uint32_t>();
-        ORAMA_TRY(launch_select(ctx, p, s));
-    }
+    if (top_k)
+        ORAMA_TRY(select_enqueue(ctx, sc, qb, d_docs, cand_cap, top_k, sc->out_ids.as<uint64_t>(),
+                                 sc->out_val.as<float>(), sc->out_n.as<uint32_t>()));
     ORAMA_TRY(sc->h_out.reserve((size_t)kk * 12 + 4 + sizeof(Bm25State)));
     char* h = sc->h_out.as<char>();
     if (top_k) {
@@ -205,15 +211,20 @@ struct PostQuery {
     uint64_t cand_cap = 0;
     size_t vec_stage_off = 0;  // byte offset of the stage-2 staging area inside sc->h_in (after the segments)
     uint32_t n_vec_cap = 0;
+    size_t idf_stage_off = 0;  // pinned staging / device offsets of the idf values of the staged (sharded) form
+    size_t idf_dev_off = 0;
     bool hybrid = false;
     const float* omc = nullptr;
 };
+
+int post_finalize(orama_post* p, Scratch* sc, const PostQuery& stq, const orama_bm25_params* params,
+                  const float* d_idf_vals);
 
 // Stage 1 (independent of the vector leg): descriptor upload, K3 accumulate (one launch per entry rank),
 // K3 finalise (+ min/max of the full-text scores when hybrid).  Everything is enqueued on sc->stream.
 int post_stage1(orama_post* p, Scratch* sc, const orama_term_ref* refs, uint32_t n_refs, float b,
                 const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits, bool hybrid,
-                int apply_omc, uint32_t n_vec_cap, PostQuery* st) {
+                int apply_omc, uint32_t n_vec_cap, PostQuery* st, bool finalize_now = true) {
     ORAMA_TRY(check_params(params));
     ORAMA_REQUIRE(n_refs == 0 || refs, "null refs");
     ORAMA_REQUIRE(p->n_docs > 0 || n_refs == 0, "postings store is empty (orama_post_build not called)");
@@ -236,7 +247,6 @@ int post_stage1(orama_post* p, Scratch* sc, const orama_term_ref* refs, uint32_t
     st->cand_cap = st->touched_cap + n_vec_cap;
     ORAMA_TRY(prepare_query(sc, p->n_docs ? p->n_docs : 1, params->n_tokens, st->cand_cap, (uint32_t)total_postings,
                             &st->qb));
-    ORAMA_TRY(ensure_idf_table(p, params->total_documents, s));
     const QueryBuffers& qb = st->qb;
 
     // segments, grouped by rank
@@ -276,8 +286,10 @@ int post_stage1(orama_post* p, Scratch* sc, const orama_term_ref* refs, uint32_t
     // pinned staging: [segments | stage-2 vector entries] — stage 2 must not touch bytes an in-flight copy reads
     st->vec_stage_off = (seg_bytes + 63) & ~(size_t)63;
     st->n_vec_cap = n_vec_cap;
-    ORAMA_TRY(sc->h_in.reserve(st->vec_stage_off + (size_t)n_vec_cap * 8 + 64));
-    ORAMA_TRY(sc->misc0.reserve(seg_bytes + 16));
+    st->idf_stage_off = (st->vec_stage_off + (size_t)n_vec_cap * 8 + 63) & ~(size_t)63;
+    ORAMA_TRY(sc->h_in.reserve(st->idf_stage_off + kMaxTokens * 4 + 64));
+    st->idf_dev_off = (seg_bytes + 63) & ~(size_t)63;  // idf values live behind the segments in misc0
+    ORAMA_TRY(sc->misc0.reserve(st->idf_dev_off + kMaxTokens * 4 + 16));
     if (seg_bytes) {
         memcpy(sc->h_in.p, segs.data(), seg_bytes);
         ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, sc->h_in.p, seg_bytes, hipMemcpyHostToDevice, s));
@@ -306,10 +318,24 @@ int post_stage1(orama_post* p, Scratch* sc, const orama_term_ref* refs, uint32_t
         ORAMA_TRY(launch_bm25_accumulate(p->ctx, a, s));
     }
     st->omc = (apply_omc && p->has_omc) ? p->d_omc.as<float>() : nullptr;
+    if (!finalize_now) return ORAMA_OK;
+    ORAMA_TRY(ensure_idf_table(p, params->total_documents, s));
+    return post_finalize(p, sc, *st, params, nullptr);
+}
+
+// K3 finalise (+ min/max of the full-text scores when hybrid).  d_idf_vals == nullptr: idf looked up in the
+// per-index table by the df counted on this device; otherwise idf[t] given (sharded index: global df, §8e).
+int post_finalize(orama_post* p, Scratch* sc, const PostQuery& stq, const orama_bm25_params* params,
+                  const float* d_idf_vals) {
+    const PostQuery* st = &stq;
+    const QueryBuffers& qb = st->qb;
+    const bool hybrid = st->hybrid;
+    hipStream_t s = sc->stream;
     Bm25Finalize f;
     f.n_tokens = params->n_tokens;
     f.k = params->k;
-    f.idf_table = p->d_idf.as<float>();
+    f.idf_table = d_idf_vals ? nullptr : p->d_idf.as<float>();
+    f.idf_vals = d_idf_vals;
     f.use_threshold = params->use_threshold != 0;
     f.threshold = params->threshold;
     f.track_minmax = hybrid;
@@ -327,41 +353,54 @@ int post_stage1(orama_post* p, Scratch* sc, const orama_term_ref* refs, uint32_t
     return launch_bm25_finalize(p->ctx, f, s);
 }
 
-// Stage 2: [hybrid: K5 combine with the vector map +] OMC, K4 top-k, download (synchronises sc->stream).
+// Stage 2a: [hybrid: K5 combine with the vector map +] OMC.  `skip_foreign`: vector hits whose doc is not a
+// document of this store belong to another shard of the index and are combined there (sharded form, §8e).
+int post_combine(orama_post* p, Scratch* sc, const PostQuery& st, const uint64_t* vec_doc, const float* vec_score,
+                 uint32_t n_vec, bool skip_foreign) {
+    if (!st.hybrid) return ORAMA_OK;
+    hipStream_t s = sc->stream;
+    const QueryBuffers& qb = st.qb;
+    ORAMA_REQUIRE(n_vec <= st.n_vec_cap, "hybrid: vector map larger than announced");
+    HybridCombine h;
+    vec_min_max(vec_score, n_vec, &h.vec_min, &h.vec_max);  // over the WHOLE vector map, owned here or not
+    // map the vector map to local doc indices (host, <= limit entries) and upload it
+    uint32_t* h_idx = reinterpret_cast<uint32_t*>(sc->h_in.as<char>() + st.vec_stage_off);
+    uint32_t n_own = 0;
+    for (uint32_t j = 0; j < n_vec; ++j) {
+        uint32_t local;
+        if (p->local_of(vec_doc[j], &local)) {
+            h_idx[n_own++] = local;
+        } else {
+            ORAMA_REQUIRE(skip_foreign, "hybrid: vector hit doc %llu is not a document of this index",
+                          (unsigned long long)vec_doc[j]);
+        }
+    }
+    float* h_sc = reinterpret_cast<float*>(h_idx + n_own);
+    uint32_t local;
+    for (uint32_t j = 0, o = 0; j < n_vec; ++j)
+        if (p->local_of(vec_doc[j], &local)) h_sc[o++] = vec_score[j];
+    ORAMA_TRY(sc->misc1.reserve((size_t)n_own * 8 + 16));
+    if (n_own) ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc1.p, h_idx, (size_t)n_own * 8, hipMemcpyHostToDevice, s));
+    h.vec_idx = sc->misc1.as<uint32_t>();
+    h.vec_score = reinterpret_cast<const float*>(sc->misc1.as<uint32_t>() + n_own);
+    h.n_vec = n_own;
+    h.omc_dense = st.omc;
+    h.epoch = qb.epoch;
+    h.cand_cap = (uint32_t)st.touched_cap;
+    h.state = qb.state;
+    h.cand_score = qb.cand_score;
+    h.cand_idx = qb.cand_idx;
+    h.emit = qb.emit;
+    return launch_hybrid_combine(p->ctx, h, s);
+}
+
+// Stage 2: combine, K4 top-k, download (synchronises sc->stream).
 int post_stage2(orama_post* p, Scratch* sc, const PostQuery& st, const orama_bm25_params* params,
                 const uint64_t* vec_doc, const float* vec_score, uint32_t n_vec, uint64_t* out_ids,
                 float* out_scores, uint32_t* out_n, uint64_t* out_count) {
-    hipStream_t s = sc->stream;
-    const QueryBuffers& qb = st.qb;
-    if (st.hybrid) {
-        ORAMA_REQUIRE(st.touched_cap + n_vec <= st.cand_cap, "hybrid: vector map larger than announced");
-        // map the vector map to local doc indices (host, <= limit entries) and upload it
-        ORAMA_REQUIRE(n_vec <= st.n_vec_cap, "hybrid: vector map larger than announced");
-        ORAMA_TRY(sc->misc1.reserve((size_t)n_vec * 8 + 16));
-        uint32_t* h_idx = reinterpret_cast<uint32_t*>(sc->h_in.as<char>() + st.vec_stage_off);
-        float* h_sc = reinterpret_cast<float*>(h_idx + n_vec);
-        for (uint32_t j = 0; j < n_vec; ++j) {
-            ORAMA_REQUIRE(p->local_of(vec_doc[j], &h_idx[j]),
-                          "hybrid: vector hit doc %llu is not a document of this index", (unsigned long long)vec_doc[j]);
-            h_sc[j] = vec_score[j];
-        }
-        if (n_vec) ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc1.p, h_idx, (size_t)n_vec * 8, hipMemcpyHostToDevice, s));
-        HybridCombine h;
-        vec_min_max(vec_score, n_vec, &h.vec_min, &h.vec_max);
-        h.vec_idx = sc->misc1.as<uint32_t>();
-        h.vec_score = reinterpret_cast<const float*>(sc->misc1.as<uint32_t>() + n_vec);
-        h.n_vec = n_vec;
-        h.omc_dense = st.omc;
-        h.epoch = qb.epoch;
-        h.cand_cap = (uint32_t)st.touched_cap;
-        h.state = qb.state;
-        h.cand_score = qb.cand_score;
-        h.cand_idx = qb.cand_idx;
-        h.emit = qb.emit;
-        ORAMA_TRY(launch_hybrid_combine(p->ctx, h, s));
-    }
-    return select_and_download(p->ctx, sc, qb, p->d_docs.as<uint64_t>(), (uint32_t)st.cand_cap, params->top_k, out_ids,
-                               out_scores, out_n, out_count);
+    ORAMA_TRY(post_combine(p, sc, st, vec_doc, vec_score, n_vec, false));
+    return select_and_download(p->ctx, sc, st.qb, p->d_docs.as<uint64_t>(), (uint32_t)st.cand_cap, params->top_k,
+                               out_ids, out_scores, out_n, out_count);
 }
 
 int post_search_impl(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, float b,
@@ -610,6 +649,125 @@ int orama_post_search_hybrid(orama_post* p, const orama_term_ref* refs, uint32_t
                              uint32_t* out_n, uint64_t* out_count) {
     return post_search_impl(p, refs, n_refs, b, params, allow_bitmap, bitmap_bits, vec_doc, vec_score, n_vec, true,
                             apply_omc, out_ids, out_scores, out_n, out_count);
+}
+
+// ================================================================= staged query: one index sharded over GPUs
+// SURVEY §8e.  Every stage enqueues on the caller's stream; the caller runs the collectives between them.
+struct orama_post_query {
+    orama_post* p = nullptr;
+    std::shared_lock<std::shared_mutex> lk;
+    ScratchLease lease;
+    hipStream_t own_stream = nullptr;  // the lease's stream, put back when the query ends
+    PostQuery st;
+    orama_bm25_params params{};
+    int stage = 0;  // 1 accumulated, 2 scored, 3 finished
+    explicit orama_post_query(orama_post* post) : p(post), lk(post->mu), lease(post->ctx) {}
+    ~orama_post_query() {
+        if (lease.s && own_stream) lease.s->stream = own_stream;
+    }
+};
+
+uint64_t orama_post_block_bytes(uint32_t top_k) { return packed_block_bytes(1, top_k) + 8; }
+
+int orama_post_query_begin(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, float b,
+                           const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits,
+                           int hybrid, int apply_omc, uint32_t n_vec_cap, void* hip_stream, int32_t* d_df,
+                           orama_post_query** out) {
+    ORAMA_REQUIRE(p && params && d_df && out, "null argument");
+    *out = nullptr;
+    ORAMA_REQUIRE(params->top_k >= 1, "staged query: top_k must be >= 1");
+    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    std::unique_ptr<orama_post_query> q(new (std::nothrow) orama_post_query(p));
+    if (!q) {
+        set_error("out of host memory");
+        return ORAMA_ERR_OOM;
+    }
+    ORAMA_TRY(q->lease.init());
+    Scratch* sc = q->lease.s.get();
+    q->own_stream = sc->stream;
+    sc->stream = static_cast<hipStream_t>(hip_stream);
+    q->params = *params;
+    ORAMA_TRY(post_stage1(p, sc, refs, n_refs, b, params, allow_bitmap, bitmap_bits, hybrid != 0, apply_omc, n_vec_cap,
+                          &q->st, false));
+    ORAMA_TRY(launch_df_export(q->st.qb.state, params->n_tokens, d_df, sc->stream));
+    q->stage = 1;
+    *out = q.release();
+    return ORAMA_OK;
+}
+
+int orama_post_query_score(orama_post_query* q, const uint32_t* df_global, int64_t* d_minmax) {
+    ORAMA_REQUIRE(q && df_global, "null argument");
+    ORAMA_REQUIRE(q->stage == 1, "staged query: score called out of order");
+    ORAMA_REQUIRE(!q->st.hybrid || d_minmax, "staged query: hybrid needs the min/max exchange buffer");
+    orama_post* p = q->p;
+    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    Scratch* sc = q->lease.s.get();
+    hipStream_t s = sc->stream;
+    // idf by the host libm from the GLOBAL df and N (calculate_idf, bm25.rs:78-82; df.max(1), token_score.rs:275)
+    float* h_idf = reinterpret_cast<float*>(sc->h_in.as<char>() + q->st.idf_stage_off);
+    for (uint32_t t = 0; t < q->params.n_tokens; ++t) {
+        const float d = (float)(df_global[t] < 1 ? 1u : df_global[t]);
+        h_idf[t] = log1pf((q->params.total_documents - d + 0.5f) / (d + 0.5f));
+    }
+    float* d_idf = reinterpret_cast<float*>(sc->misc0.as<char>() + q->st.idf_dev_off);
+    ORAMA_HIP_TRY(hipMemcpyAsync(d_idf, h_idf, (size_t)q->params.n_tokens * 4, hipMemcpyHostToDevice, s));
+    ORAMA_TRY(post_finalize(p, sc, q->st, &q->params, d_idf));
+    if (q->st.hybrid) ORAMA_TRY(launch_minmax_export(q->st.qb.state, reinterpret_cast<long long*>(d_minmax), s));
+    q->stage = 2;
+    return ORAMA_OK;
+}
+
+int orama_post_query_finish(orama_post_query* q, const int64_t* d_minmax_global, const uint64_t* vec_doc,
+                            const float* vec_score, uint32_t n_vec, void* d_block) {
+    ORAMA_REQUIRE(q && d_block, "null argument");
+    ORAMA_REQUIRE(q->stage == 2, "staged query: finish called out of order");
+    orama_post* p = q->p;
+    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    Scratch* sc = q->lease.s.get();
+    hipStream_t s = sc->stream;
+    if (q->st.hybrid) {
+        ORAMA_REQUIRE(d_minmax_global, "staged query: hybrid needs the reduced min/max");
+        ORAMA_REQUIRE(n_vec == 0 || (vec_doc && vec_score), "null vector map");
+        ORAMA_TRY(launch_minmax_import(q->st.qb.state, reinterpret_cast<const long long*>(d_minmax_global), s));
+        ORAMA_TRY(post_combine(p, sc, q->st, vec_doc, vec_score, n_vec, true));
+    }
+    const uint32_t k = q->params.top_k;
+    char* blk = static_cast<char*>(d_block);
+    ORAMA_TRY(sc->out_n.reserve(4));
+    ORAMA_TRY(select_enqueue(p->ctx, sc, q->st.qb, p->d_docs.as<uint64_t>(), (uint32_t)q->st.cand_cap, k,
+                             reinterpret_cast<uint64_t*>(blk), reinterpret_cast<float*>(blk + (size_t)k * 8),
+                             sc->out_n.as<uint32_t>()));
+    ORAMA_TRY(launch_count_export(q->st.qb.state, reinterpret_cast<unsigned long long*>(blk + packed_block_bytes(1, k)),
+                                  s));
+    q->stage = 3;
+    return ORAMA_OK;
+}
+
+void orama_post_query_end(orama_post_query* q) {
+    if (!q) return;
+    // the scratch set goes back to the pool: everything enqueued on the caller's stream must have drained
+    if (q->lease.s) (void)hipStreamSynchronize(q->lease.s->stream);
+    delete q;
+}
+
+int orama_post_merge_blocks_device(orama_ctx* ctx, const void* d_blocks, uint32_t lists, uint32_t top_k,
+                                   uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_n,
+                                   uint64_t* d_out_count, void* hip_stream) {
+    ORAMA_REQUIRE(ctx && d_blocks && d_out_ids && d_out_scores && d_out_n && d_out_count, "null argument");
+    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const uint64_t stride = orama_post_block_bytes(top_k);
+    ORAMA_TRY(launch_merge_blocks(ctx, d_blocks, stride, lists, 1, top_k, true, d_out_ids, d_out_scores, d_out_n, s));
+    return launch_count_sum(d_blocks, stride, packed_block_bytes(1, top_k), lists,
+                            reinterpret_cast<unsigned long long*>(d_out_count), s);
+}
+
+int orama_post_set_avg_len(orama_post* p, const float* avg_field_len, uint32_t n_fields) {
+    ORAMA_REQUIRE(p && avg_field_len, "null argument");
+    std::unique_lock<std::shared_mutex> lk(p->mu);
+    ORAMA_REQUIRE(n_fields == p->n_fields, "expected %u field averages, got %u", p->n_fields, n_fields);
+    p->avg_len.assign(avg_field_len, avg_field_len + n_fields);
+    return ORAMA_OK;
 }
 
 // search_hybrid (token_score.rs:357-387) as ONE call: the vector leg (K1/K2 + K4 on its own HIP stream) and

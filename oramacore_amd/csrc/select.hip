@@ -325,8 +325,8 @@ __global__ __launch_bounds__(kSortThreads) void select_small_kernel(
 // (separate arrays: stride = q*k elements; packed all-gather blocks: stride = block size).
 __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(
     const char* __restrict__ ids, uint64_t ids_stride, const char* __restrict__ dist,
-    uint64_t dist_stride, uint32_t lists, uint32_t q, uint32_t k, uint64_t* out_ids, float* out_dist,
-    uint32_t* out_n) {
+    uint64_t dist_stride, uint32_t lists, uint32_t q, uint32_t k, bool descending, uint64_t* out_ids,
+    float* out_dist, uint32_t* out_n) {
     __shared__ SortLds s;
     __shared__ uint32_t valid_s;
     const uint32_t qi = blockIdx.x;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(
             const uint64_t id = reinterpret_cast<const uint64_t*>(ids + (uint64_t)l * ids_stride)[src];
             const float x = reinterpret_cast<const float*>(dist + (uint64_t)l * dist_stride)[src];
             if (id != ~0ull && x == x) {
-                s.hi[i] = ~f32_to_ordered(x);
+                s.hi[i] = descending ? f32_to_ordered(x) : ~f32_to_ordered(x);
                 s.idx[i] = i;
                 s.id[i] = id;
                 ok = true;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(
     __syncthreads();
     lds_bitonic_sort(s, p2);
     const uint32_t count = min(valid_s, k);
-    write_sorted(s, count, k, false, nullptr, out_ids + (uint64_t)qi * k, out_dist + (uint64_t)qi * k,
+    write_sorted(s, count, k, descending, nullptr, out_ids + (uint64_t)qi * k, out_dist + (uint64_t)qi * k,
                  out_n ? out_n + qi : nullptr);
 }
 
@@ -507,7 +507,7 @@ int launch_merge_candidates(orama_ctx* ctx, const uint64_t* d_ids, const float* 
                   (unsigned long long)lists * k, kSelectMaxK);
     hipLaunchKernelGGL(merge_candidates_kernel, dim3(q), dim3(kSortThreads), 0, stream,
                        reinterpret_cast<const char*>(d_ids), (uint64_t)q * k * 8,
-                       reinterpret_cast<const char*>(d_dist), (uint64_t)q * k * 4, lists, q, k, d_out_ids,
+                       reinterpret_cast<const char*>(d_dist), (uint64_t)q * k * 4, lists, q, k, false, d_out_ids,
                        d_out_dist, d_out_n);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
@@ -520,14 +520,22 @@ uint64_t packed_block_bytes(uint32_t q, uint32_t k) {
 int launch_merge_packed(orama_ctx* ctx, const void* d_packed, uint32_t lists, uint32_t q, uint32_t k,
                         uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n,
                         hipStream_t stream) {
+    return launch_merge_blocks(ctx, d_packed, packed_block_bytes(q, k), lists, q, k, false, d_out_ids, d_out_dist,
+                               d_out_n, stream);
+}
+
+int launch_merge_blocks(orama_ctx* ctx, const void* d_blocks, uint64_t block_stride, uint32_t lists, uint32_t q,
+                        uint32_t k, bool descending, uint64_t* d_out_ids, float* d_out_val, uint32_t* d_out_n,
+                        hipStream_t stream) {
     (void)ctx;
     ORAMA_REQUIRE(lists >= 1 && q >= 1 && k >= 1, "merge: empty shape");
     ORAMA_REQUIRE((uint64_t)lists * k <= kSelectMaxK, "merge: lists*k=%llu exceeds %u",
                   (unsigned long long)lists * k, kSelectMaxK);
-    const uint64_t block = packed_block_bytes(q, k);
-    const char* base = reinterpret_cast<const char*>(d_packed);
-    hipLaunchKernelGGL(merge_candidates_kernel, dim3(q), dim3(kSortThreads), 0, stream, base, block,
-                       base + (uint64_t)q * k * 8, block, lists, q, k, d_out_ids, d_out_dist, d_out_n);
+    ORAMA_REQUIRE(block_stride >= packed_block_bytes(q, k) && block_stride % 8 == 0, "merge: bad block stride");
+    const char* base = reinterpret_cast<const char*>(d_blocks);
+    hipLaunchKernelGGL(merge_candidates_kernel, dim3(q), dim3(kSortThreads), 0, stream, base, block_stride,
+                       base + (uint64_t)q * k * 8, block_stride, lists, q, k, descending, d_out_ids, d_out_val,
+                       d_out_n);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -69,5 +69,10 @@ uint64_t packed_block_bytes(uint32_t q, uint32_t k);
 // K6 over `lists` consecutive packed blocks (the output of one all-gather).
 int launch_merge_packed(orama_ctx* ctx, const void* d_packed, uint32_t lists, uint32_t q, uint32_t k,
                         uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n, hipStream_t stream);
+// Same merge over blocks `block_stride` bytes apart (each starts with [q*k u64 ids][q*k f32 values]; trailing
+// bytes are the caller's), values ascending (distances) or descending (scores).
+int launch_merge_blocks(orama_ctx* ctx, const void* d_blocks, uint64_t block_stride, uint32_t lists, uint32_t q,
+                        uint32_t k, bool descending, uint64_t* d_out_ids, float* d_out_val, uint32_t* d_out_n,
+                        hipStream_t stream);
 
 }  // namespace orama

@@ -315,3 +315,64 @@ class PostingsStore:
                                                        1 if apply_omc else 0, out_ids.ctypes.data,
                                                        out_sc.ctypes.data, C.byref(out_n), C.byref(out_count)))
         return out_ids[: out_n.value], out_sc[: out_n.value], out_count.value
+
+    def set_avg_len(self, avg_field_len) -> None:
+        """Index-wide per-field average lengths for the shards of one index."""
+        avg = _f32(avg_field_len)
+        N.check(self._lib.orama_post_set_avg_len(self._h, avg.ctypes.data, avg.shape[0]))
+
+    def staged_query(self, refs, n_tokens: int, total_documents: float, top_k: int, d_df_ptr: int, stream: int,
+                     threshold=None, allow: AllowBitmap | None = None, apply_omc: bool = True, hybrid: bool = False,
+                     n_vec_cap: int = 0, b: float = B_DEFAULT, k: float = K1_DEFAULT) -> "StagedQuery":
+        """Stage 1 of the sharded form (orama_post_query_begin): K3 accumulate on this shard, local df per token
+        written to the device buffer at `d_df_ptr` (int32[n_tokens]) on HIP stream `stream`."""
+        arr = self._refs(refs)
+        params = _params(total_documents, n_tokens, threshold, top_k, k)
+        bm_ptr, bm_bits = (allow.words.ctypes.data, allow.n_bits) if allow is not None else (None, 0)
+        h = C.c_void_p()
+        N.check(self._lib.orama_post_query_begin(self._h, arr, len(refs), b, C.byref(params), bm_ptr, bm_bits,
+                                                 1 if hybrid else 0, 1 if apply_omc else 0, int(n_vec_cap),
+                                                 C.c_void_p(stream), C.c_void_p(d_df_ptr), C.byref(h)))
+        return StagedQuery(self._lib, h, top_k)
+
+
+def post_block_bytes(top_k: int) -> int:
+    """Mirror of orama_post_block_bytes: [k u64 ids][k f32 scores][pad to 8][u64 count]."""
+    return ((top_k * 12 + 7) & ~7) + 8
+
+
+class StagedQuery:
+    """One query of a sharded index between its stages (include/orama_hip.h, "one index sharded over several
+    GPUs").  All calls must come from the thread that created it; `end()` waits for the stream."""
+
+    def __init__(self, lib, handle, top_k: int):
+        self._lib = lib
+        self._h = handle
+        self.top_k = top_k
+
+    def score(self, df_global, d_minmax_ptr: int | None) -> None:
+        df = np.ascontiguousarray(df_global, dtype=np.uint32)
+        N.check(self._lib.orama_post_query_score(self._h, df.ctypes.data,
+                                                 C.c_void_p(d_minmax_ptr) if d_minmax_ptr else None))
+
+    def finish(self, d_minmax_ptr: int | None, vector, d_block_ptr: int) -> None:
+        if vector is None:
+            v_doc, v_sc = _u64([]), _f32([])
+        elif isinstance(vector, dict):
+            v_doc, v_sc = _u64(list(vector.keys())), _f32(list(vector.values()))
+        else:
+            v_doc, v_sc = _u64(vector[0]), _f32(vector[1])
+        N.check(self._lib.orama_post_query_finish(self._h, C.c_void_p(d_minmax_ptr) if d_minmax_ptr else None,
+                                                  v_doc.ctypes.data, v_sc.ctypes.data, v_doc.shape[0],
+                                                  C.c_void_p(d_block_ptr)))
+
+    def end(self) -> None:
+        if self._h:
+            self._lib.orama_post_query_end(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.end()
+        except Exception:  # noqa: BLE001
+            pass

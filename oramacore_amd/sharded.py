@@ -120,3 +120,98 @@ class ShardedSearcher:
         dist.all_gather_into_tensor(self.blocks, self.block, group=self.group)
         self.ops.merge(self.blocks, self.world, q, k, self.out_ids, self.out_dist, self.out_n)
         return self.out_ids, self.out_dist, self.out_n
+
+
+# ===================================================================== full-text / hybrid over a sharded index
+def post_block_bytes(k: int) -> int:
+    """Mirror of orama_post_block_bytes: [k u64 ids][k f32 scores][pad to 8][u64 count]."""
+    return ((k * 12 + 7) & ~7) + 8
+
+
+class HipPostOps:
+    """The product's compute steps for one shard of a full-text index — K3/K5/K4 through the staged C ABI
+    (orama_post_query_*), K6 + count sum through orama_post_merge_blocks_device."""
+
+    def __init__(self, ctx, store):
+        self.lib = N.load()
+        self.ctx = ctx
+        self.store = store
+
+    def begin(self, query: dict, d_df: torch.Tensor):
+        stream = torch.cuda.current_stream().cuda_stream
+        return self.store.staged_query(d_df_ptr=d_df.data_ptr(), stream=stream, **query)
+
+    def score(self, q, df_global, d_minmax) -> None:
+        q.score(df_global, d_minmax.data_ptr() if d_minmax is not None else None)
+
+    def finish(self, q, d_minmax, vector, d_block: torch.Tensor) -> None:
+        q.finish(d_minmax.data_ptr() if d_minmax is not None else None, vector, d_block.data_ptr())
+
+    def end(self, q) -> None:
+        q.end()
+
+    def merge(self, blocks: torch.Tensor, lists: int, k: int, out_ids, out_scores, out_n, out_count) -> None:
+        stream = torch.cuda.current_stream().cuda_stream
+        N.check(self.lib.orama_post_merge_blocks_device(self.ctx.handle, blocks.data_ptr(), lists, k,
+                                                        out_ids.data_ptr(), out_scores.data_ptr(), out_n.data_ptr(),
+                                                        out_count.data_ptr(), stream))
+
+
+class ShardedFulltextSearcher:
+    """search_full_text / search_hybrid (token_score.rs:186-387) over ONE index whose documents are split into
+    contiguous doc-id ranges, one per rank.  The reference reads three index-wide quantities; each
+    becomes one small collective between the stages of the local query:
+
+        df per token (token_score.rs:262-275)            all-reduce SUM   int32[n_tokens]
+        min/max of the score maps (token_score.rs:398-401) all-reduce MAX   int64[2]        (hybrid only)
+        top-k + match count (sort.rs:260-279, search.rs:482) all-gather      [k ids][k scores][count] per rank
+
+    N (`total_documents`) and the per-field average lengths are index-wide constants given at build time.  The
+    vector map of a hybrid query is the GLOBAL map (ShardedSearcher + a2 epilogue), identical on every rank; each
+    rank adds the entries whose document it owns."""
+
+    def __init__(self, ops, rank: int, world: int, device: torch.device, group=None):
+        self.ops = ops
+        self.rank = rank
+        self.world = world
+        self.device = device
+        self.group = group
+
+    def search(self, refs, n_tokens: int, total_documents: float, top_k: int, threshold=None, allow=None,
+               apply_omc: bool = True, vector=None, **kw):
+        """Returns (ids u64[n], scores f32[n], count) — identical on every rank."""
+        dev = self.device
+        hybrid = vector is not None
+        n_vec = 0 if vector is None else (len(vector) if isinstance(vector, dict) else len(vector[0]))
+        d_df = torch.zeros((n_tokens,), dtype=torch.int32, device=dev)
+        d_minmax = torch.zeros((2,), dtype=torch.int64, device=dev) if hybrid else None
+        nb = post_block_bytes(top_k)
+        block = torch.zeros((nb,), dtype=torch.uint8, device=dev)
+        blocks = torch.zeros((self.world * nb,), dtype=torch.uint8, device=dev)
+        out_ids = torch.zeros((top_k,), dtype=torch.int64, device=dev)
+        out_sc = torch.zeros((top_k,), dtype=torch.float32, device=dev)
+        out_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+        out_count = torch.zeros((1,), dtype=torch.int64, device=dev)
+        query = dict(refs=refs, n_tokens=n_tokens, total_documents=total_documents, top_k=top_k,
+                     threshold=threshold, allow=allow, apply_omc=apply_omc, hybrid=hybrid, n_vec_cap=n_vec, **kw)
+        q = self.ops.begin(query, d_df)
+        try:
+            if self.world > 1:
+                dist.all_reduce(d_df, op=dist.ReduceOp.SUM, group=self.group)
+            df_global = d_df.cpu().numpy().astype("uint32")
+            self.ops.score(q, df_global, d_minmax)
+            if hybrid and self.world > 1:
+                dist.all_reduce(d_minmax, op=dist.ReduceOp.MAX, group=self.group)
+            self.ops.finish(q, d_minmax, vector, block)
+            if self.world > 1:
+                dist.all_gather_into_tensor(blocks, block, group=self.group)
+            else:
+                blocks.copy_(block)
+            self.ops.merge(blocks, self.world, top_k, out_ids, out_sc, out_n, out_count)
+            n = int(out_n.cpu()[0])
+            ids = out_ids.cpu().numpy().view("uint64")[:n].copy()
+            sc = out_sc.cpu().numpy()[:n].copy()
+            count = int(out_count.cpu()[0])
+        finally:
+            self.ops.end(q)
+        return ids, sc, count

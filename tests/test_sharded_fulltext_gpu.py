@@ -1,0 +1,186 @@
+"""One index sharded over G doc-id ranges, full-text and hybrid, through the staged C ABI.
+
+The G shard stores live on the one GPU of the test box and are driven in lockstep; the three collectives of
+ShardedFulltextSearcher (df all-reduce SUM, min/max all-reduce MAX, block all-gather) are emulated with torch ops
+on the same device buffers the real RCCL calls would use.  Bar: bit-identical to the oracle over the union (and
+therefore to the single-store search): ids, scores and match count.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oramacore_amd as oa
+import util
+from oracle import oracle as orc
+from oramacore_amd import fulltext as ft
+from oramacore_amd import sharded
+from test_fulltext_gpu import bits, oracle_topk
+from test_oracle_golden import bm25_synth_entries
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def synth():
+    meta = util.load_json("bm25_synth.json")
+    fields = util.mg.zipf_corpus(meta["n_docs"], meta["vocab"], meta["n_fields"], seed=meta["seed"])
+    doc_ids = np.arange(meta["n_docs"], dtype=np.uint64) * np.uint64(meta["doc_id_mul"]) + np.uint64(meta["doc_id_add"])
+    allow = (util.hash_u64(doc_ids + np.uint64(5)) % np.uint64(3)) != 0
+    return meta, fields, doc_ids, allow
+
+
+def build_shards(ctx, meta, fields, doc_ids, cuts):
+    """Shard g holds documents [cuts[g], cuts[g+1]) (positions in doc_ids); every shard has every list id."""
+    keys = [(f, term) for f in range(meta["n_fields"]) for term in sorted(fields[f]["postings"])]
+    list_id = {key: i for i, key in enumerate(keys)}
+    avg = [fields[f]["avg"] for f in range(meta["n_fields"])]  # index-wide averages
+    stores = []
+    for g in range(len(cuts) - 1):
+        lo, hi = cuts[g], cuts[g + 1]
+        lists = []
+        for f, term in keys:
+            pl = [p for p in fields[f]["postings"][term] if lo <= p[0] < hi]
+            dix = np.array([p[0] for p in pl], dtype=np.int64)
+            lists.append(ft.PostingList(field=f, docs=doc_ids[dix], tf=np.array([p[1] for p in pl], dtype=np.uint32),
+                                        field_len=fields[f]["lens"][dix] if len(dix) else np.zeros(0, np.uint32)))
+        st = ft.PostingsStore(ctx)
+        st.build(doc_ids[lo:hi], avg, lists)
+        stores.append(st)
+    return stores, list_id
+
+
+def run_lockstep(ctx, stores, refs, n_tok, total_docs, top_k, threshold=None, allow=None, vector=None,
+                 apply_omc=True):
+    """ShardedFulltextSearcher.search with the collectives replaced by in-process reductions."""
+    dev = torch.device("cuda:0")
+    G = len(stores)
+    ops = [sharded.HipPostOps(ctx, s) for s in stores]
+    hybrid = vector is not None
+    n_vec = len(vector) if vector else 0
+    nb = sharded.post_block_bytes(top_k)
+    assert nb == ops[0].lib.orama_post_block_bytes(top_k)
+    d_df = [torch.zeros((n_tok,), dtype=torch.int32, device=dev) for _ in range(G)]
+    d_mm = [torch.zeros((2,), dtype=torch.int64, device=dev) for _ in range(G)]
+    blocks = torch.zeros((G * nb,), dtype=torch.uint8, device=dev)
+    query = dict(refs=refs, n_tokens=n_tok, total_documents=total_docs, top_k=top_k, threshold=threshold,
+                 allow=allow, apply_omc=apply_omc, hybrid=hybrid, n_vec_cap=n_vec)
+    qs = [ops[g].begin(query, d_df[g]) for g in range(G)]
+    try:
+        df = torch.stack(d_df).sum(dim=0).cpu().numpy().astype(np.uint32)            # all-reduce SUM
+        for g in range(G):
+            ops[g].score(qs[g], df, d_mm[g] if hybrid else None)
+        mm = torch.stack(d_mm).max(dim=0).values.contiguous() if hybrid else None   # all-reduce MAX
+        for g in range(G):
+            ops[g].finish(qs[g], mm, vector, blocks[g * nb:(g + 1) * nb])            # all-gather
+        out_ids = torch.zeros((top_k,), dtype=torch.int64, device=dev)
+        out_sc = torch.zeros((top_k,), dtype=torch.float32, device=dev)
+        out_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+        out_count = torch.zeros((1,), dtype=torch.int64, device=dev)
+        ops[0].merge(blocks, G, top_k, out_ids, out_sc, out_n, out_count)
+        n = int(out_n.cpu()[0])
+        return (out_ids.cpu().numpy().view(np.uint64)[:n].copy(), out_sc.cpu().numpy()[:n].copy(),
+                int(out_count.cpu()[0]), df)
+    finally:
+        for q in qs:
+            q.end()
+
+
+def refs_of(meta, list_id, case):
+    return [(ti, list_id[(f, t)], meta["boosts"][f]) for ti, t in enumerate(case["terms"])
+            for f in range(meta["n_fields"]) if (f, t) in list_id]
+
+
+@pytest.mark.parametrize("cuts_frac", [(0.0, 0.5, 1.0), (0.0, 0.13, 0.5, 0.51, 1.0)], ids=["2shards", "4ragged"])
+def test_sharded_bm25_bit_exact(ctx, synth, cuts_frac):
+    meta, fields, doc_ids, allow = synth
+    cuts = [int(round(f * meta["n_docs"])) for f in cuts_frac]
+    stores, list_id = build_shards(ctx, meta, fields, doc_ids, cuts)
+    bm = oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[allow])
+    for case in meta["cases"][::3]:
+        refs = refs_of(meta, list_id, case)
+        entries = bm25_synth_entries(meta, fields, case, doc_ids, allow)
+        n_tok = len(case["terms"])
+        ids, sc, count, df = run_lockstep(ctx, stores, refs, n_tok, float(meta["n_docs"]), 50, case["threshold"],
+                                          allow=bm if case["filter"] else None)
+        od, os_, ocount = oracle_topk(entries, n_tok, meta["n_docs"], 50, case["threshold"])
+        assert count == ocount, (case["query"], case["threshold"], case["filter"])
+        assert ids.tolist() == od.tolist(), (case["query"], case["threshold"], case["filter"])
+        assert np.array_equal(bits(sc), bits(os_))
+    for s in stores:
+        s.close()
+
+
+def test_sharded_hybrid_and_omc_bit_exact(ctx, synth):
+    meta, fields, doc_ids, allow = synth
+    cuts = [0, meta["n_docs"] // 3, meta["n_docs"] // 3 + 7, meta["n_docs"]]
+    stores, list_id = build_shards(ctx, meta, fields, doc_ids, cuts)
+    rng = np.random.default_rng(11)
+    for ci in (0, 12, 24, 30):
+        case = {**meta["cases"][ci], "filter": False}
+        refs = refs_of(meta, list_id, case)
+        entries = bm25_synth_entries(meta, fields, case, doc_ids, allow)
+        n_tok = len(case["terms"])
+        fd, fs = orc.search_full_text(entries, n_tok, float(meta["n_docs"]), 1.2, case["threshold"])
+        inside = rng.choice(fd, size=min(6, len(fd)), replace=False) if len(fd) else np.array([], dtype=np.uint64)
+        outside = np.setdiff1d(doc_ids[::97], fd)[:6]  # vector-only docs spread over all shards
+        vec = {int(d): float(s) for d, s in zip(np.concatenate([inside, outside]),
+                                                 rng.uniform(-0.2, 1.0, size=len(inside) + len(outside)))}
+        for omc in (None, {int(doc_ids[3]): 2.0, int(doc_ids[-2]): 4.0, int(fd[0]) if len(fd) else 1: 0.5}):
+            od, os_ = orc.normalize_and_combine(list(vec), list(vec.values()), fd, fs)
+            if omc:
+                os_ = orc.apply_omc(od, os_, list(omc), list(omc.values()))
+                for s in stores:
+                    s.set_omc(omc)
+            td, ts = orc.top_n(od, os_, 30)
+            ids, sc, count, _ = run_lockstep(ctx, stores, refs, n_tok, float(meta["n_docs"]), 30, case["threshold"],
+                                             vector=vec, apply_omc=omc is not None)
+            assert count == len(od), (ci, omc)
+            assert ids.tolist() == td.tolist(), (ci, omc)
+            assert np.array_equal(bits(sc), bits(ts))
+    # OMC without hybrid
+    case = meta["cases"][12]
+    refs = refs_of(meta, list_id, case)
+    entries = bm25_synth_entries(meta, fields, {**case, "filter": False}, doc_ids, allow)
+    omc = {int(doc_ids[5]): 10.0, int(doc_ids[1500]): 0.25}
+    for s in stores:
+        s.set_omc(omc)
+    ids, sc, count, _ = run_lockstep(ctx, stores, refs, len(case["terms"]), float(meta["n_docs"]), 100)
+    od, os_, ocount = oracle_topk(entries, len(case["terms"]), meta["n_docs"], 100, omc=omc)
+    assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
+    for s in stores:
+        s.close()
+
+
+def test_searcher_class_single_rank(ctx, synth):
+    """ShardedFulltextSearcher at world == 1 (no process group): same stages, equals PostingsStore.search."""
+    meta, fields, doc_ids, allow = synth
+    stores, list_id = build_shards(ctx, meta, fields, doc_ids, [0, meta["n_docs"]])
+    srch = sharded.ShardedFulltextSearcher(sharded.HipPostOps(ctx, stores[0]), 0, 1, torch.device("cuda:0"))
+    case = meta["cases"][12]
+    refs = refs_of(meta, list_id, case)
+    n_tok = len(case["terms"])
+    ids, sc, count = srch.search(refs, n_tok, float(meta["n_docs"]), 40)
+    ids1, sc1, count1 = stores[0].search(refs, n_tok, float(meta["n_docs"]), 40)
+    assert count == count1 and ids.tolist() == ids1.tolist() and np.array_equal(bits(sc), bits(sc1))
+    vec = {int(doc_ids[1]): 0.9, int(ids1[0]): 0.4}
+    ids, sc, count = srch.search(refs, n_tok, float(meta["n_docs"]), 40, vector=vec)
+    ids1, sc1, count1 = stores[0].search(refs, n_tok, float(meta["n_docs"]), 40, vector=vec)
+    assert count == count1 and ids.tolist() == ids1.tolist() and np.array_equal(bits(sc), bits(sc1))
+    stores[0].close()
+
+
+def test_staged_query_order_is_enforced(ctx, synth):
+    meta, fields, doc_ids, allow = synth
+    stores, list_id = build_shards(ctx, meta, fields, doc_ids, [0, meta["n_docs"]])
+    dev = torch.device("cuda:0")
+    d_df = torch.zeros((1,), dtype=torch.int32, device=dev)
+    block = torch.zeros((sharded.post_block_bytes(5),), dtype=torch.uint8, device=dev)
+    q = stores[0].staged_query([(0, 0, 1.0)], 1, 100.0, 5, d_df.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(oa.OramaError):
+        q.finish(None, None, block.data_ptr())  # score not called yet
+    q.score(np.array([3], dtype=np.uint32), None)
+    with pytest.raises(oa.OramaError):
+        q.score(np.array([3], dtype=np.uint32), None)
+    q.finish(None, None, block.data_ptr())
+    q.end()
+    stores[0].close()
