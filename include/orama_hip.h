@@ -164,6 +164,20 @@ int orama_vec_fill_synthetic(orama_vec* v, uint64_t n_rows, uint64_t seed, uint6
 int orama_vec_get_rows(orama_vec* v, const uint64_t* row_idx, uint64_t n, float* out_rows,
                        uint64_t* out_doc_ids);
 
+/* ------------------------------------------------------------------ request micro-batcher
+ * The reference API has no batch entry (EmbeddingFieldStorage::search takes ONE target,
+ * embedding_field.rs:250-254); concurrent single-query callers are coalesced here so that one corpus pass serves
+ * up to max_batch requests (K2's MFMA path at Q <= 64 per pass).  orama_batcher_search blocks the calling thread
+ * until its answer is ready and has the semantics of orama_vec_search(q = 1, no filter); max_wait_us = 0 means
+ * "never delay": a batch is whatever arrived while the previous pass was running.  Extension — no reference
+ * counterpart; the Rust shim would call it from spawn_blocking. */
+typedef struct orama_batcher orama_batcher;
+int orama_batcher_create(orama_vec* v, uint32_t max_batch, uint32_t max_wait_us, orama_batcher** out);
+void orama_batcher_destroy(orama_batcher* b);
+int orama_batcher_search(orama_batcher* b, const float* query, uint32_t k, uint64_t* out_ids, float* out_dist,
+                         uint32_t* out_n);
+int orama_batcher_stats(orama_batcher* b, uint64_t* requests, uint64_t* batches, uint32_t* largest_batch);
+
 /* ------------------------------------------------------------------ BM25F full-text scoring
  * Replaces the in-tree hot loop search_full_text + BM25Scorer + top_n:
  *   src/collection_manager/sides/read/index/token_score.rs:257-302,

@@ -1,0 +1,172 @@
+// batcher.hip — request micro-batcher in front of orama_vec_search.
+//
+// The reference has no batch entry: every HTTP request reaches EmbeddingFieldStorage::search
+// (embedding_field.rs:250-278) alone, on its own tokio worker.  One corpus pass costs the same HBM traffic for 1
+// query as for 64 (K2 is bandwidth-bound), so concurrent single-query callers are coalesced here: callers block in
+// orama_batcher_search, one dispatcher thread turns whatever is pending into ONE orama_vec_search(q = batch).
+// No artificial delay by default — batches form naturally while the previous pass occupies the GPU; max_wait_us > 0
+// additionally holds an under-full batch open for that long after its first request.
+//
+// Per-request k: the batch runs with the largest k; the total order (distance asc, doc asc, row asc) makes every
+// smaller-k answer a prefix of it.  Filtered searches do not go through the batcher (filters differ per request).
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <string>
+#include <thread>
+
+#include "common.hpp"
+#include "select.hpp"
+#include "vec_internal.hpp"
+
+using namespace orama;
+
+namespace {
+struct Request {
+    const float* query = nullptr;
+    uint32_t k = 0;
+    uint64_t* out_ids = nullptr;
+    float* out_dist = nullptr;
+    uint32_t* out_n = nullptr;
+    int status = ORAMA_OK;
+    std::string error;
+    bool done = false;
+};
+}  // namespace
+
+struct orama_batcher {
+    orama_vec* v = nullptr;
+    uint32_t dim = 0;
+    uint32_t max_batch = 64;
+    uint32_t max_wait_us = 0;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<Request*> pending;
+    bool stop = false;
+    uint64_t n_requests = 0, n_batches = 0;
+    uint32_t largest = 0;
+    std::thread worker;
+
+    void run() {
+        std::vector<Request*> batch;
+        std::vector<float> queries;
+        std::vector<uint64_t> ids;
+        std::vector<float> dist;
+        std::vector<uint32_t> cnt;
+        for (;;) {
+            batch.clear();
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !pending.empty(); });
+                if (pending.empty() && stop) return;
+                if (max_wait_us && pending.size() < max_batch) {
+                    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_wait_us);
+                    cv_work.wait_until(lk, deadline, [&] { return stop || pending.size() >= max_batch; });
+                }
+                while (!pending.empty() && batch.size() < max_batch) {
+                    batch.push_back(pending.front());
+                    pending.pop_front();
+                }
+                n_requests += batch.size();
+                n_batches += 1;
+                largest = std::max<uint32_t>(largest, (uint32_t)batch.size());
+            }
+            const uint32_t q = (uint32_t)batch.size();
+            uint32_t kmax = 0;
+            for (Request* r : batch) kmax = std::max(kmax, r->k);
+            queries.resize((size_t)q * dim);
+            for (uint32_t i = 0; i < q; ++i) memcpy(&queries[(size_t)i * dim], batch[i]->query, (size_t)dim * 4);
+            ids.assign((size_t)q * std::max(kmax, 1u), 0);
+            dist.assign((size_t)q * std::max(kmax, 1u), 0.f);
+            cnt.assign(q, 0);
+            int st = ORAMA_OK;
+            std::string err;
+            if (kmax > 0) {
+                st = orama_vec_search(v, queries.data(), q, kmax, nullptr, 0, ids.data(), dist.data(), cnt.data());
+                if (st != ORAMA_OK) err = orama_last_error();  // this thread's error slot
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                for (uint32_t i = 0; i < q; ++i) {
+                    Request* r = batch[i];
+                    r->status = st;
+                    r->error = err;
+                    if (st == ORAMA_OK) {
+                        const uint32_t n = std::min(cnt[i], r->k);
+                        memcpy(r->out_ids, &ids[(size_t)i * kmax], (size_t)n * 8);
+                        memcpy(r->out_dist, &dist[(size_t)i * kmax], (size_t)n * 4);
+                        *r->out_n = n;
+                    }
+                    r->done = true;
+                }
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+
+extern "C" {
+
+int orama_batcher_create(orama_vec* v, uint32_t max_batch, uint32_t max_wait_us, orama_batcher** out) {
+    ORAMA_REQUIRE(v && out, "null argument");
+    *out = nullptr;
+    ORAMA_REQUIRE(max_batch >= 1 && max_batch <= 1024, "max_batch %u outside [1, 1024]", max_batch);
+    orama_batcher* b = new (std::nothrow) orama_batcher();
+    if (!b) {
+        set_error("out of host memory");
+        return ORAMA_ERR_OOM;
+    }
+    b->v = v;
+    b->dim = vec_dim(v);
+    b->max_batch = max_batch;
+    b->max_wait_us = max_wait_us;
+    b->worker = std::thread([b] { b->run(); });
+    *out = b;
+    return ORAMA_OK;
+}
+
+void orama_batcher_destroy(orama_batcher* b) {
+    if (!b) return;
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        b->stop = true;  // pending requests are still served before the dispatcher leaves
+    }
+    b->cv_work.notify_all();
+    if (b->worker.joinable()) b->worker.join();
+    delete b;
+}
+
+int orama_batcher_search(orama_batcher* b, const float* query, uint32_t k, uint64_t* out_ids, float* out_dist,
+                         uint32_t* out_n) {
+    ORAMA_REQUIRE(b && query && out_n, "null argument");
+    *out_n = 0;
+    if (k == 0) return ORAMA_OK;
+    ORAMA_REQUIRE(out_ids && out_dist, "null output");
+    ORAMA_REQUIRE(k <= kSelectMaxK, "limit %u exceeds the supported maximum %u", k, kSelectMaxK);
+    Request r;
+    r.query = query;
+    r.k = k;
+    r.out_ids = out_ids;
+    r.out_dist = out_dist;
+    r.out_n = out_n;
+    {
+        std::unique_lock<std::mutex> lk(b->mu);
+        ORAMA_REQUIRE(!b->stop, "batcher is shutting down");
+        b->pending.push_back(&r);
+        b->cv_work.notify_one();
+        b->cv_done.wait(lk, [&] { return r.done; });
+    }
+    if (r.status != ORAMA_OK) set_error("%s", r.error.c_str());
+    return r.status;
+}
+
+int orama_batcher_stats(orama_batcher* b, uint64_t* requests, uint64_t* batches, uint32_t* largest_batch) {
+    ORAMA_REQUIRE(b, "null handle");
+    std::lock_guard<std::mutex> lk(b->mu);
+    if (requests) *requests = b->n_requests;
+    if (batches) *batches = b->n_batches;
+    if (largest_batch) *largest_batch = b->largest;
+    return ORAMA_OK;
+}
+
+}  // extern "C"

@@ -209,3 +209,43 @@ class EmbeddingFieldStorage:
     @property
     def handle(self):
         return self._h
+
+
+class SearchBatcher:
+    """Micro-batcher in front of one EmbeddingFieldStorage (orama_batcher_*): concurrent
+    single-query callers (threads) share corpus passes.  `search` blocks like storage_search(q=1, no filter)."""
+
+    def __init__(self, storage: EmbeddingFieldStorage, max_batch: int = 64, max_wait_us: int = 0):
+        self._lib = N.load()
+        self.storage = storage
+        h = C.c_void_p()
+        N.check(self._lib.orama_batcher_create(storage.handle, int(max_batch), int(max_wait_us), C.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.orama_batcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def search(self, target, limit: int):
+        """Row-level k-NN of ONE target: (doc_ids [n], distances [n])."""
+        t = np.ascontiguousarray(np.asarray(target, dtype=np.float32).reshape(self.storage.dim))
+        k = int(limit)
+        ids = np.zeros(max(k, 1), dtype=np.uint64)
+        dist = np.zeros(max(k, 1), dtype=np.float32)
+        n = C.c_uint32()
+        N.check(self._lib.orama_batcher_search(self._h, t.ctypes.data, k, ids.ctypes.data, dist.ctypes.data,
+                                               C.byref(n)))
+        return ids[: n.value], dist[: n.value]
+
+    def stats(self) -> dict:
+        r, b, l = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        N.check(self._lib.orama_batcher_stats(self._h, C.byref(r), C.byref(b), C.byref(l)))
+        return {"requests": r.value, "batches": b.value, "largest_batch": l.value,
+                "mean_batch": (r.value / b.value) if b.value else 0.0}
