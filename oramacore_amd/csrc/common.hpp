@@ -175,6 +175,7 @@ struct orama_ctx {
     // the 64-bit shuffle re-reduction per insert lengthens each wave's latency-bound critical path and the LDS
     // bitonic reduction of the wave lists costs more than the dense radix select — so it is off by default.
     int fused_topk = 0;
+    int f32_multi = 1;   // K1b: fp32 batches of 2..8 queries share one corpus pass (ORAMA_F32_MULTI=0 disables)
     int f16_kc = 8, f16_nbuf = 3;   // K2 register ring: k-steps per chunk, chunks (ORAMA_F16_KC / ORAMA_F16_NBUF)
     int compute_units = 0;
     uint64_t hbm_bytes = 0;

@@ -36,6 +36,13 @@ int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a, hipStream_t stream);
 uint32_t vec_scan_f32_waves(orama_ctx* ctx, const ScanArgs& a);
 constexpr uint32_t kWaveListKeys = 128;
 
+// K1b: one corpus pass, nq in [2, 8] queries (a.query = nq contiguous queries); distances of query j go to
+// a.out_dist[j * out_stride + row].  Bit-identical per (row, query) to launch_vec_scan_f32.  Dense mode only.
+constexpr uint32_t kScanMultiMaxQ = 8;
+bool vec_scan_f32_multi_supported(const ScanArgs& a);
+int launch_vec_scan_f32_multi(orama_ctx* ctx, const ScanArgs& a, uint32_t nq, uint64_t out_stride,
+                              hipStream_t stream);
+
 // 1/|x| per row (cosine) for rows [first, first + n).
 int launch_row_inv_norm_f32(const float* corpus, uint64_t first, uint64_t n, uint32_t dim,
                             float* inv_norm, hipStream_t stream);

@@ -209,7 +209,7 @@ int search_enqueue_f32(orama_vec* v, Scratch* sc, const float* d_queries, uint32
     for (uint32_t q0 = 0; q0 < q; q0 += group) {
         const uint32_t gq = (q - q0) < group ? (q - q0) : group;
         ORAMA_TRY(scan_begin(sc, s_scan, s));
-        for (uint32_t j = 0; j < gq; ++j) {
+        for (uint32_t j = 0; j < gq;) {
             ScanArgs a;
             a.corpus = v->rows.as<float>();
             a.inv_norm = v->inv_norm.as<float>();
@@ -222,7 +222,15 @@ int search_enqueue_f32(orama_vec* v, Scratch* sc, const float* d_queries, uint32
             a.allow = d_allow;
             a.allow_bits = allow_bits;
             a.out_dist = sc->dist.as<float>() + (size_t)j * n;
-            ORAMA_TRY(launch_vec_scan_f32(v->ctx, a, s_scan));
+            // K1b: up to 8 queries share one corpus pass (a micro-batch of concurrent requests)
+            const uint32_t nq = std::min<uint32_t>(gq - j, v->ctx->f32_multi ? kScanMultiMaxQ : 1u);
+            if (nq >= 2 && vec_scan_f32_multi_supported(a)) {
+                ORAMA_TRY(launch_vec_scan_f32_multi(v->ctx, a, nq, n, s_scan));
+                j += nq;
+            } else {
+                ORAMA_TRY(launch_vec_scan_f32(v->ctx, a, s_scan));
+                j += 1;
+            }
         }
         ORAMA_TRY(scan_end(sc, s_scan, s));
         SelectPlan p;

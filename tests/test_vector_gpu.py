@@ -312,3 +312,26 @@ def test_experimental_fused_topk_path_is_exact(monkeypatch):
         assert np.array_equal(got[0], w[0]) and np.array_equal(got[1], w[1]) and np.array_equal(got[2], w[2])
     st.close()
     fctx.close()
+
+
+@pytest.mark.parametrize("d,metric", [(768, 0), (384, 0), (1024, 0), (100, 0), (256, 1), (768, 1)])
+def test_batched_fp32_pass_equals_solo_queries(ctx, d, metric):
+    """K1b (2..8 queries share one corpus pass) must return, per query, exactly what the single-query K1 pass
+    returns: same ids, bit-identical distances — with tombstones and an allow-bitmap too."""
+    n = 3001
+    corpus = util.gaussian_rows(n, d, seed=31 + d)
+    st = make_store(ctx, corpus, metric=oa.METRIC_L2SQ if metric else oa.METRIC_COSINE,
+                    row_doc=np.arange(n, dtype=np.uint64) * 2 + 5)
+    for doc in (5, 7, 2005):
+        st.delete(doc)
+    bm = oa.AllowBitmap.from_mask((np.arange(2 * n + 6) % 5) != 0)
+    queries = util.gaussian_rows(19, d, seed=77 + d)
+    for allow in (None, bm):
+        solo = [st.storage_search(queries[i], 40, allow) for i in range(19)]
+        for nq in (2, 3, 4, 5, 8, 9, 19):
+            ids, dist, cnt = st.storage_search(queries[:nq], 40, allow)
+            for i in range(nq):
+                assert cnt[i] == solo[i][2][0]
+                assert np.array_equal(ids[i], solo[i][0][0]), (nq, i)
+                assert np.array_equal(dist[i].view(np.uint32), solo[i][1][0].view(np.uint32)), (nq, i)
+    st.close()
