@@ -38,6 +38,8 @@ WORKLOADS = {
     "c2": (1_000_000, 384, 100, 1, "f32", "1M x 384 fp32 embeddings, single-query cosine top-100 (BASELINE configs[1])"),
     "c3": (10_000_000, 768, 100, 64, "f16", "10M x 768 fp16 embeddings, batch-64 queries, MFMA scan + top-100 "
                                             "(BASELINE configs[2])"),
+    "c5": (80_000_000, 768, 100, 256, "f16", "80M x 768 fp16 embeddings sharded over the ranks, batch-256 queries, "
+                                             "MFMA scan + top-100 + RCCL all-gather (BASELINE configs[4])"),
 }
 
 
@@ -221,7 +223,8 @@ def main():
                       "FETCH_SIZE x2 per MI355X_MICROARCH.md)"
 
     out = {
-        "metric": "queries/sec, cosine top-100 scan (10M x 768) — HBM GB/s vs peak in `roofline`",
+        "metric": f"queries/sec, cosine top-{k} scan ({n_total // 1_000_000}M x {dim} {dtype}) — HBM GB/s vs peak in "
+                  "`roofline`",
         "value": args.steps * qb / elapsed,
         "unit": "queries/s",
         "n_gpus": world,
