@@ -164,6 +164,20 @@ int orama_vec_fill_synthetic(orama_vec* v, uint64_t n_rows, uint64_t seed, uint6
 int orama_vec_get_rows(orama_vec* v, const uint64_t* row_idx, uint64_t n, float* out_rows,
                        uint64_t* out_doc_ids);
 
+/* ------------------------------------------------------------------ resident allow-bitmaps
+ * A filter — FilterResult<DocumentId> (index/filter.rs:344-392), including the "NOT uncommitted-deleted" predicate
+ * every search carries while deletes are pending — materialised once as a bit per DocumentId and kept in HBM.
+ * orama_allow_token() is what a search takes: ANY `allow_bitmap` argument of this header accepts either host
+ * words (uploaded for that call) or the token of a resident bitmap (used in place, no PCIe traffic;
+ * `bitmap_bits` must not exceed the bitmap's size).  The shim caches handles per filter hash and flips single bits
+ * with orama_allow_set when a document is deleted / re-admitted (under the index's write lock, like the delete
+ * itself: a search in flight may see either state).  Destroy only after searches using the token returned. */
+typedef struct orama_allow orama_allow;
+int orama_allow_create(orama_ctx* ctx, const uint64_t* words, uint64_t bitmap_bits, orama_allow** out);
+void orama_allow_destroy(orama_allow* a);
+const uint64_t* orama_allow_token(const orama_allow* a);
+int orama_allow_set(orama_allow* a, const uint64_t* doc_ids, uint64_t n, int allowed);
+
 /* ------------------------------------------------------------------ request micro-batcher
  * The reference API has no batch entry (EmbeddingFieldStorage::search takes ONE target,
  * embedding_field.rs:250-254); concurrent single-query callers are coalesced here so that one corpus pass serves

@@ -6,4 +6,5 @@ interfaces for that path, used by the tests and bench.py.
 """
 from ._native import DTYPE_F16, DTYPE_F32, METRIC_COSINE, METRIC_L2SQ, OramaError  # noqa: F401
 from .context import Context  # noqa: F401
-from .embedding_field import AllowBitmap, EmbeddingFieldStorage, Model, SearchBatcher, VectorSearchParams  # noqa: F401
+from .embedding_field import (AllowBitmap, EmbeddingFieldStorage, Model, ResidentAllowBitmap, SearchBatcher,
+                              VectorSearchParams)  # noqa: F401

@@ -13,6 +13,7 @@
 #include <mutex>
 #include <string>
 #include <utility>
+#include <unordered_map>
 #include <vector>
 
 #include "orama_hip.h"
@@ -183,6 +184,10 @@ struct orama_ctx {
     orama::Profiler prof;
     std::mutex pool_mu;
     std::vector<std::unique_ptr<orama::Scratch>> pool;
+    // resident allow-bitmaps (orama_allow_*): device pointer -> bits; a search whose `allow_bitmap` argument is one
+    // of these pointers uses it in place instead of uploading host words
+    std::mutex allow_mu;
+    std::unordered_map<const void*, uint64_t> allow_reg;
 
     // Borrow a scratch set (creates one when the pool is empty).
     int acquire(std::unique_ptr<orama::Scratch>* out);
@@ -200,6 +205,11 @@ struct ScratchLease {
     }
     Scratch* operator->() { return s.get(); }
 };
+
+// The device bitmap a search reads: `allow_bitmap` itself when it is the token of a resident bitmap
+// (orama_allow_token), else a per-call upload of the host words into sc->bitmap on `s`.  nullptr stays nullptr.
+int resolve_allow(orama_ctx* ctx, Scratch* sc, const uint64_t* allow_bitmap, uint64_t bitmap_bits, hipStream_t s,
+                  const uint64_t** d_allow);
 
 inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 }  // namespace orama

@@ -1,5 +1,6 @@
 // context.hip — error channel, per-GPU context, scratch pool, HIP-event profiler.
 #include <cstdlib>
+#include <memory>
 
 #include "common.hpp"
 #include "vec_kernels.hpp"
@@ -100,7 +101,92 @@ void orama_ctx::release(std::unique_ptr<orama::Scratch> s) {
     pool.push_back(std::move(s));
 }
 
+namespace orama {
+int resolve_allow(orama_ctx* ctx, Scratch* sc, const uint64_t* allow_bitmap, uint64_t bitmap_bits, hipStream_t s,
+                  const uint64_t** d_allow) {
+    *d_allow = nullptr;
+    if (!allow_bitmap) return ORAMA_OK;
+    {
+        std::lock_guard<std::mutex> g(ctx->allow_mu);
+        auto it = ctx->allow_reg.find(allow_bitmap);
+        if (it != ctx->allow_reg.end()) {
+            ORAMA_REQUIRE(bitmap_bits <= it->second, "resident bitmap holds %llu bits, %llu requested",
+                          (unsigned long long)it->second, (unsigned long long)bitmap_bits);
+            *d_allow = allow_bitmap;
+            return ORAMA_OK;
+        }
+    }
+    const size_t words = (size_t)((bitmap_bits + 63) / 64);
+    ORAMA_TRY(sc->bitmap.reserve(std::max<size_t>(8, words * 8)));
+    if (words) ORAMA_HIP_TRY(hipMemcpyAsync(sc->bitmap.p, allow_bitmap, words * 8, hipMemcpyHostToDevice, s));
+    *d_allow = sc->bitmap.as<uint64_t>();
+    return ORAMA_OK;
+}
+}  // namespace orama
+
+// Resident allow-bitmap: the materialised FilterResult<DocumentId> kept in HBM.
+struct orama_allow {
+    orama_ctx* ctx = nullptr;
+    orama::DevBuf words;
+    uint64_t bits = 0;
+};
+
 extern "C" {
+
+int orama_allow_create(orama_ctx* ctx, const uint64_t* words, uint64_t bitmap_bits, orama_allow** out) {
+    ORAMA_REQUIRE(ctx && out, "null argument");
+    *out = nullptr;
+    ORAMA_REQUIRE(bitmap_bits == 0 || words, "null words");
+    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    std::unique_ptr<orama_allow> a(new (std::nothrow) orama_allow());
+    if (!a) {
+        orama::set_error("out of host memory");
+        return ORAMA_ERR_OOM;
+    }
+    a->ctx = ctx;
+    a->bits = bitmap_bits;
+    const size_t n = (size_t)((bitmap_bits + 63) / 64);
+    ORAMA_TRY(a->words.reserve(std::max<size_t>(8, n * 8)));
+    if (n) ORAMA_HIP_TRY(hipMemcpy(a->words.p, words, n * 8, hipMemcpyHostToDevice));
+    {
+        std::lock_guard<std::mutex> g(ctx->allow_mu);
+        ctx->allow_reg[a->words.p] = bitmap_bits;
+    }
+    *out = a.release();
+    return ORAMA_OK;
+}
+
+void orama_allow_destroy(orama_allow* a) {
+    if (!a) return;
+    (void)hipSetDevice(a->ctx->device);
+    (void)hipDeviceSynchronize();  // searches still reading the bitmap
+    {
+        std::lock_guard<std::mutex> g(a->ctx->allow_mu);
+        a->ctx->allow_reg.erase(a->words.p);
+    }
+    delete a;
+}
+
+const uint64_t* orama_allow_token(const orama_allow* a) {
+    return a ? static_cast<const uint64_t*>(a->words.p) : nullptr;
+}
+
+int orama_allow_set(orama_allow* a, const uint64_t* doc_ids, uint64_t n, int allowed) {
+    ORAMA_REQUIRE(a && (n == 0 || doc_ids), "null argument");
+    ORAMA_HIP_TRY(hipSetDevice(a->ctx->device));
+    // read-modify-write of the touched words (n is small: the documents deleted / re-admitted since the last call)
+    for (uint64_t i = 0; i < n; ++i) {
+        ORAMA_REQUIRE(doc_ids[i] < a->bits, "doc id %llu outside the bitmap (%llu bits)",
+                      (unsigned long long)doc_ids[i], (unsigned long long)a->bits);
+        uint64_t w = 0;
+        uint64_t* dw = a->words.as<uint64_t>() + (doc_ids[i] >> 6);
+        ORAMA_HIP_TRY(hipMemcpy(&w, dw, 8, hipMemcpyDeviceToHost));
+        const uint64_t bit = 1ull << (doc_ids[i] & 63);
+        w = allowed ? (w | bit) : (w & ~bit);
+        ORAMA_HIP_TRY(hipMemcpy(dw, &w, 8, hipMemcpyHostToDevice));
+    }
+    return ORAMA_OK;
+}
 
 int orama_abi_version(void) { return ORAMA_ABI_VERSION; }
 

@@ -276,12 +276,7 @@ int post_stage1(orama_post* p, Scratch* sc, const orama_term_ref* refs, uint32_t
     rank_begin[max_rank] = (uint32_t)segs.size();
 
     const uint64_t* d_allow = nullptr;
-    if (allow_bitmap) {
-        const size_t words = (size_t)((bitmap_bits + 63) / 64);
-        ORAMA_TRY(sc->bitmap.reserve(std::max<size_t>(8, words * 8)));
-        if (words) ORAMA_HIP_TRY(hipMemcpyAsync(sc->bitmap.p, allow_bitmap, words * 8, hipMemcpyHostToDevice, s));
-        d_allow = sc->bitmap.as<uint64_t>();
-    }
+    ORAMA_TRY(resolve_allow(p->ctx, sc, allow_bitmap, bitmap_bits, s, &d_allow));
     const size_t seg_bytes = segs.size() * sizeof(Bm25Seg);
     // pinned staging: [segments | stage-2 vector entries] — stage 2 must not touch bytes an in-flight copy reads
     st->vec_stage_off = (seg_bytes + 63) & ~(size_t)63;
@@ -802,12 +797,7 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
         memcpy(a->h_in.p, query, (size_t)dim * 4);
         ORAMA_HIP_TRY(hipMemcpyAsync(a->query.p, a->h_in.p, (size_t)dim * 4, hipMemcpyHostToDevice, sa));
         const uint64_t* d_allow = nullptr;
-        if (allow_bitmap) {
-            const size_t words = (size_t)((bitmap_bits + 63) / 64);
-            ORAMA_TRY(a->bitmap.reserve(std::max<size_t>(8, words * 8)));
-            if (words) ORAMA_HIP_TRY(hipMemcpyAsync(a->bitmap.p, allow_bitmap, words * 8, hipMemcpyHostToDevice, sa));
-            d_allow = a->bitmap.as<uint64_t>();
-        }
+        ORAMA_TRY(resolve_allow(ctx, a.s.get(), allow_bitmap, bitmap_bits, sa, &d_allow));
         ORAMA_TRY(a->out_ids.reserve((size_t)kk * 8));
         ORAMA_TRY(a->out_val.reserve((size_t)kk * 4));
         ORAMA_TRY(a->out_n.reserve(4));

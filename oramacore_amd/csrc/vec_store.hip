@@ -608,13 +608,7 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     memcpy(sc->h_in.p, queries, qbytes);
     ORAMA_HIP_TRY(hipMemcpyAsync(sc->query.p, sc->h_in.p, qbytes, hipMemcpyHostToDevice, s));
     const uint64_t* d_allow = nullptr;
-    if (allow_bitmap) {
-        const size_t words = (size_t)((bitmap_bits + 63) / 64);
-        ORAMA_TRY(sc->bitmap.reserve(std::max<size_t>(8, words * 8)));
-        if (words)
-            ORAMA_HIP_TRY(hipMemcpyAsync(sc->bitmap.p, allow_bitmap, words * 8, hipMemcpyHostToDevice, s));
-        d_allow = sc->bitmap.as<uint64_t>();
-    }
+    ORAMA_TRY(resolve_allow(v->ctx, sc.s.get(), allow_bitmap, bitmap_bits, s, &d_allow));
     const size_t nk = (size_t)q * k;
     ORAMA_TRY(sc->out_ids.reserve(nk * 8));
     ORAMA_TRY(sc->out_val.reserve(nk * 4));

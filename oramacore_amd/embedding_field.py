@@ -88,6 +88,50 @@ class AllowBitmap:
             return False
         return bool((int(self.words[doc_id >> 6]) >> (doc_id & 63)) & 1)
 
+    def ffi_args(self):
+        """(pointer, bits) for the `allow_bitmap` / `bitmap_bits` arguments: host words, uploaded per call."""
+        return self.words.ctypes.data, self.n_bits
+
+    def to_device(self, ctx) -> "ResidentAllowBitmap":
+        return ResidentAllowBitmap(ctx, self)
+
+
+class ResidentAllowBitmap:
+    """The same filter kept in HBM (orama_allow_*): searches take its token in place of host
+    words — no per-query upload.  `set(doc_ids, allowed)` flips single documents (delete / re-admit)."""
+
+    def __init__(self, ctx, bitmap: AllowBitmap):
+        self._lib = N.load()
+        self.n_bits = bitmap.n_bits
+        self._host = bitmap  # kept in sync so that `contains` still answers on the host
+        h = C.c_void_p()
+        N.check(self._lib.orama_allow_create(ctx.handle, bitmap.words.ctypes.data, bitmap.n_bits, C.byref(h)))
+        self._h = h
+
+    def ffi_args(self):
+        return self._lib.orama_allow_token(self._h), self.n_bits
+
+    def contains(self, doc_id: int) -> bool:
+        return self._host.contains(doc_id)
+
+    def set(self, doc_ids, allowed: bool) -> None:
+        ids = np.ascontiguousarray(doc_ids, dtype=np.uint64)
+        N.check(self._lib.orama_allow_set(self._h, ids.ctypes.data, ids.shape[0], 1 if allowed else 0))
+        for d in ids.tolist():
+            w, b = d >> 6, np.uint64(1) << np.uint64(d & 63)
+            self._host.words[w] = (self._host.words[w] | b) if allowed else (self._host.words[w] & ~b)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.orama_allow_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
 
 @dataclass
 class VectorSearchParams:
@@ -178,7 +222,7 @@ class EmbeddingFieldStorage:
         cnt = np.zeros(q, dtype=np.uint32)
         bm_ptr, bm_bits = None, 0
         if allow is not None:
-            bm_ptr, bm_bits = allow.words.ctypes.data, allow.n_bits
+            bm_ptr, bm_bits = allow.ffi_args()
         N.check(self._lib.orama_vec_search(self._h, t.ctypes.data, q, k, bm_ptr, bm_bits,
                                            ids.ctypes.data, dist.ctypes.data, cnt.ctypes.data))
         return ids, dist, cnt

@@ -255,7 +255,7 @@ class PostingsStore:
         out_sc = np.zeros(max(top_k, 1), dtype=np.float32)
         out_n = C.c_uint32()
         out_count = C.c_uint64()
-        bm_ptr, bm_bits = (allow.words.ctypes.data, allow.n_bits) if allow is not None else (None, 0)
+        bm_ptr, bm_bits = allow.ffi_args() if allow is not None else (None, 0)
         N.check(self._lib.orama_hybrid_search(vec_store.handle, self._h, qv.ctypes.data, int(limit), float(similarity),
                                               1 if rescale_e5 else 0, arr, len(refs), b, C.byref(params), bm_ptr,
                                               bm_bits, 1 if apply_omc else 0, out_ids.ctypes.data, out_sc.ctypes.data,
@@ -300,7 +300,7 @@ class PostingsStore:
         out_sc = np.zeros(max(top_k, 1), dtype=np.float32)
         out_n = C.c_uint32()
         out_count = C.c_uint64()
-        bm_ptr, bm_bits = (allow.words.ctypes.data, allow.n_bits) if allow is not None else (None, 0)
+        bm_ptr, bm_bits = allow.ffi_args() if allow is not None else (None, 0)
         if vector is None:
             N.check(self._lib.orama_post_search(self._h, arr, len(refs), b, C.byref(params), bm_ptr, bm_bits,
                                                 1 if apply_omc else 0, out_ids.ctypes.data, out_sc.ctypes.data,
@@ -328,7 +328,7 @@ class PostingsStore:
         written to the device buffer at `d_df_ptr` (int32[n_tokens]) on HIP stream `stream`."""
         arr = self._refs(refs)
         params = _params(total_documents, n_tokens, threshold, top_k, k)
-        bm_ptr, bm_bits = (allow.words.ctypes.data, allow.n_bits) if allow is not None else (None, 0)
+        bm_ptr, bm_bits = allow.ffi_args() if allow is not None else (None, 0)
         h = C.c_void_p()
         N.check(self._lib.orama_post_query_begin(self._h, arr, len(refs), b, C.byref(params), bm_ptr, bm_bits,
                                                  1 if hybrid else 0, 1 if apply_omc else 0, int(n_vec_cap),
