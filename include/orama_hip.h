@@ -238,6 +238,17 @@ int orama_post_build(orama_post* p, const uint64_t* docs, uint64_t n_docs, uint3
                      const float* avg_field_len, uint32_t n_lists, const uint32_t* field_of_list,
                      const uint64_t* list_off, const uint64_t* post_doc, const uint32_t* post_tf,
                      const uint32_t* post_len);
+/* Live update between commits (StringFieldStorage::insert, string_field.rs:155-170): append
+ * n_docs NEW documents (ids ascending and greater than every stored id — DocumentIds are handed out sequentially,
+ * write/collection_document_storage.rs:73-77) and n_lists NEW posting lists holding their postings.  The new lists
+ * get the ids n_lists_before … n_lists_before + n_lists − 1 (orama_post_info); a query references the committed
+ * list AND the delta list(s) of a term with the same `token` in consecutive orama_term_ref entries — exactly how
+ * several fields of one token are passed.  avg_field_len[n_fields] replaces the field averages (they move with
+ * every insert).  Deletes reach the scorer through the allow bitmap (the reference's NOT-deleted predicate,
+ * see orama_allow_*) until the next orama_post_build.  Runs under the store's exclusive lock. */
+int orama_post_append(orama_post* p, const uint64_t* docs, uint64_t n_docs, const float* avg_field_len,
+                      uint32_t n_lists, const uint32_t* field_of_list, const uint64_t* list_off,
+                      const uint64_t* post_doc, const uint32_t* post_tf, const uint32_t* post_len);
 /* Bench utility (no reference counterpart): synthetic postings generated in HBM.  n_docs documents
  * with dense ids [first_doc_id, first_doc_id + n_docs), one field, field length ~ LogNormal(4.0, 0.6) clipped to
  * [4, 2000]; list l models the term of Zipf(1.07) rank ranks[l] over a 2^20 vocabulary:

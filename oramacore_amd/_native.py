@@ -146,6 +146,7 @@ def _declare(lib: C.CDLL) -> None:
         "orama_post_create": [vp, C.POINTER(vp)],
         "orama_post_build": [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_uint32, vp, vp, vp, vp, vp],
         "orama_post_set_omc": [vp, vp, vp, C.c_uint64],
+        "orama_post_append": [vp, vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp, vp, vp],
         "orama_post_get_list": [vp, C.c_uint32, C.c_uint64, vp, vp, vp, u64p],
         "orama_post_info": [vp, u64p, u32p, u64p, f32p],
         "orama_post_fill_synthetic": [vp, C.c_uint64, C.c_uint64, C.c_uint32, vp, C.c_uint64, u64p],

@@ -99,15 +99,7 @@ __global__ __launch_bounds__(kThreads) void bm25_accumulate_kernel(Bm25Accum a) 
 template <bool TRACK_MINMAX>
 __global__ __launch_bounds__(kThreads) void bm25_finalize_kernel(Bm25Finalize f) {
     __shared__ float idf[kMaxTokens];
-    for (uint32_t t = threadIdx.x; t < f.n_tokens; t += kThreads) {
-        if (f.idf_table) {
-            uint32_t df = f.state->df[t];
-            if (df < 1) df = 1;  // corpus_docs.len().max(1), token_score.rs:275
-            idf[t] = f.idf_table[df];
-        } else {
-            idf[t] = f.idf_vals[t];
-        }
-    }
+    for (uint32_t t = threadIdx.x; t < f.n_tokens; t += kThreads) idf[t] = f.idf_vals[t];
     __syncthreads();
     const uint32_t n = f.n_slots;
     const float k1 = f.k + 1.0f;
@@ -382,7 +374,7 @@ int launch_bm25_accumulate(orama_ctx* ctx, const Bm25Accum& a, hipStream_t strea
 int launch_bm25_finalize(orama_ctx* ctx, const Bm25Finalize& f, hipStream_t stream) {
     ORAMA_REQUIRE(f.n_tokens >= 1 && f.n_tokens <= kMaxTokens, "bm25: n_tokens %u outside [1, %u]",
                   f.n_tokens, kMaxTokens);
-    ORAMA_REQUIRE(f.idf_table || f.idf_vals, "bm25: idf source missing");
+    ORAMA_REQUIRE(f.idf_vals, "bm25: idf values missing");
     ProfScope prof(&ctx->prof, "bm25_finalize", stream);
     dim3 grid(grid_for(f.n_slots ? f.n_slots : 1, ctx, 1));
     if (grid.x > (uint32_t)ctx->compute_units * 4u) grid.x = (uint32_t)ctx->compute_units * 4u;

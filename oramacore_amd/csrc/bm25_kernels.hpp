@@ -63,8 +63,7 @@ int launch_bm25_accumulate(orama_ctx* ctx, const Bm25Accum& a, hipStream_t strea
 struct Bm25Finalize {
     uint32_t n_tokens = 0;
     float k = 1.2f;
-    const float* idf_table = nullptr;  // nullable: idf[df] for df in [0, n_docs]
-    const float* idf_vals = nullptr;   // else: idf per token (device, n_tokens)
+    const float* idf_vals = nullptr;   // idf per token (device, n_tokens) — computed by the host libm
     bool use_threshold = false;
     uint32_t threshold = 0;
     bool track_minmax = false;         // hybrid: reduce min/max of the emitted scores into `state`

@@ -29,6 +29,8 @@ int reserve_zeroed(DevBuf& b, size_t bytes, hipStream_t s) {
     return ORAMA_OK;
 }
 
+constexpr size_t kDfStageOff = (sizeof(Bm25State) + 63) & ~(size_t)63;  // df read-back area inside h_misc
+
 struct QueryBuffers {
     Bm25State* state = nullptr;
     uint32_t* touched = nullptr;
@@ -58,7 +60,7 @@ int prepare_query(Scratch* sc, uint64_t n_docs, uint32_t n_tokens, uint64_t cand
     ORAMA_TRY(sc->misc3.reserve((size_t)(cand_cap ? cand_cap : 1) * 4));      // touched
     ORAMA_TRY(sc->misc4.reserve((size_t)(cand_cap ? cand_cap : 1) * 4));      // cand_score
     ORAMA_TRY(sc->misc5.reserve((size_t)(cand_cap ? cand_cap : 1) * 4));      // cand_idx
-    ORAMA_TRY(sc->h_misc.reserve(sizeof(Bm25State) + 4096));
+    ORAMA_TRY(sc->h_misc.reserve(kDfStageOff + 4096));
     Bm25State* hs = sc->h_misc.as<Bm25State>();
     memset(hs, 0, sizeof(Bm25State));
     hs->min_key = 0xffffffffu;
@@ -178,31 +180,11 @@ struct orama_post {
     std::vector<float> avg_len;
     std::vector<uint32_t> field_of_list;
     std::vector<uint64_t> list_off;
-    DevBuf d_docs, d_post_doc, d_post_val, d_omc, d_idf;
+    DevBuf d_docs, d_post_doc, d_post_val, d_omc;
     bool has_omc = false;
-    float idf_total_docs = -1.0f;  // the N the idf table was built for
-    std::mutex idf_mu;
 };
 
 namespace {
-
-// idf[df] = ln_1p((N - df + 0.5) / (df + 0.5)) via the host libm (bm25.rs:78-82), df in [0, n_docs]
-int ensure_idf_table(orama_post* p, float total_documents, hipStream_t s) {
-    std::lock_guard<std::mutex> g(p->idf_mu);
-    if (p->idf_total_docs == total_documents && p->d_idf.p) return ORAMA_OK;
-    const uint64_t n = p->n_docs + 1;
-    std::vector<float> t((size_t)n);
-    for (uint64_t df = 0; df < n; ++df) {
-        const float d = (float)df;
-        const float ratio = (total_documents - d + 0.5f) / (d + 0.5f);
-        t[(size_t)df] = log1pf(ratio);
-    }
-    ORAMA_TRY(p->d_idf.reserve((size_t)n * 4));
-    ORAMA_HIP_TRY(hipMemcpyAsync(p->d_idf.p, t.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-    ORAMA_HIP_TRY(hipStreamSynchronize(s));
-    p->idf_total_docs = total_documents;
-    return ORAMA_OK;
-}
 
 // State of one resident-postings query between its two stages.
 struct PostQuery {
@@ -314,12 +296,34 @@ int post_stage1(orama_post* p, Scratch* sc, const orama_term_ref* refs, uint32_t
     }
     st->omc = (apply_omc && p->has_omc) ? p->d_omc.as<float>() : nullptr;
     if (!finalize_now) return ORAMA_OK;
-    ORAMA_TRY(ensure_idf_table(p, params->total_documents, s));
-    return post_finalize(p, sc, *st, params, nullptr);
+    // idf per token by the host libm (calculate_idf, bm25.rs:78-82; df.max(1), token_score.rs:275) — the device
+    // never evaluates a logarithm.  df is known on the host when every token expands to at most one list and no
+    // filter drops postings (docs are unique in a list: df = list length); otherwise it is what K3 counted and
+    // costs one read-back of 4*n_tokens bytes.
+    uint32_t df[kMaxTokens] = {0};
+    bool df_known = d_allow == nullptr;
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        if (per_token[refs[i].token] > 1) df_known = false;
+        df[refs[i].token] += (uint32_t)(p->list_off[refs[i].list + 1] - p->list_off[refs[i].list]);
+    }
+    if (!df_known) {
+        uint32_t* h_df = reinterpret_cast<uint32_t*>(sc->h_misc.as<char>() + kDfStageOff);
+        ORAMA_HIP_TRY(hipMemcpyAsync(h_df, qb.state->df, (size_t)params->n_tokens * 4, hipMemcpyDeviceToHost, s));
+        ORAMA_HIP_TRY(hipStreamSynchronize(s));
+        memcpy(df, h_df, (size_t)params->n_tokens * 4);
+    }
+    float* h_idf = reinterpret_cast<float*>(sc->h_in.as<char>() + st->idf_stage_off);
+    for (uint32_t t = 0; t < params->n_tokens; ++t) {
+        const float d = (float)(df[t] < 1 ? 1u : df[t]);
+        h_idf[t] = log1pf((params->total_documents - d + 0.5f) / (d + 0.5f));
+    }
+    float* d_idf = reinterpret_cast<float*>(sc->misc0.as<char>() + st->idf_dev_off);
+    ORAMA_HIP_TRY(hipMemcpyAsync(d_idf, h_idf, (size_t)params->n_tokens * 4, hipMemcpyHostToDevice, s));
+    return post_finalize(p, sc, *st, params, d_idf);
 }
 
-// K3 finalise (+ min/max of the full-text scores when hybrid).  d_idf_vals == nullptr: idf looked up in the
-// per-index table by the df counted on this device; otherwise idf[t] given (sharded index: global df, §8e).
+// K3 finalise (+ min/max of the full-text scores when hybrid) with idf[t] given (host libm; a sharded index
+// computes it from the global df, §8e).
 int post_finalize(orama_post* p, Scratch* sc, const PostQuery& stq, const orama_bm25_params* params,
                   const float* d_idf_vals) {
     const PostQuery* st = &stq;
@@ -329,7 +333,6 @@ int post_finalize(orama_post* p, Scratch* sc, const PostQuery& stq, const orama_
     Bm25Finalize f;
     f.n_tokens = params->n_tokens;
     f.k = params->k;
-    f.idf_table = d_idf_vals ? nullptr : p->d_idf.as<float>();
     f.idf_vals = d_idf_vals;
     f.use_threshold = params->use_threshold != 0;
     f.threshold = params->threshold;
@@ -508,7 +511,108 @@ int orama_post_build(orama_post* p, const uint64_t* docs, uint64_t n_docs, uint3
     p->list_off.assign(list_off, list_off + (n_lists ? n_lists + 1 : 0));
     if (!n_lists) p->list_off.assign(1, 0);
     p->has_omc = false;
-    p->idf_total_docs = -1.0f;
+    return ORAMA_OK;
+}
+
+// Live update between commits: new documents + delta posting lists appended in place.
+int orama_post_append(orama_post* p, const uint64_t* docs, uint64_t n_new, const float* avg_field_len,
+                      uint32_t n_lists_new, const uint32_t* field_of_list, const uint64_t* list_off,
+                      const uint64_t* post_doc, const uint32_t* post_tf, const uint32_t* post_len) {
+    ORAMA_REQUIRE(p, "null handle");
+    ORAMA_REQUIRE(n_new == 0 || docs, "null docs");
+    ORAMA_REQUIRE(n_lists_new == 0 || (field_of_list && list_off), "null list table");
+    ORAMA_REQUIRE(p->n_fields > 0, "orama_post_append needs a built store (orama_post_build first)");
+    ORAMA_REQUIRE(avg_field_len, "null avg_field_len");
+    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    std::unique_lock<std::shared_mutex> lk(p->mu);
+    const uint64_t n_old = p->n_docs, n_all = n_old + n_new;
+    ORAMA_REQUIRE(n_all < 0xffffffffull, "postings store limited to 2^32-1 documents");
+    const uint64_t last_old = n_old ? (p->dense ? p->dense_base + n_old - 1 : p->h_docs.back()) : 0;
+    for (uint64_t i = 0; i < n_new; ++i) {
+        ORAMA_REQUIRE((i == 0 && (n_old == 0 || docs[0] > last_old)) || (i > 0 && docs[i] > docs[i - 1]),
+                      "appended docs must be ascending and greater than every stored id (position %llu)",
+                      (unsigned long long)i);
+    }
+    // the id table after the append: stays implicit while the ids remain one dense run
+    const bool dense_after = (n_old == 0 || p->dense) &&
+                             (n_new == 0 || ((n_old == 0 || docs[0] == p->dense_base + n_old) &&
+                                             docs[n_new - 1] - docs[0] == n_new - 1));
+    std::vector<uint64_t> all_docs;
+    if (!dense_after) {
+        all_docs.reserve((size_t)n_all);
+        if (p->dense) for (uint64_t i = 0; i < n_old; ++i) all_docs.push_back(p->dense_base + i);
+        else all_docs = p->h_docs;
+        all_docs.insert(all_docs.end(), docs, docs + n_new);
+    }
+    const uint64_t base_new = n_old ? p->dense_base : (n_new ? docs[0] : 0);
+    auto local_after = [&](uint64_t id, uint32_t* out) -> bool {
+        if (dense_after) {
+            if (id < base_new || id - base_new >= n_all) return false;
+            *out = (uint32_t)(id - base_new);
+            return true;
+        }
+        auto it = std::lower_bound(all_docs.begin(), all_docs.end(), id);
+        if (it == all_docs.end() || *it != id) return false;
+        *out = (uint32_t)(it - all_docs.begin());
+        return true;
+    };
+    const uint64_t n_post_new = n_lists_new ? list_off[n_lists_new] : 0;
+    ORAMA_REQUIRE(n_post_new == 0 || (post_doc && post_tf && post_len), "null postings");
+    std::vector<uint32_t> pd((size_t)n_post_new), pv((size_t)n_post_new);
+    for (uint32_t l = 0; l < n_lists_new; ++l) {
+        ORAMA_REQUIRE(field_of_list[l] < p->n_fields, "list %u: field %u out of range", l, field_of_list[l]);
+        ORAMA_REQUIRE(list_off[l] <= list_off[l + 1], "list offsets must be non-decreasing");
+        for (uint64_t i = list_off[l]; i < list_off[l + 1]; ++i) {
+            ORAMA_REQUIRE(i == list_off[l] || post_doc[i] > post_doc[i - 1], "list %u: docs must be strictly ascending", l);
+            uint32_t local;
+            ORAMA_REQUIRE(local_after(post_doc[i], &local), "list %u: doc %llu not in the store", l,
+                          (unsigned long long)post_doc[i]);
+            ORAMA_REQUIRE(post_tf[i] <= 0xffffu && post_len[i] <= 0xffffu, "tf / field_length must fit u16");
+            pd[(size_t)i] = local;
+            pv[(size_t)i] = (post_tf[i] << 16) | post_len[i];
+        }
+    }
+    // grow the device arrays (old contents copied device-to-device) and append
+    auto grow = [](DevBuf& buf, size_t old_bytes, size_t new_bytes) -> int {
+        if (new_bytes <= buf.cap) return ORAMA_OK;
+        DevBuf bigger;
+        ORAMA_TRY(bigger.reserve(new_bytes + new_bytes / 4));
+        if (old_bytes) ORAMA_HIP_TRY(hipMemcpy(bigger.p, buf.p, old_bytes, hipMemcpyDeviceToDevice));
+        std::swap(buf.p, bigger.p);
+        std::swap(buf.cap, bigger.cap);
+        return ORAMA_OK;
+    };
+    ORAMA_HIP_TRY(hipDeviceSynchronize());
+    const uint64_t n_post_old = p->n_postings;
+    ORAMA_TRY(grow(p->d_docs, (size_t)n_old * 8, std::max<size_t>(8, (size_t)n_all * 8)));
+    ORAMA_TRY(grow(p->d_post_doc, (size_t)n_post_old * 4, std::max<size_t>(4, (size_t)(n_post_old + n_post_new) * 4)));
+    ORAMA_TRY(grow(p->d_post_val, (size_t)n_post_old * 4, std::max<size_t>(4, (size_t)(n_post_old + n_post_new) * 4)));
+    if (n_new) ORAMA_HIP_TRY(hipMemcpy(p->d_docs.as<uint64_t>() + n_old, docs, (size_t)n_new * 8, hipMemcpyHostToDevice));
+    if (n_post_new) {
+        ORAMA_HIP_TRY(hipMemcpy(p->d_post_doc.as<uint32_t>() + n_post_old, pd.data(), (size_t)n_post_new * 4, hipMemcpyHostToDevice));
+        ORAMA_HIP_TRY(hipMemcpy(p->d_post_val.as<uint32_t>() + n_post_old, pv.data(), (size_t)n_post_new * 4, hipMemcpyHostToDevice));
+    }
+    if (p->has_omc && n_new) {  // new documents carry no multiplier: x * 1.0 == x
+        ORAMA_TRY(grow(p->d_omc, (size_t)n_old * 4, (size_t)n_all * 4));
+        std::vector<float> ones((size_t)n_new, 1.0f);
+        ORAMA_HIP_TRY(hipMemcpy(p->d_omc.as<float>() + n_old, ones.data(), (size_t)n_new * 4, hipMemcpyHostToDevice));
+    }
+    if (p->list_off.empty()) p->list_off.assign(1, 0);
+    for (uint32_t l = 0; l < n_lists_new; ++l) {
+        p->field_of_list.push_back(field_of_list[l]);
+        p->list_off.push_back(n_post_old + list_off[l + 1]);
+    }
+    p->n_lists += n_lists_new;
+    p->n_postings = n_post_old + n_post_new;
+    p->n_docs = n_all;
+    p->dense = dense_after;
+    if (dense_after) {
+        p->dense_base = base_new;
+        p->h_docs.clear();
+    } else {
+        p->h_docs.swap(all_docs);
+    }
+    p->avg_len.assign(avg_field_len, avg_field_len + p->n_fields);
     return ORAMA_OK;
 }
 
@@ -570,7 +674,6 @@ int orama_post_fill_synthetic(orama_post* p, uint64_t n_docs, uint64_t first_doc
     p->field_of_list.assign(n_lists, 0u);
     p->list_off = off;
     p->has_omc = false;
-    p->idf_total_docs = -1.0f;
     if (out_total_postings) *out_total_postings = total;
     return ORAMA_OK;
 }

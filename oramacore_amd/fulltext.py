@@ -234,6 +234,28 @@ class PostingsStore:
                                            ptf.ctypes.data, plen.ctypes.data))
         self.n_docs = int(docs.shape[0])
 
+    def append(self, docs, avg_field_len, lists: list[PostingList]) -> int:
+        """Live update (orama_post_append): new documents + delta posting lists. Returns the id of the first new list."""
+        first = self.info()["n_lists"]
+        docs = _u64(docs)
+        avg = _f32(avg_field_len)
+        n_lists = len(lists)
+        fol = np.ascontiguousarray([l.field for l in lists], dtype=np.uint32)
+        off = np.zeros(n_lists + 1, dtype=np.uint64)
+        for i, l in enumerate(lists):
+            off[i + 1] = off[i] + np.uint64(len(l.docs))
+        if n_lists:
+            pdoc = _u64(np.concatenate([_u64(l.docs) for l in lists]))
+            ptf = np.ascontiguousarray(np.concatenate([np.asarray(l.tf) for l in lists]), dtype=np.uint32)
+            plen = np.ascontiguousarray(np.concatenate([np.asarray(l.field_len) for l in lists]), dtype=np.uint32)
+        else:
+            pdoc, ptf, plen = _u64([]), np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+        N.check(self._lib.orama_post_append(self._h, docs.ctypes.data, docs.shape[0], avg.ctypes.data, n_lists,
+                                            fol.ctypes.data, off.ctypes.data, pdoc.ctypes.data, ptf.ctypes.data,
+                                            plen.ctypes.data))
+        self.n_docs += int(docs.shape[0])
+        return first
+
     def fill_synthetic(self, n_docs: int, ranks, seed: int, first_doc_id: int = 0) -> int:
         """Bench utility: Zipf(1.07) posting lists generated in HBM. Returns the number of postings."""
         r = np.ascontiguousarray(ranks, dtype=np.uint32)
