@@ -13,6 +13,11 @@
 //   top_n                  (sides/read/sort.rs:260-279)                   orama::host::top_n
 //   normalize_and_combine  (index/token_score.rs:393-422)                 orama::host::normalize_and_combine
 //   apply_omc_multipliers  (sides/read/search.rs:39-48)                   folded into the scoring calls
+//   StringFieldStorage postings on the GPU (index/string_field.rs:155-225) orama::host::PostingsStore
+//   search_full_text / search_hybrid (index/token_score.rs:186-387)       PostingsStore::search / search_hybrid /
+//                                                                         hybrid_search (both legs, one call)
+//   cached filter (index/filter.rs:344-392), kept in HBM                  orama::host::ResidentBitmap
+//   request coalescing at the wrapper (extension)      orama::host::SearchBatcher
 //   anyhow::Error                                                         orama::host::Error (status + message)
 #pragma once
 
@@ -91,17 +96,48 @@ struct DocBitmap {
     bool contains(DocumentId d) const { return d < bits && ((words[d >> 6] >> (d & 63)) & 1ull); }
 };
 
+// The same bitmap kept in HBM (orama_allow_*): created once per distinct filter, passed by token afterwards.
+class ResidentBitmap {
+   public:
+    ResidentBitmap(Context& ctx, const DocBitmap& b) : bits_(b.bits) {
+        check(orama_allow_create(ctx.raw(), b.words.data(), b.bits, &h_));
+    }
+    ~ResidentBitmap() { orama_allow_destroy(h_); }
+    ResidentBitmap(const ResidentBitmap&) = delete;
+    ResidentBitmap& operator=(const ResidentBitmap&) = delete;
+    void set(DocumentId d, bool allowed) { check(orama_allow_set(h_, &d, 1, allowed ? 1 : 0)); }
+    const uint64_t* token() const { return orama_allow_token(h_); }
+    uint64_t bits() const { return bits_; }
+
+   private:
+    orama_allow* h_ = nullptr;
+    uint64_t bits_ = 0;
+};
+
+// What a search takes as its filter: nothing, host words (uploaded for the call) or a resident bitmap.
+struct FilterRef {
+    const uint64_t* words = nullptr;
+    uint64_t bits = 0;
+    FilterRef() = default;
+    FilterRef(const DocBitmap* b) : words(b ? b->words.data() : nullptr), bits(b ? b->bits : 0) {}  // NOLINT
+    FilterRef(const DocBitmap& b) : words(b.words.data()), bits(b.bits) {}                            // NOLINT
+    FilterRef(const ResidentBitmap& b) : words(b.token()), bits(b.bits()) {}                          // NOLINT
+};
+
 struct VectorSearchParams {  // committed_field/vector.rs:10-15
     const std::vector<float>* target = nullptr;
     float similarity = 0.7f;  // Similarity default, types.rs:879-885
     size_t limit = 10;        // Limit default, types.rs:748-754
-    const DocBitmap* filtered_doc_ids = nullptr;
+    FilterRef filtered_doc_ids;
 };
 
 class EmbeddingFieldStorage {
    public:
-    EmbeddingFieldStorage(Context& ctx, Model model) : model_(model), dim_(dimensions(model)) {  // :65-76
-        check(orama_vec_create(ctx.raw(), (uint32_t)dim_, ORAMA_METRIC_COSINE, ORAMA_DTYPE_F32, 0, &h_));
+    // :65-76.  half_precision: rows stored as f16 in the MFMA-tiled layout (K2; batched queries share a pass)
+    EmbeddingFieldStorage(Context& ctx, Model model, bool half_precision = false)
+        : model_(model), dim_(dimensions(model)) {
+        check(orama_vec_create(ctx.raw(), (uint32_t)dim_, ORAMA_METRIC_COSINE,
+                               half_precision ? ORAMA_DTYPE_F16 : ORAMA_DTYPE_F32, 0, &h_));
     }
     ~EmbeddingFieldStorage() { orama_vec_destroy(h_); }
     EmbeddingFieldStorage(const EmbeddingFieldStorage&) = delete;
@@ -137,8 +173,8 @@ class EmbeddingFieldStorage {
         std::vector<uint64_t> ids(k ? k : 1);
         std::vector<float> dist(k ? k : 1);
         uint32_t n = 0;
-        const uint64_t* bm = params.filtered_doc_ids ? params.filtered_doc_ids->words.data() : nullptr;
-        const uint64_t bits = params.filtered_doc_ids ? params.filtered_doc_ids->bits : 0;
+        const uint64_t* bm = params.filtered_doc_ids.words;
+        const uint64_t bits = params.filtered_doc_ids.bits;
         check(orama_vec_search(h_, params.target->data(), 1, (uint32_t)k, bm, bits, ids.data(), dist.data(), &n));
         for (uint32_t i = 0; i < n; ++i) {
             const float similarity = 1.0f - dist[i];
@@ -298,6 +334,177 @@ inline TopResult normalize_and_combine(Context& ctx, const std::unordered_map<Do
     for (uint32_t i = 0; i < out_n; ++i) r.hits.push_back(TokenScore{ids[i], sc[i]});
     return r;
 }
+
+// Request coalescing in front of one EmbeddingFieldStorage (orama_batcher_*): concurrent single-target callers
+// share corpus passes; `search` has the semantics of the storage call of EmbeddingFieldStorage::search without
+// a filter and blocks the calling thread until its batch has been scanned.
+class SearchBatcher {
+   public:
+    explicit SearchBatcher(EmbeddingFieldStorage& field, uint32_t max_batch = 64, uint32_t max_wait_us = 0)
+        : field_(field) {
+        check(orama_batcher_create(field.raw(), max_batch, max_wait_us, &h_));
+    }
+    ~SearchBatcher() { orama_batcher_destroy(h_); }
+    SearchBatcher(const SearchBatcher&) = delete;
+    SearchBatcher& operator=(const SearchBatcher&) = delete;
+
+    // EmbeddingFieldStorage::search (:250-278) for an unfiltered request
+    void search(const VectorSearchParams& params, std::unordered_map<DocumentId, float>& output) const {
+        const size_t k = params.limit;
+        std::vector<uint64_t> ids(k ? k : 1);
+        std::vector<float> dist(k ? k : 1);
+        uint32_t n = 0;
+        check(orama_batcher_search(h_, params.target->data(), (uint32_t)k, ids.data(), dist.data(), &n));
+        for (uint32_t i = 0; i < n; ++i) {
+            const float similarity = 1.0f - dist[i];
+            const float score = rescale_score(field_.model(), similarity);
+            if (score >= params.similarity) output[ids[i]] += score;
+        }
+    }
+
+   private:
+    EmbeddingFieldStorage& field_;
+    orama_batcher* h_ = nullptr;
+};
+
+// One posting list as StringFieldStorage holds it per (field, term): (doc, tf = positions.len(), field_length).
+struct PostingList {
+    uint32_t field = 0;
+    std::vector<uint64_t> docs;  // ascending
+    std::vector<uint32_t> tf, field_len;
+};
+
+// (token index, posting list, field boost) — SearchParams.boost, token_score.rs:234-238
+using TermRef = orama_term_ref;
+
+struct FullTextParams {            // what search_full_text derives (token_score.rs:186-302)
+    uint32_t n_tokens = 1;
+    float total_documents = 1.0f;  // the index's document_count (:221)
+    size_t top_k = 10;             // limit + offset (sort.rs:24-34)
+    bool use_threshold = false;    // Threshold -> floor(n_tokens * t) (:211-218)
+    uint32_t threshold = 0;
+    float k = 1.2f, b = 0.75f;     // Bm25Params::default()
+    bool apply_omc = true;
+    FilterRef filter;
+};
+
+// The committed postings of one index, resident in HBM (seam ii) + the scoring entry points over them.
+class PostingsStore {
+   public:
+    explicit PostingsStore(Context& ctx) { check(orama_post_create(ctx.raw(), &h_)); }
+    ~PostingsStore() { orama_post_destroy(h_); }
+    PostingsStore(const PostingsStore&) = delete;
+    PostingsStore& operator=(const PostingsStore&) = delete;
+
+    // commit: all live documents (ascending ids), per-field average lengths, one list per (field, term)
+    void build(const std::vector<uint64_t>& docs, const std::vector<float>& avg_field_len,
+               const std::vector<PostingList>& lists) {
+        Flat f(lists);
+        check(orama_post_build(h_, docs.data(), docs.size(), (uint32_t)avg_field_len.size(), avg_field_len.data(),
+                               (uint32_t)lists.size(), f.field.data(), f.off.data(), f.doc.data(), f.tf.data(),
+                               f.len.data()));
+    }
+    // insert between commits: new documents + delta lists; returns the id of the first new list
+    uint32_t append(const std::vector<uint64_t>& docs, const std::vector<float>& avg_field_len,
+                    const std::vector<PostingList>& lists) {
+        uint32_t first = 0;
+        check(orama_post_info(h_, nullptr, &first, nullptr, nullptr));
+        Flat f(lists);
+        check(orama_post_append(h_, docs.data(), docs.size(), avg_field_len.data(), (uint32_t)lists.size(),
+                                f.field.data(), f.off.data(), f.doc.data(), f.tf.data(), f.len.data()));
+        return first;
+    }
+    void set_omc(const std::map<DocumentId, float>& omc) {  // Index::get_all_omc, index/mod.rs:1720-1739
+        std::vector<uint64_t> d;
+        std::vector<float> m;
+        for (auto& kv : omc) {
+            d.push_back(kv.first);
+            m.push_back(kv.second);
+        }
+        check(orama_post_set_omc(h_, d.data(), m.data(), d.size()));
+    }
+
+    // search_full_text (+ apply_omc + count + top_n) — token_score.rs:186-302, search.rs:39-48,482, sort.rs:260-279
+    TopResult search(const std::vector<TermRef>& refs, const FullTextParams& p) const {
+        Out o(p.top_k);
+        const orama_bm25_params bp = params(p);
+        check(orama_post_search(h_, refs.data(), (uint32_t)refs.size(), p.b, &bp, p.filter.words, p.filter.bits,
+                                p.apply_omc ? 1 : 0, o.ids.data(), o.sc.data(), &o.n, &o.r.count));
+        return o.done();
+    }
+    // search_hybrid with the vector map already computed (token_score.rs:357-422)
+    TopResult search_hybrid(const std::vector<TermRef>& refs, const FullTextParams& p,
+                            const std::unordered_map<DocumentId, float>& vector) const {
+        std::vector<uint64_t> vd;
+        std::vector<float> vs;
+        for (auto& kv : vector) {
+            vd.push_back(kv.first);
+            vs.push_back(kv.second);
+        }
+        Out o(p.top_k);
+        const orama_bm25_params bp = params(p);
+        check(orama_post_search_hybrid(h_, refs.data(), (uint32_t)refs.size(), p.b, &bp, p.filter.words,
+                                       p.filter.bits, vd.data(), vs.data(), (uint32_t)vd.size(), p.apply_omc ? 1 : 0,
+                                       o.ids.data(), o.sc.data(), &o.n, &o.r.count));
+        return o.done();
+    }
+    // search_hybrid as ONE call: vector leg (field, target, limit, similarity) and full-text leg overlap on two
+    // HIP streams; the EmbeddingFieldStorage::search epilogue runs inside the library
+    TopResult hybrid_search(const EmbeddingFieldStorage& field, const VectorSearchParams& v,
+                            const std::vector<TermRef>& refs, const FullTextParams& p) const {
+        Out o(p.top_k);
+        const orama_bm25_params bp = params(p);
+        check(orama_hybrid_search(field.raw(), h_, v.target->data(), (uint32_t)v.limit, v.similarity,
+                                  is_e5(field.model()) ? 1 : 0, refs.data(), (uint32_t)refs.size(), p.b, &bp,
+                                  p.filter.words, p.filter.bits, p.apply_omc ? 1 : 0, o.ids.data(), o.sc.data(), &o.n,
+                                  &o.r.count));
+        return o.done();
+    }
+    orama_post* raw() const { return h_; }
+
+   private:
+    struct Flat {
+        std::vector<uint32_t> field, tf, len;
+        std::vector<uint64_t> off, doc;
+        explicit Flat(const std::vector<PostingList>& lists) : off(1, 0) {
+            for (const auto& l : lists) {
+                field.push_back(l.field);
+                doc.insert(doc.end(), l.docs.begin(), l.docs.end());
+                tf.insert(tf.end(), l.tf.begin(), l.tf.end());
+                len.insert(len.end(), l.field_len.begin(), l.field_len.end());
+                off.push_back(doc.size());
+            }
+            if (doc.empty()) {  // keep data() non-null
+                doc.reserve(1);
+                tf.reserve(1);
+                len.reserve(1);
+            }
+            if (field.empty()) field.reserve(1);
+        }
+    };
+    struct Out {
+        std::vector<uint64_t> ids;
+        std::vector<float> sc;
+        uint32_t n = 0;
+        TopResult r;
+        explicit Out(size_t k) : ids(k ? k : 1), sc(k ? k : 1) {}
+        TopResult done() {
+            for (uint32_t i = 0; i < n; ++i) r.hits.push_back(TokenScore{ids[i], sc[i]});
+            return std::move(r);
+        }
+    };
+    static orama_bm25_params params(const FullTextParams& p) {
+        orama_bm25_params bp{};
+        bp.total_documents = p.total_documents;
+        bp.k = p.k;
+        bp.n_tokens = p.n_tokens;
+        bp.use_threshold = p.use_threshold ? 1 : 0;
+        bp.threshold = p.threshold;
+        bp.top_k = (uint32_t)p.top_k;
+        return bp;
+    }
+    orama_post* h_ = nullptr;
+};
 
 }  // namespace host
 }  // namespace orama

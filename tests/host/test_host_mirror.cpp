@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <random>
+#include <thread>
 
 #include "orama/host.hpp"
 extern "C" {
@@ -216,6 +217,156 @@ static void test_errors_surface_as_exceptions(Context& ctx) {
     CHECK(threw);
 }
 
+// PostingsStore (seam ii) against the oracle fed with host-computed ntf, then append == rebuild, filters (host
+// words and resident), hybrid in one call vs the two-step form.
+static void test_postings_store(Context& ctx) {
+    const size_t n_docs = 3000, T = 4;
+    std::mt19937 rng(11);
+    std::vector<uint64_t> docs(n_docs);
+    std::vector<uint32_t> len(n_docs);
+    double sum_len = 0;
+    for (size_t i = 0; i < n_docs; ++i) {
+        docs[i] = 5 + 2 * i;
+        len[i] = 5 + rng() % 200;
+        sum_len += len[i];
+    }
+    const float avg = (float)(sum_len / (double)n_docs);
+    auto make_lists = [&](size_t lo, size_t hi) {
+        std::mt19937 r2(99);
+        std::vector<PostingList> lists(T);
+        for (size_t t = 0; t < T; ++t)
+            for (size_t i = 0; i < n_docs; ++i) {
+                const uint32_t roll = r2();  // same stream for every (lo, hi): list t is a fixed subset
+                if (roll % (3 + t) != 0) continue;
+                if (i < lo || i >= hi) continue;
+                lists[t].docs.push_back(docs[i]);
+                lists[t].tf.push_back(1 + (roll >> 8) % 4);
+                lists[t].field_len.push_back(len[i]);
+            }
+        return lists;
+    };
+    const auto lists = make_lists(0, n_docs);
+    PostingsStore store(ctx);
+    store.build(docs, {avg}, lists);
+    std::vector<TermRef> refs;
+    for (uint32_t t = 0; t < T; ++t) refs.push_back(TermRef{t, t, 1.0f});
+    FullTextParams p;
+    p.n_tokens = T;
+    p.total_documents = (float)n_docs;
+    p.top_k = 50;
+    // oracle: contributions with ntf = boost * tf / (1 - b + b * len / avglen)
+    std::vector<std::vector<float>> ntf(T);
+    std::vector<orc_entry> entries;
+    for (size_t t = 0; t < T; ++t) {
+        for (size_t i = 0; i < lists[t].docs.size(); ++i)
+            ntf[t].push_back(1.0f * orc_bm25f_normalized_tf(lists[t].tf[i], lists[t].field_len[i], avg, 0.75f));
+        entries.push_back(orc_entry{(uint32_t)t, lists[t].docs.data(), ntf[t].data(), (uint64_t)lists[t].docs.size()});
+    }
+    std::vector<uint64_t> od(n_docs), td(50);
+    std::vector<float> os(n_docs), ts(50);
+    for (int thr : {0, 2}) {
+        p.use_threshold = thr != 0;
+        p.threshold = (uint32_t)thr;
+        const uint64_t on = orc_search_full_text(entries.data(), (uint32_t)entries.size(), T, (float)n_docs, 1.2f,
+                                                 thr != 0, (uint32_t)thr, od.data(), os.data());
+        const uint64_t tn = orc_top_n(od.data(), os.data(), on, 50, td.data(), ts.data());
+        TopResult r = store.search(refs, p);
+        CHECK(r.count == on && r.hits.size() == tn);
+        for (uint64_t i = 0; i < tn && i < r.hits.size(); ++i)
+            CHECK(r.hits[i].document_id == td[i] && bits(r.hits[i].score) == bits(ts[i]));
+    }
+    p.use_threshold = false;
+    // filters: host words == resident handle
+    DocBitmap bm(docs.back() + 1);
+    for (size_t i = 0; i < n_docs; ++i)
+        if (i % 4 != 1) bm.insert(docs[i]);
+    ResidentBitmap rbm(ctx, bm);
+    p.filter = bm;
+    TopResult fa = store.search(refs, p);
+    p.filter = rbm;
+    TopResult fb = store.search(refs, p);
+    CHECK(fa.count == fb.count && fa.hits.size() == fb.hits.size() && fa.count > 0);
+    for (size_t i = 0; i < fa.hits.size() && i < fb.hits.size(); ++i)
+        CHECK(fa.hits[i].document_id == fb.hits[i].document_id && bits(fa.hits[i].score) == bits(fb.hits[i].score) &&
+              bm.contains(fa.hits[i].document_id));
+    p.filter = FilterRef();
+    // append == rebuild (average length passed index-wide both times)
+    PostingsStore live(ctx);
+    live.build(std::vector<uint64_t>(docs.begin(), docs.begin() + 2000), {avg}, make_lists(0, 2000));
+    const uint32_t first = live.append(std::vector<uint64_t>(docs.begin() + 2000, docs.end()), {avg}, make_lists(2000, n_docs));
+    CHECK(first == T);
+    std::vector<TermRef> refs2;
+    for (uint32_t t = 0; t < T; ++t) {
+        refs2.push_back(TermRef{t, t, 1.0f});
+        refs2.push_back(TermRef{t, first + t, 1.0f});
+    }
+    TopResult a = store.search(refs, p), b = live.search(refs2, p);
+    CHECK(a.count == b.count && a.hits.size() == b.hits.size());
+    for (size_t i = 0; i < a.hits.size() && i < b.hits.size(); ++i)
+        CHECK(a.hits[i].document_id == b.hits[i].document_id && bits(a.hits[i].score) == bits(b.hits[i].score));
+    // hybrid: one call == vector search + epilogue + search_hybrid
+    EmbeddingFieldStorage field(ctx, Model::BGESmall);
+    std::normal_distribution<float> nd;
+    std::vector<float> q(384);
+    for (auto& x : q) x = nd(rng);
+    for (size_t i = 0; i < n_docs; ++i) {
+        std::vector<float> v(384);
+        const float w = (i % 40 == 0) ? 0.9f : 0.0f;
+        for (size_t c = 0; c < 384; ++c) v[c] = w * q[c] + (1.0f - w) * nd(rng);
+        field.insert(docs[i], {v});
+    }
+    VectorSearchParams vp;
+    vp.target = &q;
+    vp.similarity = 0.3f;
+    vp.limit = 20;
+    std::unordered_map<DocumentId, float> vmap;
+    field.search(vp, vmap);
+    CHECK(!vmap.empty());
+    TopResult h2 = store.search_hybrid(refs, p, vmap), h1 = store.hybrid_search(field, vp, refs, p);
+    CHECK(h1.count == h2.count && h1.hits.size() == h2.hits.size());
+    for (size_t i = 0; i < h1.hits.size() && i < h2.hits.size(); ++i)
+        CHECK(h1.hits[i].document_id == h2.hits[i].document_id && bits(h1.hits[i].score) == bits(h2.hits[i].score));
+}
+
+// SearchBatcher: 24 threads, one request each, answers identical to the direct wrapper call
+static void test_search_batcher(Context& ctx) {
+    EmbeddingFieldStorage field(ctx, Model::BGESmall, /*half_precision=*/true);
+    std::mt19937 rng(5);
+    std::normal_distribution<float> nd;
+    for (DocumentId d = 0; d < 4000; ++d) {
+        std::vector<float> v(384);
+        for (auto& x : v) x = nd(rng);
+        field.insert(d, {v});
+    }
+    const int T = 24;
+    std::vector<std::vector<float>> qs(T, std::vector<float>(384));
+    for (auto& q : qs)
+        for (auto& x : q) x = nd(rng);
+    std::vector<std::unordered_map<DocumentId, float>> direct(T), batched(T);
+    for (int i = 0; i < T; ++i) {
+        VectorSearchParams p;
+        p.target = &qs[i];
+        p.similarity = -1.0f;
+        p.limit = 10 + i;
+        field.search(p, direct[i]);
+    }
+    SearchBatcher batcher(field, 8, 500);
+    std::vector<std::thread> th;
+    for (int i = 0; i < T; ++i)
+        th.emplace_back([&, i] {
+            VectorSearchParams p;
+            p.target = &qs[i];
+            p.similarity = -1.0f;
+            p.limit = 10 + i;
+            batcher.search(p, batched[i]);
+        });
+    for (auto& t : th) t.join();
+    for (int i = 0; i < T; ++i) {
+        CHECK(direct[i].size() == batched[i].size() && direct[i].size() == (size_t)(10 + i));
+        for (auto& kv : direct[i]) CHECK(batched[i].count(kv.first) == 1 && bits(batched[i][kv.first]) == bits(kv.second));
+    }
+}
+
 int main() {
     Context ctx(0);
 #define RUN(t)                      \
@@ -230,6 +381,8 @@ int main() {
     RUN(test_embedding_field_search);
     RUN(test_normalize_and_combine_and_top_n);
     RUN(test_errors_surface_as_exceptions);
+    RUN(test_postings_store);
+    RUN(test_search_batcher);
     std::printf(g_failed ? "FAILED (%d checks)\n" : "ALL PASSED\n", g_failed);
     return g_failed ? 1 : 0;
 }

@@ -16,7 +16,7 @@ def build():
     subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
     csrc = ROOT / "oramacore_amd" / "csrc"
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", f"-I{ROOT / 'include'}", f"-I{ROOT / 'oracle'}", str(SRC), "-o", str(EXE),
-           f"-L{csrc}", "-lorama_hip", f"-L{ROOT / 'oracle'}", "-lorama_oracle",
+           f"-L{csrc}", "-lorama_hip", f"-L{ROOT / 'oracle'}", "-lorama_oracle", "-pthread",
            f"-Wl,-rpath,{csrc}", f"-Wl,-rpath,{ROOT / 'oracle'}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
