@@ -264,13 +264,19 @@ def main():
         out["latency_ms_p95_host_api"] = float(np.percentile(lat, 95))
         if not args.no_cpu_baseline and not f16:
             out["cpu_baseline"] = cpu_baseline(store, dim, n_total, k, args.cpu_sample_rows)
-    if rank == 0:
-        out["device"] = ctx.device_info()["name"]
-        print(json.dumps(out), flush=True)
+    device_name = ctx.device_info()["name"]
     store.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        out["device"] = device_name
+        # RCCL writes its version banner through C stdio (fully buffered when stdout is a pipe): push it out first
+        # so that the JSON line is the LAST line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -4,7 +4,9 @@
 HBM traffic follows MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 reports exactly 1/2 of the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled;
 WRITE_SIZE is uncalibrated and taken as is.  Usage:
-    python scripts/pmc_summary.py gpurun_out/pmc vec_scan_f32_kernel <alg_bytes_per_launch> > profiles/xxx.json
+    python scripts/pmc_summary.py gpurun_out/pmc vec_scan_f32_kernel <alg_bytes_per_launch> [mean] > profiles/xxx.json
+`mean`: launches of unequal size (K2's dense head + filter super-chunks) — use the per-launch MEAN instead of the
+median; <alg_bytes_per_launch> is then the mean algorithmic bytes per launch as bench.py reports it.
 """
 import csv
 import glob
@@ -13,7 +15,7 @@ import statistics
 import sys
 
 
-def main(root: str, kernel: str, alg_bytes: float) -> None:
+def main(root: str, kernel: str, alg_bytes: float, use_mean: bool = False) -> None:
     vals = {}
     dur = []
     for path in glob.glob(f"{root}/*/*counter_collection.csv"):
@@ -23,8 +25,8 @@ def main(root: str, kernel: str, alg_bytes: float) -> None:
                     continue
                 vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
                 dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-    med = {k: statistics.median(v) for k, v in vals.items()}
-    out = {"kernel": kernel, "launches_per_counter": {k: len(v) for k, v in vals.items()}, "median": med,
+    med = {k: (statistics.fmean(v) if use_mean else statistics.median(v)) for k, v in vals.items()}
+    out = {"kernel": kernel, "launches_per_counter": {k: len(v) for k, v in vals.items()}, "statistic": "mean" if use_mean else "median", "median": med,
            "median_duration_us_under_pmc": statistics.median(dur) / 1e3 if dur else None}
     if "FETCH_SIZE" in med:
         fetch = med["FETCH_SIZE"] * 1024 * 2  # gfx950: x2 for wide coalesced streaming reads
@@ -44,4 +46,4 @@ def main(root: str, kernel: str, alg_bytes: float) -> None:
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], float(sys.argv[3]))
+    main(sys.argv[1], sys.argv[2], float(sys.argv[3]), len(sys.argv) > 4 and sys.argv[4] == "mean")
