@@ -162,7 +162,8 @@ struct Scratch {
 
 namespace orama {
 struct ScanTuning {
-    int rows_per_wave = 4;  // rows each wave keeps in flight per iteration (1, 2, 4, 8)
+    int rows_per_wave = 8;  // rows each wave keeps in flight per iteration (1, 2, 4, 8); capped so that
+                            // rows x ceil(dim/256) <= 16 loads of 16 B per lane (768 dims: 4 rows, 384 dims: 8 rows)
     int blocks_per_cu = 2;  // persistent grid = CUs x this (measured best on MI355X: profiles/r01_sweep_ns_v1.json)
     int nontemporal = 1;    // stream the corpus with `nt` loads
 };

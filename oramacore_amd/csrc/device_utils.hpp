@@ -55,6 +55,76 @@ __device__ __forceinline__ float ordered_to_f32(uint32_t k) {
     return __builtin_bit_cast(float, u);
 }
 
+// ---------------------------------------------------------------- transposed wave reduction
+// ---- transposed wave reduction: QB per-lane partial sums -> one wave total per query, spread over the lanes.
+// wave_sum() reduces ONE value with the tree  pairs (xor 1) -> quads (xor 2) -> octets -> rows of 16 ->
+// (row0 + row1) + (row2 + row3).  Reducing QB values that way costs QB x (4 DPP adds + 4 readlanes + 3 adds); here
+// every level that pairs lanes also halves the values a lane is responsible for (a reduce-scatter), so the QB
+// values cost ~QB + log(QB) + 6 adds in total.  The summation TREE is the same one (float add is commutative, so it
+// does not matter which lane of a pair evaluates a node): results are bit-identical to wave_sum().
+// After the call lane l holds the total of query  qidx(l) = 4*(l&1) + 2*((l>>1)&1) + ((l>>2)&1)  (QB = 8)
+// resp.  qidx(l) = 2*(l&1) + ((l>>1)&1)  (QB = 4),  l&1  (QB = 2).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// value of lane (l ^ 4) inside its row of 16: row_shl:4 feeds banks 0 and 2, row_shr:4 banks 1 and 3
+__device__ __forceinline__ float dpp_xor4(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xF, 0x5, false);
+    t = __builtin_amdgcn_update_dpp(t, __builtin_bit_cast(int, v), 0x114, 0xF, 0xA, false);
+    return __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float finish_rows(float e) {
+    e = e + dpp_mov<0x128>(e);                 // row_ror:8 = lane ^ 8: the two octets of a row
+    e = e + __shfl_xor(e, 16, 64);             // row0 + row1 | row2 + row3
+    e = e + __shfl_xor(e, 32, 64);             // (row0 + row1) + (row2 + row3)
+    return e;
+}
+template <int QB>
+__device__ __forceinline__ float wave_sum_scatter(const float (&a)[QB], int lane) {
+    const bool p0 = lane & 1, p1 = lane & 2, p2 = lane & 4;
+    if constexpr (QB == 8) {
+        float b[4], c[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float keep = p0 ? a[4 + j] : a[j], send = p0 ? a[j] : a[4 + j];
+            b[j] = keep + dpp_mov<0xB1>(send);  // quad_perm [1,0,3,2] = lane ^ 1
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float keep = p1 ? b[2 + j] : b[j], send = p1 ? b[j] : b[2 + j];
+            c[j] = keep + dpp_mov<0x4E>(send);  // quad_perm [2,3,0,1] = lane ^ 2
+        }
+        const float keep = p2 ? c[1] : c[0], send = p2 ? c[0] : c[1];
+        return finish_rows(keep + dpp_xor4(send));
+    } else if constexpr (QB == 2) {
+        const float keep = p0 ? a[1] : a[0], send = p0 ? a[0] : a[1];
+        float c = keep + dpp_mov<0xB1>(send);
+        c = c + dpp_mov<0x4E>(c);
+        (void)p1;
+        (void)p2;
+        return finish_rows(c + dpp_xor4(c));
+    } else {
+        static_assert(QB == 4, "QB must be 2, 4 or 8");
+        float b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float keep = p0 ? a[2 + j] : a[j], send = p0 ? a[j] : a[2 + j];
+            b[j] = keep + dpp_mov<0xB1>(send);
+        }
+        const float keep = p1 ? b[1] : b[0], send = p1 ? b[0] : b[1];
+        const float c = keep + dpp_mov<0x4E>(send);
+        (void)p2;
+        return finish_rows(c + dpp_xor4(c));
+    }
+}
+template <int QB>
+__device__ __forceinline__ int lane_query(int lane) {
+    if constexpr (QB == 8) return 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
+    if constexpr (QB == 2) return lane & 1;
+    return 2 * (lane & 1) + ((lane >> 1) & 1);
+}
+
 // ---------------------------------------------------------------- per-wave running top-k (k <= 128)
 // 64-bit keys, "larger is better", 0 = empty slot.  The list lives in REGISTERS: lane l holds entries l and
 // l + 64.  `thr` (wave-uniform) is the smallest kept key once the list is full, so the hot-path test is one

@@ -106,46 +106,73 @@ __global__ __launch_bounds__(kScanThreads) void vec_scan_f32_kernel(ScanArgs a) 
                 x[r][c] = ok ? load16<NT>(p + c * kWave) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        float mine = 0.0f;
+        // per-lane partial dot products of the ROWS rows
+        float acc[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
-            float acc = 0.0f;
+            acc[r] = 0.0f;
 #pragma unroll
             for (int c = 0; c < NCHUNK; ++c) {
                 if (METRIC == ORAMA_METRIC_COSINE) {
-                    acc = fmaf(x[r][c].x, qv[c].x, acc);
-                    acc = fmaf(x[r][c].y, qv[c].y, acc);
-                    acc = fmaf(x[r][c].z, qv[c].z, acc);
-                    acc = fmaf(x[r][c].w, qv[c].w, acc);
+                    acc[r] = fmaf(x[r][c].x, qv[c].x, acc[r]);
+                    acc[r] = fmaf(x[r][c].y, qv[c].y, acc[r]);
+                    acc[r] = fmaf(x[r][c].z, qv[c].z, acc[r]);
+                    acc[r] = fmaf(x[r][c].w, qv[c].w, acc[r]);
                 } else {
                     float t0 = x[r][c].x - qv[c].x, t1 = x[r][c].y - qv[c].y;
                     float t2 = x[r][c].z - qv[c].z, t3 = x[r][c].w - qv[c].w;
-                    acc = fmaf(t0, t0, acc);
-                    acc = fmaf(t1, t1, acc);
-                    acc = fmaf(t2, t2, acc);
-                    acc = fmaf(t3, t3, acc);
+                    acc[r] = fmaf(t0, t0, acc[r]);
+                    acc[r] = fmaf(t1, t1, acc[r]);
+                    acc[r] = fmaf(t2, t2, acc[r]);
+                    acc[r] = fmaf(t3, t3, acc[r]);
                 }
-            }
-            const float tot = wave_sum(acc);
-            float dist;
-            if (METRIC == ORAMA_METRIC_COSINE) {
-                const float inv = live[r] ? a.inv_norm[r0 + r] : 0.0f;
-                dist = 1.0f - tot * (inv * qscale);
-            } else {
-                dist = tot;
-            }
-            if (!live[r]) dist = __builtin_nanf("");
-            if (fused) {
-                if (live[r] && dist == dist) {  // smaller distance wins, then lower row: key = ~ordered(d) << 32 | ~row
-                    const unsigned long long key =
-                        ((unsigned long long)(~f32_to_ordered(dist)) << 32) | (unsigned long long)(uint32_t)(~(uint32_t)(r0 + r));
-                    if (best.count < a.topk || key > best.thr) best.insert(key, a.topk, lane);
-                }
-            } else if (lane == r) {
-                mine = dist;
             }
         }
-        if (!fused && lane < ROWS && r0 + lane < a.n) a.out_dist[r0 + lane] = mine;
+        if constexpr (!fused && ROWS >= 2) {
+            // ONE transposed reduction for the ROWS rows (same summation tree as wave_sum, see device_utils.hpp):
+            // lane l ends up with the total of row r0 + lane_query<ROWS>(l); lanes 0..ROWS-1 finish their row
+            const float tot = wave_sum_scatter<ROWS>(acc, lane);
+            const int my_r = lane_query<ROWS>(lane);
+            bool my_live = false;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+                if (my_r == r) my_live = live[r];
+            if (lane < ROWS) {
+                float dist;
+                if (METRIC == ORAMA_METRIC_COSINE) {
+                    const float inv = my_live ? a.inv_norm[r0 + my_r] : 0.0f;
+                    dist = 1.0f - tot * (inv * qscale);
+                } else {
+                    dist = tot;
+                }
+                if (!my_live) dist = __builtin_nanf("");
+                if (r0 + my_r < a.n) a.out_dist[r0 + my_r] = dist;
+            }
+        } else {
+            float mine = 0.0f;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const float tot = wave_sum(acc[r]);
+                float dist;
+                if (METRIC == ORAMA_METRIC_COSINE) {
+                    const float inv = live[r] ? a.inv_norm[r0 + r] : 0.0f;
+                    dist = 1.0f - tot * (inv * qscale);
+                } else {
+                    dist = tot;
+                }
+                if (!live[r]) dist = __builtin_nanf("");
+                if (fused) {
+                    if (live[r] && dist == dist) {  // smaller distance wins, then lower row: key = ~ordered(d) << 32 | ~row
+                        const unsigned long long key =
+                            ((unsigned long long)(~f32_to_ordered(dist)) << 32) | (unsigned long long)(uint32_t)(~(uint32_t)(r0 + r));
+                        if (best.count < a.topk || key > best.thr) best.insert(key, a.topk, lane);
+                    }
+                } else if (lane == r) {
+                    mine = dist;
+                }
+            }
+            if (!fused && lane < ROWS && r0 + lane < a.n) a.out_dist[r0 + lane] = mine;
+        }
     }
     if (fused) {
         unsigned long long* out = a.wave_lists + (uint64_t)wave * kWaveListKeys;
@@ -373,7 +400,8 @@ uint32_t vec_scan_f32_waves(orama_ctx* ctx, const ScanArgs& a) {
     return a.n ? scan_geom(ctx, a).blocks * kWavesPerBlock : 0;
 }
 
-int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a, hipStream_t stream) {
+int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a_in, hipStream_t stream) {
+    const ScanArgs& a = a_in;
     ORAMA_REQUIRE(a.corpus && a.query && a.dim > 0, "vec_scan: bad arguments");
     ORAMA_REQUIRE(a.out_dist || (a.wave_lists && a.topk >= 1 && a.topk <= kWaveListKeys), "vec_scan: no output mode");
     ORAMA_REQUIRE(a.metric != ORAMA_METRIC_COSINE || a.inv_norm, "vec_scan: cosine needs inv_norm");
