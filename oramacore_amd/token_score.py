@@ -126,23 +126,46 @@ class Index:
             self._post.set_omc(self.omc)
         self._field_order = field_ids
 
-    def lookup(self, field_id: int, token: str, exact: bool) -> list[int]:
-        """Dictionary step of collect_contributions: exact term, or (non-exact) every term with the token as
-        prefix — evidenced by src/tests/fulltext_search.rs:603-753 ("christoph" matches "christopher")."""
+    def lookup(self, field_id: int, token: str, exact: bool, tolerance: int | None = None) -> list[int]:
+        """Dictionary step of collect_contributions (host side, third-party in the reference): the exact term, or
+        (non-exact) every term with the token as prefix — src/tests/fulltext_search.rs:603-753 ("christoph" matches
+        "christopher") — plus, with `tolerance`, every term within that Levenshtein distance of the token —
+        src/tests/fulltext_search.rs:956-1018 ("Mxin" finds "Main Street" with tolerance 1).  List order: dictionary
+        (lexicographic) order of the terms."""
         if exact:
             l = self._lists.get((field_id, token))
             return [] if l is None else [l]
         import bisect
 
         terms = self._terms.get(field_id, [])
+        hit = set()
         i = bisect.bisect_left(terms, token)
-        out = []
         while i < len(terms) and terms[i].startswith(token):
-            l = self._lists.get((field_id, terms[i]))
+            hit.add(terms[i])
+            i += 1
+        if tolerance:
+            for t in terms:
+                if t not in hit and abs(len(t) - len(token)) <= tolerance and _levenshtein_le(t, token, tolerance):
+                    hit.add(t)
+        out = []
+        for t in sorted(hit):
+            l = self._lists.get((field_id, t))
             if l is not None:
                 out.append(l)
-            i += 1
         return out
+
+
+def _levenshtein_le(a: str, b: str, k: int) -> bool:
+    """Levenshtein(a, b) <= k (plain DP; dictionary terms are short)."""
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i] + [0] * len(b)
+        for j, cb in enumerate(b, 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb))
+        if min(cur) > k:
+            return False
+        prev = cur
+    return prev[-1] <= k
 
 
 @dataclass
@@ -167,23 +190,21 @@ class TokenScoreContext:
         out = [t for t, _ in toks] if exact else [x for t, s in toks for x in ((t,) if s is None else (t, s))]
         return out or [""]
 
-    def _refs(self, tokens, properties, boost, exact):
+    def _refs(self, tokens, properties, boost, exact, tolerance=None):
         fields = sorted(self.index.string_fields) if properties is None else sorted(
             f for f in properties if f in self.index.string_fields)  # canonical order: ascending FieldId
         refs = []
         for ti, tok in enumerate(tokens):
             for fid in fields:
-                for l in self.index.lookup(fid, tok, exact):
+                for l in self.index.lookup(fid, tok, exact, tolerance):
                     refs.append((ti, l, float(boost.get(fid, 1.0))))
         return refs
 
     # token_score.rs:186-303 (+ OMC, count, top-(limit+offset) fused)
     def search_full_text(self, mode: FulltextMode, params: TokenScoreParams, vector: dict | None = None):
-        if mode.tolerance not in (None, 0):
-            raise NotImplementedError("Levenshtein expansion lives in the third-party dictionary (SURVEY §8f rank 4)")
         tokens = self._tokens(mode.term, mode.exact)
         thr = None if mode.threshold is None else threshold_tokens(len(tokens), mode.threshold)
-        refs = self._refs(tokens, params.properties, params.boost, mode.exact)
+        refs = self._refs(tokens, params.properties, params.boost, mode.exact, mode.tolerance)
         return self.index._post.search(refs, len(tokens), float(self.index.document_count),
                                        params.limit + params.offset, thr, allow=params.filtered_doc_ids,
                                        apply_omc=bool(self.index.omc), b=B_DEFAULT, k=K1_DEFAULT, vector=vector)

@@ -236,3 +236,40 @@ def test_fused_hybrid_search_equals_two_call_path(ctx):
                     assert f_cnt == e_cnt and f_ids.tolist() == e_ids.tolist(), (model, sim, limit)
                     assert np.array_equal(f_sc.view(np.uint32), e_sc.view(np.uint32))
         ef.close()
+
+
+def test_fulltext_tolerance(ctx):
+    """src/tests/fulltext_search.rs:956-1018 — "Mxin" / "Msple" with tolerance 1 find exactly one document each."""
+    idx = make_index(ctx, {1: {"text": "Main Street"}, 2: {"text": "Maple Avenue"}, 3: {"text": "Another Street"}})
+    tsc = TokenScoreContext(idx)
+    hits, count = tsc.execute(TokenScoreParams(mode=FulltextMode("Mxin", tolerance=1)))
+    assert count == 1 and [h[0] for h in hits] == [1]
+    hits, count = tsc.execute(TokenScoreParams(mode=FulltextMode("Msple", tolerance=1)))
+    assert count == 1 and [h[0] for h in hits] == [2]
+    hits, count = tsc.execute(TokenScoreParams(mode=FulltextMode("Mxin")))  # no tolerance: nothing
+    assert count == 0 and hits == []
+    hits, count = tsc.execute(TokenScoreParams(mode=FulltextMode("street", tolerance=1)))
+    assert count == 2 and sorted(h[0] for h in hits) == [1, 3]
+
+
+def test_boost_ratio_bounds(ctx):
+    """src/tests/boost_integration.rs:370-447 in spirit: raising a field's boost raises the score of documents
+    matching in that field monotonically, sub-linearly (BM25 saturation k = 1.2), and leaves the ordering among
+    them intact; results equal the oracle bit for bit."""
+    docs = {i: {"title": "gpu search " + "pad " * (i % 7), "body": "search engine " + "gpu " * (i % 3)} for i in range(60)}
+    idx = make_index(ctx, docs, fields=("title", "body"))
+    tsc = TokenScoreContext(idx)
+    prev = None
+    for boost in (1.0, 2.0, 4.0):
+        hits, count = tsc.execute(TokenScoreParams(mode=FulltextMode("gpu"), boost={0: boost}, limit=60))
+        od, os_ = oracle_fulltext(idx, ["gpu"], exact=False, boost={0: boost})
+        td, ts = orc.top_n(od, os_, 60)
+        assert count == len(od) and [h[0] for h in hits] == td.tolist()
+        assert np.array_equal(np.array([h[1] for h in hits], dtype=np.float32).view(np.uint32), ts.view(np.uint32))
+        sc = dict(hits)
+        if prev is not None:
+            for d in sc:
+                assert sc[d] > prev[d]                       # monotone
+                assert sc[d] / prev[d] < 2.0                 # saturating: doubling the boost less than doubles the score
+            assert min(sc[d] / prev[d] for d in sc) > 1.05
+        prev = sc
