@@ -348,6 +348,14 @@ int orama_hybrid_combine(orama_ctx* ctx, const uint64_t* vec_doc, const float* v
                          uint64_t n_ft, uint32_t top_k, uint64_t* out_ids, float* out_scores,
                          uint32_t* out_n, uint64_t* out_count);
 
+/* Reciprocal-rank fusion — an EXTRA next to the parity path above (the reference merges by min-max + sum; RRF is
+ * what north_star names).  Each list is cut to its best `depth` entries (score desc, DocumentId asc; ranks from 1)
+ * and score[doc] = sum 1 / (rrf_k + rank) over the lists holding doc (f32, full-text term first).  out_count =
+ * documents in the union of the two cut lists.  rrf_k is conventionally 60. */
+int orama_hybrid_rrf(orama_ctx* ctx, const uint64_t* vec_doc, const float* vec_score, uint64_t n_vec,
+                     const uint64_t* ft_doc, const float* ft_score, uint64_t n_ft, float rrf_k, uint32_t depth,
+                     uint32_t top_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count);
+
 /* ------------------------------------------------------------------ top-n
  * top_n — sort.rs:260-279 over an explicit (doc, score) list: NaN dropped, score desc, doc asc. */
 int orama_top_n(orama_ctx* ctx, const uint64_t* doc, const float* score, uint64_t n, uint32_t top_k,

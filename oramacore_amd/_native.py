@@ -163,6 +163,8 @@ def _declare(lib: C.CDLL) -> None:
         "orama_post_merge_blocks_device": [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp],
         "orama_post_set_avg_len": [vp, vp, C.c_uint32],
         "orama_hybrid_combine": [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u32p, u64p],
+        "orama_hybrid_rrf": [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, vp, vp, u32p,
+                             u64p],
         "orama_top_n": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u32p],
     }
     for name, argtypes in sig.items():

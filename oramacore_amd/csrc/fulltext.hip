@@ -1260,4 +1260,49 @@ int orama_top_n(orama_ctx* ctx, const uint64_t* doc, const float* score, uint64_
     return ORAMA_OK;
 }
 
+// Reciprocal-rank fusion — EXTRA, not the parity path: the reference merges by min-max + sum
+// (normalize_and_combine); north_star names RRF, so it is offered next to it.  Both lists are cut to their best
+// `depth` entries with K4 (score desc, DocumentId asc), ranks start at 1, score[doc] = sum over the lists holding
+// doc of 1 / (rrf_k + rank) in f32 — the full-text term first, then the vector term, like the reference's combine
+// adds vector' onto fulltext'.  count = documents in the union of the two cut lists.
+int orama_hybrid_rrf(orama_ctx* ctx, const uint64_t* vec_doc, const float* vec_score, uint64_t n_vec,
+                     const uint64_t* ft_doc, const float* ft_score, uint64_t n_ft, float rrf_k, uint32_t depth,
+                     uint32_t top_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count) {
+    ORAMA_REQUIRE(ctx && out_n, "null argument");
+    *out_n = 0;
+    if (out_count) *out_count = 0;
+    ORAMA_REQUIRE(depth >= 1 && depth <= kSelectMaxK, "rrf depth %u outside [1, %u]", depth, kSelectMaxK);
+    ORAMA_REQUIRE(top_k == 0 || (out_ids && out_scores), "null output");
+    ORAMA_REQUIRE(rrf_k >= 0.0f, "rrf_k must be >= 0");
+    std::vector<uint64_t> fd(depth), vd(depth);
+    std::vector<float> fs(depth), vs(depth);
+    uint32_t nf = 0, nv = 0;
+    ORAMA_TRY(orama_top_n(ctx, ft_doc, ft_score, n_ft, depth, fd.data(), fs.data(), &nf));
+    ORAMA_TRY(orama_top_n(ctx, vec_doc, vec_score, n_vec, depth, vd.data(), vs.data(), &nv));
+    std::vector<std::pair<uint64_t, float>> fused;  // (doc, score), full-text order first
+    fused.reserve((size_t)nf + nv);
+    for (uint32_t r = 0; r < nf; ++r) fused.emplace_back(fd[r], 0.0f + 1.0f / (rrf_k + (float)(r + 1)));
+    std::vector<std::pair<uint64_t, uint32_t>> pos;  // doc -> index in fused
+    pos.reserve(nf);
+    for (uint32_t r = 0; r < nf; ++r) pos.emplace_back(fd[r], r);
+    std::sort(pos.begin(), pos.end());
+    for (uint32_t r = 0; r < nv; ++r) {
+        const float term = 1.0f / (rrf_k + (float)(r + 1));
+        auto it = std::lower_bound(pos.begin(), pos.end(), std::make_pair(vd[r], 0u));
+        if (it != pos.end() && it->first == vd[r]) fused[it->second].second = fused[it->second].second + term;
+        else fused.emplace_back(vd[r], 0.0f + term);
+    }
+    if (out_count) *out_count = fused.size();
+    std::sort(fused.begin(), fused.end(), [](const std::pair<uint64_t, float>& a, const std::pair<uint64_t, float>& b) {
+        return a.second != b.second ? a.second > b.second : a.first < b.first;
+    });
+    const uint32_t n = (uint32_t)std::min<size_t>(top_k, fused.size());
+    for (uint32_t i = 0; i < n; ++i) {
+        out_ids[i] = fused[i].first;
+        out_scores[i] = fused[i].second;
+    }
+    *out_n = n;
+    return ORAMA_OK;
+}
+
 }  // extern "C"

@@ -96,6 +96,21 @@ def hybrid_combine(ctx: Context, vector: dict, fulltext: dict, top_k: int):
     return out_ids[: out_n.value], out_sc[: out_n.value], out_count.value
 
 
+def hybrid_rrf(ctx: Context, vector: dict, fulltext: dict, top_k: int, rrf_k: float = 60.0, depth: int = 1000):
+    """Reciprocal-rank fusion (extra; the parity path is hybrid_combine). Returns (ids, scores, count)."""
+    lib = N.load()
+    v_doc, v_sc = _u64(list(vector.keys())), _f32(list(vector.values()))
+    f_doc, f_sc = _u64(list(fulltext.keys())), _f32(list(fulltext.values()))
+    out_ids = np.zeros(max(top_k, 1), dtype=np.uint64)
+    out_sc = np.zeros(max(top_k, 1), dtype=np.float32)
+    out_n = C.c_uint32()
+    out_count = C.c_uint64()
+    N.check(lib.orama_hybrid_rrf(ctx.handle, v_doc.ctypes.data, v_sc.ctypes.data, v_doc.shape[0], f_doc.ctypes.data,
+                                 f_sc.ctypes.data, f_doc.shape[0], float(rrf_k), int(depth), top_k,
+                                 out_ids.ctypes.data, out_sc.ctypes.data, C.byref(out_n), C.byref(out_count)))
+    return out_ids[: out_n.value], out_sc[: out_n.value], out_count.value
+
+
 def top_n(ctx: Context, token_scores: dict | tuple, n: int):
     """sort.rs:260-279 over a {DocumentId: score} map (or a (docs, scores) pair)."""
     lib = N.load()

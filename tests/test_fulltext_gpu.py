@@ -272,3 +272,30 @@ def test_hybrid_resident(ctx, synth):
             assert ids.tolist() == td.tolist(), (ci, omc)
             assert np.array_equal(bits(sc), bits(ts))
     store.close()
+
+
+def test_rrf_extra(ctx):
+    """orama_hybrid_rrf (extra next to the min-max parity path): ranks from the K4 order (score desc, doc asc),
+    1/(k + rank) in f32, full-text term first — against a numpy restatement, bit for bit."""
+    rng = np.random.default_rng(17)
+    ft_docs = rng.choice(5000, size=1200, replace=False)
+    ft_map = {int(d): float(np.float32(s)) for d, s in zip(ft_docs, rng.uniform(0, 9, size=1200).round(1))}  # many ties
+    vec_docs = np.concatenate([rng.choice(ft_docs, size=30, replace=False), np.arange(6000, 6040)])
+    vec_map = {int(d): float(np.float32(s)) for d, s in zip(vec_docs, rng.uniform(0.7, 1.0, size=len(vec_docs)).round(2))}
+    for depth, rrf_k, top_k in ((1000, 60.0, 50), (100, 1.0, 4000), (20, 60.0, 10)):
+        ids, sc, count = ft.hybrid_rrf(ctx, vec_map, ft_map, top_k, rrf_k=rrf_k, depth=depth)
+
+        def ranked(m):
+            return [d for d, _ in sorted(m.items(), key=lambda kv: (-np.float32(kv[1]), kv[0]))][:depth]
+
+        fused = {}
+        for r, d in enumerate(ranked(ft_map)):
+            fused[d] = F(F(0.0) + F(1.0) / F(F(rrf_k) + F(r + 1)))
+        for r, d in enumerate(ranked(vec_map)):
+            fused[d] = F(fused.get(d, F(0.0)) + F(1.0) / F(F(rrf_k) + F(r + 1)))
+        exp = sorted(fused.items(), key=lambda kv: (-kv[1], kv[0]))[:top_k]
+        assert count == len(fused)
+        assert ids.tolist() == [d for d, _ in exp]
+        assert np.array_equal(bits(sc), bits([s for _, s in exp]))
+    ids, sc, count = ft.hybrid_rrf(ctx, {}, {7: 1.0}, 5)
+    assert ids.tolist() == [7] and count == 1
