@@ -143,6 +143,7 @@ struct Scratch {
     DevBuf sel_keys;   // collected composite keys
     DevBuf out_idx, out_val, out_n, out_ids;
     DevBuf bitmap;     // uploaded allow bitmap
+    DevBuf f16_bfrag;  // K2c: fp16 query fragments + 1/|q| of the current wide batch
     DevBuf misc0, misc1, misc2, misc3, misc4, misc5;
     PinnedBuf h_in, h_out, h_misc;
     // BM25 accumulators: epoch-stamped, zeroed only when (re)allocated (see bm25_kernels.hip)
@@ -178,6 +179,7 @@ struct orama_ctx {
     // bitonic reduction of the wave lists costs more than the dense radix select — so it is off by default.
     int fused_topk = 0;
     int f32_multi = 1;   // K1b: fp32 batches of 2..8 queries share one corpus pass (ORAMA_F32_MULTI=0 disables)
+    int f16_wide = 1;    // K2c: fp16 batches of 65..256 queries share one corpus pass (ORAMA_F16_WIDE=0: 64 per pass)
     int f16_kc = 8, f16_nbuf = 3;   // K2 register ring: k-steps per chunk, chunks (ORAMA_F16_KC / ORAMA_F16_NBUF)
     int compute_units = 0;
     uint64_t hbm_bytes = 0;

@@ -215,6 +215,7 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
     c->scan_tuning = orama::default_scan_tuning();
     if (const char* e = std::getenv("ORAMA_FUSED_TOPK")) c->fused_topk = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F32_MULTI")) c->f32_multi = std::atoi(e);
+    if (const char* e = std::getenv("ORAMA_F16_WIDE")) c->f16_wide = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_KC")) c->f16_kc = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_NBUF")) c->f16_nbuf = std::atoi(e);
     c->device = device_ordinal;

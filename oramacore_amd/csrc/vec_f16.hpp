@@ -57,6 +57,15 @@ struct F16ScanArgs {
 // K2. Algorithmic HBM traffic: (row_end - row_begin) * kpad * 2 bytes per launch (serves all q queries).
 int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream);
 
+// K2c (vec_f16_wide.hip): the same scan for 65..256 queries per corpus pass — a register-blocked GEMM (block tile
+// 256 rows x 256 queries, corpus and query fragments staged through an LDS double buffer).  `d_query_frags`
+// (f16_wide_query_bytes(dim) bytes of HBM scratch) receives the fp16 query fragments + 1/|q| when `prepare` is set
+// (first launch of a batch); later launches of the same batch reuse them.  Same F16ScanArgs semantics, a.q <= 256.
+constexpr uint32_t kF16WideMaxQ = 256;
+size_t f16_wide_query_bytes(uint32_t dim);
+int launch_vec_scan_f16_wide(orama_ctx* ctx, const F16ScanArgs& a, void* d_query_frags, bool prepare,
+                             hipStream_t stream);
+
 // tau[j] = k-th best distance of list j when the list is full, else +inf; and seed the candidate lists
 // with the current best entries: cand[j][0..n_j) = (dist, row), cand_count[j] = n_j.
 int launch_f16_seed_candidates(const float* best_dist, const uint32_t* best_row, const uint32_t* best_n,

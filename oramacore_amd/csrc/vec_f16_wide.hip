@@ -1,0 +1,340 @@
+// vec_f16_wide.hip — K2c: the fp16 scan for WIDE query batches (65..256 queries per corpus pass; config C5).
+//
+// K2 keeps the whole query batch as B fragments in LDS (<= 64 queries fit) and feeds one A fragment into two
+// MFMAs.  At 256 queries the batch no longer fits LDS (384 KB) and one pass per 64 queries re-reads the corpus
+// four times, so this kernel is a register-blocked GEMM instead:
+//
+//   workgroup (512 threads, 8 waves, one per CU, persistent) : block tile = 256 rows x 256 queries
+//   wave w                                                    : 64 rows x 128 queries = 2 x 4 MFMA tiles,
+//                                                               128 accumulator VGPRs, never spilled to memory
+//   K loop                                                    : stages of KS = 3 k-steps; per stage the workgroup
+//       moves 24 KB of corpus fragments (HBM) and 24 KB of query fragments (L2-resident, prepared once per launch)
+//       straight into a 3-deep LDS ring with global_load_lds_dwordx4 (no staging registers); the DMA of stage g+2
+//       is issued before the MFMAs of stage g, one barrier per stage
+//   per k-step and wave : 2 A + 4 B fragment reads (ds_read_b128, lane-linear) feed 8 MFMAs (0.75 KB of LDS
+//                         traffic per v_mfma_f32_32x32x16_f16 instead of 1 KB)
+//
+// The corpus is read from HBM exactly once per 256 queries; flops = 2·256·rows·kpad (AI = 256 flop/B against a
+// ridge of ~312): the kernel sits at the corner of the roofline — HBM, MFMA and LDS bandwidth are all within 2x of
+// their limits.  Epilogue (1 - s/|x||q|, tombstones, allow-bit, threshold filter / dense store) is K2's, applied
+// to the accumulator registers; the accumulation order over k is K2's too, so a wide batch returns bit-identical
+// distances to solo queries.
+#include "vec_f16.hpp"
+
+#include "device_utils.hpp"
+
+namespace orama {
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWB = 512;                    // threads per workgroup
+constexpr int KS = 3;                       // k-steps per stage
+constexpr int NBUF = 3;                     // LDS ring: stage g lives in buffer g % 3, two stages in flight
+constexpr int kOpBytes = 8 * KS * 1024;     // one operand of a stage: 8 row (or query) tiles x KS fragments = 24 KiB
+constexpr int kStageBytes = 2 * kOpBytes;   // A | B
+constexpr int kPieces = kOpBytes / 16 / kWB;  // 16-byte pieces per thread and operand per stage (= 3)
+constexpr int kMetaOff = NBUF * kStageBytes;  // 1/|x| of the block tile's 256 rows + 8 tombstone words
+constexpr int kLdsBytes = kMetaOff + 256 * 4 + 8 * 4;
+
+// s_waitcnt immediates (gfx9 encoding): vmcnt only, expcnt / lgkmcnt untouched
+constexpr int kWaitVm0 = 0x0F70;
+constexpr int kWaitVmOneStage = 0x0F70 | (2 * kPieces);  // leave the newest stage (2 * kPieces loads) in flight
+
+// 16 bytes per lane, global -> LDS, asynchronous (completion is counted by vmcnt): lane l's data lands at LDS
+// address m0 + 16 l.  Issued through inline asm on purpose: for the builtin the compiler's wait-count pass assumes
+// any later LDS read may alias the DMA and drains vmcnt(0) before every ds_read — which serialises the ring.  Here
+// the ring discipline guarantees disjoint buffers and the waits are explicit (kWaitVm*).
+template <bool NT>
+__device__ __forceinline__ void dma16(uint64_t saddr_uniform, uint32_t voff, uint32_t lds_addr_uniform) {
+    if constexpr (NT)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+                     :
+                     : "v"(voff), "s"(saddr_uniform), "s"(lds_addr_uniform)
+                     : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(voff), "s"(saddr_uniform), "s"(lds_addr_uniform)
+                     : "memory", "m0");
+}
+
+// queries (f32) -> fp16 B fragments [query tile 0..7][k-step][lane][8 halves] + 1/|q| of the rounded query
+__global__ __launch_bounds__(256) void f16_prepare_queries_kernel(const float* __restrict__ queries, uint32_t q,
+                                                                  uint32_t dim, uint32_t ksteps,
+                                                                  char* __restrict__ bfrag, float* __restrict__ qinv) {
+    const uint32_t frag_total = 8u * ksteps * 64u;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < frag_total; idx += gridDim.x * blockDim.x) {
+        const uint32_t qt = idx / (ksteps * 64u);
+        const uint32_t rem = idx - qt * (ksteps * 64u);
+        const uint32_t ks = rem >> 6, l = rem & 63;
+        const uint32_t j = qt * 32 + (l & 31);
+        const uint32_t k0 = ks * 16 + (l >> 5) * 8;
+        h8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t k = k0 + e;
+            const float x = (j < q && k < dim) ? queries[(size_t)j * dim + k] : 0.0f;
+            v[e] = (_Float16)x;
+        }
+        *reinterpret_cast<h8*>(bfrag + (size_t)idx * 16) = v;
+    }
+    // |q| of the fp16-rounded query, f32 accumulation in k order (the order K2 uses)
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < 256) {
+        float ss = 0.0f;
+        if (j < q) {
+            for (uint32_t k = 0; k < ksteps * 16; ++k) {
+                const float x = k < dim ? (float)(_Float16)queries[(size_t)j * dim + k] : 0.0f;
+                ss = fmaf(x, x, ss);
+            }
+        }
+        qinv[j] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, const char* __restrict__ bfrag,
+                                                                const float* __restrict__ qinv, uint32_t ksteps,
+                                                                uint64_t tile_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // [NBUF][A | B] + tile metadata
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = uniform_u32(tid >> 6);
+    const int wr = w & 3;   // row group: row tiles 2wr, 2wr+1 of the block tile
+    const int wq = w >> 2;  // query group: query tiles 4wq .. 4wq+3
+
+    const uint64_t t_first = a.row_begin >> 5;
+    const uint64_t t_end = (a.row_end + 31) >> 5;            // row tiles [t_first, t_end)
+    const uint64_t n_bt = (t_end - t_first + 7) >> 3;        // block tiles of 8 row tiles
+    if (blockIdx.x >= n_bt) return;
+    const uint64_t my_bt = (n_bt - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const uint32_t S = ksteps / KS;                          // stages per block tile
+    const uint64_t total = my_bt * S;
+    const char* base = reinterpret_cast<const char*>(a.tiled);
+    float* inv_lds = reinterpret_cast<float*>(lds + kMetaOff);
+    uint32_t* dead_lds = reinterpret_cast<uint32_t*>(lds + kMetaOff + 256 * 4);
+
+    // ---- stage loader: global -> LDS DMA (global_load_lds_dwordx4), no staging registers.  A wave moves 64
+    // consecutive 16-byte pieces per instruction; piece p = (tile p / (KS*64), k-step (p / 64) % KS, lane p % 64),
+    // LDS offset 16 p — the fragment layout itself.
+    // All addresses are wave-uniform except the lane's 16-byte slot: scalar base (running, no multiplies in the
+    // loop) + one constant VGPR offset.
+    uint64_t ld_bt = blockIdx.x;  // cursor of the NEXT stage to load: (block tile, stage)
+    uint32_t ld_s = 0;
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const uint32_t vlane = (uint32_t)lane * 16;
+    uint32_t piece_lds[kPieces];   // LDS offset of the wave's i-th piece group inside an operand
+    uint64_t piece_a[kPieces];     // its corpus offset inside a block tile at k-step 0
+    uint64_t piece_b[kPieces];     // its address in the query fragments at k-step 0
+    uint32_t piece_tl[kPieces];
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+        const uint32_t p0 = (uint32_t)w * 64 + (uint32_t)kWB * i;  // wave-uniform first piece
+        const uint32_t tl = p0 / (KS * 64), ks = (p0 >> 6) % KS;
+        piece_tl[i] = tl;
+        piece_lds[i] = p0 * 16;
+        piece_a[i] = (uint64_t)tl * tile_bytes + (uint64_t)ks * 1024;
+        piece_b[i] = (uint64_t)(uintptr_t)bfrag + ((uint64_t)tl * ksteps + ks) * 1024;
+    }
+    const uint64_t bt_stride = (uint64_t)gridDim.x * 8 * tile_bytes;
+    uint64_t ld_base = (uint64_t)(uintptr_t)base + (t_first + (uint64_t)blockIdx.x * 8) * tile_bytes;  // block tile, k = 0
+    uint32_t ld_koff = 0;                                                                           // ld_s * KS * 1024
+    const bool partial_last = ((t_end - t_first) & 7) != 0;
+    auto issue_stage = [&](int buf) {
+        const uint32_t lbuf = lds_base + (uint32_t)buf * kStageBytes;
+        const bool clamp = partial_last && ld_bt == n_bt - 1;  // rare: the last block tile has < 8 row tiles
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            uint64_t sa = ld_base + piece_a[i] + ld_koff;
+            if (clamp && t_first + ld_bt * 8 + piece_tl[i] >= t_end)  // re-read a valid tile; its rows are masked later
+                sa = (uint64_t)(uintptr_t)base + (t_end - 1) * tile_bytes + (piece_a[i] - (uint64_t)piece_tl[i] * tile_bytes) + ld_koff;
+            dma16<true>(sa, vlane, lbuf + piece_lds[i]);
+            dma16<false>(piece_b[i] + ld_koff, vlane, lbuf + kOpBytes + piece_lds[i]);
+        }
+        ld_koff += KS * 1024;
+        if (++ld_s == S) {
+            ld_s = 0;
+            ld_koff = 0;
+            ld_bt += gridDim.x;
+            ld_base += bt_stride;
+        }
+    };
+
+    // ---- per-lane epilogue constants: the 4 query columns of this lane
+    float qi_reg[4], tau_reg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t col = (uint32_t)(wq * 4 + j) * 32 + (lane & 31);
+        qi_reg[j] = qinv[col];
+        tau_reg[j] = (a.tau && col < a.q) ? a.tau[col] : 0.0f;
+    }
+
+    f16v acc[2][4];
+    auto epilogue = [&](uint64_t bt) {
+        const uint32_t hi = (lane >> 5) ? 4u : 0u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t tl = (uint32_t)(wr * 2 + i);
+            const uint64_t tile = t_first + bt * 8 + tl;
+            if (tile >= t_end) continue;  // wave-uniform
+            const uint32_t dead_word = dead_lds[tl];
+            float nrm[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nrm[r] = inv_lds[tl * 32 + (r & 3) + 8 * (r >> 2) + hi];
+            const bool full = tile * 32 + 32 <= a.row_end;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t col = (uint32_t)(wq * 4 + j) * 32 + (lane & 31);
+                if (col >= a.q) continue;
+                const float qi = qi_reg[j];
+                const float tau = tau_reg[j];
+                if (!a.out_dense) {
+                    // filter mode, fast reject: almost no row beats the running k-th best distance, so take the
+                    // minimum of the 16 distances first (2-3 VALU per element, no branches) and look closer only
+                    // when it passes.  Tombstones / rows past the end are sorted out on the slow path.
+                    float best = __builtin_huge_valf();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) best = fminf(best, 1.0f - acc[i][j][r] * (nrm[r] * qi));
+                    if (!(best < tau)) continue;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t ri = (uint32_t)((r & 3) + 8 * (r >> 2)) + hi;
+                    const uint64_t row = tile * 32 + ri;
+                    if (!full && row >= a.row_end) continue;
+                    const float dist = 1.0f - acc[i][j][r] * (nrm[r] * qi);
+                    bool excluded = (dead_word >> ri) & 1u;
+                    if (a.out_dense) {
+                        if (!excluded && a.allow) {
+                            const uint64_t doc = a.row_doc[row];
+                            excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
+                        }
+                        a.out_dense[(uint64_t)col * a.dense_stride + (row - a.row_begin)] =
+                            excluded ? __builtin_nanf("") : dist;
+                    } else if (!excluded && dist < tau) {
+                        if (a.allow) {  // only rows that pass the threshold pay for the filter lookup
+                            const uint64_t doc = a.row_doc[row];
+                            excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
+                        }
+                        if (!excluded) {
+                            const uint32_t pos = atomicAdd(&a.cand_count[col], 1u);
+                            a.cand_dist[(uint64_t)col * a.cand_stride + pos] = dist;
+                            a.cand_row[(uint64_t)col * a.cand_stride + pos] = (uint32_t)row;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    h8 fa[2][2], fb[2][4];  // fragment registers, double-buffered over the k-steps of a stage
+    auto load_frags = [&](int buf, int ks, int slot) {
+        const char* la = lds + (size_t)buf * kStageBytes + (size_t)lane * 16;
+        const char* lb = la + kOpBytes;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            fa[slot][i] = *reinterpret_cast<const h8*>(la + (size_t)((wr * 2 + i) * KS + ks) * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            fb[slot][j] = *reinterpret_cast<const h8*>(lb + (size_t)((wq * 4 + j) * KS + ks) * 1024);
+    };
+    // the fragments of k-step 0 are already in fa[0] / fb[0] (issued before the DMA of the next stage)
+    auto compute = [&](int buf, bool first) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) load_frags(buf, ks + 1, (ks + 1) & 1);
+            if (ks == 0 && first) {  // wave-uniform: a new block tile starts from C = 0 (no accumulator clearing)
+                const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][j], zero, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- pipeline: stage g lives in LDS buffer g % 3; its DMA was issued two iterations earlier
+    issue_stage(0);
+    if (total > 1) issue_stage(1);
+    uint64_t cp_bt = blockIdx.x;
+    uint32_t cp_s = 0;
+    int buf = 0;
+    for (uint64_t g = 0; g < total; ++g) {
+        // my DMA of stage g has landed (the newer stage g+1 may still be in flight) ...
+        if (g + 1 < total) __builtin_amdgcn_s_waitcnt(kWaitVmOneStage);
+        else __builtin_amdgcn_s_waitcnt(kWaitVm0);
+        __syncthreads();  // ... and everybody's; everybody is also done reading buffer (g+2) % 3 (stage g-1)
+        load_frags(buf, 0, 0);  // LDS latency of the first fragments overlaps the DMA issue below
+        if (g + 2 < total) issue_stage(buf == 0 ? 2 : buf - 1);  // (buf + 2) % 3
+        const bool first = cp_s == 0;
+        if (first) {
+            if (tid < 256) {
+                const uint64_t row = (t_first + cp_bt * 8) * 32 + (uint64_t)tid;
+                inv_lds[tid] = row < a.n_rows ? a.inv_norm[row] : 0.0f;
+            } else if (tid < 264) {
+                const uint64_t tile = t_first + cp_bt * 8 + (uint64_t)(tid - 256);
+                dead_lds[tid - 256] = (a.dead && tile < t_end) ? a.dead[tile] : 0u;
+            }
+        }
+        compute(buf, first);
+        if (++cp_s == S) {
+            epilogue(cp_bt);
+            cp_s = 0;
+            cp_bt += gridDim.x;
+        }
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
+    }
+}
+
+}  // namespace
+
+size_t f16_wide_query_bytes(uint32_t dim) { return (size_t)8 * (f16_kpad(dim) / 16) * 1024 + 256 * sizeof(float); }
+
+int launch_vec_scan_f16_wide(orama_ctx* ctx, const F16ScanArgs& a, void* d_query_frags, bool prepare,
+                             hipStream_t stream) {
+    ORAMA_REQUIRE(a.tiled && a.inv_norm && a.queries && d_query_frags, "vec_scan_f16_wide: bad arguments");
+    ORAMA_REQUIRE(a.q >= 1 && a.q <= kF16WideMaxQ, "vec_scan_f16_wide: q=%u outside [1, %u]", a.q, kF16WideMaxQ);
+    ORAMA_REQUIRE((a.row_begin & 31) == 0 && a.row_begin <= a.row_end, "vec_scan_f16_wide: bad row range");
+    ORAMA_REQUIRE(a.out_dense || (a.tau && a.cand_dist && a.cand_row && a.cand_count),
+                  "vec_scan_f16_wide: no output mode");
+    ORAMA_REQUIRE(!a.allow || a.row_doc, "vec_scan_f16_wide: filter needs row_doc");
+    const uint32_t kpad = f16_kpad(a.dim);
+    const uint32_t ksteps = kpad / 16;
+    ORAMA_REQUIRE(ksteps % KS == 0, "vec_scan_f16_wide: kpad %u not a multiple of %d", kpad, KS * 16);
+    static_assert(kLdsBytes <= 160 * 1024, "K2c LDS budget");
+    char* bfrag = reinterpret_cast<char*>(d_query_frags);
+    float* qinv = reinterpret_cast<float*>(bfrag + (size_t)8 * ksteps * 1024);
+    if (prepare) {
+        hipLaunchKernelGGL(f16_prepare_queries_kernel, dim3(64), dim3(256), 0, stream, a.queries, a.q, a.dim, ksteps,
+                           bfrag, qinv);
+        ORAMA_HIP_TRY(hipGetLastError());
+    }
+    if (a.row_begin == a.row_end) return ORAMA_OK;
+    ProfScope prof(&ctx->prof, "vec_scan_f16", stream);
+    static bool attr_done = false;
+    const size_t lds_bytes = kLdsBytes;  // 3 x 48 KiB ring + tile metadata
+    if (!attr_done) {
+        ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_wide_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const uint64_t tiles = ((a.row_end + 31) >> 5) - (a.row_begin >> 5);
+    uint64_t blocks = (tiles + 7) / 8;
+    if (blocks > (uint64_t)ctx->compute_units) blocks = (uint64_t)ctx->compute_units;
+    hipLaunchKernelGGL(vec_scan_f16_wide_kernel, dim3((uint32_t)blocks), dim3(kWB), lds_bytes, stream, a,
+                       (const char*)bfrag, (const float*)qinv, ksteps, f16_tile_bytes(a.dim));
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+}  // namespace orama

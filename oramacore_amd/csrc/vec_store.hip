@@ -269,8 +269,19 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
     ORAMA_REQUIRE(v->metric == ORAMA_METRIC_COSINE, "f16 storage implements the cosine metric only");
     constexpr uint64_t kS1 = 131072;                 // dense head (rows), multiple of 32
     constexpr uint64_t kCandBudget = 6ull << 30;     // bytes of candidate lists per pass
-    for (uint32_t q0 = 0; q0 < q; q0 += kF16MaxQ) {
-        const uint32_t gq = std::min<uint32_t>(kF16MaxQ, q - q0);
+    const uint32_t kpad_k = f16_kpad(v->dim);
+    for (uint32_t q0 = 0; q0 < q;) {
+        // <= 64 queries: K2 (whole batch as LDS-resident B fragments); more: K2c (GEMM-tiled, <= 256 per pass)
+        const bool wide = v->ctx->f16_wide && (q - q0) > kF16MaxQ && (kpad_k / 16) % 3 == 0;
+        const uint32_t gq = std::min<uint32_t>(wide ? kF16WideMaxQ : kF16MaxQ, q - q0);
+        if (wide) ORAMA_TRY(sc->f16_bfrag.reserve(f16_wide_query_bytes(v->dim)));
+        bool wide_prepared = false;
+        auto scan = [&](const F16ScanArgs& args) -> int {
+            if (!wide) return launch_vec_scan_f16(v->ctx, args, s);
+            const int st = launch_vec_scan_f16_wide(v->ctx, args, sc->f16_bfrag.p, !wide_prepared, s);
+            wide_prepared = true;
+            return st;
+        };
         const uint64_t s1 = std::min<uint64_t>(n, kS1);
         // super-chunk size: gq * (rows + k) * 8 B <= budget
         uint64_t chunk_rows = kCandBudget / ((uint64_t)gq * 8);
@@ -311,7 +322,7 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
         a.row_end = s1;
         a.out_dense = sc->dist.as<float>();
         a.dense_stride = s1;
-        ORAMA_TRY(launch_vec_scan_f16(v->ctx, a, s));
+        ORAMA_TRY(scan(a));
         SelectPlan p;
         p.vals = sc->dist.as<float>();
         p.stride = s1;
@@ -328,6 +339,7 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
             p.out_val = out_dist;
             p.out_n = out_n;
             ORAMA_TRY(launch_select(v->ctx, p, s));
+            q0 += gq;
             continue;
         }
         p.out_idx = best_row;
@@ -347,7 +359,7 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
             a.cand_row = cand_row;
             a.cand_count = cand_count;
             a.cand_stride = cand_stride;
-            ORAMA_TRY(launch_vec_scan_f16(v->ctx, a, s));
+            ORAMA_TRY(scan(a));
             SelectPlan c;
             c.vals = cand_dist;
             c.idx = cand_row;
@@ -371,6 +383,7 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
             }
             ORAMA_TRY(launch_select(v->ctx, c, s));
         }
+        q0 += gq;
     }
     return ORAMA_OK;
 }

@@ -129,3 +129,35 @@ def test_synthetic_fill_f16_1m(ctx):
     od = orc.distances(rows, q16(queries[5]))
     assert np.max(np.abs(od - dist[5])) <= TOL
     st.close()
+
+
+@pytest.mark.parametrize("d", [768, 384, 1024])
+def test_wide_batches_equal_solo_queries(ctx, d):
+    """K2c (65..256 queries per corpus pass, GEMM-tiled) must return per query exactly what K2 returns for the
+    query alone: same ids, bit-identical distances — across the dense head, the threshold-filter super-chunks,
+    tombstones and an allow bitmap; and sound against the oracle on the quantised rows."""
+    n = 140_000 if d == 768 else 40_000          # 768: beyond the 131072-row dense head → filter path too
+    corpus = util.gaussian_rows(n, d, seed=50 + d)
+    st = make_store(ctx, corpus, row_doc=np.arange(n, dtype=np.uint64) * 2 + 1)
+    for doc in (1, 3, 2 * 77 + 1):
+        st.delete(doc)
+    bm = oa.AllowBitmap.from_mask((np.arange(2 * n + 2) % 7) != 3)
+    queries = util.gaussian_rows(256, d, seed=60 + d)
+    for allow in (None, bm):
+        picks = (0, 31, 32, 64, 127, 128, 199, 255)
+        solo = {i: st.storage_search(queries[i], 30, allow) for i in picks}
+        for nq in (65, 200, 256):
+            ids, dist, cnt = st.storage_search(queries[:nq], 30, allow)
+            assert cnt.tolist() == [30] * nq
+            for i in picks:
+                if i >= nq:
+                    continue
+                assert np.array_equal(ids[i], solo[i][0][0]), (nq, i)
+                assert np.array_equal(dist[i].view(np.uint32), solo[i][1][0].view(np.uint32)), (nq, i)
+    c16 = q16(corpus)
+    ids, dist, cnt = st.storage_search(queries[:70], 30)
+    for qi in (0, 69):
+        full = orc.distances(c16, q16(queries[qi])).astype(np.float64)
+        full[[0, 1, 77]] = np.nan
+        util.assert_topk_sound((ids[qi] - 1) // 2, dist[qi], full, 30, TOL, f"wide q{qi}")
+    st.close()
