@@ -34,15 +34,17 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int kWB = 512;                    // threads per workgroup
 constexpr int KS = 3;                       // k-steps per stage
 constexpr int NBUF = 3;                     // LDS ring: stage g lives in buffer g % 3, two stages in flight
-constexpr int kOpBytes = 8 * KS * 1024;     // one operand of a stage: 8 row (or query) tiles x KS fragments = 24 KiB
-constexpr int kStageBytes = 2 * kOpBytes;   // A | B
-constexpr int kPieces = kOpBytes / 16 / kWB;  // 16-byte pieces per thread and operand per stage (= 3)
-constexpr int kMetaOff = NBUF * kStageBytes;  // 1/|x| of the block tile's 256 rows + 8 tombstone words
-constexpr int kLdsBytes = kMetaOff + 256 * 4 + 8 * 4;
+constexpr int kOpBytes = 8 * KS * 1024;     // operand A of a stage: 8 row tiles x KS fragments of 1 KiB = 24 KiB
+// operand B of a stage: 2 query groups x QT query tiles x KS fragments (QT = 4: 256 queries, 24 KiB; QT = 2: 128, 12 KiB)
+constexpr int op_b_bytes(int qt) { return 2 * qt * KS * 1024; }
+constexpr int stage_bytes(int qt) { return kOpBytes + op_b_bytes(qt); }
+constexpr int kMetaBytes = 2 * 256 * 4;     // 1/|x| of the block tile's 256 rows, double-buffered over block tiles
+constexpr int lds_bytes_for(int qt) { return NBUF * stage_bytes(qt) + kMetaBytes; }
+// DMA instructions (64 pieces of 16 B each) per wave and stage: A 24 / 8 waves = 3; B (8 QT KS / 8) = 3 or 1.5
+constexpr int kInstrA = kOpBytes / 1024 / 8;
 
 // s_waitcnt immediates (gfx9 encoding): vmcnt only, expcnt / lgkmcnt untouched
 constexpr int kWaitVm0 = 0x0F70;
-constexpr int kWaitVmOneStage = 0x0F70 | (2 * kPieces);  // leave the newest stage (2 * kPieces loads) in flight
 
 // 16 bytes per lane, global -> LDS, asynchronous (completion is counted by vmcnt): lane l's data lands at LDS
 // address m0 + 16 l.  Issued through inline asm on purpose: for the builtin the compiler's wait-count pass assumes
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(256) void f16_prepare_queries_kernel(const float* _
     }
 }
 
+template <int QT>
 __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, const char* __restrict__ bfrag,
                                                                 const float* __restrict__ qinv, uint32_t ksteps,
                                                                 uint64_t tile_bytes) {
@@ -104,7 +107,10 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
     const int lane = tid & 63;
     const int w = uniform_u32(tid >> 6);
     const int wr = w & 3;   // row group: row tiles 2wr, 2wr+1 of the block tile
-    const int wq = w >> 2;  // query group: query tiles 4wq .. 4wq+3
+    const int wq = w >> 2;  // query group: query tiles QT wq .. QT wq + QT - 1
+    constexpr int kStageBytes = stage_bytes(QT);
+    constexpr int kInstrB = (2 * QT * KS + 7) / 8;      // per wave, upper bound (waves with w + 8 i >= 2 QT KS skip)
+    constexpr int kMetaOff = NBUF * kStageBytes;
 
     const uint64_t t_first = a.row_begin >> 5;
     const uint64_t t_end = (a.row_end + 31) >> 5;            // row tiles [t_first, t_end)
@@ -114,8 +120,7 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
     const uint32_t S = ksteps / KS;                          // stages per block tile
     const uint64_t total = my_bt * S;
     const char* base = reinterpret_cast<const char*>(a.tiled);
-    float* inv_lds = reinterpret_cast<float*>(lds + kMetaOff);
-    uint32_t* dead_lds = reinterpret_cast<uint32_t*>(lds + kMetaOff + 256 * 4);
+    const float* inv_lds = reinterpret_cast<const float*>(lds + kMetaOff);  // [2][256]
 
     // ---- stage loader: global -> LDS DMA (global_load_lds_dwordx4), no staging registers.  A wave moves 64
     // consecutive 16-byte pieces per instruction; piece p = (tile p / (KS*64), k-step (p / 64) % KS, lane p % 64),
@@ -126,68 +131,91 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
     uint32_t ld_s = 0;
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds;
     const uint32_t vlane = (uint32_t)lane * 16;
-    uint32_t piece_lds[kPieces];   // LDS offset of the wave's i-th piece group inside an operand
-    uint64_t piece_a[kPieces];     // its corpus offset inside a block tile at k-step 0
-    uint64_t piece_b[kPieces];     // its address in the query fragments at k-step 0
-    uint32_t piece_tl[kPieces];
+    // wave w moves the 1-KiB fragments t = w + 8 i of each operand; fragment t = (tile t / KS, k-step t % KS)
+    uint32_t a_lds[kInstrA], b_lds[kInstrB], a_tl[kInstrA];
+    uint64_t a_off[kInstrA], b_adr[kInstrB];
+    int my_b = 0;  // B fragments this wave moves per stage (wave-uniform)
 #pragma unroll
-    for (int i = 0; i < kPieces; ++i) {
-        const uint32_t p0 = (uint32_t)w * 64 + (uint32_t)kWB * i;  // wave-uniform first piece
-        const uint32_t tl = p0 / (KS * 64), ks = (p0 >> 6) % KS;
-        piece_tl[i] = tl;
-        piece_lds[i] = p0 * 16;
-        piece_a[i] = (uint64_t)tl * tile_bytes + (uint64_t)ks * 1024;
-        piece_b[i] = (uint64_t)(uintptr_t)bfrag + ((uint64_t)tl * ksteps + ks) * 1024;
+    for (int i = 0; i < kInstrA; ++i) {
+        const uint32_t t = (uint32_t)w + 8u * i;
+        a_tl[i] = t / KS;
+        a_lds[i] = t * 1024;
+        a_off[i] = (uint64_t)(t / KS) * tile_bytes + (uint64_t)(t % KS) * 1024;
+    }
+#pragma unroll
+    for (int i = 0; i < kInstrB; ++i) {
+        const uint32_t t = (uint32_t)w + 8u * i;
+        if (t < 2u * QT * KS) my_b = i + 1;
+        b_lds[i] = kOpBytes + t * 1024;
+        b_adr[i] = (uint64_t)(uintptr_t)bfrag + ((uint64_t)(t / KS) * ksteps + (t % KS)) * 1024;
     }
     const uint64_t bt_stride = (uint64_t)gridDim.x * 8 * tile_bytes;
     uint64_t ld_base = (uint64_t)(uintptr_t)base + (t_first + (uint64_t)blockIdx.x * 8) * tile_bytes;  // block tile, k = 0
     uint32_t ld_koff = 0;                                                                           // ld_s * KS * 1024
+    uint32_t ld_par = 0;                                                                            // metadata buffer parity
     const bool partial_last = ((t_end - t_first) & 7) != 0;
     auto issue_stage = [&](int buf) {
         const uint32_t lbuf = lds_base + (uint32_t)buf * kStageBytes;
+        if (ld_s == 0 && w == 0) {
+            // first stage of a block tile: wave 0 also fetches the tile's 256 inverse norms (1 KiB, contiguous).
+            // Issued BEFORE the stage's fragments, so the counted waits below (which leave the newest fragments in
+            // flight) cover it.  Rows past the end of the store read the zero-initialised padding of inv_norm.
+            dma16<false>((uint64_t)(uintptr_t)a.inv_norm + (t_first + ld_bt * 8) * 128, vlane,
+                         lds_base + kMetaOff + ld_par * 1024);
+        }
         const bool clamp = partial_last && ld_bt == n_bt - 1;  // rare: the last block tile has < 8 row tiles
 #pragma unroll
-        for (int i = 0; i < kPieces; ++i) {
-            uint64_t sa = ld_base + piece_a[i] + ld_koff;
-            if (clamp && t_first + ld_bt * 8 + piece_tl[i] >= t_end)  // re-read a valid tile; its rows are masked later
-                sa = (uint64_t)(uintptr_t)base + (t_end - 1) * tile_bytes + (piece_a[i] - (uint64_t)piece_tl[i] * tile_bytes) + ld_koff;
-            dma16<true>(sa, vlane, lbuf + piece_lds[i]);
-            dma16<false>(piece_b[i] + ld_koff, vlane, lbuf + kOpBytes + piece_lds[i]);
+        for (int i = 0; i < kInstrA; ++i) {
+            uint64_t sa = ld_base + a_off[i] + ld_koff;
+            if (clamp && t_first + ld_bt * 8 + a_tl[i] >= t_end)  // re-read a valid tile; its rows are masked later
+                sa = (uint64_t)(uintptr_t)base + (t_end - 1) * tile_bytes + (a_off[i] - (uint64_t)a_tl[i] * tile_bytes) + ld_koff;
+            dma16<true>(sa, vlane, lbuf + a_lds[i]);
         }
+#pragma unroll
+        for (int i = 0; i < kInstrB; ++i)
+            if (i < my_b) dma16<false>(b_adr[i] + ld_koff, vlane, lbuf + b_lds[i]);
         ld_koff += KS * 1024;
         if (++ld_s == S) {
             ld_s = 0;
             ld_koff = 0;
             ld_bt += gridDim.x;
             ld_base += bt_stride;
+            ld_par ^= 1;
         }
+    };
+    // counted wait that leaves exactly this wave's newest stage in flight
+    auto wait_one_stage_in_flight = [&]() {
+        if (kInstrA + my_b == 6) __builtin_amdgcn_s_waitcnt(kWaitVm0 | 6);
+        else if (kInstrA + my_b == 5) __builtin_amdgcn_s_waitcnt(kWaitVm0 | 5);
+        else __builtin_amdgcn_s_waitcnt(kWaitVm0 | 4);
     };
 
     // ---- per-lane epilogue constants: the 4 query columns of this lane
-    float qi_reg[4], tau_reg[4];
+    float qi_reg[QT], tau_reg[QT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t col = (uint32_t)(wq * 4 + j) * 32 + (lane & 31);
+    for (int j = 0; j < QT; ++j) {
+        const uint32_t col = (uint32_t)(wq * QT + j) * 32 + (lane & 31);
         qi_reg[j] = qinv[col];
         tau_reg[j] = (a.tau && col < a.q) ? a.tau[col] : 0.0f;
     }
 
-    f16v acc[2][4];
-    auto epilogue = [&](uint64_t bt) {
+    f16v acc[2][QT];
+    typedef const uint32_t __attribute__((address_space(4))) cu32;
+    auto epilogue = [&](uint64_t bt, uint32_t par) {
         const uint32_t hi = (lane >> 5) ? 4u : 0u;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const uint32_t tl = (uint32_t)(wr * 2 + i);
             const uint64_t tile = t_first + bt * 8 + tl;
             if (tile >= t_end) continue;  // wave-uniform
-            const uint32_t dead_word = dead_lds[tl];
+            const uint32_t dead_word = a.dead ? ((cu32*)(uintptr_t)a.dead)[tile] : 0u;  // scalar load
             float nrm[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) nrm[r] = inv_lds[tl * 32 + (r & 3) + 8 * (r >> 2) + hi];
+            for (int r = 0; r < 16; ++r) nrm[r] = inv_lds[par * 256 + tl * 32 + (r & 3) + 8 * (r >> 2) + hi];
             const bool full = tile * 32 + 32 <= a.row_end;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t col = (uint32_t)(wq * 4 + j) * 32 + (lane & 31);
+            for (int j = 0; j < QT; ++j) {
+                const uint32_t col = (uint32_t)(wq * QT + j) * 32 + (lane & 31);
                 if (col >= a.q) continue;
                 const float qi = qi_reg[j];
                 const float tau = tau_reg[j];
@@ -230,7 +258,7 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
         }
     };
 
-    h8 fa[2][2], fb[2][4];  // fragment registers, double-buffered over the k-steps of a stage
+    h8 fa[2][2], fb[2][QT];  // fragment registers, double-buffered over the k-steps of a stage
     auto load_frags = [&](int buf, int ks, int slot) {
         const char* la = lds + (size_t)buf * kStageBytes + (size_t)lane * 16;
         const char* lb = la + kOpBytes;
@@ -238,8 +266,8 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
         for (int i = 0; i < 2; ++i)
             fa[slot][i] = *reinterpret_cast<const h8*>(la + (size_t)((wr * 2 + i) * KS + ks) * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            fb[slot][j] = *reinterpret_cast<const h8*>(lb + (size_t)((wq * 4 + j) * KS + ks) * 1024);
+        for (int j = 0; j < QT; ++j)
+            fb[slot][j] = *reinterpret_cast<const h8*>(lb + (size_t)((wq * QT + j) * KS + ks) * 1024);
     };
     // the fragments of k-step 0 are already in fa[0] / fb[0] (issued before the DMA of the next stage)
     auto compute = [&](int buf, bool first) {
@@ -251,13 +279,13 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < QT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][j], zero, 0, 0, 0);
             } else {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < QT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
             }
         }
@@ -267,29 +295,20 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
     issue_stage(0);
     if (total > 1) issue_stage(1);
     uint64_t cp_bt = blockIdx.x;
-    uint32_t cp_s = 0;
+    uint32_t cp_s = 0, cp_par = 0;
     int buf = 0;
     for (uint64_t g = 0; g < total; ++g) {
         // my DMA of stage g has landed (the newer stage g+1 may still be in flight) ...
-        if (g + 1 < total) __builtin_amdgcn_s_waitcnt(kWaitVmOneStage);
+        if (g + 1 < total) wait_one_stage_in_flight();
         else __builtin_amdgcn_s_waitcnt(kWaitVm0);
         __syncthreads();  // ... and everybody's; everybody is also done reading buffer (g+2) % 3 (stage g-1)
         load_frags(buf, 0, 0);  // LDS latency of the first fragments overlaps the DMA issue below
         if (g + 2 < total) issue_stage(buf == 0 ? 2 : buf - 1);  // (buf + 2) % 3
-        const bool first = cp_s == 0;
-        if (first) {
-            if (tid < 256) {
-                const uint64_t row = (t_first + cp_bt * 8) * 32 + (uint64_t)tid;
-                inv_lds[tid] = row < a.n_rows ? a.inv_norm[row] : 0.0f;
-            } else if (tid < 264) {
-                const uint64_t tile = t_first + cp_bt * 8 + (uint64_t)(tid - 256);
-                dead_lds[tid - 256] = (a.dead && tile < t_end) ? a.dead[tile] : 0u;
-            }
-        }
-        compute(buf, first);
+        compute(buf, cp_s == 0);
         if (++cp_s == S) {
-            epilogue(cp_bt);
+            epilogue(cp_bt, cp_par);
             cp_s = 0;
+            cp_par ^= 1;
             cp_bt += gridDim.x;
         }
         buf = buf == NBUF - 1 ? 0 : buf + 1;
@@ -311,7 +330,6 @@ int launch_vec_scan_f16_wide(orama_ctx* ctx, const F16ScanArgs& a, void* d_query
     const uint32_t kpad = f16_kpad(a.dim);
     const uint32_t ksteps = kpad / 16;
     ORAMA_REQUIRE(ksteps % KS == 0, "vec_scan_f16_wide: kpad %u not a multiple of %d", kpad, KS * 16);
-    static_assert(kLdsBytes <= 160 * 1024, "K2c LDS budget");
     char* bfrag = reinterpret_cast<char*>(d_query_frags);
     float* qinv = reinterpret_cast<float*>(bfrag + (size_t)8 * ksteps * 1024);
     if (prepare) {
@@ -321,18 +339,29 @@ int launch_vec_scan_f16_wide(orama_ctx* ctx, const F16ScanArgs& a, void* d_query
     }
     if (a.row_begin == a.row_end) return ORAMA_OK;
     ProfScope prof(&ctx->prof, "vec_scan_f16", stream);
-    static bool attr_done = false;
-    const size_t lds_bytes = kLdsBytes;  // 3 x 48 KiB ring + tile metadata
-    if (!attr_done) {
-        ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_wide_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static_assert(lds_bytes_for(4) <= 160 * 1024, "K2c LDS budget");
     const uint64_t tiles = ((a.row_end + 31) >> 5) - (a.row_begin >> 5);
     uint64_t blocks = (tiles + 7) / 8;
     if (blocks > (uint64_t)ctx->compute_units) blocks = (uint64_t)ctx->compute_units;
-    hipLaunchKernelGGL(vec_scan_f16_wide_kernel, dim3((uint32_t)blocks), dim3(kWB), lds_bytes, stream, a,
-                       (const char*)bfrag, (const float*)qinv, ksteps, f16_tile_bytes(a.dim));
+    if (a.q <= 128) {  // 2 query tiles per wave: half the MFMAs and half the query-fragment traffic
+        static bool attr2 = false;
+        if (!attr2) {
+            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_wide_kernel<2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr2 = true;
+        }
+        hipLaunchKernelGGL((vec_scan_f16_wide_kernel<2>), dim3((uint32_t)blocks), dim3(kWB), lds_bytes_for(2), stream, a,
+                           (const char*)bfrag, (const float*)qinv, ksteps, f16_tile_bytes(a.dim));
+    } else {
+        static bool attr4 = false;
+        if (!attr4) {
+            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_wide_kernel<4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr4 = true;
+        }
+        hipLaunchKernelGGL((vec_scan_f16_wide_kernel<4>), dim3((uint32_t)blocks), dim3(kWB), lds_bytes_for(4), stream, a,
+                           (const char*)bfrag, (const float*)qinv, ksteps, f16_tile_bytes(a.dim));
+    }
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

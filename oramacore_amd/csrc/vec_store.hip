@@ -65,13 +65,15 @@ int alloc_arrays(orama_vec* v, uint64_t cap, Arrays* a, hipStream_t s) {
     if (v->f16()) cap = (cap + 31) & ~31ull;
     const size_t dead_words = (size_t)((cap + 31) / 32);
     ORAMA_HIP_TRY(hipMalloc(&a->rows, std::max<size_t>(256, v->matrix_bytes(cap))));
-    ORAMA_HIP_TRY(hipMalloc(&a->norm, (size_t)cap * sizeof(float)));
+    // f16: K2c fetches the 256 inverse norms of a block tile with one 1-KiB DMA — pad to whole block tiles
+    const size_t norm_bytes = (size_t)(v->f16() ? ((cap + 255) & ~255ull) : cap) * sizeof(float);
+    ORAMA_HIP_TRY(hipMalloc(&a->norm, std::max<size_t>(norm_bytes, 4)));
     ORAMA_HIP_TRY(hipMalloc(&a->doc, (size_t)cap * sizeof(uint64_t)));
     ORAMA_HIP_TRY(hipMalloc(&a->dead, dead_words * sizeof(uint32_t)));
     ORAMA_HIP_TRY(hipMemsetAsync(a->dead, 0, dead_words * sizeof(uint32_t), s));
     if (v->f16()) {  // padding rows of partial tiles must read as zeros
         ORAMA_HIP_TRY(hipMemsetAsync(a->rows, 0, v->matrix_bytes(cap), s));
-        ORAMA_HIP_TRY(hipMemsetAsync(a->norm, 0, (size_t)cap * sizeof(float), s));
+        ORAMA_HIP_TRY(hipMemsetAsync(a->norm, 0, norm_bytes, s));
     }
     a->cap = cap;
     return ORAMA_OK;
