@@ -53,7 +53,9 @@ def _fingerprint() -> str:
     for p in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + list(INCLUDE.glob("*.h"))):
         h.update(p.name.encode())
         h.update(p.read_bytes())
-    h.update(" ".join(COMMON_FLAGS).encode())
+    # flags without the checkout-specific include paths: the tree is shipped to the GPU box under another root, and a
+    # path in the fingerprint would force a rebuild there on every run
+    h.update(" ".join(f for f in COMMON_FLAGS if not f.startswith("-I")).encode())
     return h.hexdigest()
 
 
