@@ -32,36 +32,32 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWB = 512;                    // threads per workgroup
-constexpr int KS = 3;                       // k-steps per stage
+// KS = k-steps per stage: 3 when the padded dimension allows it (768, 384: 48 / 24 k-steps), else 2 (1024: 64)
 constexpr int NBUF = 3;                     // LDS ring: stage g lives in buffer g % 3, two stages in flight
-constexpr int kOpBytes = 8 * KS * 1024;     // operand A of a stage: 8 row tiles x KS fragments of 1 KiB = 24 KiB
-// operand B of a stage: 2 query groups x QT query tiles x KS fragments (QT = 4: 256 queries, 24 KiB; QT = 2: 128, 12 KiB)
-constexpr int op_b_bytes(int qt) { return 2 * qt * KS * 1024; }
-constexpr int stage_bytes(int qt) { return kOpBytes + op_b_bytes(qt); }
+// operand A of a stage: 8 row tiles x KS fragments of 1 KiB (24 KiB at KS = 3)
+constexpr int op_a_bytes(int ks) { return 8 * ks * 1024; }
+// operand B of a stage: 2 query groups x QT query tiles x KS fragments (QT = 4: 256 queries, QT = 2: 128)
+constexpr int op_b_bytes(int qt, int ks) { return 2 * qt * ks * 1024; }
+constexpr int stage_bytes(int qt, int ks) { return op_a_bytes(ks) + op_b_bytes(qt, ks); }
 constexpr int kMetaBytes = 2 * 256 * 4;     // 1/|x| of the block tile's 256 rows, double-buffered over block tiles
-constexpr int lds_bytes_for(int qt) { return NBUF * stage_bytes(qt) + kMetaBytes; }
-// DMA instructions (64 pieces of 16 B each) per wave and stage: A 24 / 8 waves = 3; B (8 QT KS / 8) = 3 or 1.5
-constexpr int kInstrA = kOpBytes / 1024 / 8;
+constexpr int lds_bytes_for(int qt, int ks) { return NBUF * stage_bytes(qt, ks) + kMetaBytes; }
+// DMA scheduling: the two wave groups (waves 0-3 / 4-7) load alternate stages, so a wave only ever has the DMA of
+// ONE stage outstanding when it must wait for it — the waits are plain vmcnt(0).  (Counted waits that leave a newer
+// stage in flight are not safe: LDS-DMA loads were observed to complete out of issue order.)
+// DMA instructions (one 1-KiB fragment each) per wave and loaded stage: A 8 KS / 4 waves; B 2 QT KS / 4 waves.
 
 // s_waitcnt immediates (gfx9 encoding): vmcnt only, expcnt / lgkmcnt untouched
-constexpr int kWaitVm0 = 0x0F70;
+constexpr int kWaitVm0 = 0x0F70;  // vmcnt(0)
 
 // 16 bytes per lane, global -> LDS, asynchronous (completion is counted by vmcnt): lane l's data lands at LDS
 // address m0 + 16 l.  Issued through inline asm on purpose: for the builtin the compiler's wait-count pass assumes
 // any later LDS read may alias the DMA and drains vmcnt(0) before every ds_read — which serialises the ring.  Here
 // the ring discipline guarantees disjoint buffers and the waits are explicit (kWaitVm*).
-template <bool NT>
 __device__ __forceinline__ void dma16(uint64_t saddr_uniform, uint32_t voff, uint32_t lds_addr_uniform) {
-    if constexpr (NT)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
-                     :
-                     : "v"(voff), "s"(saddr_uniform), "s"(lds_addr_uniform)
-                     : "memory", "m0");
-    else
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                     :
-                     : "v"(voff), "s"(saddr_uniform), "s"(lds_addr_uniform)
-                     : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(saddr_uniform), "s"(lds_addr_uniform)
+                 : "memory", "m0");
 }
 
 // queries (f32) -> fp16 B fragments [query tile 0..7][k-step][lane][8 halves] + 1/|q| of the rounded query
@@ -98,7 +94,7 @@ __global__ __launch_bounds__(256) void f16_prepare_queries_kernel(const float* _
     }
 }
 
-template <int QT>
+template <int QT, int KS>
 __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, const char* __restrict__ bfrag,
                                                                 const float* __restrict__ qinv, uint32_t ksteps,
                                                                 uint64_t tile_bytes) {
@@ -108,8 +104,9 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
     const int w = uniform_u32(tid >> 6);
     const int wr = w & 3;   // row group: row tiles 2wr, 2wr+1 of the block tile
     const int wq = w >> 2;  // query group: query tiles QT wq .. QT wq + QT - 1
-    constexpr int kStageBytes = stage_bytes(QT);
-    constexpr int kInstrB = (2 * QT * KS + 7) / 8;      // per wave, upper bound (waves with w + 8 i >= 2 QT KS skip)
+    constexpr int kStageBytes = stage_bytes(QT, KS);
+    constexpr int kOpBytes = op_a_bytes(KS);
+    constexpr int kInstrA = 8 * KS / 4;
     constexpr int kMetaOff = NBUF * kStageBytes;
 
     const uint64_t t_first = a.row_begin >> 5;
@@ -127,53 +124,35 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
     // LDS offset 16 p — the fragment layout itself.
     // All addresses are wave-uniform except the lane's 16-byte slot: scalar base (running, no multiplies in the
     // loop) + one constant VGPR offset.
-    uint64_t ld_bt = blockIdx.x;  // cursor of the NEXT stage to load: (block tile, stage)
-    uint32_t ld_s = 0;
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds;
     const uint32_t vlane = (uint32_t)lane * 16;
-    // wave w moves the 1-KiB fragments t = w + 8 i of each operand; fragment t = (tile t / KS, k-step t % KS)
-    uint32_t a_lds[kInstrA], b_lds[kInstrB], a_tl[kInstrA];
-    uint64_t a_off[kInstrA], b_adr[kInstrB];
-    int my_b = 0;  // B fragments this wave moves per stage (wave-uniform)
+    // wave lw = w & 3 of a group moves the 1-KiB fragments t = lw + 4 i of each operand; t = (tile t / KS, k-step t % KS)
+    constexpr int kInstrB = 2 * QT * KS / 4;
+    static_assert((kInstrA + kInstrB) % KS == 0, "DMA instructions split evenly over the k-steps");
+    constexpr int kPerStep = (kInstrA + kInstrB) / KS;
+    const int grp = w >> 2, lw = w & 3;
+    uint32_t f_lds[kInstrA + kInstrB], a_tl[kInstrA];
+    uint64_t f_adr[kInstrA + kInstrB];  // A: offset inside the block tile at k-step 0; B: absolute address at k-step 0
 #pragma unroll
     for (int i = 0; i < kInstrA; ++i) {
-        const uint32_t t = (uint32_t)w + 8u * i;
+        const uint32_t t = (uint32_t)lw + 4u * i;
         a_tl[i] = t / KS;
-        a_lds[i] = t * 1024;
-        a_off[i] = (uint64_t)(t / KS) * tile_bytes + (uint64_t)(t % KS) * 1024;
+        f_lds[i] = t * 1024;
+        f_adr[i] = (uint64_t)(t / KS) * tile_bytes + (uint64_t)(t % KS) * 1024;
     }
 #pragma unroll
     for (int i = 0; i < kInstrB; ++i) {
-        const uint32_t t = (uint32_t)w + 8u * i;
-        if (t < 2u * QT * KS) my_b = i + 1;
-        b_lds[i] = kOpBytes + t * 1024;
-        b_adr[i] = (uint64_t)(uintptr_t)bfrag + ((uint64_t)(t / KS) * ksteps + (t % KS)) * 1024;
+        const uint32_t t = (uint32_t)lw + 4u * i;
+        f_lds[kInstrA + i] = kOpBytes + t * 1024;
+        f_adr[kInstrA + i] = (uint64_t)(uintptr_t)bfrag + ((uint64_t)(t / KS) * ksteps + (t % KS)) * 1024;
     }
     const uint64_t bt_stride = (uint64_t)gridDim.x * 8 * tile_bytes;
+    // load cursor of THIS wave's group: the group loads stages grp, grp + 2, grp + 4, ... of the workgroup's sequence
+    uint64_t ld_bt = blockIdx.x;
+    uint32_t ld_s = 0, ld_koff = 0, ld_par = 0;
     uint64_t ld_base = (uint64_t)(uintptr_t)base + (t_first + (uint64_t)blockIdx.x * 8) * tile_bytes;  // block tile, k = 0
-    uint32_t ld_koff = 0;                                                                           // ld_s * KS * 1024
-    uint32_t ld_par = 0;                                                                            // metadata buffer parity
     const bool partial_last = ((t_end - t_first) & 7) != 0;
-    auto issue_stage = [&](int buf) {
-        const uint32_t lbuf = lds_base + (uint32_t)buf * kStageBytes;
-        if (ld_s == 0 && w == 0) {
-            // first stage of a block tile: wave 0 also fetches the tile's 256 inverse norms (1 KiB, contiguous).
-            // Issued BEFORE the stage's fragments, so the counted waits below (which leave the newest fragments in
-            // flight) cover it.  Rows past the end of the store read the zero-initialised padding of inv_norm.
-            dma16<false>((uint64_t)(uintptr_t)a.inv_norm + (t_first + ld_bt * 8) * 128, vlane,
-                         lds_base + kMetaOff + ld_par * 1024);
-        }
-        const bool clamp = partial_last && ld_bt == n_bt - 1;  // rare: the last block tile has < 8 row tiles
-#pragma unroll
-        for (int i = 0; i < kInstrA; ++i) {
-            uint64_t sa = ld_base + a_off[i] + ld_koff;
-            if (clamp && t_first + ld_bt * 8 + a_tl[i] >= t_end)  // re-read a valid tile; its rows are masked later
-                sa = (uint64_t)(uintptr_t)base + (t_end - 1) * tile_bytes + (a_off[i] - (uint64_t)a_tl[i] * tile_bytes) + ld_koff;
-            dma16<true>(sa, vlane, lbuf + a_lds[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < kInstrB; ++i)
-            if (i < my_b) dma16<false>(b_adr[i] + ld_koff, vlane, lbuf + b_lds[i]);
+    auto advance_cursor = [&]() {
         ld_koff += KS * 1024;
         if (++ld_s == S) {
             ld_s = 0;
@@ -183,11 +162,33 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
             ld_par ^= 1;
         }
     };
-    // counted wait that leaves exactly this wave's newest stage in flight
-    auto wait_one_stage_in_flight = [&]() {
-        if (kInstrA + my_b == 6) __builtin_amdgcn_s_waitcnt(kWaitVm0 | 6);
-        else if (kInstrA + my_b == 5) __builtin_amdgcn_s_waitcnt(kWaitVm0 | 5);
-        else __builtin_amdgcn_s_waitcnt(kWaitVm0 | 4);
+    if (grp == 1) advance_cursor();
+    // part `step` (0..KS-1) of the DMA of the stage under the cursor, issued in the shadow of the MFMAs of a k-step
+    auto issue_part = [&](int buf, int step) {
+        const uint32_t lbuf = lds_base + (uint32_t)buf * kStageBytes;
+        if (step == 0 && ld_s == 0 && lw == 0) {
+            // first stage of a block tile: also fetch the tile's 256 inverse norms (1 KiB, contiguous; rows past the
+            // end of the store read the zero-initialised padding of inv_norm)
+            dma16((uint64_t)(uintptr_t)a.inv_norm + (t_first + ld_bt * 8) * 128, vlane,
+                  lds_base + kMetaOff + ld_par * 1024);
+        }
+        const bool clamp = partial_last && ld_bt == n_bt - 1;  // rare: the last block tile has < 8 row tiles
+#pragma unroll
+        for (int x = 0; x < kPerStep; ++x) {
+            const int i = step * kPerStep + x;
+            if (i < kInstrA) {
+                uint64_t sa = ld_base + f_adr[i] + ld_koff;
+                if (clamp && t_first + ld_bt * 8 + a_tl[i] >= t_end)  // re-read a valid tile; its rows are masked later
+                    sa = (uint64_t)(uintptr_t)base + (t_end - 1) * tile_bytes + (f_adr[i] - (uint64_t)a_tl[i] * tile_bytes) + ld_koff;
+                dma16(sa, vlane, lbuf + f_lds[i]);
+            } else {
+                dma16(f_adr[i] + ld_koff, vlane, lbuf + f_lds[i]);
+            }
+        }
+        if (step == KS - 1) {  // this group's next stage is two stages further
+            advance_cursor();
+            advance_cursor();
+        }
     };
 
     // ---- per-lane epilogue constants: the 4 query columns of this lane
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
             fb[slot][j] = *reinterpret_cast<const h8*>(lb + (size_t)((wq * QT + j) * KS + ks) * 1024);
     };
     // the fragments of k-step 0 are already in fa[0] / fb[0] (issued before the DMA of the next stage)
-    auto compute = [&](int buf, bool first) {
+    auto compute = [&](int buf, bool first, bool prefetch, int pbuf) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + 1 < KS) load_frags(buf, ks + 1, (ks + 1) & 1);
@@ -288,23 +289,27 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
                     for (int j = 0; j < QT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
             }
+            if (prefetch) issue_part(pbuf, ks);  // in the shadow of the MFMAs just issued
         }
     };
 
-    // ---- pipeline: stage g lives in LDS buffer g % 3; its DMA was issued two iterations earlier
-    issue_stage(0);
-    if (total > 1) issue_stage(1);
+    // ---- pipeline: stage g lives in LDS buffer g % 3 and was loaded by wave group g & 1, which issued it while
+    // stage g - 2 was being multiplied.
+    static_assert(NBUF == 3, "ring of three stages: one being read, two being filled");
+    if ((uint64_t)grp < total) {
+#pragma unroll
+        for (int step = 0; step < KS; ++step) issue_part(grp, step);  // stage grp -> buffer grp
+    }
     uint64_t cp_bt = blockIdx.x;
     uint32_t cp_s = 0, cp_par = 0;
     int buf = 0;
     for (uint64_t g = 0; g < total; ++g) {
-        // my DMA of stage g has landed (the newer stage g+1 may still be in flight) ...
-        if (g + 1 < total) wait_one_stage_in_flight();
-        else __builtin_amdgcn_s_waitcnt(kWaitVm0);
-        __syncthreads();  // ... and everybody's; everybody is also done reading buffer (g+2) % 3 (stage g-1)
-        load_frags(buf, 0, 0);  // LDS latency of the first fragments overlaps the DMA issue below
-        if (g + 2 < total) issue_stage(buf == 0 ? 2 : buf - 1);  // (buf + 2) % 3
-        compute(buf, cp_s == 0);
+        const bool mine = ((uint32_t)g & 1u) == (uint32_t)grp;
+        if (mine) __builtin_amdgcn_s_waitcnt(kWaitVm0);  // my group's DMA of stage g (its only outstanding loads) landed
+        __syncthreads();  // ... everybody's did; everybody is also done reading the buffer of stage g-1
+        load_frags(buf, 0, 0);
+        // my group now refills the buffer stage g-1 just left with stage g+2: (buf + 2) % 3
+        compute(buf, cp_s == 0, mine && g + 2 < total, buf == 0 ? 2 : buf - 1);
         if (++cp_s == S) {
             epilogue(cp_bt, cp_par);
             cp_s = 0;
@@ -329,7 +334,7 @@ int launch_vec_scan_f16_wide(orama_ctx* ctx, const F16ScanArgs& a, void* d_query
     ORAMA_REQUIRE(!a.allow || a.row_doc, "vec_scan_f16_wide: filter needs row_doc");
     const uint32_t kpad = f16_kpad(a.dim);
     const uint32_t ksteps = kpad / 16;
-    ORAMA_REQUIRE(ksteps % KS == 0, "vec_scan_f16_wide: kpad %u not a multiple of %d", kpad, KS * 16);
+    ORAMA_REQUIRE(ksteps % 2 == 0, "vec_scan_f16_wide: kpad %u not a multiple of 32", kpad);
     char* bfrag = reinterpret_cast<char*>(d_query_frags);
     float* qinv = reinterpret_cast<float*>(bfrag + (size_t)8 * ksteps * 1024);
     if (prepare) {
@@ -339,29 +344,33 @@ int launch_vec_scan_f16_wide(orama_ctx* ctx, const F16ScanArgs& a, void* d_query
     }
     if (a.row_begin == a.row_end) return ORAMA_OK;
     ProfScope prof(&ctx->prof, "vec_scan_f16", stream);
-    static_assert(lds_bytes_for(4) <= 160 * 1024, "K2c LDS budget");
+    static_assert(lds_bytes_for(4, 3) <= 160 * 1024 && lds_bytes_for(4, 2) <= 160 * 1024, "K2c LDS budget");
     const uint64_t tiles = ((a.row_end + 31) >> 5) - (a.row_begin >> 5);
     uint64_t blocks = (tiles + 7) / 8;
     if (blocks > (uint64_t)ctx->compute_units) blocks = (uint64_t)ctx->compute_units;
-    if (a.q <= 128) {  // 2 query tiles per wave: half the MFMAs and half the query-fragment traffic
-        static bool attr2 = false;
-        if (!attr2) {
-            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_wide_kernel<2>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr2 = true;
-        }
-        hipLaunchKernelGGL((vec_scan_f16_wide_kernel<2>), dim3((uint32_t)blocks), dim3(kWB), lds_bytes_for(2), stream, a,
-                           (const char*)bfrag, (const float*)qinv, ksteps, f16_tile_bytes(a.dim));
+    const dim3 grid((uint32_t)blocks);
+    const uint64_t tile_bytes = f16_tile_bytes(a.dim);
+    // QT: 2 query tiles per wave up to 128 queries (half the MFMAs and half the query-fragment traffic), else 4
+#define ORAMA_WIDE_LAUNCH(QT_, KS_)                                                                                 \
+    do {                                                                                                            \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) {                                                                                           \
+            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_wide_kernel<QT_, KS_>),     \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));             \
+            attr_done = true;                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL((vec_scan_f16_wide_kernel<QT_, KS_>), grid, dim3(kWB), lds_bytes_for(QT_, KS_), stream, a, \
+                           (const char*)bfrag, (const float*)qinv, ksteps, tile_bytes);                             \
+    } while (0)
+    const bool ks3 = ksteps % 3 == 0;
+    if (a.q <= 128) {
+        if (ks3) ORAMA_WIDE_LAUNCH(2, 3);
+        else ORAMA_WIDE_LAUNCH(2, 2);
     } else {
-        static bool attr4 = false;
-        if (!attr4) {
-            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_wide_kernel<4>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr4 = true;
-        }
-        hipLaunchKernelGGL((vec_scan_f16_wide_kernel<4>), dim3((uint32_t)blocks), dim3(kWB), lds_bytes_for(4), stream, a,
-                           (const char*)bfrag, (const float*)qinv, ksteps, f16_tile_bytes(a.dim));
+        if (ks3) ORAMA_WIDE_LAUNCH(4, 3);
+        else ORAMA_WIDE_LAUNCH(4, 2);
     }
+#undef ORAMA_WIDE_LAUNCH
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

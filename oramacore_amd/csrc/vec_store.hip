@@ -274,7 +274,7 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
     const uint32_t kpad_k = f16_kpad(v->dim);
     for (uint32_t q0 = 0; q0 < q;) {
         // <= 64 queries: K2 (whole batch as LDS-resident B fragments); more: K2c (GEMM-tiled, <= 256 per pass)
-        const bool wide = v->ctx->f16_wide && (q - q0) > kF16MaxQ && (kpad_k / 16) % 3 == 0;
+        const bool wide = v->ctx->f16_wide && (q - q0) > kF16MaxQ && (kpad_k / 16) % 2 == 0;
         const uint32_t gq = std::min<uint32_t>(wide ? kF16WideMaxQ : kF16MaxQ, q - q0);
         if (wide) ORAMA_TRY(sc->f16_bfrag.reserve(f16_wide_query_bytes(v->dim)));
         bool wide_prepared = false;

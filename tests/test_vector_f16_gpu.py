@@ -143,10 +143,10 @@ def test_wide_batches_equal_solo_queries(ctx, d):
         st.delete(doc)
     bm = oa.AllowBitmap.from_mask((np.arange(2 * n + 2) % 7) != 3)
     queries = util.gaussian_rows(256, d, seed=60 + d)
-    for allow in (None, bm):
-        picks = (0, 31, 32, 64, 127, 128, 199, 255)
+    for allow in (None, bm, None, None):  # repeated: the K2c pipeline is asynchronous (LDS DMA ring) — catch races
+        picks = (0, 31, 32, 63, 64, 69, 96, 100, 127, 128, 160, 199, 224, 255)
         solo = {i: st.storage_search(queries[i], 30, allow) for i in picks}
-        for nq in (65, 200, 256):
+        for nq in (65, 70, 128, 129, 200, 256):
             ids, dist, cnt = st.storage_search(queries[:nq], 30, allow)
             assert cnt.tolist() == [30] * nq
             for i in picks:
