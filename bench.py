@@ -252,6 +252,11 @@ def main():
         flops = 2.0 * qb * n_local * kpad * args.steps
         out["roofline"]["mfma_tflops"] = flops / (scan_ms / 1e3) / 1e12 if scan_ms else 0.0
         out["roofline"]["mfma_peak_tflops_dense_f16"] = 2500.0
+        out["roofline"]["mfma_frac"] = out["roofline"]["mfma_tflops"] / 2500.0
+        if qb > 64:
+            out["roofline"]["note"] = ("K2c (GEMM-tiled, 256 queries per pass): the corpus crosses HBM once per batch and the "
+                                       "query fragments are re-read from L2 byte for byte as often; both share the CU's "
+                                       "L1-miss queue, so the HBM fraction alone understates the load (DESIGN.md K2c)")
 
     if rank == 0 and world == 1:
         # host-buffer API latency (adds the PCIe hop for the query and the k results)

@@ -14,6 +14,8 @@
 #include <shared_mutex>
 #include <unordered_map>
 
+#include <cstdlib>
+
 #include "common.hpp"
 #include "select.hpp"
 #include "vec_f16.hpp"
@@ -286,7 +288,11 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
         };
         const uint64_t s1 = std::min<uint64_t>(n, kS1);
         // super-chunk size: gq * (rows + k) * 8 B <= budget
-        uint64_t chunk_rows = kCandBudget / ((uint64_t)gq * 8);
+        static const uint64_t budget = [] {
+            const char* e = std::getenv("ORAMA_F16_CAND_MIB");
+            return e ? (uint64_t)std::strtoull(e, nullptr, 10) << 20 : kCandBudget;
+        }();
+        uint64_t chunk_rows = budget / ((uint64_t)gq * 8);
         chunk_rows = std::max<uint64_t>(chunk_rows & ~31ull, 1u << 20);
         const uint64_t rest = n > s1 ? n - s1 : 0;
         const uint64_t cand_stride = std::min<uint64_t>(rest, chunk_rows) + k;

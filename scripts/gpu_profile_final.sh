@@ -28,3 +28,12 @@ python scripts/pmc_summary.py $O/pmc_c2 vec_scan_f32_kernel 1536000000 > $O/pmc_
 python scripts/pmc_summary.py $O/pmc_c3 vec_scan_f16_kernel 7680000000 mean > $O/pmc_c3_vec_scan.json 2>$O/pmc_c3.err
 find $O -name "*.csv" -size +2M -delete; find $O -name "*.db" -delete
 du -sh $O; head -8 $O/ns_kernel_stats.md | cut -c1-200; cat $O/pmc_c2_vec_scan.json | head -30
+echo "== c5 per-GPU shard probe (10M x 768 fp16, Q = 64 / 128 / 256)"; timeout 300 python scripts/k2c_probe.py > $O/k2c_probe.log 2>&1; tail -3 $O/k2c_probe.log
+echo "== bench c5 on one GPU"; timeout 600 python bench.py --workload c5 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_c5_1gpu.json 2> $O/bench_c5.err; tail -c 300 $O/bench_c5_1gpu.json; echo
+echo "== batcher"; timeout 300 python scripts/bench_batcher.py --dtype f16 --threads 128 > $O/bench_batcher_f16.json 2>/dev/null; timeout 300 python scripts/bench_batcher.py --dtype f16 --threads 512 --per-thread 8 --max-batch 256 > $O/bench_batcher_f16_b256.json 2>/dev/null; timeout 300 python scripts/bench_batcher.py --dtype f32 --threads 32 --per-thread 10 --max-batch 16 > $O/bench_batcher_f32.json 2>/dev/null
+echo "== c4 / c1"; timeout 300 python scripts/bench_hybrid.py --steps 50 --warmup 5 > $O/bench_c4.json 2>/dev/null; timeout 200 python scripts/bench_c1.py > $O/bench_c1.json 2>/dev/null
+cd /tmp; echo "== rocprof c5 shard"; NQ=256 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c5 -o c5 -- python $R/scripts/k2c_probe.py > $O/rocprof_c5.log 2>&1; cd $R
+python scripts/rocpd_summary.py $(find $O/prof_c5 -name "*results.db" | head -1) > $O/c5_kernel_stats.md 2>/dev/null; find $O -name "*.db" -delete
+for f in bench_batcher_f16 bench_batcher_f16_b256 bench_batcher_f32; do python -c "
+import json,sys
+d=json.load(open('$O/$f.json')); print('$f', 'direct %.0f QPS'%d['direct_calls']['qps'], 'batched %.0f QPS'%d['through_batcher']['qps'], 'mean batch %.1f'%d['through_batcher']['mean_batch'], d['batched_equals_solo'])"; done
