@@ -65,3 +65,38 @@ def test_batcher_limits_and_errors(ctx):
         oa.SearchBatcher(st, max_batch=0)
     b.close()
     st.close()
+
+
+def test_wide_batches_through_the_batcher(ctx):
+    """max_batch > 64 on an fp16 store: batches of 65..256 requests take the GEMM-tiled pass (K2c) and every caller
+    still gets its solo answer."""
+    n, d, n_clients = 30000, 384, 160
+    st = oa.EmbeddingFieldStorage(ctx, dimensions=d, dtype=N.DTYPE_F16)
+    st.insert_rows(np.arange(n, dtype=np.uint64), util.gaussian_rows(n, d, seed=13))
+    queries = util.gaussian_rows(n_clients, d, seed=14)
+    solo = []
+    for i in range(n_clients):
+        ids, dist, cnt = st.storage_search(queries[i], 20)
+        solo.append((ids[0, :cnt[0]].copy(), dist[0, :cnt[0]].copy()))
+    b = oa.SearchBatcher(st, max_batch=256, max_wait_us=20000)
+    got = [None] * n_clients
+    errs = []
+
+    def client(i):
+        try:
+            got[i] = b.search(queries[i], 20)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=client, args=(i,)) for i in range(n_clients)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for i in range(n_clients):
+        assert got[i][0].tolist() == solo[i][0].tolist(), i
+        assert np.array_equal(got[i][1], solo[i][1]), i
+    assert b.stats()["largest_batch"] > 64
+    b.close()
+    st.close()
