@@ -281,6 +281,21 @@ int orama_post_search(orama_post* p, const orama_term_ref* refs, uint32_t n_refs
                       uint64_t bitmap_bits, int apply_omc, uint64_t* out_ids, float* out_scores,
                       uint32_t* out_n, uint64_t* out_count);
 
+/* ------------------------------------------------------------------ term-dictionary expansion
+ * The dictionary step of collect_contributions (third-party in the reference: an FST walked with a prefix /
+ * Levenshtein automaton).  Semantics as the reference's tests show them: `exact` -> the term itself; otherwise
+ * every term the token is a PREFIX of (src/tests/fulltext_search.rs:603-753) plus, with `tolerance` > 0, every term
+ * within that Levenshtein distance (:956-1018).  The sorted terms of one field live in HBM (blob + offsets[n+1],
+ * strictly ascending byte-wise); orama_dict_expand scans all of them in one kernel and returns the matching term
+ * indexes in ascending order.  out_n = number of matches; when it exceeds `capacity` only an arbitrary subset of
+ * `capacity` matches was written — retry with a larger buffer.  Distances are over bytes; tokens <= 64 bytes. */
+typedef struct orama_dict orama_dict;
+int orama_dict_create(orama_ctx* ctx, const uint8_t* blob, const uint32_t* offsets, uint32_t n_terms,
+                      orama_dict** out);
+void orama_dict_destroy(orama_dict* d);
+int orama_dict_expand(orama_dict* d, const uint8_t* token, uint32_t token_len, int exact, uint32_t tolerance,
+                      uint32_t capacity, uint32_t* out_terms, uint32_t* out_n);
+
 /* ------------------------------------------------------------------ hybrid
  * search_hybrid + normalize_and_combine — token_score.rs:357-422, then OMC + count + top-k.
  * vec_doc/vec_score: the vector result MAP after the a2 epilogue (<= limit entries, any order,

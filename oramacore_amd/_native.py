@@ -138,6 +138,8 @@ def _declare(lib: C.CDLL) -> None:
         "orama_vec_get_rows": [vp, vp, C.c_uint64, vp, vp],
         "orama_allow_create": [vp, vp, C.c_uint64, C.POINTER(vp)],
         "orama_allow_set": [vp, vp, C.c_uint64, C.c_int],
+        "orama_dict_create": [vp, vp, vp, C.c_uint32, C.POINTER(vp)],
+        "orama_dict_expand": [vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, vp, u32p],
         "orama_batcher_create": [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)],
         "orama_batcher_search": [vp, vp, C.c_uint32, vp, vp, u32p],
         "orama_batcher_stats": [vp, u64p, u64p, u32p],
@@ -178,7 +180,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.orama_post_block_bytes.argtypes = [C.c_uint32]
     lib.orama_post_block_bytes.restype = C.c_uint64
     for name in ("orama_ctx_destroy", "orama_vec_destroy", "orama_post_destroy", "orama_post_query_end",
-                 "orama_batcher_destroy", "orama_allow_destroy"):
+                 "orama_batcher_destroy", "orama_allow_destroy",
+                 "orama_dict_destroy"):
         fn = getattr(lib, name)
         fn.argtypes = [vp]
         fn.restype = None

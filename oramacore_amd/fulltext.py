@@ -413,3 +413,51 @@ class StagedQuery:
             self.end()
         except Exception:  # noqa: BLE001
             pass
+
+
+class TermDictionary:
+    """The sorted terms of one string field, resident in HBM (orama_dict_*): `expand` is the
+    dictionary step of collect_contributions — exact term, or every term the token prefixes plus, with `tolerance`,
+    every term within that Levenshtein distance (bytes) — as one device scan over all terms."""
+
+    def __init__(self, ctx: Context, terms):
+        self._lib = N.load()
+        self.terms = list(terms)
+        enc = [t.encode("utf-8") for t in self.terms]
+        if any(a >= b for a, b in zip(enc, enc[1:])):
+            raise ValueError("terms must be strictly ascending (byte order)")
+        blob = np.frombuffer(b"".join(enc), dtype=np.uint8) if enc else np.zeros(0, np.uint8)
+        off = np.zeros(len(enc) + 1, dtype=np.uint32)
+        if enc:
+            off[1:] = np.cumsum([len(e) for e in enc])
+        blob = np.ascontiguousarray(blob)
+        h = C.c_void_p()
+        N.check(self._lib.orama_dict_create(ctx.handle, blob.ctypes.data if blob.size else None, off.ctypes.data,
+                                            len(enc), C.byref(h)))
+        self._h = h
+
+    def expand(self, token: str, exact: bool = False, tolerance: int = 0) -> list[int]:
+        """Indexes (ascending) of the matching terms."""
+        tok = np.frombuffer(token.encode("utf-8"), dtype=np.uint8)
+        tok = np.ascontiguousarray(tok)
+        cap = 1024
+        while True:
+            out = np.zeros(cap, dtype=np.uint32)
+            n = C.c_uint32()
+            N.check(self._lib.orama_dict_expand(self._h, tok.ctypes.data if tok.size else None, tok.size,
+                                                1 if exact else 0, int(tolerance or 0), cap, out.ctypes.data,
+                                                C.byref(n)))
+            if n.value <= cap:
+                return out[: n.value].tolist()
+            cap = int(n.value)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.orama_dict_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

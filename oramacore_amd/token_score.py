@@ -23,7 +23,7 @@ import numpy as np
 
 from .context import Context
 from .embedding_field import AllowBitmap, EmbeddingFieldStorage, VectorSearchParams
-from .fulltext import B_DEFAULT, K1_DEFAULT, PostingList, PostingsStore, threshold_tokens
+from .fulltext import TermDictionary, B_DEFAULT, K1_DEFAULT, PostingList, PostingsStore, threshold_tokens
 
 
 # ----------------------------------------------------------------------------- modes (src/types.rs:838-940)
@@ -125,6 +125,11 @@ class Index:
         if self.omc:
             self._post.set_omc(self.omc)
         self._field_order = field_ids
+        # resident term dictionaries: the non-exact dictionary step (prefix / Levenshtein) runs on the device
+        for d in getattr(self, "_dicts", {}).values():
+            d.close()
+        self._dicts = {fid: TermDictionary(self.ctx, sorted(self._terms[fid], key=lambda t: t.encode("utf-8")))
+                       for fid in field_ids if self._terms.get(fid)}
 
     def lookup(self, field_id: int, token: str, exact: bool, tolerance: int | None = None) -> list[int]:
         """Dictionary step of collect_contributions (host side, third-party in the reference): the exact term, or
@@ -135,21 +140,12 @@ class Index:
         if exact:
             l = self._lists.get((field_id, token))
             return [] if l is None else [l]
-        import bisect
-
-        terms = self._terms.get(field_id, [])
-        hit = set()
-        i = bisect.bisect_left(terms, token)
-        while i < len(terms) and terms[i].startswith(token):
-            hit.add(terms[i])
-            i += 1
-        if tolerance:
-            for t in terms:
-                if t not in hit and abs(len(t) - len(token)) <= tolerance and _levenshtein_le(t, token, tolerance):
-                    hit.add(t)
+        d = self._dicts.get(field_id) if hasattr(self, "_dicts") else None
+        if d is None:
+            return []
         out = []
-        for t in sorted(hit):
-            l = self._lists.get((field_id, t))
+        for ti in d.expand(token, exact=False, tolerance=int(tolerance or 0)):  # ascending = dictionary order
+            l = self._lists.get((field_id, d.terms[ti]))
             if l is not None:
                 out.append(l)
         return out
