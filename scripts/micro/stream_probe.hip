@@ -35,13 +35,18 @@ __global__ __launch_bounds__(256) void vgpr_stream(const f4* __restrict__ src, s
     if (acc.x == 12345.678f) out[0] = acc.y + acc.z + acc.w;
 }
 
+template <bool NT>
 __device__ __forceinline__ void dma16(uint64_t saddr, uint32_t voff, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(saddr), "s"(lds_addr)
-                 : "memory", "m0");
+    if (NT)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff), "s"(saddr), "s"(lds_addr)
+                     : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(saddr), "s"(lds_addr)
+                     : "memory", "m0");
 }
 
 // each wave owns DEPTH KiB of LDS and keeps DEPTH 1-KiB DMA loads in flight; the data is read back with ds_read
-template <int DEPTH, bool CONSUME>
+template <int DEPTH, bool CONSUME, bool NT = false>
 __global__ __launch_bounds__(256) void dma_stream(const char* __restrict__ src, size_t n_kb, float* out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(256) void dma_stream(const char* __restrict__ src, 
         for (int i = 0; i < DEPTH; ++i) {
             const uint64_t ad = (uint64_t)(uintptr_t)src + (kb + i) * 1024;
             const uint32_t lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)ad), hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(ad >> 32));
-            dma16(((uint64_t)hi << 32) | lo, lane * 16, __builtin_amdgcn_readfirstlane((int)(lbase + i * 1024)));
+            dma16<NT>(((uint64_t)hi << 32) | lo, lane * 16, __builtin_amdgcn_readfirstlane((int)(lbase + i * 1024)));
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
         if (CONSUME) {
@@ -102,6 +107,10 @@ int main() {
         run(nm, bytes, [&] { hipLaunchKernelGGL((dma_stream<8, false>), dim3(grid), dim3(256), 4 * 8 * 1024, 0, src, n_kb, out); });
         snprintf(nm, sizeof nm, "dma depth8 + ds_read x%d blocks/CU", bpc);
         run(nm, bytes, [&] { hipLaunchKernelGGL((dma_stream<8, true>), dim3(grid), dim3(256), 4 * 8 * 1024, 0, src, n_kb, out); });
+        snprintf(nm, sizeof nm, "dma nt depth8 + ds_read x%d blocks/CU", bpc);
+        run(nm, bytes, [&] { hipLaunchKernelGGL((dma_stream<8, true, true>), dim3(grid), dim3(256), 4 * 8 * 1024, 0, src, n_kb, out); });
+        snprintf(nm, sizeof nm, "dma nt depth12 + ds_read x%d blocks/CU", bpc);
+        run(nm, bytes, [&] { hipLaunchKernelGGL((dma_stream<12, true, true>), dim3(grid), dim3(256), 4 * 12 * 1024, 0, src, n_kb, out); });
         if (bpc <= 2) {
             snprintf(nm, sizeof nm, "dma depth16 x%d blocks/CU", bpc);
             run(nm, bytes, [&] { hipLaunchKernelGGL((dma_stream<16, false>), dim3(grid), dim3(256), 4 * 16 * 1024, 0, src, n_kb, out); });
