@@ -239,3 +239,32 @@ class TokenScoreContext:
             raise TypeError(f"unknown score mode {type(m)}")
         hits = list(zip(ids.tolist(), sc.tolist()))[params.offset: params.offset + params.limit]
         return hits, count
+
+
+def search_on_indexes(contexts: list, params: TokenScoreParams):
+    """`Search::search_on_indexes` + the tail of `Search::execute` (src/collection_manager/sides/read/search.rs:
+    297-343, 481-500) over several indexes of one collection: every index scores on its own (BM25 statistics, the
+    hybrid min-max and the OMC multipliers are per index — token_score.rs:221, 492-500; index/mod.rs:1720-1739),
+    the per-index score maps are `extend`ed into one (DocumentIds are collection-unique, so nothing merges),
+    `count` is the size of that map and the hits are its top-(limit + offset) after skip(offset).take(limit).
+
+    The per-index maps never leave the GPU: an index hands back its own top-(limit + offset) and its map size; the
+    global top-(limit + offset) of a disjoint union is contained in the union of the per-index tops, so the final
+    cut over those (K4 again, `orama_top_n`) is exact."""
+    from . import fulltext as ft
+
+    top = params.limit + params.offset
+    per_index = TokenScoreParams(mode=params.mode, properties=params.properties, boost=params.boost, limit=top, offset=0,
+                                 filtered_doc_ids=params.filtered_doc_ids)
+    docs, scores, count = [], [], 0
+    for tsc in contexts:
+        hits, c = tsc.execute(per_index)
+        count += c
+        docs.extend(h[0] for h in hits)
+        scores.extend(h[1] for h in hits)
+    if not docs:
+        return [], count
+    ids, sc = ft.top_n(contexts[0].index.ctx, (np.asarray(docs, dtype=np.uint64), np.asarray(scores, dtype=np.float32)),
+                       top)
+    hits = list(zip(ids.tolist(), sc.tolist()))[params.offset: params.offset + params.limit]
+    return hits, count

@@ -273,3 +273,31 @@ def test_boost_ratio_bounds(ctx):
                 assert sc[d] / prev[d] < 2.0                 # saturating: doubling the boost less than doubles the score
             assert min(sc[d] / prev[d] for d in sc) > 1.05
         prev = sc
+
+
+def test_search_on_several_indexes(ctx):
+    """search.rs:297-343, 481-500: two indexes of one collection (disjoint DocumentIds, their own BM25 statistics
+    and OMC maps) — the merged result equals the oracle's per-index maps extended into one, then top-n."""
+    from oramacore_amd.token_score import search_on_indexes
+
+    docs_a = {i: {"text": "alpha beta " + "gamma " * (i % 4)} for i in range(0, 120)}
+    docs_b = {i: {"text": "beta gamma delta " + "alpha " * (i % 3)} for i in range(1000, 1090)}
+    idx_a, idx_b = make_index(ctx, docs_a), make_index(ctx, docs_b)
+    idx_b.omc = {1003: 5.0, 1010: 0.5}
+    idx_b.commit()
+    tscs = [TokenScoreContext(idx_a), TokenScoreContext(idx_b)]
+    for query, limit, offset in (("alpha gamma", 10, 0), ("beta", 25, 5), ("delta", 10, 0), ("absent", 10, 0)):
+        hits, count = search_on_indexes(tscs, TokenScoreParams(mode=FulltextMode(query), limit=limit, offset=offset))
+        toks = [t for t, _ in tscs[0].text_parser.tokenize_and_stem(query)]
+        all_d, all_s = [], []
+        for idx in (idx_a, idx_b):
+            od, os_ = oracle_fulltext(idx, toks, exact=False)
+            if idx.omc:
+                os_ = orc.apply_omc(od, os_, list(idx.omc), list(idx.omc.values()))
+            all_d.append(od)
+            all_s.append(os_)
+        od, os_ = np.concatenate(all_d), np.concatenate(all_s)
+        td, ts = orc.top_n(od, os_, limit + offset)
+        assert count == len(od)
+        assert [h[0] for h in hits] == td[offset:].tolist(), query
+        assert np.array_equal(np.array([h[1] for h in hits], dtype=np.float32).view(np.uint32), ts[offset:].view(np.uint32))
