@@ -68,7 +68,7 @@ int alloc_arrays(orama_vec* v, uint64_t cap, Arrays* a, hipStream_t s) {
     const size_t dead_words = (size_t)((cap + 31) / 32);
     ORAMA_HIP_TRY(hipMalloc(&a->rows, std::max<size_t>(256, v->matrix_bytes(cap))));
     // f16: K2c fetches the 256 inverse norms of a block tile with one 1-KiB DMA — pad to whole block tiles
-    const size_t norm_bytes = (size_t)(v->f16() ? ((cap + 255) & ~255ull) : cap) * sizeof(float);
+    const size_t norm_bytes = (size_t)(v->f16() ? ((cap + 255) & ~255ull) + 256 : cap) * sizeof(float);
     ORAMA_HIP_TRY(hipMalloc(&a->norm, std::max<size_t>(norm_bytes, 4)));
     ORAMA_HIP_TRY(hipMalloc(&a->doc, (size_t)cap * sizeof(uint64_t)));
     ORAMA_HIP_TRY(hipMalloc(&a->dead, dead_words * sizeof(uint32_t)));
@@ -293,7 +293,7 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
             return e ? (uint64_t)std::strtoull(e, nullptr, 10) << 20 : kCandBudget;
         }();
         uint64_t chunk_rows = budget / ((uint64_t)gq * 8);
-        chunk_rows = std::max<uint64_t>(chunk_rows & ~31ull, 1u << 20);
+        chunk_rows = std::max<uint64_t>(chunk_rows & ~255ull, 1u << 20);  // whole K2c block tiles (256 rows)
         const uint64_t rest = n > s1 ? n - s1 : 0;
         const uint64_t cand_stride = std::min<uint64_t>(rest, chunk_rows) + k;
         ORAMA_TRY(sc->dist.reserve((size_t)gq * (size_t)std::max<uint64_t>(s1, 1) * 4));
