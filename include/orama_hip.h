@@ -372,7 +372,8 @@ int orama_hybrid_rrf(orama_ctx* ctx, const uint64_t* vec_doc, const float* vec_s
                      uint32_t top_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count);
 
 /* ------------------------------------------------------------------ top-n
- * top_n — sort.rs:260-279 over an explicit (doc, score) list: NaN dropped, score desc, doc asc. */
+ * top_n — sort.rs:260-279 over an explicit (doc, score) list: NaN dropped, score desc, doc asc.
+ * (+0.0 and -0.0 tie, as NotNan<f32> compares them; a -0.0 score is returned as +0.0.) */
 int orama_top_n(orama_ctx* ctx, const uint64_t* doc, const float* score, uint64_t n, uint32_t top_k,
                 uint64_t* out_ids, float* out_scores, uint32_t* out_n);
 
