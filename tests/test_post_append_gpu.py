@@ -79,3 +79,59 @@ def test_append_validation(ctx):
     st.append(doc_ids[50:60], [10.0], [])
     assert st.info()["n_docs"] == 60
     st.close()
+
+
+def test_searches_concurrent_with_appends(ctx):
+    """update_data(&self) runs while searches hold the read lock (index/mod.rs:1436): searches issued while another
+    thread appends documents must each see a consistent store — the answer before or after an append, never a mix."""
+    import threading
+
+    n, T = 4000, 3
+    doc_ids, lens, terms = make_corpus(n, T, seed=33)
+    avg = float(lens.mean())
+    cuts = list(range(2000, n + 1, 250))
+    live = ft.PostingsStore(ctx)
+    live.build(doc_ids[:cuts[0]], [avg], lists_for(doc_ids, lens, terms, 0, cuts[0]))
+    # expected answers for every prefix length, from separately built stores
+    expected = {}
+    for hi in cuts:
+        ref = ft.PostingsStore(ctx)
+        ref.build(doc_ids[:hi], [avg], lists_for(doc_ids, lens, terms, 0, hi))
+        ids, sc, count = ref.search([(t, t, 1.0) for t in range(T)], T, float(n), 30)
+        expected[count] = (ids.tolist(), sc.view(np.uint32).tolist())
+        ref.close()
+    refs_now = [[(t, t, 1.0)] for t in range(T)]
+    lock = threading.Lock()
+    stop = threading.Event()
+    errors = []
+
+    def searcher():
+        while not stop.is_set():
+            with lock:
+                flat = [r for t in range(T) for r in refs_now[t]]
+            try:
+                ids, sc, count = live.search(flat, T, float(n), 30)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+                return
+            # refs may lag the store by one append (then the newest delta lists are simply not referenced yet):
+            # the count identifies which prefix was answered, and that answer must be exact
+            if count not in expected or expected[count] != (ids.tolist(), sc.view(np.uint32).tolist()):
+                errors.append(AssertionError(f"inconsistent answer for count {count}"))
+                return
+
+    threads = [threading.Thread(target=searcher) for _ in range(4)]
+    for th in threads:
+        th.start()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        first = live.append(doc_ids[a:b], [avg], lists_for(doc_ids, lens, terms, a, b))
+        with lock:
+            for t in range(T):
+                refs_now[t].append((t, first + t, 1.0))
+    stop.set()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:2]
+    ids, sc, count = live.search([r for t in range(T) for r in refs_now[t]], T, float(n), 30)
+    assert expected[count] == (ids.tolist(), sc.view(np.uint32).tolist()) and count == max(expected)
+    live.close()
