@@ -61,3 +61,12 @@ def test_product_never_imports_the_oracle():
         if re.search(r"\boracle\b|orama_oracle|liborama_oracle", t):
             offenders.append(str(p))
     assert not offenders, offenders
+
+
+def test_integration_doc_mentions_every_entry_point():
+    """INTEGRATION.md shows the binding (or says why none is needed) for every symbol the header declares."""
+    from oramacore_amd import _native
+
+    doc = (ROOT / "INTEGRATION.md").read_text()
+    missing = [s for s in _native.declared_symbols() if s not in doc]
+    assert not missing, missing
