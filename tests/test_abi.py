@@ -67,6 +67,6 @@ def test_integration_doc_mentions_every_entry_point():
     """INTEGRATION.md shows the binding (or says why none is needed) for every symbol the header declares."""
     from oramacore_amd import _native
 
-    doc = (ROOT / "INTEGRATION.md").read_text()
+    doc = (_build.ROOT / "INTEGRATION.md").read_text()
     missing = [s for s in _native.declared_symbols() if s not in doc]
     assert not missing, missing
