@@ -203,6 +203,18 @@ def main():
             od = orc.distances(rows, qv)
             err = float(np.max(np.abs(od - dst_h[mine])))
             assert err <= 1e-4, f"bench parity check failed: {err}"
+        # "no better row was missed": no row of a random sample of this rank's shard beats the reported k-th
+        # distance unless it is in the result (size-independent property, SURVEY §8c / tests/test_full_size_gpu.py)
+        srng = np.random.default_rng(1234 + qi)
+        sample = srng.choice(n_local, size=min(20_000, n_local), replace=False).astype(np.uint64)
+        srows, sdocs = store.get_rows(sample)
+        qv = queries_h[(total_b - 1) * qb + qi]
+        if f16:
+            qv = qv.astype(np.float16).astype(np.float32)
+        sd = orc.distances(srows, qv, threads=8)
+        inside = set(ids_h.tolist())
+        missed = [int(dd) for dd, x in zip(sdocs.tolist(), sd.tolist()) if x < dst_h[-1] - 2e-4 and int(dd) not in inside]
+        assert not missed, f"bench parity check failed: rows {missed[:5]} beat the reported k-th distance"
 
     kern = "vec_scan_f16" if f16 else "vec_scan_f32"
     scan_ms, scan_n = ctx.prof_get(kern)

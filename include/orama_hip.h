@@ -76,6 +76,19 @@ int orama_prof_enable(orama_ctx* ctx, int on);
 int orama_prof_reset(orama_ctx* ctx);
 int orama_prof_get(orama_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
 
+/* Raw HBM buffers for callers that drive the *_device entry points themselves (tests, bench.py, a shim that keeps
+ * queries / results resident): plain hipMalloc / hipMemcpy on the context's device — no torch, no other runtime.
+ * `offset` is in bytes.  Copies are synchronous with respect to the host. */
+int orama_dev_malloc(orama_ctx* ctx, uint64_t bytes, void** out);
+void orama_dev_free(orama_ctx* ctx, void* d_ptr);
+int orama_dev_upload(orama_ctx* ctx, void* d_dst, uint64_t offset, const void* src, uint64_t bytes);
+int orama_dev_download(orama_ctx* ctx, const void* d_src, uint64_t offset, void* dst, uint64_t bytes);
+/* HIP streams owned by the library (priority: 0 normal, 1 high — high-priority streams get their own hardware
+ * queues on ROCm, which keeps a launch-bound tail from queueing behind a corpus scan). */
+int orama_stream_create(orama_ctx* ctx, int high_priority, void** out_stream);
+void orama_stream_destroy(orama_ctx* ctx, void* stream);
+int orama_stream_synchronize(orama_ctx* ctx, void* stream);
+
 /* ------------------------------------------------------------------ vector store
  * Replaces oramacore_fields::embedding::EmbeddingStorage behind
  * EmbeddingFieldStorage (src/collection_manager/sides/read/index/embedding_field.rs:63-320). */

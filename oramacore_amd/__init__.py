@@ -5,6 +5,6 @@ include/orama_hip.h).  This Python package is the thin host-side mirror of the r
 interfaces for that path, used by the tests and bench.py.
 """
 from ._native import DTYPE_F16, DTYPE_F32, METRIC_COSINE, METRIC_L2SQ, OramaError  # noqa: F401
-from .context import Context  # noqa: F401
+from .context import Context, DeviceBuffer, Stream  # noqa: F401
 from .embedding_field import (AllowBitmap, EmbeddingFieldStorage, Model, ResidentAllowBitmap, SearchBatcher,
                               VectorSearchParams)  # noqa: F401

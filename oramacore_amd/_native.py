@@ -123,6 +123,11 @@ def _declare(lib: C.CDLL) -> None:
         "orama_prof_enable": [vp, C.c_int],
         "orama_prof_reset": [vp],
         "orama_prof_get": [vp, C.c_char_p, C.POINTER(C.c_double), u64p],
+        "orama_dev_malloc": [vp, C.c_uint64, C.POINTER(vp)],
+        "orama_dev_upload": [vp, vp, C.c_uint64, vp, C.c_uint64],
+        "orama_dev_download": [vp, vp, C.c_uint64, vp, C.c_uint64],
+        "orama_stream_create": [vp, C.c_int, C.POINTER(vp)],
+        "orama_stream_synchronize": [vp, vp],
         "orama_vec_create": [vp, C.c_uint32, C.c_int, C.c_int, C.c_uint64, C.POINTER(vp)],
         "orama_vec_insert": [vp, vp, vp, C.c_uint64, u64p],
         "orama_vec_delete": [vp, vp, C.c_uint64],
@@ -179,6 +184,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.orama_allow_token.restype = vp
     lib.orama_post_block_bytes.argtypes = [C.c_uint32]
     lib.orama_post_block_bytes.restype = C.c_uint64
+    for name in ("orama_dev_free", "orama_stream_destroy"):
+        fn = getattr(lib, name)
+        fn.argtypes = [vp, vp]
+        fn.restype = None
     for name in ("orama_ctx_destroy", "orama_vec_destroy", "orama_post_destroy", "orama_post_query_end",
                  "orama_batcher_destroy", "orama_allow_destroy",
                  "orama_dict_destroy"):

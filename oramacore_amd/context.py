@@ -65,3 +65,70 @@ class Context:
         n = C.c_uint64()
         N.check(self._lib.orama_prof_get(self.handle, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class DeviceBuffer:
+    """A raw HBM allocation (orama_dev_*): what callers of the *_device entry points pass as device pointers.
+    Plumbing for tests / bench.py — replaces the torch tensors used for this in round 1."""
+
+    def __init__(self, ctx: Context, nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        N.check(ctx._lib.orama_dev_malloc(ctx.handle, self.nbytes, C.byref(p)))
+        self._p = p
+
+    @property
+    def ptr(self) -> int:
+        if not self._p:
+            raise RuntimeError("device buffer already freed")
+        return self._p.value
+
+    def upload(self, array, offset: int = 0) -> "DeviceBuffer":
+        import numpy as np
+
+        a = np.ascontiguousarray(array)
+        assert offset + a.nbytes <= self.nbytes
+        N.check(self.ctx._lib.orama_dev_upload(self.ctx.handle, self._p, offset, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self, dtype, count: int, offset: int = 0):
+        import numpy as np
+
+        out = np.empty(count, dtype=dtype)
+        assert offset + out.nbytes <= self.nbytes
+        N.check(self.ctx._lib.orama_dev_download(self.ctx.handle, self._p, offset, out.ctypes.data, out.nbytes))
+        return out
+
+    def free(self) -> None:
+        if getattr(self, "_p", None):
+            self.ctx._lib.orama_dev_free(self.ctx.handle, self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class Stream:
+    """A HIP stream created by the library (orama_stream_*)."""
+
+    def __init__(self, ctx: Context, high_priority: bool = False):
+        self.ctx = ctx
+        p = C.c_void_p()
+        N.check(ctx._lib.orama_stream_create(ctx.handle, 1 if high_priority else 0, C.byref(p)))
+        self._p = p
+
+    @property
+    def ptr(self) -> int:
+        return self._p.value or 0
+
+    def synchronize(self) -> None:
+        N.check(self.ctx._lib.orama_stream_synchronize(self.ctx.handle, self._p))
+
+    def close(self) -> None:
+        if getattr(self, "_p", None):
+            self.ctx._lib.orama_stream_destroy(self.ctx.handle, self._p)
+            self._p = None

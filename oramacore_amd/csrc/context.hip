@@ -272,6 +272,61 @@ int orama_ctx_set_f16_tuning(orama_ctx* ctx, int ksteps_per_chunk, int ring_chun
     return ORAMA_OK;
 }
 
+int orama_dev_malloc(orama_ctx* ctx, uint64_t bytes, void** out) {
+    ORAMA_REQUIRE(ctx && out, "null argument");
+    *out = nullptr;
+    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_HIP_TRY(hipMalloc(out, bytes ? (size_t)bytes : 8));
+    return ORAMA_OK;
+}
+
+void orama_dev_free(orama_ctx* ctx, void* d_ptr) {
+    if (!ctx || !d_ptr) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipFree(d_ptr);
+}
+
+int orama_dev_upload(orama_ctx* ctx, void* d_dst, uint64_t offset, const void* src, uint64_t bytes) {
+    ORAMA_REQUIRE(ctx && (bytes == 0 || (d_dst && src)), "null argument");
+    if (bytes == 0) return ORAMA_OK;
+    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_HIP_TRY(hipMemcpy(static_cast<char*>(d_dst) + offset, src, (size_t)bytes, hipMemcpyHostToDevice));
+    return ORAMA_OK;
+}
+
+int orama_dev_download(orama_ctx* ctx, const void* d_src, uint64_t offset, void* dst, uint64_t bytes) {
+    ORAMA_REQUIRE(ctx && (bytes == 0 || (d_src && dst)), "null argument");
+    if (bytes == 0) return ORAMA_OK;
+    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_HIP_TRY(hipMemcpy(dst, static_cast<const char*>(d_src) + offset, (size_t)bytes, hipMemcpyDeviceToHost));
+    return ORAMA_OK;
+}
+
+int orama_stream_create(orama_ctx* ctx, int high_priority, void** out_stream) {
+    ORAMA_REQUIRE(ctx && out_stream, "null argument");
+    *out_stream = nullptr;
+    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    int lo = 0, hi = 0;  // numerically lower = higher priority
+    ORAMA_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    hipStream_t s = nullptr;
+    ORAMA_HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? hi : lo));
+    *out_stream = s;
+    return ORAMA_OK;
+}
+
+void orama_stream_destroy(orama_ctx* ctx, void* stream) {
+    if (!ctx || !stream) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamDestroy(static_cast<hipStream_t>(stream));
+}
+
+int orama_stream_synchronize(orama_ctx* ctx, void* stream) {
+    ORAMA_REQUIRE(ctx, "null ctx");
+    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return ORAMA_OK;
+}
+
 int orama_prof_enable(orama_ctx* ctx, int on) {
     ORAMA_REQUIRE(ctx, "null ctx");
     ctx->prof.on = on != 0;

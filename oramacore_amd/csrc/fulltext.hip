@@ -961,13 +961,58 @@ int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_
     ORAMA_REQUIRE(n_entries == 0 || entries, "null entries");
     ORAMA_REQUIRE(params->top_k == 0 || (out_ids && out_scores), "null output");
     ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    // The reference scorer accepts the same (doc, ntf) key several times for one token — add_field pushes onto a
+    // Vec per key (bm25.rs:355-366) and finalize sums them in push order — so a per_doc_ntf list may repeat a doc
+    // (a prefix / fuzzy expansion inside the third-party store could emit one pair per matched term).  The
+    // accumulate kernel gives every (token, doc) cell ONE writer per launch, so an entry whose docs repeat is split
+    // here into pieces with unique docs: occurrence number o of a doc goes to piece o, the pieces take the place of
+    // the entry in the token's rank order — the additions happen in exactly the reference's order.
+    struct Piece {
+        uint32_t token;
+        const uint64_t* doc;
+        const float* ntf;
+        uint64_t len;
+    };
+    std::vector<Piece> pieces;
+    std::vector<std::vector<uint64_t>> own_doc;  // storage of split entries (stable: reserved up front)
+    std::vector<std::vector<float>> own_ntf;
+    pieces.reserve(n_entries);
     uint64_t total = 0, max_id = 0;
     for (uint32_t e = 0; e < n_entries; ++e) {
         ORAMA_REQUIRE(entries[e].token < params->n_tokens, "entry %u: token out of range", e);
         ORAMA_REQUIRE(entries[e].len == 0 || (entries[e].doc && entries[e].ntf), "entry %u: null arrays", e);
         total += entries[e].len;
-        for (uint64_t i = 0; i < entries[e].len; ++i) max_id = std::max(max_id, entries[e].doc[i]);
+        bool ascending = true;  // strictly ascending docs are unique — the common case, one pass, no hashing
+        for (uint64_t i = 0; i < entries[e].len; ++i) {
+            max_id = std::max(max_id, entries[e].doc[i]);
+            if (i && entries[e].doc[i] <= entries[e].doc[i - 1]) ascending = false;
+        }
+        if (ascending) {
+            pieces.push_back(Piece{entries[e].token, entries[e].doc, entries[e].ntf, entries[e].len});
+            continue;
+        }
+        std::unordered_map<uint64_t, uint32_t> seen;
+        seen.reserve((size_t)entries[e].len);
+        std::vector<std::vector<uint64_t>> pd;
+        std::vector<std::vector<float>> pn;
+        for (uint64_t i = 0; i < entries[e].len; ++i) {
+            const uint32_t occ = seen[entries[e].doc[i]]++;
+            if (occ >= pd.size()) {
+                pd.emplace_back();
+                pn.emplace_back();
+            }
+            pd[occ].push_back(entries[e].doc[i]);
+            pn[occ].push_back(entries[e].ntf[i]);
+        }
+        for (size_t o = 0; o < pd.size(); ++o) {
+            own_doc.push_back(std::move(pd[o]));
+            own_ntf.push_back(std::move(pn[o]));
+            // the inner heap buffers do not move when the outer vectors grow
+            pieces.push_back(Piece{entries[e].token, own_doc.back().data(), own_ntf.back().data(),
+                                   (uint64_t)own_doc.back().size()});
+        }
     }
+    const uint32_t n_pieces = (uint32_t)pieces.size();
     ORAMA_REQUIRE(total < 0xffffffffull, "too many postings");
     if (total == 0) return ORAMA_OK;
     // local doc space: identity when ids are reasonably dense (the reference assigns sequential u64
@@ -976,7 +1021,7 @@ int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_
     const bool identity = max_id < 0xfffffff0ull && max_id <= 8 * total + (1u << 20);
     if (!identity) {
         docs.reserve((size_t)total);
-        for (uint32_t e = 0; e < n_entries; ++e) docs.insert(docs.end(), entries[e].doc, entries[e].doc + entries[e].len);
+        for (uint32_t e = 0; e < n_pieces; ++e) docs.insert(docs.end(), pieces[e].doc, pieces[e].doc + pieces[e].len);
         std::sort(docs.begin(), docs.end());
         docs.erase(std::unique(docs.begin(), docs.end()), docs.end());
     }
@@ -989,15 +1034,15 @@ int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_
     ORAMA_TRY(prepare_query(sc.s.get(), n_docs, params->n_tokens, touched_cap, (uint32_t)total, &qb));
 
     // pack postings (local doc, ntf bits) + segments grouped by rank + doc table
-    std::vector<uint32_t> rank(n_entries, 0), per_token(kMaxTokens, 0);
+    std::vector<uint32_t> rank(n_pieces, 0), per_token(kMaxTokens, 0);
     uint32_t max_rank = 0;
-    for (uint32_t e = 0; e < n_entries; ++e) {
-        rank[e] = per_token[entries[e].token]++;
+    for (uint32_t e = 0; e < n_pieces; ++e) {
+        rank[e] = per_token[pieces[e].token]++;
         max_rank = std::max(max_rank, rank[e] + 1);
     }
     const size_t post_bytes = (size_t)total * 4;
     const size_t seg_off = ((2 * post_bytes) + 15) & ~(size_t)15;
-    const size_t doc_off = (seg_off + (size_t)n_entries * sizeof(Bm25Seg) + 15) & ~(size_t)15;
+    const size_t doc_off = (seg_off + (size_t)n_pieces * sizeof(Bm25Seg) + 15) & ~(size_t)15;
     const size_t omc_off = doc_off + (size_t)n_docs * 8;
     const size_t all_bytes = omc_off + (size_t)n_omc * 8;
     ORAMA_TRY(sc->h_in.reserve(all_bytes + 64));
@@ -1014,30 +1059,28 @@ int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_
     for (uint32_t r = 0; r < max_rank; ++r) {
         rank_begin[r] = nseg;
         uint64_t virt = 0;
-        for (uint32_t e = 0; e < n_entries; ++e) {
-            if (rank[e] != r || entries[e].len == 0) continue;
+        for (uint32_t e = 0; e < n_pieces; ++e) {
+            if (rank[e] != r || pieces[e].len == 0) continue;
             Bm25Seg g{};
             g.post_begin = cursor;
             g.virt_begin = virt;
-            g.len = (uint32_t)entries[e].len;
-            g.token = entries[e].token;
+            g.len = (uint32_t)pieces[e].len;
+            g.token = pieces[e].token;
             g.boost = 1.0f;
             g.avg_len = 1.0f;
-            uint64_t prev = 0;
-            for (uint64_t i = 0; i < entries[e].len; ++i) {
-                const uint64_t d = entries[e].doc[i];
+            for (uint64_t i = 0; i < pieces[e].len; ++i) {
+                const uint64_t d = pieces[e].doc[i];
                 uint32_t local;
                 if (identity) {
                     local = (uint32_t)d;
                 } else {
                     local = (uint32_t)(std::lower_bound(docs.begin(), docs.end(), d) - docs.begin());
                 }
-                (void)prev;
                 h_pd[cursor + i] = local;
-                memcpy(&h_pv[cursor + i], &entries[e].ntf[i], 4);
+                memcpy(&h_pv[cursor + i], &pieces[e].ntf[i], 4);
             }
-            cursor += entries[e].len;
-            virt += entries[e].len;
+            cursor += pieces[e].len;
+            virt += pieces[e].len;
             h_seg[nseg++] = g;
         }
         rank_total[r] = virt;

@@ -137,9 +137,14 @@ class Index:
         "christopher") — plus, with `tolerance`, every term within that Levenshtein distance of the token —
         src/tests/fulltext_search.rs:956-1018 ("Mxin" finds "Main Street" with tolerance 1).  List order: dictionary
         (lexicographic) order of the terms."""
+        return [l for l, _ in self.lookup_terms(field_id, token, exact, tolerance)]
+
+    def lookup_terms(self, field_id: int, token: str, exact: bool, tolerance: int | None = None) -> list[tuple]:
+        """`lookup` with the match kind: [(list id, term == token)] — the caller folds the exact-match boost into the
+        reference's `boost` of the lists whose term IS the token (SURVEY §8c assumption 3)."""
         if exact:
             l = self._lists.get((field_id, token))
-            return [] if l is None else [l]
+            return [] if l is None else [(l, True)]
         d = self._dicts.get(field_id) if hasattr(self, "_dicts") else None
         if d is None:
             return []
@@ -147,21 +152,8 @@ class Index:
         for ti in d.expand(token, exact=False, tolerance=int(tolerance or 0)):  # ascending = dictionary order
             l = self._lists.get((field_id, d.terms[ti]))
             if l is not None:
-                out.append(l)
+                out.append((l, d.terms[ti] == token))
         return out
-
-
-def _levenshtein_le(a: str, b: str, k: int) -> bool:
-    """Levenshtein(a, b) <= k (plain DP; dictionary terms are short)."""
-    prev = list(range(len(b) + 1))
-    for i, ca in enumerate(a, 1):
-        cur = [i] + [0] * len(b)
-        for j, cb in enumerate(b, 1):
-            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb))
-        if min(cur) > k:
-            return False
-        prev = cur
-    return prev[-1] <= k
 
 
 @dataclass
@@ -171,14 +163,23 @@ class TokenScoreParams:
     boost: dict = field(default_factory=dict)    # field_id -> boost
     limit: int = 10                              # Limit default 10, types.rs:748-754
     offset: int = 0
+    # `limit_hint` (token_score.rs:488,497 <- search.rs:334 `limit_hint: score_params.limit`): the k of the vector
+    # leg is the REQUEST's limit, never limit + offset; None = `limit`
+    limit_hint: Optional[int] = None
     filtered_doc_ids: Optional[AllowBitmap] = None
 
 
 class TokenScoreContext:
-    def __init__(self, index: Index, embed: Callable[[str, object], np.ndarray] | None = None, tokenizer=None):
+    def __init__(self, index: Index, embed: Callable[[str, object], np.ndarray] | None = None, tokenizer=None,
+                 exact_match_boost: float = 1.0):
         self.index = index
         self.embed = embed
         self.text_parser = tokenizer or SimpleTokenizer()
+        # The third-party store folds an exact-match boost into ntf (comments token_score.rs:182-185, 226-228); its
+        # value is not visible in this checkout (SURVEY §8c assumption 3), so it is a parameter: the factor applied
+        # to postings of the dictionary term that equals the query token (prefix / fuzzy expansions keep 1.0).  It
+        # reaches the device through orama_term_ref.boost (= field boost x this factor).  Default 1.0.
+        self.exact_match_boost = float(exact_match_boost)
 
     # token_score.rs:196-209
     def _tokens(self, term: str, exact: bool) -> list[str]:
@@ -192,8 +193,11 @@ class TokenScoreContext:
         refs = []
         for ti, tok in enumerate(tokens):
             for fid in fields:
-                for l in self.index.lookup(fid, tok, exact, tolerance):
-                    refs.append((ti, l, float(boost.get(fid, 1.0))))
+                for l, is_exact_term in self.index.lookup_terms(fid, tok, exact, tolerance):
+                    bo = np.float32(boost.get(fid, 1.0))
+                    if is_exact_term and self.exact_match_boost != 1.0:
+                        bo = np.float32(bo * np.float32(self.exact_match_boost))
+                    refs.append((ti, l, float(bo)))
         return refs
 
     # token_score.rs:186-303 (+ OMC, count, top-(limit+offset) fused)
@@ -211,7 +215,8 @@ class TokenScoreContext:
         for fid in sorted(self.index.embedding_fields):
             ef = self.index.embedding_fields[fid]
             target = self.embed(mode.term, ef.model())
-            ef.search(VectorSearchParams(target=target, similarity=mode.similarity, limit=params.limit,
+            limit_hint = params.limit if params.limit_hint is None else params.limit_hint
+            ef.search(VectorSearchParams(target=target, similarity=mode.similarity, limit=limit_hint,
                                          filtered_doc_ids=params.filtered_doc_ids), output)
         return output
 
@@ -254,8 +259,11 @@ def search_on_indexes(contexts: list, params: TokenScoreParams):
     from . import fulltext as ft
 
     top = params.limit + params.offset
+    # every index returns its own top-(limit + offset); the vector leg keeps the request's limit (limit_hint,
+    # search.rs:334 / token_score.rs:339-344) — with offset > 0 the two differ
     per_index = TokenScoreParams(mode=params.mode, properties=params.properties, boost=params.boost, limit=top, offset=0,
-                                 filtered_doc_ids=params.filtered_doc_ids)
+                                 filtered_doc_ids=params.filtered_doc_ids,
+                                 limit_hint=params.limit if params.limit_hint is None else params.limit_hint)
     docs, scores, count = [], [], 0
     for tsc in contexts:
         hits, c = tsc.execute(per_index)

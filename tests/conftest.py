@@ -15,10 +15,18 @@ def pytest_configure(config):
 
 
 def _has_gpu() -> bool:
+    # device discovery through the product library itself (no torch import: it costs minutes on a fresh box)
     try:
-        import torch  # plumbing only: device discovery
+        import ctypes as C
 
-        return torch.cuda.is_available()
+        from oramacore_amd import _native as N
+
+        lib = N.load()
+        h = C.c_void_p()
+        if lib.orama_ctx_create(0, C.byref(h)) != 0:
+            return False
+        lib.orama_ctx_destroy(h)
+        return True
     except Exception:  # noqa: BLE001
         return os.path.exists("/dev/kfd")
 

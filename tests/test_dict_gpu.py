@@ -5,7 +5,7 @@ import pytest
 
 import oramacore_amd as oa
 from oramacore_amd import fulltext as ft
-from oramacore_amd.token_score import _levenshtein_le
+from util import levenshtein_le
 
 pytestmark = pytest.mark.gpu
 
@@ -17,7 +17,7 @@ def host_expand(terms, token, exact, tolerance):
             hit = t == token
         else:
             hit = t.startswith(token) or (tolerance > 0 and abs(len(t) - len(token)) <= tolerance
-                                           and _levenshtein_le(t, token, tolerance))
+                                           and levenshtein_le(t, token, tolerance))
         if hit:
             out.append(i)
     return out

@@ -107,3 +107,129 @@ def test_c4_full_size_bm25_bit_exact(ctx):
         ids2, sc2, count2 = post.search(refs, T, float(n), k)                    # idempotence (epoch-stamped scratch)
         assert count2 == count and ids2.tolist() == ids.tolist() and np.array_equal(sc2, sc)
     post.close()
+
+
+def _sample_property(st, ids_row, dist_row, q, n, seed, size=50_000):
+    """No row of a random sample is better than the reported k-th distance unless it is in the result."""
+    rng = np.random.default_rng(seed)
+    sample = rng.choice(n, size=size, replace=False).astype(np.uint64)
+    srows, _ = st.get_rows(sample)
+    sd = orc.distances(srows, q, threads=8)
+    inside = set(ids_row.tolist())
+    worse = sd >= dist_row[-1] - 2 * TOL
+    bad = [int(r) for w, r in zip(worse.tolist(), sample.tolist()) if not w and int(r) not in inside]
+    assert not bad, f"rows clearly inside the top-k are missing: {bad[:5]}"
+
+
+def test_c5_per_gpu_shard_fp16_wide_batch256(ctx):
+    """BASELINE configs[4], the shape ONE of the 8 GPUs runs: 10 M x 768 fp16 rows, a batch of 256 queries in one
+    corpus pass (K2c: global->LDS DMA ring + register-blocked MFMA tiles), per-query top-100, then the exchange
+    tail of the sharded path — packed candidate blocks of 8 (emulated) shards -> K6 merge.
+
+    Checks: sorted + complete; reported distances equal the oracle's on the rows read back (1e-4, the oracle scores
+    the fp16-rounded query against the stored fp16 rows); the 50 K-row sample property; planted exact matches on
+    top; THREE repetitions bit-identical (the DMA ring has no ordering slack to hide a race behind); wide batch ==
+    solo queries (K2); shard/merge identity through the packed C-ABI entry points."""
+    n, d, k, Q = 10_000_000, 768, 100, 256
+    lib = N.load()
+    st = oa.EmbeddingFieldStorage(ctx, dimensions=d, reserve_rows=n + 64, dtype=N.DTYPE_F16)
+    st.fill_synthetic(n, seed=0xC0FFEE)
+    qs = util.gaussian_rows(Q, d, seed=0xBEEF)
+    plant = np.stack([qs[0] * np.float32(s) for s in (0.5, 1.0, 3.0)] + [qs[255] * np.float32(2.0)])
+    st.insert_rows(np.arange(n, n + 4, dtype=np.uint64), plant)
+    n_all = n + 4
+    ids, dist, cnt = st.storage_search(qs, k)
+    assert cnt.tolist() == [k] * Q and np.all(np.diff(dist, axis=1) >= 0)
+    assert sorted(ids[0, :3].tolist()) == [n, n + 1, n + 2] and np.all(np.abs(dist[0, :3]) < 2e-3)
+    assert ids[255, 0] == n + 3 and abs(dist[255, 0]) < 2e-3
+    for rep in range(3):                                                  # pipeline races would show here
+        ids2, dist2, cnt2 = st.storage_search(qs, k)
+        assert np.array_equal(ids, ids2) and np.array_equal(dist, dist2), f"repetition {rep} differs"
+    qh = qs.astype(np.float16).astype(np.float32)                        # what the fp16 path scores
+    for j in (0, 1, 63, 64, 127, 128, 200, 255):
+        rows, docs = st.get_rows(ids[j])
+        assert np.array_equal(docs, ids[j])
+        assert np.max(np.abs(orc.distances(rows, qh[j]) - dist[j])) <= TOL, j
+    for j in (5, 130, 254):
+        _sample_property(st, ids[j], dist[j], qh[j], n, seed=100 + j)
+    for j in (0, 77, 255):                                                # K2c batch == K2 solo, bit for bit
+        si, sd, sc = st.storage_search(qs[j], k)
+        assert np.array_equal(ids[j], si[0]) and np.array_equal(dist[j], sd[0]), j
+
+    # ---- the exchange tail of the sharded path through the C ABI: 8 shards emulated by doc-id residues, each
+    # writes its packed block [q*k ids][q*k dist] into its slot of the "all-gathered" buffer, K6 merges them
+    G = 8
+    nb = lib.orama_packed_block_bytes(Q, k)
+    assert nb == (Q * k * 12 + 7) // 8 * 8
+    d_q = oa.DeviceBuffer(ctx, qs.nbytes).upload(qs)
+    d_blocks = oa.DeviceBuffer(ctx, G * nb)
+    d_n = oa.DeviceBuffer(ctx, Q * 4)
+    d_oi, d_od, d_on = oa.DeviceBuffer(ctx, Q * k * 8), oa.DeviceBuffer(ctx, Q * k * 4), oa.DeviceBuffer(ctx, Q * 4)
+    for g in range(G):
+        bm = oa.AllowBitmap.from_mask(np.arange(n_all) % G == g).to_device(ctx)
+        tok, bits = bm.ffi_args()
+        N.check(lib.orama_vec_search_packed_device(st.handle, d_q.ptr, Q, k, tok, bits, d_blocks.ptr + g * nb,
+                                                   d_n.ptr, None))
+        ctx.synchronize()
+        assert d_n.download(np.uint32, Q).tolist() == [k] * Q
+        bm.close()
+    N.check(lib.orama_merge_packed_device(ctx.handle, d_blocks.ptr, G, Q, k, d_oi.ptr, d_od.ptr, d_on.ptr, None))
+    ctx.synchronize()
+    m_ids = d_oi.download(np.uint64, Q * k).reshape(Q, k)
+    m_dist = d_od.download(np.float32, Q * k).reshape(Q, k)
+    assert d_on.download(np.uint32, Q).tolist() == [k] * Q
+    assert np.array_equal(m_ids, ids) and np.array_equal(m_dist, dist)
+    for b in (d_q, d_blocks, d_n, d_oi, d_od, d_on):
+        b.free()
+    st.close()
+
+
+def test_c4_full_size_hybrid_bit_exact(ctx):
+    """BASELINE configs[3] at full size through ONE call (orama_hybrid_search: vector leg and BM25F leg on two HIP
+    streams, a2 epilogue inside the library, K5 combine, OMC, count, K4): 10 M documents, 12-token queries
+    (~600 K postings) + 10 M x 768 fp32 rows.  The result must equal the oracle pipeline bit for bit GIVEN the
+    device's vector hits (whose distances are themselves checked against the oracle on the stored rows, 1e-4, and
+    by the sample property): normalize_and_combine -> apply_omc -> top_n, ids / scores / count."""
+    n, d, k, T = 10_000_000, 768, 100, 12
+    vec = oa.EmbeddingFieldStorage(ctx, dimensions=d, reserve_rows=n)
+    vec.fill_synthetic(n, seed=0xC0FFEE)
+    rng = np.random.default_rng(0xB26)
+    ranks = np.unique(np.exp(rng.uniform(np.log(100), np.log(100000), size=256)).astype(np.uint32))
+    post = ft.PostingsStore(ctx)
+    post.fill_synthetic(n, ranks, seed=0xB25)
+    avg = np.float32(post.info()["avg_field_length"])
+    omc_docs = rng.choice(n, size=2000, replace=False).astype(np.uint64)
+    omc = {int(dd): float(m) for dd, m in zip(omc_docs, rng.choice([0.25, 0.5, 2.0, 5.0, 10.0], size=2000))}
+    post.set_omc(omc)
+    qv = util.gaussian_rows(3, d, seed=0xBEEF)
+    for trial in range(3):
+        ql = rng.choice(len(ranks), size=T, replace=False)
+        refs = [(t, int(l), 1.0) for t, l in enumerate(ql)]
+        apply_omc = trial != 0
+        sim_min = 0.0 if trial < 2 else 0.02
+        h_ids, h_sc, h_count = post.hybrid_search(vec, qv[trial], k, sim_min, refs, T, float(n), k,
+                                                  apply_omc=apply_omc)
+        # oracle: full-text map from the stored postings
+        entries = []
+        for t, l in enumerate(ql):
+            d_, tf, ln = post.get_list(int(l))
+            ntf = (tf.astype(np.float32) / (np.float32(0.25) + np.float32(0.75) * (ln.astype(np.float32) / avg))
+                   ).astype(np.float32)
+            entries.append((t, d_, np.float32(1.0) * ntf))
+        od, os_ = orc.search_full_text(entries, T, float(n), 1.2, None)
+        # vector leg: the device's hits, validated against the oracle on the rows read back
+        v_ids, v_dist, v_cnt = vec.storage_search(qv[trial], k)
+        assert v_cnt[0] == k
+        rows, _ = vec.get_rows(v_ids[0])
+        assert np.max(np.abs(orc.distances(rows, qv[trial]) - v_dist[0])) <= TOL
+        _sample_property(vec, v_ids[0], v_dist[0], qv[trial], n, seed=7 + trial, size=20_000)
+        vmap = orc.embedding_epilogue(v_ids[0], v_dist[0], False, sim_min)
+        cd, cs = orc.normalize_and_combine(list(vmap), list(vmap.values()), od, os_)
+        if apply_omc:
+            cs = orc.apply_omc(cd, cs, list(omc), list(omc.values()))
+        td, ts = orc.top_n(cd, cs, k)
+        assert h_count == len(cd), trial
+        assert h_ids.tolist() == td.tolist(), trial
+        assert np.array_equal(h_sc.view(np.uint32), ts.view(np.uint32)), trial
+    post.close()
+    vec.close()

@@ -301,3 +301,53 @@ def test_search_on_several_indexes(ctx):
         assert count == len(od)
         assert [h[0] for h in hits] == td[offset:].tolist(), query
         assert np.array_equal(np.array([h[1] for h in hits], dtype=np.float32).view(np.uint32), ts[offset:].view(np.uint32))
+
+
+def test_hybrid_on_several_indexes_with_offset(ctx):
+    """search.rs:334 `limit_hint: score_params.limit` → token_score.rs:339-344/488/497: with offset > 0 the vector
+    leg of every index still asks the storage for `limit` rows (NOT limit + offset); only the final cut uses
+    limit + offset.  Two indexes, hybrid mode, offset 7: candidate set, count, per-index min/max and therefore every
+    score must equal the oracle pipeline run with k = limit."""
+    from oramacore_amd.token_score import search_on_indexes
+
+    dim = 384
+    embed = fake_embed(dim)
+    q = embed("red blue", None)
+    rng = np.random.default_rng(21)
+    tscs, per_index = [], []
+    for base, n in ((0, 150), (5000, 90)):
+        docs = {base + i: {"text": ("red " * (i % 3 + 1)) + ("blue " if i % 2 else "") + f"w{i}"} for i in range(n)}
+        idx = make_index(ctx, docs)
+        ef = oa.EmbeddingFieldStorage(ctx, oa.Model.BGESmall)
+        rows = []
+        for i in range(n):
+            noise = rng.standard_normal(dim).astype(np.float32)
+            w = np.float32(0.9 - 0.004 * i)
+            rows.append(w * q / np.linalg.norm(q) + (1 - w) * noise / np.linalg.norm(noise))
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        row_doc = np.arange(base, base + n, dtype=np.uint64)
+        ef.insert_rows(row_doc, rows)
+        idx.embedding_fields[0] = ef
+        tscs.append(TokenScoreContext(idx, embed=embed))
+        per_index.append((idx, ef, rows, row_doc))
+    limit, offset = 6, 7
+    hits, count = search_on_indexes(tscs, TokenScoreParams(mode=HybridMode("red blue", similarity=0.0), limit=limit,
+                                                           offset=offset))
+    all_d, all_s = [], []
+    for idx, ef, rows, row_doc in per_index:
+        o_ids, o_dist, _ = orc.vector_search(rows, row_doc, q, limit)      # k = limit, not limit + offset
+        vmap = orc.embedding_epilogue(o_ids, o_dist, False, 0.0)
+        fd, fs = oracle_fulltext(idx, ["red", "blue"], exact=False)
+        cd, cs = orc.normalize_and_combine(list(vmap), list(vmap.values()), fd, fs)
+        all_d.append(np.asarray(cd, dtype=np.uint64))
+        all_s.append(np.asarray(cs, dtype=np.float32))
+    od, os_ = np.concatenate(all_d), np.concatenate(all_s)
+    td, ts = orc.top_n(od, os_, limit + offset)
+    assert count == len(od)
+    assert [h[0] for h in hits] == td[offset:].tolist()
+    got = np.array([h[1] for h in hits], dtype=np.float32)
+    # the vector similarities come from the device scan (tree-reduced dot products): 1e-4 on the cosine, the
+    # min-max normalisation keeps that scale
+    assert np.max(np.abs(got - ts[offset:])) <= 2e-4
+    for _, ef, _, _ in per_index:
+        ef.close()

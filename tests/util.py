@@ -76,3 +76,16 @@ def assert_topk_sound(got_rows, got_val, all_val, k: int, tol: float, what: str 
     must = np.nonzero(valid & (all_val < kth - 2 * tol))[0]
     missing = set(must.tolist()) - set(got_rows.tolist())
     assert not missing, f"{what}: rows clearly inside the top-k are missing: {sorted(missing)[:5]}"
+
+
+def levenshtein_le(a: str, b: str, k: int) -> bool:
+    """Levenshtein(a, b) <= k (plain DP; dictionary terms are short)."""
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i] + [0] * len(b)
+        for j, cb in enumerate(b, 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb))
+        if min(cur) > k:
+            return False
+        prev = cur
+    return prev[-1] <= k
