@@ -68,6 +68,9 @@ int orama_ctx_device_info(orama_ctx* ctx, char* name256, int* compute_units, uin
 int orama_ctx_set_scan_tuning(orama_ctx* ctx, int rows_per_wave, int blocks_per_cu, int nontemporal);
 /* Register-ring geometry of the K2 fp16 scan: k-steps per chunk (8/12/16) and chunks in the ring (2..4). */
 int orama_ctx_set_f16_tuning(orama_ctx* ctx, int ksteps_per_chunk, int ring_chunks);
+/* Kernel used for fp16 batches of 65..256 queries per corpus pass: 0 = K2 in passes of 64, 1 = K2c (MFMA waves also
+ * issue the LDS-DMA), 2 / 3 = K2d producer/consumer kernel, geometry 1 / 2 (vec_f16_pc.hip).  Default 2. */
+int orama_ctx_set_f16_wide(orama_ctx* ctx, int mode);
 
 /* Per-kernel HIP-event timing (used by bench.py's roofline leg).  When enabled, the library
  * brackets each launch of the named hot kernels with hipEvents on the launching stream.

@@ -179,7 +179,9 @@ struct orama_ctx {
     // bitonic reduction of the wave lists costs more than the dense radix select — so it is off by default.
     int fused_topk = 0;
     int f32_multi = 1;   // K1b: fp32 batches of 2..8 queries share one corpus pass (ORAMA_F32_MULTI=0 disables)
-    int f16_wide = 1;    // K2c: fp16 batches of 65..256 queries share one corpus pass (ORAMA_F16_WIDE=0: 64 per pass)
+    // fp16 batches of 65..256 queries share one corpus pass: 2 = K2d (dedicated loader waves, default), 3 = K2d second
+    // geometry, 1 = K2c (round 1: MFMA waves issue the DMA), 0 = K2 in passes of 64 (ORAMA_F16_WIDE)
+    int f16_wide = 2;
     int f16_kc = 8, f16_nbuf = 3;   // K2 register ring: k-steps per chunk, chunks (ORAMA_F16_KC / ORAMA_F16_NBUF)
     int compute_units = 0;
     uint64_t hbm_bytes = 0;

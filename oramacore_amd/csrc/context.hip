@@ -327,6 +327,13 @@ int orama_stream_synchronize(orama_ctx* ctx, void* stream) {
     return ORAMA_OK;
 }
 
+int orama_ctx_set_f16_wide(orama_ctx* ctx, int mode) {
+    ORAMA_REQUIRE(ctx, "null ctx");
+    ORAMA_REQUIRE(mode >= 0 && mode <= 3, "f16 wide mode %d outside [0, 3]", mode);
+    ctx->f16_wide = mode;
+    return ORAMA_OK;
+}
+
 int orama_prof_enable(orama_ctx* ctx, int on) {
     ORAMA_REQUIRE(ctx, "null ctx");
     ctx->prof.on = on != 0;

@@ -72,9 +72,10 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
             const float x = (float)reinterpret_cast<const _Float16*>(lds + (size_t)((ks * NQT + qt) * 64 + l) * 16)[e];
             ss = fmaf(x, x, ss);
         }
-        qinv[j] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+        qinv[j] = a.metric == ORAMA_METRIC_L2SQ ? ss : (ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f);
     }
     __syncthreads();
+    const bool l2 = a.metric == ORAMA_METRIC_L2SQ;
 
     // ---- tiles of this wave
     const uint32_t gw = uniform_u32(blockIdx.x * kWavesPerBlock + (tid >> 6));
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
                     excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
                 }
                 const float inv = hi_half ? nrm_s[i0 + 4] : nrm_s[i0];
-                const float dist = 1.0f - acc[qt][r] * (inv * qi);
+                const float dist = l2 ? (qi + inv) - 2.0f * acc[qt][r] : 1.0f - acc[qt][r] * (inv * qi);
                 if (a.out_dense) {
                     a.out_dense[(uint64_t)j * a.dense_stride + (row - a.row_begin)] =
                         excluded ? __builtin_nanf("") : dist;
@@ -241,7 +242,7 @@ __device__ __forceinline__ h8 f16_piece(const char* tiled, uint64_t row, uint32_
 
 __global__ __launch_bounds__(256) void f16_inv_norm_kernel(const char* __restrict__ tiled, uint64_t first,
                                                            uint64_t n, uint32_t kpad, uint64_t tile_bytes,
-                                                           float* __restrict__ inv_norm) {
+                                                           float* __restrict__ inv_norm, bool l2) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void f16_inv_norm_kernel(const char* __restric
             for (int e = 0; e < 8; ++e) ss = fmaf((float)v[e], (float)v[e], ss);
         }
         ss = wave_sum(ss);
-        if (lane == 0) inv_norm[row] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+        if (lane == 0) inv_norm[row] = l2 ? ss : (ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f);
     }
 }
 
@@ -328,10 +329,11 @@ int launch_f16_store_rows(void* tiled, const float* src, uint64_t first, uint64_
 }
 
 int launch_f16_inv_norm(const void* tiled, uint64_t first, uint64_t n, uint32_t dim, float* inv_norm,
-                        hipStream_t stream) {
+                        hipStream_t stream, int metric) {
     if (n == 0) return ORAMA_OK;
     hipLaunchKernelGGL(f16_inv_norm_kernel, dim3(blocks_for(n, 4, 8192)), dim3(256), 0, stream,
-                       reinterpret_cast<const char*>(tiled), first, n, f16_kpad(dim), f16_tile_bytes(dim), inv_norm);
+                       reinterpret_cast<const char*>(tiled), first, n, f16_kpad(dim), f16_tile_bytes(dim), inv_norm,
+                       metric == ORAMA_METRIC_L2SQ);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

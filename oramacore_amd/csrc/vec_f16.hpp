@@ -23,9 +23,9 @@ constexpr uint32_t kF16MaxQ = 64;  // queries per corpus pass (2 MFMA column til
 // rows [first, first+n) of `src` (f32 row-major [n][dim]) → fp16 (RNE) into the tiled store.
 int launch_f16_store_rows(void* tiled, const float* src, uint64_t first, uint64_t n, uint32_t dim,
                           hipStream_t stream);
-// 1/|x| of the STORED (fp16-rounded) rows, accumulated in f32.
+// 1/|x| (cosine) or |x|^2 (L2) of the STORED (fp16-rounded) rows, accumulated in f32.
 int launch_f16_inv_norm(const void* tiled, uint64_t first, uint64_t n, uint32_t dim, float* inv_norm,
-                        hipStream_t stream);
+                        hipStream_t stream, int metric = ORAMA_METRIC_COSINE);
 // out[i] = row row_idx[i] converted back to f32.
 int launch_f16_gather_rows(const void* tiled, const uint64_t* d_row_idx, uint64_t n, uint32_t dim,
                            float* d_out, hipStream_t stream);
@@ -38,6 +38,9 @@ struct F16ScanArgs {
     const float* queries = nullptr;  // q x dim f32 (HBM); converted to fp16 fragments in LDS by every block
     uint32_t q = 0;                  // 1..64
     uint32_t dim = 0;
+    // ORAMA_METRIC_COSINE: inv_norm[] holds 1/|x| and the distance is 1 - s/(|x||q|);  ORAMA_METRIC_L2SQ: inv_norm[]
+    // holds |x|^2 (of the stored, fp16-rounded row) and the distance is (|q|^2 + |x|^2) - 2 s
+    int metric = ORAMA_METRIC_COSINE;
     uint64_t n_rows = 0;             // rows in the store
     uint64_t row_begin = 0, row_end = 0;  // rows scanned by this launch (row_begin % 32 == 0)
     const uint64_t* row_doc = nullptr;
@@ -65,6 +68,16 @@ constexpr uint32_t kF16WideMaxQ = 256;
 size_t f16_wide_query_bytes(uint32_t dim);
 int launch_vec_scan_f16_wide(orama_ctx* ctx, const F16ScanArgs& a, void* d_query_frags, bool prepare,
                              hipStream_t stream);
+
+// fp16 query fragments [query tile 0..7][k-step][lane][8 halves] + per-query 1/|q| (cosine) or |q|^2 (L2) of the
+// fp16-rounded query into `d_query_frags` (f16_wide_query_bytes(dim) bytes) — shared by K2c and K2d.
+int launch_f16_prepare_queries(const float* d_queries, uint32_t q, uint32_t dim, int metric, void* d_query_frags,
+                               hipStream_t stream);
+// K2d (vec_f16_pc.hip): the wide-batch scan as a producer/consumer kernel — dedicated loader waves feed the LDS ring,
+// consumer waves only read fragments and issue MFMAs.  Same arguments as K2c; the fragments must have been prepared.
+// geometry 1: 12 consumers of 2 x 2 MFMA tiles + 4 loaders (192 rows x 256 queries per block tile) — the default;
+// 2: 8 consumers of 3 x 2 tiles + 4 loaders.
+int launch_vec_scan_f16_pc(orama_ctx* ctx, const F16ScanArgs& a, void* d_query_frags, hipStream_t stream, int geometry);
 
 // tau[j] = k-th best distance of list j when the list is full, else +inf; and seed the candidate lists
 // with the current best entries: cand[j][0..n_j) = (dist, row), cand_count[j] = n_j.

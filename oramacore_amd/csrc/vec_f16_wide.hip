@@ -78,7 +78,7 @@ __device__ __forceinline__ void dma16_nt(uint64_t saddr_uniform, uint32_t voff, 
 
 // queries (f32) -> fp16 B fragments [query tile 0..7][k-step][lane][8 halves] + 1/|q| of the rounded query
 __global__ __launch_bounds__(256) void f16_prepare_queries_kernel(const float* __restrict__ queries, uint32_t q,
-                                                                  uint32_t dim, uint32_t ksteps,
+                                                                  uint32_t dim, uint32_t ksteps, bool l2,
                                                                   char* __restrict__ bfrag, float* __restrict__ qinv) {
     const uint32_t frag_total = 8u * ksteps * 64u;
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < frag_total; idx += gridDim.x * blockDim.x) {
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void f16_prepare_queries_kernel(const float* _
                 ss = fmaf(x, x, ss);
             }
         }
-        qinv[j] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+        qinv[j] = l2 ? ss : (ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f);
     }
 }
 
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
     }
 
     f16v acc[2][QT];
+    const bool l2 = a.metric == ORAMA_METRIC_L2SQ;
     typedef const uint32_t __attribute__((address_space(4))) cu32;
     auto epilogue = [&](uint64_t bt, uint32_t par) {
         const uint32_t hi = (lane >> 5) ? 4u : 0u;
@@ -245,7 +246,8 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
                     // when it passes.  Tombstones / rows past the end are sorted out on the slow path.
                     float best = __builtin_huge_valf();
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) best = fminf(best, 1.0f - acc[i][j][r] * (nrm[r] * qi));
+                    for (int r = 0; r < 16; ++r)
+                        best = fminf(best, l2 ? (qi + nrm[r]) - 2.0f * acc[i][j][r] : 1.0f - acc[i][j][r] * (nrm[r] * qi));
                     if (!(best < tau)) continue;
                 }
 #pragma unroll
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
                     const uint32_t ri = (uint32_t)((r & 3) + 8 * (r >> 2)) + hi;
                     const uint64_t row = tile * 32 + ri;
                     if (!full && row >= a.row_end) continue;
-                    const float dist = 1.0f - acc[i][j][r] * (nrm[r] * qi);
+                    const float dist = l2 ? (qi + nrm[r]) - 2.0f * acc[i][j][r] : 1.0f - acc[i][j][r] * (nrm[r] * qi);
                     bool excluded = (dead_word >> ri) & 1u;
                     if (a.out_dense) {
                         if (!excluded && a.allow) {
@@ -359,6 +361,18 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
 
 }  // namespace
 
+int launch_f16_prepare_queries(const float* d_queries, uint32_t q, uint32_t dim, int metric, void* d_query_frags,
+                               hipStream_t stream) {
+    ORAMA_REQUIRE(d_queries && d_query_frags && q >= 1 && q <= kF16WideMaxQ, "f16_prepare_queries: bad arguments");
+    const uint32_t ksteps = f16_kpad(dim) / 16;
+    char* bfrag = reinterpret_cast<char*>(d_query_frags);
+    float* qinv = reinterpret_cast<float*>(bfrag + (size_t)8 * ksteps * 1024);
+    hipLaunchKernelGGL(f16_prepare_queries_kernel, dim3(64), dim3(256), 0, stream, d_queries, q, dim, ksteps,
+                       metric == ORAMA_METRIC_L2SQ, bfrag, qinv);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
 size_t f16_wide_query_bytes(uint32_t dim) { return (size_t)8 * (f16_kpad(dim) / 16) * 1024 + 256 * sizeof(float); }
 
 int launch_vec_scan_f16_wide(orama_ctx* ctx, const F16ScanArgs& a, void* d_query_frags, bool prepare,
@@ -374,11 +388,7 @@ int launch_vec_scan_f16_wide(orama_ctx* ctx, const F16ScanArgs& a, void* d_query
     ORAMA_REQUIRE(ksteps % 2 == 0, "vec_scan_f16_wide: kpad %u not a multiple of 32", kpad);
     char* bfrag = reinterpret_cast<char*>(d_query_frags);
     float* qinv = reinterpret_cast<float*>(bfrag + (size_t)8 * ksteps * 1024);
-    if (prepare) {
-        hipLaunchKernelGGL(f16_prepare_queries_kernel, dim3(64), dim3(256), 0, stream, a.queries, a.q, a.dim, ksteps,
-                           bfrag, qinv);
-        ORAMA_HIP_TRY(hipGetLastError());
-    }
+    if (prepare) ORAMA_TRY(launch_f16_prepare_queries(a.queries, a.q, a.dim, a.metric, d_query_frags, stream));
     if (a.row_begin == a.row_end) return ORAMA_OK;
     ProfScope prof(&ctx->prof, "vec_scan_f16", stream);
     static_assert(lds_bytes_for(4, 3) <= 160 * 1024 && lds_bytes_for(4, 2) <= 160 * 1024, "K2c LDS budget");

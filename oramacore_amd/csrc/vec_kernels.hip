@@ -320,6 +320,7 @@ __global__ __launch_bounds__(kScanThreads) void synth_fill_kernel(float* __restr
             float r = sqrtf(-2.0f * __logf(u01((uint32_t)h)));
             float th = 6.28318530718f * u01((uint32_t)(h >> 32));
             float g0 = r * __cosf(th), g1 = r * __sinf(th);
+            if (seed == ~0ull) g0 = g1 = 1.0f;  // diagnostic corpus: constant rows (minimal operand toggling)
             ss = fmaf(g0, g0, ss);
             if (c + 1 < dim) ss = fmaf(g1, g1, ss);
         }
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(kScanThreads) void synth_fill_kernel(float* __restr
             float r = sqrtf(-2.0f * __logf(u01((uint32_t)h)));
             float th = 6.28318530718f * u01((uint32_t)(h >> 32));
             float g0 = r * __cosf(th), g1 = r * __sinf(th);
+            if (seed == ~0ull) g0 = g1 = 1.0f;
             p[c] = g0 * scale;
             if (c + 1 < dim) p[c + 1] = g1 * scale;
         }

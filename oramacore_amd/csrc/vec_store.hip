@@ -132,7 +132,7 @@ int store_rows_from_device(orama_vec* v, void* rows_base, float* norm_base, cons
                            uint64_t n, hipStream_t s) {
     if (v->f16()) {
         ORAMA_TRY(launch_f16_store_rows(rows_base, d_src, first, n, v->dim, s));
-        ORAMA_TRY(launch_f16_inv_norm(rows_base, first, n, v->dim, norm_base, s));
+        ORAMA_TRY(launch_f16_inv_norm(rows_base, first, n, v->dim, norm_base, s, v->metric));
     } else {
         ORAMA_HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(rows_base) + (size_t)first * v->row_bytes(), d_src,
                                      (size_t)n * v->row_bytes(), hipMemcpyDeviceToDevice, s));
@@ -270,7 +270,6 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
                        uint32_t* d_out_n, hipStream_t s) {
     const uint64_t n = v->n_rows;
-    ORAMA_REQUIRE(v->metric == ORAMA_METRIC_COSINE, "f16 storage implements the cosine metric only");
     constexpr uint64_t kS1 = 131072;                 // dense head (rows), multiple of 32
     constexpr uint64_t kCandBudget = 6ull << 30;     // bytes of candidate lists per pass
     const uint32_t kpad_k = f16_kpad(v->dim);
@@ -282,9 +281,12 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
         bool wide_prepared = false;
         auto scan = [&](const F16ScanArgs& args) -> int {
             if (!wide) return launch_vec_scan_f16(v->ctx, args, s);
-            const int st = launch_vec_scan_f16_wide(v->ctx, args, sc->f16_bfrag.p, !wide_prepared, s);
+            if (!wide_prepared)
+                ORAMA_TRY(launch_f16_prepare_queries(args.queries, args.q, args.dim, args.metric, sc->f16_bfrag.p, s));
             wide_prepared = true;
-            return st;
+            // f16_wide: 1 = K2c (MFMA waves also issue the DMA), 2.. = K2d (dedicated loader waves), geometry f16_wide-1
+            if (v->ctx->f16_wide >= 2) return launch_vec_scan_f16_pc(v->ctx, args, sc->f16_bfrag.p, s, v->ctx->f16_wide - 1);
+            return launch_vec_scan_f16_wide(v->ctx, args, sc->f16_bfrag.p, false, s);
         };
         const uint64_t s1 = std::min<uint64_t>(n, kS1);
         // super-chunk size: gq * (rows + k) * 8 B <= budget
@@ -320,6 +322,7 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
         a.queries = d_queries + (size_t)q0 * v->dim;
         a.q = gq;
         a.dim = v->dim;
+        a.metric = v->metric;
         a.n_rows = n;
         a.row_doc = v->row_doc.as<uint64_t>();
         a.dead = v->n_dead ? v->dead.as<uint32_t>() : nullptr;
@@ -431,10 +434,6 @@ int orama_vec_create(orama_ctx* ctx, uint32_t dim, int metric, int dtype, uint64
     ORAMA_REQUIRE(dim >= 1 && dim <= 65536, "dimensions %u outside [1, 65536]", dim);
     ORAMA_REQUIRE(metric == ORAMA_METRIC_COSINE || metric == ORAMA_METRIC_L2SQ, "unknown metric %d", metric);
     ORAMA_REQUIRE(dtype == ORAMA_DTYPE_F32 || dtype == ORAMA_DTYPE_F16, "unknown dtype %d", dtype);
-    if (dtype == ORAMA_DTYPE_F16 && metric != ORAMA_METRIC_COSINE) {
-        set_error("f16 storage implements the cosine metric only");
-        return ORAMA_ERR_UNSUPPORTED;
-    }
     if (dtype == ORAMA_DTYPE_F16 && dim > 2048) {
         set_error("f16 storage: dimensions %u > 2048 exceed the LDS query tile", dim);
         return ORAMA_ERR_UNSUPPORTED;
