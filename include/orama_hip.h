@@ -372,6 +372,78 @@ int orama_post_merge_blocks_device(orama_ctx* ctx, const void* d_blocks, uint32_
 /* Replace the per-field average lengths (index-wide averages for the shards of one index). */
 int orama_post_set_avg_len(orama_post* p, const float* avg_field_len, uint32_t n_fields);
 
+/* ------------------------------------------------------------------ sharded index, exchange inside the library
+ * The staged entry points above leave the collectives to the caller.  A shard GROUP owns them: RCCL communicators
+ * (loaded with dlopen on first use), one exchange stream and the gathered buffers per local shard, so that a sharded
+ * search is ONE call from the reference's single Rust process (ReadSide, src/collection_manager/sides/read/mod.rs:
+ * 621-738) — no torch, no second runtime.  Deployments:
+ *   orama_shard_group_create(devices[n], n, flags)  one process, n shards:
+ *       devices all distinct  -> one RCCL communicator per GPU (ncclCommInitAll), collectives over xGMI;
+ *       devices all the same  -> the shards share one GPU: no communicator, every shard writes its block into the
+ *                                same gathered buffer and the reductions are device-local kernels (what a 1-GPU box
+ *                                and the parity tests run); ORAMA_SHARD_FORCE_RCCL with n == 1 builds a 1-rank
+ *                                communicator anyway (plumbing test of the RCCL path on one GPU);
+ *   orama_shard_group_create_rank(id, rank, world, device)  one process per GPU (bench.py under
+ *       torch.distributed.run): rank 0 makes the 128-byte id with orama_shard_unique_id, the launcher carries it.
+ * orama_shard_group_ctx(g, i) is the context of local shard i: create its orama_vec / orama_post with it (shard r of
+ * `world` holds one contiguous DocumentId range).  Calls on one group are serialised (collectives must be
+ * issued in the same order on every rank); in the one-process-per-GPU form every rank makes the same calls.
+ * Index-wide quantities and where they travel: df[n_tokens] all-reduce SUM (token_score.rs:262-275), hybrid
+ * {max, min} all-reduce MAX (token_score.rs:398-401), candidates + count all-gather then K6 (sort.rs:260-279,
+ * search.rs:482); idf comes from the host libm after ONE pinned read-back of 4*n_tokens bytes.  Results are
+ * bit-identical to the single-store search over the union of the shards. */
+typedef struct orama_shard_group orama_shard_group;
+#define ORAMA_SHARD_FORCE_RCCL 1u
+int orama_shard_unique_id(void* out_id128);
+int orama_shard_group_create(const int* devices, uint32_t n_shards, uint32_t flags, orama_shard_group** out);
+int orama_shard_group_create_rank(const void* id128, int rank, int world, int device, orama_shard_group** out);
+void orama_shard_group_destroy(orama_shard_group* g);
+orama_ctx* orama_shard_group_ctx(orama_shard_group* g, uint32_t local_shard);
+int orama_shard_group_info(orama_shard_group* g, uint32_t* world, uint32_t* n_local_shards, uint32_t* first_rank,
+                           int* uses_rccl);
+/* Barrier over all shards of the group (local devices drained + one all-reduced word). */
+int orama_shard_group_barrier(orama_shard_group* g);
+/* max over all ranks of one host double (the slowest rank's elapsed time in bench.py). */
+int orama_shard_group_allreduce_max_f64(orama_shard_group* g, double* inout);
+
+/* EmbeddingStorage::search over the row shards of one field (call site embedding_field.rs:255-266): `shards` holds the
+ * local shards in rank order; queries / outputs as orama_vec_search (host buffers, q x k).  allow_bitmaps: NULL, or
+ * one RESIDENT bitmap token per local shard (orama_allow_token; each lives on its shard's device). */
+int orama_shard_vec_search(orama_shard_group* g, orama_vec* const* shards, const float* queries, uint32_t q, uint32_t k,
+                           const uint64_t* const* allow_bitmaps, uint64_t bitmap_bits, uint64_t* out_ids,
+                           float* out_dist, uint32_t* out_n);
+/* search_full_text (hybrid = 0) / the full-text leg of search_hybrid with the GLOBAL vector map (hybrid = 1) over the
+ * document shards of one index — token_score.rs:186-303, 357-422.  Every shard store was built from its doc-id range
+ * with the SAME list numbering and the index-wide field averages; params->total_documents is the index-wide N;
+ * params->top_k >= 1.  Outputs as orama_post_search. */
+int orama_shard_post_search(orama_shard_group* g, orama_post* const* shards, const orama_term_ref* refs, uint32_t n_refs,
+                            float b, const orama_bm25_params* params, const uint64_t* const* allow_bitmaps,
+                            uint64_t bitmap_bits, int apply_omc, int hybrid, const uint64_t* vec_doc,
+                            const float* vec_score, uint32_t n_vec, uint64_t* out_ids, float* out_scores,
+                            uint32_t* out_n, uint64_t* out_count);
+/* search_hybrid over a sharded index in one call: sharded vector leg, the in-tree epilogue of
+ * EmbeddingFieldStorage::search on the <= limit global hits (embedding_field.rs:268-276), sharded full-text leg. */
+int orama_shard_hybrid_search(orama_shard_group* g, orama_vec* const* vec_shards, orama_post* const* post_shards,
+                              const float* query, uint32_t limit, float min_similarity, int rescale_e5,
+                              const orama_term_ref* refs, uint32_t n_refs, float b, const orama_bm25_params* params,
+                              const uint64_t* const* allow_bitmaps, uint64_t bitmap_bits, int apply_omc,
+                              uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count);
+
+/* Pipelined vector-search session (serving loop / bench.py): `n_queries` queries resident in HBM on every local
+ * device; orama_shard_session_step(s, i) enqueues step i — queries [i*q, (i+1)*q) modulo the resident set — without
+ * host synchronisation: corpus scans of consecutive steps run back to back on ONE scan stream per device, the
+ * launch-bound tail (K4, all-gather, K6) on `n_slots` high-priority streams used round-robin, so the tail of step i
+ * overlaps the scan of step i+1.  Results stay in HBM; orama_shard_session_result reads the last step of a slot after
+ * orama_shard_session_sync.  With one shard and force_exchange == 0 no exchange runs (the block is the answer). */
+typedef struct orama_shard_session orama_shard_session;
+int orama_shard_session_create(orama_shard_group* g, orama_vec* const* shards, const float* queries, uint32_t n_queries,
+                               uint32_t q_per_step, uint32_t k, uint32_t n_slots, int force_exchange,
+                               orama_shard_session** out);
+void orama_shard_session_destroy(orama_shard_session* s);
+int orama_shard_session_step(orama_shard_session* s, uint32_t step);
+int orama_shard_session_sync(orama_shard_session* s);
+int orama_shard_session_result(orama_shard_session* s, uint32_t slot, uint64_t* out_ids, float* out_dist, uint32_t* out_n);
+
 /* Standalone normalize_and_combine on host-provided maps (both sides small or large) — the
  * literal replacement of token_score.rs:393-422 + top_n for callers that keep seam (i). */
 int orama_hybrid_combine(orama_ctx* ctx, const uint64_t* vec_doc, const float* vec_score,

@@ -170,6 +170,21 @@ def _declare(lib: C.CDLL) -> None:
         "orama_post_query_finish": [vp, vp, vp, vp, C.c_uint32, vp],
         "orama_post_merge_blocks_device": [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp],
         "orama_post_set_avg_len": [vp, vp, C.c_uint32],
+        "orama_shard_unique_id": [vp],
+        "orama_shard_group_create": [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)],
+        "orama_shard_group_create_rank": [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+        "orama_shard_group_info": [vp, u32p, u32p, u32p, C.POINTER(C.c_int)],
+        "orama_shard_group_barrier": [vp],
+        "orama_shard_group_allreduce_max_f64": [vp, C.POINTER(C.c_double)],
+        "orama_shard_vec_search": [vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, vp],
+        "orama_shard_post_search": [vp, vp, C.POINTER(TermRef), C.c_uint32, C.c_float, C.POINTER(Bm25Params), vp,
+                                    C.c_uint64, C.c_int, C.c_int, vp, vp, C.c_uint32, vp, vp, u32p, u64p],
+        "orama_shard_hybrid_search": [vp, vp, vp, vp, C.c_uint32, C.c_float, C.c_int, C.POINTER(TermRef), C.c_uint32,
+                                      C.c_float, C.POINTER(Bm25Params), vp, C.c_uint64, C.c_int, vp, vp, u32p, u64p],
+        "orama_shard_session_create": [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)],
+        "orama_shard_session_step": [vp, C.c_uint32],
+        "orama_shard_session_sync": [vp],
+        "orama_shard_session_result": [vp, C.c_uint32, vp, vp, vp],
         "orama_hybrid_combine": [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u32p, u64p],
         "orama_hybrid_rrf": [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, vp, vp, u32p,
                              u64p],
@@ -189,7 +204,9 @@ def _declare(lib: C.CDLL) -> None:
         fn = getattr(lib, name)
         fn.argtypes = [vp, vp]
         fn.restype = None
-    for name in ("orama_ctx_destroy", "orama_vec_destroy", "orama_post_destroy", "orama_post_query_end",
+    lib.orama_shard_group_ctx.argtypes = [vp, C.c_uint32]
+    lib.orama_shard_group_ctx.restype = vp
+    for name in ("orama_ctx_destroy", "orama_shard_group_destroy", "orama_shard_session_destroy", "orama_vec_destroy", "orama_post_destroy", "orama_post_query_end",
                  "orama_batcher_destroy", "orama_allow_destroy",
                  "orama_dict_destroy"):
         fn = getattr(lib, name)

@@ -1,19 +1,19 @@
-"""One index sharded over G doc-id ranges, full-text and hybrid, through the staged C ABI.
+"""One index sharded over G doc-id ranges, full-text and hybrid, through orama_shard_post_search: the
+exchange (df all-reduce SUM, min/max all-reduce MAX, block all-gather + K6) runs INSIDE the library.
 
-The G shard stores live on the one GPU of the test box and are driven in lockstep; the three collectives of
-ShardedFulltextSearcher (df all-reduce SUM, min/max all-reduce MAX, block all-gather) are emulated with torch ops
-on the same device buffers the real RCCL calls would use.  Bar: bit-identical to the oracle over the union (and
-therefore to the single-store search): ids, scores and match count.
+The G shard stores live on the one GPU of the test box (a co-located shard group: same stages, same buffers, the
+reductions are device-local kernels instead of RCCL calls; tests/test_shard_group_gpu.py runs the RCCL form at
+world 1).  Bar: bit-identical to the oracle over the union (and therefore to the single-store search): ids, scores
+and match count.
 """
 import numpy as np
 import pytest
-import torch
 
 import oramacore_amd as oa
 import util
 from oracle import oracle as orc
 from oramacore_amd import fulltext as ft
-from oramacore_amd import sharded
+from oramacore_amd.shard_group import ShardGroup
 from test_fulltext_gpu import bits, oracle_topk
 from test_oracle_golden import bm25_synth_entries
 
@@ -49,40 +49,18 @@ def build_shards(ctx, meta, fields, doc_ids, cuts):
     return stores, list_id
 
 
-def run_lockstep(ctx, stores, refs, n_tok, total_docs, top_k, threshold=None, allow=None, vector=None,
-                 apply_omc=True):
-    """ShardedFulltextSearcher.search with the collectives replaced by in-process reductions."""
-    dev = torch.device("cuda:0")
-    G = len(stores)
-    ops = [sharded.HipPostOps(ctx, s) for s in stores]
-    hybrid = vector is not None
-    n_vec = len(vector) if vector else 0
-    nb = sharded.post_block_bytes(top_k)
-    assert nb == ops[0].lib.orama_post_block_bytes(top_k)
-    d_df = [torch.zeros((n_tok,), dtype=torch.int32, device=dev) for _ in range(G)]
-    d_mm = [torch.zeros((2,), dtype=torch.int64, device=dev) for _ in range(G)]
-    blocks = torch.zeros((G * nb,), dtype=torch.uint8, device=dev)
-    query = dict(refs=refs, n_tokens=n_tok, total_documents=total_docs, top_k=top_k, threshold=threshold,
-                 allow=allow, apply_omc=apply_omc, hybrid=hybrid, n_vec_cap=n_vec)
-    qs = [ops[g].begin(query, d_df[g]) for g in range(G)]
+def run_sharded(group, stores, refs, n_tok, total_docs, top_k, threshold=None, allow=None, vector=None,
+                apply_omc=True):
+    """One sharded query through the library (the caller of round 1's staged entry points, now one C call)."""
+    res_allow = None
+    if allow is not None:
+        res_allow = [allow.to_device(group.ctx(i)) for i in range(group.n_local)]
     try:
-        df = torch.stack(d_df).sum(dim=0).cpu().numpy().astype(np.uint32)            # all-reduce SUM
-        for g in range(G):
-            ops[g].score(qs[g], df, d_mm[g] if hybrid else None)
-        mm = torch.stack(d_mm).max(dim=0).values.contiguous() if hybrid else None   # all-reduce MAX
-        for g in range(G):
-            ops[g].finish(qs[g], mm, vector, blocks[g * nb:(g + 1) * nb])            # all-gather
-        out_ids = torch.zeros((top_k,), dtype=torch.int64, device=dev)
-        out_sc = torch.zeros((top_k,), dtype=torch.float32, device=dev)
-        out_n = torch.zeros((1,), dtype=torch.int32, device=dev)
-        out_count = torch.zeros((1,), dtype=torch.int64, device=dev)
-        ops[0].merge(blocks, G, top_k, out_ids, out_sc, out_n, out_count)
-        n = int(out_n.cpu()[0])
-        return (out_ids.cpu().numpy().view(np.uint64)[:n].copy(), out_sc.cpu().numpy()[:n].copy(),
-                int(out_count.cpu()[0]), df)
+        return group.post_search(stores, refs, n_tok, total_docs, top_k, threshold=threshold, allow=res_allow,
+                                 apply_omc=apply_omc, vector=vector)
     finally:
-        for q in qs:
-            q.end()
+        for a in res_allow or []:
+            a.close()
 
 
 def refs_of(meta, list_id, case):
@@ -94,26 +72,29 @@ def refs_of(meta, list_id, case):
 def test_sharded_bm25_bit_exact(ctx, synth, cuts_frac):
     meta, fields, doc_ids, allow = synth
     cuts = [int(round(f * meta["n_docs"])) for f in cuts_frac]
-    stores, list_id = build_shards(ctx, meta, fields, doc_ids, cuts)
+    group = ShardGroup([0] * (len(cuts) - 1))
+    stores, list_id = build_shards(group.ctx(0), meta, fields, doc_ids, cuts)
     bm = oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[allow])
     for case in meta["cases"][::3]:
         refs = refs_of(meta, list_id, case)
         entries = bm25_synth_entries(meta, fields, case, doc_ids, allow)
         n_tok = len(case["terms"])
-        ids, sc, count, df = run_lockstep(ctx, stores, refs, n_tok, float(meta["n_docs"]), 50, case["threshold"],
-                                          allow=bm if case["filter"] else None)
+        ids, sc, count = run_sharded(group, stores, refs, n_tok, float(meta["n_docs"]), 50, case["threshold"],
+                                     allow=bm if case["filter"] else None)
         od, os_, ocount = oracle_topk(entries, n_tok, meta["n_docs"], 50, case["threshold"])
         assert count == ocount, (case["query"], case["threshold"], case["filter"])
         assert ids.tolist() == od.tolist(), (case["query"], case["threshold"], case["filter"])
         assert np.array_equal(bits(sc), bits(os_))
     for s in stores:
         s.close()
+    group.close()
 
 
 def test_sharded_hybrid_and_omc_bit_exact(ctx, synth):
     meta, fields, doc_ids, allow = synth
     cuts = [0, meta["n_docs"] // 3, meta["n_docs"] // 3 + 7, meta["n_docs"]]
-    stores, list_id = build_shards(ctx, meta, fields, doc_ids, cuts)
+    group = ShardGroup([0] * (len(cuts) - 1))
+    stores, list_id = build_shards(group.ctx(0), meta, fields, doc_ids, cuts)
     rng = np.random.default_rng(11)
     for ci in (0, 12, 24, 30):
         case = {**meta["cases"][ci], "filter": False}
@@ -132,8 +113,8 @@ def test_sharded_hybrid_and_omc_bit_exact(ctx, synth):
                 for s in stores:
                     s.set_omc(omc)
             td, ts = orc.top_n(od, os_, 30)
-            ids, sc, count, _ = run_lockstep(ctx, stores, refs, n_tok, float(meta["n_docs"]), 30, case["threshold"],
-                                             vector=vec, apply_omc=omc is not None)
+            ids, sc, count = run_sharded(group, stores, refs, n_tok, float(meta["n_docs"]), 30, case["threshold"],
+                                         vector=vec, apply_omc=omc is not None)
             assert count == len(od), (ci, omc)
             assert ids.tolist() == td.tolist(), (ci, omc)
             assert np.array_equal(bits(sc), bits(ts))
@@ -144,43 +125,47 @@ def test_sharded_hybrid_and_omc_bit_exact(ctx, synth):
     omc = {int(doc_ids[5]): 10.0, int(doc_ids[1500]): 0.25}
     for s in stores:
         s.set_omc(omc)
-    ids, sc, count, _ = run_lockstep(ctx, stores, refs, len(case["terms"]), float(meta["n_docs"]), 100)
+    ids, sc, count = run_sharded(group, stores, refs, len(case["terms"]), float(meta["n_docs"]), 100)
     od, os_, ocount = oracle_topk(entries, len(case["terms"]), meta["n_docs"], 100, omc=omc)
     assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
     for s in stores:
         s.close()
+    group.close()
 
 
-def test_searcher_class_single_rank(ctx, synth):
-    """ShardedFulltextSearcher at world == 1 (no process group): same stages, equals PostingsStore.search."""
+def test_single_shard_group_equals_store(ctx, synth):
+    """A group of ONE shard: the same stages (begin / score / finish / merge) — equals PostingsStore.search."""
     meta, fields, doc_ids, allow = synth
-    stores, list_id = build_shards(ctx, meta, fields, doc_ids, [0, meta["n_docs"]])
-    srch = sharded.ShardedFulltextSearcher(sharded.HipPostOps(ctx, stores[0]), 0, 1, torch.device("cuda:0"))
+    group = ShardGroup([0])
+    stores, list_id = build_shards(group.ctx(0), meta, fields, doc_ids, [0, meta["n_docs"]])
     case = meta["cases"][12]
     refs = refs_of(meta, list_id, case)
     n_tok = len(case["terms"])
-    ids, sc, count = srch.search(refs, n_tok, float(meta["n_docs"]), 40)
+    ids, sc, count = group.post_search(stores, refs, n_tok, float(meta["n_docs"]), 40)
     ids1, sc1, count1 = stores[0].search(refs, n_tok, float(meta["n_docs"]), 40)
     assert count == count1 and ids.tolist() == ids1.tolist() and np.array_equal(bits(sc), bits(sc1))
     vec = {int(doc_ids[1]): 0.9, int(ids1[0]): 0.4}
-    ids, sc, count = srch.search(refs, n_tok, float(meta["n_docs"]), 40, vector=vec)
+    ids, sc, count = group.post_search(stores, refs, n_tok, float(meta["n_docs"]), 40, vector=vec)
     ids1, sc1, count1 = stores[0].search(refs, n_tok, float(meta["n_docs"]), 40, vector=vec)
     assert count == count1 and ids.tolist() == ids1.tolist() and np.array_equal(bits(sc), bits(sc1))
     stores[0].close()
+    group.close()
 
 
 def test_staged_query_order_is_enforced(ctx, synth):
     meta, fields, doc_ids, allow = synth
     stores, list_id = build_shards(ctx, meta, fields, doc_ids, [0, meta["n_docs"]])
-    dev = torch.device("cuda:0")
-    d_df = torch.zeros((1,), dtype=torch.int32, device=dev)
-    block = torch.zeros((sharded.post_block_bytes(5),), dtype=torch.uint8, device=dev)
-    q = stores[0].staged_query([(0, 0, 1.0)], 1, 100.0, 5, d_df.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    lib = oa._native.load()
+    d_df = oa.DeviceBuffer(ctx, 64 * 4)
+    block = oa.DeviceBuffer(ctx, int(lib.orama_post_block_bytes(5)))
+    stream = oa.Stream(ctx)
+    q = stores[0].staged_query([(0, 0, 1.0)], 1, 100.0, 5, d_df.ptr, stream.ptr)
     with pytest.raises(oa.OramaError):
-        q.finish(None, None, block.data_ptr())  # score not called yet
+        q.finish(None, None, block.ptr)  # score not called yet
     q.score(np.array([3], dtype=np.uint32), None)
     with pytest.raises(oa.OramaError):
         q.score(np.array([3], dtype=np.uint32), None)
-    q.finish(None, None, block.data_ptr())
+    q.finish(None, None, block.ptr)
     q.end()
+    stream.close()
     stores[0].close()

@@ -161,3 +161,23 @@ def test_wide_batches_equal_solo_queries(ctx, d):
         full[[0, 1, 77]] = np.nan
         util.assert_topk_sound((ids[qi] - 1) // 2, dist[qi], full, 30, TOL, f"wide q{qi}")
     st.close()
+
+
+@pytest.mark.parametrize("nq", [1, 40, 70, 200])
+def test_l2_metric_on_fp16_storage(ctx, nq):
+    """Squared-L2 on the fp16 store (north_star: cosine/L2): the MFMA kernels accumulate q.x and finish with
+    (|q|^2 + |x|^2) - 2 q.x, norms of the fp16-rounded vectors in f32.  Against the oracle's direct sum of squared
+    differences on the same rounded vectors; the expanded form cancels ~|q|^2 + |x|^2 (<= 8 here), so the absolute
+    bar is 3e-4 instead of the cosine path's 1e-4.  Sizes cross the dense head so K2 (<= 64), K2d (65..256) and the
+    threshold filter all run in L2 mode."""
+    n, d, k = 140_000, 384, 50
+    corpus = util.gaussian_rows(n, d, seed=31)
+    queries = util.gaussian_rows(nq, d, seed=32)
+    st = oa.EmbeddingFieldStorage(ctx, dimensions=d, dtype=oa.DTYPE_F16, metric=oa.METRIC_L2SQ)
+    assert st.insert_rows(np.arange(n, dtype=np.uint64), corpus) == n
+    c16 = q16(corpus)
+    ids, dist, cnt = st.storage_search(queries, k)
+    for qi in sorted({0, nq // 2, nq - 1}):
+        full = orc.distances(c16, q16(queries[qi]), metric=1).astype(np.float64)
+        util.assert_topk_sound(ids[qi, :cnt[qi]], dist[qi, :cnt[qi]], full, k, 3e-4, f"l2 f16 q{qi}")
+    st.close()
