@@ -10,6 +10,10 @@ N > 1 — one RCCL all-gather of the per-shard candidates + K6 (merge).  Corpus 
 resident in HBM before the timed region; results stay in HBM (the host-buffer API, which adds the
 PCIe hop, is timed separately and reported as `latency_ms_p50_host_api`).
 
+No torch in this process: buffers, streams and the RCCL exchange live inside liborama_hip.so
+(orama_shard_*); under torch.distributed.run the ranks only read RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* from the environment and pass the 128-byte communicator id over a localhost socket.
+
 Strong scaling: the 10 M rows are split statically over the N ranks, so queries/sec
 should grow ~linearly with N.
 
@@ -103,31 +107,23 @@ def cpu_baseline(store, dim: int, n_total: int, k: int, sample_rows: int) -> dic
 
 def main():
     args = parse_args()
-    import torch
-    import torch.distributed as dist
-
     import oramacore_amd as oa
-    from oramacore_amd.sharded import HipOps, ShardedSearcher, ShardPlan
+    from oramacore_amd.launch import RankEnv, ShardPlan, exchange_unique_id
+    from oramacore_amd.shard_group import FORCE_RCCL, ShardGroup
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_exchange
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29517")
-            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
-        else:
-            dist.init_process_group(backend="nccl", device_id=device)
+    env = RankEnv.from_env()
+    world, rank, local_rank = env.world, env.rank, env.local_rank
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # The exchange (RCCL all-gather of the per-shard candidates + K6) runs inside liborama_hip.so: one process per
+    # GPU, rank 0 makes the communicator id and hands it to the others over a localhost socket.  No torch here.
+    if world > 1:
+        uid = exchange_unique_id(env, ShardGroup.unique_id)
+        group = ShardGroup.from_rank(uid, rank, world, local_rank)
+    else:
+        group = ShardGroup([local_rank], flags=FORCE_RCCL if args.force_exchange else 0)
+    ctx = group.ctx(0)
 
     n_total, dim, k, qb, dtype, desc = WORKLOADS[args.workload]
     if args.rows:
@@ -137,7 +133,6 @@ def main():
     n_local = hi - lo
     f16 = dtype == "f16"
 
-    ctx = oa.Context(local_rank)
     store = oa.EmbeddingFieldStorage(ctx, dimensions=dim, reserve_rows=n_local,
                                      dtype=oa.DTYPE_F16 if f16 else oa.DTYPE_F32)
     t_fill = time.perf_counter()
@@ -147,48 +142,32 @@ def main():
     total_b = args.warmup + args.steps  # batches
     rng = np.random.default_rng(0xBEEF)
     queries_h = rng.standard_normal((total_b * qb, dim)).astype(np.float32)
-    queries = torch.from_numpy(queries_h).to(device)
-    # Stream plan: ONE scan stream (corpus scans of consecutive steps run back to back, never concurrently, so
-    # each keeps the whole HBM bandwidth) + `--streams` tail streams used round-robin for top-k / all-gather /
-    # merge, which are launch-bound and overlap the next step's scan.
+    # Stream plan (inside the session): ONE scan stream (corpus scans of consecutive steps run back to back, never
+    # concurrently, so each keeps the whole HBM bandwidth) + `--streams` high-priority tail streams used round-robin
+    # for top-k / all-gather / merge, which are launch-bound and overlap the next step's scan.
     n_streams = max(1, args.streams)
-    scan_stream = torch.cuda.Stream(device=device) if n_streams > 1 else None
-    # tail streams are HIGH priority: ROCm gives priority levels their own hardware queues, so the launch-bound
-    # tail never queues behind a scan in the same HW queue (observed with same-priority streams: profiles/).
-    streams = [torch.cuda.Stream(device=device, priority=-1 if n_streams > 1 else 0) for _ in range(n_streams)]
-    searchers = [ShardedSearcher(HipOps(ctx, store, scan_stream), rank, world, device,
-                                 always_exchange=args.force_exchange) for _ in range(n_streams)]
-
-    def step(i):
-        with torch.cuda.stream(streams[i % n_streams]):
-            return searchers[i % n_streams].search(queries[i * qb:(i + 1) * qb], k)
+    sess = group.session([store], queries_h, qb, k, n_slots=n_streams, force_exchange=args.force_exchange)
 
     def barrier():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sess.sync()
+        group.barrier()  # local devices drained + one all-reduced word over RCCL + drained again
 
     for i in range(args.warmup):
-        step(i)
+        sess.step(i)
     barrier()
     ctx.prof_reset()
     ctx.prof_enable(True)
     t0 = time.perf_counter()
     for i in range(args.warmup, total_b):
-        ids, dst, cnt = step(i)
+        sess.step(i)
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = group.allreduce_max(elapsed)  # the slowest rank's time
 
-    # ---- sanity of the last step (outside the timed region): sorted, and exact on re-computation
-    ids_all = ids.cpu().numpy().view(np.uint64)
-    dst_all = dst.cpu().numpy()
-    assert np.all(cnt.cpu().numpy() == k), "bench result incomplete"
+    # ---- sanity of the last step (outside the timed region): sorted, exact on re-computation, nothing missed
+    ids_all, dst_all, cnt = sess.result((total_b - 1) % n_streams)
+    assert np.all(cnt == k), "bench result incomplete"
     from oracle import oracle as orc  # checker only
 
     for qi in sorted({0, qb - 1}):
@@ -249,8 +228,9 @@ def main():
         "dtype": dtype,
         "data": "synthetic",
         "config": {"workload": desc, "rows_total": n_total, "rows_per_gpu": n_local, "dim": dim, "k": k,
-                   "queries_per_step": qb, "parallelism": f"row-shard x{world} + all-gather(top-k) over RCCL"
-                   if world > 1 else "single GPU", "streams": n_streams, "valid": not bool(args.rows)},
+                   "queries_per_step": qb, "parallelism": f"row-shard x{world} + all-gather(top-k) over RCCL (inside "
+                   "liborama_hip.so, one process per GPU)" if world > 1 else "single GPU", "streams": n_streams,
+                   "valid": not bool(args.rows)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
@@ -266,9 +246,9 @@ def main():
         out["roofline"]["mfma_peak_tflops_dense_f16"] = 2500.0
         out["roofline"]["mfma_frac"] = out["roofline"]["mfma_tflops"] / 2500.0
         if qb > 64:
-            out["roofline"]["note"] = ("K2c (GEMM-tiled, 256 queries per pass): the corpus crosses HBM once per batch and the "
-                                       "query fragments are re-read from L2 byte for byte as often; both share the CU's "
-                                       "L1-miss queue, so the HBM fraction alone understates the load (DESIGN.md K2c)")
+            out["roofline"]["note"] = ("K2d (producer/consumer GEMM tiles, 256 queries per pass): the corpus crosses HBM once "
+                                       "per batch; with the matrix pipes and the HBM stream both active the part sits at "
+                                       "its package-power limit (DESIGN.md K2d, profiles/r02_power_probe.log)")
 
     if rank == 0 and world == 1:
         # host-buffer API latency (adds the PCIe hop for the query and the k results)
@@ -282,10 +262,10 @@ def main():
         if not args.no_cpu_baseline and not f16:
             out["cpu_baseline"] = cpu_baseline(store, dim, n_total, k, args.cpu_sample_rows)
     device_name = ctx.device_info()["name"]
+    sess.close()
     store.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.barrier()
+    group.close()
     if rank == 0:
         out["device"] = device_name
         # RCCL writes its version banner through C stdio (fully buffered when stdout is a pipe): push it out first

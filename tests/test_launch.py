@@ -1,0 +1,60 @@
+"""The launcher plumbing of the one-process-per-GPU form (oramacore_amd/launch.py) with world_size 3 on CPU:
+every rank ends up with the id rank 0 made, ranks that start before rank 0 simply retry, and the static shard plan
+covers the corpus exactly once.  (The collectives themselves run inside liborama_hip.so — tests/test_shard_group_gpu.py.)"""
+import os
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+from oramacore_amd.launch import RankEnv, ShardPlan
+
+ROOT = Path(__file__).resolve().parent.parent
+
+WORKER = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, {root!r})
+    from oramacore_amd.launch import RankEnv, exchange_unique_id
+    env = RankEnv.from_env()
+    if env.rank == 0:
+        time.sleep(0.7)            # the other ranks are already knocking
+    made = []
+    def make():
+        made.append(1)
+        return bytes((i * 7 + 3) % 256 for i in range(128))
+    uid = exchange_unique_id(env, make, timeout=30)
+    assert (len(made) == 1) == (env.rank == 0)
+    print(env.rank, uid.hex())
+""")
+
+
+def test_unique_id_reaches_every_rank(tmp_path):
+    world = 3
+    port = 20000 + os.getpid() % 20000
+    procs = []
+    for r in range(world):
+        e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER.format(root=str(ROOT))], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=60) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1] for o in outs]
+    ids = {o[0].split()[1] for o in outs}
+    assert len(ids) == 1 and ids.pop() == bytes((i * 7 + 3) % 256 for i in range(128)).hex()
+    assert sorted(int(o[0].split()[0]) for o in outs) == [0, 1, 2]
+
+
+def test_world_one_needs_no_socket():
+    from oramacore_amd.launch import exchange_unique_id
+
+    assert exchange_unique_id(RankEnv(0, 0, 1, "127.0.0.1", 1), lambda: b"a" * 128) == b"a" * 128
+
+
+def test_shard_plan_is_a_partition():
+    for n, g in ((10_000_000, 8), (80_000_000, 8), (1_000_003, 3), (5, 8)):
+        plan = ShardPlan(n, g)
+        ranges = [plan.range(r) for r in range(g)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(ranges[i][1] == ranges[i + 1][0] for i in range(g - 1))
+        assert sum(plan.rows(r) for r in range(g)) == n
+        assert max(plan.rows(r) for r in range(g)) - min(plan.rows(r) for r in range(g)) <= 1
