@@ -217,7 +217,8 @@ int orama_batcher_stats(orama_batcher* b, uint64_t* requests, uint64_t* batches,
  * (ContributionsResult.token_contributions[i].per_doc_ntf, token_score.rs:264-271). */
 typedef struct {
     uint32_t token;      /* query token index (term_index) */
-    const uint64_t* doc; /* host, `len` DocumentIds, unique inside the entry */
+    const uint64_t* doc; /* host, `len` DocumentIds; a doc MAY repeat inside an entry — the reference scorer pushes every
+                          * (doc, ntf) pair (bm25.rs:355-366) and sums them in order; repeats are split into extra ranks */
     const float* ntf;    /* host, `len` normalised TFs (boost + length norm already folded in) */
     uint64_t len;
 } orama_ntf_entry;
@@ -239,6 +240,13 @@ int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_
                      const orama_bm25_params* params, const uint64_t* omc_doc, const float* omc_mul,
                      uint64_t n_omc, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
                      uint64_t* out_count);
+
+/* BM25Scorer::get_scores (bm25.rs:416-428) for seam (i): the WHOLE score map of the same computation, any size —
+ * *out_n receives the number of entries; with capacity >= *out_n the (DocumentId, score) pairs are written (order
+ * unspecified, like a HashMap's); capacity == 0 only counts.  (The selection entry above is limited to top_k <= 4096.) */
+int orama_bm25_score_map(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_entries,
+                         const orama_bm25_params* params, const uint64_t* omc_doc, const float* omc_mul, uint64_t n_omc,
+                         uint64_t capacity, uint64_t* out_ids, float* out_scores, uint64_t* out_n);
 
 /* Seam (ii): HBM-resident postings (SURVEY §8b option ii).  The store mirrors what
  * StringFieldStorage holds per field (src/collection_manager/sides/read/index/string_field.rs):
@@ -277,7 +285,9 @@ int orama_post_get_list(orama_post* p, uint32_t list, uint64_t capacity, uint64_
                         uint32_t* out_len, uint64_t* out_n);
 int orama_post_info(orama_post* p, uint64_t* n_docs, uint32_t* n_lists, uint64_t* n_postings, float* avg_len0);
 
-/* OMC multipliers of the index (Index::get_all_omc, index/mod.rs:1720-1739); doc ids ascending. */
+/* OMC multipliers of the index (Index::get_all_omc, index/mod.rs:1720-1739); doc ids ascending.  The multipliers are
+ * stored densely against the CURRENT doc table: orama_post_build / orama_post_fill_synthetic drop them — call
+ * orama_post_set_omc again after every rebuild (orama_post_append keeps them, new documents get 1.0). */
 int orama_post_set_omc(orama_post* p, const uint64_t* omc_doc, const float* omc_mul, uint64_t n);
 
 /* One (token, list) reference of a query: token `token` expands to posting list `list`
@@ -296,6 +306,59 @@ int orama_post_search(orama_post* p, const orama_term_ref* refs, uint32_t n_refs
                       const orama_bm25_params* params, const uint64_t* allow_bitmap,
                       uint64_t bitmap_bits, int apply_omc, uint64_t* out_ids, float* out_scores,
                       uint32_t* out_n, uint64_t* out_count);
+
+/* ------------------------------------------------------------------ score map, facets, groups
+ * The reference hands the WHOLE HashMap<DocumentId, f32> of a search to facets and groups
+ * (src/collection_manager/sides/read/search.rs:355-400 -> index/facet.rs:35-209, index/group.rs:107-170,
+ * sort.rs:129-230).  orama_post_search_scores is orama_post_search / orama_post_search_hybrid (hybrid != 0) that ALSO
+ * keeps that map resident: the handle owns the scratch set the scorer wrote (candidate list + position index) and a
+ * read lock on the store until orama_scores_destroy — destroy it before the next orama_post_build / append.
+ * Calls on one handle are serialised; different handles run concurrently.
+ *
+ *   orama_scores_count   token_score_results.len() (search.rs:482)
+ *   orama_scores_export  every (DocumentId, score) entry, any size (what BM25Scorer::get_scores returns)
+ *   orama_scores_lookup  token_scores.get(doc) for a list of ids (present[i] = contains_key)
+ *
+ * A facet FIELD is the resident image of one filter field of the index (BoolFieldStorage / StringFilterFieldStorage /
+ * NumberFieldStorage, index/{bool,string_filter,number}_field.rs): its DocumentIds are resolved to the index's local
+ * doc order once, at creation (ids the index does not hold are dropped — they can never be keys of a score map); it
+ * goes stale when the index is rebuilt (ORAMA_ERR_INVALID from the calls below).
+ *   buckets : bucket b = the ids `storage.filter(value_b)` yields — bool: {true, false}; string filter: one bucket per
+ *             key; group-by: one bucket per value combination (the intersections GroupContext::execute builds,
+ *             group.rs:134-166, are independent of the query — the shim materialises them once per commit)
+ *   numbers : one (doc, value) entry per stored number (i32 / f32 widened to f64, exactly representable)
+ *
+ *   orama_facet_count         counts[b] = |bucket b ∩ keys(map)|                  bool_field.rs:182-208,
+ *                                                                                   string_filter_field.rs:175-193
+ *   orama_facet_count_ranges  counts[r] = entries with from[r] <= v <= to[r] whose doc is a key of the map
+ *                                                                                   number_field.rs:368-387 (Between is
+ *                                                                                   inclusive, :604-631)
+ *   orama_group_top           per bucket the best `max_results` docs by score among keys of the map with a non-NaN
+ *                             score (sort.rs:203-213; DECLARED tie rule: score desc, DocumentId asc).
+ *                             out_ids / out_scores: n_buckets x max_results, out_n: n_buckets; max_results <= 1024.
+ * The "facets are computed on the UNFILTERED score map when the request has filters" rule (search.rs:361-396) is the
+ * caller's: it runs the second search with only the NOT-deleted bitmap and passes that handle. */
+typedef struct orama_scores orama_scores;
+typedef struct orama_facet_field orama_facet_field;
+int orama_post_search_scores(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, float b,
+                             const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits,
+                             int hybrid, const uint64_t* vec_doc, const float* vec_score, uint32_t n_vec, int apply_omc,
+                             uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count,
+                             orama_scores** out_map);
+void orama_scores_destroy(orama_scores* sm);
+int orama_scores_count(orama_scores* sm, uint64_t* out);
+int orama_scores_export(orama_scores* sm, uint64_t capacity, uint64_t* out_ids, float* out_scores, uint64_t* out_n);
+int orama_scores_lookup(orama_scores* sm, const uint64_t* doc_ids, uint32_t n, float* out_scores, uint8_t* out_present);
+int orama_facet_field_create_buckets(orama_post* index, const uint64_t* bucket_off, const uint64_t* bucket_docs,
+                                     uint32_t n_buckets, orama_facet_field** out);
+int orama_facet_field_create_numbers(orama_post* index, const uint64_t* docs, const double* values, uint64_t n,
+                                     orama_facet_field** out);
+void orama_facet_field_destroy(orama_facet_field* f);
+int orama_facet_count(orama_scores* sm, orama_facet_field* f, uint64_t* out_counts);
+int orama_facet_count_ranges(orama_scores* sm, orama_facet_field* f, const double* from, const double* to,
+                             uint32_t n_ranges, uint64_t* out_counts);
+int orama_group_top(orama_scores* sm, orama_facet_field* f, uint32_t max_results, uint64_t* out_ids, float* out_scores,
+                    uint32_t* out_n);
 
 /* ------------------------------------------------------------------ term-dictionary expansion
  * The dictionary step of collect_contributions (third-party in the reference: an FST walked with a prefix /

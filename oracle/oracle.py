@@ -50,6 +50,12 @@ def lib() -> C.CDLL:
     L.orc_rescale_score.argtypes = [C.c_float, C.c_int]
     L.orc_embedding_epilogue.restype = None
     L.orc_embedding_epilogue.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_float, vp, vp, vp]
+    L.orc_facet_count_buckets.restype = None
+    L.orc_facet_count_buckets.argtypes = [vp, C.c_uint64, vp, vp, C.c_uint32, vp]
+    L.orc_facet_count_ranges.restype = None
+    L.orc_facet_count_ranges.argtypes = [vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, C.c_uint32, vp]
+    L.orc_group_top.restype = None
+    L.orc_group_top.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.orc_bm25_idf.restype = C.c_float
     L.orc_bm25_idf.argtypes = [C.c_float, C.c_uint64]
     L.orc_bm25f_normalized_tf.restype = C.c_float
@@ -220,3 +226,36 @@ def top_n(doc, score, n: int):
     m = lib().orc_top_n(doc.ctypes.data, score.ctypes.data, doc.shape[0], n, out_doc.ctypes.data,
                         out_score.ctypes.data)
     return out_doc[:m].copy(), out_score[:m].copy()
+
+
+def facet_count_buckets(map_doc, bucket_off, bucket_doc) -> np.ndarray:
+    map_doc, bucket_off, bucket_doc = _u64(map_doc), _u64(bucket_off), _u64(bucket_doc)
+    out = np.zeros(len(bucket_off) - 1, dtype=np.uint64)
+    lib().orc_facet_count_buckets(map_doc.ctypes.data, C.c_uint64(len(map_doc)), bucket_off.ctypes.data,
+                                  bucket_doc.ctypes.data, C.c_uint32(len(out)), out.ctypes.data)
+    return out
+
+
+def facet_count_ranges(map_doc, doc, value, ranges) -> np.ndarray:
+    map_doc, doc = _u64(map_doc), _u64(doc)
+    value = np.ascontiguousarray(value, dtype=np.float64)
+    fr = np.ascontiguousarray([r[0] for r in ranges], dtype=np.float64)
+    to = np.ascontiguousarray([r[1] for r in ranges], dtype=np.float64)
+    out = np.zeros(len(ranges), dtype=np.uint64)
+    lib().orc_facet_count_ranges(map_doc.ctypes.data, C.c_uint64(len(map_doc)), doc.ctypes.data, value.ctypes.data,
+                                 C.c_uint64(len(doc)), fr.ctypes.data, to.ctypes.data, C.c_uint32(len(ranges)),
+                                 out.ctypes.data)
+    return out
+
+
+def group_top(map_doc, map_score, group_off, group_doc, max_results: int):
+    map_doc, group_off, group_doc = _u64(map_doc), _u64(group_off), _u64(group_doc)
+    map_score = _f32(map_score)
+    g = len(group_off) - 1
+    od = np.zeros((g, max_results), dtype=np.uint64)
+    os_ = np.zeros((g, max_results), dtype=np.float32)
+    on = np.zeros(g, dtype=np.uint32)
+    lib().orc_group_top(map_doc.ctypes.data, map_score.ctypes.data, C.c_uint64(len(map_doc)), group_off.ctypes.data,
+                        group_doc.ctypes.data, C.c_uint32(g), C.c_uint32(max_results), od.ctypes.data, os_.ctypes.data,
+                        on.ctypes.data)
+    return od, os_, on

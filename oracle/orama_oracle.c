@@ -441,3 +441,97 @@ uint64_t orc_top_n(const uint64_t* doc, const float* score, uint64_t n_in, uint6
     free(a);
     return kk;
 }
+
+/* ---------------------------------------------------------------- facets / groups */
+
+static int u64_cmp(const void* a, const void* b) {
+    const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return (x > y) - (x < y);
+}
+
+/* token_scores.contains_key(doc) over a sorted copy of the map's keys */
+static int map_contains(const uint64_t* sorted, uint64_t n, uint64_t doc) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) / 2;
+        if (sorted[mid] < doc) lo = mid + 1; else hi = mid;
+    }
+    return lo < n && sorted[lo] == doc;
+}
+
+/* BoolFieldStorage::calculate_facet (bool_field.rs:182-208) and StringFilterFieldStorage::calculate_facet
+ * (string_filter_field.rs:175-193): for every value of the field (a bucket = the doc ids `storage.filter(value)`
+ * yields) count the ids that are keys of token_scores.  A NaN score is still a key. */
+void orc_facet_count_buckets(const uint64_t* map_doc, uint64_t n_map, const uint64_t* bucket_off,
+                             const uint64_t* bucket_doc, uint32_t n_buckets, uint64_t* out_counts) {
+    uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n_map ? n_map : 1));
+    memcpy(keys, map_doc, sizeof(uint64_t) * (size_t)n_map);
+    qsort(keys, (size_t)n_map, sizeof(uint64_t), u64_cmp);
+    for (uint32_t b = 0; b < n_buckets; ++b) {
+        uint64_t c = 0;
+        for (uint64_t i = bucket_off[b]; i < bucket_off[b + 1]; ++i) c += (uint64_t)map_contains(keys, n_map, bucket_doc[i]);
+        out_counts[b] = c;
+    }
+    free(keys);
+}
+
+/* NumberFieldStorage::calculate_facet (number_field.rs:368-387): per range, the documents the filter
+ * NumberFilter::Between((from, to)) yields — BetweenInclusive on both storages (number_field.rs:604-631) — that are keys
+ * of token_scores.  One (doc, value) entry per stored number (a doc holding two numbers inside one range is yielded
+ * twice by the storage iterator and counted twice, as `.filter(..).count()` does).  Values compared as f64. */
+void orc_facet_count_ranges(const uint64_t* map_doc, uint64_t n_map, const uint64_t* doc, const double* value, uint64_t n,
+                            const double* from, const double* to, uint32_t n_ranges, uint64_t* out_counts) {
+    uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n_map ? n_map : 1));
+    memcpy(keys, map_doc, sizeof(uint64_t) * (size_t)n_map);
+    qsort(keys, (size_t)n_map, sizeof(uint64_t), u64_cmp);
+    for (uint32_t r = 0; r < n_ranges; ++r) out_counts[r] = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (!map_contains(keys, n_map, doc[i])) continue;
+        for (uint32_t r = 0; r < n_ranges; ++r)
+            if (from[r] <= value[i] && value[i] <= to[r]) out_counts[r] += 1;
+    }
+    free(keys);
+}
+
+static int ts_by_doc(const void* a, const void* b) {
+    const ts_t* x = (const ts_t*)a;
+    const ts_t* y = (const ts_t*)b;
+    return (x->doc > y->doc) - (x->doc < y->doc);
+}
+
+/* sort_groups without sort_by (sort.rs:203-213): per group (the doc-id set GroupContext::execute built, group.rs:
+ * 107-170) a CappedHeap of `max_results` over the docs that are keys of token_scores with a non-NaN score, best score
+ * first.  Declared tie rule (the reference iterates a HashSet into a heap — undefined): score desc, DocumentId asc.
+ * out_doc / out_score: n_groups x max_results, out_n: n_groups. */
+void orc_group_top(const uint64_t* map_doc, const float* map_score, uint64_t n_map, const uint64_t* group_off,
+                   const uint64_t* group_doc, uint32_t n_groups, uint32_t max_results, uint64_t* out_doc,
+                   float* out_score, uint32_t* out_n) {
+    ts_t* m = (ts_t*)malloc(sizeof(ts_t) * (size_t)(n_map ? n_map : 1));
+    for (uint64_t i = 0; i < n_map; ++i) {
+        m[i].doc = map_doc[i];
+        m[i].score = map_score[i];
+    }
+    qsort(m, (size_t)n_map, sizeof(ts_t), ts_by_doc);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint64_t len = group_off[g + 1] - group_off[g];
+        ts_t* c = (ts_t*)malloc(sizeof(ts_t) * (size_t)(len ? len : 1));
+        uint64_t nc = 0;
+        for (uint64_t i = group_off[g]; i < group_off[g + 1]; ++i) {
+            uint64_t lo = 0, hi = n_map;
+            while (lo < hi) {
+                uint64_t mid = (lo + hi) / 2;
+                if (m[mid].doc < group_doc[i]) lo = mid + 1; else hi = mid;
+            }
+            if (lo < n_map && m[lo].doc == group_doc[i] && !isnan(m[lo].score)) c[nc++] = m[lo];
+        }
+        qsort(c, (size_t)nc, sizeof(ts_t), ts_cmp);
+        const uint32_t k = (uint32_t)(nc < max_results ? nc : max_results);
+        for (uint32_t i = 0; i < k; ++i) {
+            out_doc[(size_t)g * max_results + i] = c[i].doc;
+            out_score[(size_t)g * max_results + i] = c[i].score;
+        }
+        out_n[g] = k;
+        free(c);
+    }
+    free(m);
+}

@@ -134,6 +134,23 @@ void orc_apply_omc(uint64_t* doc, float* score, uint64_t n,
 uint64_t orc_top_n(const uint64_t* doc, const float* score, uint64_t n_in, uint64_t n,
                    uint64_t* out_doc, float* out_score);
 
+/* ---------------------------------------------------------------- facets / groups over the score map (§8f rank 4) */
+
+/* BoolFieldStorage::calculate_facet (src/collection_manager/sides/read/index/bool_field.rs:182-208) and
+ * StringFilterFieldStorage::calculate_facet (string_filter_field.rs:175-193): per field value (bucket b = doc ids
+ * bucket_doc[bucket_off[b] .. bucket_off[b+1])) the number of ids that are keys of token_scores (NaN scores count). */
+void orc_facet_count_buckets(const uint64_t* map_doc, uint64_t n_map, const uint64_t* bucket_off,
+                             const uint64_t* bucket_doc, uint32_t n_buckets, uint64_t* out_counts);
+/* NumberFieldStorage::calculate_facet (number_field.rs:368-387): NumberFilter::Between is inclusive on both ends
+ * (number_field.rs:604-631); one (doc, value) entry per stored number. */
+void orc_facet_count_ranges(const uint64_t* map_doc, uint64_t n_map, const uint64_t* doc, const double* value, uint64_t n,
+                            const double* from, const double* to, uint32_t n_ranges, uint64_t* out_counts);
+/* sort_groups without sort_by (src/collection_manager/sides/read/sort.rs:203-213): per group the best `max_results`
+ * documents of the group that are in token_scores with a non-NaN score.  DECLARED tie rule: score desc, id asc. */
+void orc_group_top(const uint64_t* map_doc, const float* map_score, uint64_t n_map, const uint64_t* group_off,
+                   const uint64_t* group_doc, uint32_t n_groups, uint32_t max_results, uint64_t* out_doc,
+                   float* out_score, uint32_t* out_n);
+
 #ifdef __cplusplus
 }
 #endif

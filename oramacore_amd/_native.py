@@ -151,6 +151,8 @@ def _declare(lib: C.CDLL) -> None:
         "orama_batcher_stats": [vp, u64p, u64p, u32p],
         "orama_bm25_score": [vp, C.POINTER(NtfEntry), C.c_uint32, C.POINTER(Bm25Params), vp, vp, C.c_uint64,
                              vp, vp, u32p, u64p],
+        "orama_bm25_score_map": [vp, C.POINTER(NtfEntry), C.c_uint32, C.POINTER(Bm25Params), vp, vp, C.c_uint64, C.c_uint64,
+                                 vp, vp, u64p],
         "orama_post_create": [vp, C.POINTER(vp)],
         "orama_post_build": [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_uint32, vp, vp, vp, vp, vp],
         "orama_post_set_omc": [vp, vp, vp, C.c_uint64],
@@ -185,6 +187,16 @@ def _declare(lib: C.CDLL) -> None:
         "orama_shard_session_step": [vp, C.c_uint32],
         "orama_shard_session_sync": [vp],
         "orama_shard_session_result": [vp, C.c_uint32, vp, vp, vp],
+        "orama_post_search_scores": [vp, C.POINTER(TermRef), C.c_uint32, C.c_float, C.POINTER(Bm25Params), vp, C.c_uint64,
+                                     C.c_int, vp, vp, C.c_uint32, C.c_int, vp, vp, u32p, u64p, C.POINTER(vp)],
+        "orama_scores_count": [vp, u64p],
+        "orama_scores_export": [vp, C.c_uint64, vp, vp, u64p],
+        "orama_scores_lookup": [vp, vp, C.c_uint32, vp, vp],
+        "orama_facet_field_create_buckets": [vp, vp, vp, C.c_uint32, C.POINTER(vp)],
+        "orama_facet_field_create_numbers": [vp, vp, vp, C.c_uint64, C.POINTER(vp)],
+        "orama_facet_count": [vp, vp, vp],
+        "orama_facet_count_ranges": [vp, vp, vp, vp, C.c_uint32, vp],
+        "orama_group_top": [vp, vp, C.c_uint32, vp, vp, vp],
         "orama_hybrid_combine": [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u32p, u64p],
         "orama_hybrid_rrf": [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, vp, vp, u32p,
                              u64p],
@@ -206,7 +218,7 @@ def _declare(lib: C.CDLL) -> None:
         fn.restype = None
     lib.orama_shard_group_ctx.argtypes = [vp, C.c_uint32]
     lib.orama_shard_group_ctx.restype = vp
-    for name in ("orama_ctx_destroy", "orama_shard_group_destroy", "orama_shard_session_destroy", "orama_vec_destroy", "orama_post_destroy", "orama_post_query_end",
+    for name in ("orama_ctx_destroy", "orama_scores_destroy", "orama_facet_field_destroy", "orama_shard_group_destroy", "orama_shard_session_destroy", "orama_vec_destroy", "orama_post_destroy", "orama_post_query_end",
                  "orama_batcher_destroy", "orama_allow_destroy",
                  "orama_dict_destroy"):
         fn = getattr(lib, name)

@@ -116,6 +116,28 @@ int launch_count_export(const Bm25State* st, unsigned long long* d_out, hipStrea
 int launch_count_sum(const void* d_blocks, uint64_t stride, uint64_t off, uint32_t lists, unsigned long long* d_out,
                      hipStream_t stream);
 
+// ---- the score map of one search as the facet / group kernels see it (facets.hip)
+struct ScoreMapDev {
+    const unsigned long long* emit = nullptr;  // [n_docs] {epoch:32 | position:32}
+    const float* cand_score = nullptr;         // candidate list = the map's entries (NaN slots are empty)
+    const uint32_t* cand_idx = nullptr;
+    const uint64_t* docs = nullptr;            // local idx -> DocumentId; nullptr when ids are dense_base + idx
+    uint64_t dense_base = 0;
+    uint32_t epoch = 0;
+};
+constexpr uint32_t kGroupMaxK = 1024;  // max_results of a group-by (LDS-resident running top-k)
+int launch_facet_count_buckets(const ScoreMapDev& m, const uint32_t* d_entry_doc, const uint64_t* d_bucket_off,
+                               uint32_t n_buckets, uint64_t n_entries, unsigned long long* d_counts, hipStream_t s);
+int launch_facet_count_ranges(const ScoreMapDev& m, const uint32_t* d_entry_doc, const double* d_entry_val, uint64_t n_entries,
+                              const double* d_from, const double* d_to, uint32_t n_ranges, unsigned long long* d_counts,
+                              hipStream_t s);
+int launch_group_top(const ScoreMapDev& m, const uint32_t* d_entry_doc, const uint64_t* d_bucket_off, uint32_t n_buckets,
+                     uint32_t k, uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_n, hipStream_t s);
+int launch_scores_export(const ScoreMapDev& m, uint32_t list_len, uint64_t* d_out_ids, float* d_out_scores,
+                         uint32_t* d_cursor, hipStream_t s);
+int launch_scores_lookup(const ScoreMapDev& m, const uint32_t* d_doc, uint32_t n, float* d_out, uint8_t* d_present,
+                         hipStream_t s);
+
 // ---- synthetic postings generated in HBM (bench utility)
 // len[doc] ~ LogNormal(4.0, 0.6) clipped to [4, 2000]
 int launch_synth_doc_len(uint16_t* d_len, uint64_t n_docs, uint64_t seed, hipStream_t stream);

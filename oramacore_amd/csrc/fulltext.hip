@@ -182,6 +182,7 @@ struct orama_post {
     std::vector<uint64_t> list_off;
     DevBuf d_docs, d_post_doc, d_post_val, d_omc;
     bool has_omc = false;
+    uint64_t generation = 0;  // bumped by every rebuild of the doc table: facet fields resolved against an older one are stale
 };
 
 namespace {
@@ -510,7 +511,10 @@ int orama_post_build(orama_post* p, const uint64_t* docs, uint64_t n_docs, uint3
     p->field_of_list.assign(field_of_list, field_of_list + n_lists);
     p->list_off.assign(list_off, list_off + (n_lists ? n_lists + 1 : 0));
     if (!n_lists) p->list_off.assign(1, 0);
+    // the multiplier array was sized and indexed for the previous doc table: call orama_post_set_omc again
     p->has_omc = false;
+    p->d_omc.release();
+    ++p->generation;
     return ORAMA_OK;
 }
 
@@ -674,6 +678,8 @@ int orama_post_fill_synthetic(orama_post* p, uint64_t n_docs, uint64_t first_doc
     p->field_of_list.assign(n_lists, 0u);
     p->list_off = off;
     p->has_omc = false;
+    p->d_omc.release();
+    ++p->generation;
     if (out_total_postings) *out_total_postings = total;
     return ORAMA_OK;
 }
@@ -748,6 +754,273 @@ int orama_post_search_hybrid(orama_post* p, const orama_term_ref* refs, uint32_t
     return post_search_impl(p, refs, n_refs, b, params, allow_bitmap, bitmap_bits, vec_doc, vec_score, n_vec, true,
                             apply_omc, out_ids, out_scores, out_n, out_count);
 }
+
+// ================================================================= score-map handle, facets, groups (§8f rank 4)
+// The reference keeps the whole HashMap<DocumentId, f32> of a search around for facets and groups
+// (src/collection_manager/sides/read/search.rs:355-400).  Here the map is the candidate list + position index the
+// scorer left in its scratch set; an orama_scores handle keeps that scratch set leased (and the store read-locked)
+// until it is destroyed, so facet / group passes run over it in HBM and nothing of size `count` crosses PCIe.
+struct orama_scores {
+    orama_post* p = nullptr;
+    std::shared_lock<std::shared_mutex> lk;
+    ScratchLease lease;
+    PostQuery st;
+    uint64_t generation = 0;
+    uint64_t count = 0;
+    uint32_t list_len = 0;
+    std::mutex mu;  // facet / group / export calls on one handle are serialised (they share its stream)
+    DevBuf tmp_a, tmp_b, tmp_c;
+    explicit orama_scores(orama_post* post) : p(post), lk(post->mu), lease(post->ctx) {}
+    ScoreMapDev dev() const {
+        ScoreMapDev m;
+        m.emit = st.qb.emit;
+        m.cand_score = st.qb.cand_score;
+        m.cand_idx = st.qb.cand_idx;
+        m.docs = p->d_docs.as<uint64_t>();
+        m.dense_base = p->dense_base;
+        m.epoch = st.qb.epoch;
+        return m;
+    }
+};
+
+struct orama_facet_field {
+    orama_post* p = nullptr;  // identity only (compared, never dereferenced after creation: the index may be gone)
+    int device = 0;
+    uint64_t generation = 0;
+    bool numbers = false;
+    uint32_t n_buckets = 0;
+    uint64_t n_entries = 0;
+    DevBuf entry_doc, entry_val, bucket_off;
+};
+
+namespace {
+int check_field(orama_scores* sm, orama_facet_field* f, bool numbers) {
+    ORAMA_REQUIRE(sm && f, "null argument");
+    ORAMA_REQUIRE(f->p == sm->p, "facet field and score map belong to different indexes");
+    ORAMA_REQUIRE(f->generation == sm->generation, "facet field is stale: the index was rebuilt since it was created");
+    ORAMA_REQUIRE(f->numbers == numbers, numbers ? "this call needs a number field" : "this call needs a bucket field");
+    return ORAMA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int orama_post_search_scores(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, float b,
+                             const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits,
+                             int hybrid, const uint64_t* vec_doc, const float* vec_score, uint32_t n_vec, int apply_omc,
+                             uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count,
+                             orama_scores** out_map) {
+    ORAMA_REQUIRE(p && out_n && params && out_map, "null argument");
+    *out_map = nullptr;
+    *out_n = 0;
+    if (out_count) *out_count = 0;
+    ORAMA_REQUIRE(params->top_k == 0 || (out_ids && out_scores), "null output");
+    ORAMA_REQUIRE(!hybrid || n_vec == 0 || (vec_doc && vec_score), "null vector map");
+    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    std::unique_ptr<orama_scores> h(new (std::nothrow) orama_scores(p));
+    if (!h) {
+        set_error("out of host memory");
+        return ORAMA_ERR_OOM;
+    }
+    ORAMA_TRY(h->lease.init());
+    Scratch* sc = h->lease.s.get();
+    ORAMA_TRY(post_stage1(p, sc, refs, n_refs, b, params, allow_bitmap, bitmap_bits, hybrid != 0, apply_omc, hybrid ? n_vec : 0,
+                          &h->st));
+    uint64_t count = 0;
+    ORAMA_TRY(post_stage2(p, sc, h->st, params, vec_doc, vec_score, hybrid ? n_vec : 0, out_ids, out_scores, out_n, &count));
+    ORAMA_HIP_TRY(hipMemcpy(&h->list_len, &h->st.qb.state->list_len, 4, hipMemcpyDeviceToHost));
+    h->count = count;
+    h->generation = p->generation;
+    if (out_count) *out_count = count;
+    *out_map = h.release();
+    return ORAMA_OK;
+}
+
+void orama_scores_destroy(orama_scores* sm) {
+    if (!sm) return;
+    (void)hipSetDevice(sm->p->ctx->device);
+    if (sm->lease.s) (void)hipStreamSynchronize(sm->lease.s->stream);
+    delete sm;
+}
+
+int orama_scores_count(orama_scores* sm, uint64_t* out) {
+    ORAMA_REQUIRE(sm && out, "null argument");
+    *out = sm->count;
+    return ORAMA_OK;
+}
+
+int orama_scores_export(orama_scores* sm, uint64_t capacity, uint64_t* out_ids, float* out_scores, uint64_t* out_n) {
+    ORAMA_REQUIRE(sm && out_n, "null argument");
+    *out_n = sm->count;
+    if (capacity == 0 || sm->count == 0) return ORAMA_OK;
+    ORAMA_REQUIRE(capacity >= sm->count && out_ids && out_scores, "capacity %llu < map size %llu",
+                  (unsigned long long)capacity, (unsigned long long)sm->count);
+    ORAMA_HIP_TRY(hipSetDevice(sm->p->ctx->device));
+    std::lock_guard<std::mutex> g(sm->mu);
+    hipStream_t s = sm->lease.s->stream;
+    ORAMA_TRY(sm->tmp_a.reserve((size_t)sm->count * 8));
+    ORAMA_TRY(sm->tmp_b.reserve((size_t)sm->count * 4));
+    ORAMA_TRY(sm->tmp_c.reserve(16));
+    ORAMA_TRY(launch_scores_export(sm->dev(), sm->list_len, sm->tmp_a.as<uint64_t>(), sm->tmp_b.as<float>(),
+                                   sm->tmp_c.as<uint32_t>(), s));
+    ORAMA_HIP_TRY(hipMemcpyAsync(out_ids, sm->tmp_a.p, (size_t)sm->count * 8, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipMemcpyAsync(out_scores, sm->tmp_b.p, (size_t)sm->count * 4, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    return ORAMA_OK;
+}
+
+int orama_scores_lookup(orama_scores* sm, const uint64_t* doc_ids, uint32_t n, float* out_scores, uint8_t* out_present) {
+    ORAMA_REQUIRE(sm && (n == 0 || (doc_ids && out_scores && out_present)), "null argument");
+    if (n == 0) return ORAMA_OK;
+    ORAMA_HIP_TRY(hipSetDevice(sm->p->ctx->device));
+    std::lock_guard<std::mutex> g(sm->mu);
+    hipStream_t s = sm->lease.s->stream;
+    std::vector<uint32_t> local(n);
+    for (uint32_t i = 0; i < n; ++i)
+        if (!sm->p->local_of(doc_ids[i], &local[i])) local[i] = 0xffffffffu;
+    ORAMA_TRY(sm->tmp_a.reserve((size_t)n * 4));
+    ORAMA_TRY(sm->tmp_b.reserve((size_t)n * 4));
+    ORAMA_TRY(sm->tmp_c.reserve((size_t)n + 16));
+    ORAMA_HIP_TRY(hipMemcpyAsync(sm->tmp_a.p, local.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    ORAMA_TRY(launch_scores_lookup(sm->dev(), sm->tmp_a.as<uint32_t>(), n, sm->tmp_b.as<float>(), sm->tmp_c.as<uint8_t>(), s));
+    ORAMA_HIP_TRY(hipMemcpyAsync(out_scores, sm->tmp_b.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipMemcpyAsync(out_present, sm->tmp_c.p, (size_t)n, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    return ORAMA_OK;
+}
+
+int orama_facet_field_create_buckets(orama_post* index, const uint64_t* bucket_off, const uint64_t* bucket_docs,
+                                     uint32_t n_buckets, orama_facet_field** out) {
+    ORAMA_REQUIRE(index && out && (n_buckets == 0 || bucket_off), "null argument");
+    *out = nullptr;
+    const uint64_t n = n_buckets ? bucket_off[n_buckets] : 0;
+    ORAMA_REQUIRE(n == 0 || bucket_docs, "null bucket docs");
+    for (uint32_t b = 0; b < n_buckets; ++b)
+        ORAMA_REQUIRE(bucket_off[b] <= bucket_off[b + 1], "bucket offsets must be non-decreasing");
+    ORAMA_HIP_TRY(hipSetDevice(index->ctx->device));
+    std::shared_lock<std::shared_mutex> lk(index->mu);
+    std::unique_ptr<orama_facet_field> f(new (std::nothrow) orama_facet_field());
+    if (!f) {
+        set_error("out of host memory");
+        return ORAMA_ERR_OOM;
+    }
+    f->p = index;
+    f->device = index->ctx->device;
+    f->generation = index->generation;
+    f->numbers = false;
+    f->n_buckets = n_buckets;
+    f->n_entries = n;
+    // DocumentId -> local doc index once, here; ids the index does not hold can never be keys of a score map
+    std::vector<uint32_t> local((size_t)n);
+    for (uint64_t i = 0; i < n; ++i)
+        if (!index->local_of(bucket_docs[i], &local[(size_t)i])) local[(size_t)i] = 0xffffffffu;
+    ORAMA_TRY(f->entry_doc.reserve(std::max<size_t>(4, (size_t)n * 4)));
+    ORAMA_TRY(f->bucket_off.reserve((size_t)(n_buckets + 1) * 8));
+    if (n) ORAMA_HIP_TRY(hipMemcpy(f->entry_doc.p, local.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    const uint64_t zero = 0;
+    ORAMA_HIP_TRY(hipMemcpy(f->bucket_off.p, n_buckets ? bucket_off : &zero, (size_t)(n_buckets + 1) * 8, hipMemcpyHostToDevice));
+    *out = f.release();
+    return ORAMA_OK;
+}
+
+int orama_facet_field_create_numbers(orama_post* index, const uint64_t* docs, const double* values, uint64_t n,
+                                     orama_facet_field** out) {
+    ORAMA_REQUIRE(index && out && (n == 0 || (docs && values)), "null argument");
+    *out = nullptr;
+    ORAMA_HIP_TRY(hipSetDevice(index->ctx->device));
+    std::shared_lock<std::shared_mutex> lk(index->mu);
+    std::unique_ptr<orama_facet_field> f(new (std::nothrow) orama_facet_field());
+    if (!f) {
+        set_error("out of host memory");
+        return ORAMA_ERR_OOM;
+    }
+    f->p = index;
+    f->device = index->ctx->device;
+    f->generation = index->generation;
+    f->numbers = true;
+    f->n_entries = n;
+    std::vector<uint32_t> local((size_t)n);
+    for (uint64_t i = 0; i < n; ++i)
+        if (!index->local_of(docs[i], &local[(size_t)i])) local[(size_t)i] = 0xffffffffu;
+    ORAMA_TRY(f->entry_doc.reserve(std::max<size_t>(4, (size_t)n * 4)));
+    ORAMA_TRY(f->entry_val.reserve(std::max<size_t>(8, (size_t)n * 8)));
+    if (n) {
+        ORAMA_HIP_TRY(hipMemcpy(f->entry_doc.p, local.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        ORAMA_HIP_TRY(hipMemcpy(f->entry_val.p, values, (size_t)n * 8, hipMemcpyHostToDevice));
+    }
+    *out = f.release();
+    return ORAMA_OK;
+}
+
+void orama_facet_field_destroy(orama_facet_field* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    (void)hipDeviceSynchronize();
+    delete f;
+}
+
+int orama_facet_count(orama_scores* sm, orama_facet_field* f, uint64_t* out_counts) {
+    ORAMA_TRY(check_field(sm, f, false));
+    if (f->n_buckets == 0) return ORAMA_OK;
+    ORAMA_REQUIRE(out_counts, "null output");
+    ORAMA_HIP_TRY(hipSetDevice(sm->p->ctx->device));
+    std::lock_guard<std::mutex> g(sm->mu);
+    hipStream_t s = sm->lease.s->stream;
+    ORAMA_TRY(sm->tmp_a.reserve((size_t)f->n_buckets * 8));
+    ORAMA_TRY(launch_facet_count_buckets(sm->dev(), f->entry_doc.as<uint32_t>(), f->bucket_off.as<uint64_t>(), f->n_buckets,
+                                         f->n_entries, sm->tmp_a.as<unsigned long long>(), s));
+    ORAMA_HIP_TRY(hipMemcpyAsync(out_counts, sm->tmp_a.p, (size_t)f->n_buckets * 8, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    return ORAMA_OK;
+}
+
+int orama_facet_count_ranges(orama_scores* sm, orama_facet_field* f, const double* from, const double* to,
+                             uint32_t n_ranges, uint64_t* out_counts) {
+    ORAMA_TRY(check_field(sm, f, true));
+    if (n_ranges == 0) return ORAMA_OK;
+    ORAMA_REQUIRE(from && to && out_counts, "null argument");
+    ORAMA_HIP_TRY(hipSetDevice(sm->p->ctx->device));
+    std::lock_guard<std::mutex> g(sm->mu);
+    hipStream_t s = sm->lease.s->stream;
+    // ranges in chunks of 64 (the kernel keeps them in LDS)
+    for (uint32_t r0 = 0; r0 < n_ranges; r0 += 64) {
+        const uint32_t nr = std::min<uint32_t>(64, n_ranges - r0);
+        ORAMA_TRY(sm->tmp_a.reserve(64 * 8));
+        ORAMA_TRY(sm->tmp_b.reserve(2 * 64 * 8));
+        ORAMA_HIP_TRY(hipMemcpyAsync(sm->tmp_b.p, from + r0, (size_t)nr * 8, hipMemcpyHostToDevice, s));
+        ORAMA_HIP_TRY(hipMemcpyAsync(sm->tmp_b.as<double>() + 64, to + r0, (size_t)nr * 8, hipMemcpyHostToDevice, s));
+        ORAMA_TRY(launch_facet_count_ranges(sm->dev(), f->entry_doc.as<uint32_t>(), f->entry_val.as<double>(), f->n_entries,
+                                            sm->tmp_b.as<double>(), sm->tmp_b.as<double>() + 64, nr,
+                                            sm->tmp_a.as<unsigned long long>(), s));
+        ORAMA_HIP_TRY(hipMemcpyAsync(out_counts + r0, sm->tmp_a.p, (size_t)nr * 8, hipMemcpyDeviceToHost, s));
+        ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    }
+    return ORAMA_OK;
+}
+
+int orama_group_top(orama_scores* sm, orama_facet_field* f, uint32_t max_results, uint64_t* out_ids, float* out_scores,
+                    uint32_t* out_n) {
+    ORAMA_TRY(check_field(sm, f, false));
+    if (f->n_buckets == 0) return ORAMA_OK;
+    ORAMA_REQUIRE(out_ids && out_scores && out_n, "null output");
+    ORAMA_REQUIRE(max_results >= 1 && max_results <= kGroupMaxK, "max_results %u outside [1, %u]", max_results, kGroupMaxK);
+    ORAMA_HIP_TRY(hipSetDevice(sm->p->ctx->device));
+    std::lock_guard<std::mutex> g(sm->mu);
+    hipStream_t s = sm->lease.s->stream;
+    const size_t nk = (size_t)f->n_buckets * max_results;
+    ORAMA_TRY(sm->tmp_a.reserve(nk * 8));
+    ORAMA_TRY(sm->tmp_b.reserve(nk * 4));
+    ORAMA_TRY(sm->tmp_c.reserve((size_t)f->n_buckets * 4));
+    ORAMA_TRY(launch_group_top(sm->dev(), f->entry_doc.as<uint32_t>(), f->bucket_off.as<uint64_t>(), f->n_buckets, max_results,
+                               sm->tmp_a.as<uint64_t>(), sm->tmp_b.as<float>(), sm->tmp_c.as<uint32_t>(), s));
+    ORAMA_HIP_TRY(hipMemcpyAsync(out_ids, sm->tmp_a.p, nk * 8, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipMemcpyAsync(out_scores, sm->tmp_b.p, nk * 4, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipMemcpyAsync(out_n, sm->tmp_c.p, (size_t)f->n_buckets * 4, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    return ORAMA_OK;
+}
+
+}  // extern "C"
 
 // ================================================================= staged query: one index sharded over GPUs
 // SURVEY §8e.  Every stage enqueues on the caller's stream; the caller runs the collectives between them.
@@ -950,14 +1223,20 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
 }
 
 // ================================================================= seam (i): host-provided contributions
-int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_entries,
-                     const orama_bm25_params* params, const uint64_t* omc_doc, const float* omc_mul,
-                     uint64_t n_omc, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
-                     uint64_t* out_count) {
-    ORAMA_REQUIRE(ctx && out_n, "null argument");
-    *out_n = 0;
+// export_capacity > 0: instead of the top-k, return EVERY (DocumentId, score) entry of the map (get_scores()).
+static int bm25_score_impl(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_entries,
+                           const orama_bm25_params* params_in, const uint64_t* omc_doc, const float* omc_mul,
+                           uint64_t n_omc, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
+                           uint64_t* out_count, uint64_t export_capacity, uint64_t* out_n64) {
+    ORAMA_REQUIRE(ctx && (out_n || out_n64), "null argument");
+    if (out_n) *out_n = 0;
+    if (out_n64) *out_n64 = 0;
     if (out_count) *out_count = 0;
-    ORAMA_TRY(check_params(params));
+    ORAMA_TRY(check_params(params_in));
+    orama_bm25_params params_copy = *params_in;
+    const bool export_all = out_n64 != nullptr;
+    if (export_all) params_copy.top_k = 0;
+    const orama_bm25_params* params = &params_copy;
     ORAMA_REQUIRE(n_entries == 0 || entries, "null entries");
     ORAMA_REQUIRE(params->top_k == 0 || (out_ids && out_scores), "null output");
     ORAMA_HIP_TRY(hipSetDevice(ctx->device));
@@ -1164,8 +1443,48 @@ int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_
         ORAMA_TRY(launch_omc_sparse(reinterpret_cast<const uint32_t*>(db + omc_off),
                                     reinterpret_cast<const float*>(db + omc_off + (size_t)n_omc * 4), n_o, qb.epoch,
                                     qb.emit, qb.cand_score, s));
-    return select_and_download(ctx, sc.s.get(), qb, reinterpret_cast<const uint64_t*>(db + doc_off),
-                               (uint32_t)touched_cap, params->top_k, out_ids, out_scores, out_n, out_count);
+    uint32_t dummy_n = 0;
+    uint64_t count = 0;
+    ORAMA_TRY(select_and_download(ctx, sc.s.get(), qb, reinterpret_cast<const uint64_t*>(db + doc_off),
+                                  (uint32_t)touched_cap, params->top_k, out_ids, out_scores, out_n ? out_n : &dummy_n, &count));
+    if (out_count) *out_count = count;
+    if (!export_all) return ORAMA_OK;
+    *out_n64 = count;
+    if (export_capacity == 0 || count == 0) return ORAMA_OK;
+    ORAMA_REQUIRE(export_capacity >= count && out_ids && out_scores, "capacity %llu < map size %llu",
+                  (unsigned long long)export_capacity, (unsigned long long)count);
+    ScoreMapDev m;
+    m.emit = qb.emit;
+    m.cand_score = qb.cand_score;
+    m.cand_idx = qb.cand_idx;
+    m.docs = reinterpret_cast<const uint64_t*>(db + doc_off);
+    m.epoch = qb.epoch;
+    ORAMA_TRY(sc->out_ids.reserve((size_t)count * 8));
+    ORAMA_TRY(sc->out_val.reserve((size_t)count * 4));
+    ORAMA_TRY(sc->out_n.reserve(16));
+    ORAMA_TRY(launch_scores_export(m, (uint32_t)touched_cap, sc->out_ids.as<uint64_t>(), sc->out_val.as<float>(),
+                                   sc->out_n.as<uint32_t>(), s));
+    ORAMA_HIP_TRY(hipMemcpyAsync(out_ids, sc->out_ids.p, (size_t)count * 8, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipMemcpyAsync(out_scores, sc->out_val.p, (size_t)count * 4, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    return ORAMA_OK;
+}
+
+int orama_bm25_score(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_entries,
+                     const orama_bm25_params* params, const uint64_t* omc_doc, const float* omc_mul,
+                     uint64_t n_omc, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
+                     uint64_t* out_count) {
+    ORAMA_REQUIRE(out_n, "null argument");
+    return bm25_score_impl(ctx, entries, n_entries, params, omc_doc, omc_mul, n_omc, out_ids, out_scores, out_n, out_count, 0,
+                           nullptr);
+}
+
+int orama_bm25_score_map(orama_ctx* ctx, const orama_ntf_entry* entries, uint32_t n_entries,
+                         const orama_bm25_params* params, const uint64_t* omc_doc, const float* omc_mul, uint64_t n_omc,
+                         uint64_t capacity, uint64_t* out_ids, float* out_scores, uint64_t* out_n) {
+    ORAMA_REQUIRE(out_n, "null argument");
+    return bm25_score_impl(ctx, entries, n_entries, params, omc_doc, omc_mul, n_omc, out_ids, out_scores, nullptr, nullptr,
+                           capacity, out_n);
 }
 
 int orama_hybrid_combine(orama_ctx* ctx, const uint64_t* vec_doc, const float* vec_score, uint64_t n_vec,

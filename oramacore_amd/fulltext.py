@@ -81,6 +81,35 @@ def bm25_score(ctx: Context, entries, n_tokens: int, total_documents: float, top
     return out_ids[: out_n.value], out_sc[: out_n.value], out_count.value
 
 
+def bm25_score_map(ctx: Context, entries, n_tokens: int, total_documents: float, threshold=None, omc: dict | None = None,
+                   k: float = K1_DEFAULT) -> dict:
+    """Seam (i), the WHOLE score map (BM25Scorer::get_scores, bm25.rs:416-428) — any size."""
+    lib = N.load()
+    keep = []
+    arr = (N.NtfEntry * max(len(entries), 1))()
+    for i, (tok, docs, ntf) in enumerate(entries):
+        docs, ntf = _u64(docs), _f32(ntf)
+        keep.append((docs, ntf))
+        arr[i].token = int(tok)
+        arr[i].doc = docs.ctypes.data_as(C.POINTER(C.c_uint64))
+        arr[i].ntf = ntf.ctypes.data_as(C.POINTER(C.c_float))
+        arr[i].len = docs.shape[0]
+    params = _params(total_documents, n_tokens, threshold, 0, k)
+    omc_doc = omc_mul = None
+    n_omc = 0
+    if omc:
+        items = sorted(omc.items())
+        omc_doc, omc_mul, n_omc = _u64([d for d, _ in items]), _f32([m for _, m in items]), len(items)
+    cap = sum(len(e[1]) for e in entries)
+    out_ids = np.zeros(max(cap, 1), dtype=np.uint64)
+    out_sc = np.zeros(max(cap, 1), dtype=np.float32)
+    out_n = C.c_uint64()
+    N.check(lib.orama_bm25_score_map(ctx.handle, arr, len(entries), C.byref(params),
+                                     omc_doc.ctypes.data if n_omc else None, omc_mul.ctypes.data if n_omc else None, n_omc,
+                                     cap, out_ids.ctypes.data, out_sc.ctypes.data, C.byref(out_n)))
+    return {int(d): np.float32(v) for d, v in zip(out_ids[: out_n.value], out_sc[: out_n.value])}
+
+
 def hybrid_combine(ctx: Context, vector: dict, fulltext: dict, top_k: int):
     """normalize_and_combine (token_score.rs:393-422) + count + top_n. Returns (ids, scores, count)."""
     lib = N.load()
@@ -193,11 +222,10 @@ class BM25Scorer:
         return bm25_score(self.ctx, self._entries, self._n_tokens(), total_documents, n, self.threshold, omc, k)
 
     def get_scores(self) -> dict:
-        total = sum(len(e[1]) for e in self._entries)
-        ids, sc, count = self.top_n(min(max(total, 1), 4096))
-        if count > len(ids):
-            raise N.OramaError(N.ORAMA_ERR_UNSUPPORTED, "get_scores(): map larger than 4096 entries; use top_n()")
-        return {int(d): np.float32(s) for d, s in zip(ids, sc)}
+        """The whole HashMap<K, f32> (bm25.rs:416-428), any size (orama_bm25_score_map)."""
+        total_documents = self._finalized[0][1] if self._finalized else 1.0
+        k = self._finalized[0][2] if self._finalized else K1_DEFAULT
+        return bm25_score_map(self.ctx, self._entries, self._n_tokens(), total_documents, self.threshold, None, k)
 
 
 @dataclass
@@ -206,6 +234,105 @@ class PostingList:
     docs: np.ndarray   # DocumentIds ascending
     tf: np.ndarray
     field_len: np.ndarray
+
+
+class ScoreMap:
+    """The HashMap<DocumentId, f32> of one search, resident in HBM (orama_scores): what the reference hands to
+    FacetContext / GroupContext (search.rs:355-400).  Close it before the next build / append of its store."""
+
+    def __init__(self, lib, handle, hits):
+        self._lib = lib
+        self._h = handle
+        self.hits = hits  # (ids, scores, count) of the search that produced the map
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.orama_scores_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __len__(self) -> int:
+        n = C.c_uint64()
+        N.check(self._lib.orama_scores_count(self._h, C.byref(n)))
+        return n.value
+
+    def to_dict(self) -> dict:
+        n = len(self)
+        ids, sc, out_n = np.zeros(max(n, 1), dtype=np.uint64), np.zeros(max(n, 1), dtype=np.float32), C.c_uint64()
+        N.check(self._lib.orama_scores_export(self._h, n, ids.ctypes.data, sc.ctypes.data, C.byref(out_n)))
+        return {int(d): np.float32(v) for d, v in zip(ids[: out_n.value], sc[: out_n.value])}
+
+    def lookup(self, doc_ids):
+        d = _u64(doc_ids)
+        sc = np.zeros(max(len(d), 1), dtype=np.float32)
+        pr = np.zeros(max(len(d), 1), dtype=np.uint8)
+        N.check(self._lib.orama_scores_lookup(self._h, d.ctypes.data, len(d), sc.ctypes.data, pr.ctypes.data))
+        return sc[: len(d)], pr[: len(d)].astype(bool)
+
+    def facet_count(self, field: "FacetField") -> np.ndarray:
+        out = np.zeros(max(field.n_buckets, 1), dtype=np.uint64)
+        N.check(self._lib.orama_facet_count(self._h, field._h, out.ctypes.data))
+        return out[: field.n_buckets]
+
+    def facet_count_ranges(self, field: "FacetField", ranges) -> np.ndarray:
+        fr = np.ascontiguousarray([r[0] for r in ranges], dtype=np.float64)
+        to = np.ascontiguousarray([r[1] for r in ranges], dtype=np.float64)
+        out = np.zeros(max(len(ranges), 1), dtype=np.uint64)
+        N.check(self._lib.orama_facet_count_ranges(self._h, field._h, fr.ctypes.data, to.ctypes.data, len(ranges),
+                                                   out.ctypes.data))
+        return out[: len(ranges)]
+
+    def group_top(self, field: "FacetField", max_results: int):
+        g = field.n_buckets
+        ids = np.zeros((max(g, 1), max_results), dtype=np.uint64)
+        sc = np.zeros((max(g, 1), max_results), dtype=np.float32)
+        n = np.zeros(max(g, 1), dtype=np.uint32)
+        N.check(self._lib.orama_group_top(self._h, field._h, int(max_results), ids.ctypes.data, sc.ctypes.data, n.ctypes.data))
+        return ids[:g], sc[:g], n[:g]
+
+
+class FacetField:
+    """Resident image of one filter field of an index (orama_facet_field): buckets (bool / string filter / group
+    combinations) or numbers.  index/{bool,string_filter,number}_field.rs."""
+
+    def __init__(self, lib, handle, n_buckets):
+        self._lib, self._h, self.n_buckets = lib, handle, n_buckets
+
+    @classmethod
+    def buckets(cls, store: "PostingsStore", buckets: list) -> "FacetField":
+        """buckets: list of doc-id arrays, one per field value."""
+        off = np.zeros(len(buckets) + 1, dtype=np.uint64)
+        for i, b in enumerate(buckets):
+            off[i + 1] = off[i] + len(b)
+        docs = _u64(np.concatenate([_u64(b) for b in buckets]) if buckets else [])
+        h = C.c_void_p()
+        N.check(store._lib.orama_facet_field_create_buckets(store._h, off.ctypes.data, docs.ctypes.data, len(buckets),
+                                                            C.byref(h)))
+        return cls(store._lib, h, len(buckets))
+
+    @classmethod
+    def numbers(cls, store: "PostingsStore", docs, values) -> "FacetField":
+        d = _u64(docs)
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        h = C.c_void_p()
+        N.check(store._lib.orama_facet_field_create_numbers(store._h, d.ctypes.data, v.ctypes.data, len(d), C.byref(h)))
+        return cls(store._lib, h, 0)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.orama_facet_field_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class PostingsStore:
@@ -357,6 +484,26 @@ class PostingsStore:
         """Index-wide per-field average lengths for the shards of one index."""
         avg = _f32(avg_field_len)
         N.check(self._lib.orama_post_set_avg_len(self._h, avg.ctypes.data, avg.shape[0]))
+
+    def search_scores(self, refs, n_tokens: int, total_documents: float, top_k: int, threshold=None,
+                      allow: AllowBitmap | None = None, apply_omc: bool = True, b: float = B_DEFAULT,
+                      k: float = K1_DEFAULT, vector: dict | None = None) -> ScoreMap:
+        """`search` that also keeps the whole score map resident (orama_post_search_scores): returns a ScoreMap whose
+        `.hits` are (ids, scores, count)."""
+        arr = self._refs(refs)
+        params = _params(total_documents, n_tokens, threshold, top_k, k)
+        out_ids = np.zeros(max(top_k, 1), dtype=np.uint64)
+        out_sc = np.zeros(max(top_k, 1), dtype=np.float32)
+        out_n, out_count, h = C.c_uint32(), C.c_uint64(), C.c_void_p()
+        bm_ptr, bm_bits = allow.ffi_args() if allow is not None else (None, 0)
+        hybrid = vector is not None
+        vd = _u64(list(vector) if hybrid else [])
+        vs = _f32(list(vector.values()) if hybrid else [])
+        N.check(self._lib.orama_post_search_scores(self._h, arr, len(refs), b, C.byref(params), bm_ptr, bm_bits,
+                                                   1 if hybrid else 0, vd.ctypes.data, vs.ctypes.data, len(vd),
+                                                   1 if apply_omc else 0, out_ids.ctypes.data, out_sc.ctypes.data,
+                                                   C.byref(out_n), C.byref(out_count), C.byref(h)))
+        return ScoreMap(self._lib, h, (out_ids[: out_n.value].copy(), out_sc[: out_n.value].copy(), out_count.value))
 
     def staged_query(self, refs, n_tokens: int, total_documents: float, top_k: int, d_df_ptr: int, stream: int,
                      threshold=None, allow: AllowBitmap | None = None, apply_omc: bool = True, hybrid: bool = False,

@@ -23,7 +23,8 @@ import numpy as np
 
 from .context import Context
 from .embedding_field import AllowBitmap, EmbeddingFieldStorage, VectorSearchParams
-from .fulltext import TermDictionary, B_DEFAULT, K1_DEFAULT, PostingList, PostingsStore, threshold_tokens
+from .fulltext import (TermDictionary, B_DEFAULT, K1_DEFAULT, FacetField, PostingList, PostingsStore, ScoreMap,
+                       threshold_tokens)
 
 
 # ----------------------------------------------------------------------------- modes (src/types.rs:838-940)
@@ -95,6 +96,11 @@ class Index:
     embedding_fields: dict[int, EmbeddingFieldStorage] = field(default_factory=dict)
     omc: dict[int, float] = field(default_factory=dict)
     document_ids: set = field(default_factory=set)
+    # filter fields (index/{bool,number,string_filter}_field.rs) as the facet / group code reads them:
+    # field name -> {doc id: value | [values]}
+    bool_fields: dict = field(default_factory=dict)
+    number_fields: dict = field(default_factory=dict)
+    string_filter_fields: dict = field(default_factory=dict)
     _post: Optional[PostingsStore] = None
     _lists: dict = field(default_factory=dict)      # (field_id, term) -> list id
     _terms: dict = field(default_factory=dict)      # field_id -> sorted term list
@@ -130,6 +136,50 @@ class Index:
             d.close()
         self._dicts = {fid: TermDictionary(self.ctx, sorted(self._terms[fid], key=lambda t: t.encode("utf-8")))
                        for fid in field_ids if self._terms.get(fid)}
+        self._commit_filter_fields()
+
+    # ---- resident images of the filter fields (orama_facet_field), rebuilt at commit like the postings
+    def _commit_filter_fields(self) -> None:
+        for f in getattr(self, "_facet_fields", {}).values():
+            f[0].close()
+        self._facet_fields = {}
+        live = self.document_ids
+        for name, vals in self.bool_fields.items():
+            keys = [True, False]  # BoolFacetDefinition {true, false}, bool_field.rs:182-208
+            buckets = [sorted(d for d, v in vals.items() if v is k and d in live) for k in keys]
+            self._facet_fields[name] = (FacetField.buckets(self._post, buckets), "bool", keys)
+        for name, vals in self.string_filter_fields.items():
+            by_key: dict = {}
+            for d, v in vals.items():
+                if d not in live:
+                    continue
+                for key in (v if isinstance(v, (list, tuple)) else [v]):
+                    by_key.setdefault(key, set()).add(d)
+            keys = sorted(by_key)  # storage.keys(), string_filter_field.rs:180
+            self._facet_fields[name] = (FacetField.buckets(self._post, [sorted(by_key[k]) for k in keys]), "string", keys)
+        for name, vals in self.number_fields.items():
+            docs, nums = [], []
+            for d, v in vals.items():
+                if d not in live:
+                    continue
+                for x in (v if isinstance(v, (list, tuple)) else [v]):
+                    docs.append(d)
+                    nums.append(float(x))
+            self._facet_fields[name] = (FacetField.numbers(self._post, docs, nums), "number", None)
+
+    def group_variants(self, name: str) -> dict:
+        """calculate_group_for_field (group.rs:181-270): value -> set of doc ids."""
+        live = self.document_ids
+        out: dict = {}
+        for store in (self.bool_fields, self.number_fields, self.string_filter_fields):
+            if name in store:
+                for d, v in store[name].items():
+                    if d not in live:
+                        continue
+                    for x in (v if isinstance(v, (list, tuple)) else [v]):
+                        out.setdefault(x, set()).add(d)
+                return out
+        return None
 
     def lookup(self, field_id: int, token: str, exact: bool, tolerance: int | None = None) -> list[int]:
         """Dictionary step of collect_contributions (host side, third-party in the reference): the exact term, or
@@ -244,6 +294,76 @@ class TokenScoreContext:
             raise TypeError(f"unknown score mode {type(m)}")
         hits = list(zip(ids.tolist(), sc.tolist()))[params.offset: params.offset + params.limit]
         return hits, count
+
+
+def facets_and_groups(tsc: "TokenScoreContext", params: TokenScoreParams, facets: dict | None = None,
+                      group_by: tuple | None = None, has_where_filter: bool = False, not_deleted=None):
+    """The facet / group tail of `search_on_indexes` for ONE index (src/collection_manager/sides/read/search.rs:
+    345-420 + sort.rs:129-230 without sort_by), over the score map kept resident in HBM.
+
+    facets   : {field name: "bool" | "string" | [(from, to), ...]}  (FacetDefinition, types.rs:770-800)
+    group_by : (properties [field names], max_results)
+    has_where_filter : the request carried a `where` filter — the reference then RE-SCORES without it (only the
+        NOT-deleted predicate, `not_deleted`) and counts facets on that map, so that the facet numbers do not move when
+        a user clicks a category (search.rs:347-396).  Groups always use the filtered map (sort.rs:129-136).
+    Returns (hits, count, facet_results {name: {"count", "values"}}, group_results {tuple(values): [(doc, score)]})."""
+    m = params.mode
+    if not isinstance(m, FulltextMode):
+        raise TypeError("facets_and_groups mirrors the full-text path (the vector map is <= limit entries on the host)")
+    idx = tsc.index
+    tokens = tsc._tokens(m.term, m.exact)
+    thr = None if m.threshold is None else threshold_tokens(len(tokens), m.threshold)
+    refs = tsc._refs(tokens, params.properties, params.boost, m.exact, m.tolerance)
+    top = params.limit + params.offset
+
+    def scored(allow) -> ScoreMap:
+        return idx._post.search_scores(refs, len(tokens), float(idx.document_count), top, thr, allow=allow,
+                                       apply_omc=bool(idx.omc))
+
+    sm = scored(params.filtered_doc_ids)
+    ids, sc, count = sm.hits
+    hits = list(zip(ids.tolist(), sc.tolist()))[params.offset: params.offset + params.limit]
+    facet_results, group_results = {}, {}
+    try:
+        if facets:
+            fm = scored(not_deleted) if has_where_filter else sm
+            try:
+                for name, definition in facets.items():
+                    if name not in idx._facet_fields:
+                        continue  # warn!("Unknown field name"), facet.rs:159-163
+                    fld, kind, keys = idx._facet_fields[name]
+                    if kind == "number":
+                        counts = fm.facet_count_ranges(fld, definition)
+                        values = {f"{a}-{b}": int(c) for (a, b), c in zip(definition, counts)}  # number_field.rs:382
+                    else:
+                        counts = fm.facet_count(fld)
+                        labels = [("true" if k else "false") for k in keys] if kind == "bool" else keys
+                        values = {str(l): int(c) for l, c in zip(labels, counts)}
+                    facet_results[name] = {"count": len(values), "values": values}  # facet.rs:196-206
+            finally:
+                if fm is not sm:
+                    fm.close()
+        if group_by:
+            props, max_results = group_by
+            variants = [idx.group_variants(p) for p in props]
+            if all(v is not None for v in variants):  # group.rs:113-121: every property must exist in this index
+                import itertools
+
+                combos, buckets = [], []
+                for combo in itertools.product(*[sorted(v, key=str) for v in variants]):
+                    docs = set.intersection(*[variants[i][val] for i, val in enumerate(combo)])  # group.rs:143-160
+                    combos.append(combo)
+                    buckets.append(sorted(docs))
+                fld = FacetField.buckets(idx._post, buckets)
+                try:
+                    g_ids, g_sc, g_n = sm.group_top(fld, max_results)  # sort.rs:203-213
+                finally:
+                    fld.close()
+                for combo, i_, s_, n_ in zip(combos, g_ids, g_sc, g_n):
+                    group_results[combo] = list(zip(i_[: int(n_)].tolist(), s_[: int(n_)].tolist()))
+    finally:
+        sm.close()
+    return hits, count, facet_results, group_results
 
 
 def search_on_indexes(contexts: list, params: TokenScoreParams):
