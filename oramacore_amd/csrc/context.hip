@@ -96,8 +96,41 @@ int orama_ctx::acquire(std::unique_ptr<orama::Scratch>* out) {
     return ORAMA_OK;
 }
 
+namespace {
+// HBM held by one scratch set (the buffers that scale with the corpus / the index)
+size_t scratch_bytes(const orama::Scratch& s) {
+    size_t b = 0;
+    for (const orama::DevBuf* d : {&s.query, &s.dist, &s.sel_state, &s.sel_keys, &s.out_idx, &s.out_val, &s.out_n, &s.out_ids,
+                                   &s.bitmap, &s.f16_bfrag, &s.misc0, &s.misc1, &s.misc2, &s.misc3, &s.misc4, &s.misc5,
+                                   &s.bm25_acc, &s.bm25_emit})
+        b += d->cap;
+    return b;
+}
+size_t scratch_pool_budget() {
+    static const size_t v = [] {
+        const char* e = std::getenv("ORAMA_SCRATCH_POOL_MIB");
+        return (e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)8192) << 20;
+    }();
+    return v;
+}
+}  // namespace
+
+// Scratch sets are pooled so that a search allocates nothing in steady state — but a set sized by a large index
+// (the BM25 accumulator alone is slots x n_docs x 8 B: 1.3 GB at 10 M docs and 12 tokens) stays that large.  Many
+// concurrent callers (the reference searches from every tokio worker) would otherwise pin peak-concurrency x that
+// much HBM forever: when the idle pool exceeds its budget (ORAMA_SCRATCH_POOL_MIB, default 8 GiB) the set being
+// returned gives its large buffers back to the driver and keeps only its stream and small buffers.
 void orama_ctx::release(std::unique_ptr<orama::Scratch> s) {
     std::lock_guard<std::mutex> g(pool_mu);
+    size_t pooled = 0;
+    for (const auto& q : pool) pooled += scratch_bytes(*q);
+    if (pooled + scratch_bytes(*s) > scratch_pool_budget()) {
+        (void)hipSetDevice(device);
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+        for (orama::DevBuf* d : {&s->dist, &s->sel_keys, &s->out_ids, &s->bitmap, &s->misc0, &s->misc1, &s->misc2, &s->misc3,
+                                 &s->misc4, &s->misc5, &s->bm25_acc, &s->bm25_emit})
+            if (d->cap > ((size_t)16 << 20)) d->release();
+    }
     pool.push_back(std::move(s));
 }
 

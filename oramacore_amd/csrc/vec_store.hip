@@ -10,9 +10,9 @@
 //   per row: 1/|x| (f32), DocumentId (u64), tombstone bit.
 // Sized for 288 GB: the matrix is ONE allocation (30.7 GB for 10 M x 768 f32) that grows geometrically.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <shared_mutex>
-#include <unordered_map>
 
 #include <cstdlib>
 
@@ -24,26 +24,220 @@
 
 using namespace orama;
 
+// Plain device-side copy / zero-fill.  Everything that WRITES into (or reads out of) the in-place-growing arrays below
+// goes through these kernels, never through hipMemcpyAsync / hipMemsetAsync: on this stack the copy engines do not
+// reliably see memory that was mapped with hipMemMap moments ago (rows and DocumentIds arrived corrupted in ~1 of 50
+// runs of the GPU suite), while kernels — which use the shader page tables the mapping call updates — always do.
+namespace {
+__global__ void copy_bytes_kernel(char* __restrict__ dst, const char* __restrict__ src, size_t bytes) {
+    const size_t n16 = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0 ? bytes / 16 : 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = t; i < n16; i += stride) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (size_t i = n16 * 16 + t; i < bytes; i += stride) dst[i] = src[i];
+}
+__global__ void zero_bytes_kernel(char* __restrict__ dst, size_t bytes) {
+    const size_t n16 = ((uintptr_t)dst & 15) == 0 ? bytes / 16 : 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (size_t i = t; i < n16; i += stride) reinterpret_cast<uint4*>(dst)[i] = z;
+    for (size_t i = n16 * 16 + t; i < bytes; i += stride) dst[i] = 0;
+}
+int launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (!bytes) return ORAMA_OK;
+    const uint32_t blocks = (uint32_t)std::min<size_t>(4096, std::max<size_t>(1, bytes / (256 * 16)));
+    hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks), dim3(256), 0, s, static_cast<char*>(dst), static_cast<const char*>(src), bytes);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+int launch_zero_bytes(void* dst, size_t bytes, hipStream_t s) {
+    if (!bytes) return ORAMA_OK;
+    const uint32_t blocks = (uint32_t)std::min<size_t>(4096, std::max<size_t>(1, bytes / (256 * 16)));
+    hipLaunchKernelGGL(zero_bytes_kernel, dim3(blocks), dim3(256), 0, s, static_cast<char*>(dst), bytes);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+}  // namespace
+
+// A device array that grows IN PLACE: one virtual range reserved up front (hipMemAddressReserve), physical chunks
+// mapped behind it on demand (hipMemCreate / hipMemMap / hipMemSetAccess — profiles/r02_vmm_probe.log: 1 GiB mapped in
+// 0.02-0.1 ms, same streaming bandwidth as hipMalloc).  The base address never changes while the array fits its
+// reservation, so a scan that started before an insert keeps reading valid memory and appends need no copy and no
+// reader exclusion.  Outgrowing the reservation (4x the initial need) re-maps the SAME physical chunks into a bigger
+// range — still no copy, but the base moves, so that step runs under the store's exclusive lock.
+struct GrowBuf {
+    char* base = nullptr;
+    size_t va_bytes = 0;   // reserved virtual range
+    size_t mapped = 0;     // bytes backed by physical memory (multiple of chunk)
+    size_t chunk = 0;
+    bool vmm = false;
+    int device = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<size_t> handle_bytes;
+    char* old_base = nullptr;  // non-VMM growth: the previous allocation, alive until drop_old()
+
+    void drop_old() {
+        if (old_base) (void)hipFree(old_base);
+        old_base = nullptr;
+    }
+
+    GrowBuf() = default;
+    GrowBuf(const GrowBuf&) = delete;
+    GrowBuf& operator=(const GrowBuf&) = delete;
+    ~GrowBuf() { release(); }
+
+    static bool vmm_supported(int device) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeVirtualMemoryManagementSupported, device) != hipSuccess) return false;
+        // OPT-IN (ORAMA_VMM=1).  The mechanism works (scripts/micro/vmm_probe*.hip) and removes every copy from growth,
+        // but with many stores created and destroyed in one process — virtual ranges freed and re-reserved over different
+        // physical memory — kernels on this stack (ROCm 7.2 / 7.0 runtimes alike) intermittently read and wrote through
+        // stale translations: 8 of 61 vector tests failed at random with zeroed / foreign DocumentIds
+        // (profiles/r02_vmm_store_failures.md).  Until that is understood the default is allocate + copy BESIDE the
+        // running searches (see reserve_rows_locked), which blocks readers only for the pointer swap.
+        static const bool on = [] {
+            const char* e = std::getenv("ORAMA_VMM");
+            return e && std::atoi(e) != 0;
+        }();
+        return v != 0 && on;
+    }
+    hipMemAllocationProp prop() const {
+        hipMemAllocationProp p = {};
+        p.type = hipMemAllocationTypePinned;
+        p.location.type = hipMemLocationTypeDevice;
+        p.location.id = device;
+        return p;
+    }
+    // piece by piece, exactly as mapped (one hipMemUnmap over a range that spans several allocations is not relied upon)
+    void unmap_all() {
+        size_t off = 0;
+        for (size_t i = 0; i < handles.size(); ++i) {
+            (void)hipMemUnmap(base + off, handle_bytes[i]);
+            off += handle_bytes[i];
+        }
+    }
+    void release() {
+        drop_old();
+        if (!base) return;
+        if (vmm) {
+            unmap_all();
+            for (auto h : handles) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(base, va_bytes);
+        } else {
+            (void)hipFree(base);
+        }
+        handles.clear();
+        base = nullptr;
+        va_bytes = mapped = 0;
+    }
+    // the last GiB of a reservation is slack for the piece rounding below
+    static constexpr size_t kSlack = (size_t)1 << 30;
+    bool needs_move(size_t bytes) const { return vmm ? bytes + kSlack > va_bytes && bytes > mapped : bytes > mapped; }
+    // Make [0, bytes) usable.  New memory is zeroed on `s` when `zero_new`.  When needs_move(bytes) the base changes:
+    // the caller must hold the store's exclusive lock (no scan may be reading the old range).
+    int ensure(int dev, size_t bytes, size_t va_hint, bool zero_new, hipStream_t s) {
+        device = dev;
+        if (bytes <= mapped) return ORAMA_OK;
+        if (!base) {
+            vmm = vmm_supported(dev);
+            chunk = 2u << 20;  // 2 MiB granules; big arrays take whole multiples per step below
+        }
+        if (!vmm) {  // fallback: allocate-and-copy (the pre-VMM behaviour), geometric growth
+            size_t cap = mapped ? mapped : 4096;
+            while (cap < bytes) cap += cap / 2 + 4096;
+            char* nb = nullptr;
+            ORAMA_HIP_TRY(hipMalloc(&nb, cap));
+            if (mapped) ORAMA_HIP_TRY(hipMemcpyAsync(nb, base, mapped, hipMemcpyDeviceToDevice, s));
+            if (zero_new) ORAMA_HIP_TRY(hipMemsetAsync(nb + mapped, 0, cap - mapped, s));
+            ORAMA_HIP_TRY(hipStreamSynchronize(s));
+            old_base = base;  // released by the caller once no reader can hold it (drop_old)
+            base = nb;
+            mapped = va_bytes = cap;
+            return ORAMA_OK;
+        }
+        auto round_up = [&](size_t x) { return (x + chunk - 1) / chunk * chunk; };
+        if (bytes + kSlack > va_bytes) {  // (re-)reserve: 4x head room, the existing physical chunks move to the new range
+            size_t want = round_up(std::max(std::max(bytes * 4, va_hint), (size_t)64 << 20)) + kSlack;
+            void* nb = nullptr;
+            ORAMA_HIP_TRY(hipMemAddressReserve(&nb, want, chunk, nullptr, 0));
+            if (base) {
+                unmap_all();
+                size_t off = 0;
+                hipMemAccessDesc acc = {};
+                acc.location = prop().location;
+                acc.flags = hipMemAccessFlagsProtReadWrite;
+                for (size_t i = 0; i < handles.size(); ++i) {
+                    const size_t sz = handle_bytes[i];
+                    ORAMA_HIP_TRY(hipMemMap(static_cast<char*>(nb) + off, sz, 0, handles[i], 0));
+                    off += sz;
+                }
+                if (off) ORAMA_HIP_TRY(hipMemSetAccess(nb, off, &acc, 1));
+                (void)hipMemAddressFree(base, va_bytes);
+            }
+            base = static_cast<char*>(nb);
+            va_bytes = want;
+        }
+        // map what is missing in physical pieces of exactly 1 GiB, 64 MiB or 2 MiB: hipMemSetAccess on this stack
+        // rejects some other sizes ("invalid argument" for e.g. 313 x 2 MiB), these three are measured good
+        // (scripts/micro/vmm_probe2.hip).  Over-allocation is below one piece of the size class.
+        size_t need = round_up(bytes) - mapped;
+        hipMemAllocationProp p = prop();
+        hipMemAccessDesc acc = {};
+        acc.location = p.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        size_t zero_from = ~(size_t)0;
+        while (need) {
+            const size_t piece = need >= ((size_t)1 << 30) ? (size_t)1 << 30 : (need > ((size_t)32 << 20) ? (size_t)64 << 20 : chunk);
+            hipMemGenericAllocationHandle_t h;
+            ORAMA_HIP_TRY(hipMemCreate(&h, piece, &p, 0));
+            hipError_t e = hipMemMap(base + mapped, piece, 0, h, 0);
+            if (e != hipSuccess) {
+                (void)hipMemRelease(h);
+                ORAMA_HIP_TRY(e);
+            }
+            handles.push_back(h);
+            handle_bytes.push_back(piece);
+            if (zero_new) zero_from = std::min(zero_from, mapped);
+            mapped += piece;
+            need -= std::min(need, piece);
+        }
+        // ONE hipMemSetAccess over everything mapped so far: per-piece calls fail on this stack for a smaller piece that
+        // follows >= ~14 one-GiB pieces ("invalid argument"; scripts/micro/vmm_probe2.hip reproduces it), the whole-range
+        // form does not.  Re-granting access to the part that was already accessible is a no-op for running kernels.
+        hipError_t ea = hipMemSetAccess(base, mapped, &acc, 1);
+        if (ea != hipSuccess) {
+            set_error("hipMemSetAccess(%p, %zu bytes of a %zu-byte reservation, %zu pieces): %s", (void*)base, mapped, va_bytes,
+                      handles.size(), hipGetErrorString(ea));
+            return ORAMA_ERR_HIP;
+        }
+        if (zero_from != ~(size_t)0) ORAMA_TRY(launch_zero_bytes(base + zero_from, mapped - zero_from, s));
+        return ORAMA_OK;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(base); }
+};
+
 struct orama_vec {
     orama_ctx* ctx = nullptr;
     uint32_t dim = 0;
     int metric = ORAMA_METRIC_COSINE;
     int dtype = ORAMA_DTYPE_F32;
-    std::shared_mutex mu;  // searches: shared; insert/delete/compact: exclusive
+    // Locking (the reference's insert(&self) runs beside searches, index/mod.rs:1436,1688-1698; deletes and compaction are
+    // exclusive there, index/mod.rs:1346-1424):
+    //   mu        shared: searches, inserts, deletes      exclusive: compaction, re-reservation of an array
+    //   write_mu  one writer (insert / delete / compact) at a time
+    // Inserts write rows BEYOND the published row count and publish it last, so a search works on the snapshot it read at
+    // its start (arc-swap semantics) and is never blocked by an insert.
+    std::shared_mutex mu;
+    std::mutex write_mu;
 
-    DevBuf rows;      // f32: cap_rows x dim; f16: tiles(cap_rows) x tile_bytes
-    DevBuf inv_norm;  // cap_rows f32
-    DevBuf row_doc;   // cap_rows u64
-    DevBuf dead;      // cap_rows bits (u32 words)
-    uint64_t n_rows = 0;
-    uint64_t cap_rows = 0;
-    uint64_t n_dead = 0;
+    GrowBuf rows;      // f32: rows x dim; f16: tiles(rows) x tile_bytes
+    GrowBuf inv_norm;  // f32 per row (+ one block tile of padding for the f16 kernels)
+    GrowBuf row_doc;   // u64 per row
+    GrowBuf dead;      // bit per row (u32 words), zero = live
+    std::atomic<uint64_t> n_rows{0};  // published rows
+    std::atomic<uint64_t> n_dead{0};
+    uint64_t cap_rows = 0;            // rows the arrays can hold without growing
     uint64_t version = 0;
-
-    std::vector<uint64_t> h_row_doc;  // host mirror of row_doc
-    std::vector<uint32_t> h_dead;     // host mirror of the tombstone bitmap
-    bool doc_rows_built = false;
-    std::unordered_map<uint64_t, std::vector<uint32_t>> doc_rows;  // built lazily for delete
 
     // scratch for the device-pointer entry point, one per caller stream
     std::mutex dev_mu;
@@ -54,69 +248,92 @@ struct orama_vec {
     size_t matrix_bytes(uint64_t rows_) const {
         return f16() ? (size_t)(f16_tiles(rows_) * f16_tile_bytes(dim)) : (size_t)rows_ * row_bytes();
     }
+    size_t norm_bytes(uint64_t rows_) const {
+        // f16: K2c / K2d fetch the inverse norms of a block tile with one 1-KiB DMA — pad to whole block tiles
+        return (size_t)(f16() ? ((rows_ + 255) & ~255ull) + 256 : rows_) * sizeof(float);
+    }
 };
 
 namespace {
 
-struct Arrays {
-    void *rows = nullptr, *norm = nullptr, *doc = nullptr, *dead = nullptr;
-    uint64_t cap = 0;
+// What one search reads: pointers + the row count published when it started.
+struct View {
+    void* rows = nullptr;
+    float* inv_norm = nullptr;
+    uint64_t* row_doc = nullptr;
+    uint32_t* dead = nullptr;  // nullptr when no row was deleted at snapshot time
+    uint64_t n_rows = 0;
 };
-
-int alloc_arrays(orama_vec* v, uint64_t cap, Arrays* a, hipStream_t s) {
-    if (v->f16()) cap = (cap + 31) & ~31ull;
-    const size_t dead_words = (size_t)((cap + 31) / 32);
-    ORAMA_HIP_TRY(hipMalloc(&a->rows, std::max<size_t>(256, v->matrix_bytes(cap))));
-    // f16: K2c fetches the 256 inverse norms of a block tile with one 1-KiB DMA — pad to whole block tiles
-    const size_t norm_bytes = (size_t)(v->f16() ? ((cap + 255) & ~255ull) + 256 : cap) * sizeof(float);
-    ORAMA_HIP_TRY(hipMalloc(&a->norm, std::max<size_t>(norm_bytes, 4)));
-    ORAMA_HIP_TRY(hipMalloc(&a->doc, (size_t)cap * sizeof(uint64_t)));
-    ORAMA_HIP_TRY(hipMalloc(&a->dead, dead_words * sizeof(uint32_t)));
-    ORAMA_HIP_TRY(hipMemsetAsync(a->dead, 0, dead_words * sizeof(uint32_t), s));
-    if (v->f16()) {  // padding rows of partial tiles must read as zeros
-        ORAMA_HIP_TRY(hipMemsetAsync(a->rows, 0, v->matrix_bytes(cap), s));
-        ORAMA_HIP_TRY(hipMemsetAsync(a->norm, 0, norm_bytes, s));
-    }
-    a->cap = cap;
-    return ORAMA_OK;
+View snapshot(orama_vec* v) {
+    View w;
+    w.n_rows = v->n_rows.load(std::memory_order_acquire);
+    w.rows = v->rows.base;
+    w.inv_norm = v->inv_norm.as<float>();
+    w.row_doc = v->row_doc.as<uint64_t>();
+    w.dead = v->n_dead.load(std::memory_order_acquire) ? v->dead.as<uint32_t>() : nullptr;
+    return w;
 }
 
-void adopt_arrays(orama_vec* v, const Arrays& a) {
-    v->rows.release();
-    v->inv_norm.release();
-    v->row_doc.release();
-    v->dead.release();
-    v->rows.p = a.rows;
-    v->rows.cap = std::max<size_t>(256, v->matrix_bytes(a.cap));
-    v->inv_norm.p = a.norm;
-    v->inv_norm.cap = (size_t)a.cap * sizeof(float);
-    v->row_doc.p = a.doc;
-    v->row_doc.cap = (size_t)a.cap * sizeof(uint64_t);
-    v->dead.p = a.dead;
-    v->dead.cap = (size_t)((a.cap + 31) / 32) * sizeof(uint32_t);
-    v->cap_rows = a.cap;
+bool grow_needs_move(orama_vec* v, uint64_t need_rows) {
+    uint64_t cap = v->f16() ? ((need_rows + 31) & ~31ull) : need_rows;
+    return v->rows.needs_move(std::max<size_t>(256, v->matrix_bytes(cap))) || v->inv_norm.needs_move(v->norm_bytes(cap)) ||
+           v->row_doc.needs_move((size_t)cap * 8) || v->dead.needs_move((size_t)((cap + 31) / 32) * 4);
 }
 
+// Capacity for `need_rows` rows.  New memory of the f16 matrix / norms / tombstones is zeroed (padding rows of
+// partial tiles must read as zeros; zero = live).  Call with the exclusive lock held iff grow_needs_move().
 int grow(orama_vec* v, uint64_t need_rows, hipStream_t s) {
     if (need_rows <= v->cap_rows) return ORAMA_OK;
     ORAMA_REQUIRE(need_rows < 0xfffffff0ull, "vector store limited to 2^32-16 rows");
-    uint64_t cap = v->cap_rows ? v->cap_rows : 1024;
-    while (cap < need_rows) cap += cap / 2 + 1024;
-    Arrays a;
-    ORAMA_TRY(alloc_arrays(v, cap, &a, s));
-    if (v->n_rows) {
-        ORAMA_HIP_TRY(hipMemcpyAsync(a.rows, v->rows.p, v->matrix_bytes(v->n_rows), hipMemcpyDeviceToDevice, s));
-        ORAMA_HIP_TRY(hipMemcpyAsync(a.norm, v->inv_norm.p, (size_t)v->n_rows * sizeof(float),
-                                     hipMemcpyDeviceToDevice, s));
-        ORAMA_HIP_TRY(hipMemcpyAsync(a.doc, v->row_doc.p, (size_t)v->n_rows * sizeof(uint64_t),
-                                     hipMemcpyDeviceToDevice, s));
-        ORAMA_HIP_TRY(hipMemcpyAsync(a.dead, v->dead.p, (size_t)((v->n_rows + 31) / 32) * 4,
-                                     hipMemcpyDeviceToDevice, s));
+    uint64_t cap = need_rows;
+    if (v->f16()) cap = (cap + 31) & ~31ull;
+    const int dev = v->ctx->device;
+    const uint64_t hint_rows = std::max<uint64_t>(cap * 4, 1u << 20);
+    ORAMA_TRY(v->rows.ensure(dev, std::max<size_t>(256, v->matrix_bytes(cap)), v->matrix_bytes(hint_rows), v->f16(), s));
+    ORAMA_TRY(v->inv_norm.ensure(dev, v->norm_bytes(cap), v->norm_bytes(hint_rows), v->f16(), s));
+    ORAMA_TRY(v->row_doc.ensure(dev, (size_t)cap * 8, (size_t)hint_rows * 8, false, s));
+    ORAMA_TRY(v->dead.ensure(dev, (size_t)((cap + 31) / 32) * 4, (size_t)((hint_rows + 31) / 32) * 4, true, s));
+    // capacity = what the smallest array now holds
+    uint64_t c = v->row_doc.mapped / 8;
+    c = std::min<uint64_t>(c, v->dead.mapped / 4 * 32);
+    if (v->f16()) {
+        c = std::min<uint64_t>(c, (uint64_t)(v->rows.mapped / f16_tile_bytes(v->dim)) * 32);
+        const uint64_t nf = v->inv_norm.mapped / 4;
+        c = std::min<uint64_t>(c, nf > 512 ? (nf - 256) & ~255ull : 0);
+    } else {
+        c = std::min<uint64_t>(c, v->rows.mapped / v->row_bytes());
+        c = std::min<uint64_t>(c, v->inv_norm.mapped / 4);
     }
-    ORAMA_HIP_TRY(hipStreamSynchronize(s));
-    adopt_arrays(v, a);
+    ORAMA_REQUIRE(c >= need_rows, "internal: capacity %llu below the %llu rows asked for", (unsigned long long)c,
+                  (unsigned long long)need_rows);
+    v->cap_rows = c;
     return ORAMA_OK;
 }
+
+// ---- small device helpers of the mutation path
+// tombstone every row whose DocumentId is in the (sorted) list; *newly counts rows that were live before
+__global__ void mark_deleted_kernel(const uint64_t* __restrict__ row_doc, uint64_t n_rows, const uint64_t* __restrict__ docs,
+                                    uint32_t n_docs, uint32_t* __restrict__ dead, unsigned long long* __restrict__ newly) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t d = row_doc[r];
+        uint32_t lo = 0, hi = n_docs;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (docs[mid] < d) lo = mid + 1; else hi = mid;
+        }
+        if (lo < n_docs && docs[lo] == d) {
+            const uint32_t bit = 1u << (r & 31);
+            const uint32_t old = atomicOr(&dead[r >> 5], bit);
+            if (!(old & bit)) atomicAdd(newly, 1ull);
+        }
+    }
+}
+__global__ void gather_u64_kernel(const uint64_t* __restrict__ src, const uint64_t* __restrict__ idx, uint64_t n,
+                                  uint64_t* __restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = src[idx[i]];
+}
+uint32_t blocks_for_rows(uint64_t n) { return (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1, (n + 255) / 256)); }
 
 bool row_valid(const float* x, uint32_t d) {  // EmbeddingIndexer::index_vec_vec -> None (assumption)
     float n2 = 0.0f;
@@ -134,8 +351,8 @@ int store_rows_from_device(orama_vec* v, void* rows_base, float* norm_base, cons
         ORAMA_TRY(launch_f16_store_rows(rows_base, d_src, first, n, v->dim, s));
         ORAMA_TRY(launch_f16_inv_norm(rows_base, first, n, v->dim, norm_base, s, v->metric));
     } else {
-        ORAMA_HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(rows_base) + (size_t)first * v->row_bytes(), d_src,
-                                     (size_t)n * v->row_bytes(), hipMemcpyDeviceToDevice, s));
+        ORAMA_TRY(launch_copy_bytes(reinterpret_cast<char*>(rows_base) + (size_t)first * v->row_bytes(), d_src,
+                                    (size_t)n * v->row_bytes(), s));
         if (v->metric == ORAMA_METRIC_COSINE)
             ORAMA_TRY(launch_row_inv_norm_f32(reinterpret_cast<const float*>(rows_base), first, n, v->dim,
                                               norm_base, s));
@@ -166,20 +383,20 @@ int tail_end(Scratch* sc, hipStream_t s_scan, hipStream_t s) {
     return ORAMA_OK;
 }
 
-int search_enqueue_f32(orama_vec* v, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
+int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
                        uint32_t* d_out_n, hipStream_t s, hipStream_t s_scan) {
-    const uint64_t n = v->n_rows;
+    const uint64_t n = w.n_rows;
     if (k <= kWaveListKeys && v->ctx->fused_topk) {
         // fused path: each K1 wave keeps its own best-k in registers; no dense distance array at all.
         ScanArgs a;
-        a.corpus = v->rows.as<float>();
-        a.inv_norm = v->inv_norm.as<float>();
+        a.corpus = static_cast<const float*>(w.rows);
+        a.inv_norm = w.inv_norm;
         a.n = n;
         a.dim = v->dim;
         a.metric = v->metric;
-        a.row_doc = v->row_doc.as<uint64_t>();
-        a.dead = v->n_dead ? v->dead.as<uint32_t>() : nullptr;
+        a.row_doc = w.row_doc;
+        a.dead = w.dead;
         a.allow = d_allow;
         a.allow_bits = allow_bits;
         a.topk = k;
@@ -196,7 +413,7 @@ int search_enqueue_f32(orama_vec* v, Scratch* sc, const float* d_queries, uint32
         }
         ORAMA_TRY(scan_end(sc, s_scan, s));
         ORAMA_TRY(launch_keys_topk(v->ctx, sc->sel_keys.as<unsigned long long>(), n_keys, n_keys, q, k, false,
-                                v->row_doc.as<uint64_t>(), sc->dist.as<unsigned long long>(), nullptr, d_out_ids,
+                                w.row_doc, sc->dist.as<unsigned long long>(), nullptr, d_out_ids,
                                 d_out_dist, d_out_n, s));
         return tail_end(sc, s_scan, s);
     }
@@ -215,14 +432,14 @@ int search_enqueue_f32(orama_vec* v, Scratch* sc, const float* d_queries, uint32
         ORAMA_TRY(scan_begin(sc, s_scan, s));
         for (uint32_t j = 0; j < gq;) {
             ScanArgs a;
-            a.corpus = v->rows.as<float>();
-            a.inv_norm = v->inv_norm.as<float>();
+            a.corpus = static_cast<const float*>(w.rows);
+            a.inv_norm = w.inv_norm;
             a.query = d_queries + (size_t)(q0 + j) * v->dim;
             a.n = n;
             a.dim = v->dim;
             a.metric = v->metric;
-            a.row_doc = v->row_doc.as<uint64_t>();
-            a.dead = v->n_dead ? v->dead.as<uint32_t>() : nullptr;
+            a.row_doc = w.row_doc;
+            a.dead = w.dead;
             a.allow = d_allow;
             a.allow_bits = allow_bits;
             a.out_dist = sc->dist.as<float>() + (size_t)j * n;
@@ -244,7 +461,7 @@ int search_enqueue_f32(orama_vec* v, Scratch* sc, const float* d_queries, uint32
         p.q = gq;
         p.k = k;
         p.descending = false;
-        p.id_map = v->row_doc.as<uint64_t>();
+        p.id_map = w.row_doc;
         p.state = sc->sel_state.as<SelectState>();
         p.keys = sc->sel_keys.as<unsigned long long>();
         p.out_ids = d_out_ids + (size_t)q0 * k;
@@ -266,10 +483,10 @@ int search_enqueue_f32(orama_vec* v, Scratch* sc, const float* d_queries, uint32
 //   3. the last reduction also maps rows → DocumentIds and applies the final tie order.
 // Scores are never materialised for more than S1 rows; HBM traffic beyond the corpus pass is the
 // candidate appends (expected k·ln(N/S1) per query on unordered data).
-int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
+int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
                        uint32_t* d_out_n, hipStream_t s) {
-    const uint64_t n = v->n_rows;
+    const uint64_t n = w.n_rows;
     constexpr uint64_t kS1 = 131072;                 // dense head (rows), multiple of 32
     constexpr uint64_t kCandBudget = 6ull << 30;     // bytes of candidate lists per pass
     const uint32_t kpad_k = f16_kpad(v->dim);
@@ -317,15 +534,15 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
         uint32_t* out_n = d_out_n + q0;
 
         F16ScanArgs a;
-        a.tiled = v->rows.p;
-        a.inv_norm = v->inv_norm.as<float>();
+        a.tiled = w.rows;
+        a.inv_norm = w.inv_norm;
         a.queries = d_queries + (size_t)q0 * v->dim;
         a.q = gq;
         a.dim = v->dim;
         a.metric = v->metric;
         a.n_rows = n;
-        a.row_doc = v->row_doc.as<uint64_t>();
-        a.dead = v->n_dead ? v->dead.as<uint32_t>() : nullptr;
+        a.row_doc = w.row_doc;
+        a.dead = w.dead;
         a.allow = d_allow;
         a.allow_bits = allow_bits;
         // 1. dense head
@@ -345,7 +562,7 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
         p.keys = sc->sel_keys.as<unsigned long long>();
         const bool only_head = rest == 0;
         if (only_head) {
-            p.id_map = v->row_doc.as<uint64_t>();
+            p.id_map = w.row_doc;
             p.out_ids = out_ids;
             p.out_val = out_dist;
             p.out_n = out_n;
@@ -385,7 +602,7 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
             c.keys = sc->sel_keys.as<unsigned long long>();
             c.out_n = out_n;
             if (r1 == n) {  // 3. final reduction: ids + final tie order
-                c.id_map = v->row_doc.as<uint64_t>();
+                c.id_map = w.row_doc;
                 c.out_ids = out_ids;
                 c.out_val = out_dist;
             } else {
@@ -401,12 +618,19 @@ int search_enqueue_f16(orama_vec* v, Scratch* sc, const float* d_queries, uint32
 
 // `s_scan` (nullable = same as s): stream the corpus scans run on.  The f16 pipeline interleaves scans and
 // selections with dependencies in both directions, so it stays on `s`.
+// The caller holds the store's shared lock; the search works on the snapshot taken here: rows published later are
+// not seen, and nothing it reads can move (arrays grow in place; compaction needs the exclusive lock).
 int search_enqueue(orama_vec* v, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                    const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
                    uint32_t* d_out_n, hipStream_t s, hipStream_t s_scan = nullptr, bool two_streams = false) {
-    return v->f16() ? search_enqueue_f16(v, sc, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist,
+    const View w = snapshot(v);
+    if (w.n_rows == 0) {  // empty store: no hits
+        ORAMA_HIP_TRY(hipMemsetAsync(d_out_n, 0, (size_t)q * 4, s));
+        return ORAMA_OK;
+    }
+    return v->f16() ? search_enqueue_f16(v, w, sc, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist,
                                          d_out_n, s)
-                    : search_enqueue_f32(v, sc, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist,
+                    : search_enqueue_f32(v, w, sc, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist,
                                          d_out_n, s, two_streams ? s_scan : s);
 }
 
@@ -417,7 +641,7 @@ VecSharedLock::VecSharedLock(orama_vec* v) : v_(v) { v_->mu.lock_shared(); }
 VecSharedLock::~VecSharedLock() { v_->mu.unlock_shared(); }
 orama_ctx* vec_ctx(orama_vec* v) { return v->ctx; }
 uint32_t vec_dim(orama_vec* v) { return v->dim; }
-uint64_t vec_rows(orama_vec* v) { return v->n_rows; }
+uint64_t vec_rows(orama_vec* v) { return v->n_rows.load(std::memory_order_acquire); }
 int vec_search_enqueue(orama_vec* v, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
                        uint32_t* d_out_n, hipStream_t s) {
@@ -452,6 +676,7 @@ int orama_vec_create(orama_ctx* ctx, uint32_t dim, int metric, int dtype, uint64
         ScratchLease sc(ctx);
         int st = sc.init();
         if (st == ORAMA_OK) st = grow(v, reserve_rows, sc->stream);
+        if (st == ORAMA_OK && hipStreamSynchronize(sc->stream) != hipSuccess) st = ORAMA_ERR_HIP;
         if (st != ORAMA_OK) {
             delete v;
             return st;
@@ -468,6 +693,38 @@ void orama_vec_destroy(orama_vec* v) {
     delete v;
 }
 
+// Writers reserve capacity first (write_mu held by the caller).
+//   default  : allocate bigger arrays and copy the old contents BESIDE the running searches (shared lock: a search that
+//              snapshots a mix of old and new base pointers still reads identical published rows), then take the
+//              exclusive lock for an instant — a barrier that outlives every search which may still hold an old base —
+//              and free the old arrays.  Readers are never blocked for the duration of a copy.
+//   ORAMA_VMM: grow in place (no copy at all); only outgrowing the virtual reservation re-maps under the exclusive lock.
+static int reserve_rows_locked(orama_vec* v, uint64_t need_rows, hipStream_t s) {
+    if (need_rows <= v->cap_rows) return ORAMA_OK;
+    const bool vmm = GrowBuf::vmm_supported(v->ctx->device);
+    if (vmm && grow_needs_move(v, need_rows)) {
+        std::unique_lock<std::shared_mutex> x(v->mu);  // waits for running scans, blocks new ones for the re-map
+        ORAMA_TRY(grow(v, need_rows, s));
+        ORAMA_HIP_TRY(hipStreamSynchronize(s));
+        return ORAMA_OK;
+    }
+    {
+        std::shared_lock<std::shared_mutex> r(v->mu);  // vs compaction only
+        // geometric growth: the copy is amortised over the rows that fit the new capacity
+        const uint64_t target = vmm ? need_rows : std::max<uint64_t>(need_rows, v->cap_rows + v->cap_rows / 2 + 1024);
+        ORAMA_TRY(grow(v, target, s));
+        ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (!vmm) {
+        { std::unique_lock<std::shared_mutex> barrier(v->mu); }
+        v->rows.drop_old();
+        v->inv_norm.drop_old();
+        v->row_doc.drop_old();
+        v->dead.drop_old();
+    }
+    return ORAMA_OK;
+}
+
 int orama_vec_insert(orama_vec* v, const uint64_t* doc_ids, const float* rows, uint64_t n_rows,
                      uint64_t* accepted) {
     ORAMA_REQUIRE(v, "null handle");
@@ -475,7 +732,7 @@ int orama_vec_insert(orama_vec* v, const uint64_t* doc_ids, const float* rows, u
     if (n_rows == 0) return ORAMA_OK;
     ORAMA_REQUIRE(doc_ids && rows, "null input");
     ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
-    std::unique_lock<std::shared_mutex> lk(v->mu);
+    std::lock_guard<std::mutex> wl(v->write_mu);  // one writer; searches keep running on the published snapshot
     ScratchLease sc(v->ctx);
     ORAMA_TRY(sc.init());
     hipStream_t s = sc->stream;
@@ -485,28 +742,30 @@ int orama_vec_insert(orama_vec* v, const uint64_t* doc_ids, const float* rows, u
     uint64_t total_ok = 0;
     for (uint64_t r0 = 0; r0 < n_rows; r0 += slab_rows) {
         const uint64_t cnt = std::min(slab_rows, n_rows - r0);
-        ORAMA_TRY(sc->h_in.reserve((size_t)cnt * rb));
+        ORAMA_TRY(sc->h_in.reserve((size_t)cnt * (rb + 8)));
         float* stage = sc->h_in.as<float>();
+        uint64_t* stage_doc = reinterpret_cast<uint64_t*>(sc->h_in.as<char>() + (size_t)cnt * rb);
         uint64_t ok = 0;
-        const uint64_t first = v->n_rows;
         for (uint64_t i = 0; i < cnt; ++i) {
             const float* x = rows + (r0 + i) * (uint64_t)v->dim;
             if (!row_valid(x, v->dim)) continue;
             memcpy(stage + ok * (uint64_t)v->dim, x, rb);
-            v->h_row_doc.push_back(doc_ids[r0 + i]);
-            if (v->doc_rows_built) v->doc_rows[doc_ids[r0 + i]].push_back((uint32_t)(first + ok));
+            stage_doc[ok] = doc_ids[r0 + i];
             ++ok;
         }
         if (!ok) continue;
-        ORAMA_TRY(grow(v, first + ok, s));
+        const uint64_t first = v->n_rows.load(std::memory_order_relaxed);
+        ORAMA_TRY(reserve_rows_locked(v, first + ok, s));
+        std::shared_lock<std::shared_mutex> r(v->mu);  // vs compaction
         ORAMA_TRY(sc->misc1.reserve((size_t)ok * rb));
         ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc1.p, stage, (size_t)ok * rb, hipMemcpyHostToDevice, s));
-        ORAMA_TRY(store_rows_from_device(v, v->rows.p, v->inv_norm.as<float>(), sc->misc1.as<float>(), first, ok, s));
-        ORAMA_HIP_TRY(hipMemcpyAsync(v->row_doc.as<uint64_t>() + first, v->h_row_doc.data() + first,
-                                     (size_t)ok * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        // rows [first, first + ok) are beyond the published count: no search reads them yet
+        ORAMA_TRY(store_rows_from_device(v, v->rows.base, v->inv_norm.as<float>(), sc->misc1.as<float>(), first, ok, s));
+        ORAMA_TRY(sc->misc2.reserve((size_t)ok * sizeof(uint64_t)));
+        ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc2.p, stage_doc, (size_t)ok * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        ORAMA_TRY(launch_copy_bytes(v->row_doc.as<uint64_t>() + first, sc->misc2.p, (size_t)ok * sizeof(uint64_t), s));
         ORAMA_HIP_TRY(hipStreamSynchronize(s));
-        v->n_rows = first + ok;
-        v->h_dead.resize((size_t)((v->n_rows + 31) / 32), 0u);
+        v->n_rows.store(first + ok, std::memory_order_release);  // publish: later searches see the slab
         total_ok += ok;
     }
     if (accepted) *accepted = total_ok;
@@ -517,56 +776,69 @@ int orama_vec_delete(orama_vec* v, const uint64_t* doc_ids, uint64_t n) {
     ORAMA_REQUIRE(v, "null handle");
     if (n == 0) return ORAMA_OK;
     ORAMA_REQUIRE(doc_ids, "null input");
+    ORAMA_REQUIRE(n < 0xffffffffull, "too many ids in one delete");
     ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
-    std::unique_lock<std::shared_mutex> lk(v->mu);
-    if (!v->doc_rows_built) {
-        v->doc_rows.clear();
-        v->doc_rows.reserve((size_t)v->n_rows);
-        for (uint64_t r = 0; r < v->n_rows; ++r) v->doc_rows[v->h_row_doc[r]].push_back((uint32_t)r);
-        v->doc_rows_built = true;
-    }
-    v->h_dead.resize((size_t)((v->n_rows + 31) / 32), 0u);
-    bool changed = false;
-    for (uint64_t i = 0; i < n; ++i) {
-        auto it = v->doc_rows.find(doc_ids[i]);
-        if (it == v->doc_rows.end()) continue;
-        for (uint32_t r : it->second) {
-            uint32_t& w = v->h_dead[r >> 5];
-            const uint32_t bit = 1u << (r & 31);
-            if (!(w & bit)) {
-                w |= bit;
-                ++v->n_dead;
-                changed = true;
-            }
-        }
-        v->doc_rows.erase(it);
-    }
-    if (changed) {
-        ORAMA_HIP_TRY(hipMemcpy(v->dead.p, v->h_dead.data(), v->h_dead.size() * sizeof(uint32_t),
-                                hipMemcpyHostToDevice));
-    }
+    std::lock_guard<std::mutex> wl(v->write_mu);
+    std::shared_lock<std::shared_mutex> r(v->mu);  // searches keep running; each sees the tombstones or not
+    const uint64_t rows = v->n_rows.load(std::memory_order_acquire);
+    if (rows == 0) return ORAMA_OK;
+    ScratchLease sc(v->ctx);
+    ORAMA_TRY(sc.init());
+    hipStream_t s = sc->stream;
+    // one pass over row_doc on the device (8 B per row: 80 MB at 10 M rows) instead of a host hash map of every row
+    std::vector<uint64_t> sorted(doc_ids, doc_ids + n);
+    std::sort(sorted.begin(), sorted.end());
+    sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
+    ORAMA_TRY(sc->misc0.reserve(sorted.size() * 8 + 16));
+    ORAMA_TRY(sc->h_in.reserve(sorted.size() * 8));
+    memcpy(sc->h_in.p, sorted.data(), sorted.size() * 8);
+    unsigned long long* d_newly = reinterpret_cast<unsigned long long*>(sc->misc0.as<char>() + sorted.size() * 8);
+    ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, sc->h_in.p, sorted.size() * 8, hipMemcpyHostToDevice, s));
+    ORAMA_HIP_TRY(hipMemsetAsync(d_newly, 0, 8, s));
+    hipLaunchKernelGGL(mark_deleted_kernel, dim3(blocks_for_rows(rows)), dim3(256), 0, s, v->row_doc.as<uint64_t>(), rows,
+                       sc->misc0.as<uint64_t>(), (uint32_t)sorted.size(), v->dead.as<uint32_t>(), d_newly);
+    ORAMA_HIP_TRY(hipGetLastError());
+    ORAMA_TRY(sc->h_out.reserve(8));
+    ORAMA_HIP_TRY(hipMemcpyAsync(sc->h_out.p, d_newly, 8, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    const uint64_t newly = *sc->h_out.as<uint64_t>();
+    if (newly) v->n_dead.fetch_add(newly, std::memory_order_release);
     return ORAMA_OK;
 }
 
 int orama_vec_compact(orama_vec* v, uint64_t version) {
     ORAMA_REQUIRE(v, "null handle");
     ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
-    std::unique_lock<std::shared_mutex> lk(v->mu);
+    std::lock_guard<std::mutex> wl(v->write_mu);
+    std::unique_lock<std::shared_mutex> lk(v->mu);  // rows move: no scan may run (the reference's compact is exclusive too)
     v->version = version;
-    if (v->n_dead == 0) return ORAMA_OK;
-    // Re-pack live rows (device gather through a row-index list, in slabs), rebuild the side arrays.
-    std::vector<uint64_t> live;
-    live.reserve((size_t)(v->n_rows - v->n_dead));
-    for (uint64_t r = 0; r < v->n_rows; ++r)
-        if (!((v->h_dead[r >> 5] >> (r & 31)) & 1u)) live.push_back(r);
-    const uint64_t m = live.size();
+    const uint64_t n_old = v->n_rows.load(std::memory_order_acquire);
+    if (v->n_dead.load(std::memory_order_acquire) == 0) return ORAMA_OK;
     ScratchLease sc(v->ctx);
     ORAMA_TRY(sc.init());
     hipStream_t s = sc->stream;
-    Arrays a;
-    ORAMA_TRY(alloc_arrays(v, m ? m : 1, &a, s));
-    std::vector<uint64_t> ndoc_h(m);
-    for (uint64_t i = 0; i < m; ++i) ndoc_h[i] = v->h_row_doc[live[i]];
+    // live row list from the tombstone bitmap (n/8 bytes over PCIe; compaction is rare)
+    std::vector<uint32_t> h_dead((size_t)((n_old + 31) / 32));
+    ORAMA_TRY(sc->misc2.reserve(h_dead.size() * 4));
+    ORAMA_TRY(launch_copy_bytes(sc->misc2.p, v->dead.base, h_dead.size() * 4, s));
+    ORAMA_HIP_TRY(hipMemcpyAsync(h_dead.data(), sc->misc2.p, h_dead.size() * 4, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    std::vector<uint64_t> live;
+    live.reserve((size_t)n_old);
+    for (uint64_t r = 0; r < n_old; ++r)
+        if (!((h_dead[r >> 5] >> (r & 31)) & 1u)) live.push_back(r);
+    const uint64_t m = live.size();
+    // Re-pack into FRESH arrays (device gather through the row-index list, in slabs), then swap.
+    std::unique_ptr<orama_vec> nv(new (std::nothrow) orama_vec());
+    if (!nv) {
+        set_error("out of host memory");
+        return ORAMA_ERR_OOM;
+    }
+    nv->ctx = v->ctx;
+    nv->dim = v->dim;
+    nv->metric = v->metric;
+    nv->dtype = v->dtype;
+    ORAMA_TRY(grow(nv.get(), m ? m : 1, s));
     if (m) {
         const uint64_t slab = std::max<uint64_t>(1, (256ull << 20) / v->row_bytes());
         ORAMA_TRY(sc->misc0.reserve((size_t)m * sizeof(uint64_t)));
@@ -575,36 +847,48 @@ int orama_vec_compact(orama_vec* v, uint64_t version) {
         for (uint64_t i0 = 0; i0 < m; i0 += slab) {
             const uint64_t cnt = std::min(slab, m - i0);
             if (v->f16())
-                ORAMA_TRY(launch_f16_gather_rows(v->rows.p, sc->misc0.as<uint64_t>() + i0, cnt, v->dim,
+                ORAMA_TRY(launch_f16_gather_rows(v->rows.base, sc->misc0.as<uint64_t>() + i0, cnt, v->dim,
                                                  sc->misc1.as<float>(), s));
             else
                 ORAMA_TRY(launch_gather_rows_f32(v->rows.as<float>(), sc->misc0.as<uint64_t>() + i0, cnt, v->dim,
                                                  sc->misc1.as<float>(), s));
-            ORAMA_TRY(store_rows_from_device(v, a.rows, reinterpret_cast<float*>(a.norm), sc->misc1.as<float>(),
-                                             i0, cnt, s));
+            ORAMA_TRY(store_rows_from_device(v, nv->rows.base, nv->inv_norm.as<float>(), sc->misc1.as<float>(), i0, cnt, s));
         }
-        ORAMA_HIP_TRY(hipMemcpyAsync(a.doc, ndoc_h.data(), (size_t)m * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(blocks_for_rows(m)), dim3(256), 0, s, v->row_doc.as<uint64_t>(),
+                           sc->misc0.as<uint64_t>(), m, nv->row_doc.as<uint64_t>());
+        ORAMA_HIP_TRY(hipGetLastError());
     }
     ORAMA_HIP_TRY(hipStreamSynchronize(s));
-    adopt_arrays(v, a);
-    v->n_rows = m;
-    v->n_dead = 0;
-    v->h_row_doc.swap(ndoc_h);
-    v->h_dead.assign((size_t)((m + 31) / 32), 0u);
-    v->doc_rows.clear();
-    v->doc_rows_built = false;
-    return ORAMA_OK;
+    auto swap_buf = [](GrowBuf& a, GrowBuf& b) {
+        std::swap(a.base, b.base);
+        std::swap(a.va_bytes, b.va_bytes);
+        std::swap(a.mapped, b.mapped);
+        std::swap(a.chunk, b.chunk);
+        std::swap(a.vmm, b.vmm);
+        std::swap(a.device, b.device);
+        a.handles.swap(b.handles);
+        a.handle_bytes.swap(b.handle_bytes);
+    };
+    swap_buf(v->rows, nv->rows);
+    swap_buf(v->inv_norm, nv->inv_norm);
+    swap_buf(v->row_doc, nv->row_doc);
+    swap_buf(v->dead, nv->dead);
+    v->cap_rows = nv->cap_rows;
+    v->n_rows.store(m, std::memory_order_release);
+    v->n_dead.store(0, std::memory_order_release);
+    return ORAMA_OK;  // nv (holding the old arrays) is released here
 }
 
 int orama_vec_info(orama_vec* v, orama_vec_info_t* out) {
     ORAMA_REQUIRE(v && out, "null argument");
     std::shared_lock<std::shared_mutex> lk(v->mu);
+    const uint64_t n = v->n_rows.load(std::memory_order_acquire), d = v->n_dead.load(std::memory_order_acquire);
     out->dimensions = v->dim;
-    out->num_rows = v->n_rows;
-    out->num_embeddings = v->n_rows - v->n_dead;
-    out->pending_ops = v->n_dead;
+    out->num_rows = n;
+    out->num_embeddings = n - d;
+    out->pending_ops = d;
     out->version = v->version;
-    out->hbm_bytes = (uint64_t)(v->rows.cap + v->inv_norm.cap + v->row_doc.cap + v->dead.cap);
+    out->hbm_bytes = (uint64_t)(v->rows.mapped + v->inv_norm.mapped + v->row_doc.mapped + v->dead.mapped);
     return ORAMA_OK;
 }
 
@@ -618,7 +902,7 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     ORAMA_REQUIRE(k <= kSelectMaxK, "limit %u exceeds the supported maximum %u", k, kSelectMaxK);
     ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
     std::shared_lock<std::shared_mutex> lk(v->mu);
-    if (v->n_rows == 0) return ORAMA_OK;
+    if (v->n_rows.load(std::memory_order_acquire) == 0) return ORAMA_OK;
     ScratchLease sc(v->ctx);
     ORAMA_TRY(sc.init());
     hipStream_t s = sc->stream;
@@ -722,12 +1006,13 @@ int orama_vec_fill_synthetic(orama_vec* v, uint64_t n_rows, uint64_t seed, uint6
     ORAMA_REQUIRE(v, "null handle");
     if (n_rows == 0) return ORAMA_OK;
     ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
-    std::unique_lock<std::shared_mutex> lk(v->mu);
+    std::lock_guard<std::mutex> wl(v->write_mu);
     ScratchLease sc(v->ctx);
     ORAMA_TRY(sc.init());
     hipStream_t s = sc->stream;
-    const uint64_t first = v->n_rows;
-    ORAMA_TRY(grow(v, first + n_rows, s));
+    const uint64_t first = v->n_rows.load(std::memory_order_relaxed);
+    ORAMA_TRY(reserve_rows_locked(v, first + n_rows, s));
+    std::shared_lock<std::shared_mutex> r(v->mu);
     if (v->f16()) {
         // generate f32 slabs in scratch with the SAME generator (row index = store row), then quantise
         const uint64_t slab = std::max<uint64_t>(32, ((512ull << 20) / v->row_bytes()) & ~31ull);
@@ -737,7 +1022,7 @@ int orama_vec_fill_synthetic(orama_vec* v, uint64_t n_rows, uint64_t seed, uint6
             // rows are generated at virtual positions first+r0.. by offsetting the base pointer
             float* virt = sc->misc1.as<float>() - (first + r0) * (uint64_t)v->dim;
             ORAMA_TRY(launch_synth_fill_f32(virt, first + r0, cnt, v->dim, seed, s));
-            ORAMA_TRY(store_rows_from_device(v, v->rows.p, v->inv_norm.as<float>(), sc->misc1.as<float>(),
+            ORAMA_TRY(store_rows_from_device(v, v->rows.base, v->inv_norm.as<float>(), sc->misc1.as<float>(),
                                              first + r0, cnt, s));
         }
     } else {
@@ -746,13 +1031,8 @@ int orama_vec_fill_synthetic(orama_vec* v, uint64_t n_rows, uint64_t seed, uint6
             ORAMA_TRY(launch_row_inv_norm_f32(v->rows.as<float>(), first, n_rows, v->dim, v->inv_norm.as<float>(), s));
     }
     ORAMA_TRY(launch_iota_u64(v->row_doc.as<uint64_t>() + first, n_rows, first_doc_id, s));
-    v->h_row_doc.resize((size_t)(first + n_rows));
-    for (uint64_t i = 0; i < n_rows; ++i) v->h_row_doc[first + i] = first_doc_id + i;
-    if (v->doc_rows_built)
-        for (uint64_t i = 0; i < n_rows; ++i) v->doc_rows[first_doc_id + i].push_back((uint32_t)(first + i));
     ORAMA_HIP_TRY(hipStreamSynchronize(s));
-    v->n_rows = first + n_rows;
-    v->h_dead.resize((size_t)((v->n_rows + 31) / 32), 0u);
+    v->n_rows.store(first + n_rows, std::memory_order_release);
     return ORAMA_OK;
 }
 
@@ -763,8 +1043,9 @@ int orama_vec_get_rows(orama_vec* v, const uint64_t* row_idx, uint64_t n, float*
     ORAMA_REQUIRE(row_idx && out_rows, "null argument");
     ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
     std::shared_lock<std::shared_mutex> lk(v->mu);
+    const uint64_t rows = v->n_rows.load(std::memory_order_acquire);
     for (uint64_t i = 0; i < n; ++i)
-        ORAMA_REQUIRE(row_idx[i] < v->n_rows, "row %llu out of range", (unsigned long long)row_idx[i]);
+        ORAMA_REQUIRE(row_idx[i] < rows, "row %llu out of range", (unsigned long long)row_idx[i]);
     ScratchLease sc(v->ctx);
     ORAMA_TRY(sc.init());
     hipStream_t s = sc->stream;
@@ -772,14 +1053,19 @@ int orama_vec_get_rows(orama_vec* v, const uint64_t* row_idx, uint64_t n, float*
     ORAMA_TRY(sc->misc1.reserve((size_t)n * v->row_bytes()));
     ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, row_idx, (size_t)n * 8, hipMemcpyHostToDevice, s));
     if (v->f16())
-        ORAMA_TRY(launch_f16_gather_rows(v->rows.p, sc->misc0.as<uint64_t>(), n, v->dim, sc->misc1.as<float>(), s));
+        ORAMA_TRY(launch_f16_gather_rows(v->rows.base, sc->misc0.as<uint64_t>(), n, v->dim, sc->misc1.as<float>(), s));
     else
         ORAMA_TRY(launch_gather_rows_f32(v->rows.as<float>(), sc->misc0.as<uint64_t>(), n, v->dim,
                                          sc->misc1.as<float>(), s));
     ORAMA_HIP_TRY(hipMemcpyAsync(out_rows, sc->misc1.p, (size_t)n * v->row_bytes(), hipMemcpyDeviceToHost, s));
+    if (out_doc_ids) {
+        ORAMA_TRY(sc->misc2.reserve((size_t)n * 8));
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(blocks_for_rows(n)), dim3(256), 0, s, v->row_doc.as<uint64_t>(),
+                           sc->misc0.as<uint64_t>(), n, sc->misc2.as<uint64_t>());
+        ORAMA_HIP_TRY(hipGetLastError());
+        ORAMA_HIP_TRY(hipMemcpyAsync(out_doc_ids, sc->misc2.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    }
     ORAMA_HIP_TRY(hipStreamSynchronize(s));
-    if (out_doc_ids)
-        for (uint64_t i = 0; i < n; ++i) out_doc_ids[i] = v->h_row_doc[row_idx[i]];
     return ORAMA_OK;
 }
 
