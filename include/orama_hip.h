@@ -197,8 +197,8 @@ int orama_allow_set(orama_allow* a, const uint64_t* doc_ids, uint64_t n, int all
 /* ------------------------------------------------------------------ request micro-batcher
  * The reference API has no batch entry (EmbeddingFieldStorage::search takes ONE target,
  * embedding_field.rs:250-254); concurrent single-query callers are coalesced here so that one corpus pass serves
- * up to max_batch requests (K2's MFMA path at Q <= 64 per pass).  orama_batcher_search blocks the calling thread
- * until its answer is ready and has the semantics of orama_vec_search(q = 1, no filter); max_wait_us = 0 means
+ * up to max_batch requests (K2's MFMA path at Q <= 64 per pass, K2d above).  orama_batcher_search blocks the calling
+ * thread until its answer is ready and has the semantics of orama_vec_search(q = 1, no filter); max_wait_us = 0 means
  * "never delay": a batch is whatever arrived while the previous pass was running.  Extension — no reference
  * counterpart; the Rust shim would call it from spawn_blocking. */
 typedef struct orama_batcher orama_batcher;
@@ -206,6 +206,12 @@ int orama_batcher_create(orama_vec* v, uint32_t max_batch, uint32_t max_wait_us,
 void orama_batcher_destroy(orama_batcher* b);
 int orama_batcher_search(orama_batcher* b, const float* query, uint32_t k, uint64_t* out_ids, float* out_dist,
                          uint32_t* out_n);
+/* The same with the request's filter (semantics of orama_vec_search with allow_bitmap — the reference's
+ * search_with_filter, embedding_field.rs:255-262).  A batch shares one bitmap: requests are grouped by their
+ * (allow_bitmap pointer, bitmap_bits) pair, so pass the SAME resident token (orama_allow_token) for the same filter —
+ * e.g. the index's NOT-deleted bitmap, which every search carries while deletes are pending (index/filter.rs:344-392). */
+int orama_batcher_search_filtered(orama_batcher* b, const float* query, uint32_t k, const uint64_t* allow_bitmap,
+                                  uint64_t bitmap_bits, uint64_t* out_ids, float* out_dist, uint32_t* out_n);
 int orama_batcher_stats(orama_batcher* b, uint64_t* requests, uint64_t* batches, uint32_t* largest_batch);
 
 /* ------------------------------------------------------------------ BM25F full-text scoring
@@ -306,6 +312,20 @@ int orama_post_search(orama_post* p, const orama_term_ref* refs, uint32_t n_refs
                       const orama_bm25_params* params, const uint64_t* allow_bitmap,
                       uint64_t bitmap_bits, int apply_omc, uint64_t* out_ids, float* out_scores,
                       uint32_t* out_n, uint64_t* out_count);
+
+/* Many independent orama_post_search queries in one call (batch extension, no reference counterpart — the reference
+ * reaches this path one request per tokio worker): up to `max_parallel` (0 = 8) library threads each take the next
+ * query and run the single-query path on their own stream + scratch set, so the launch-bound kernels of different
+ * queries overlap on the device.  Results of query i: out_ids / out_scores + i * stride_k (stride_k >= every top_k),
+ * out_n[i], out_count[i] — each identical to what orama_post_search returns for that query. */
+typedef struct {
+    const orama_term_ref* refs;
+    uint32_t n_refs;
+    orama_bm25_params params;
+} orama_post_query_desc;
+int orama_post_search_batch(orama_post* p, const orama_post_query_desc* queries, uint32_t n_queries, float b,
+                            const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc, uint32_t max_parallel,
+                            uint32_t stride_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count);
 
 /* ------------------------------------------------------------------ score map, facets, groups
  * The reference hands the WHOLE HashMap<DocumentId, f32> of a search to facets and groups

@@ -70,6 +70,10 @@ class TermRef(C.Structure):
     _fields_ = [("token", C.c_uint32), ("list", C.c_uint32), ("boost", C.c_float)]
 
 
+class PostQueryDesc(C.Structure):
+    _fields_ = [("refs", C.POINTER(TermRef)), ("n_refs", C.c_uint32), ("params", Bm25Params)]
+
+
 def declared_symbols() -> list[str]:
     """Every function name declared in include/orama_hip.h (used by the ABI export test)."""
     text = HEADER.read_text()
@@ -148,6 +152,7 @@ def _declare(lib: C.CDLL) -> None:
         "orama_dict_expand": [vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, vp, u32p],
         "orama_batcher_create": [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)],
         "orama_batcher_search": [vp, vp, C.c_uint32, vp, vp, u32p],
+        "orama_batcher_search_filtered": [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, u32p],
         "orama_batcher_stats": [vp, u64p, u64p, u32p],
         "orama_bm25_score": [vp, C.POINTER(NtfEntry), C.c_uint32, C.POINTER(Bm25Params), vp, vp, C.c_uint64,
                              vp, vp, u32p, u64p],
@@ -162,6 +167,8 @@ def _declare(lib: C.CDLL) -> None:
         "orama_post_fill_synthetic": [vp, C.c_uint64, C.c_uint64, C.c_uint32, vp, C.c_uint64, u64p],
         "orama_post_search": [vp, C.POINTER(TermRef), C.c_uint32, C.c_float, C.POINTER(Bm25Params), vp,
                               C.c_uint64, C.c_int, vp, vp, u32p, u64p],
+        "orama_post_search_batch": [vp, C.POINTER(PostQueryDesc), C.c_uint32, C.c_float, vp, C.c_uint64, C.c_int, C.c_uint32,
+                                    C.c_uint32, vp, vp, vp, vp],
         "orama_post_search_hybrid": [vp, C.POINTER(TermRef), C.c_uint32, C.c_float, C.POINTER(Bm25Params), vp,
                                      C.c_uint64, vp, vp, C.c_uint32, C.c_int, vp, vp, u32p, u64p],
         "orama_hybrid_search": [vp, vp, vp, C.c_uint32, C.c_float, C.c_int, C.POINTER(TermRef), C.c_uint32, C.c_float,

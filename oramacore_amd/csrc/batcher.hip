@@ -8,7 +8,12 @@
 // additionally holds an under-full batch open for that long after its first request.
 //
 // Per-request k: the batch runs with the largest k; the total order (distance asc, doc asc, row asc) makes every
-// smaller-k answer a prefix of it.  Filtered searches do not go through the batcher (filters differ per request).
+// smaller-k answer a prefix of it.
+// Filters: a batch shares ONE allow bitmap, so requests are grouped by their (bitmap pointer, bits) pair — the
+// dispatcher takes the oldest pending request and every later one carrying the same pair.  That is the common case:
+// while deletes are pending EVERY search of an index carries the same NOT-deleted predicate
+// (index/filter.rs:344-392), which the shim keeps as one resident bitmap (orama_allow_*), so single-query traffic
+// stays on the MFMA path under live deletes; requests with other filters simply form their own batches.
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -25,6 +30,8 @@ namespace {
 struct Request {
     const float* query = nullptr;
     uint32_t k = 0;
+    const uint64_t* allow = nullptr;  // resident token or caller-owned host words (borrowed while the caller blocks)
+    uint64_t allow_bits = 0;
     uint64_t* out_ids = nullptr;
     float* out_dist = nullptr;
     uint32_t* out_n = nullptr;
@@ -63,9 +70,16 @@ struct orama_batcher {
                     const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_wait_us);
                     cv_work.wait_until(lk, deadline, [&] { return stop || pending.size() >= max_batch; });
                 }
-                while (!pending.empty() && batch.size() < max_batch) {
-                    batch.push_back(pending.front());
-                    pending.pop_front();
+                // the oldest request decides the filter of this batch; later requests with the same filter join it
+                const uint64_t* allow = pending.front()->allow;
+                const uint64_t bits = pending.front()->allow_bits;
+                for (auto it = pending.begin(); it != pending.end() && batch.size() < max_batch;) {
+                    if ((*it)->allow == allow && (*it)->allow_bits == bits) {
+                        batch.push_back(*it);
+                        it = pending.erase(it);
+                    } else {
+                        ++it;
+                    }
                 }
                 n_requests += batch.size();
                 n_batches += 1;
@@ -82,7 +96,8 @@ struct orama_batcher {
             int st = ORAMA_OK;
             std::string err;
             if (kmax > 0) {
-                st = orama_vec_search(v, queries.data(), q, kmax, nullptr, 0, ids.data(), dist.data(), cnt.data());
+                st = orama_vec_search(v, queries.data(), q, kmax, batch[0]->allow, batch[0]->allow_bits, ids.data(),
+                                      dist.data(), cnt.data());
                 if (st != ORAMA_OK) err = orama_last_error();  // this thread's error slot
             }
             {
@@ -138,6 +153,11 @@ void orama_batcher_destroy(orama_batcher* b) {
 
 int orama_batcher_search(orama_batcher* b, const float* query, uint32_t k, uint64_t* out_ids, float* out_dist,
                          uint32_t* out_n) {
+    return orama_batcher_search_filtered(b, query, k, nullptr, 0, out_ids, out_dist, out_n);
+}
+
+int orama_batcher_search_filtered(orama_batcher* b, const float* query, uint32_t k, const uint64_t* allow_bitmap,
+                                  uint64_t bitmap_bits, uint64_t* out_ids, float* out_dist, uint32_t* out_n) {
     ORAMA_REQUIRE(b && query && out_n, "null argument");
     *out_n = 0;
     if (k == 0) return ORAMA_OK;
@@ -146,6 +166,8 @@ int orama_batcher_search(orama_batcher* b, const float* query, uint32_t k, uint6
     Request r;
     r.query = query;
     r.k = k;
+    r.allow = allow_bitmap;
+    r.allow_bits = allow_bitmap ? bitmap_bits : 0;
     r.out_ids = out_ids;
     r.out_dist = out_dist;
     r.out_n = out_n;

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -188,14 +189,20 @@ struct orama_ctx {
     char name[256] = {0};
     orama::Profiler prof;
     std::mutex pool_mu;
+    std::condition_variable pool_cv;
     std::vector<std::unique_ptr<orama::Scratch>> pool;
+    uint32_t leased = 0;  // scratch sets out on lease; bounded by max_inflight (callers beyond it wait their turn)
+    uint32_t max_inflight = 32;
     // resident allow-bitmaps (orama_allow_*): device pointer -> bits; a search whose `allow_bitmap` argument is one
     // of these pointers uses it in place instead of uploading host words
     std::mutex allow_mu;
     std::unordered_map<const void*, uint64_t> allow_reg;
 
-    // Borrow a scratch set (creates one when the pool is empty).
+    // Borrow a scratch set (creates one when the pool is empty); blocks while max_inflight sets are out.
     int acquire(std::unique_ptr<orama::Scratch>* out);
+    // Two sets at once (the fused hybrid search runs its legs on two streams): taken together, so that callers holding
+    // one set each can never wait for each other.
+    int acquire2(std::unique_ptr<orama::Scratch>* a, std::unique_ptr<orama::Scratch>* b);
     void release(std::unique_ptr<orama::Scratch> s);
 };
 
@@ -205,6 +212,7 @@ struct ScratchLease {
     std::unique_ptr<Scratch> s;
     explicit ScratchLease(orama_ctx* c) : ctx(c) {}
     int init() { return ctx->acquire(&s); }
+    static int init_pair(ScratchLease& a, ScratchLease& b) { return a.ctx->acquire2(&a.s, &b.s); }
     ~ScratchLease() {
         if (s) ctx->release(std::move(s));
     }

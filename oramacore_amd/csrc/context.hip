@@ -1,4 +1,5 @@
 // context.hip — error channel, per-GPU context, scratch pool, HIP-event profiler.
+#include <algorithm>
 #include <cstdlib>
 #include <memory>
 
@@ -81,18 +82,38 @@ Profiler::~Profiler() {
 
 }  // namespace orama
 
-int orama_ctx::acquire(std::unique_ptr<orama::Scratch>* out) {
-    {
-        std::lock_guard<std::mutex> g(pool_mu);
-        if (!pool.empty()) {
-            *out = std::move(pool.back());
-            pool.pop_back();
-            return ORAMA_OK;
-        }
+namespace {
+int take_one(orama_ctx* c, std::unique_ptr<orama::Scratch>* out) {  // pool_mu held
+    if (!c->pool.empty()) {
+        *out = std::move(c->pool.back());
+        c->pool.pop_back();
+        return ORAMA_OK;
     }
     std::unique_ptr<orama::Scratch> s(new orama::Scratch());
     ORAMA_HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     *out = std::move(s);
+    return ORAMA_OK;
+}
+}  // namespace
+
+int orama_ctx::acquire(std::unique_ptr<orama::Scratch>* out) {
+    std::unique_lock<std::mutex> g(pool_mu);
+    pool_cv.wait(g, [&] { return leased < max_inflight; });
+    ORAMA_TRY(take_one(this, out));
+    ++leased;
+    return ORAMA_OK;
+}
+
+int orama_ctx::acquire2(std::unique_ptr<orama::Scratch>* a, std::unique_ptr<orama::Scratch>* b) {
+    std::unique_lock<std::mutex> g(pool_mu);
+    pool_cv.wait(g, [&] { return leased + 2 <= max_inflight; });
+    ORAMA_TRY(take_one(this, a));
+    const int st = take_one(this, b);
+    if (st != ORAMA_OK) {
+        pool.push_back(std::move(*a));
+        return st;
+    }
+    leased += 2;
     return ORAMA_OK;
 }
 
@@ -109,7 +130,7 @@ size_t scratch_bytes(const orama::Scratch& s) {
 size_t scratch_pool_budget() {
     static const size_t v = [] {
         const char* e = std::getenv("ORAMA_SCRATCH_POOL_MIB");
-        return (e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)8192) << 20;
+        return (e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)65536) << 20;
     }();
     return v;
 }
@@ -118,8 +139,11 @@ size_t scratch_pool_budget() {
 // Scratch sets are pooled so that a search allocates nothing in steady state — but a set sized by a large index
 // (the BM25 accumulator alone is slots x n_docs x 8 B: 1.3 GB at 10 M docs and 12 tokens) stays that large.  Many
 // concurrent callers (the reference searches from every tokio worker) would otherwise pin peak-concurrency x that
-// much HBM forever: when the idle pool exceeds its budget (ORAMA_SCRATCH_POOL_MIB, default 8 GiB) the set being
-// returned gives its large buffers back to the driver and keeps only its stream and small buffers.
+// much HBM forever.  Two bounds: at most `max_inflight` sets are out at any time (ORAMA_MAX_INFLIGHT, default 32 — further
+// callers wait their turn, which also bounds the peak), and when the idle pool exceeds its byte budget
+// (ORAMA_SCRATCH_POOL_MIB, default 64 GiB of the 288) the set being returned gives its large buffers back to the driver
+// and keeps only its stream and small buffers.  (A budget below what the steady concurrency needs makes every query
+// re-allocate and re-zero its accumulator: 10 K -> 0.5 K queries/s at 8 threads with an 8 GiB budget.)
 void orama_ctx::release(std::unique_ptr<orama::Scratch> s) {
     std::lock_guard<std::mutex> g(pool_mu);
     size_t pooled = 0;
@@ -132,6 +156,8 @@ void orama_ctx::release(std::unique_ptr<orama::Scratch> s) {
             if (d->cap > ((size_t)16 << 20)) d->release();
     }
     pool.push_back(std::move(s));
+    if (leased) --leased;
+    pool_cv.notify_all();
 }
 
 namespace orama {
@@ -251,6 +277,7 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
     if (const char* e = std::getenv("ORAMA_F16_WIDE")) c->f16_wide = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_KC")) c->f16_kc = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_NBUF")) c->f16_nbuf = std::atoi(e);
+    if (const char* e = std::getenv("ORAMA_MAX_INFLIGHT")) c->max_inflight = (uint32_t)std::max(2, std::atoi(e));
     c->device = device_ordinal;
     c->compute_units = prop.multiProcessorCount;
     c->hbm_bytes = (uint64_t)prop.totalGlobalMem;

@@ -277,15 +277,17 @@ class SearchBatcher:
         except Exception:  # noqa: BLE001
             pass
 
-    def search(self, target, limit: int):
-        """Row-level k-NN of ONE target: (doc_ids [n], distances [n])."""
+    def search(self, target, limit: int, allow=None):
+        """Row-level k-NN of ONE target: (doc_ids [n], distances [n]).  `allow`: the request's filter — pass the SAME
+        ResidentAllowBitmap object for the same filter so that those requests share corpus passes."""
         t = np.ascontiguousarray(np.asarray(target, dtype=np.float32).reshape(self.storage.dim))
         k = int(limit)
         ids = np.zeros(max(k, 1), dtype=np.uint64)
         dist = np.zeros(max(k, 1), dtype=np.float32)
         n = C.c_uint32()
-        N.check(self._lib.orama_batcher_search(self._h, t.ctypes.data, k, ids.ctypes.data, dist.ctypes.data,
-                                               C.byref(n)))
+        bm_ptr, bm_bits = allow.ffi_args() if allow is not None else (None, 0)
+        N.check(self._lib.orama_batcher_search_filtered(self._h, t.ctypes.data, k, bm_ptr, bm_bits, ids.ctypes.data,
+                                                        dist.ctypes.data, C.byref(n)))
         return ids[: n.value], dist[: n.value]
 
     def stats(self) -> dict:

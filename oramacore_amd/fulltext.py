@@ -485,6 +485,29 @@ class PostingsStore:
         avg = _f32(avg_field_len)
         N.check(self._lib.orama_post_set_avg_len(self._h, avg.ctypes.data, avg.shape[0]))
 
+    def search_batch(self, queries, total_documents: float, top_k: int, allow: AllowBitmap | None = None,
+                     apply_omc: bool = True, max_parallel: int = 8, b: float = B_DEFAULT, k: float = K1_DEFAULT):
+        """queries: list of (refs, n_tokens, threshold | None).  One call, `max_parallel` library threads
+        (orama_post_search_batch).  Returns a list of (ids, scores, count), each identical to `search` of that query."""
+        nq = len(queries)
+        descs = (N.PostQueryDesc * max(nq, 1))()
+        keep = []
+        for i, (refs, n_tokens, thr) in enumerate(queries):
+            arr = self._refs(refs)
+            keep.append(arr)
+            descs[i].refs = C.cast(arr, C.POINTER(N.TermRef))
+            descs[i].n_refs = len(refs)
+            descs[i].params = _params(total_documents, n_tokens, thr, top_k, k)
+        out_ids = np.zeros((max(nq, 1), max(top_k, 1)), dtype=np.uint64)
+        out_sc = np.zeros((max(nq, 1), max(top_k, 1)), dtype=np.float32)
+        out_n = np.zeros(max(nq, 1), dtype=np.uint32)
+        out_count = np.zeros(max(nq, 1), dtype=np.uint64)
+        bm_ptr, bm_bits = allow.ffi_args() if allow is not None else (None, 0)
+        N.check(self._lib.orama_post_search_batch(self._h, descs, nq, b, bm_ptr, bm_bits, 1 if apply_omc else 0,
+                                                  int(max_parallel), max(top_k, 1), out_ids.ctypes.data,
+                                                  out_sc.ctypes.data, out_n.ctypes.data, out_count.ctypes.data))
+        return [(out_ids[i, : out_n[i]].copy(), out_sc[i, : out_n[i]].copy(), int(out_count[i])) for i in range(nq)]
+
     def search_scores(self, refs, n_tokens: int, total_documents: float, top_k: int, threshold=None,
                       allow: AllowBitmap | None = None, apply_omc: bool = True, b: float = B_DEFAULT,
                       k: float = K1_DEFAULT, vector: dict | None = None) -> ScoreMap:

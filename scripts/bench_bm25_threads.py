@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""BM25-only throughput of the C4 full-text shape (10 M docs, 12 tokens, ~600 K postings per query) with T concurrent
+caller threads — the reference serves searches from many tokio workers; every call is an independent
+orama_post_search (own stream + scratch set)."""
+import argparse, json, sys, threading, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import oramacore_amd as oa  # noqa: E402
+from oramacore_amd import fulltext as ft  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--docs", type=int, default=10_000_000)
+ap.add_argument("--threads", default="1,2,4,8,16")
+ap.add_argument("--per-thread", type=int, default=150)
+ap.add_argument("--budget-s", type=float, default=6.0, help="give up on a thread count after this many seconds")
+args = ap.parse_args()
+n, T, k = args.docs, 12, 100
+ctx = oa.Context(0)
+rng = np.random.default_rng(0xB26)
+ranks = np.unique(np.exp(rng.uniform(np.log(100), np.log(100000), size=2048)).astype(np.uint32))
+post = ft.PostingsStore(ctx)
+post.fill_synthetic(n, ranks, seed=0xB25)
+qlists = [rng.choice(len(ranks), size=T, replace=False) for _ in range(512)]
+refs = [[(t, int(l), 1.0) for t, l in enumerate(ql)] for ql in qlists]
+out = {}
+for nt in [int(x) for x in args.threads.split(",")]:
+    for i in range(20):
+        post.search(refs[i], T, float(n), k)
+
+    done = [0] * nt
+    deadline = time.perf_counter() + args.budget_s
+
+    def worker(tid):
+        for i in range(args.per_thread):
+            if time.perf_counter() > deadline:
+                return
+            post.search(refs[(tid * 131 + i) % len(refs)], T, float(n), k)
+            done[tid] += 1
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(nt)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    el = time.perf_counter() - t0
+    out[nt] = sum(done) / el
+    print(f"caller threads {nt:3d}: {out[nt]:9.0f} queries/s ({sum(done)} queries in {el:.2f} s)", flush=True)
+# one caller, the batch entry (library worker threads)
+batch = [(refs[i % len(refs)], T, None) for i in range(1024)]
+for par in (1, 4, 8, 16):
+    post.search_batch(batch[:64], float(n), k, max_parallel=par)
+    t0 = time.perf_counter()
+    post.search_batch(batch, float(n), k, max_parallel=par)
+    el = time.perf_counter() - t0
+    out[f"batch_par{par}"] = len(batch) / el
+    print(f"orama_post_search_batch, {par:2d} library threads: {len(batch) / el:9.0f} queries/s", flush=True)
+print(json.dumps({"metric": "BM25-only queries/s, 10M docs, 12 tokens/query, top-100", "by_threads": out}))

@@ -7,6 +7,7 @@ import pytest
 
 import oramacore_amd as oa
 import util
+from oracle import oracle as orc
 from oramacore_amd import _native as N
 
 pytestmark = pytest.mark.gpu
@@ -99,4 +100,56 @@ def test_wide_batches_through_the_batcher(ctx):
         assert np.array_equal(got[i][1], solo[i][1]), i
     assert b.stats()["largest_batch"] > 64
     b.close()
+    st.close()
+
+
+def test_filtered_requests_share_passes_and_match_the_oracle(ctx):
+    """While deletes are pending every search carries the NOT-deleted predicate (index/filter.rs:344-392 ->
+    search_with_filter, embedding_field.rs:255-262).  Requests with the SAME resident bitmap share corpus passes;
+    requests with another filter form their own batches; every answer is checked against the ORACLE's filtered scan
+    (on the fp16-rounded vectors, 1e-4), not only against a solo run."""
+    n, d, k = 20000, 384, 15
+    corpus = util.gaussian_rows(n, d, seed=41)
+    doc_ids = np.arange(n, dtype=np.uint64)
+    st = oa.EmbeddingFieldStorage(ctx, dimensions=d, dtype=N.DTYPE_F16)
+    st.insert_rows(doc_ids, corpus)
+    c16 = corpus.astype(np.float16).astype(np.float32)
+    deleted = np.arange(0, n, 7)
+    not_deleted = oa.AllowBitmap.from_mask(~np.isin(np.arange(n), deleted))
+    category = oa.AllowBitmap.from_mask(np.arange(n) % 5 == 2)
+    res_nd, res_cat = not_deleted.to_device(ctx), category.to_device(ctx)
+    n_clients = 96
+    queries = util.gaussian_rows(n_clients, d, seed=42)
+    filt = [res_cat if i % 8 == 0 else (None if i % 8 == 1 else res_nd) for i in range(n_clients)]
+    b = oa.SearchBatcher(st, max_batch=64, max_wait_us=30000)
+    got, errs = [None] * n_clients, []
+
+    def client(i):
+        try:
+            got[i] = b.search(queries[i], k, allow=filt[i])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=client, args=(i,)) for i in range(n_clients)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for i in range(n_clients):
+        host = None if filt[i] is None else (category if filt[i] is res_cat else not_deleted)
+        q16 = queries[i].astype(np.float16).astype(np.float32)
+        full = orc.distances(c16, q16).astype(np.float64)
+        if host is not None:
+            mask = np.array([host.contains(int(x)) for x in range(n)])
+            full[~mask] = np.nan
+        ids, dist = got[i]
+        util.assert_topk_sound(ids, dist, full, k, 1e-4, f"client {i}")
+        if host is not None:
+            assert all(host.contains(int(x)) for x in ids.tolist())
+    s = b.stats()
+    assert s["requests"] == n_clients and s["batches"] < n_clients // 2 and s["largest_batch"] > 8
+    b.close()
+    res_nd.close()
+    res_cat.close()
     st.close()

@@ -299,3 +299,35 @@ def test_rrf_extra(ctx):
         assert np.array_equal(bits(sc), bits([s for _, s in exp]))
     ids, sc, count = ft.hybrid_rrf(ctx, {}, {7: 1.0}, 5)
     assert ids.tolist() == [7] and count == 1
+
+
+def test_batch_entry_equals_single_queries(ctx):
+    """orama_post_search_batch: many queries in one call on library worker threads — every result equals the
+    single-query call bit for bit (and therefore the oracle, which the other tests of this file pin it to)."""
+    rng = np.random.default_rng(19)
+    n_docs, n_lists = 30_000, 24
+    doc_ids = np.arange(n_docs, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    lens = rng.integers(5, 150, size=n_docs).astype(np.uint32)
+    lists = []
+    for l in range(n_lists):
+        pos = np.sort(rng.choice(n_docs, size=int(rng.integers(100, 9000)), replace=False))
+        lists.append(ft.PostingList(field=0, docs=doc_ids[pos], tf=rng.integers(1, 6, size=len(pos)).astype(np.uint32),
+                                    field_len=lens[pos]))
+    post = ft.PostingsStore(ctx)
+    post.build(doc_ids, [float(lens.mean())], lists)
+    queries = []
+    for i in range(70):
+        nt = int(rng.integers(1, 6))
+        ls = rng.choice(n_lists, size=nt, replace=False)
+        refs = [(t, int(l), float(rng.choice([1.0, 2.0]))) for t, l in enumerate(ls)]
+        queries.append((refs, nt, None if i % 3 else max(1, nt - 1)))
+    allow = oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[rng.random(n_docs) < 0.8]).to_device(ctx)
+    for flt in (None, allow):
+        for par in (1, 8):
+            got = post.search_batch(queries, float(n_docs), 25, allow=flt, max_parallel=par)
+            for (refs, nt, thr), (ids, sc, count) in zip(queries, got):
+                e_ids, e_sc, e_count = post.search(refs, nt, float(n_docs), 25, thr, allow=flt)
+                assert count == e_count and ids.tolist() == e_ids.tolist()
+                assert np.array_equal(sc.view(np.uint32), e_sc.view(np.uint32))
+    allow.close()
+    post.close()
