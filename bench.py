@@ -145,7 +145,10 @@ def main():
     # Stream plan (inside the session): ONE scan stream (corpus scans of consecutive steps run back to back, never
     # concurrently, so each keeps the whole HBM bandwidth) + `--streams` high-priority tail streams used round-robin
     # for top-k / all-gather / merge, which are launch-bound and overlap the next step's scan.
-    n_streams = max(1, args.streams)
+    # fp16 workloads: the scan and its threshold-filter selections depend on each other step by step and all run on the
+    # tail stream, so a second slot would only make two corpus scans share the HBM bandwidth (and inflate the per-launch
+    # durations the roofline is computed from) — one slot.
+    n_streams = 1 if f16 else max(1, args.streams)
     sess = group.session([store], queries_h, qb, k, n_slots=n_streams, force_exchange=args.force_exchange)
 
     def barrier():

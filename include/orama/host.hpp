@@ -273,13 +273,28 @@ class BM25Scorer {
         for (uint32_t i = 0; i < out_n; ++i) r.hits.push_back(TokenScore{ids[i], sc[i]});
         return r;
     }
+    // The whole HashMap<K, f32> (bm25.rs:416-428), any size: orama_bm25_score_map.
     std::unordered_map<DocumentId, float> get_scores() const {
+        std::vector<orama_ntf_entry> raw;
         size_t total = 0;
-        for (const auto& e : entries_) total += e.doc.size();
-        TopResult r = top_n(std::min<size_t>(std::max<size_t>(total, 1), 4096));
-        if (r.count > r.hits.size()) throw Error(ORAMA_ERR_UNSUPPORTED, "get_scores(): more than 4096 entries; use top_n()");
+        for (const auto& e : entries_) {
+            raw.push_back(orama_ntf_entry{e.token, e.doc.data(), e.ntf.data(), (uint64_t)e.doc.size()});
+            total += e.doc.size();
+        }
+        orama_bm25_params p{};
+        p.total_documents = total_documents_;
+        p.k = k_;
+        p.n_tokens = std::max<uint32_t>(term_index_, 1);
+        p.use_threshold = with_threshold_ ? 1 : 0;
+        p.threshold = threshold_;
+        p.top_k = 0;
+        std::vector<uint64_t> ids(total ? total : 1);
+        std::vector<float> sc(total ? total : 1);
+        uint64_t n = 0;
+        check(orama_bm25_score_map(ctx_.raw(), raw.data(), (uint32_t)raw.size(), &p, nullptr, nullptr, 0, total, ids.data(),
+                                   sc.data(), &n));
         std::unordered_map<DocumentId, float> m;
-        for (auto& h : r.hits) m[h.document_id] = h.score;
+        for (uint64_t i = 0; i < n; ++i) m[ids[i]] = sc[i];
         return m;
     }
 
