@@ -237,7 +237,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                     "kernel": kern + "_kernel", "alg_bytes_per_launch": alg_bytes,
+                     "kernel": ("vec_scan_f16_pc_kernel" if f16 and qb > 64 else kern + "_kernel"),
+                     "alg_bytes_per_launch": alg_bytes,
                      "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_n,
                      "scan_launches_per_step": launches_per_step,
                      "topk_select_ms_per_step": sel_ms / args.steps},
