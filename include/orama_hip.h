@@ -18,6 +18,22 @@
  *     serialises mutation internally and gives each search its own stream + scratch.
  *   - there is NO CPU fallback: without a HIP device every compute entry point fails with
  *     ORAMA_ERR_HIP.
+ *
+ * Limits of the implemented envelope.  A request beyond one of them is well-formed but not served:
+ * the call returns ORAMA_ERR_UNSUPPORTED (never a truncated answer) and the shim should route it to the
+ * reference's own CPU path.  ORAMA_ERR_INVALID is reserved for malformed arguments (null pointers,
+ * mismatched dimensions, zero where the reference itself has no meaning for it).
+ *   - result size: limit / top_k <= 4096 per query (exact radix select + one-workgroup sort of the
+ *     winners); for a shard group additionally shards * k <= 4096 (the merge runs in one workgroup);
+ *     group-by max_results <= 1024.  (Whole score maps of ANY size: orama_post_search_scores.)
+ *   - query tokens: n_tokens <= 64.  Threshold masks use bit (1 << (t % 32)) like the reference's u32
+ *     shift in release mode (token_score.rs:286-288), so > 32 tokens alias there too.
+ *   - a vector store holds < 2^32 - 16 rows, a postings store < 2^32 - 1 documents, one query references
+ *     < 2^32 - 1 postings (row / local-document indices are 32-bit on the device; DocumentIds are
+ *     64-bit everywhere).  Vector dimensions <= 65536.
+ *   - fp16 query batches: any q; 65..256 queries share one corpus pass, larger batches run in
+ *     passes of 256.
+ *   - facet ranges: <= 64 ranges per orama_facet_count_ranges call.
  */
 #ifndef ORAMA_HIP_H
 #define ORAMA_HIP_H

@@ -162,7 +162,7 @@ int orama_batcher_search_filtered(orama_batcher* b, const float* query, uint32_t
     *out_n = 0;
     if (k == 0) return ORAMA_OK;
     ORAMA_REQUIRE(out_ids && out_dist, "null output");
-    ORAMA_REQUIRE(k <= kSelectMaxK, "limit %u exceeds the supported maximum %u", k, kSelectMaxK);
+    ORAMA_SUPPORT(k <= kSelectMaxK, "limit %u exceeds the supported maximum %u", k, kSelectMaxK);
     Request r;
     r.query = query;
     r.k = k;

@@ -49,6 +49,15 @@ void clear_error();
         }                                   \
     } while (0)
 
+// A valid request outside the implemented envelope (the limits listed at the top of orama_hip.h).
+#define ORAMA_SUPPORT(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::orama::set_error(__VA_ARGS__); \
+            return ORAMA_ERR_UNSUPPORTED;   \
+        }                                   \
+    } while (0)
+
 // ---------------------------------------------------------------- device / pinned buffers
 struct DevBuf {
     void* p = nullptr;

@@ -210,7 +210,7 @@ int launch_facet_count_buckets(const ScoreMapDev& m, const uint32_t* d_entry_doc
 int launch_facet_count_ranges(const ScoreMapDev& m, const uint32_t* d_entry_doc, const double* d_entry_val, uint64_t n_entries,
                               const double* d_from, const double* d_to, uint32_t n_ranges, unsigned long long* d_counts,
                               hipStream_t s) {
-    ORAMA_REQUIRE(n_ranges <= kMaxRanges, "at most %u ranges per facet call", kMaxRanges);
+    ORAMA_SUPPORT(n_ranges <= kMaxRanges, "at most %u ranges per facet call", kMaxRanges);
     ORAMA_HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)(n_ranges ? n_ranges : 1) * 8, s));
     if (n_entries == 0 || n_ranges == 0) return ORAMA_OK;
     hipLaunchKernelGGL(facet_count_ranges_kernel, dim3(grid_for(n_entries, 2048)), dim3(kThreads), 0, s, m, d_entry_doc,
@@ -221,7 +221,8 @@ int launch_facet_count_ranges(const ScoreMapDev& m, const uint32_t* d_entry_doc,
 
 int launch_group_top(const ScoreMapDev& m, const uint32_t* d_entry_doc, const uint64_t* d_bucket_off, uint32_t n_buckets,
                      uint32_t k, uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_n, hipStream_t s) {
-    ORAMA_REQUIRE(k >= 1 && k <= kGroupMaxK, "group max_results %u outside [1, %u]", k, kGroupMaxK);
+    ORAMA_REQUIRE(k >= 1, "group max_results is 0");
+    ORAMA_SUPPORT(k <= kGroupMaxK, "group max_results %u outside [1, %u]", k, kGroupMaxK);
     if (n_buckets == 0) return ORAMA_OK;
     hipLaunchKernelGGL(group_top_kernel, dim3(n_buckets), dim3(kGroupThreads), 0, s, m, d_entry_doc, d_bucket_off, k,
                        d_out_ids, d_out_scores, d_out_n);

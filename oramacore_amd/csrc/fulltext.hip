@@ -149,9 +149,10 @@ void vec_min_max(const float* v, uint32_t n, float* mn, float* mx) {
 
 int check_params(const orama_bm25_params* p) {
     ORAMA_REQUIRE(p, "null params");
-    ORAMA_REQUIRE(p->n_tokens >= 1 && p->n_tokens <= kMaxTokens, "n_tokens %u outside [1, %u]", p->n_tokens,
+    ORAMA_REQUIRE(p->n_tokens >= 1, "no query tokens");
+    ORAMA_SUPPORT(p->n_tokens <= kMaxTokens, "n_tokens %u outside [1, %u]", p->n_tokens,
                   kMaxTokens);
-    ORAMA_REQUIRE(p->top_k <= kSelectMaxK, "top_k %u exceeds the supported maximum %u", p->top_k, kSelectMaxK);
+    ORAMA_SUPPORT(p->top_k <= kSelectMaxK, "top_k %u exceeds the supported maximum %u", p->top_k, kSelectMaxK);
     return ORAMA_OK;
 }
 
@@ -226,7 +227,7 @@ int post_stage1(orama_post* p, Scratch* sc, const orama_term_ref* refs, uint32_t
         max_rank = std::max(max_rank, rank[i] + 1);
         total_postings += p->list_off[refs[i].list + 1] - p->list_off[refs[i].list];
     }
-    ORAMA_REQUIRE(total_postings < 0xffffffffull, "query touches too many postings");
+    ORAMA_SUPPORT(total_postings < 0xffffffffull, "query touches too many postings");
     hipStream_t s = sc->stream;
     st->hybrid = hybrid;
     st->touched_cap = total_postings;  // one slot per posting (first touches hold the doc, the rest are empty)
@@ -454,7 +455,7 @@ int orama_post_build(orama_post* p, const uint64_t* docs, uint64_t n_docs, uint3
                      const uint32_t* post_len) {
     ORAMA_REQUIRE(p, "null handle");
     ORAMA_REQUIRE(n_docs == 0 || docs, "null docs");
-    ORAMA_REQUIRE(n_docs < 0xffffffffull, "postings store limited to 2^32-1 documents");
+    ORAMA_SUPPORT(n_docs < 0xffffffffull, "postings store limited to 2^32-1 documents");
     ORAMA_REQUIRE(n_fields == 0 || avg_field_len, "null avg_field_len");
     ORAMA_REQUIRE(n_lists == 0 || (field_of_list && list_off), "null list table");
     for (uint64_t i = 1; i < n_docs; ++i)
@@ -533,7 +534,7 @@ int orama_post_append(orama_post* p, const uint64_t* docs, uint64_t n_new, const
     ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
     std::unique_lock<std::shared_mutex> lk(p->mu);
     const uint64_t n_old = p->n_docs, n_all = n_old + n_new;
-    ORAMA_REQUIRE(n_all < 0xffffffffull, "postings store limited to 2^32-1 documents");
+    ORAMA_SUPPORT(n_all < 0xffffffffull, "postings store limited to 2^32-1 documents");
     const uint64_t last_old = n_old ? (p->dense ? p->dense_base + n_old - 1 : p->h_docs.back()) : 0;
     for (uint64_t i = 0; i < n_new; ++i) {
         ORAMA_REQUIRE((i == 0 && (n_old == 0 || docs[0] > last_old)) || (i > 0 && docs[i] > docs[i - 1]),
@@ -1050,7 +1051,8 @@ int orama_group_top(orama_scores* sm, orama_facet_field* f, uint32_t max_results
     ORAMA_TRY(check_field(sm, f, false));
     if (f->n_buckets == 0) return ORAMA_OK;
     ORAMA_REQUIRE(out_ids && out_scores && out_n, "null output");
-    ORAMA_REQUIRE(max_results >= 1 && max_results <= kGroupMaxK, "max_results %u outside [1, %u]", max_results, kGroupMaxK);
+    ORAMA_REQUIRE(max_results >= 1, "max_results is 0");
+    ORAMA_SUPPORT(max_results <= kGroupMaxK, "max_results %u outside [1, %u]", max_results, kGroupMaxK);
     ORAMA_HIP_TRY(hipSetDevice(sm->p->ctx->device));
     std::lock_guard<std::mutex> g(sm->mu);
     hipStream_t s = sm->lease.s->stream;
@@ -1199,7 +1201,7 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
     *out_n = 0;
     if (out_count) *out_count = 0;
     ORAMA_REQUIRE(params->top_k == 0 || (out_ids && out_scores), "null output");
-    ORAMA_REQUIRE(limit <= kSelectMaxK, "limit %u exceeds the supported maximum %u", limit, kSelectMaxK);
+    ORAMA_SUPPORT(limit <= kSelectMaxK, "limit %u exceeds the supported maximum %u", limit, kSelectMaxK);
     orama_ctx* ctx = p->ctx;
     ORAMA_REQUIRE(vec_ctx(v) == ctx, "vector store and postings store live on different contexts");
     ORAMA_HIP_TRY(hipSetDevice(ctx->device));
@@ -1338,7 +1340,7 @@ static int bm25_score_impl(orama_ctx* ctx, const orama_ntf_entry* entries, uint3
         }
     }
     const uint32_t n_pieces = (uint32_t)pieces.size();
-    ORAMA_REQUIRE(total < 0xffffffffull, "too many postings");
+    ORAMA_SUPPORT(total < 0xffffffffull, "too many postings");
     if (total == 0) return ORAMA_OK;
     // local doc space: identity when ids are reasonably dense (the reference assigns sequential u64
     // ids, write/collection_document_storage.rs:73-77), otherwise the sorted set of ids that occur.
@@ -1539,11 +1541,11 @@ int orama_hybrid_combine(orama_ctx* ctx, const uint64_t* vec_doc, const float* v
     ORAMA_REQUIRE(ctx && out_n, "null argument");
     *out_n = 0;
     if (out_count) *out_count = 0;
-    ORAMA_REQUIRE(top_k <= kSelectMaxK, "top_k %u exceeds the supported maximum %u", top_k, kSelectMaxK);
+    ORAMA_SUPPORT(top_k <= kSelectMaxK, "top_k %u exceeds the supported maximum %u", top_k, kSelectMaxK);
     ORAMA_REQUIRE(n_vec == 0 || (vec_doc && vec_score), "null vector map");
     ORAMA_REQUIRE(n_ft == 0 || (ft_doc && ft_score), "null fulltext map");
     ORAMA_REQUIRE(top_k == 0 || (out_ids && out_scores), "null output");
-    ORAMA_REQUIRE(n_vec + n_ft < 0xffffffffull, "maps too large");
+    ORAMA_SUPPORT(n_vec + n_ft < 0xffffffffull, "maps too large");
     if (n_vec + n_ft == 0) return ORAMA_OK;
     ORAMA_HIP_TRY(hipSetDevice(ctx->device));
     // local doc space = sorted union of both key sets
@@ -1609,8 +1611,8 @@ int orama_top_n(orama_ctx* ctx, const uint64_t* doc, const float* score, uint64_
     *out_n = 0;
     if (top_k == 0 || n == 0) return ORAMA_OK;
     ORAMA_REQUIRE(doc && score && out_ids && out_scores, "null argument");
-    ORAMA_REQUIRE(top_k <= kSelectMaxK, "top_k %u exceeds the supported maximum %u", top_k, kSelectMaxK);
-    ORAMA_REQUIRE(n < 0xffffffffull, "top_n limited to 2^32-1 entries");
+    ORAMA_SUPPORT(top_k <= kSelectMaxK, "top_k %u exceeds the supported maximum %u", top_k, kSelectMaxK);
+    ORAMA_SUPPORT(n < 0xffffffffull, "top_n limited to 2^32-1 entries");
     ORAMA_HIP_TRY(hipSetDevice(ctx->device));
     ScratchLease sc(ctx);
     ORAMA_TRY(sc.init());

@@ -466,7 +466,8 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
 }
 
 int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
-    ORAMA_REQUIRE(p.k >= 1 && p.k <= kSelectMaxK, "top-k: k=%u outside [1, %u]", p.k, kSelectMaxK);
+    ORAMA_REQUIRE(p.k >= 1, "top-k: k is 0");
+    ORAMA_SUPPORT(p.k <= kSelectMaxK, "top-k: k=%u outside [1, %u]", p.k, kSelectMaxK);
     ORAMA_REQUIRE(p.q >= 1 && p.vals && p.out_val, "top-k: bad plan");
     ProfScope prof(&ctx->prof, "topk_select", stream);
     if (p.n <= kSelectMaxK) {
@@ -503,7 +504,7 @@ int launch_merge_candidates(orama_ctx* ctx, const uint64_t* d_ids, const float* 
                             float* d_out_dist, uint32_t* d_out_n, hipStream_t stream) {
     (void)ctx;
     ORAMA_REQUIRE(lists >= 1 && q >= 1 && k >= 1, "merge: empty shape");
-    ORAMA_REQUIRE((uint64_t)lists * k <= kSelectMaxK, "merge: lists*k=%llu exceeds %u",
+    ORAMA_SUPPORT((uint64_t)lists * k <= kSelectMaxK, "merge: lists*k=%llu exceeds %u",
                   (unsigned long long)lists * k, kSelectMaxK);
     hipLaunchKernelGGL(merge_candidates_kernel, dim3(q), dim3(kSortThreads), 0, stream,
                        reinterpret_cast<const char*>(d_ids), (uint64_t)q * k * 8,
@@ -529,7 +530,7 @@ int launch_merge_blocks(orama_ctx* ctx, const void* d_blocks, uint64_t block_str
                         hipStream_t stream) {
     (void)ctx;
     ORAMA_REQUIRE(lists >= 1 && q >= 1 && k >= 1, "merge: empty shape");
-    ORAMA_REQUIRE((uint64_t)lists * k <= kSelectMaxK, "merge: lists*k=%llu exceeds %u",
+    ORAMA_SUPPORT((uint64_t)lists * k <= kSelectMaxK, "merge: lists*k=%llu exceeds %u",
                   (unsigned long long)lists * k, kSelectMaxK);
     ORAMA_REQUIRE(block_stride >= packed_block_bytes(q, k) && block_stride % 8 == 0, "merge: bad block stride");
     const char* base = reinterpret_cast<const char*>(d_blocks);

@@ -428,7 +428,7 @@ int orama_shard_vec_search(orama_shard_group* g, orama_vec* const* shards, const
     ORAMA_REQUIRE(queries && q >= 1 && out_ids && out_dist && out_n, "null argument");
     for (uint32_t j = 0; j < q; ++j) out_n[j] = 0;
     if (k == 0) return ORAMA_OK;
-    ORAMA_REQUIRE(k <= kSelectMaxK && (uint64_t)g->world * k <= kSelectMaxK, "limit %u x %d shards exceeds the merge capacity %u",
+    ORAMA_SUPPORT(k <= kSelectMaxK && (uint64_t)g->world * k <= kSelectMaxK, "limit %u x %d shards exceeds the merge capacity %u",
                   k, g->world, kSelectMaxK);
     std::lock_guard<std::mutex> lk(g->mu);
     const size_t nb = (size_t)packed_block_bytes(q, k);
@@ -489,9 +489,10 @@ int orama_shard_post_search(orama_shard_group* g, orama_post* const* shards, con
     if (out_count) *out_count = 0;
     const uint32_t k = params->top_k;
     ORAMA_REQUIRE(k >= 1 && (out_ids && out_scores), "sharded full-text search needs top_k >= 1 and output buffers");
-    ORAMA_REQUIRE((uint64_t)g->world * k <= kSelectMaxK, "top_k %u x %d shards exceeds the merge capacity %u", k, g->world,
+    ORAMA_SUPPORT((uint64_t)g->world * k <= kSelectMaxK, "top_k %u x %d shards exceeds the merge capacity %u", k, g->world,
                   kSelectMaxK);
-    ORAMA_REQUIRE(params->n_tokens >= 1 && params->n_tokens <= kMaxTokens, "n_tokens %u outside [1, %u]", params->n_tokens,
+    ORAMA_REQUIRE(params->n_tokens >= 1, "no query tokens");
+    ORAMA_SUPPORT(params->n_tokens <= kMaxTokens, "n_tokens %u outside [1, %u]", params->n_tokens,
                   kMaxTokens);
     ORAMA_REQUIRE(!hybrid || n_vec == 0 || (vec_doc && vec_score), "null vector map");
     std::lock_guard<std::mutex> lk(g->mu);
@@ -659,7 +660,7 @@ int orama_shard_session_create(orama_shard_group* g, orama_vec* const* shards, c
     ORAMA_TRY(check_group_args(g, shards));
     ORAMA_REQUIRE(queries && out && q_per_step >= 1 && n_queries >= q_per_step && k >= 1 && n_slots >= 1 && n_slots <= 8,
                   "bad session arguments");
-    ORAMA_REQUIRE(k <= kSelectMaxK && (uint64_t)g->world * k <= kSelectMaxK, "limit %u x %d shards exceeds the merge capacity", k,
+    ORAMA_SUPPORT(k <= kSelectMaxK && (uint64_t)g->world * k <= kSelectMaxK, "limit %u x %d shards exceeds the merge capacity", k,
                   g->world);
     *out = nullptr;
     std::unique_ptr<orama_shard_session> s(new (std::nothrow) orama_shard_session());

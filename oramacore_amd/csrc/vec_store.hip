@@ -284,7 +284,7 @@ bool grow_needs_move(orama_vec* v, uint64_t need_rows) {
 // partial tiles must read as zeros; zero = live).  Call with the exclusive lock held iff grow_needs_move().
 int grow(orama_vec* v, uint64_t need_rows, hipStream_t s) {
     if (need_rows <= v->cap_rows) return ORAMA_OK;
-    ORAMA_REQUIRE(need_rows < 0xfffffff0ull, "vector store limited to 2^32-16 rows");
+    ORAMA_SUPPORT(need_rows < 0xfffffff0ull, "vector store limited to 2^32-16 rows");
     uint64_t cap = need_rows;
     if (v->f16()) cap = (cap + 31) & ~31ull;
     const int dev = v->ctx->device;
@@ -655,7 +655,8 @@ int orama_vec_create(orama_ctx* ctx, uint32_t dim, int metric, int dtype, uint64
                      orama_vec** out) {
     ORAMA_REQUIRE(ctx && out, "null argument");
     *out = nullptr;
-    ORAMA_REQUIRE(dim >= 1 && dim <= 65536, "dimensions %u outside [1, 65536]", dim);
+    ORAMA_REQUIRE(dim >= 1, "dimensions is 0");
+    ORAMA_SUPPORT(dim <= 65536, "dimensions %u outside [1, 65536]", dim);
     ORAMA_REQUIRE(metric == ORAMA_METRIC_COSINE || metric == ORAMA_METRIC_L2SQ, "unknown metric %d", metric);
     ORAMA_REQUIRE(dtype == ORAMA_DTYPE_F32 || dtype == ORAMA_DTYPE_F16, "unknown dtype %d", dtype);
     if (dtype == ORAMA_DTYPE_F16 && dim > 2048) {
@@ -899,7 +900,7 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     ORAMA_REQUIRE(q >= 1 && queries && out_ids && out_dist && out_n, "null argument");
     for (uint32_t i = 0; i < q; ++i) out_n[i] = 0;
     if (k == 0) return ORAMA_OK;  // limit 0: empty result, like the reference's CappedHeap(0)
-    ORAMA_REQUIRE(k <= kSelectMaxK, "limit %u exceeds the supported maximum %u", k, kSelectMaxK);
+    ORAMA_SUPPORT(k <= kSelectMaxK, "limit %u exceeds the supported maximum %u", k, kSelectMaxK);
     ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
     std::shared_lock<std::shared_mutex> lk(v->mu);
     if (v->n_rows.load(std::memory_order_acquire) == 0) return ORAMA_OK;
@@ -937,7 +938,8 @@ int orama_vec_search_device(orama_vec* v, const float* d_queries, uint32_t q, ui
                             void* hip_stream) {
     ORAMA_REQUIRE(v, "null handle");
     ORAMA_REQUIRE(q >= 1 && d_queries && d_out_ids && d_out_dist && d_out_n, "null argument");
-    ORAMA_REQUIRE(k >= 1 && k <= kSelectMaxK, "limit %u outside [1, %u]", k, kSelectMaxK);
+    ORAMA_REQUIRE(k >= 1, "limit is 0");
+    ORAMA_SUPPORT(k <= kSelectMaxK, "limit %u outside [1, %u]", k, kSelectMaxK);
     ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
     hipStream_t s = (hipStream_t)hip_stream;
     std::shared_lock<std::shared_mutex> lk(v->mu);
@@ -956,7 +958,8 @@ int orama_vec_search_packed_device2(orama_vec* v, const float* d_queries, uint32
                                     uint32_t* d_out_n, void* scan_stream, void* tail_stream) {
     ORAMA_REQUIRE(v && d_packed_block, "null argument");
     ORAMA_REQUIRE(q >= 1 && d_queries && d_out_n, "null argument");
-    ORAMA_REQUIRE(k >= 1 && k <= kSelectMaxK, "limit %u outside [1, %u]", k, kSelectMaxK);
+    ORAMA_REQUIRE(k >= 1, "limit is 0");
+    ORAMA_SUPPORT(k <= kSelectMaxK, "limit %u outside [1, %u]", k, kSelectMaxK);
     ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
     hipStream_t s = (hipStream_t)tail_stream, ss = (hipStream_t)scan_stream;
     std::shared_lock<std::shared_mutex> lk(v->mu);

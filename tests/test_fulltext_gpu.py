@@ -229,6 +229,56 @@ def test_many_tokens_and_three_entries_per_token(ctx):
         assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
 
 
+def test_repeated_docs_inside_one_entry(ctx):
+    """BM25Scorer::add is a plain `+=` per call (bm25.rs:369-405): an entry may name the same document several times
+    (one field indexed through several locale buckets) and in any order.  Contributions add in entry order and df
+    counts the document once — compared bit for bit with the oracle, including the whole score map."""
+    rng = np.random.default_rng(11)
+    entries = []
+    n_tok = 3
+    for t in range(n_tok):
+        for _ in range(2):
+            docs = rng.integers(0, 60, size=200).astype(np.uint64) * np.uint64(7) + np.uint64(3)  # many repeats, unsorted
+            entries.append((t, docs, (rng.random(200).astype(np.float32) + np.float32(0.01)) * 2))
+    # a run of one doc only, and a doc that appears in every entry
+    entries.append((0, np.full(17, 3, dtype=np.uint64), rng.random(17).astype(np.float32)))
+    for thr in (None, 2, 3):
+        ids, sc, count = ft.bm25_score(ctx, entries, n_tok, 500.0, 40, thr)
+        od, os_, ocount = oracle_topk(entries, n_tok, 500, 40, thr)
+        assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_)), thr
+    full = ft.bm25_score_map(ctx, entries, n_tok, 500.0)
+    odocs, oscores = orc.search_full_text(entries, n_tok, 500.0, 1.2, None)
+    assert sorted(full) == odocs.tolist()
+    assert np.array_equal(bits([full[int(d)] for d in odocs]), bits(oscores))
+
+
+def test_rebuild_forgets_the_old_omc(ctx):
+    """A rebuilt store is a new index generation: multipliers set for the previous document table must not leak
+    into it (they were indexed by the OLD local document numbers)."""
+    docs1 = np.arange(100, dtype=np.uint64)
+    lens1 = np.full(100, 5)
+    store = ft.PostingsStore(ctx)
+    store.build(docs1, [5.0], [ft.PostingList(field=0, docs=docs1, tf=np.arange(1, 101), field_len=lens1)])
+    store.set_omc({99: 0.001, 98: 0.002})
+    ids, sc, _ = store.search([(0, 0, 1.0)], 1, 100.0, 3)
+    assert ids.tolist() == [97, 96, 95]  # 99 and 98 were pushed down
+    # rebuild with a different (larger, shifted) document table
+    docs2 = np.arange(1000, 1300, dtype=np.uint64)
+    tf2 = np.arange(1, 301)
+    lens2 = np.full(300, 9)
+    store.build(docs2, [9.0], [ft.PostingList(field=0, docs=docs2, tf=tf2, field_len=lens2)])
+    ntf = np.array([orc.bm25f_normalized_tf(int(t), 9, 9.0, 0.75) for t in tf2], dtype=np.float32)
+    od, os_, ocount = oracle_topk([(0, docs2, ntf)], 1, 300, 20)
+    ids, sc, count = store.search([(0, 0, 1.0)], 1, 300.0, 20, apply_omc=True)  # no OMC is set any more
+    assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
+    store.set_omc({1299: 0.5})
+    ids, sc, _ = store.search([(0, 0, 1.0)], 1, 300.0, 20)
+    os2 = orc.apply_omc(*orc.search_full_text([(0, docs2, ntf)], 1, 300.0, 1.2, None), [1299], [0.5])
+    td, ts = orc.top_n(docs2, os2, 20)
+    assert ids.tolist() == td.tolist() and np.array_equal(bits(sc), bits(ts))
+    store.close()
+
+
 # ----------------------------------------------------------------------------- hybrid
 @pytest.mark.parametrize("case", util.load_json("hybrid_kat.json")["cases"], ids=lambda c: c["name"])
 def test_hybrid_combine_golden(ctx, case):
