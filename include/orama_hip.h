@@ -33,7 +33,6 @@
  *     64-bit everywhere).  Vector dimensions <= 65536.
  *   - fp16 query batches: any q; 65..256 queries share one corpus pass, larger batches run in
  *     passes of 256.
- *   - facet ranges: <= 64 ranges per orama_facet_count_ranges call.
  */
 #ifndef ORAMA_HIP_H
 #define ORAMA_HIP_H
@@ -87,10 +86,15 @@ int orama_ctx_set_f16_tuning(orama_ctx* ctx, int ksteps_per_chunk, int ring_chun
 /* Kernel used for fp16 batches of 65..256 queries per corpus pass: 0 = K2 in passes of 64, 1 = K2c (MFMA waves also
  * issue the LDS-DMA), 2 / 3 = K2d producer/consumer kernel, geometry 1 / 2 (vec_f16_pc.hip).  Default 2. */
 int orama_ctx_set_f16_wide(orama_ctx* ctx, int mode);
+/* Scorer of the plain (non-hybrid, top-k) BM25 search over a resident store: 1 (default) = K3r, the document-range
+ * partitioned scorer that takes whole query batches per launch (bm25_ranges.hip); 0 = K3, per-document records in HBM
+ * (bm25_kernels.hip), which the hybrid / score-map / precomputed-ntf entry points always use.  Same results bit for bit. */
+int orama_ctx_set_bm25_ranges(orama_ctx* ctx, int on);
 
 /* Per-kernel HIP-event timing (used by bench.py's roofline leg).  When enabled, the library
  * brackets each launch of the named hot kernels with hipEvents on the launching stream.
- * kernels: "vec_scan_f32", "vec_scan_f16", "topk_select", "bm25_accumulate", "bm25_finalize". */
+ * kernels: "vec_scan_f32", "vec_scan_f16", "topk_select", "bm25_accumulate", "bm25_finalize",
+ * "bm25_range_bounds", "bm25_range_df", "bm25_range_score". */
 int orama_prof_enable(orama_ctx* ctx, int on);
 int orama_prof_reset(orama_ctx* ctx);
 int orama_prof_get(orama_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);

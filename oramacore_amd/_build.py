@@ -34,7 +34,7 @@ COMMON_FLAGS = [
 ]
 # Translation units whose f32 arithmetic must round exactly like the scalar reference
 # (BM25F scores must be bit-identical to the scalar f32 evaluation): no FMA contraction.
-EXACT_FP = {"fulltext.hip", "bm25_kernels.hip"}
+EXACT_FP = {"fulltext.hip", "bm25_kernels.hip", "bm25_ranges.hip"}
 
 
 def _hipcc() -> str:

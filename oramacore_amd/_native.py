@@ -125,6 +125,7 @@ def _declare(lib: C.CDLL) -> None:
         "orama_ctx_set_scan_tuning": [vp, C.c_int, C.c_int, C.c_int],
         "orama_ctx_set_f16_tuning": [vp, C.c_int, C.c_int],
         "orama_ctx_set_f16_wide": [vp, C.c_int],
+        "orama_ctx_set_bm25_ranges": [vp, C.c_int],
         "orama_prof_enable": [vp, C.c_int],
         "orama_prof_reset": [vp],
         "orama_prof_get": [vp, C.c_char_p, C.POINTER(C.c_double), u64p],

@@ -53,6 +53,10 @@ class Context:
     def set_f16_tuning(self, ksteps_per_chunk: int, ring_chunks: int) -> None:
         N.check(self._lib.orama_ctx_set_f16_tuning(self.handle, ksteps_per_chunk, ring_chunks))
 
+    def set_bm25_ranges(self, on: bool) -> None:
+        """Plain BM25 top-k searches: True = K3r range-partitioned batch scorer (default), False = K3 per-document records."""
+        N.check(self._lib.orama_ctx_set_bm25_ranges(self.handle, 1 if on else 0))
+
     def set_f16_wide(self, mode: int) -> None:
         """0 = K2 passes of 64, 1 = K2c, 2 / 3 = K2d geometry 1 / 2 (orama_ctx_set_f16_wide)."""
         N.check(self._lib.orama_ctx_set_f16_wide(self.handle, int(mode)))

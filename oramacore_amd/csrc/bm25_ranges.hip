@@ -1,0 +1,289 @@
+// bm25_ranges.hip — K3r: BM25F over resident postings, partitioned by document range, batched over queries.
+//
+// K3 (bm25_kernels.hip) scatters every posting into a per-document record in HBM (random 64-byte read-modify-writes
+// into a table of n_docs records) and walks the records again to finalise: ~130 B of random HBM traffic per posting
+// and ~20 small launches per query.  Posting lists are sorted by document (orama_post_build checks it), so the
+// union of a query's lists is a k-way merge, and a merge can be cut anywhere in DOCUMENT space:
+//
+//   range_bounds_kernel   one thread per referenced posting: where does each list cross the range boundaries
+//                         (range = 2^log_r consecutive local documents, log_r chosen per query so that a range
+//                         holds ~512 postings on average).  bounds[list][r] = postings of the list in ranges < r.
+//   range_score_kernel    one workgroup per (range, query): gathers the <= 2048 postings of its range from the
+//                         lists (coalesced: each list contributes one contiguous run), computes the normalised tf,
+//                         sorts (document, token, list rank | ntf) keys in LDS, and the first thread of every
+//                         document walks its run IN ORDER — lists of a token in reference order, tokens ascending —
+//                         exactly the additions BM25Scorer::add / get_scores perform (bm25.rs:369-428), so scores
+//                         are bit-identical to K3 and to the CPU restatement.  Output: one 64-bit key
+//                         ordered(score) << 32 | ~document per scored document, at the slot of its first posting
+//                         (slot base of a range = sum of its bounds: no cursor, no atomics), 0 elsewhere.
+//   launch_keys_topk      (select.hip) exact top-k over the key lists of the whole batch.
+//
+// HBM traffic: 8 B per posting read twice (bounds, score) + 8 B per posting written and read once by the top-k.
+// Nothing is sized by n_docs: a query needs 8 B per referenced posting of scratch instead of K3's 136 B per
+// document of the index.  df (token_score.rs:262-275): known on the host when no filter applies and every token has
+// one list; otherwise the same kernel runs once in counting mode first.
+// A range that holds more than 2048 postings (documents of a term clustered in id space) raises the query's
+// `overflow` flag; the host reruns that query with 8x smaller ranges (always terminates: a range of one document
+// holds at most one posting per list).
+//
+// Compiled with -ffp-contract=off (see bm25_kernels.hip).
+#include "bm25_ranges.hpp"
+
+#include "device_utils.hpp"
+
+namespace orama {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr unsigned long long kDropped = ~0ull;
+
+__device__ __forceinline__ bool f32_is_normal(float x) {
+    const uint32_t e = (__builtin_bit_cast(uint32_t, x) >> 23) & 0xffu;
+    return e != 0u && e != 0xffu;
+}
+
+__device__ __forceinline__ uint32_t seg_of(const RangeSeg* __restrict__ segs, uint32_t lo, uint32_t hi, uint64_t v) {
+    while (hi - lo > 1) {  // last seg with virt_begin <= v
+        const uint32_t mid = (lo + hi) >> 1;
+        if (segs[mid].virt_begin <= v) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kThreads) void range_bounds_kernel(RangeBatch b) {
+    __shared__ uint32_t s_first, s_last;
+    const uint64_t v0 = (uint64_t)blockIdx.x * kThreads;
+    if (threadIdx.x < 2) {
+        const uint64_t v = threadIdx.x ? min(v0 + kThreads - 1, b.total_virt - 1) : v0;
+        const uint32_t s = seg_of(b.segs, 0, b.n_segs, v);
+        if (threadIdx.x) s_last = s; else s_first = s;
+    }
+    __syncthreads();
+    const uint64_t v = v0 + threadIdx.x;
+    if (v >= b.total_virt) return;
+    const uint32_t si = seg_of(b.segs, s_first, s_last + 1, v);
+    const RangeSeg sg = b.segs[si];
+    const uint32_t j = (uint32_t)(v - sg.virt_begin);
+    const uint32_t* pd = b.post_doc + sg.post_begin;
+    const uint32_t r = pd[j] >> sg.log_r;
+    uint32_t* row = b.bounds + sg.bounds_off;
+    // entries (prev_r, r] start at this posting; the first posting also covers the ranges before it
+    uint32_t from = j ? (pd[j - 1] >> sg.log_r) + 1 : 0;
+    for (uint32_t rr = from; rr <= r; ++rr) row[rr] = j;
+    if (j == sg.len - 1)
+        for (uint32_t rr = r + 1; rr <= sg.n_ranges; ++rr) row[rr] = sg.len;
+}
+
+// key layout of the in-range sort: [local doc:16 | token:6 | rank:10 | ntf bits:32]
+__device__ __forceinline__ uint32_t key_doc(unsigned long long k) { return (uint32_t)(k >> 48); }
+__device__ __forceinline__ uint32_t key_tok(unsigned long long k) { return (uint32_t)(k >> 42) & 63u; }
+
+template <bool DF_ONLY>
+__global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
+    __shared__ unsigned long long s[kRangeCap];
+    __shared__ uint32_t seg_b0[kRangeMaxRefs];   // first posting of each reference inside this range
+    __shared__ uint32_t seg_off[kRangeMaxRefs + 1];
+    __shared__ float idf[kMaxTokens];
+    __shared__ uint32_t df_lds[kMaxTokens];
+    __shared__ uint32_t red[2];
+
+    const uint32_t qi = blockIdx.y;
+    const RangeQuery q = b.queries[qi];
+    const uint32_t r = blockIdx.x;
+    if (r >= q.n_ranges) return;
+    if (DF_ONLY && !q.want_df) return;
+    const uint32_t ns = q.seg_end - q.seg_begin;
+    const RangeSeg* segs = b.segs + q.seg_begin;
+
+    if (threadIdx.x < 2) red[threadIdx.x] = 0;
+    for (uint32_t t = threadIdx.x; t < kMaxTokens; t += kThreads) {
+        df_lds[t] = 0;
+        if (!DF_ONLY) idf[t] = t < q.n_tokens ? b.idf[(size_t)qi * kMaxTokens + t] : 0.0f;
+    }
+    __syncthreads();
+    // this range's run of every reference; slot base = postings of the query in earlier ranges
+    uint32_t base_part = 0;
+    for (uint32_t i = threadIdx.x; i < ns; i += kThreads) {
+        const uint32_t* row = b.bounds + segs[i].bounds_off;
+        const uint32_t b0 = row[r], b1 = row[r + 1];
+        seg_b0[i] = b0;
+        seg_off[i + 1] = b1 - b0;
+        base_part += b0;
+    }
+    base_part = wave_sum_u32(base_part);
+    if ((threadIdx.x & 63) == 0 && base_part) atomicAdd(&red[0], base_part);
+    __syncthreads();
+    if (threadIdx.x < 64) {  // inclusive scan of the run lengths by one wave, 64 references at a time
+        uint32_t carry = 0;
+        for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
+            const uint32_t i = i0 + threadIdx.x;
+            uint32_t x = i < ns ? seg_off[i + 1] : 0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y = __shfl_up(x, off, 64);
+                if ((int)threadIdx.x >= off) x += y;
+            }
+            if (i < ns) seg_off[i + 1] = carry + x;
+            carry += __shfl(x, 63, 64);
+        }
+        if (threadIdx.x == 0) seg_off[0] = 0;
+    }
+    __syncthreads();
+    const uint32_t cap = seg_off[ns];
+    if (cap == 0) return;
+    const uint32_t slot_base = red[0];
+    if (cap > kRangeCap) {
+        // the query is rerun with smaller ranges; its slots still reach the batch's top-k, so they must be empty
+        if (!DF_ONLY)
+            for (uint32_t e = threadIdx.x; e < cap; e += kThreads) b.keys[q.key_off + slot_base + e] = 0ull;
+        if (threadIdx.x == 0) b.results[qi].overflow = 1;
+        return;
+    }
+    uint32_t p2 = 2;
+    while (p2 < cap) p2 <<= 1;
+
+    // gather: element e belongs to the reference whose [seg_off[i], seg_off[i+1]) holds it
+    const float one_minus_b = 1.0f - b.b;
+    const uint32_t doc0 = r << q.log_r;
+    for (uint32_t e = threadIdx.x; e < p2; e += kThreads) {
+        unsigned long long key = kDropped;
+        if (e < cap) {
+            uint32_t lo = 0, hi = ns;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (seg_off[mid] <= e) lo = mid; else hi = mid;
+            }
+            const RangeSeg& sg = segs[lo];
+            const uint64_t p = sg.post_begin + seg_b0[lo] + (e - seg_off[lo]);
+            const uint32_t doc = b.post_doc[p];
+            bool keep = true;
+            if (b.allow) {  // collect_contributions_with_filter: filtered docs never reach the scorer
+                const uint64_t id = b.docs[doc];
+                keep = id < b.allow_bits && ((b.allow[id >> 6] >> (id & 63)) & 1ull);
+            }
+            if (keep) {
+                uint32_t ntf_bits = 0;
+                if (!DF_ONLY) {
+                    const uint32_t val = b.post_val[p];
+                    const float tf = (float)(val >> 16);
+                    const float len = (float)(val & 0xffffu);
+                    const float ntf = sg.boost * (tf / (one_minus_b + b.b * (len / sg.avg_len)));
+                    ntf_bits = __builtin_bit_cast(uint32_t, ntf);
+                }
+                key = ((unsigned long long)(((doc - doc0) << 16) | sg.tok_rank) << 32) | ntf_bits;
+            }
+        }
+        s[e] = key;
+    }
+    __syncthreads();
+    // bitonic sort, ascending on the whole 64-bit key ((doc, token, rank) is unique among the kept postings)
+    for (uint32_t size = 2; size <= p2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (p2 >> 1); t += kThreads) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long x = s[lo], y = s[hi];
+                if ((x > y) == up) {
+                    s[lo] = y;
+                    s[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    if (DF_ONLY) {
+        // corpus_docs.len(): distinct (token, document) pairs (token_score.rs:262-275)
+        for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
+            const unsigned long long key = s[e];
+            if (key == kDropped) continue;
+            if (e == 0 || (s[e - 1] >> 42) != (key >> 42)) atomicAdd(&df_lds[key_tok(key)], 1u);
+        }
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < q.n_tokens; t += kThreads)
+            if (df_lds[t]) atomicAdd(&b.results[qi].df[t], df_lds[t]);
+        return;
+    }
+
+    const float k1 = q.k + 1.0f;
+    unsigned long long* out = b.keys + q.key_off + slot_base;
+    uint32_t my_count = 0;
+    for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
+        const unsigned long long key = s[e];
+        unsigned long long out_key = 0ull;
+        if (key != kDropped && (e == 0 || key_doc(s[e - 1]) != key_doc(key))) {
+            // first posting of a document: fold its run
+            const uint32_t dl = key_doc(key);
+            float score = 0.0f;  // entry(key).or_insert(0.0)
+            uint32_t mask = 0u;
+            bool applied = false;
+            uint32_t tok = key_tok(key);
+            float sum = 0.0f;
+            uint32_t j = e;
+            unsigned long long kj = key;
+            for (;;) {
+                sum = sum + 1.0f * __builtin_bit_cast(float, (uint32_t)kj);  // Iterator::sum() from 0.0, weight 1.0
+                ++j;
+                bool more = false;
+                uint32_t ntok = tok;
+                if (j < cap) {
+                    kj = s[j];
+                    more = kj != kDropped && key_doc(kj) == dl;
+                    if (more) ntok = key_tok(kj);
+                }
+                if (!more || ntok != tok) {  // close the token
+                    if (f32_is_normal(sum)) {
+                        const float term = idf[tok] * k1 * sum / (q.k + sum);  // bm25f_score, bm25.rs:124-126
+                        if (term == term) {
+                            score = score + term * 1.0f;  // phrase boost 1.0
+                            mask |= 1u << (tok & 31u);    // 1 << term_index on u32 (wrapping shift)
+                            applied = true;
+                        }
+                    }
+                    sum = 0.0f;
+                    tok = ntok;
+                }
+                if (!more) break;
+            }
+            if (applied && !(q.use_threshold && (uint32_t)__popc(mask) < q.threshold)) {
+                const uint32_t doc = doc0 + dl;
+                if (b.omc_dense) score = score * b.omc_dense[doc];
+                ++my_count;
+                if (score == score)  // a NaN score stays in the map (count) and is never selected
+                    out_key = ((unsigned long long)f32_to_ordered(score) << 32) | (unsigned long long)(~doc);
+            }
+        }
+        out[e] = out_key;
+    }
+    my_count = wave_sum_u32(my_count);
+    if ((threadIdx.x & 63) == 0 && my_count) atomicAdd(&red[1], my_count);
+    __syncthreads();
+    if (threadIdx.x == 0 && red[1]) atomicAdd(&b.results[qi].count, red[1]);
+}
+
+}  // namespace
+
+int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream) {
+    if (b.total_virt == 0) return ORAMA_OK;
+    ProfScope prof(&ctx->prof, "bm25_range_bounds", stream);
+    const uint64_t blocks = (b.total_virt + kThreads - 1) / kThreads;
+    ORAMA_SUPPORT(blocks < 0x7fffffffull, "bm25 ranges: batch references too many postings");
+    hipLaunchKernelGGL(range_bounds_kernel, dim3((uint32_t)blocks), dim3(kThreads), 0, stream, b);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStream_t stream) {
+    if (b.total_virt == 0 || b.n_queries == 0 || b.max_ranges == 0) return ORAMA_OK;
+    ORAMA_REQUIRE(b.n_queries <= 65535, "bm25 ranges: batch too large");
+    ProfScope prof(&ctx->prof, df_only ? "bm25_range_df" : "bm25_range_score", stream);
+    const dim3 grid(b.max_ranges, b.n_queries);
+    if (df_only) hipLaunchKernelGGL(range_score_kernel<true>, grid, dim3(kThreads), 0, stream, b);
+    else hipLaunchKernelGGL(range_score_kernel<false>, grid, dim3(kThreads), 0, stream, b);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+}  // namespace orama

@@ -1,0 +1,75 @@
+// bm25_ranges.hpp — K3r: BM25F over resident postings by DOCUMENT RANGE, for whole batches of queries.
+// Same arithmetic as K3 (bm25_kernels.hip), different data movement: see bm25_ranges.hip.
+//   src/collection_manager/sides/read/index/token_score.rs:257-302, src/collection_manager/bm25.rs:369-428
+#pragma once
+
+#include "bm25_kernels.hpp"
+
+namespace orama {
+
+constexpr uint32_t kRangeCap = 2048;     // postings one workgroup merges (LDS sort size)
+constexpr uint32_t kRangeMaxLogR = 15;   // documents per range <= 32768 (local document in 16 key bits; 0xffff.. = dropped)
+constexpr uint32_t kRangeMaxRefs = 1024; // non-empty posting lists per query (10-bit list rank in the sort key)
+
+// One (token, posting list) reference of one query of the batch.
+struct RangeSeg {
+    uint64_t post_begin;  // first posting of the list inside the postings arrays
+    uint64_t virt_begin;  // first virtual posting of this reference inside the batch (bounds kernel)
+    uint64_t bounds_off;  // first entry of this reference's bounds row (n_ranges + 1 entries)
+    uint32_t len;
+    uint32_t query;       // index of the query inside the batch
+    uint32_t tok_rank;    // token << 10 | rank (position of the list among the token's lists)
+    uint32_t log_r;       // of its query
+    uint32_t n_ranges;    // of its query
+    float boost;
+    float avg_len;
+    uint32_t pad;
+};
+
+struct RangeQuery {
+    uint64_t key_off;     // first slot of this query in the key buffer (one slot per referenced posting)
+    uint32_t seg_begin, seg_end;
+    uint32_t log_r;       // a range = 2^log_r consecutive local documents
+    uint32_t n_ranges;
+    uint32_t n_tokens;
+    uint32_t use_threshold, threshold;
+    float k;
+    uint32_t want_df;     // count df on the device (filter, or a token with several lists)
+    uint32_t pad;
+};
+
+// Per-query result words (device): 128 bytes apart so that the per-workgroup atomics of different queries and of
+// different quantities never share a cache line.
+struct RangeResult {
+    uint32_t count;       // documents in the score map
+    uint32_t pad0[31];
+    uint32_t overflow;    // a range held more than kRangeCap postings: rerun with smaller ranges
+    uint32_t pad1[31];
+    uint32_t df[kMaxTokens];
+};
+
+struct RangeBatch {
+    const RangeSeg* segs = nullptr;      // sorted by virt_begin
+    const RangeQuery* queries = nullptr;
+    uint32_t n_segs = 0, n_queries = 0;
+    uint64_t total_virt = 0;
+    uint32_t max_ranges = 0;             // grid.x of the scoring launch
+    const uint32_t* post_doc = nullptr;
+    const uint32_t* post_val = nullptr;
+    uint32_t* bounds = nullptr;
+    const uint64_t* docs = nullptr;      // local idx -> DocumentId (filter)
+    const uint64_t* allow = nullptr;
+    uint64_t allow_bits = 0;
+    float b = 0.75f;
+    const float* idf = nullptr;          // [n_queries][kMaxTokens]
+    const float* omc_dense = nullptr;
+    unsigned long long* keys = nullptr;  // ordered(score) << 32 | ~local doc; 0 = empty
+    RangeResult* results = nullptr;
+};
+
+// bounds[seg][r] = postings of the reference whose document lies in a range < r.
+int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream);
+// df_only: count distinct (token, document) pairs into results[q].df for the queries that want it.
+int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStream_t stream);
+
+}  // namespace orama

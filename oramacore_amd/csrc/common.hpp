@@ -192,6 +192,9 @@ struct orama_ctx {
     // fp16 batches of 65..256 queries share one corpus pass: 2 = K2d (dedicated loader waves, default), 3 = K2d second
     // geometry, 1 = K2c (round 1: MFMA waves issue the DMA), 0 = K2 in passes of 64 (ORAMA_F16_WIDE)
     int f16_wide = 2;
+    // plain BM25 top-k searches of a resident store use the range-partitioned scorer (K3r, bm25_ranges.hip);
+    // 0 = always the per-document-record scorer K3 (ORAMA_BM25_RANGES, orama_ctx_set_bm25_ranges)
+    int bm25_ranges = 1;
     int f16_kc = 8, f16_nbuf = 3;   // K2 register ring: k-steps per chunk, chunks (ORAMA_F16_KC / ORAMA_F16_NBUF)
     int compute_units = 0;
     uint64_t hbm_bytes = 0;

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "bm25_kernels.hpp"
+#include "bm25_ranges.hpp"
 #include "common.hpp"
 #include "select.hpp"
 #include "vec_internal.hpp"
@@ -406,6 +407,252 @@ int post_stage2(orama_post* p, Scratch* sc, const PostQuery& st, const orama_bm2
                                out_ids, out_scores, out_n, out_count);
 }
 
+// ---------------------------------------------------------------- K3r: range-partitioned scoring of query batches
+struct RangeJob {
+    const orama_term_ref* refs;
+    uint32_t n_refs;
+    const orama_bm25_params* params;
+    uint64_t* out_ids;
+    float* out_scores;
+    uint32_t* out_n;
+    uint64_t* out_count;
+};
+
+constexpr uint32_t kRangeBatchMax = 32;             // queries scored by one set of launches
+constexpr uint64_t kRangeKeyBudget = 1ull << 28;    // key slots (8 B each) one set of launches may use
+
+// The plain top-k search of the resident store can take the K3r path when its references fit the sort key.
+bool ranges_eligible(const orama_post* p, const orama_term_ref* refs, uint32_t n_refs, const orama_bm25_params* params) {
+    if (!p->ctx->bm25_ranges || !params || params->n_tokens < 1 || params->n_tokens > kMaxTokens) return false;
+    uint32_t nonempty = 0;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        if (refs[i].list >= p->n_lists) return false;  // the ordinary path reports the error
+        const uint64_t len = p->list_off[refs[i].list + 1] - p->list_off[refs[i].list];
+        nonempty += len != 0;
+        total += len;
+    }
+    return nonempty <= kRangeMaxRefs && total < 0x7fffffffull;
+}
+
+// log2 of the documents per range: ~512 postings per range on average, `shrink` times 8x smaller after an overflow.
+uint32_t choose_log_r(uint64_t n_docs, uint64_t total_postings, uint32_t shrink) {
+    uint32_t lr = 0;
+    while (lr < kRangeMaxLogR && ((uint64_t)2 << lr) * total_postings <= n_docs * 512ull) ++lr;
+    // at least two ranges per compute unit's worth of work is pointless for tiny stores: one range may hold them all
+    return lr > 3 * shrink ? lr - 3 * shrink : 0;
+}
+
+// Score `n_jobs` eligible queries (each validated by check_params and ranges_eligible) on sc->stream; synchronises.
+int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_t n_jobs, float b,
+                       const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc) {
+    hipStream_t s = sc->stream;
+    const uint64_t* d_allow = nullptr;
+    ORAMA_TRY(resolve_allow(p->ctx, sc, allow_bitmap, bitmap_bits, s, &d_allow));
+    struct Pending {
+        uint32_t job;
+        uint32_t shrink;
+        uint64_t total;
+    };
+    std::vector<Pending> pending;
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        const RangeJob& jb = jobs[j];
+        *jb.out_n = 0;
+        if (jb.out_count) *jb.out_count = 0;
+        ORAMA_REQUIRE(jb.params->top_k == 0 || (jb.out_ids && jb.out_scores), "null output");
+        ORAMA_REQUIRE(jb.n_refs == 0 || jb.refs, "null refs");
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < jb.n_refs; ++i) {
+            ORAMA_REQUIRE(jb.refs[i].token < jb.params->n_tokens, "ref %u: token %u >= n_tokens %u", i, jb.refs[i].token,
+                          jb.params->n_tokens);
+            ORAMA_REQUIRE(jb.refs[i].list < p->n_lists, "ref %u: list %u out of range", i, jb.refs[i].list);
+            total += p->list_off[jb.refs[i].list + 1] - p->list_off[jb.refs[i].list];
+        }
+        if (total) pending.push_back({j, 0u, total});
+    }
+    ORAMA_REQUIRE(p->n_docs > 0 || pending.empty(), "postings store is empty (orama_post_build not called)");
+
+    std::vector<RangeSeg> segs;
+    std::vector<RangeQuery> queries;
+    std::vector<uint32_t> lens, chunk;
+    while (!pending.empty()) {
+        // next chunk: up to kRangeBatchMax queries whose padded key lists fit the budget
+        chunk.clear();
+        uint64_t max_total = 0;
+        uint32_t kmax = 0;
+        for (uint32_t i = 0; i < pending.size() && chunk.size() < kRangeBatchMax; ++i) {
+            const uint64_t mt = std::max(max_total, pending[i].total);
+            if (!chunk.empty() && mt * (chunk.size() + 1) > kRangeKeyBudget) break;
+            max_total = mt;
+            kmax = std::max(kmax, jobs[pending[i].job].params->top_k);
+            chunk.push_back(i);
+        }
+        const uint32_t nq = (uint32_t)chunk.size();
+        segs.clear();
+        queries.assign(nq, RangeQuery{});
+        lens.assign(nq, 0);
+        uint64_t virt = 0, bounds_entries = 0;
+        uint32_t max_ranges = 0;
+        bool any_df = false;
+        ORAMA_TRY(sc->h_misc.reserve((size_t)nq * kMaxTokens * 4 + 64));
+        float* h_idf = sc->h_misc.as<float>();
+        for (uint32_t c = 0; c < nq; ++c) {
+            const Pending& pd = pending[chunk[c]];
+            const RangeJob& jb = jobs[pd.job];
+            RangeQuery& q = queries[c];
+            q.key_off = (uint64_t)c * max_total;
+            q.seg_begin = (uint32_t)segs.size();
+            q.log_r = choose_log_r(p->n_docs, pd.total, pd.shrink);
+            q.n_ranges = (uint32_t)(((p->n_docs - 1) >> q.log_r) + 1);
+            q.n_tokens = jb.params->n_tokens;
+            q.use_threshold = jb.params->use_threshold != 0;
+            q.threshold = jb.params->threshold;
+            q.k = jb.params->k;
+            lens[c] = (uint32_t)pd.total;
+            max_ranges = std::max(max_ranges, q.n_ranges);
+            uint32_t per_token[kMaxTokens] = {0}, df[kMaxTokens] = {0};
+            bool df_known = d_allow == nullptr;
+            // references in (token, reference order): the rank of a list among its token's lists is its position
+            for (uint32_t t = 0; t < q.n_tokens; ++t) {
+                for (uint32_t i = 0; i < jb.n_refs; ++i) {
+                    if (jb.refs[i].token != t) continue;
+                    const uint32_t l = jb.refs[i].list;
+                    const uint32_t len = (uint32_t)(p->list_off[l + 1] - p->list_off[l]);
+                    if (len == 0) continue;
+                    RangeSeg g{};
+                    g.post_begin = p->list_off[l];
+                    g.virt_begin = virt;
+                    g.bounds_off = bounds_entries;
+                    g.len = len;
+                    g.query = c;
+                    g.tok_rank = (t << 10) | per_token[t];
+                    g.log_r = q.log_r;
+                    g.n_ranges = q.n_ranges;
+                    g.boost = jb.refs[i].boost;
+                    g.avg_len = p->avg_len[p->field_of_list[l]];
+                    virt += len;
+                    bounds_entries += (uint64_t)q.n_ranges + 1;
+                    segs.push_back(g);
+                    if (++per_token[t] > 1) df_known = false;
+                    df[t] += len;
+                }
+            }
+            q.seg_end = (uint32_t)segs.size();
+            q.want_df = df_known ? 0u : 1u;
+            any_df |= !df_known;
+            // idf per token by the host libm (calculate_idf, bm25.rs:78-82; df.max(1), token_score.rs:275)
+            for (uint32_t t = 0; t < kMaxTokens; ++t) {
+                const float d = (float)(df[t] < 1 ? 1u : df[t]);
+                h_idf[(size_t)c * kMaxTokens + t] =
+                    t < q.n_tokens ? log1pf((jb.params->total_documents - d + 0.5f) / (d + 0.5f)) : 0.0f;
+            }
+        }
+        ORAMA_SUPPORT(virt < 0xffffffffull && bounds_entries < 0xffffffffull, "query batch references too many postings");
+        // device tables: [segs | queries | idf | list lengths]
+        const size_t seg_bytes = (segs.size() * sizeof(RangeSeg) + 63) & ~(size_t)63;
+        const size_t q_bytes = ((size_t)nq * sizeof(RangeQuery) + 63) & ~(size_t)63;
+        const size_t idf_bytes = (size_t)nq * kMaxTokens * 4;
+        const size_t len_bytes = ((size_t)nq * 4 + 63) & ~(size_t)63;
+        ORAMA_TRY(sc->h_in.reserve(seg_bytes + q_bytes + idf_bytes + len_bytes));
+        char* h = sc->h_in.as<char>();
+        memcpy(h, segs.data(), segs.size() * sizeof(RangeSeg));
+        memcpy(h + seg_bytes, queries.data(), (size_t)nq * sizeof(RangeQuery));
+        memcpy(h + seg_bytes + q_bytes, h_idf, idf_bytes);
+        memcpy(h + seg_bytes + q_bytes + idf_bytes, lens.data(), (size_t)nq * 4);
+        ORAMA_TRY(sc->misc0.reserve(seg_bytes + q_bytes + idf_bytes + len_bytes));
+        ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, h, seg_bytes + q_bytes + idf_bytes + len_bytes, hipMemcpyHostToDevice, s));
+        ORAMA_TRY(sc->misc1.reserve((size_t)bounds_entries * 4));
+        ORAMA_TRY(sc->misc2.reserve((size_t)nq * sizeof(RangeResult)));
+        ORAMA_TRY(sc->misc3.reserve((size_t)nq * max_total * 8));
+        ORAMA_HIP_TRY(hipMemsetAsync(sc->misc2.p, 0, (size_t)nq * sizeof(RangeResult), s));
+        char* d = sc->misc0.as<char>();
+        float* d_idf = reinterpret_cast<float*>(d + seg_bytes + q_bytes);
+        RangeBatch rb;
+        rb.segs = reinterpret_cast<const RangeSeg*>(d);
+        rb.queries = reinterpret_cast<const RangeQuery*>(d + seg_bytes);
+        rb.n_segs = (uint32_t)segs.size();
+        rb.n_queries = nq;
+        rb.total_virt = virt;
+        rb.max_ranges = max_ranges;
+        rb.post_doc = p->d_post_doc.as<uint32_t>();
+        rb.post_val = p->d_post_val.as<uint32_t>();
+        rb.bounds = sc->misc1.as<uint32_t>();
+        rb.docs = p->d_docs.as<uint64_t>();
+        rb.allow = d_allow;
+        rb.allow_bits = bitmap_bits;
+        rb.b = b;
+        rb.idf = d_idf;
+        rb.omc_dense = (apply_omc && p->has_omc) ? p->d_omc.as<float>() : nullptr;
+        rb.keys = sc->misc3.as<unsigned long long>();
+        rb.results = sc->misc2.as<RangeResult>();
+        ORAMA_TRY(launch_range_bounds(p->ctx, rb, s));
+        ORAMA_TRY(sc->h_out.reserve((size_t)nq * sizeof(RangeResult) + (size_t)nq * std::max(kmax, 1u) * 12 + (size_t)nq * 4 + 64));
+        RangeResult* h_res = sc->h_out.as<RangeResult>();
+        if (any_df) {
+            // df counted on the device (filter, or tokens with several lists): one read-back, then idf by the host libm
+            ORAMA_TRY(launch_range_score(p->ctx, rb, true, s));
+            ORAMA_HIP_TRY(hipMemcpyAsync(h_res, sc->misc2.p, (size_t)nq * sizeof(RangeResult), hipMemcpyDeviceToHost, s));
+            ORAMA_HIP_TRY(hipStreamSynchronize(s));
+            for (uint32_t c = 0; c < nq; ++c) {
+                if (!queries[c].want_df) continue;
+                const orama_bm25_params* pr = jobs[pending[chunk[c]].job].params;
+                for (uint32_t t = 0; t < queries[c].n_tokens; ++t) {
+                    const float dd = (float)(h_res[c].df[t] < 1 ? 1u : h_res[c].df[t]);
+                    h_idf[(size_t)c * kMaxTokens + t] = log1pf((pr->total_documents - dd + 0.5f) / (dd + 0.5f));
+                }
+            }
+            ORAMA_HIP_TRY(hipMemcpyAsync(d_idf, h_idf, idf_bytes, hipMemcpyHostToDevice, s));
+        }
+        ORAMA_TRY(launch_range_score(p->ctx, rb, false, s));
+        const uint32_t kk = std::max(kmax, 1u);
+        ORAMA_TRY(sc->out_ids.reserve((size_t)nq * kk * 8));
+        ORAMA_TRY(sc->out_val.reserve((size_t)nq * kk * 4));
+        ORAMA_TRY(sc->out_n.reserve((size_t)nq * 4));
+        if (kmax) {
+            ORAMA_TRY(sc->misc4.reserve((size_t)keys_topk_scratch_keys((uint32_t)max_total, nq, kmax) * 8 + 8));
+            ORAMA_TRY(launch_keys_topk(p->ctx, rb.keys, (uint32_t)max_total, max_total, nq, kmax, true, p->d_docs.as<uint64_t>(),
+                                       sc->misc4.as<unsigned long long>(), nullptr, sc->out_ids.as<uint64_t>(),
+                                       sc->out_val.as<float>(), sc->out_n.as<uint32_t>(), s,
+                                       reinterpret_cast<const uint32_t*>(d + seg_bytes + q_bytes + idf_bytes)));
+        }
+        char* h_ids = reinterpret_cast<char*>(h_res + nq);
+        char* h_val = h_ids + (size_t)nq * kk * 8;
+        char* h_n = h_val + (size_t)nq * kk * 4;
+        ORAMA_HIP_TRY(hipMemcpyAsync(h_res, sc->misc2.p, (size_t)nq * sizeof(RangeResult), hipMemcpyDeviceToHost, s));
+        if (kmax) {
+            ORAMA_HIP_TRY(hipMemcpyAsync(h_ids, sc->out_ids.p, (size_t)nq * kk * 8, hipMemcpyDeviceToHost, s));
+            ORAMA_HIP_TRY(hipMemcpyAsync(h_val, sc->out_val.p, (size_t)nq * kk * 4, hipMemcpyDeviceToHost, s));
+            ORAMA_HIP_TRY(hipMemcpyAsync(h_n, sc->out_n.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        }
+        ORAMA_HIP_TRY(hipStreamSynchronize(s));
+        // hand the answers out; a query whose ranges overflowed stays pending with smaller ranges
+        std::vector<Pending> still;
+        std::vector<char> in_chunk(pending.size(), 0);
+        for (uint32_t c = 0; c < nq; ++c) {
+            in_chunk[chunk[c]] = 1;
+            Pending pd = pending[chunk[c]];
+            const RangeJob& jb = jobs[pd.job];
+            if (h_res[c].overflow) {
+                ORAMA_REQUIRE(queries[c].log_r > 0, "internal: a one-document range overflowed");
+                ++pd.shrink;
+                still.push_back(pd);
+                continue;
+            }
+            if (jb.out_count) *jb.out_count = h_res[c].count;
+            if (jb.params->top_k) {
+                const uint32_t n = std::min(reinterpret_cast<const uint32_t*>(h_n)[c], jb.params->top_k);
+                memcpy(jb.out_ids, h_ids + (size_t)c * kk * 8, (size_t)n * 8);
+                memcpy(jb.out_scores, h_val + (size_t)c * kk * 4, (size_t)n * 4);
+                *jb.out_n = n;
+            }
+        }
+        for (uint32_t i = 0; i < pending.size(); ++i)
+            if (!in_chunk[i]) still.push_back(pending[i]);
+        pending.swap(still);
+    }
+    return ORAMA_OK;
+}
+
 int post_search_impl(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, float b,
                      const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits,
                      const uint64_t* vec_doc, const float* vec_score, uint32_t n_vec, bool hybrid,
@@ -420,6 +667,11 @@ int post_search_impl(orama_post* p, const orama_term_ref* refs, uint32_t n_refs,
     std::shared_lock<std::shared_mutex> lk(p->mu);
     ScratchLease sc(p->ctx);
     ORAMA_TRY(sc.init());
+    if (!hybrid && ranges_eligible(p, refs, n_refs, params)) {
+        ORAMA_TRY(check_params(params));
+        const RangeJob job{refs, n_refs, params, out_ids, out_scores, out_n, out_count};
+        return post_search_ranges(p, sc.s.get(), &job, 1, b, allow_bitmap, bitmap_bits, apply_omc);
+    }
     PostQuery st;
     ORAMA_TRY(post_stage1(p, sc.s.get(), refs, n_refs, b, params, allow_bitmap, bitmap_bits, hybrid, apply_omc, n_vec, &st));
     return post_stage2(p, sc.s.get(), st, params, vec_doc, vec_score, n_vec, out_ids, out_scores, out_n, out_count);
@@ -750,9 +1002,10 @@ int orama_post_search(orama_post* p, const orama_term_ref* refs, uint32_t n_refs
                             apply_omc, out_ids, out_scores, out_n, out_count);
 }
 
-// Many independent full-text queries from ONE caller: a handful of worker threads pull queries off a shared counter and
-// run the ordinary single-query path, each on its own stream + scratch set, so the launch-bound kernels of different
-// queries overlap on the device (a lone caller is latency-bound at ~6 K queries/s on the C4 shape).
+// Many independent full-text queries from ONE caller.  Queries the range-partitioned scorer takes (K3r, bm25_ranges.hip:
+// plain top-k over sorted resident lists — the normal case) are scored 32 at a time by ONE set of launches; the others
+// are pulled off a shared counter by a handful of worker threads that run the per-query path, each on its own stream +
+// scratch set, so that their launch-bound kernels overlap on the device.
 int orama_post_search_batch(orama_post* p, const orama_post_query_desc* queries, uint32_t n_queries, float b,
                             const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc, uint32_t max_parallel,
                             uint32_t stride_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count) {
@@ -762,15 +1015,51 @@ int orama_post_search_batch(orama_post* p, const orama_post_query_desc* queries,
         ORAMA_REQUIRE(queries[i].params.top_k <= stride_k, "query %u: top_k %u exceeds the output stride %u", i,
                       queries[i].params.top_k, stride_k);
     ORAMA_REQUIRE(stride_k == 0 || (out_ids && out_scores), "null output");
-    const uint32_t workers = std::max(1u, std::min(std::min(max_parallel ? max_parallel : 8u, n_queries), 64u));
+    // queries that fit the range-partitioned scorer (K3r) are scored together by one set of launches per 32 queries;
+    // the rest (or all of them when K3r is switched off) run the per-query path on worker threads
+    std::vector<uint32_t> rest;
+    {
+        std::vector<RangeJob> jobs;
+        std::vector<uint64_t> counts;
+        std::vector<uint32_t> owner;
+        {
+            std::shared_lock<std::shared_mutex> lk(p->mu);
+            for (uint32_t i = 0; i < n_queries; ++i) {
+                if (ranges_eligible(p, queries[i].refs, queries[i].n_refs, &queries[i].params)) owner.push_back(i);
+                else rest.push_back(i);
+            }
+        }
+        if (!owner.empty()) {
+            counts.assign(owner.size(), 0);
+            for (size_t j = 0; j < owner.size(); ++j) {
+                const uint32_t i = owner[j];
+                ORAMA_TRY(check_params(&queries[i].params));
+                jobs.push_back(RangeJob{queries[i].refs, queries[i].n_refs, &queries[i].params,
+                                        out_ids ? out_ids + (size_t)i * stride_k : nullptr,
+                                        out_scores ? out_scores + (size_t)i * stride_k : nullptr, &out_n[i], &counts[j]});
+            }
+            ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+            std::shared_lock<std::shared_mutex> lk(p->mu);
+            ScratchLease sc(p->ctx);
+            ORAMA_TRY(sc.init());
+            ORAMA_TRY(post_search_ranges(p, sc.s.get(), jobs.data(), (uint32_t)jobs.size(), b, allow_bitmap, bitmap_bits,
+                                         apply_omc));
+            if (out_count)
+                for (size_t j = 0; j < owner.size(); ++j) out_count[owner[j]] = counts[j];
+        }
+    }
+    if (rest.empty()) return ORAMA_OK;
+    const uint32_t n_rest = (uint32_t)rest.size();
+    const uint32_t workers = std::max(1u, std::min(std::min(max_parallel ? max_parallel : 8u, n_rest), 64u));
     std::atomic<uint32_t> next{0};
     std::atomic<int> first_status{ORAMA_OK};
     std::string first_error;
     std::mutex err_mu;
     auto work = [&]() {
         for (;;) {
-            const uint32_t i = next.fetch_add(1);
-            if (i >= n_queries || first_status.load() != ORAMA_OK) return;
+            const uint32_t r = next.fetch_add(1);
+            if (r >= n_rest || first_status.load() != ORAMA_OK) return;
+            const uint32_t i = rest[r];
             uint64_t cnt = 0;
             const int st = post_search_impl(p, queries[i].refs, queries[i].n_refs, b, &queries[i].params, allow_bitmap,
                                             bitmap_bits, nullptr, nullptr, 0, false, apply_omc,

@@ -368,12 +368,19 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(
 // One workgroup per (chunk, list): bitonic-sort up to 8192 u64 keys in LDS (descending), keep the best k.
 __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigned long long* __restrict__ keys,
                                                                    uint32_t n_keys, uint64_t in_stride,
+                                                                   const uint32_t* __restrict__ n_per_list,
                                                                    uint32_t k, unsigned long long* __restrict__ out,
                                                                    uint64_t out_stride) {
     __shared__ unsigned long long s[kKeysChunk];
     const uint32_t qi = blockIdx.y;
     const unsigned long long* in = keys + (uint64_t)qi * in_stride;
     const uint32_t begin = blockIdx.x * kKeysChunk;
+    if (n_per_list) n_keys = min(n_keys, n_per_list[qi]);  // lists shorter than the stride: the tail is not read
+    unsigned long long* o = out + (uint64_t)qi * out_stride + (uint64_t)blockIdx.x * k;
+    if (begin >= n_keys) {
+        for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = 0ull;
+        return;
+    }
     const uint32_t cnt = min(kKeysChunk, n_keys - begin);
     uint32_t p2 = 2;
     while (p2 < cnt) p2 <<= 1;
@@ -394,13 +401,13 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
             __syncthreads();
         }
     }
-    unsigned long long* o = out + (uint64_t)qi * out_stride + (uint64_t)blockIdx.x * k;
     for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = i < p2 ? s[i] : 0ull;
 }
 
 // Final ordering of <= 4096 keys: (value, 64-bit id asc, idx asc), empties (0) dropped.
 __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned long long* __restrict__ keys,
-                                                                  uint32_t n_keys, uint64_t in_stride, uint32_t k,
+                                                                  uint32_t n_keys, uint64_t in_stride,
+                                                                  const uint32_t* __restrict__ n_per_list, uint32_t k,
                                                                   bool descending,
                                                                   const uint64_t* __restrict__ id_map,
                                                                   uint32_t* out_idx, uint64_t* out_ids, float* out_val,
@@ -409,7 +416,8 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
     __shared__ uint32_t valid_s;
     const uint32_t qi = blockIdx.x;
     const unsigned long long* in = keys + (uint64_t)qi * in_stride;
-    const uint32_t p2 = next_pow2(n_keys);
+    if (n_per_list) n_keys = min(n_keys, n_per_list[qi]);
+    const uint32_t p2 = next_pow2(max(n_keys, 1u));
     if (threadIdx.x == 0) valid_s = 0;
     __syncthreads();
     uint32_t my_valid = 0;
@@ -438,29 +446,42 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
 
 }  // namespace
 
+uint64_t keys_topk_scratch_keys(uint32_t n_keys, uint32_t q, uint32_t k) {
+    uint64_t total = 0;
+    uint32_t n = n_keys;
+    while (n > kSelectMaxK) {
+        const uint32_t chunks = (n + kKeysChunk - 1) / kKeysChunk;
+        total += (uint64_t)q * chunks * k;
+        n = chunks * k;
+    }
+    return total;
+}
+
 int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t n_keys, uint64_t stride,
                      uint32_t q, uint32_t k, bool descending, const uint64_t* id_map,
                      unsigned long long* d_tmp, uint32_t* out_idx, uint64_t* out_ids, float* out_val,
-                     uint32_t* out_n, hipStream_t stream) {
+                     uint32_t* out_n, hipStream_t stream, const uint32_t* d_n_per_list) {
     ORAMA_REQUIRE(k >= 1 && k <= kSelectMaxK && q >= 1 && d_keys && out_val, "keys top-k: bad arguments");
     ProfScope prof(&ctx->prof, "topk_select", stream);
     const unsigned long long* cur = d_keys;
     uint64_t cur_stride = stride;
     uint32_t n = n_keys;
     unsigned long long* tmp = d_tmp;
+    const uint32_t* n_per_list = d_n_per_list;  // applies to the caller's lists only; reduced levels are full
     while (n > kSelectMaxK) {
         ORAMA_REQUIRE(tmp, "keys top-k: scratch missing");
         const uint32_t chunks = (n + kKeysChunk - 1) / kKeysChunk;
         const uint64_t out_stride = (uint64_t)chunks * k;
-        hipLaunchKernelGGL(keys_reduce_kernel, dim3(chunks, q), dim3(kSortThreads), 0, stream, cur, n, cur_stride, k,
-                           tmp, out_stride);
+        hipLaunchKernelGGL(keys_reduce_kernel, dim3(chunks, q), dim3(kSortThreads), 0, stream, cur, n, cur_stride,
+                           n_per_list, k, tmp, out_stride);
         cur = tmp;
         cur_stride = out_stride;
         n = chunks * k;
+        n_per_list = nullptr;
         tmp = tmp + (uint64_t)q * out_stride;  // next level (if any) writes behind this one
     }
-    hipLaunchKernelGGL(keys_final_kernel, dim3(q), dim3(kSortThreads), 0, stream, cur, n, cur_stride, k, descending,
-                       id_map, out_idx, out_ids, out_val, out_n);
+    hipLaunchKernelGGL(keys_final_kernel, dim3(q), dim3(kSortThreads), 0, stream, cur, n, cur_stride, n_per_list, k,
+                       descending, id_map, out_idx, out_ids, out_val, out_n);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -57,12 +57,15 @@ int launch_merge_candidates(orama_ctx* ctx, const uint64_t* d_ids, const float* 
 // Top-k over lists of 64-bit composite keys (value-key << 32 | ~idx, "larger wins", 0 = empty) — the output
 // of the fused per-wave top-k of K1.  List i = keys + i*stride, n_keys entries.  Reduction: workgroups sort
 // 8192-key chunks in LDS and keep their best k until <= 4096 keys remain, then one workgroup applies the
-// final order (value, 64-bit id asc, idx asc).  d_tmp must hold q * ceil(n_keys/8192) * k keys.
+// final order (value, 64-bit id asc, idx asc).  d_tmp must hold keys_topk_scratch_keys() keys.  d_n_per_list (optional,
+// device): list i holds only min(n_keys, d_n_per_list[i]) keys — what lies behind them is never read.
 constexpr uint32_t kKeysChunk = 8192;
 int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t n_keys, uint64_t stride,
                      uint32_t q, uint32_t k, bool descending, const uint64_t* id_map,
                      unsigned long long* d_tmp, uint32_t* out_idx, uint64_t* out_ids, float* out_val,
-                     uint32_t* out_n, hipStream_t stream);
+                     uint32_t* out_n, hipStream_t stream, const uint32_t* d_n_per_list = nullptr);
+// Keys of scratch launch_keys_topk needs for lists of n_keys entries.
+uint64_t keys_topk_scratch_keys(uint32_t n_keys, uint32_t q, uint32_t k);
 
 // Packed exchange block of one rank: [q*k u64 ids][q*k f32 distances], padded to 8 bytes.
 uint64_t packed_block_bytes(uint32_t q, uint32_t k);

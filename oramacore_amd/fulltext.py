@@ -240,10 +240,11 @@ class ScoreMap:
     """The HashMap<DocumentId, f32> of one search, resident in HBM (orama_scores): what the reference hands to
     FacetContext / GroupContext (search.rs:355-400).  Close it before the next build / append of its store."""
 
-    def __init__(self, lib, handle, hits):
+    def __init__(self, lib, handle, hits, store=None):
         self._lib = lib
         self._h = handle
         self.hits = hits  # (ids, scores, count) of the search that produced the map
+        self._store = store  # keeps the store alive: the handle holds a read lock on it
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -300,8 +301,9 @@ class FacetField:
     """Resident image of one filter field of an index (orama_facet_field): buckets (bool / string filter / group
     combinations) or numbers.  index/{bool,string_filter,number}_field.rs."""
 
-    def __init__(self, lib, handle, n_buckets):
+    def __init__(self, lib, handle, n_buckets, store=None):
         self._lib, self._h, self.n_buckets = lib, handle, n_buckets
+        self._store = store  # a field must not outlive the store it was resolved against
 
     @classmethod
     def buckets(cls, store: "PostingsStore", buckets: list) -> "FacetField":
@@ -313,7 +315,7 @@ class FacetField:
         h = C.c_void_p()
         N.check(store._lib.orama_facet_field_create_buckets(store._h, off.ctypes.data, docs.ctypes.data, len(buckets),
                                                             C.byref(h)))
-        return cls(store._lib, h, len(buckets))
+        return cls(store._lib, h, len(buckets), store)
 
     @classmethod
     def numbers(cls, store: "PostingsStore", docs, values) -> "FacetField":
@@ -321,7 +323,7 @@ class FacetField:
         v = np.ascontiguousarray(values, dtype=np.float64)
         h = C.c_void_p()
         N.check(store._lib.orama_facet_field_create_numbers(store._h, d.ctypes.data, v.ctypes.data, len(d), C.byref(h)))
-        return cls(store._lib, h, 0)
+        return cls(store._lib, h, 0, store)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -487,17 +489,20 @@ class PostingsStore:
 
     def search_batch(self, queries, total_documents: float, top_k: int, allow: AllowBitmap | None = None,
                      apply_omc: bool = True, max_parallel: int = 8, b: float = B_DEFAULT, k: float = K1_DEFAULT):
-        """queries: list of (refs, n_tokens, threshold | None).  One call, `max_parallel` library threads
-        (orama_post_search_batch).  Returns a list of (ids, scores, count), each identical to `search` of that query."""
+        """queries: list of (refs, n_tokens, threshold | None[, top_k of this query <= top_k]).  One call
+        (orama_post_search_batch): queries are scored 32 at a time by the range-partitioned scorer; those it does not
+        take run on `max_parallel` library threads.  Returns a list of (ids, scores, count), each identical to `search`
+        of that query."""
         nq = len(queries)
         descs = (N.PostQueryDesc * max(nq, 1))()
         keep = []
-        for i, (refs, n_tokens, thr) in enumerate(queries):
+        for i, qd in enumerate(queries):
+            refs, n_tokens, thr = qd[0], qd[1], qd[2]
             arr = self._refs(refs)
             keep.append(arr)
             descs[i].refs = C.cast(arr, C.POINTER(N.TermRef))
             descs[i].n_refs = len(refs)
-            descs[i].params = _params(total_documents, n_tokens, thr, top_k, k)
+            descs[i].params = _params(total_documents, n_tokens, thr, qd[3] if len(qd) > 3 else top_k, k)
         out_ids = np.zeros((max(nq, 1), max(top_k, 1)), dtype=np.uint64)
         out_sc = np.zeros((max(nq, 1), max(top_k, 1)), dtype=np.float32)
         out_n = np.zeros(max(nq, 1), dtype=np.uint32)
@@ -526,7 +531,7 @@ class PostingsStore:
                                                    1 if hybrid else 0, vd.ctypes.data, vs.ctypes.data, len(vd),
                                                    1 if apply_omc else 0, out_ids.ctypes.data, out_sc.ctypes.data,
                                                    C.byref(out_n), C.byref(out_count), C.byref(h)))
-        return ScoreMap(self._lib, h, (out_ids[: out_n.value].copy(), out_sc[: out_n.value].copy(), out_count.value))
+        return ScoreMap(self._lib, h, (out_ids[: out_n.value].copy(), out_sc[: out_n.value].copy(), out_count.value), self)
 
     def staged_query(self, refs, n_tokens: int, total_documents: float, top_k: int, d_df_ptr: int, stream: int,
                      threshold=None, allow: AllowBitmap | None = None, apply_omc: bool = True, hybrid: bool = False,

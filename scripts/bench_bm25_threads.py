@@ -15,6 +15,8 @@ ap.add_argument("--docs", type=int, default=10_000_000)
 ap.add_argument("--threads", default="1,2,4,8,16")
 ap.add_argument("--per-thread", type=int, default=150)
 ap.add_argument("--budget-s", type=float, default=6.0, help="give up on a thread count after this many seconds")
+ap.add_argument("--scorers", default="k3r,k3", help="k3r = range-partitioned batch scorer, k3 = per-document records")
+ap.add_argument("--batch-callers", default="1,2,4", help="concurrent callers of the batch entry")
 args = ap.parse_args()
 n, T, k = args.docs, 12, 100
 ctx = oa.Context(0)
@@ -24,37 +26,61 @@ post = ft.PostingsStore(ctx)
 post.fill_synthetic(n, ranks, seed=0xB25)
 qlists = [rng.choice(len(ranks), size=T, replace=False) for _ in range(512)]
 refs = [[(t, int(l), 1.0) for t, l in enumerate(ql)] for ql in qlists]
-out = {}
-for nt in [int(x) for x in args.threads.split(",")]:
-    for i in range(20):
-        post.search(refs[i], T, float(n), k)
+all_out = {}
+for scorer in args.scorers.split(","):
+    ctx.set_bm25_ranges(scorer == "k3r")
+    ctx.prof_reset()
+    print(f"--- scorer {scorer}", flush=True)
+    out = {}
+    for nt in [int(x) for x in args.threads.split(",")]:
+        for i in range(20):
+            post.search(refs[i], T, float(n), k)
 
-    done = [0] * nt
-    deadline = time.perf_counter() + args.budget_s
+        done = [0] * nt
+        deadline = time.perf_counter() + args.budget_s
 
-    def worker(tid):
-        for i in range(args.per_thread):
-            if time.perf_counter() > deadline:
-                return
-            post.search(refs[(tid * 131 + i) % len(refs)], T, float(n), k)
-            done[tid] += 1
+        def worker(tid):
+            for i in range(args.per_thread):
+                if time.perf_counter() > deadline:
+                    return
+                post.search(refs[(tid * 131 + i) % len(refs)], T, float(n), k)
+                done[tid] += 1
 
-    ths = [threading.Thread(target=worker, args=(t,)) for t in range(nt)]
-    t0 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    el = time.perf_counter() - t0
-    out[nt] = sum(done) / el
-    print(f"caller threads {nt:3d}: {out[nt]:9.0f} queries/s ({sum(done)} queries in {el:.2f} s)", flush=True)
-# one caller, the batch entry (library worker threads)
-batch = [(refs[i % len(refs)], T, None) for i in range(1024)]
-for par in (1, 4, 8, 16):
-    post.search_batch(batch[:64], float(n), k, max_parallel=par)
-    t0 = time.perf_counter()
-    post.search_batch(batch, float(n), k, max_parallel=par)
-    el = time.perf_counter() - t0
-    out[f"batch_par{par}"] = len(batch) / el
-    print(f"orama_post_search_batch, {par:2d} library threads: {len(batch) / el:9.0f} queries/s", flush=True)
-print(json.dumps({"metric": "BM25-only queries/s, 10M docs, 12 tokens/query, top-100", "by_threads": out}))
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(nt)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        el = time.perf_counter() - t0
+        out[nt] = sum(done) / el
+        print(f"caller threads {nt:3d}: {out[nt]:9.0f} queries/s ({sum(done)} queries in {el:.2f} s)", flush=True)
+    # the batch entry: one call per 1024 queries, from 1..4 concurrent callers
+    batch = [(refs[i % len(refs)], T, None) for i in range(1024)]
+    post.search_batch(batch[:64], float(n), k, max_parallel=8)
+    for callers in [int(x) for x in args.batch_callers.split(",")]:
+        def bworker():
+            post.search_batch(batch, float(n), k, max_parallel=8)
+        ths = [threading.Thread(target=bworker) for _ in range(callers)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        el = time.perf_counter() - t0
+        out[f"batch_callers{callers}"] = callers * len(batch) / el
+        print(f"orama_post_search_batch x {callers} callers: {callers * len(batch) / el:9.0f} queries/s", flush=True)
+    # device time per query of the batch path (HIP events around the kernels, one caller)
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    post.search_batch(batch, float(n), k, max_parallel=8)
+    ctx.prof_enable(False)
+    prof = {}
+    for name in ("bm25_range_bounds", "bm25_range_df", "bm25_range_score", "bm25_accumulate", "bm25_finalize", "topk_select"):
+        ms, cnt = ctx.prof_get(name)
+        if cnt:
+            prof[name] = {"ms_total": ms, "launches": cnt, "us_per_query": ms * 1e3 / len(batch)}
+    print("   device time of one 1024-query batch:", json.dumps(prof), flush=True)
+    out["device_time"] = prof
+    all_out[scorer] = out
+print(json.dumps({"metric": "BM25-only queries/s, 10M docs, 12 tokens/query, top-100", "by_scorer": all_out}))

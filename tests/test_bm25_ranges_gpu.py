@@ -1,0 +1,211 @@
+"""K3r — the document-range partitioned BM25F scorer (bm25_ranges.hip) — against the oracle and against K3 (the
+per-document-record scorer), bit for bit: filters, several lists per token (df counted on the device), thresholds,
+OMC, more than 32 tokens, documents clustered in id space (range overflow -> smaller ranges), queries the sort key
+cannot hold (fall back to K3), and the batch entry with mixed queries."""
+import numpy as np
+import pytest
+
+import oramacore_amd as oa
+from oramacore_amd import fulltext as ft
+from oracle import oracle as orc  # checker only
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = oa.Context(0)
+    yield c
+    c.set_bm25_ranges(True)
+    c.close()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def ntf_of(tf, length, avg, boost, b=0.75):
+    """bm25f normalised tf in f32, one rounding per operation (what the resident path computes on the device)."""
+    tf, length = np.asarray(tf, dtype=F), np.asarray(length, dtype=F)
+    return (F(boost) * (tf / ((F(1.0) - F(b)) + F(b) * (length / F(avg))))).astype(F)
+
+
+def test_ntf_helper_matches_the_oracle_function():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        tf, ln, avg = int(rng.integers(1, 50)), int(rng.integers(1, 3000)), float(F(rng.uniform(1, 500)))
+        assert bits([ntf_of([tf], [ln], avg, 1.0)[0]])[0] == bits([orc.bm25f_normalized_tf(tf, ln, avg, 0.75)])[0]
+
+
+class Corpus:
+    """Random resident store: `n_fields` fields, explicit lists; remembers what the oracle needs."""
+
+    def __init__(self, ctx, n_docs, lists, avg, doc_ids=None, seed=0):
+        rng = np.random.default_rng(seed)
+        self.n_docs = n_docs
+        self.doc_ids = np.arange(n_docs, dtype=np.uint64) if doc_ids is None else doc_ids
+        self.avg = [float(F(a)) for a in avg]
+        self.lists = []
+        pls = []
+        for field, local in lists:  # local: sorted unique local doc indices
+            local = np.asarray(local, dtype=np.int64)
+            tf = rng.integers(1, 6, size=len(local))
+            ln = rng.integers(1, 400, size=len(local))
+            self.lists.append((field, local, tf, ln))
+            pls.append(ft.PostingList(field=field, docs=self.doc_ids[local], tf=tf, field_len=ln))
+        self.store = ft.PostingsStore(ctx)
+        self.store.build(self.doc_ids, self.avg, pls)
+
+    def entries(self, refs, allow_mask=None):
+        out = []
+        for tok, lst, boost in refs:
+            field, local, tf, ln = self.lists[lst]
+            keep = np.ones(len(local), dtype=bool) if allow_mask is None else allow_mask[local]
+            out.append((tok, self.doc_ids[local[keep]], ntf_of(tf[keep], ln[keep], self.avg[field], boost)))
+        return out
+
+    def oracle(self, refs, n_tok, top_k, thr=None, allow_mask=None, omc=None):
+        docs, scores = orc.search_full_text(self.entries(refs, allow_mask), n_tok, float(self.n_docs), 1.2, thr)
+        if omc:
+            scores = orc.apply_omc(docs, scores, list(omc), list(omc.values()))
+        td, ts = orc.top_n(docs, scores, top_k)
+        return td, ts, len(docs)
+
+
+def check(ctx, corpus, refs, n_tok, top_k, thr=None, allow=None, allow_mask=None, omc=None, tag=""):
+    od, os_, ocount = corpus.oracle(refs, n_tok, top_k, thr, allow_mask, omc)
+    got = {}
+    for ranges in (True, False):
+        ctx.set_bm25_ranges(ranges)
+        ids, sc, count = corpus.store.search(refs, n_tok, float(corpus.n_docs), top_k, thr, allow=allow,
+                                             apply_omc=omc is not None)
+        assert count == ocount, (tag, ranges, count, ocount)
+        assert ids.tolist() == od.tolist(), (tag, ranges)
+        assert np.array_equal(bits(sc), bits(os_)), (tag, ranges)
+        got[ranges] = (ids, sc)
+    ctx.set_bm25_ranges(True)
+
+
+def random_lists(rng, n_docs, n_lists, n_fields, lo, hi):
+    out = []
+    for l in range(n_lists):
+        n = int(rng.integers(lo, min(hi, n_docs) + 1))
+        out.append((l % n_fields, np.sort(rng.choice(n_docs, size=n, replace=False))))
+    return out
+
+
+def test_ranges_equal_oracle_and_k3(ctx):
+    rng = np.random.default_rng(1)
+    n_docs = 40_000
+    doc_ids = np.cumsum(rng.integers(1, 4, size=n_docs)).astype(np.uint64) + np.uint64(10**9)  # non-dense 64-bit ids
+    corpus = Corpus(ctx, n_docs, random_lists(rng, n_docs, 24, 3, 50, 9000), [120.0, 33.5, 7.25], doc_ids, seed=2)
+    allow_mask = rng.random(n_docs) < 0.6
+    bm = oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[allow_mask])
+    corpus.store.set_omc({int(doc_ids[i]): float(m) for i, m in zip(rng.choice(n_docs, 300, replace=False),
+                                                                      rng.choice([0.25, 0.5, 2.0, 5.0], 300))})
+    omc = None
+    for case in range(12):
+        n_tok = int(rng.integers(1, 9))
+        refs = []
+        for t in range(n_tok):
+            for l in rng.choice(24, size=int(rng.integers(1, 4)), replace=False):  # 1-3 lists per token: df on the device
+                refs.append((t, int(l), float(F(rng.choice([1.0, 0.5, 2.0, 3.5])))))
+        rng.shuffle(refs)  # reference order is the accumulation order inside a token, whatever the interleaving
+        thr = None if case % 3 else int(rng.integers(1, n_tok + 1))
+        for filt in (False, True):
+            check(ctx, corpus, refs, n_tok, int(rng.choice([1, 10, 100, 1000])), thr, bm if filt else None,
+                  allow_mask if filt else None, omc, tag=("mixed", case, filt))
+    # one list per token and no filter: df known on the host, a single scoring pass
+    for case in range(4):
+        n_tok = int(rng.integers(1, 13))
+        refs = [(t, int(l), 1.0) for t, l in enumerate(rng.choice(24, size=n_tok, replace=False))]
+        check(ctx, corpus, refs, n_tok, 50, None, tag=("single", case))
+    # the dense multipliers of the store
+    omc_map = {}
+    ids0, _, _ = corpus.store.search([(0, 0, 1.0)], 1, float(n_docs), 20, apply_omc=False)
+    omc_map = {int(ids0[0]): 0.001, int(ids0[1]): 7.0}
+    corpus.store.set_omc(omc_map)
+    check(ctx, corpus, [(0, 0, 1.0), (1, 5, 2.0)], 2, 30, None, omc=omc_map, tag="omc")
+    corpus.store.close()
+
+
+def test_many_tokens_wrap_the_threshold_mask(ctx):
+    rng = np.random.default_rng(3)
+    n_docs = 3000
+    corpus = Corpus(ctx, n_docs, random_lists(rng, n_docs, 64, 2, 100, 1500), [50.0, 9.0], seed=4)
+    refs = [(t, t, 1.0) for t in range(64)]
+    for thr in (None, 5, 20, 33):
+        check(ctx, corpus, refs, 64, 200, thr, tag=("64 tokens", thr))
+    corpus.store.close()
+
+
+def test_clustered_documents_shrink_the_ranges(ctx):
+    """5 000 postings of one term inside 5 000 consecutive documents of a 1 M-document index: the first choice of
+    range width (tens of thousands of documents) overflows a workgroup's 2 048 slots and the query reruns with 8x
+    and 64x smaller ranges; another term is everywhere (one posting per document: a range never exceeds its width)."""
+    rng = np.random.default_rng(5)
+    n_docs = 1_000_000
+    cluster = np.arange(400_000, 405_000)
+    sparse = np.sort(rng.choice(n_docs, size=300, replace=False))
+    dense_run = np.arange(0, 6000)
+    corpus = Corpus(ctx, n_docs, [(0, cluster), (0, sparse), (1, dense_run), (1, cluster[::3])], [40.0, 12.0], seed=6)
+    check(ctx, corpus, [(0, 0, 1.0), (1, 1, 1.0)], 2, 100, tag="cluster")
+    check(ctx, corpus, [(0, 0, 1.0), (0, 3, 2.0), (1, 2, 1.0)], 2, 1000, 2, tag="cluster, two lists per token")
+    res = corpus.store.search_batch([([(0, 0, 1.0)], 1, None), ([(0, 1, 1.0)], 1, None), ([(0, 2, 1.0), (1, 0, 1.0)], 2, 1)],
+                                    float(n_docs), 64)
+    for (refs, n_tok, thr), (ids, sc, count) in zip([([(0, 0, 1.0)], 1, None), ([(0, 1, 1.0)], 1, None),
+                                                     ([(0, 2, 1.0), (1, 0, 1.0)], 2, 1)], res):
+        od, os_, ocount = corpus.oracle(refs, n_tok, 64, thr)
+        assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
+    corpus.store.close()
+
+
+def test_batch_with_mixed_queries(ctx):
+    """orama_post_search_batch: queries with different token counts, thresholds and top_k (0 = count only), an empty
+    query, a query whose 1 100 references do not fit the sort key (falls back to K3), all under one filter."""
+    rng = np.random.default_rng(7)
+    n_docs = 20_000
+    lists = random_lists(rng, n_docs, 40, 2, 20, 3000) + [(0, np.array([], dtype=np.int64))]
+    corpus = Corpus(ctx, n_docs, lists, [80.0, 15.0], seed=8)
+    allow_mask = rng.random(n_docs) < 0.8
+    bm = oa.AllowBitmap(n_docs, np.nonzero(allow_mask)[0].astype(np.uint64))
+    queries = []
+    for i in range(70):  # > 2 chunks of 32
+        n_tok = int(rng.integers(1, 7))
+        refs = [(t, int(rng.integers(0, 40)), 1.0) for t in range(n_tok) for _ in range(int(rng.integers(1, 3)))]
+        queries.append((refs, n_tok, None if i % 4 else 1, int(rng.choice([0, 1, 10, 64]))))
+    queries.append(([], 1, None, 10))                                   # no references
+    queries.append(([(0, 40, 1.0)], 1, None, 10))                       # only an empty list
+    queries.append(([(0, int(l % 40), 1.0) for l in range(1100)], 1, None, 25))  # too many lists for the sort key
+    for allow, mask in ((None, None), (bm, allow_mask)):
+        res = corpus.store.search_batch(queries, float(n_docs), 64, allow=allow)
+        assert len(res) == len(queries)
+        for (refs, n_tok, thr, k), (ids, sc, count) in zip(queries, res):
+            od, os_, ocount = corpus.oracle(refs, n_tok, k, thr, mask)
+            assert count == ocount, (len(refs), k)
+            assert ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_)), (len(refs), k)
+    corpus.store.close()
+
+
+def test_appended_lists_and_dense_ids(ctx):
+    """Delta lists appended after the build (orama_post_append) are sorted like built ones: the range scorer reads
+    both; dense ids take the implicit doc table."""
+    rng = np.random.default_rng(9)
+    n0, n1 = 5000, 2000
+    corpus = Corpus(ctx, n0, random_lists(rng, n0, 6, 1, 200, 2500), [60.0], seed=10)
+    new_docs = np.arange(n0, n0 + n1, dtype=np.uint64)
+    delta = []
+    for l in range(3):
+        local = np.sort(rng.choice(n0 + n1, size=900, replace=False))
+        local = local[local >= n0] if l == 0 else local  # one list of new documents only
+        tf, ln = rng.integers(1, 6, size=len(local)), rng.integers(1, 400, size=len(local))
+        corpus.lists.append((0, local, tf, ln))
+        delta.append(ft.PostingList(field=0, docs=local.astype(np.uint64), tf=tf, field_len=ln))
+    corpus.doc_ids = np.arange(n0 + n1, dtype=np.uint64)
+    corpus.n_docs = n0 + n1
+    corpus.avg = [float(F(61.5))]
+    first = corpus.store.append(new_docs, corpus.avg, delta)
+    assert first == 6
+    check(ctx, corpus, [(0, 0, 1.0), (0, 6, 1.0), (1, 7, 2.0), (2, 8, 1.0), (2, 3, 1.0)], 3, 500, tag="append")
+    corpus.store.close()

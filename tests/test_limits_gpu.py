@@ -54,7 +54,7 @@ def test_fulltext_limits(ctx):
     big = np.arange(n, dtype=np.uint64)
     full = ft.bm25_score_map(ctx, [(0, big, np.ones(n, dtype=np.float32))], 1, float(n))
     assert len(full) == n
-    assert status_of(lambda: ft.top_n(ctx, big, np.ones(n, np.float32), 4097)) == UNSUPPORTED
+    assert status_of(lambda: ft.top_n(ctx, (big, np.ones(n, np.float32)), 4097)) == UNSUPPORTED
 
 
 def test_group_and_range_limits(ctx):
@@ -67,8 +67,8 @@ def test_group_and_range_limits(ctx):
     assert status_of(lambda: smap.group_top(field, 1025)) == UNSUPPORTED
     assert status_of(lambda: smap.group_top(field, 0)) == INVALID
     nums = ft.FacetField.numbers(store, docs, np.arange(100, dtype=np.float64))
-    assert status_of(lambda: smap.facet_count_ranges(nums, [(float(i), float(i + 1)) for i in range(65)])) == UNSUPPORTED
-    assert smap.facet_count_ranges(nums, [(float(i), float(i + 1)) for i in range(64)]).tolist() == [2] * 64
+    # any number of ranges (the library counts 64 per launch)
+    assert smap.facet_count_ranges(nums, [(float(i), float(i + 1)) for i in range(99)]).tolist() == [2] * 99
     field.close()
     nums.close()
     smap.close()
