@@ -437,8 +437,13 @@ bool ranges_eligible(const orama_post* p, const orama_term_ref* refs, uint32_t n
 
 // log2 of the documents per range: ~512 postings per range on average, `shrink` times 8x smaller after an overflow.
 uint32_t choose_log_r(uint64_t n_docs, uint64_t total_postings, uint32_t shrink) {
+    static const uint64_t target = [] {  // postings per range aimed at (tuning knob, ORAMA_K3R_TARGET)
+        const char* e = std::getenv("ORAMA_K3R_TARGET");
+        const long v = e ? std::atol(e) : 0;
+        return (uint64_t)(v >= 16 && v <= 2048 ? v : 512);
+    }();
     uint32_t lr = 0;
-    while (lr < kRangeMaxLogR && ((uint64_t)2 << lr) * total_postings <= n_docs * 512ull) ++lr;
+    while (lr < kRangeMaxLogR && ((uint64_t)2 << lr) * total_postings <= n_docs * target) ++lr;
     // at least two ranges per compute unit's worth of work is pointless for tiny stores: one range may hold them all
     return lr > 3 * shrink ? lr - 3 * shrink : 0;
 }
@@ -562,9 +567,13 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         ORAMA_TRY(sc->misc0.reserve(seg_bytes + q_bytes + idf_bytes + len_bytes));
         ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, h, seg_bytes + q_bytes + idf_bytes + len_bytes, hipMemcpyHostToDevice, s));
         ORAMA_TRY(sc->misc1.reserve((size_t)bounds_entries * 4));
-        ORAMA_TRY(sc->misc2.reserve((size_t)nq * sizeof(RangeResult)));
+        // device results in ONE block: [RangeResult x nq | ids | scores | n]  -> one read-back per round
+        const uint32_t kk = std::max(kmax, 1u);
+        const size_t res_bytes = (size_t)nq * sizeof(RangeResult);
+        const size_t out_bytes = res_bytes + (size_t)nq * kk * 12 + (size_t)nq * 4;
+        ORAMA_TRY(sc->misc2.reserve(out_bytes));
         ORAMA_TRY(sc->misc3.reserve((size_t)nq * max_total * 8));
-        ORAMA_HIP_TRY(hipMemsetAsync(sc->misc2.p, 0, (size_t)nq * sizeof(RangeResult), s));
+        ORAMA_HIP_TRY(hipMemsetAsync(sc->misc2.p, 0, res_bytes, s));
         char* d = sc->misc0.as<char>();
         float* d_idf = reinterpret_cast<float*>(d + seg_bytes + q_bytes);
         RangeBatch rb;
@@ -586,12 +595,12 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         rb.keys = sc->misc3.as<unsigned long long>();
         rb.results = sc->misc2.as<RangeResult>();
         ORAMA_TRY(launch_range_bounds(p->ctx, rb, s));
-        ORAMA_TRY(sc->h_out.reserve((size_t)nq * sizeof(RangeResult) + (size_t)nq * std::max(kmax, 1u) * 12 + (size_t)nq * 4 + 64));
+        ORAMA_TRY(sc->h_out.reserve(out_bytes + 64));
         RangeResult* h_res = sc->h_out.as<RangeResult>();
         if (any_df) {
             // df counted on the device (filter, or tokens with several lists): one read-back, then idf by the host libm
             ORAMA_TRY(launch_range_score(p->ctx, rb, true, s));
-            ORAMA_HIP_TRY(hipMemcpyAsync(h_res, sc->misc2.p, (size_t)nq * sizeof(RangeResult), hipMemcpyDeviceToHost, s));
+            ORAMA_HIP_TRY(hipMemcpyAsync(h_res, sc->misc2.p, res_bytes, hipMemcpyDeviceToHost, s));
             ORAMA_HIP_TRY(hipStreamSynchronize(s));
             for (uint32_t c = 0; c < nq; ++c) {
                 if (!queries[c].want_df) continue;
@@ -604,26 +613,20 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             ORAMA_HIP_TRY(hipMemcpyAsync(d_idf, h_idf, idf_bytes, hipMemcpyHostToDevice, s));
         }
         ORAMA_TRY(launch_range_score(p->ctx, rb, false, s));
-        const uint32_t kk = std::max(kmax, 1u);
-        ORAMA_TRY(sc->out_ids.reserve((size_t)nq * kk * 8));
-        ORAMA_TRY(sc->out_val.reserve((size_t)nq * kk * 4));
-        ORAMA_TRY(sc->out_n.reserve((size_t)nq * 4));
+        char* d_out = sc->misc2.as<char>();
+        uint64_t* d_ids = reinterpret_cast<uint64_t*>(d_out + res_bytes);
+        float* d_val = reinterpret_cast<float*>(d_out + res_bytes + (size_t)nq * kk * 8);
+        uint32_t* d_n = reinterpret_cast<uint32_t*>(d_out + res_bytes + (size_t)nq * kk * 12);
         if (kmax) {
             ORAMA_TRY(sc->misc4.reserve((size_t)keys_topk_scratch_keys((uint32_t)max_total, nq, kmax) * 8 + 8));
             ORAMA_TRY(launch_keys_topk(p->ctx, rb.keys, (uint32_t)max_total, max_total, nq, kmax, true, p->d_docs.as<uint64_t>(),
-                                       sc->misc4.as<unsigned long long>(), nullptr, sc->out_ids.as<uint64_t>(),
-                                       sc->out_val.as<float>(), sc->out_n.as<uint32_t>(), s,
+                                       sc->misc4.as<unsigned long long>(), nullptr, d_ids, d_val, d_n, s,
                                        reinterpret_cast<const uint32_t*>(d + seg_bytes + q_bytes + idf_bytes)));
         }
-        char* h_ids = reinterpret_cast<char*>(h_res + nq);
-        char* h_val = h_ids + (size_t)nq * kk * 8;
-        char* h_n = h_val + (size_t)nq * kk * 4;
-        ORAMA_HIP_TRY(hipMemcpyAsync(h_res, sc->misc2.p, (size_t)nq * sizeof(RangeResult), hipMemcpyDeviceToHost, s));
-        if (kmax) {
-            ORAMA_HIP_TRY(hipMemcpyAsync(h_ids, sc->out_ids.p, (size_t)nq * kk * 8, hipMemcpyDeviceToHost, s));
-            ORAMA_HIP_TRY(hipMemcpyAsync(h_val, sc->out_val.p, (size_t)nq * kk * 4, hipMemcpyDeviceToHost, s));
-            ORAMA_HIP_TRY(hipMemcpyAsync(h_n, sc->out_n.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-        }
+        const char* h_ids = reinterpret_cast<const char*>(h_res) + res_bytes;
+        const char* h_val = h_ids + (size_t)nq * kk * 8;
+        const char* h_n = h_val + (size_t)nq * kk * 4;
+        ORAMA_HIP_TRY(hipMemcpyAsync(h_res, d_out, kmax ? out_bytes : res_bytes, hipMemcpyDeviceToHost, s));
         ORAMA_HIP_TRY(hipStreamSynchronize(s));
         // hand the answers out; a query whose ranges overflowed stays pending with smaller ranges
         std::vector<Pending> still;

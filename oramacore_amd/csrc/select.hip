@@ -364,14 +364,22 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(
                  out_n ? out_n + qi : nullptr);
 }
 
-// ---------------------------------------------------------------- key lists (fused per-wave top-k of K1)
-// One workgroup per (chunk, list): bitonic-sort up to 8192 u64 keys in LDS (descending), keep the best k.
+// ---------------------------------------------------------------- key lists (fused per-wave top-k of K1, K3r)
+// One workgroup per (chunk, list): the best k of up to 8192 u64 keys, as a SET (the final kernel orders the survivors).
+// MSB-first radix select in LDS instead of a sort: the bits above the first one in which the chunk's largest and
+// smallest key differ are skipped (BM25 scores of one query share sign, exponent and often leading mantissa bits),
+// then 8-bit digits: per-digit histogram with LDS atomics, one wave finds the bin that holds the k-th key, everything
+// above it is taken; stops as soon as a bin is taken whole.  Keys are unique (the low word is ~index), 0 = empty.
 __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigned long long* __restrict__ keys,
                                                                    uint32_t n_keys, uint64_t in_stride,
                                                                    const uint32_t* __restrict__ n_per_list,
                                                                    uint32_t k, unsigned long long* __restrict__ out,
                                                                    uint64_t out_stride) {
     __shared__ unsigned long long s[kKeysChunk];
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
+    __shared__ uint32_t red_nz[kSortThreads / 64];
+    __shared__ uint32_t sel_bin, sel_above, sel_cnt, cursor;
     const uint32_t qi = blockIdx.y;
     const unsigned long long* in = keys + (uint64_t)qi * in_stride;
     const uint32_t begin = blockIdx.x * kKeysChunk;
@@ -382,26 +390,109 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
         return;
     }
     const uint32_t cnt = min(kKeysChunk, n_keys - begin);
-    uint32_t p2 = 2;
-    while (p2 < cnt) p2 <<= 1;
-    for (uint32_t i = threadIdx.x; i < p2; i += blockDim.x) s[i] = i < cnt ? in[begin + i] : 0ull;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long mx = 0ull, mn = ~0ull;
+    uint32_t nz = 0;
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const unsigned long long key = in[begin + i];
+        s[i] = key;
+        if (key) {
+            ++nz;
+            mx = key > mx ? key : mx;
+            mn = key < mn ? key : mn;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(mx, off, 64), b = __shfl_xor(mn, off, 64);
+        mx = a > mx ? a : mx;
+        mn = b < mn ? b : mn;
+        nz += __shfl_xor(nz, off, 64);
+    }
+    if (lane == 0) {
+        red_max[wave] = mx;
+        red_min[wave] = mn;
+        red_nz[wave] = nz;
+    }
+    if (threadIdx.x == 0) cursor = 0;
     __syncthreads();
-    for (uint32_t size = 2; size <= p2; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (p2 >> 1); t += blockDim.x) {
-                const uint32_t lo = 2 * t - (t & (stride - 1));
-                const uint32_t hi = lo + stride;
-                const bool up = ((lo & size) == 0);
-                const unsigned long long a = s[lo], b = s[hi];
-                if ((b > a) == up) {
-                    s[lo] = b;
-                    s[hi] = a;
+    mx = 0ull, mn = ~0ull, nz = 0;
+    for (uint32_t w = 0; w < kSortThreads / 64; ++w) {
+        mx = red_max[w] > mx ? red_max[w] : mx;
+        mn = red_min[w] < mn ? red_min[w] : mn;
+        nz += red_nz[w];
+    }
+    unsigned long long thr = 1ull;  // take every non-empty key
+    if (nz > k) {
+        // bits above `low` are common to all non-empty keys; the k-th largest is searched below them
+        uint32_t low = 64u - (uint32_t)__builtin_clzll(mx ^ mn);  // mx != mn: nz > k >= 1 unique keys
+        unsigned long long prefix = low >= 64u ? 0ull : (mx >> low) << low;
+        uint32_t need = k;
+        for (;;) {
+            const uint32_t d = low < 8u ? low : 8u;
+            const uint32_t shift = low - d;
+            const unsigned long long above_mask = low >= 64u ? 0ull : ~0ull << low;
+            for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+                const unsigned long long key = s[i];
+                if (key && (key & above_mask) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & ((1u << d) - 1u)], 1u);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t c[4], tot = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    c[j] = hist[lane * 4 + j];
+                    tot += c[j];
+                }
+                uint32_t incl = tot;  // keys in the bins of this lane and of the lanes above it
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t y = __shfl_down(incl, off, 64);
+                    if (lane + off < 64) incl += y;
+                }
+                uint32_t above = incl - tot;
+                if (above < need && need <= incl) {  // exactly one lane: the k-th key lies in its bins
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        if (above + c[j] >= need) {
+                            sel_bin = (uint32_t)lane * 4 + j;
+                            sel_above = above;
+                            sel_cnt = c[j];
+                            break;
+                        }
+                        above += c[j];
+                    }
                 }
             }
             __syncthreads();
+            prefix |= (unsigned long long)sel_bin << shift;
+            need -= sel_above;
+            low = shift;
+            const bool whole = sel_cnt == need;
+            __syncthreads();  // sel_* are rewritten by the next round
+            if (whole || low == 0) break;
+        }
+        thr = prefix;  // keys >= thr: exactly k of them (unique keys)
+    }
+    // compact the selected keys (order is irrelevant here): one LDS atomic per wave and pass
+    for (uint32_t i0 = 0; i0 < cnt; i0 += blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        const unsigned long long key = i < cnt ? s[i] : 0ull;
+        const bool take = key >= thr;  // thr >= 1: empties never
+        const unsigned long long m = __ballot(take);
+        uint32_t base = 0;
+        if (lane == 0 && m) base = atomicAdd(&cursor, (uint32_t)__popcll(m));
+        base = __shfl(base, 0, 64);
+        if (take) {
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (pos < k) o[pos] = key;
         }
     }
-    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = i < p2 ? s[i] : 0ull;
+    __syncthreads();
+    const uint32_t taken = min(cursor, k);
+    for (uint32_t i = taken + threadIdx.x; i < k; i += blockDim.x) o[i] = 0ull;
 }
 
 // Final ordering of <= 4096 keys: (value, 64-bit id asc, idx asc), empties (0) dropped.

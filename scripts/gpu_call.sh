@@ -1,7 +1,9 @@
 #!/bin/bash
-# one GPU call: the whole parity suite
 set -x
-O=gpurun_out/r02full
+O=gpurun_out/r02k3r2
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-( time timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; tail -8 $O/pytest.log
+( time timeout 600 python -m pytest tests/test_bm25_ranges_gpu.py tests/test_fulltext_gpu.py tests/test_random_gpu.py tests/test_vector_gpu.py "tests/test_full_size_gpu.py::test_c4_full_size_bm25_bit_exact" -m gpu -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+for t in 512 256 1024; do
+ORAMA_K3R_TARGET=$t timeout 300 python scripts/bench_bm25_threads.py --threads 1,8 --scorers k3r > $O/bm25_t$t.log 2>&1; grep -v "^{" $O/bm25_t$t.log
+done
