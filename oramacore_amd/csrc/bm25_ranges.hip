@@ -7,10 +7,11 @@
 //
 //   range_bounds_kernel   one thread per referenced posting: where does each list cross the range boundaries
 //                         (range = 2^log_r consecutive local documents, log_r chosen per query so that a range
-//                         holds ~512 postings on average).  bounds[list][r] = postings of the list in ranges < r.
+//                         holds 512..1024 postings on average).  bounds[list][r] = postings of the list in ranges < r.
 //   range_score_kernel    one workgroup per (range, query): gathers the <= 2048 postings of its range from the
-//                         lists (coalesced: each list contributes one contiguous run), computes the normalised tf,
-//                         sorts (document, token, list rank | ntf) keys in LDS, and the first thread of every
+//                         lists (coalesced: each list contributes one contiguous, already sorted run), computes the
+//                         normalised tf, merges the runs by (document, token, list rank) in LDS — a merge tree by
+//                         ranking, log2(lists) levels — and the first thread of every
 //                         document walks its run IN ORDER — lists of a token in reference order, tokens ascending —
 //                         exactly the additions BM25Scorer::add / get_scores perform (bm25.rs:369-428), so scores
 //                         are bit-identical to K3 and to the CPU restatement.  Output: one 64-bit key
@@ -36,7 +37,6 @@ namespace orama {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr unsigned long long kDropped = ~0ull;
 
 __device__ __forceinline__ bool f32_is_normal(float x) {
     const uint32_t e = (__builtin_bit_cast(uint32_t, x) >> 23) & 0xffu;
@@ -67,23 +67,30 @@ __global__ __launch_bounds__(kThreads) void range_bounds_kernel(RangeBatch b) {
     const uint32_t j = (uint32_t)(v - sg.virt_begin);
     const uint32_t* pd = b.post_doc + sg.post_begin;
     const uint32_t r = pd[j] >> sg.log_r;
-    uint32_t* row = b.bounds + sg.bounds_off;
+    uint32_t* col = b.bounds + sg.bounds_off;  // [range][reference]: consecutive ranges are bounds_stride apart
     // entries (prev_r, r] start at this posting; the first posting also covers the ranges before it
     uint32_t from = j ? (pd[j - 1] >> sg.log_r) + 1 : 0;
-    for (uint32_t rr = from; rr <= r; ++rr) row[rr] = j;
+    for (uint32_t rr = from; rr <= r; ++rr) col[(uint64_t)rr * sg.bounds_stride] = j;
     if (j == sg.len - 1)
-        for (uint32_t rr = r + 1; rr <= sg.n_ranges; ++rr) row[rr] = sg.len;
+        for (uint32_t rr = r + 1; rr <= sg.n_ranges; ++rr) col[(uint64_t)rr * sg.bounds_stride] = sg.len;
 }
 
-// key layout of the in-range sort: [local doc:16 | token:6 | rank:10 | ntf bits:32]
-__device__ __forceinline__ uint32_t key_doc(unsigned long long k) { return (uint32_t)(k >> 48); }
-__device__ __forceinline__ uint32_t key_tok(unsigned long long k) { return (uint32_t)(k >> 42) & 63u; }
+// key of the in-range merge: [local doc:15 | token:6 | rank:10 | dropped:1 | ntf bits:32] — the order of the upper
+// 31 bits is (document, token, list rank); a posting dropped by the filter keeps its place in its run.
+__device__ __forceinline__ uint32_t key_doc(unsigned long long k) { return (uint32_t)(k >> 49); }
+__device__ __forceinline__ uint32_t key_tok(unsigned long long k) { return (uint32_t)(k >> 43) & 63u; }
+__device__ __forceinline__ uint32_t key_doc_tok(unsigned long long k) { return (uint32_t)(k >> 43); }
+__device__ __forceinline__ bool key_dropped(unsigned long long k) { return (k >> 32) & 1ull; }
+
+constexpr int kPerThread = kRangeCap / kThreads;  // merge elements a thread carries in registers
 
 template <bool DF_ONLY>
 __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     __shared__ unsigned long long s[kRangeCap];
-    __shared__ uint32_t seg_b0[kRangeMaxRefs];   // first posting of each reference inside this range
-    __shared__ uint32_t seg_off[kRangeMaxRefs + 1];
+    __shared__ unsigned long long seg_pos[kRangeMaxRefs];  // first posting of each reference inside this range
+    __shared__ uint32_t seg_off[kRangeMaxRefs + 1];        // start of each reference's run among the gathered postings
+    __shared__ uint32_t seg_key[kRangeMaxRefs];            // token << 11 | rank << 1
+    __shared__ float seg_boost[kRangeMaxRefs], seg_avg[kRangeMaxRefs];
     __shared__ float idf[kMaxTokens];
     __shared__ uint32_t df_lds[kMaxTokens];
     __shared__ uint32_t red[2];
@@ -102,13 +109,19 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
         if (!DF_ONLY) idf[t] = t < q.n_tokens ? b.idf[(size_t)qi * kMaxTokens + t] : 0.0f;
     }
     __syncthreads();
-    // this range's run of every reference; slot base = postings of the query in earlier ranges
+    // this range's run of every reference (the bounds of a range are contiguous over the references, and their
+    // address does not depend on the reference table: both loads are issued together);
+    // slot base = postings of the query in earlier ranges
     uint32_t base_part = 0;
     for (uint32_t i = threadIdx.x; i < ns; i += kThreads) {
-        const uint32_t* row = b.bounds + segs[i].bounds_off;
-        const uint32_t b0 = row[r], b1 = row[r + 1];
-        seg_b0[i] = b0;
+        const uint32_t* row = b.bounds + q.bounds_base + (uint64_t)r * ns;
+        const uint32_t b0 = row[i], b1 = row[ns + i];
+        const RangeSeg sg = segs[i];
+        seg_pos[i] = sg.post_begin + b0;
         seg_off[i + 1] = b1 - b0;
+        seg_key[i] = sg.tok_rank << 1;
+        seg_boost[i] = sg.boost;
+        seg_avg[i] = sg.avg_len;
         base_part += b0;
     }
     base_part = wave_sum_u32(base_part);
@@ -140,66 +153,95 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
         if (threadIdx.x == 0) b.results[qi].overflow = 1;
         return;
     }
-    uint32_t p2 = 2;
-    while (p2 < cap) p2 <<= 1;
 
-    // gather: element e belongs to the reference whose [seg_off[i], seg_off[i+1]) holds it
+    // gather: element e belongs to the reference whose [seg_off[i], seg_off[i+1]) holds it; runs are sorted by
+    // document, so by key
     const float one_minus_b = 1.0f - b.b;
     const uint32_t doc0 = r << q.log_r;
-    for (uint32_t e = threadIdx.x; e < p2; e += kThreads) {
-        unsigned long long key = kDropped;
-        if (e < cap) {
-            uint32_t lo = 0, hi = ns;
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (seg_off[mid] <= e) lo = mid; else hi = mid;
-            }
-            const RangeSeg& sg = segs[lo];
-            const uint64_t p = sg.post_begin + seg_b0[lo] + (e - seg_off[lo]);
-            const uint32_t doc = b.post_doc[p];
-            bool keep = true;
-            if (b.allow) {  // collect_contributions_with_filter: filtered docs never reach the scorer
-                const uint64_t id = b.docs[doc];
-                keep = id < b.allow_bits && ((b.allow[id >> 6] >> (id & 63)) & 1ull);
-            }
-            if (keep) {
-                uint32_t ntf_bits = 0;
-                if (!DF_ONLY) {
-                    const uint32_t val = b.post_val[p];
-                    const float tf = (float)(val >> 16);
-                    const float len = (float)(val & 0xffffu);
-                    const float ntf = sg.boost * (tf / (one_minus_b + b.b * (len / sg.avg_len)));
-                    ntf_bits = __builtin_bit_cast(uint32_t, ntf);
-                }
-                key = ((unsigned long long)(((doc - doc0) << 16) | sg.tok_rank) << 32) | ntf_bits;
-            }
+    for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
+        uint32_t lo = 0, hi = ns;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (seg_off[mid] <= e) lo = mid; else hi = mid;
         }
-        s[e] = key;
+        const uint64_t p = seg_pos[lo] + (e - seg_off[lo]);
+        const uint32_t doc = b.post_doc[p];
+        uint32_t dropped = 0;
+        if (b.allow) {  // collect_contributions_with_filter: filtered docs never reach the scorer
+            const uint64_t id = b.docs[doc];
+            dropped = !(id < b.allow_bits && ((b.allow[id >> 6] >> (id & 63)) & 1ull));
+        }
+        uint32_t ntf_bits = 0;
+        if (!DF_ONLY) {
+            const uint32_t val = b.post_val[p];
+            const float tf = (float)(val >> 16);
+            const float len = (float)(val & 0xffffu);
+            const float ntf = seg_boost[lo] * (tf / (one_minus_b + b.b * (len / seg_avg[lo])));
+            ntf_bits = __builtin_bit_cast(uint32_t, ntf);
+        }
+        s[e] = ((unsigned long long)(((doc - doc0) << 17) | seg_key[lo] | dropped) << 32) | ntf_bits;
     }
     __syncthreads();
-    // bitonic sort, ascending on the whole 64-bit key ((doc, token, rank) is unique among the kept postings)
-    for (uint32_t size = 2; size <= p2; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (p2 >> 1); t += kThreads) {
-                const uint32_t lo = 2 * t - (t & (stride - 1));
-                const uint32_t hi = lo + stride;
-                const bool up = ((lo & size) == 0);
-                const unsigned long long x = s[lo], y = s[hi];
-                if ((x > y) == up) {
-                    s[lo] = y;
-                    s[hi] = x;
-                }
+    // merge tree over the runs: at level l the sorted groups are 2^l consecutive references; a group pair is merged
+    // by ranking — an element moves to (its index in its group) + (elements of the sibling group below it).  The upper
+    // 32 bits are unique, so a plain `<` ranks both sides consistently.  Elements travel through registers: read and
+    // rank everything, barrier, write in place, barrier.
+    for (uint32_t w = 1; w < ns; w <<= 1) {  // w = references per group
+        unsigned long long my_key[kPerThread];
+        uint32_t my_pos[kPerThread];
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const uint32_t e = threadIdx.x + (uint32_t)j * kThreads;
+            if (e >= cap) break;
+            const unsigned long long key = s[e];
+            // group of e: largest g with seg_off[min(ns, g * w)] <= e
+            const uint32_t n_groups = (ns + w - 1) / w;
+            uint32_t lo = 0, hi = n_groups;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (seg_off[min(ns, mid * w)] <= e) lo = mid; else hi = mid;
             }
-            __syncthreads();
+            const uint32_t g = lo, sib = g ^ 1u;
+            const uint32_t g_start = seg_off[min(ns, g * w)];
+            const uint32_t pair_start = seg_off[min(ns, (g & ~1u) * w)];
+            uint32_t below = 0;
+            if (sib < n_groups) {
+                uint32_t a = seg_off[min(ns, sib * w)], z = seg_off[min(ns, (sib + 1) * w)];
+                const uint32_t a0 = a;
+                while (a < z) {  // lower bound of `key` in the sibling group
+                    const uint32_t mid = (a + z) >> 1;
+                    if (s[mid] < key) a = mid + 1; else z = mid;
+                }
+                below = a - a0;
+            }
+            my_key[j] = key;
+            my_pos[j] = pair_start + (e - g_start) + below;
         }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const uint32_t e = threadIdx.x + (uint32_t)j * kThreads;
+            if (e >= cap) break;
+            s[my_pos[j]] = my_key[j];
+        }
+        __syncthreads();
     }
 
     if (DF_ONLY) {
-        // corpus_docs.len(): distinct (token, document) pairs (token_score.rs:262-275)
+        // corpus_docs.len(): distinct (token, document) pairs among the kept postings (token_score.rs:262-275)
         for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
             const unsigned long long key = s[e];
-            if (key == kDropped) continue;
-            if (e == 0 || (s[e - 1] >> 42) != (key >> 42)) atomicAdd(&df_lds[key_tok(key)], 1u);
+            if (key_dropped(key)) continue;
+            bool first = true;
+            for (uint32_t j = e; j > 0; --j) {
+                const unsigned long long kj = s[j - 1];
+                if (key_doc_tok(kj) != key_doc_tok(key)) break;
+                if (!key_dropped(kj)) {
+                    first = false;
+                    break;
+                }
+            }
+            if (first) atomicAdd(&df_lds[key_tok(key)], 1u);
         }
         __syncthreads();
         for (uint32_t t = threadIdx.x; t < q.n_tokens; t += kThreads)
@@ -213,40 +255,41 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
         const unsigned long long key = s[e];
         unsigned long long out_key = 0ull;
-        if (key != kDropped && (e == 0 || key_doc(s[e - 1]) != key_doc(key))) {
-            // first posting of a document: fold its run
+        if (e == 0 || key_doc(s[e - 1]) != key_doc(key)) {
+            // first posting of a document: fold its run (lists of a token in reference order, tokens ascending)
             const uint32_t dl = key_doc(key);
             float score = 0.0f;  // entry(key).or_insert(0.0)
             uint32_t mask = 0u;
-            bool applied = false;
-            uint32_t tok = key_tok(key);
+            bool applied = false, have = false;
+            uint32_t tok = 0;
             float sum = 0.0f;
-            uint32_t j = e;
-            unsigned long long kj = key;
-            for (;;) {
-                sum = sum + 1.0f * __builtin_bit_cast(float, (uint32_t)kj);  // Iterator::sum() from 0.0, weight 1.0
-                ++j;
-                bool more = false;
-                uint32_t ntok = tok;
-                if (j < cap) {
-                    kj = s[j];
-                    more = kj != kDropped && key_doc(kj) == dl;
-                    if (more) ntok = key_tok(kj);
-                }
-                if (!more || ntok != tok) {  // close the token
-                    if (f32_is_normal(sum)) {
-                        const float term = idf[tok] * k1 * sum / (q.k + sum);  // bm25f_score, bm25.rs:124-126
-                        if (term == term) {
-                            score = score + term * 1.0f;  // phrase boost 1.0
-                            mask |= 1u << (tok & 31u);    // 1 << term_index on u32 (wrapping shift)
-                            applied = true;
-                        }
+            auto close_token = [&]() {
+                if (f32_is_normal(sum)) {
+                    const float term = idf[tok] * k1 * sum / (q.k + sum);  // bm25f_score, bm25.rs:124-126
+                    if (term == term) {
+                        score = score + term * 1.0f;  // phrase boost 1.0
+                        mask |= 1u << (tok & 31u);    // 1 << term_index on u32 (wrapping shift)
+                        applied = true;
                     }
-                    sum = 0.0f;
-                    tok = ntok;
                 }
-                if (!more) break;
+            };
+            unsigned long long kj = key;
+            for (uint32_t j = e;;) {
+                if (!key_dropped(kj)) {
+                    const uint32_t t = key_tok(kj);
+                    if (have && t != tok) {
+                        close_token();
+                        sum = 0.0f;
+                    }
+                    tok = t;
+                    have = true;
+                    sum = sum + 1.0f * __builtin_bit_cast(float, (uint32_t)kj);  // Iterator::sum() from 0.0, weight 1.0
+                }
+                if (++j >= cap) break;
+                kj = s[j];
+                if (key_doc(kj) != dl) break;
             }
+            if (have) close_token();
             if (applied && !(q.use_threshold && (uint32_t)__popc(mask) < q.threshold)) {
                 const uint32_t doc = doc0 + dl;
                 if (b.omc_dense) score = score * b.omc_dense[doc];

@@ -7,15 +7,16 @@
 
 namespace orama {
 
-constexpr uint32_t kRangeCap = 2048;     // postings one workgroup merges (LDS sort size)
+constexpr uint32_t kRangeCap = 2048;     // postings one workgroup merges in LDS
 constexpr uint32_t kRangeMaxLogR = 15;   // documents per range <= 32768 (local document in 16 key bits; 0xffff.. = dropped)
-constexpr uint32_t kRangeMaxRefs = 1024; // non-empty posting lists per query (10-bit list rank in the sort key)
+constexpr uint32_t kRangeMaxRefs = 256;  // non-empty posting lists per query (per-reference tables live in LDS)
 
 // One (token, posting list) reference of one query of the batch.
 struct RangeSeg {
     uint64_t post_begin;  // first posting of the list inside the postings arrays
     uint64_t virt_begin;  // first virtual posting of this reference inside the batch (bounds kernel)
-    uint64_t bounds_off;  // first entry of this reference's bounds row (n_ranges + 1 entries)
+    uint64_t bounds_off;  // entry of (range 0, this reference): bounds are laid out [query][range][reference]
+    uint32_t bounds_stride;  // references of its query = distance between consecutive ranges of one reference
     uint32_t len;
     uint32_t query;       // index of the query inside the batch
     uint32_t tok_rank;    // token << 10 | rank (position of the list among the token's lists)
@@ -23,11 +24,11 @@ struct RangeSeg {
     uint32_t n_ranges;    // of its query
     float boost;
     float avg_len;
-    uint32_t pad;
 };
 
 struct RangeQuery {
     uint64_t key_off;     // first slot of this query in the key buffer (one slot per referenced posting)
+    uint64_t bounds_base; // first bounds entry of this query
     uint32_t seg_begin, seg_end;
     uint32_t log_r;       // a range = 2^log_r consecutive local documents
     uint32_t n_ranges;
@@ -36,6 +37,7 @@ struct RangeQuery {
     float k;
     uint32_t want_df;     // count df on the device (filter, or a token with several lists)
     uint32_t pad;
+    uint64_t pad2;
 };
 
 // Per-query result words (device): 128 bytes apart so that the per-workgroup atomics of different queries and of
@@ -67,7 +69,7 @@ struct RangeBatch {
     RangeResult* results = nullptr;
 };
 
-// bounds[seg][r] = postings of the reference whose document lies in a range < r.
+// bounds[query][r][reference] = postings of the reference whose document lies in a range < r.
 int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream);
 // df_only: count distinct (token, document) pairs into results[q].df for the queries that want it.
 int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStream_t stream);

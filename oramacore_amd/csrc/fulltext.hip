@@ -435,12 +435,12 @@ bool ranges_eligible(const orama_post* p, const orama_term_ref* refs, uint32_t n
     return nonempty <= kRangeMaxRefs && total < 0x7fffffffull;
 }
 
-// log2 of the documents per range: ~512 postings per range on average, `shrink` times 8x smaller after an overflow.
+// log2 of the documents per range: 512..1024 postings per range on average, `shrink` times 8x smaller after an overflow.
 uint32_t choose_log_r(uint64_t n_docs, uint64_t total_postings, uint32_t shrink) {
     static const uint64_t target = [] {  // postings per range aimed at (tuning knob, ORAMA_K3R_TARGET)
         const char* e = std::getenv("ORAMA_K3R_TARGET");
         const long v = e ? std::atol(e) : 0;
-        return (uint64_t)(v >= 16 && v <= 2048 ? v : 512);
+        return (uint64_t)(v >= 16 && v <= 2048 ? v : 1024);
     }();
     uint32_t lr = 0;
     while (lr < kRangeMaxLogR && ((uint64_t)2 << lr) * total_postings <= n_docs * target) ++lr;
@@ -506,6 +506,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             const RangeJob& jb = jobs[pd.job];
             RangeQuery& q = queries[c];
             q.key_off = (uint64_t)c * max_total;
+            q.bounds_base = bounds_entries;
             q.seg_begin = (uint32_t)segs.size();
             q.log_r = choose_log_r(p->n_docs, pd.total, pd.shrink);
             q.n_ranges = (uint32_t)(((p->n_docs - 1) >> q.log_r) + 1);
@@ -527,7 +528,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                     RangeSeg g{};
                     g.post_begin = p->list_off[l];
                     g.virt_begin = virt;
-                    g.bounds_off = bounds_entries;
+                    g.bounds_off = 0;  // completed below, when the query's reference count is known
                     g.len = len;
                     g.query = c;
                     g.tok_rank = (t << 10) | per_token[t];
@@ -536,13 +537,18 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                     g.boost = jb.refs[i].boost;
                     g.avg_len = p->avg_len[p->field_of_list[l]];
                     virt += len;
-                    bounds_entries += (uint64_t)q.n_ranges + 1;
                     segs.push_back(g);
                     if (++per_token[t] > 1) df_known = false;
                     df[t] += len;
                 }
             }
             q.seg_end = (uint32_t)segs.size();
+            const uint32_t ns = q.seg_end - q.seg_begin;
+            for (uint32_t i = 0; i < ns; ++i) {  // bounds of a query: [range][reference]
+                segs[q.seg_begin + i].bounds_off = q.bounds_base + i;
+                segs[q.seg_begin + i].bounds_stride = ns;
+            }
+            bounds_entries += ((uint64_t)q.n_ranges + 1) * ns;
             q.want_df = df_known ? 0u : 1u;
             any_df |= !df_known;
             // idf per token by the host libm (calculate_idf, bm25.rs:78-82; df.max(1), token_score.rs:275)
