@@ -26,13 +26,16 @@ post = ft.PostingsStore(ctx)
 post.fill_synthetic(n, ranks, seed=0xB25)
 qlists = [rng.choice(len(ranks), size=T, replace=False) for _ in range(512)]
 refs = [[(t, int(l), 1.0) for t, l in enumerate(ql)] for ql in qlists]
-all_out = {}
+lens = np.array([len(post.get_list(int(l))[0]) for l in range(len(ranks))])
+avg_postings = float(np.mean([lens[ql].sum() for ql in qlists]))
+print(f"postings referenced per query: {avg_postings:.0f} on average", flush=True)
+all_out = {"avg_postings_per_query": avg_postings}
 for scorer in args.scorers.split(","):
     ctx.set_bm25_ranges(scorer == "k3r")
     ctx.prof_reset()
     print(f"--- scorer {scorer}", flush=True)
     out = {}
-    for nt in [int(x) for x in args.threads.split(",")]:
+    for nt in [int(x) for x in args.threads.split(",") if x and int(x) > 0]:
         for i in range(20):
             post.search(refs[i], T, float(n), k)
 
