@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     }
     __syncthreads();
     const uint32_t cap = seg_off[ns];
-    if (cap == 0) return;
+    if (cap == 0 || (b.debug & 4u)) return;
     const uint32_t slot_base = red[0];
     if (cap > kRangeCap) {
         // the query is rerun with smaller ranges; its slots still reach the batch's top-k, so they must be empty
@@ -182,49 +182,76 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
         s[e] = ((unsigned long long)(((doc - doc0) << 17) | seg_key[lo] | dropped) << 32) | ntf_bits;
     }
     __syncthreads();
-    // merge tree over the runs: at level l the sorted groups are 2^l consecutive references; a group pair is merged
-    // by ranking — an element moves to (its index in its group) + (elements of the sibling group below it).  The upper
-    // 32 bits are unique, so a plain `<` ranks both sides consistently.  Elements travel through registers: read and
-    // rank everything, barrier, write in place, barrier.
-    for (uint32_t w = 1; w < ns; w <<= 1) {  // w = references per group
-        unsigned long long my_key[kPerThread];
-        uint32_t my_pos[kPerThread];
-#pragma unroll
-        for (int j = 0; j < kPerThread; ++j) {
-            const uint32_t e = threadIdx.x + (uint32_t)j * kThreads;
-            if (e >= cap) break;
-            const unsigned long long key = s[e];
-            // group of e: largest g with seg_off[min(ns, g * w)] <= e
-            const uint32_t n_groups = (ns + w - 1) / w;
-            uint32_t lo = 0, hi = n_groups;
+    // merge tree over the runs: at level l the sorted groups are 2^l consecutive references; neighbouring groups are
+    // merged pairwise (merge path): a thread produces K = ceil(cap / 256) CONSECUTIVE outputs — one binary search
+    // along its diagonal finds how many elements of each group precede its first output, then it merges sequentially
+    // (one LDS read per output).  The spans of the groups never change, only the order inside them, so a thread's
+    // first output stays in the pair of the run it started in.  The upper 32 bits of a key are unique: no ties.
+    // Outputs travel through registers: produce everything, barrier, write in place, barrier.
+    {
+        const uint32_t K = (cap + kThreads - 1) / kThreads;  // 1..kPerThread
+        const uint32_t o_begin = threadIdx.x * K;
+        const uint32_t o_end = min(cap, o_begin + K);
+        uint32_t run0 = 0;
+        if (o_begin < cap) {
+            uint32_t lo = 0, hi = ns;
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (seg_off[min(ns, mid * w)] <= e) lo = mid; else hi = mid;
+                if (seg_off[mid] <= o_begin) lo = mid; else hi = mid;
             }
-            const uint32_t g = lo, sib = g ^ 1u;
-            const uint32_t g_start = seg_off[min(ns, g * w)];
-            const uint32_t pair_start = seg_off[min(ns, (g & ~1u) * w)];
-            uint32_t below = 0;
-            if (sib < n_groups) {
-                uint32_t a = seg_off[min(ns, sib * w)], z = seg_off[min(ns, (sib + 1) * w)];
-                const uint32_t a0 = a;
-                while (a < z) {  // lower bound of `key` in the sibling group
-                    const uint32_t mid = (a + z) >> 1;
-                    if (s[mid] < key) a = mid + 1; else z = mid;
+            run0 = lo;
+        }
+        constexpr unsigned long long kEnd = ~0ull;  // above every key (local documents use 15 bits)
+        for (uint32_t lvl = 0; (1u << lvl) < ns && !(b.debug & 1u); ++lvl) {
+            unsigned long long outv[kPerThread];
+            if (o_begin < cap) {
+                uint32_t pair = run0 >> (lvl + 1);
+                uint32_t sa = seg_off[min(ns, (2u * pair) << lvl)];
+                uint32_t sm = seg_off[min(ns, (2u * pair + 1u) << lvl)];
+                uint32_t sb = seg_off[min(ns, (2u * pair + 2u) << lvl)];
+                // merge path: i elements of the left group and diag - i of the right one precede output o_begin
+                const uint32_t diag = o_begin - sa, len_a = sm - sa, len_b = sb - sm;
+                uint32_t lo = diag > len_b ? diag - len_b : 0u, hi = min(diag, len_a);
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s[sa + mid] < s[sm + (diag - 1u - mid)]) lo = mid + 1u; else hi = mid;
                 }
-                below = a - a0;
-            }
-            my_key[j] = key;
-            my_pos[j] = pair_start + (e - g_start) + below;
-        }
-        __syncthreads();
+                uint32_t i = sa + lo, j = sm + (diag - lo);
+                unsigned long long ka = i < sm ? s[i] : kEnd, kb = j < sb ? s[j] : kEnd;
+                uint32_t o = o_begin;
 #pragma unroll
-        for (int j = 0; j < kPerThread; ++j) {
-            const uint32_t e = threadIdx.x + (uint32_t)j * kThreads;
-            if (e >= cap) break;
-            s[my_pos[j]] = my_key[j];
+                for (int n = 0; n < kPerThread; ++n) {
+                    outv[n] = 0ull;
+                    if (o < o_end) {
+                        while (o >= sb) {  // the outputs continue in the next pair, from its beginning
+                            ++pair;
+                            sa = sb;
+                            sm = seg_off[min(ns, (2u * pair + 1u) << lvl)];
+                            sb = seg_off[min(ns, (2u * pair + 2u) << lvl)];
+                            i = sa;
+                            j = sm;
+                            ka = i < sm ? s[i] : kEnd;
+                            kb = j < sb ? s[j] : kEnd;
+                        }
+                        if (kb < ka) {
+                            outv[n] = kb;
+                            ++j;
+                            kb = j < sb ? s[j] : kEnd;
+                        } else {
+                            outv[n] = ka;
+                            ++i;
+                            ka = i < sm ? s[i] : kEnd;
+                        }
+                        ++o;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < kPerThread; ++n)
+                if (o_begin + (uint32_t)n < o_end) s[o_begin + n] = outv[n];
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     if (DF_ONLY) {
@@ -255,7 +282,7 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
         const unsigned long long key = s[e];
         unsigned long long out_key = 0ull;
-        if (e == 0 || key_doc(s[e - 1]) != key_doc(key)) {
+        if (!(b.debug & 2u) && (e == 0 || key_doc(s[e - 1]) != key_doc(key))) {
             // first posting of a document: fold its run (lists of a token in reference order, tokens ascending)
             const uint32_t dl = key_doc(key);
             float score = 0.0f;  // entry(key).or_insert(0.0)

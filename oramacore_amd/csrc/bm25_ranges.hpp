@@ -67,6 +67,7 @@ struct RangeBatch {
     const float* omc_dense = nullptr;
     unsigned long long* keys = nullptr;  // ordered(score) << 32 | ~local doc; 0 = empty
     RangeResult* results = nullptr;
+    uint32_t debug = 0;  // timing ablations (ORAMA_K3R_DBG): 1 skip the merge, 2 skip the fold, 4 stop after the bounds loads
 };
 
 // bounds[query][r][reference] = postings of the reference whose document lies in a range < r.

@@ -600,6 +600,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         rb.omc_dense = (apply_omc && p->has_omc) ? p->d_omc.as<float>() : nullptr;
         rb.keys = sc->misc3.as<unsigned long long>();
         rb.results = sc->misc2.as<RangeResult>();
+        if (const char* e = std::getenv("ORAMA_K3R_DBG")) rb.debug = (uint32_t)std::atoi(e);
         ORAMA_TRY(launch_range_bounds(p->ctx, rb, s));
         ORAMA_TRY(sc->h_out.reserve(out_bytes + 64));
         RangeResult* h_res = sc->h_out.as<RangeResult>();
