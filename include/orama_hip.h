@@ -347,6 +347,21 @@ int orama_post_search_batch(orama_post* p, const orama_post_query_desc* queries,
                             const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc, uint32_t max_parallel,
                             uint32_t stride_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count);
 
+/* Request batcher for full-text searches (the BM25 side of orama_batcher_*).  The reference serves
+ * every request alone (search_full_text is reached from many tokio workers, src/collection_manager/sides/read/
+ * collection.rs:846-884); the range-partitioned scorer takes 32 queries per set of launches, so concurrent callers of
+ * orama_post_batcher_search are coalesced into orama_post_search_batch calls — grouped by the arguments a batch shares:
+ * (allow_bitmap, bitmap_bits, b, apply_omc).  Same arguments, results and errors as orama_post_search; the call blocks
+ * until the request's batch has been scored.  max_batch in [1, 4096]; max_wait_us = 0: no artificial delay (batches
+ * form while the previous one occupies the GPU).  Destroy the batcher before its store. */
+typedef struct orama_post_batcher orama_post_batcher;
+int orama_post_batcher_create(orama_post* p, uint32_t max_batch, uint32_t max_wait_us, orama_post_batcher** out);
+void orama_post_batcher_destroy(orama_post_batcher* b);
+int orama_post_batcher_search(orama_post_batcher* b, const orama_term_ref* refs, uint32_t n_refs, float bm25_b,
+                              const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits,
+                              int apply_omc, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count);
+int orama_post_batcher_stats(orama_post_batcher* b, uint64_t* requests, uint64_t* batches, uint32_t* largest_batch);
+
 /* ------------------------------------------------------------------ score map, facets, groups
  * The reference hands the WHOLE HashMap<DocumentId, f32> of a search to facets and groups
  * (src/collection_manager/sides/read/search.rs:355-400 -> index/facet.rs:35-209, index/group.rs:107-170,

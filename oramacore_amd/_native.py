@@ -170,6 +170,10 @@ def _declare(lib: C.CDLL) -> None:
                               C.c_uint64, C.c_int, vp, vp, u32p, u64p],
         "orama_post_search_batch": [vp, C.POINTER(PostQueryDesc), C.c_uint32, C.c_float, vp, C.c_uint64, C.c_int, C.c_uint32,
                                     C.c_uint32, vp, vp, vp, vp],
+        "orama_post_batcher_create": [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)],
+        "orama_post_batcher_search": [vp, C.POINTER(TermRef), C.c_uint32, C.c_float, C.POINTER(Bm25Params), vp,
+                                      C.c_uint64, C.c_int, vp, vp, u32p, u64p],
+        "orama_post_batcher_stats": [vp, u64p, u64p, u32p],
         "orama_post_search_hybrid": [vp, C.POINTER(TermRef), C.c_uint32, C.c_float, C.POINTER(Bm25Params), vp,
                                      C.c_uint64, vp, vp, C.c_uint32, C.c_int, vp, vp, u32p, u64p],
         "orama_hybrid_search": [vp, vp, vp, C.c_uint32, C.c_float, C.c_int, C.POINTER(TermRef), C.c_uint32, C.c_float,
@@ -227,7 +231,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.orama_shard_group_ctx.argtypes = [vp, C.c_uint32]
     lib.orama_shard_group_ctx.restype = vp
     for name in ("orama_ctx_destroy", "orama_scores_destroy", "orama_facet_field_destroy", "orama_shard_group_destroy", "orama_shard_session_destroy", "orama_vec_destroy", "orama_post_destroy", "orama_post_query_end",
-                 "orama_batcher_destroy", "orama_allow_destroy",
+                 "orama_batcher_destroy", "orama_post_batcher_destroy", "orama_allow_destroy",
                  "orama_dict_destroy"):
         fn = getattr(lib, name)
         fn.argtypes = [vp]

@@ -3,7 +3,8 @@
 // The reference has no batch entry: every HTTP request reaches EmbeddingFieldStorage::search
 // (embedding_field.rs:250-278) alone, on its own tokio worker.  One corpus pass costs the same HBM traffic for 1
 // query as for 64 (K2 is bandwidth-bound), so concurrent single-query callers are coalesced here: callers block in
-// orama_batcher_search, one dispatcher thread turns whatever is pending into ONE orama_vec_search(q = batch).
+// orama_batcher_search, a dispatcher thread turns whatever is pending into ONE orama_vec_search(q = batch); two
+// dispatchers alternate so that the host side of one batch overlaps the corpus pass of the other.
 // No artificial delay by default — batches form naturally while the previous pass occupies the GPU; max_wait_us > 0
 // additionally holds an under-full batch open for that long after its first request.
 //
@@ -38,6 +39,7 @@ struct Request {
     int status = ORAMA_OK;
     std::string error;
     bool done = false;
+    std::condition_variable cv;  // the caller sleeps on its own request: a finished batch wakes exactly its members
 };
 }  // namespace
 
@@ -47,12 +49,16 @@ struct orama_batcher {
     uint32_t max_batch = 64;
     uint32_t max_wait_us = 0;
     std::mutex mu;
-    std::condition_variable cv_work, cv_done;
+    std::condition_variable cv_work;
     std::deque<Request*> pending;
     bool stop = false;
     uint64_t n_requests = 0, n_batches = 0;
     uint32_t largest = 0;
-    std::thread worker;
+    // Two dispatchers alternate.  A corpus pass costs the same for 1 query as for 256, so a batch must be gathered as
+    // LATE as possible: a dispatcher takes `pass_mu` first and only then collects what is pending, runs the pass and
+    // releases it; handing the results out happens outside — beside the other dispatcher's pass.
+    std::mutex pass_mu;
+    std::vector<std::thread> workers;
 
     void run() {
         std::vector<Request*> batch;
@@ -62,6 +68,7 @@ struct orama_batcher {
         std::vector<uint32_t> cnt;
         for (;;) {
             batch.clear();
+            std::unique_lock<std::mutex> pass(pass_mu);
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv_work.wait(lk, [&] { return stop || !pending.empty(); });
@@ -69,6 +76,7 @@ struct orama_batcher {
                 if (max_wait_us && pending.size() < max_batch) {
                     const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_wait_us);
                     cv_work.wait_until(lk, deadline, [&] { return stop || pending.size() >= max_batch; });
+                    if (pending.empty()) continue;  // the other dispatcher took them
                 }
                 // the oldest request decides the filter of this batch; later requests with the same filter join it
                 const uint64_t* allow = pending.front()->allow;
@@ -100,6 +108,7 @@ struct orama_batcher {
                                       dist.data(), cnt.data());
                 if (st != ORAMA_OK) err = orama_last_error();  // this thread's error slot
             }
+            pass.unlock();
             {
                 std::lock_guard<std::mutex> lk(mu);
                 for (uint32_t i = 0; i < q; ++i) {
@@ -113,9 +122,9 @@ struct orama_batcher {
                         *r->out_n = n;
                     }
                     r->done = true;
+                    r->cv.notify_one();
                 }
             }
-            cv_done.notify_all();
         }
     }
 };
@@ -135,7 +144,7 @@ int orama_batcher_create(orama_vec* v, uint32_t max_batch, uint32_t max_wait_us,
     b->dim = vec_dim(v);
     b->max_batch = max_batch;
     b->max_wait_us = max_wait_us;
-    b->worker = std::thread([b] { b->run(); });
+    for (int w = 0; w < 2; ++w) b->workers.emplace_back([b] { b->run(); });
     *out = b;
     return ORAMA_OK;
 }
@@ -147,7 +156,8 @@ void orama_batcher_destroy(orama_batcher* b) {
         b->stop = true;  // pending requests are still served before the dispatcher leaves
     }
     b->cv_work.notify_all();
-    if (b->worker.joinable()) b->worker.join();
+    for (auto& t : b->workers)
+        if (t.joinable()) t.join();
     delete b;
 }
 
@@ -176,13 +186,202 @@ int orama_batcher_search_filtered(orama_batcher* b, const float* query, uint32_t
         ORAMA_REQUIRE(!b->stop, "batcher is shutting down");
         b->pending.push_back(&r);
         b->cv_work.notify_one();
-        b->cv_done.wait(lk, [&] { return r.done; });
+        r.cv.wait(lk, [&] { return r.done; });
     }
     if (r.status != ORAMA_OK) set_error("%s", r.error.c_str());
     return r.status;
 }
 
 int orama_batcher_stats(orama_batcher* b, uint64_t* requests, uint64_t* batches, uint32_t* largest_batch) {
+    ORAMA_REQUIRE(b, "null handle");
+    std::lock_guard<std::mutex> lk(b->mu);
+    if (requests) *requests = b->n_requests;
+    if (batches) *batches = b->n_batches;
+    if (largest_batch) *largest_batch = b->largest;
+    return ORAMA_OK;
+}
+
+}  // extern "C"
+
+// ================================================================= full-text request batcher
+// Same idea for BM25 searches: the reference's tokio workers each call search_full_text alone; K3r (bm25_ranges.hip)
+// scores 32 queries per set of launches, so concurrent single-query callers are coalesced into orama_post_search_batch
+// calls.  Requests are grouped by (filter bitmap, b, apply_omc) — the arguments a batch shares.  Two dispatcher
+// threads alternate, so that the host part of one batch (tables, read-back) overlaps the device part of the other.
+namespace {
+struct PostRequest {
+    orama_post_query_desc desc;
+    float b = 0.75f;
+    const uint64_t* allow = nullptr;
+    uint64_t allow_bits = 0;
+    int apply_omc = 0;
+    uint64_t* out_ids = nullptr;
+    float* out_scores = nullptr;
+    uint32_t* out_n = nullptr;
+    uint64_t* out_count = nullptr;
+    int status = ORAMA_OK;
+    std::string error;
+    bool done = false;
+    std::condition_variable cv;
+};
+}  // namespace
+
+struct orama_post_batcher {
+    orama_post* p = nullptr;
+    uint32_t max_batch = 64;
+    uint32_t max_wait_us = 0;
+    std::mutex mu;
+    std::condition_variable cv_work;
+    std::deque<PostRequest*> pending;
+    bool stop = false;
+    uint64_t n_requests = 0, n_batches = 0;
+    uint32_t largest = 0;
+    std::vector<std::thread> workers;
+
+    void run() {
+        std::vector<PostRequest*> batch;
+        std::vector<orama_post_query_desc> descs;
+        std::vector<uint64_t> ids, counts;
+        std::vector<float> scores;
+        std::vector<uint32_t> ns;
+        for (;;) {
+            batch.clear();
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !pending.empty(); });
+                if (pending.empty() && stop) return;
+                if (max_wait_us && pending.size() < max_batch) {
+                    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_wait_us);
+                    cv_work.wait_until(lk, deadline, [&] { return stop || pending.size() >= max_batch; });
+                    if (pending.empty()) continue;  // the other dispatcher took them
+                }
+                const PostRequest* first = pending.front();
+                for (auto it = pending.begin(); it != pending.end() && batch.size() < max_batch;) {
+                    PostRequest* r = *it;
+                    if (r->allow == first->allow && r->allow_bits == first->allow_bits && r->b == first->b &&
+                        r->apply_omc == first->apply_omc) {
+                        batch.push_back(r);
+                        it = pending.erase(it);
+                    } else {
+                        ++it;
+                    }
+                }
+                n_requests += batch.size();
+                n_batches += 1;
+                largest = std::max<uint32_t>(largest, (uint32_t)batch.size());
+            }
+            const uint32_t q = (uint32_t)batch.size();
+            uint32_t kmax = 0;
+            descs.resize(q);
+            for (uint32_t i = 0; i < q; ++i) {
+                descs[i] = batch[i]->desc;
+                kmax = std::max(kmax, descs[i].params.top_k);
+            }
+            const uint32_t stride = std::max(kmax, 1u);
+            ids.assign((size_t)q * stride, 0);
+            scores.assign((size_t)q * stride, 0.f);
+            ns.assign(q, 0);
+            counts.assign(q, 0);
+            int st = orama_post_search_batch(p, descs.data(), q, batch[0]->b, batch[0]->allow, batch[0]->allow_bits,
+                                             batch[0]->apply_omc, 8, stride, ids.data(), scores.data(), ns.data(), counts.data());
+            std::string err;
+            if (st != ORAMA_OK) err = orama_last_error();  // this thread's error slot
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                for (uint32_t i = 0; i < q; ++i) {
+                    PostRequest* r = batch[i];
+                    r->status = st;
+                    r->error = err;
+                    if (st == ORAMA_OK) {
+                        const uint32_t n = std::min(ns[i], r->desc.params.top_k);
+                        if (n) {
+                            memcpy(r->out_ids, &ids[(size_t)i * stride], (size_t)n * 8);
+                            memcpy(r->out_scores, &scores[(size_t)i * stride], (size_t)n * 4);
+                        }
+                        *r->out_n = n;
+                        if (r->out_count) *r->out_count = counts[i];
+                    }
+                    r->done = true;
+                    r->cv.notify_one();
+                }
+            }
+        }
+    }
+};
+
+extern "C" {
+
+int orama_post_batcher_create(orama_post* p, uint32_t max_batch, uint32_t max_wait_us, orama_post_batcher** out) {
+    ORAMA_REQUIRE(p && out, "null argument");
+    *out = nullptr;
+    ORAMA_REQUIRE(max_batch >= 1 && max_batch <= 4096, "max_batch %u outside [1, 4096]", max_batch);
+    orama_post_batcher* b = new (std::nothrow) orama_post_batcher();
+    if (!b) {
+        set_error("out of host memory");
+        return ORAMA_ERR_OOM;
+    }
+    b->p = p;
+    b->max_batch = max_batch;
+    b->max_wait_us = max_wait_us;
+    for (int w = 0; w < 2; ++w) b->workers.emplace_back([b] { b->run(); });
+    *out = b;
+    return ORAMA_OK;
+}
+
+void orama_post_batcher_destroy(orama_post_batcher* b) {
+    if (!b) return;
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        b->stop = true;  // pending requests are still served before the dispatchers leave
+    }
+    b->cv_work.notify_all();
+    for (auto& t : b->workers)
+        if (t.joinable()) t.join();
+    delete b;
+}
+
+int orama_post_batcher_search(orama_post_batcher* b, const orama_term_ref* refs, uint32_t n_refs, float bm25_b,
+                              const orama_bm25_params* params, const uint64_t* allow_bitmap, uint64_t bitmap_bits,
+                              int apply_omc, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count) {
+    ORAMA_REQUIRE(b && params && out_n, "null argument");
+    *out_n = 0;
+    if (out_count) *out_count = 0;
+    // a malformed request must fail alone, not with the batch it would have joined
+    ORAMA_REQUIRE(n_refs == 0 || refs, "null refs");
+    ORAMA_REQUIRE(params->n_tokens >= 1, "no query tokens");
+    ORAMA_SUPPORT(params->n_tokens <= 64, "n_tokens %u outside [1, 64]", params->n_tokens);
+    ORAMA_SUPPORT(params->top_k <= kSelectMaxK, "top_k %u exceeds the supported maximum %u", params->top_k, kSelectMaxK);
+    ORAMA_REQUIRE(params->top_k == 0 || (out_ids && out_scores), "null output");
+    uint32_t n_lists = 0;
+    ORAMA_TRY(orama_post_info(b->p, nullptr, &n_lists, nullptr, nullptr));
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        ORAMA_REQUIRE(refs[i].token < params->n_tokens, "ref %u: token %u >= n_tokens %u", i, refs[i].token, params->n_tokens);
+        ORAMA_REQUIRE(refs[i].list < n_lists, "ref %u: list %u out of range", i, refs[i].list);
+    }
+    PostRequest r;
+    r.desc.refs = refs;
+    r.desc.n_refs = n_refs;
+    r.desc.params = *params;
+    r.b = bm25_b;
+    r.allow = allow_bitmap;
+    r.allow_bits = allow_bitmap ? bitmap_bits : 0;
+    r.apply_omc = apply_omc ? 1 : 0;
+    r.out_ids = out_ids;
+    r.out_scores = out_scores;
+    r.out_n = out_n;
+    r.out_count = out_count;
+    {
+        std::unique_lock<std::mutex> lk(b->mu);
+        ORAMA_REQUIRE(!b->stop, "batcher is shutting down");
+        b->pending.push_back(&r);
+        b->cv_work.notify_one();
+        r.cv.wait(lk, [&] { return r.done; });
+    }
+    if (r.status != ORAMA_OK) set_error("%s", r.error.c_str());
+    return r.status;
+}
+
+int orama_post_batcher_stats(orama_post_batcher* b, uint64_t* requests, uint64_t* batches, uint32_t* largest_batch) {
     ORAMA_REQUIRE(b, "null handle");
     std::lock_guard<std::mutex> lk(b->mu);
     if (requests) *requests = b->n_requests;

@@ -201,7 +201,8 @@ struct orama_ctx {
     char name[256] = {0};
     orama::Profiler prof;
     std::mutex pool_mu;
-    std::condition_variable pool_cv;
+    std::condition_variable pool_cv, pool_cv_pair;  // callers waiting for one set / for two sets
+    uint32_t waiting_one = 0, waiting_pair = 0;
     std::vector<std::unique_ptr<orama::Scratch>> pool;
     uint32_t leased = 0;  // scratch sets out on lease; bounded by max_inflight (callers beyond it wait their turn)
     uint32_t max_inflight = 32;

@@ -636,3 +636,46 @@ class TermDictionary:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+class PostSearchBatcher:
+    """Request batcher in front of one PostingsStore (orama_post_batcher_*): concurrent single-query callers (threads)
+    are scored 32 at a time by the range-partitioned scorer.  `search` has PostingsStore.search's arguments and
+    results (non-hybrid)."""
+
+    def __init__(self, store: PostingsStore, max_batch: int = 256, max_wait_us: int = 0):
+        self._lib = N.load()
+        self.store = store
+        h = C.c_void_p()
+        N.check(self._lib.orama_post_batcher_create(store._h, int(max_batch), int(max_wait_us), C.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.orama_post_batcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def search(self, refs, n_tokens: int, total_documents: float, top_k: int, threshold=None,
+               allow: AllowBitmap | None = None, apply_omc: bool = True, b: float = B_DEFAULT, k: float = K1_DEFAULT):
+        arr = self.store._refs(refs)
+        params = _params(total_documents, n_tokens, threshold, top_k, k)
+        out_ids = np.zeros(max(top_k, 1), dtype=np.uint64)
+        out_sc = np.zeros(max(top_k, 1), dtype=np.float32)
+        out_n, out_count = C.c_uint32(), C.c_uint64()
+        bm_ptr, bm_bits = allow.ffi_args() if allow is not None else (None, 0)
+        N.check(self._lib.orama_post_batcher_search(self._h, arr, len(refs), b, C.byref(params), bm_ptr, bm_bits,
+                                                    1 if apply_omc else 0, out_ids.ctypes.data, out_sc.ctypes.data,
+                                                    C.byref(out_n), C.byref(out_count)))
+        return out_ids[: out_n.value], out_sc[: out_n.value], out_count.value
+
+    def stats(self) -> dict:
+        r, bt, l = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        N.check(self._lib.orama_post_batcher_stats(self._h, C.byref(r), C.byref(bt), C.byref(l)))
+        return {"requests": r.value, "batches": bt.value, "largest_batch": l.value,
+                "mean_batch": (r.value / bt.value) if bt.value else 0.0}

@@ -73,6 +73,29 @@ for scorer in args.scorers.split(","):
         el = time.perf_counter() - t0
         out[f"batch_callers{callers}"] = callers * len(batch) / el
         print(f"orama_post_search_batch x {callers} callers: {callers * len(batch) / el:9.0f} queries/s", flush=True)
+    # single-query callers through the request batcher (orama_post_batcher_*)
+    if scorer == "k3r":
+        for nt in (8, 32, 128):
+            batcher = ft.PostSearchBatcher(post, max_batch=256)
+            done = [0] * nt
+            per = max(40, 2048 // nt)
+
+            def bw(tid):
+                for i in range(per):
+                    batcher.search(refs[(tid * 131 + i) % len(refs)], T, float(n), k)
+                    done[tid] += 1
+
+            ths = [threading.Thread(target=bw, args=(t,)) for t in range(nt)]
+            t0 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            el = time.perf_counter() - t0
+            st = batcher.stats()
+            batcher.close()
+            out[f"batcher_threads{nt}"] = sum(done) / el
+            print(f"request batcher, {nt:3d} caller threads: {sum(done) / el:9.0f} queries/s (mean batch {st['mean_batch']:.1f})", flush=True)
     # device time per query of the batch path (HIP events around the kernels, one caller)
     ctx.prof_reset()
     ctx.prof_enable(True)

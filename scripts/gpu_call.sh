@@ -1,7 +1,6 @@
 #!/bin/bash
-O=gpurun_out/r02k3r6
+O=gpurun_out/r02pb
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-( time timeout 600 python -m pytest tests/test_bm25_ranges_gpu.py tests/test_fulltext_gpu.py tests/test_random_gpu.py tests/test_post_append_gpu.py tests/test_sharded_fulltext_gpu.py "tests/test_full_size_gpu.py::test_c4_full_size_bm25_bit_exact" -m gpu -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; tail -5 $O/pytest.log
-timeout 300 python scripts/bench_bm25_threads.py --threads 1,8 --scorers k3r > $O/bm25.log 2>&1; grep -v "^{" $O/bm25.log
-ORAMA_K3R_DBG=1 timeout 300 python scripts/bench_bm25_threads.py --threads 0 --batch-callers 1 --scorers k3r > $O/bm25_dbg1.log 2>&1; grep "device time" $O/bm25_dbg1.log | cut -c1-420
+( time timeout 600 python -m pytest tests/test_batcher_gpu.py -m gpu -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+timeout 300 scripts/native/bench_serving vec 10000000 100 8,64,256,512 > $O/serving_vec.log 2>&1; cat $O/serving_vec.log

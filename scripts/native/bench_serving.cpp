@@ -1,0 +1,178 @@
+// bench_serving.cpp — native load generator for the request batchers: T caller threads issue single-query requests
+// through the C ABI, the way the reference's tokio workers call search_full_text / EmbeddingFieldStorage::search
+// (src/collection_manager/sides/read/collection.rs:846-884).  Python threads cannot generate this load (the GIL
+// caps them near 20 K requests/s), hence a C++ driver.
+//   bench_serving bm25 [docs=10000000] [requests_per_thread=400] [threads=1,8,32,128]
+//   bench_serving vec  [rows=10000000] [requests_per_thread=100] [threads=8,64,256,512]   (768 dims, fp16 store, top-100)
+// Build: g++ -O2 -std=c++17 -I include scripts/native/bench_serving.cpp -L oramacore_amd/csrc -lorama_hip -pthread
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "orama_hip.h"
+
+#define CHECK(x)                                                                     \
+    do {                                                                             \
+        if ((x) != ORAMA_OK) {                                                       \
+            fprintf(stderr, "%s failed: %s\n", #x, orama_last_error());              \
+            exit(1);                                                                 \
+        }                                                                            \
+    } while (0)
+
+static std::vector<int> parse_list(const char* s) {
+    std::vector<int> v;
+    for (const char* p = s; *p;) {
+        v.push_back(atoi(p));
+        while (*p && *p != ',') ++p;
+        if (*p) ++p;
+    }
+    return v;
+}
+
+int main(int argc, char** argv) {
+    const std::string mode = argc > 1 ? argv[1] : "bm25";
+    const uint64_t n_docs = argc > 2 ? strtoull(argv[2], nullptr, 10) : 10000000ull;
+    const int per_thread = argc > 3 ? atoi(argv[3]) : 400;
+    const std::vector<int> thread_counts = parse_list(argc > 4 ? argv[4] : "1,8,32,128");
+    orama_ctx* ctx = nullptr;
+    CHECK(orama_ctx_create(0, &ctx));
+    if (mode == "vec") {
+        const uint32_t dim = 768, K = 100, NQ = 512;
+        orama_vec* vec = nullptr;
+        CHECK(orama_vec_create(ctx, dim, ORAMA_METRIC_COSINE, ORAMA_DTYPE_F16, n_docs, &vec));
+        CHECK(orama_vec_fill_synthetic(vec, n_docs, 0x5EED, 0));
+        std::mt19937_64 rng(0xBEEF);
+        std::normal_distribution<float> g(0.f, 1.f);
+        std::vector<float> qv((size_t)NQ * dim);
+        for (auto& x : qv) x = g(rng);
+        printf("vec: %llu x %u fp16 rows, top-%u, single-query requests\n", (unsigned long long)n_docs, dim, K);
+        for (int batched = 0; batched < 2; ++batched) {
+            for (int nt : thread_counts) {
+                if (!batched && nt > 64) continue;  // direct calls: one corpus pass per request
+                orama_batcher* batcher = nullptr;
+                if (batched) CHECK(orama_batcher_create(vec, 256, 0, &batcher));
+                const int count = batched ? per_thread : std::max(4, per_thread / 8);
+                std::atomic<uint64_t> checksum{0};
+                auto worker = [&](int tid, int cnt) {
+                    std::vector<uint64_t> ids(K);
+                    std::vector<float> dist(K);
+                    uint64_t acc = 0;
+                    for (int i = 0; i < cnt; ++i) {
+                        const float* q = &qv[(size_t)((tid * 131 + i) % NQ) * dim];
+                        uint32_t n = 0;
+                        if (batched) CHECK(orama_batcher_search(batcher, q, K, ids.data(), dist.data(), &n));
+                        else CHECK(orama_vec_search(vec, q, 1, K, nullptr, 0, ids.data(), dist.data(), &n));
+                        acc += ids[0];
+                    }
+                    checksum += acc;
+                };
+                worker(0, 3);
+                checksum = 0;
+                std::vector<std::thread> ths;
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int t = 0; t < nt; ++t) ths.emplace_back(worker, t, count);
+                for (auto& t : ths) t.join();
+                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                uint64_t req = 0, bat = 0;
+                uint32_t largest = 0;
+                if (batched) {
+                    CHECK(orama_batcher_stats(batcher, &req, &bat, &largest));
+                    orama_batcher_destroy(batcher);
+                }
+                printf("%-28s %4d caller threads: %9.0f requests/s", batched ? "orama_batcher_search" : "orama_vec_search (direct)", nt,
+                       (double)nt * count / el);
+                if (batched) printf("   (mean batch %.1f, largest %u)", bat ? (double)req / (double)bat : 0.0, largest);
+                printf("   checksum %llu\n", (unsigned long long)checksum.load());
+                fflush(stdout);
+            }
+        }
+        orama_vec_destroy(vec);
+        orama_ctx_destroy(ctx);
+        return 0;
+    }
+    if (mode != "bm25") {
+        fprintf(stderr, "unknown mode %s\n", mode.c_str());
+        return 2;
+    }
+    orama_post* post = nullptr;
+    CHECK(orama_post_create(ctx, &post));
+    // the C4 full-text shape: 2048 posting lists with Zipf ranks log-uniform in [100, 100000], 12 tokens per query
+    std::mt19937_64 rng(0xB26);
+    std::uniform_real_distribution<double> u(std::log(100.0), std::log(100000.0));
+    std::vector<uint32_t> ranks;
+    for (int i = 0; i < 2048; ++i) ranks.push_back((uint32_t)std::exp(u(rng)));
+    std::sort(ranks.begin(), ranks.end());
+    ranks.erase(std::unique(ranks.begin(), ranks.end()), ranks.end());
+    uint64_t total = 0;
+    CHECK(orama_post_fill_synthetic(post, n_docs, 0, (uint32_t)ranks.size(), ranks.data(), 0xB25, &total));
+    const uint32_t T = 12, K = 100, NQ = 512;
+    std::vector<std::vector<orama_term_ref>> queries(NQ);
+    for (auto& q : queries) {
+        std::vector<uint32_t> pick;
+        while (pick.size() < T) {
+            const uint32_t l = (uint32_t)(rng() % ranks.size());
+            if (std::find(pick.begin(), pick.end(), l) == pick.end()) pick.push_back(l);
+        }
+        for (uint32_t t = 0; t < T; ++t) q.push_back(orama_term_ref{t, pick[t], 1.0f});
+    }
+    orama_bm25_params params;
+    memset(&params, 0, sizeof(params));
+    params.total_documents = (float)n_docs;
+    params.n_tokens = T;
+    params.top_k = K;
+    params.k = 1.2f;
+    printf("bm25: %llu docs, %zu lists, %llu postings resident, %u tokens per query, top-%u\n", (unsigned long long)n_docs,
+           ranks.size(), (unsigned long long)total, T, K);
+
+    for (int batched = 0; batched < 2; ++batched) {
+        for (int nt : thread_counts) {
+            orama_post_batcher* batcher = nullptr;
+            if (batched) CHECK(orama_post_batcher_create(post, 256, 0, &batcher));
+            std::atomic<uint64_t> checksum{0};
+            auto worker = [&](int tid, int count) {
+                std::vector<uint64_t> ids(K);
+                std::vector<float> sc(K);
+                uint64_t acc = 0;
+                for (int i = 0; i < count; ++i) {
+                    const auto& q = queries[(size_t)(tid * 131 + i) % NQ];
+                    uint32_t n = 0;
+                    uint64_t cnt = 0;
+                    if (batched) CHECK(orama_post_batcher_search(batcher, q.data(), T, 0.75f, &params, nullptr, 0, 1, ids.data(), sc.data(), &n, &cnt));
+                    else CHECK(orama_post_search(post, q.data(), T, 0.75f, &params, nullptr, 0, 1, ids.data(), sc.data(), &n, &cnt));
+                    acc += ids[0] + cnt;
+                }
+                checksum += acc;
+            };
+            worker(0, 20);  // warm-up
+            const uint64_t warm = checksum.exchange(0);
+            (void)warm;
+            std::vector<std::thread> ths;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int t = 0; t < nt; ++t) ths.emplace_back(worker, t, per_thread);
+            for (auto& t : ths) t.join();
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            uint64_t req = 0, bat = 0;
+            uint32_t largest = 0;
+            if (batched) {
+                CHECK(orama_post_batcher_stats(batcher, &req, &bat, &largest));
+                orama_post_batcher_destroy(batcher);
+            }
+            printf("%-28s %4d caller threads: %9.0f requests/s", batched ? "orama_post_batcher_search" : "orama_post_search (direct)", nt,
+                   (double)nt * per_thread / el);
+            if (batched) printf("   (mean batch %.1f, largest %u)", bat ? (double)req / (double)bat : 0.0, largest);
+            printf("   checksum %llu\n", (unsigned long long)checksum.load());
+            fflush(stdout);
+        }
+    }
+    orama_post_destroy(post);
+    orama_ctx_destroy(ctx);
+    return 0;
+}

@@ -209,3 +209,52 @@ def test_appended_lists_and_dense_ids(ctx):
     assert first == 6
     check(ctx, corpus, [(0, 0, 1.0), (0, 6, 1.0), (1, 7, 2.0), (2, 8, 1.0), (2, 3, 1.0)], 3, 500, tag="append")
     corpus.store.close()
+
+
+def test_request_batcher_equals_direct_searches(ctx):
+    """orama_post_batcher_*: 16 threads of single-query requests (two filters, different k, thresholds) are coalesced
+    into batches; every answer equals the direct orama_post_search of the same request and the oracle's."""
+    import threading
+
+    rng = np.random.default_rng(11)
+    n_docs = 30_000
+    corpus = Corpus(ctx, n_docs, random_lists(rng, n_docs, 30, 2, 50, 4000), [70.0, 11.0], seed=12)
+    allow_mask = rng.random(n_docs) < 0.7
+    bm = oa.AllowBitmap(n_docs, np.nonzero(allow_mask)[0].astype(np.uint64))
+    reqs = []
+    for i in range(160):
+        n_tok = int(rng.integers(1, 6))
+        refs = [(t, int(rng.integers(0, 30)), 1.0) for t in range(n_tok) for _ in range(int(rng.integers(1, 3)))]
+        reqs.append((refs, n_tok, None if i % 3 else 1, int(rng.choice([1, 10, 50])), i % 2 == 1))
+    batcher = ft.PostSearchBatcher(corpus.store, max_batch=64)
+    got = [None] * len(reqs)
+    errors = []
+
+    def worker(t):
+        try:
+            for i in range(t, len(reqs), 16):
+                refs, n_tok, thr, k, filt = reqs[i]
+                got[i] = batcher.search(refs, n_tok, float(n_docs), k, thr, allow=bm if filt else None)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    for (refs, n_tok, thr, k, filt), (ids, sc, count) in zip(reqs, got):
+        od, os_, ocount = corpus.oracle(refs, n_tok, k, thr, allow_mask if filt else None)
+        assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
+        d_ids, d_sc, d_count = corpus.store.search(refs, n_tok, float(n_docs), k, thr, allow=bm if filt else None)
+        assert d_count == count and d_ids.tolist() == ids.tolist() and np.array_equal(bits(d_sc), bits(sc))
+    st = batcher.stats()
+    assert st["requests"] == len(reqs) and st["batches"] <= len(reqs)
+    # a malformed request fails alone
+    with pytest.raises(oa.OramaError):
+        batcher.search([(3, 0, 1.0)], 2, float(n_docs), 10)
+    ids, sc, count = batcher.search([(0, 0, 1.0)], 1, float(n_docs), 5)
+    assert len(ids) == 5
+    batcher.close()
+    corpus.store.close()
