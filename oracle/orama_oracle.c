@@ -302,7 +302,8 @@ uint64_t orc_search_full_text(const orc_entry* entries, uint32_t n_entries, uint
         float idf = orc_bm25_idf(total_documents, df);
         for (uint64_t i = 0; i < m;) {
             uint64_t j = i;
-            float s = 0.0f; /* Iterator::sum::<f32>() starts from 0.0 */
+            float s = 0.0f; /* Iterator::sum::<f32>(): folds from 0.0 (from -0.0 since Rust 1.83 — the same value for
+                             * every sum that matters here: a sum that stays +-0.0 is not `is_normal` and is skipped) */
             while (j < m && buf[j].doc == buf[i].doc) {
                 s = s + 1.0f * buf[j].ntf; /* contrib.weight * contrib.normalized_tf, weight = 1.0 */
                 ++j;

@@ -194,6 +194,17 @@ int resolve_allow(orama_ctx* ctx, Scratch* sc, const uint64_t* allow_bitmap, uin
 }
 }  // namespace orama
 
+namespace {
+__global__ void allow_set_kernel(unsigned long long* __restrict__ words, const uint64_t* __restrict__ ids, uint64_t n, bool allowed) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t id = ids[i];
+        const unsigned long long bit = 1ull << (id & 63);
+        if (allowed) atomicOr(&words[id >> 6], bit);
+        else atomicAnd(&words[id >> 6], ~bit);
+    }
+}
+}  // namespace
+
 // Resident allow-bitmap: the materialised FilterResult<DocumentId> kept in HBM.
 struct orama_allow {
     orama_ctx* ctx = nullptr;
@@ -243,18 +254,25 @@ const uint64_t* orama_allow_token(const orama_allow* a) {
 
 int orama_allow_set(orama_allow* a, const uint64_t* doc_ids, uint64_t n, int allowed) {
     ORAMA_REQUIRE(a && (n == 0 || doc_ids), "null argument");
+    if (n == 0) return ORAMA_OK;
     ORAMA_HIP_TRY(hipSetDevice(a->ctx->device));
-    // read-modify-write of the touched words (n is small: the documents deleted / re-admitted since the last call)
-    for (uint64_t i = 0; i < n; ++i) {
+    for (uint64_t i = 0; i < n; ++i)
         ORAMA_REQUIRE(doc_ids[i] < a->bits, "doc id %llu outside the bitmap (%llu bits)",
                       (unsigned long long)doc_ids[i], (unsigned long long)a->bits);
-        uint64_t w = 0;
-        uint64_t* dw = a->words.as<uint64_t>() + (doc_ids[i] >> 6);
-        ORAMA_HIP_TRY(hipMemcpy(&w, dw, 8, hipMemcpyDeviceToHost));
-        const uint64_t bit = 1ull << (doc_ids[i] & 63);
-        w = allowed ? (w | bit) : (w & ~bit);
-        ORAMA_HIP_TRY(hipMemcpy(dw, &w, 8, hipMemcpyHostToDevice));
-    }
+    // one upload + one kernel of atomic bit updates: searches reading the bitmap meanwhile see each document either
+    // way, as a reader of the reference's filter sees a delete before or after it (index/filter.rs:344-392)
+    orama::ScratchLease sc(a->ctx);
+    ORAMA_TRY(sc.init());
+    hipStream_t s = sc->stream;
+    ORAMA_TRY(sc->h_in.reserve((size_t)n * 8));
+    ORAMA_TRY(sc->misc0.reserve((size_t)n * 8));
+    memcpy(sc->h_in.p, doc_ids, (size_t)n * 8);
+    ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, sc->h_in.p, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(allow_set_kernel, dim3(blocks), dim3(256), 0, s, a->words.as<unsigned long long>(),
+                       sc->misc0.as<uint64_t>(), n, allowed != 0);
+    ORAMA_HIP_TRY(hipGetLastError());
+    ORAMA_HIP_TRY(hipStreamSynchronize(s));
     return ORAMA_OK;
 }
 

@@ -3,6 +3,7 @@
 // (src/collection_manager/sides/read/collection.rs:846-884).  Python threads cannot generate this load (the GIL
 // caps them near 20 K requests/s), hence a C++ driver.
 //   bench_serving bm25 [docs=10000000] [requests_per_thread=400] [threads=1,8,32,128]
+//   bench_serving hybrid [docs=10000000] [requests_per_thread=30] [threads=1,8,32,64]   (fp32 vectors + BM25F, min-max merge)
 //   bench_serving vec  [rows=10000000] [requests_per_thread=100] [threads=8,64,256,512]   (768 dims, fp16 store, top-100)
 // Build: g++ -O2 -std=c++17 -I include scripts/native/bench_serving.cpp -L oramacore_amd/csrc -lorama_hip -pthread
 #include <algorithm>
@@ -98,7 +99,8 @@ int main(int argc, char** argv) {
         orama_ctx_destroy(ctx);
         return 0;
     }
-    if (mode != "bm25") {
+    const bool hybrid = mode == "hybrid";
+    if (mode != "bm25" && !hybrid) {
         fprintf(stderr, "unknown mode %s\n", mode.c_str());
         return 2;
     }
@@ -132,6 +134,68 @@ int main(int argc, char** argv) {
     printf("bm25: %llu docs, %zu lists, %llu postings resident, %u tokens per query, top-%u\n", (unsigned long long)n_docs,
            ranks.size(), (unsigned long long)total, T, K);
 
+    if (hybrid) {
+        const uint32_t dim = 768;
+        orama_vec* vec = nullptr;
+        CHECK(orama_vec_create(ctx, dim, ORAMA_METRIC_COSINE, ORAMA_DTYPE_F32, n_docs, &vec));
+        CHECK(orama_vec_fill_synthetic(vec, n_docs, 0x5EED, 0));
+        std::normal_distribution<float> g(0.f, 1.f);
+        std::vector<float> qv((size_t)NQ * dim);
+        for (auto& x : qv) x = g(rng);
+        printf("hybrid: + %llu x %u fp32 rows; a request = vector top-%u + BM25F + min-max merge + top-%u\n", (unsigned long long)n_docs, dim, K, K);
+        for (int batched = 0; batched < 2; ++batched) {
+            for (int nt : thread_counts) {
+                orama_batcher* vb = nullptr;
+                if (batched) CHECK(orama_batcher_create(vec, 8, 0, &vb));  // fp32: K1b shares a corpus pass among <= 8 queries
+                std::atomic<uint64_t> checksum{0};
+                auto worker = [&](int tid, int cnt) {
+                    std::vector<uint64_t> ids(K), vid(K);
+                    std::vector<float> sc(K), vd(K);
+                    uint64_t acc = 0;
+                    for (int i = 0; i < cnt; ++i) {
+                        const size_t qi = (size_t)(tid * 131 + i) % NQ;
+                        const auto& q = queries[qi];
+                        uint32_t n = 0;
+                        uint64_t c = 0;
+                        if (!batched) {
+                            CHECK(orama_hybrid_search(vec, post, &qv[qi * dim], K, 0.0f, 0, q.data(), T, 0.75f, &params, nullptr, 0, 1,
+                                                      ids.data(), sc.data(), &n, &c));
+                        } else {
+                            uint32_t nv = 0;
+                            CHECK(orama_batcher_search(vb, &qv[qi * dim], K, vid.data(), vd.data(), &nv));
+                            for (uint32_t j = 0; j < nv; ++j) vd[j] = 1.0f - vd[j];  // a2 epilogue: one row per document here
+                            CHECK(orama_post_search_hybrid(post, q.data(), T, 0.75f, &params, nullptr, 0, vid.data(), vd.data(), nv, 1,
+                                                           ids.data(), sc.data(), &n, &c));
+                        }
+                        acc += ids[0] + c;
+                    }
+                    checksum += acc;
+                };
+                worker(0, 3);
+                checksum = 0;
+                std::vector<std::thread> ths;
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int t = 0; t < nt; ++t) ths.emplace_back(worker, t, per_thread);
+                for (auto& t : ths) t.join();
+                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                uint64_t req = 0, bat = 0;
+                uint32_t largest = 0;
+                if (batched) {
+                    CHECK(orama_batcher_stats(vb, &req, &bat, &largest));
+                    orama_batcher_destroy(vb);
+                }
+                printf("%-46s %4d caller threads: %8.0f requests/s", batched ? "vector batcher + orama_post_search_hybrid" : "orama_hybrid_search (one call per request)",
+                       nt, (double)nt * per_thread / el);
+                if (batched) printf("   (mean vector batch %.1f)", bat ? (double)req / (double)bat : 0.0);
+                printf("   checksum %llu\n", (unsigned long long)checksum.load());
+                fflush(stdout);
+            }
+        }
+        orama_vec_destroy(vec);
+        orama_post_destroy(post);
+        orama_ctx_destroy(ctx);
+        return 0;
+    }
     for (int batched = 0; batched < 2; ++batched) {
         for (int nt : thread_counts) {
             orama_post_batcher* batcher = nullptr;
