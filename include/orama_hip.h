@@ -62,6 +62,13 @@ extern "C" {
  * end, src/collection_manager/sides/operation/op.rs:144); f16 is a build-side extension. */
 #define ORAMA_DTYPE_F32 0
 #define ORAMA_DTYPE_F16 1
+/* fp32 rows PLUS an fp16 copy of the same rows ("shadow", +50 % HBM): orama_vec_search (and the request batcher on top
+ * of it) runs in two stages — the shadow scan (half the bytes; MFMA for query batches) proposes max(2k, k + 128)
+ * candidates, the fp32 rows give their exact distances and the final order.  The answer is the fp32 scan's, bit for bit:
+ * a query whose candidate list cannot be PROVEN to contain the exact top-k (error bound of the fp16 image, see
+ * DESIGN §4 K1s) is answered by the plain fp32 scan instead.  Cosine metric, dimensions % 4 == 0 and <= 1024, k <= 2048;
+ * outside that, and for the *_device entry points, the store behaves as ORAMA_DTYPE_F32. */
+#define ORAMA_DTYPE_F32_SHADOW16 2
 
 typedef struct orama_ctx orama_ctx;   /* one per GPU: device ordinal, stream + scratch pools */
 typedef struct orama_vec orama_vec;   /* one per embedding field  (EmbeddingFieldStorage) */
@@ -90,6 +97,8 @@ int orama_ctx_set_f16_wide(orama_ctx* ctx, int mode);
  * partitioned scorer that takes whole query batches per launch (bm25_ranges.hip); 0 = K3, per-document records in HBM
  * (bm25_kernels.hip), which the hybrid / score-map / precomputed-ntf entry points always use.  Same results bit for bit. */
 int orama_ctx_set_bm25_ranges(orama_ctx* ctx, int on);
+/* ORAMA_DTYPE_F32_SHADOW16 stores: 1 (default) = two-stage search, 0 = always the plain fp32 scan (same results). */
+int orama_ctx_set_two_stage(orama_ctx* ctx, int on);
 
 /* Per-kernel HIP-event timing (used by bench.py's roofline leg).  When enabled, the library
  * brackets each launch of the named hot kernels with hipEvents on the launching stream.
@@ -139,7 +148,9 @@ typedef struct {
     uint64_t num_rows;       /* live + tombstoned rows resident in HBM */
     uint64_t pending_ops;    /* tombstones not yet compacted */
     uint64_t version;
-    uint64_t hbm_bytes;      /* bytes of HBM held by this store */
+    uint64_t hbm_bytes;      /* bytes of HBM held by this store (incl. its fp16 shadow) */
+    uint64_t two_stage_queries;   /* ORAMA_DTYPE_F32_SHADOW16: queries answered by the two-stage plan ... */
+    uint64_t two_stage_fallbacks; /* ... of which the candidate list could not be proven complete (fp32 scan instead) */
 } orama_vec_info_t;
 int orama_vec_info(orama_vec* v, orama_vec_info_t* out);
 

@@ -22,6 +22,7 @@ METRIC_COSINE = 0
 METRIC_L2SQ = 1
 DTYPE_F32 = 0
 DTYPE_F16 = 1
+DTYPE_F32_SHADOW16 = 2
 
 HEADER = Path(__file__).resolve().parent.parent / "include" / "orama_hip.h"
 
@@ -43,6 +44,8 @@ class VecInfo(C.Structure):
         ("pending_ops", C.c_uint64),
         ("version", C.c_uint64),
         ("hbm_bytes", C.c_uint64),
+        ("two_stage_queries", C.c_uint64),
+        ("two_stage_fallbacks", C.c_uint64),
     ]
 
 
@@ -126,6 +129,7 @@ def _declare(lib: C.CDLL) -> None:
         "orama_ctx_set_f16_tuning": [vp, C.c_int, C.c_int],
         "orama_ctx_set_f16_wide": [vp, C.c_int],
         "orama_ctx_set_bm25_ranges": [vp, C.c_int],
+        "orama_ctx_set_two_stage": [vp, C.c_int],
         "orama_prof_enable": [vp, C.c_int],
         "orama_prof_reset": [vp],
         "orama_prof_get": [vp, C.c_char_p, C.POINTER(C.c_double), u64p],

@@ -195,6 +195,9 @@ struct orama_ctx {
     // plain BM25 top-k searches of a resident store use the range-partitioned scorer (K3r, bm25_ranges.hip);
     // 0 = always the per-document-record scorer K3 (ORAMA_BM25_RANGES, orama_ctx_set_bm25_ranges)
     int bm25_ranges = 1;
+    // stores created as ORAMA_DTYPE_F32_SHADOW16 answer orama_vec_search in two stages (fp16 candidates, fp32 decision);
+    // 0 = always the plain fp32 scan (ORAMA_TWO_STAGE, orama_ctx_set_two_stage)
+    int two_stage = 1;
     int f16_kc = 8, f16_nbuf = 3;   // K2 register ring: k-steps per chunk, chunks (ORAMA_F16_KC / ORAMA_F16_NBUF)
     int compute_units = 0;
     uint64_t hbm_bytes = 0;

@@ -305,6 +305,7 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
     if (const char* e = std::getenv("ORAMA_F32_MULTI")) c->f32_multi = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_WIDE")) c->f16_wide = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_BM25_RANGES")) c->bm25_ranges = std::atoi(e) != 0;
+    if (const char* e = std::getenv("ORAMA_TWO_STAGE")) c->two_stage = std::atoi(e) != 0;
     if (const char* e = std::getenv("ORAMA_F16_KC")) c->f16_kc = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_NBUF")) c->f16_nbuf = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_MAX_INFLIGHT")) c->max_inflight = (uint32_t)std::max(2, std::atoi(e));
@@ -414,6 +415,12 @@ int orama_stream_synchronize(orama_ctx* ctx, void* stream) {
     ORAMA_REQUIRE(ctx, "null ctx");
     ORAMA_HIP_TRY(hipSetDevice(ctx->device));
     ORAMA_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return ORAMA_OK;
+}
+
+int orama_ctx_set_two_stage(orama_ctx* ctx, int on) {
+    ORAMA_REQUIRE(ctx, "null context");
+    ctx->two_stage = on != 0;
     return ORAMA_OK;
 }
 

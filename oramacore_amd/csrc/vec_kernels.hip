@@ -370,6 +370,102 @@ uint32_t grid_for_rows(uint64_t n_rows_per_wave_units, uint32_t cap) {
 }  // namespace
 
 namespace {
+// ---------------------------------------------------------------- exact re-scoring of candidate rows (two-stage search)
+// One wave per (query, candidate): the distance K1's vectorised kernel computes for that (row, query) — the same
+// lane -> column mapping (lane l holds the 16-byte pieces l, l + 64, ...), the same per-lane fma chain, the same wave_sum
+// tree, the same final expression — so the value is bit-identical to a K1 scan of that row (tests compare them).
+// Cosine only, dim % 4 == 0 and dim <= 1024 (the K1 geometry this mirrors).
+__global__ __launch_bounds__(kScanThreads) void rerank_f32_kernel(const float* __restrict__ corpus,
+                                                                  const float* __restrict__ inv_norm, uint32_t dim,
+                                                                  const float* __restrict__ queries, uint32_t q,
+                                                                  const uint32_t* __restrict__ cand_rows,
+                                                                  const uint32_t* __restrict__ cand_n, uint32_t stride,
+                                                                  float* __restrict__ out_dist) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint32_t qi = (uint32_t)(wave / stride), ci = (uint32_t)(wave % stride);
+    if (qi >= q) return;
+    const uint32_t d4 = dim >> 2;
+    const uint32_t nchunk = (d4 + kWave - 1) / kWave;
+    if (ci >= cand_n[qi]) {
+        if (lane == 0) out_dist[(uint64_t)qi * stride + ci] = __builtin_nanf("");
+        return;
+    }
+    const uint64_t row = cand_rows[(uint64_t)qi * stride + ci];
+    const f32x4* __restrict__ qp = reinterpret_cast<const f32x4*>(queries + (uint64_t)qi * dim);
+    const f32x4* __restrict__ xp = reinterpret_cast<const f32x4*>(corpus) + row * d4;
+    float qq = 0.0f, acc = 0.0f;
+    f32x4 qv[4], xv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t f = (uint32_t)c * kWave + lane;
+        const bool ok = (uint32_t)c < nchunk && f < d4;
+        qv[c] = ok ? qp[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+        xv[c] = ok ? xp[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if ((uint32_t)c >= nchunk) break;
+        qq = fmaf(qv[c].x, qv[c].x, qq);
+        qq = fmaf(qv[c].y, qv[c].y, qq);
+        qq = fmaf(qv[c].z, qv[c].z, qq);
+        qq = fmaf(qv[c].w, qv[c].w, qq);
+    }
+    qq = wave_sum(qq);
+    const float qscale = qq > 0.0f ? 1.0f / sqrtf(qq) : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if ((uint32_t)c >= nchunk) break;
+        acc = fmaf(xv[c].x, qv[c].x, acc);
+        acc = fmaf(xv[c].y, qv[c].y, acc);
+        acc = fmaf(xv[c].z, qv[c].z, acc);
+        acc = fmaf(xv[c].w, qv[c].w, acc);
+    }
+    const float tot = wave_sum(acc);
+    const float inv = inv_norm[row];
+    const float dist = 1.0f - tot * (inv * qscale);
+    if (lane == 0) out_dist[(uint64_t)qi * stride + ci] = dist;
+}
+
+// flag[j] = 1 when the candidate list of query j may miss a row of the exact top-k: the list is full (n == k1) and its
+// last shadow distance lies within `band` of the k-th one.  shadow_dist: ascending per query.
+__global__ void shadow_band_kernel(const float* __restrict__ shadow_dist, const uint32_t* __restrict__ n, uint32_t q,
+                                   uint32_t k, uint32_t k1, float band, uint32_t* __restrict__ flag) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= q) return;
+    uint32_t f = 0;
+    if (n[j] >= k1 && k1 > 0) {
+        const float tau = shadow_dist[(uint64_t)j * k1 + (k - 1)];
+        const float last = shadow_dist[(uint64_t)j * k1 + (k1 - 1)];
+        f = !(last > tau + band);  // also when either is NaN
+    }
+    flag[j] = f;
+}
+}  // namespace
+
+bool vec_rerank_f32_supported(uint32_t dim) { return (dim & 3) == 0 && (dim >> 2) <= 4 * kWave; }
+
+int launch_rerank_f32(const float* corpus, const float* inv_norm, uint32_t dim, const float* d_queries, uint32_t q,
+                      const uint32_t* d_cand_rows, const uint32_t* d_cand_n, uint32_t stride, float* d_out_dist,
+                      hipStream_t stream) {
+    ORAMA_REQUIRE(vec_rerank_f32_supported(dim), "rerank: dim %u not on the vectorised K1 path", dim);
+    if (q == 0 || stride == 0) return ORAMA_OK;
+    const uint64_t waves = (uint64_t)q * stride;
+    const uint64_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(rerank_f32_kernel, dim3((uint32_t)blocks), dim3(kScanThreads), 0, stream, corpus, inv_norm, dim, d_queries,
+                       q, d_cand_rows, d_cand_n, stride, d_out_dist);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_shadow_band(const float* d_shadow_dist, const uint32_t* d_n, uint32_t q, uint32_t k, uint32_t k1, float band,
+                       uint32_t* d_flag, hipStream_t stream) {
+    hipLaunchKernelGGL(shadow_band_kernel, dim3((q + 63) / 64), dim3(64), 0, stream, d_shadow_dist, d_n, q, k, k1, band, d_flag);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+namespace {
 // geometry shared by the launcher and vec_scan_f32_waves()
 struct ScanGeom {
     bool vec4;

@@ -55,6 +55,15 @@ int launch_synth_fill_f32(float* corpus, uint64_t first, uint64_t n, uint32_t di
 int launch_gather_rows_f32(const float* corpus, const uint64_t* d_row_idx, uint64_t n, uint32_t dim,
                            float* d_out, hipStream_t stream);
 
+// Two-stage exact search (fp32 rows + fp16 shadow): exact K1 distances of candidate rows, and the check that the
+// candidate lists cannot miss a row of the exact top-k (vec_store.hip).
+bool vec_rerank_f32_supported(uint32_t dim);
+int launch_rerank_f32(const float* corpus, const float* inv_norm, uint32_t dim, const float* d_queries, uint32_t q,
+                      const uint32_t* d_cand_rows, const uint32_t* d_cand_n, uint32_t stride, float* d_out_dist,
+                      hipStream_t stream);
+int launch_shadow_band(const float* d_shadow_dist, const uint32_t* d_n, uint32_t q, uint32_t k, uint32_t k1, float band,
+                       uint32_t* d_flag, hipStream_t stream);
+
 // ids[i] = first + i
 int launch_iota_u64(uint64_t* d_ids, uint64_t n, uint64_t first, hipStream_t stream);
 

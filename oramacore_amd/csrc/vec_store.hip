@@ -239,6 +239,16 @@ struct orama_vec {
     uint64_t cap_rows = 0;            // rows the arrays can hold without growing
     uint64_t version = 0;
 
+    // Two-stage exact search (ORAMA_DTYPE_F32_SHADOW16): an fp16 copy of the same rows in the same order (an ordinary
+    // fp16 store owned by this one) proposes candidates, the fp32 rows decide.  Every mutation goes to the shadow first,
+    // then here, under composite_mu; `shadow_ok` drops to false for good when a row is inserted whose fp16 image
+    // carries no error bound (tiny norm / element beyond the fp16 range): searches then scan the fp32 rows.
+    std::unique_ptr<orama_vec> shadow;
+    std::mutex composite_mu;
+    std::shared_mutex composite_rw;  // shared: two-stage searches; exclusive: compaction of BOTH copies (row indices must agree)
+    std::atomic<bool> shadow_ok{true};
+    std::atomic<uint64_t> two_stage_queries{0}, two_stage_fallbacks{0};
+
     // scratch for the device-pointer entry point, one per caller stream
     std::mutex dev_mu;
     std::map<hipStream_t, std::unique_ptr<Scratch>> dev_scratch;
@@ -485,7 +495,7 @@ int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_
 // candidate appends (expected k·ln(N/S1) per query on unordered data).
 int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
-                       uint32_t* d_out_n, hipStream_t s) {
+                       uint32_t* d_out_n, hipStream_t s, uint32_t* d_out_rows = nullptr) {
     const uint64_t n = w.n_rows;
     constexpr uint64_t kS1 = 131072;                 // dense head (rows), multiple of 32
     constexpr uint64_t kCandBudget = 6ull << 30;     // bytes of candidate lists per pass
@@ -564,6 +574,7 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
         if (only_head) {
             p.id_map = w.row_doc;
             p.out_ids = out_ids;
+            p.out_idx = d_out_rows ? d_out_rows + (size_t)q0 * k : nullptr;
             p.out_val = out_dist;
             p.out_n = out_n;
             ORAMA_TRY(launch_select(v->ctx, p, s));
@@ -604,6 +615,7 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
             if (r1 == n) {  // 3. final reduction: ids + final tie order
                 c.id_map = w.row_doc;
                 c.out_ids = out_ids;
+                c.out_idx = d_out_rows ? d_out_rows + (size_t)q0 * k : nullptr;
                 c.out_val = out_dist;
             } else {
                 c.out_idx = best_row;
@@ -634,6 +646,72 @@ int search_enqueue(orama_vec* v, Scratch* sc, const float* d_queries, uint32_t q
                                          d_out_n, s, two_streams ? s_scan : s);
 }
 
+// ---------------------------------------------------------------- two-stage exact search (fp32 rows + fp16 shadow)
+// Stage 1: the fp16 shadow (same rows, same order, half the bytes, MFMA for batches) returns the k1 = max(2k, k + 128)
+// best rows by its approximate distance.  |shadow - exact| <= eps for every row (both operands rounded to fp16:
+// elementwise relative error 2^-11, and the shadow's norms come from the rounded rows: <= 2^-9 on the cosine, plus the
+// f32 accumulation), so every row of the exact top-k has a shadow distance <= tau + 2 eps, tau = the k-th best shadow
+// distance: the candidate list is COMPLETE when it is not full or its last entry lies beyond tau + 2 eps
+// (shadow_band_kernel); otherwise the query is flagged and answered by the plain fp32 scan.
+// Stage 2: K1's own arithmetic on the candidate rows (rerank_f32_kernel: bit-identical distances), then K4 with the
+// same tie rule as the one-stage path.  The answer equals the fp32 scan's bit for bit.
+constexpr float kShadowEps = 2.5e-3f;
+
+int two_stage_search(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k,
+                     const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n,
+                     hipStream_t s, uint8_t* h_redo) {
+    orama_vec* sh = v->shadow.get();
+    std::shared_lock<std::shared_mutex> both(v->composite_rw);
+    std::shared_lock<std::shared_mutex> sl(sh->mu);
+    const View w = snapshot(v);
+    View ws = snapshot(sh);
+    ws.n_rows = std::min(ws.n_rows, w.n_rows);  // the shadow is written first: it may already hold unpublished rows
+    if (ws.n_rows == 0) {
+        ORAMA_HIP_TRY(hipMemsetAsync(d_out_n, 0, (size_t)q * 4, s));
+        return ORAMA_OK;
+    }
+    const uint32_t k1 = (uint32_t)std::min<uint64_t>(kSelectMaxK, std::max<uint64_t>(2ull * k, (uint64_t)k + 128));
+    // stage 1 works in the second scratch set (the fp16 pipeline uses most buffers of one)
+    const size_t n1 = (size_t)q * k1;
+    ORAMA_TRY(sc2->out_ids.reserve(n1 * 8));
+    ORAMA_TRY(sc2->out_val.reserve(n1 * 4));
+    ORAMA_TRY(sc2->out_idx.reserve(n1 * 4));
+    ORAMA_TRY(sc2->out_n.reserve((size_t)q * 4 * 2));
+    uint32_t* d_n1 = sc2->out_n.as<uint32_t>();
+    uint32_t* d_flag = d_n1 + q;
+    ORAMA_TRY(search_enqueue_f16(sh, ws, sc2.s.get(), d_queries, q, k1, d_allow, allow_bits, sc2->out_ids.as<uint64_t>(),
+                                 sc2->out_val.as<float>(), d_n1, s, sc2->out_idx.as<uint32_t>()));
+    ORAMA_TRY(launch_shadow_band(sc2->out_val.as<float>(), d_n1, q, k, k1, 2.0f * kShadowEps, d_flag, s));
+    // stage 2: exact distances of the candidates, then the final order
+    ORAMA_TRY(sc->dist.reserve(n1 * 4));
+    ORAMA_TRY(launch_rerank_f32(static_cast<const float*>(w.rows), w.inv_norm, v->dim, d_queries, q, sc2->out_idx.as<uint32_t>(),
+                                d_n1, k1, sc->dist.as<float>(), s));
+    ORAMA_TRY(sc->sel_state.reserve(sizeof(SelectState) * (size_t)q));
+    ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * (size_t)q * k));
+    SelectPlan p;
+    p.vals = sc->dist.as<float>();
+    p.idx = sc2->out_idx.as<uint32_t>();
+    p.stride = k1;
+    p.n_dev = d_n1;
+    p.n = k1;
+    p.q = q;
+    p.k = k;
+    p.descending = false;
+    p.id_map = w.row_doc;
+    p.state = sc->sel_state.as<SelectState>();
+    p.keys = sc->sel_keys.as<unsigned long long>();
+    p.out_ids = d_out_ids;
+    p.out_val = d_out_dist;
+    p.out_n = d_out_n;
+    ORAMA_TRY(launch_select(v->ctx, p, s));
+    ORAMA_TRY(sc2->h_out.reserve((size_t)q * 4));
+    ORAMA_HIP_TRY(hipMemcpyAsync(sc2->h_out.p, d_flag, (size_t)q * 4, hipMemcpyDeviceToHost, s));
+    ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t* hf = sc2->h_out.as<uint32_t>();
+    for (uint32_t j = 0; j < q; ++j) h_redo[j] = hf[j] ? 1 : 0;
+    return ORAMA_OK;
+}
+
 }  // namespace
 
 namespace orama {
@@ -658,7 +736,24 @@ int orama_vec_create(orama_ctx* ctx, uint32_t dim, int metric, int dtype, uint64
     ORAMA_REQUIRE(dim >= 1, "dimensions is 0");
     ORAMA_SUPPORT(dim <= 65536, "dimensions %u outside [1, 65536]", dim);
     ORAMA_REQUIRE(metric == ORAMA_METRIC_COSINE || metric == ORAMA_METRIC_L2SQ, "unknown metric %d", metric);
-    ORAMA_REQUIRE(dtype == ORAMA_DTYPE_F32 || dtype == ORAMA_DTYPE_F16, "unknown dtype %d", dtype);
+    ORAMA_REQUIRE(dtype == ORAMA_DTYPE_F32 || dtype == ORAMA_DTYPE_F16 || dtype == ORAMA_DTYPE_F32_SHADOW16, "unknown dtype %d",
+                  dtype);
+    if (dtype == ORAMA_DTYPE_F32_SHADOW16) {
+        // fp32 rows decide every answer; an fp16 copy of the same rows proposes the candidates (two-stage exact search)
+        ORAMA_SUPPORT(metric == ORAMA_METRIC_COSINE && vec_rerank_f32_supported(dim) && dim <= 2048,
+                      "the fp16 shadow supports the cosine metric and dimensions that are a multiple of 4 up to 1024");
+        orama_vec* primary = nullptr;
+        ORAMA_TRY(orama_vec_create(ctx, dim, metric, ORAMA_DTYPE_F32, reserve_rows, &primary));
+        orama_vec* sh = nullptr;
+        const int st = orama_vec_create(ctx, dim, metric, ORAMA_DTYPE_F16, reserve_rows, &sh);
+        if (st != ORAMA_OK) {
+            orama_vec_destroy(primary);
+            return st;
+        }
+        primary->shadow.reset(sh);
+        *out = primary;
+        return ORAMA_OK;
+    }
     if (dtype == ORAMA_DTYPE_F16 && dim > 2048) {
         set_error("f16 storage: dimensions %u > 2048 exceed the LDS query tile", dim);
         return ORAMA_ERR_UNSUPPORTED;
@@ -726,8 +821,52 @@ static int reserve_rows_locked(orama_vec* v, uint64_t need_rows, hipStream_t s) 
     return ORAMA_OK;
 }
 
+static int vec_insert_one(orama_vec* v, const uint64_t* doc_ids, const float* rows, uint64_t n_rows, uint64_t* accepted);
+static int vec_delete_one(orama_vec* v, const uint64_t* doc_ids, uint64_t n);
+static int vec_compact_one(orama_vec* v, uint64_t version);
+static int vec_fill_synthetic_one(orama_vec* v, uint64_t n_rows, uint64_t seed, uint64_t first_doc_id);
+
+// fp16 image of a row with a usable error bound: elementwise relative error 2^-11 needs the elements inside the fp16
+// normal range — |x_i| < 6e4, and a norm large enough that the elements below 6.1e-5 (absolute error 2^-25 each) do not
+// matter
+static bool row_shadow_safe(const float* x, uint32_t d) {
+    float n2 = 0.0f, mx = 0.0f;
+    for (uint32_t i = 0; i < d; ++i) {
+        n2 += x[i] * x[i];
+        mx = std::max(mx, std::fabs(x[i]));
+    }
+    return n2 >= 1e-4f && mx < 6.0e4f;
+}
+
 int orama_vec_insert(orama_vec* v, const uint64_t* doc_ids, const float* rows, uint64_t n_rows,
                      uint64_t* accepted) {
+    ORAMA_REQUIRE(v, "null handle");
+    if (!v->shadow) return vec_insert_one(v, doc_ids, rows, n_rows, accepted);
+    if (accepted) *accepted = 0;
+    if (n_rows == 0) return ORAMA_OK;
+    ORAMA_REQUIRE(doc_ids && rows, "null input");
+    std::lock_guard<std::mutex> cl(v->composite_mu);
+    if (v->shadow_ok.load(std::memory_order_relaxed)) {
+        for (uint64_t i = 0; i < n_rows; ++i) {
+            const float* x = rows + i * (uint64_t)v->dim;
+            if (row_valid(x, v->dim) && !row_shadow_safe(x, v->dim)) {
+                v->shadow_ok.store(false, std::memory_order_release);
+                break;
+            }
+        }
+    }
+    // shadow first: a search clamps the shadow's row count to this store's published count
+    uint64_t a0 = 0, a1 = 0;
+    ORAMA_TRY(vec_insert_one(v->shadow.get(), doc_ids, rows, n_rows, &a0));
+    ORAMA_TRY(vec_insert_one(v, doc_ids, rows, n_rows, &a1));
+    ORAMA_REQUIRE(a0 == a1, "internal: the fp16 shadow accepted %llu rows, the store %llu", (unsigned long long)a0,
+                  (unsigned long long)a1);
+    if (accepted) *accepted = a1;
+    return ORAMA_OK;
+}
+
+static int vec_insert_one(orama_vec* v, const uint64_t* doc_ids, const float* rows, uint64_t n_rows,
+                          uint64_t* accepted) {
     ORAMA_REQUIRE(v, "null handle");
     if (accepted) *accepted = 0;
     if (n_rows == 0) return ORAMA_OK;
@@ -775,6 +914,14 @@ int orama_vec_insert(orama_vec* v, const uint64_t* doc_ids, const float* rows, u
 
 int orama_vec_delete(orama_vec* v, const uint64_t* doc_ids, uint64_t n) {
     ORAMA_REQUIRE(v, "null handle");
+    if (!v->shadow) return vec_delete_one(v, doc_ids, n);
+    std::lock_guard<std::mutex> cl(v->composite_mu);
+    ORAMA_TRY(vec_delete_one(v->shadow.get(), doc_ids, n));
+    return vec_delete_one(v, doc_ids, n);
+}
+
+static int vec_delete_one(orama_vec* v, const uint64_t* doc_ids, uint64_t n) {
+    ORAMA_REQUIRE(v, "null handle");
     if (n == 0) return ORAMA_OK;
     ORAMA_REQUIRE(doc_ids, "null input");
     ORAMA_REQUIRE(n < 0xffffffffull, "too many ids in one delete");
@@ -808,6 +955,17 @@ int orama_vec_delete(orama_vec* v, const uint64_t* doc_ids, uint64_t n) {
 }
 
 int orama_vec_compact(orama_vec* v, uint64_t version) {
+    ORAMA_REQUIRE(v, "null handle");
+    if (!v->shadow) return vec_compact_one(v, version);
+    // both copies drop the same rows (the same deletes reached both): row indices stay aligned; a two-stage search holds
+    // composite_rw shared, so it never sees one copy compacted and the other not.
+    std::lock_guard<std::mutex> cl(v->composite_mu);
+    std::unique_lock<std::shared_mutex> both(v->composite_rw);  // no two-stage search while the halves are re-packed
+    ORAMA_TRY(vec_compact_one(v->shadow.get(), version));
+    return vec_compact_one(v, version);
+}
+
+static int vec_compact_one(orama_vec* v, uint64_t version) {
     ORAMA_REQUIRE(v, "null handle");
     ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
     std::lock_guard<std::mutex> wl(v->write_mu);
@@ -890,6 +1048,12 @@ int orama_vec_info(orama_vec* v, orama_vec_info_t* out) {
     out->pending_ops = d;
     out->version = v->version;
     out->hbm_bytes = (uint64_t)(v->rows.mapped + v->inv_norm.mapped + v->row_doc.mapped + v->dead.mapped);
+    out->two_stage_queries = v->two_stage_queries.load(std::memory_order_relaxed);
+    out->two_stage_fallbacks = v->two_stage_fallbacks.load(std::memory_order_relaxed);
+    if (v->shadow) {
+        const orama_vec* sh = v->shadow.get();
+        out->hbm_bytes += (uint64_t)(sh->rows.mapped + sh->inv_norm.mapped + sh->row_doc.mapped + sh->dead.mapped);
+    }
     return ORAMA_OK;
 }
 
@@ -904,8 +1068,13 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
     std::shared_lock<std::shared_mutex> lk(v->mu);
     if (v->n_rows.load(std::memory_order_acquire) == 0) return ORAMA_OK;
-    ScratchLease sc(v->ctx);
-    ORAMA_TRY(sc.init());
+    // fp32 rows + fp16 shadow: candidates from the shadow scan, exact distances from the fp32 rows (two_stage_search)
+    bool two_stage = v->shadow && v->ctx->two_stage && v->shadow_ok.load(std::memory_order_acquire) && 2 * (uint64_t)k <= kSelectMaxK;
+    if (two_stage)
+        for (uint32_t j = 0; j < q && two_stage; ++j) two_stage = row_shadow_safe(queries + (size_t)j * v->dim, v->dim);
+    ScratchLease sc(v->ctx), sc2(v->ctx);
+    if (two_stage) ORAMA_TRY(ScratchLease::init_pair(sc, sc2));  // both at once: callers holding one set each cannot wait for each other
+    else ORAMA_TRY(sc.init());
     hipStream_t s = sc->stream;
     const size_t qbytes = (size_t)q * v->dim * sizeof(float);
     ORAMA_TRY(sc->query.reserve(qbytes));
@@ -918,8 +1087,15 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     ORAMA_TRY(sc->out_ids.reserve(nk * 8));
     ORAMA_TRY(sc->out_val.reserve(nk * 4));
     ORAMA_TRY(sc->out_n.reserve((size_t)q * 4));
-    ORAMA_TRY(search_enqueue(v, sc.s.get(), sc->query.as<float>(), q, k, d_allow, bitmap_bits,
-                             sc->out_ids.as<uint64_t>(), sc->out_val.as<float>(), sc->out_n.as<uint32_t>(), s));
+    std::vector<uint8_t> redo;
+    if (two_stage) {
+        redo.assign(q, 0);
+        ORAMA_TRY(two_stage_search(v, sc, sc2, sc->query.as<float>(), q, k, d_allow, bitmap_bits, sc->out_ids.as<uint64_t>(),
+                                   sc->out_val.as<float>(), sc->out_n.as<uint32_t>(), s, redo.data()));
+    } else {
+        ORAMA_TRY(search_enqueue(v, sc.s.get(), sc->query.as<float>(), q, k, d_allow, bitmap_bits,
+                                 sc->out_ids.as<uint64_t>(), sc->out_val.as<float>(), sc->out_n.as<uint32_t>(), s));
+    }
     ORAMA_TRY(sc->h_out.reserve(nk * 12 + (size_t)q * 4));
     char* h = sc->h_out.as<char>();
     ORAMA_HIP_TRY(hipMemcpyAsync(h, sc->out_ids.p, nk * 8, hipMemcpyDeviceToHost, s));
@@ -929,6 +1105,21 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     memcpy(out_ids, h, nk * 8);
     memcpy(out_dist, h + nk * 8, nk * 4);
     memcpy(out_n, h + nk * 12, (size_t)q * 4);
+    // queries whose candidate list could not be proven complete: the plain fp32 scan answers them
+    for (uint32_t j = 0; j < q && two_stage; ++j) {
+        if (!redo[j]) continue;
+        v->two_stage_fallbacks.fetch_add(1, std::memory_order_relaxed);
+        ORAMA_TRY(search_enqueue(v, sc.s.get(), sc->query.as<float>() + (size_t)j * v->dim, 1, k, d_allow, bitmap_bits,
+                                 sc->out_ids.as<uint64_t>(), sc->out_val.as<float>(), sc->out_n.as<uint32_t>(), s));
+        ORAMA_HIP_TRY(hipMemcpyAsync(h, sc->out_ids.p, (size_t)k * 8, hipMemcpyDeviceToHost, s));
+        ORAMA_HIP_TRY(hipMemcpyAsync(h + nk * 8, sc->out_val.p, (size_t)k * 4, hipMemcpyDeviceToHost, s));
+        ORAMA_HIP_TRY(hipMemcpyAsync(h + nk * 12, sc->out_n.p, 4, hipMemcpyDeviceToHost, s));
+        ORAMA_HIP_TRY(hipStreamSynchronize(s));
+        memcpy(out_ids + (size_t)j * k, h, (size_t)k * 8);
+        memcpy(out_dist + (size_t)j * k, h + nk * 8, (size_t)k * 4);
+        out_n[j] = *reinterpret_cast<const uint32_t*>(h + nk * 12);
+    }
+    if (two_stage) v->two_stage_queries.fetch_add(q, std::memory_order_relaxed);
     return ORAMA_OK;
 }
 
@@ -1006,6 +1197,14 @@ int orama_merge_packed_device(orama_ctx* ctx, const void* d_packed_blocks, uint3
 }
 
 int orama_vec_fill_synthetic(orama_vec* v, uint64_t n_rows, uint64_t seed, uint64_t first_doc_id) {
+    ORAMA_REQUIRE(v, "null handle");
+    if (!v->shadow) return vec_fill_synthetic_one(v, n_rows, seed, first_doc_id);
+    std::lock_guard<std::mutex> cl(v->composite_mu);
+    ORAMA_TRY(vec_fill_synthetic_one(v->shadow.get(), n_rows, seed, first_doc_id));  // same generator, same row order
+    return vec_fill_synthetic_one(v, n_rows, seed, first_doc_id);
+}
+
+static int vec_fill_synthetic_one(orama_vec* v, uint64_t n_rows, uint64_t seed, uint64_t first_doc_id) {
     ORAMA_REQUIRE(v, "null handle");
     if (n_rows == 0) return ORAMA_OK;
     ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));

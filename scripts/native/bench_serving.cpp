@@ -4,7 +4,8 @@
 // caps them near 20 K requests/s), hence a C++ driver.
 //   bench_serving bm25 [docs=10000000] [requests_per_thread=400] [threads=1,8,32,128]
 //   bench_serving hybrid [docs=10000000] [requests_per_thread=30] [threads=1,8,32,64]   (fp32 vectors + BM25F, min-max merge)
-//   bench_serving vec  [rows=10000000] [requests_per_thread=100] [threads=8,64,256,512]   (768 dims, fp16 store, top-100)
+//   bench_serving vec  [rows=10000000] [requests_per_thread=100] [threads=8,64,256,512] [f16|f32|shadow]   (768 dims, top-100;
+//                      shadow = fp32 rows + fp16 shadow, exact fp32 answers by the two-stage plan)
 // Build: g++ -O2 -std=c++17 -I include scripts/native/bench_serving.cpp -L oramacore_amd/csrc -lorama_hip -pthread
 #include <algorithm>
 #include <atomic>
@@ -48,18 +49,20 @@ int main(int argc, char** argv) {
     if (mode == "vec") {
         const uint32_t dim = 768, K = 100, NQ = 512;
         orama_vec* vec = nullptr;
-        CHECK(orama_vec_create(ctx, dim, ORAMA_METRIC_COSINE, ORAMA_DTYPE_F16, n_docs, &vec));
+        const std::string dts = argc > 5 ? argv[5] : "f16";
+        const int dt = dts == "f32" ? ORAMA_DTYPE_F32 : dts == "shadow" ? ORAMA_DTYPE_F32_SHADOW16 : ORAMA_DTYPE_F16;
+        CHECK(orama_vec_create(ctx, dim, ORAMA_METRIC_COSINE, dt, n_docs, &vec));
         CHECK(orama_vec_fill_synthetic(vec, n_docs, 0x5EED, 0));
         std::mt19937_64 rng(0xBEEF);
         std::normal_distribution<float> g(0.f, 1.f);
         std::vector<float> qv((size_t)NQ * dim);
         for (auto& x : qv) x = g(rng);
-        printf("vec: %llu x %u fp16 rows, top-%u, single-query requests\n", (unsigned long long)n_docs, dim, K);
+        printf("vec: %llu x %u rows (%s store), top-%u, single-query requests\n", (unsigned long long)n_docs, dim, dts.c_str(), K);
         for (int batched = 0; batched < 2; ++batched) {
             for (int nt : thread_counts) {
                 if (!batched && nt > 64) continue;  // direct calls: one corpus pass per request
                 orama_batcher* batcher = nullptr;
-                if (batched) CHECK(orama_batcher_create(vec, 256, 0, &batcher));
+                if (batched) CHECK(orama_batcher_create(vec, dt == ORAMA_DTYPE_F32 ? 8 : 256, 0, &batcher));
                 const int count = batched ? per_thread : std::max(4, per_thread / 8);
                 std::atomic<uint64_t> checksum{0};
                 auto worker = [&](int tid, int cnt) {

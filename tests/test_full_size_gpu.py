@@ -66,6 +66,36 @@ def test_ns_full_size_fp32(ctx):
     st.close()
 
 
+def test_ns_full_size_two_stage_equals_the_fp32_scan(ctx):
+    """NS at full size through the two-stage plan (fp32 rows + fp16 shadow, DTYPE_F32_SHADOW16): the store passes the same
+    property checks as the plain fp32 store, and its answers equal the plain scan's of the SAME store (plan switched off)
+    bit for bit — solo, small batch (K1b on the plain side) and a 64-query batch, with and without a filter."""
+    n, d, k = 10_000_000, 768, 100
+    st = oa.EmbeddingFieldStorage(ctx, dimensions=d, reserve_rows=n + 16, dtype=oa.DTYPE_F32_SHADOW16)
+    st.fill_synthetic(n, seed=0xC0FFEE)
+    q = util.gaussian_rows(1, d, seed=0xBEEF)[0]
+    _check_store(st, n, d, k, q, quantised=False)
+    qs = util.gaussian_rows(64, d, seed=99)
+    bm = oa.AllowBitmap.from_mask(np.arange(n + 3) % 3 != 0).to_device(ctx)
+    two = {"solo": st.storage_search(qs[0], k), "b5": st.storage_search(qs[:5], k), "b64": st.storage_search(qs, k),
+           "filtered": st.storage_search(qs[:3], k, bm)}
+    used = st.info()
+    assert used["two_stage_queries"] >= 73 and used["two_stage_fallbacks"] == 0
+    ctx.set_two_stage(False)
+    try:
+        one = {"solo": st.storage_search(qs[0], k), "b5": st.storage_search(qs[:5], k), "b64": st.storage_search(qs[:16], k),
+               "filtered": st.storage_search(qs[:3], k, bm)}
+    finally:
+        ctx.set_two_stage(True)
+    for name in two:
+        m = one[name][0].shape[0]
+        assert np.array_equal(two[name][0][:m], one[name][0]), name
+        assert np.array_equal(two[name][1][:m].view(np.uint32), one[name][1].view(np.uint32)), name
+        assert np.array_equal(two[name][2][:m], one[name][2]), name
+    bm.close()
+    st.close()
+
+
 def test_c3_full_size_fp16_batch64(ctx):
     n, d, k = 10_000_000, 768, 100
     st = oa.EmbeddingFieldStorage(ctx, dimensions=d, reserve_rows=n + 64, dtype=N.DTYPE_F16)

@@ -1,0 +1,177 @@
+"""Two-stage exact search (ORAMA_DTYPE_F32_SHADOW16: fp32 rows + fp16 shadow): the answers must be the plain fp32
+scan's bit for bit — ids, distances, counts — for single queries and batches, under filters, deletes, live inserts and
+compaction; adversarial data (thousands of near-duplicates around the k-th distance) must take the fp32 fallback and
+still agree; rows without an fp16 error bound switch the plan off."""
+import numpy as np
+import pytest
+
+import oramacore_amd as oa
+from oracle import oracle as orc  # checker only
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = oa.Context(0)
+    yield c
+    c.set_two_stage(True)
+    c.close()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def pair(ctx, dim, reserve=0):
+    plain = oa.EmbeddingFieldStorage(ctx, dimensions=dim, dtype=oa.DTYPE_F32, reserve_rows=reserve)
+    shadow = oa.EmbeddingFieldStorage(ctx, dimensions=dim, dtype=oa.DTYPE_F32_SHADOW16, reserve_rows=reserve)
+    return plain, shadow
+
+
+def same(plain, shadow, queries, k, allow=None, tag=""):
+    pi, pd, pn = plain.storage_search(queries, k, allow)
+    si, sd, sn = shadow.storage_search(queries, k, allow)
+    assert pn.tolist() == sn.tolist(), tag
+    for j in range(len(pn)):
+        n = int(pn[j])
+        assert pi[j, :n].tolist() == si[j, :n].tolist(), (tag, j)
+        assert np.array_equal(bits(pd[j, :n]), bits(sd[j, :n])), (tag, j)
+    return si, sd, sn
+
+
+@pytest.mark.parametrize("dim", [64, 384, 768, 1000])
+def test_equals_the_fp32_scan(ctx, dim):
+    rng = np.random.default_rng(dim)
+    n = 60_000
+    rows = (rng.standard_normal((n, dim)) * rng.uniform(0.5, 2.0, size=(n, 1))).astype(np.float32)
+    ids = (np.arange(n, dtype=np.uint64) * np.uint64(3) + np.uint64(7))
+    ids[1000:1010] = ids[999]  # several rows of one document
+    plain, shadow = pair(ctx, dim)
+    assert plain.insert_rows(ids, rows) == shadow.insert_rows(ids, rows) == n
+    q = rng.standard_normal((70, dim)).astype(np.float32)
+    for k in (1, 10, 100, 1000):
+        same(plain, shadow, q[:1], k, tag=("q1", k))
+        same(plain, shadow, q[:9], k, tag=("q9", k))
+    same(plain, shadow, q, 100, tag="q70")
+    # the oracle agrees (distance within the declared 1e-4, ids wherever distances are separated)
+    si, sd, sn = shadow.storage_search(q[:3], 50)
+    for j in range(3):
+        od = orc.distances(rows, q[j])
+        order = np.lexsort((np.arange(n), ids, od))[:50]
+        assert np.max(np.abs(od[order] - sd[j])) <= 1e-4
+    # filter + deletes + inserts + compaction
+    allow_ids = ids[rng.random(n) < 0.5]
+    bm = oa.AllowBitmap(int(ids.max()) + 1, allow_ids)
+    same(plain, shadow, q[:5], 100, bm, tag="filter")
+    for d in rng.choice(ids, size=300, replace=False):
+        plain.delete(int(d))
+        shadow.delete(int(d))
+    same(plain, shadow, q[:5], 100, tag="deleted")
+    same(plain, shadow, q[:5], 100, bm, tag="deleted+filter")
+    more = rng.standard_normal((5000, dim)).astype(np.float32)
+    more_ids = np.arange(5000, dtype=np.uint64) + np.uint64(10**9)
+    plain.insert_rows(more_ids, more)
+    shadow.insert_rows(more_ids, more)
+    same(plain, shadow, q[:5], 100, tag="inserted")
+    plain.compact(2)
+    shadow.compact(2)
+    assert plain.info()["num_rows"] == shadow.info()["num_rows"]
+    same(plain, shadow, q[:9], 100, tag="compacted")
+    info = shadow.info()
+    assert info["two_stage_queries"] > 0
+    # the plan switched off gives the same answers through the same store
+    ctx.set_two_stage(False)
+    before = shadow.info()["two_stage_queries"]
+    same(plain, shadow, q[:3], 10, tag="plan off")
+    assert shadow.info()["two_stage_queries"] == before
+    ctx.set_two_stage(True)
+    plain.close()
+    shadow.close()
+
+
+def test_near_duplicates_take_the_fallback(ctx):
+    """6 000 rows within ~1e-6 of the same direction: the band around the k-th shadow distance holds more rows than the
+    candidate list — the query must be answered by the fp32 scan (and counted as a fallback), not by an incomplete list."""
+    rng = np.random.default_rng(5)
+    dim, n = 256, 40_000
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    centre = rng.standard_normal(dim).astype(np.float32)
+    rows[:6000] = centre + (rng.standard_normal((6000, dim)) * 1e-4).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64)
+    plain, shadow = pair(ctx, dim)
+    plain.insert_rows(ids, rows)
+    shadow.insert_rows(ids, rows)
+    q = np.stack([centre + (rng.standard_normal(dim) * 1e-3).astype(np.float32), rng.standard_normal(dim).astype(np.float32)])
+    same(plain, shadow, q, 100, tag="duplicates")
+    info = shadow.info()
+    assert info["two_stage_fallbacks"] >= 1 and info["two_stage_queries"] >= 2
+    # exact duplicates: ties resolved by (doc, row) like the fp32 path
+    rows2 = np.repeat(rng.standard_normal((50, dim)).astype(np.float32), 40, axis=0)
+    p2, s2 = pair(ctx, dim)
+    p2.insert_rows(np.arange(2000, dtype=np.uint64)[::-1].copy(), rows2)
+    s2.insert_rows(np.arange(2000, dtype=np.uint64)[::-1].copy(), rows2)
+    same(p2, s2, rows2[:3] + np.float32(0.01), 90, tag="ties")
+    for st in (plain, shadow, p2, s2):
+        st.close()
+
+
+def test_rows_without_an_error_bound_switch_the_plan_off(ctx):
+    rng = np.random.default_rng(9)
+    dim = 128
+    rows = rng.standard_normal((5000, dim)).astype(np.float32)
+    plain, shadow = pair(ctx, dim)
+    ids = np.arange(5000, dtype=np.uint64)
+    plain.insert_rows(ids, rows)
+    shadow.insert_rows(ids, rows)
+    q = rng.standard_normal((2, dim)).astype(np.float32)
+    same(plain, shadow, q, 10)
+    used = shadow.info()["two_stage_queries"]
+    assert used == 2
+    tiny = (rng.standard_normal((1, dim)) * 1e-5).astype(np.float32)  # norm ~1e-4: fp16 subnormals
+    plain.insert_rows(np.array([10**6], dtype=np.uint64), tiny)
+    shadow.insert_rows(np.array([10**6], dtype=np.uint64), tiny)
+    same(plain, shadow, q, 10)
+    same(plain, shadow, tiny * 3, 10)
+    assert shadow.info()["two_stage_queries"] == used  # the plain scan answered
+    # a query outside the fp16 range is answered by the plain scan as well (another store, still two-stage capable)
+    p2, s2 = pair(ctx, dim)
+    p2.insert_rows(ids, rows)
+    s2.insert_rows(ids, rows)
+    same(p2, s2, q * np.float32(1e5), 10)
+    assert s2.info()["two_stage_queries"] == 0
+    same(p2, s2, q, 10)
+    assert s2.info()["two_stage_queries"] == 2
+    for st in (plain, shadow, p2, s2):
+        st.close()
+
+
+def test_batcher_on_a_shadow_store(ctx):
+    import threading
+
+    rng = np.random.default_rng(13)
+    dim, n = 384, 50_000
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64)
+    plain, shadow = pair(ctx, dim)
+    plain.insert_rows(ids, rows)
+    shadow.insert_rows(ids, rows)
+    qs = rng.standard_normal((48, dim)).astype(np.float32)
+    batcher = oa.SearchBatcher(shadow, max_batch=64)
+    got = [None] * len(qs)
+
+    def worker(t):
+        for i in range(t, len(qs), 12):
+            got[i] = batcher.search(qs[i], 20)
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(12)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    pi, pd, pn = plain.storage_search(qs, 20)
+    for i in range(len(qs)):
+        assert got[i][0].tolist() == pi[i].tolist() and np.array_equal(bits(got[i][1]), bits(pd[i]))
+    batcher.close()
+    plain.close()
+    shadow.close()
