@@ -145,7 +145,14 @@ struct ProfScope {
 // ---------------------------------------------------------------- per-call scratch
 // One set per in-flight search: its own stream, device scratch and pinned staging, so that
 // concurrent orama_*_search calls never share mutable state (re-entrancy contract of the ABI).
+// Two kinds of set, never mixed in use: kScratchRecords sets carry K3's per-document records (1.4 GB at 10 M documents),
+// kScratchGeneral sets everything else (a wide fp16 batch sizes its candidate lists in GB as well).  A set that served
+// both would end up holding both — 32 such sets overrun the pool's byte budget and every release would free and every
+// query re-allocate and re-zero them.
+constexpr int kScratchGeneral = 0, kScratchRecords = 1;
+
 struct Scratch {
+    int kind = kScratchGeneral;
     hipStream_t stream = nullptr;
     DevBuf query;      // q x dim f32
     DevBuf dist;       // per-row distances / dense scores
@@ -215,10 +222,11 @@ struct orama_ctx {
     std::unordered_map<const void*, uint64_t> allow_reg;
 
     // Borrow a scratch set (creates one when the pool is empty); blocks while max_inflight sets are out.
-    int acquire(std::unique_ptr<orama::Scratch>* out);
+    int acquire(std::unique_ptr<orama::Scratch>* out, int kind = orama::kScratchGeneral);
     // Two sets at once (the fused hybrid search runs its legs on two streams): taken together, so that callers holding
     // one set each can never wait for each other.
     int acquire2(std::unique_ptr<orama::Scratch>* a, std::unique_ptr<orama::Scratch>* b);
+    int acquire_n(uint32_t n, std::unique_ptr<orama::Scratch>** outs, const int* kinds = nullptr);
     void release(std::unique_ptr<orama::Scratch> s);
 };
 
@@ -226,9 +234,19 @@ namespace orama {
 struct ScratchLease {
     orama_ctx* ctx;
     std::unique_ptr<Scratch> s;
-    explicit ScratchLease(orama_ctx* c) : ctx(c) {}
-    int init() { return ctx->acquire(&s); }
-    static int init_pair(ScratchLease& a, ScratchLease& b) { return a.ctx->acquire2(&a.s, &b.s); }
+    int kind;
+    explicit ScratchLease(orama_ctx* c, int k = kScratchGeneral) : ctx(c), kind(k) {}
+    int init() { return ctx->acquire(&s, kind); }
+    static int init_pair(ScratchLease& a, ScratchLease& b) {
+        std::unique_ptr<Scratch>* outs[2] = {&a.s, &b.s};
+        const int kinds[2] = {a.kind, b.kind};
+        return a.ctx->acquire_n(2, outs, kinds);
+    }
+    static int init_three(ScratchLease& a, ScratchLease& b, ScratchLease& c) {
+        std::unique_ptr<Scratch>* outs[3] = {&a.s, &b.s, &c.s};
+        const int kinds[3] = {a.kind, b.kind, c.kind};
+        return a.ctx->acquire_n(3, outs, kinds);
+    }
     ~ScratchLease() {
         if (s) ctx->release(std::move(s));
     }

@@ -83,13 +83,15 @@ Profiler::~Profiler() {
 }  // namespace orama
 
 namespace {
-int take_one(orama_ctx* c, std::unique_ptr<orama::Scratch>* out) {  // pool_mu held
-    if (!c->pool.empty()) {
-        *out = std::move(c->pool.back());
-        c->pool.pop_back();
+int take_one(orama_ctx* c, std::unique_ptr<orama::Scratch>* out, int kind) {  // pool_mu held
+    for (size_t i = c->pool.size(); i-- > 0;) {  // most recently returned set of this kind: its buffers already fit
+        if (c->pool[i]->kind != kind) continue;
+        *out = std::move(c->pool[i]);
+        c->pool.erase(c->pool.begin() + (long)i);
         return ORAMA_OK;
     }
     std::unique_ptr<orama::Scratch> s(new orama::Scratch());
+    s->kind = kind;
     ORAMA_HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     *out = std::move(s);
     return ORAMA_OK;
@@ -99,31 +101,38 @@ int take_one(orama_ctx* c, std::unique_ptr<orama::Scratch>* out) {  // pool_mu h
 // Waiters are woken one at a time (a release frees ONE set; waking every waiter costs a context switch per waiting
 // thread and query: 128 callers of a 32-set pool ran at a quarter of the rate of 32 callers).  Callers that need two sets
 // (the fused hybrid search) wait on their own condition variable and go first when two sets are free.
-int orama_ctx::acquire(std::unique_ptr<orama::Scratch>* out) {
+int orama_ctx::acquire(std::unique_ptr<orama::Scratch>* out, int kind) {
     std::unique_lock<std::mutex> g(pool_mu);
     ++waiting_one;
     pool_cv.wait(g, [&] { return leased < max_inflight; });
     --waiting_one;
-    ORAMA_TRY(take_one(this, out));
+    ORAMA_TRY(take_one(this, out, kind));
     ++leased;
     if (leased < max_inflight && waiting_one) pool_cv.notify_one();  // capacity left: pass the baton
     return ORAMA_OK;
 }
 
-int orama_ctx::acquire2(std::unique_ptr<orama::Scratch>* a, std::unique_ptr<orama::Scratch>* b) {
+int orama_ctx::acquire_n(uint32_t n, std::unique_ptr<orama::Scratch>** outs, const int* kinds) {
     std::unique_lock<std::mutex> g(pool_mu);
+    const uint32_t need = std::min(n, max_inflight);  // a pool smaller than the request would wait for ever
     ++waiting_pair;
-    pool_cv_pair.wait(g, [&] { return leased + 2 <= max_inflight; });
+    pool_cv_pair.wait(g, [&] { return leased + need <= max_inflight; });
     --waiting_pair;
-    ORAMA_TRY(take_one(this, a));
-    const int st = take_one(this, b);
-    if (st != ORAMA_OK) {
-        pool.push_back(std::move(*a));
-        return st;
+    for (uint32_t i = 0; i < n; ++i) {
+        const int st = take_one(this, outs[i], kinds ? kinds[i] : orama::kScratchGeneral);
+        if (st != ORAMA_OK) {
+            for (uint32_t j = 0; j < i; ++j) pool.push_back(std::move(*outs[j]));
+            return st;
+        }
     }
-    leased += 2;
+    leased += n;
     if (leased < max_inflight && waiting_one) pool_cv.notify_one();
     return ORAMA_OK;
+}
+
+int orama_ctx::acquire2(std::unique_ptr<orama::Scratch>* a, std::unique_ptr<orama::Scratch>* b) {
+    std::unique_ptr<orama::Scratch>* outs[2] = {a, b};
+    return acquire_n(2, outs);
 }
 
 namespace {

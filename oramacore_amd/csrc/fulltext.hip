@@ -675,9 +675,10 @@ int post_search_impl(orama_post* p, const orama_term_ref* refs, uint32_t n_refs,
     ORAMA_REQUIRE(!hybrid || n_vec == 0 || (vec_doc && vec_score), "null vector map");
     ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
     std::shared_lock<std::shared_mutex> lk(p->mu);
-    ScratchLease sc(p->ctx);
+    const bool by_ranges = !hybrid && ranges_eligible(p, refs, n_refs, params);
+    ScratchLease sc(p->ctx, by_ranges ? kScratchGeneral : kScratchRecords);
     ORAMA_TRY(sc.init());
-    if (!hybrid && ranges_eligible(p, refs, n_refs, params)) {
+    if (by_ranges) {
         ORAMA_TRY(check_params(params));
         const RangeJob job{refs, n_refs, params, out_ids, out_scores, out_n, out_count};
         return post_search_ranges(p, sc.s.get(), &job, 1, b, allow_bitmap, bitmap_bits, apply_omc);
@@ -1117,7 +1118,7 @@ struct orama_scores {
     uint32_t list_len = 0;
     std::mutex mu;  // facet / group / export calls on one handle are serialised (they share its stream)
     DevBuf tmp_a, tmp_b, tmp_c;
-    explicit orama_scores(orama_post* post) : p(post), lk(post->mu), lease(post->ctx) {}
+    explicit orama_scores(orama_post* post) : p(post), lk(post->mu), lease(post->ctx, kScratchRecords) {}
     ScoreMapDev dev() const {
         ScoreMapDev m;
         m.emit = st.qb.emit;
@@ -1380,7 +1381,7 @@ struct orama_post_query {
     PostQuery st;
     orama_bm25_params params{};
     int stage = 0;  // 1 accumulated, 2 scored, 3 finished
-    explicit orama_post_query(orama_post* post) : p(post), lk(post->mu), lease(post->ctx) {}
+    explicit orama_post_query(orama_post* post) : p(post), lk(post->mu), lease(post->ctx, kScratchRecords) {}
     ~orama_post_query() {
         if (lease.s && own_stream) lease.s->stream = own_stream;
     }
@@ -1506,14 +1507,21 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
     ORAMA_HIP_TRY(hipSetDevice(ctx->device));
     VecSharedLock vlk(v);
     std::shared_lock<std::shared_mutex> lk(p->mu);
-    ScratchLease a(ctx), bsc(ctx);
-    ORAMA_TRY(ScratchLease::init_pair(a, bsc));
+    // a store with an fp16 shadow answers the vector leg with the two-stage plan (same answer, half the bytes scanned):
+    // it needs a third scratch set, and blocks — so the full-text leg is enqueued first and runs beside it
+    const bool two_stage = vec_rows(v) > 0 && limit > 0 && vec_two_stage_usable(v, query, 1, limit);
+    ScratchLease a(ctx), a2(ctx), bsc(ctx, kScratchRecords);
+    if (two_stage) ORAMA_TRY(ScratchLease::init_three(a, a2, bsc));
+    else ORAMA_TRY(ScratchLease::init_pair(a, bsc));
     // ---- leg A: vector scan + top-`limit` rows
     const uint32_t dim = vec_dim(v);
     const bool have_rows = vec_rows(v) > 0 && limit > 0;
     const uint32_t kk = limit ? limit : 1;
     hipStream_t sa = a->stream;
     char* ha = nullptr;
+    PostQuery st;
+    if (two_stage)  // leg B, stage 1 first
+        ORAMA_TRY(post_stage1(p, bsc.s.get(), refs, n_refs, b, params, allow_bitmap, bitmap_bits, true, apply_omc, limit, &st));
     if (have_rows) {
         ORAMA_TRY(a->query.reserve((size_t)dim * 4));
         ORAMA_TRY(a->h_in.reserve((size_t)dim * 4));
@@ -1524,8 +1532,12 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
         ORAMA_TRY(a->out_ids.reserve((size_t)kk * 8));
         ORAMA_TRY(a->out_val.reserve((size_t)kk * 4));
         ORAMA_TRY(a->out_n.reserve(4));
-        ORAMA_TRY(vec_search_enqueue(v, a.s.get(), a->query.as<float>(), 1, limit, d_allow, bitmap_bits,
-                                     a->out_ids.as<uint64_t>(), a->out_val.as<float>(), a->out_n.as<uint32_t>(), sa));
+        if (two_stage)
+            ORAMA_TRY(vec_two_stage_search(v, a, a2, a->query.as<float>(), 1, limit, d_allow, bitmap_bits, a->out_ids.as<uint64_t>(),
+                                           a->out_val.as<float>(), a->out_n.as<uint32_t>()));
+        else
+            ORAMA_TRY(vec_search_enqueue(v, a.s.get(), a->query.as<float>(), 1, limit, d_allow, bitmap_bits,
+                                         a->out_ids.as<uint64_t>(), a->out_val.as<float>(), a->out_n.as<uint32_t>(), sa));
         ORAMA_TRY(a->h_out.reserve((size_t)kk * 12 + 4));
         ha = a->h_out.as<char>();
         ORAMA_HIP_TRY(hipMemcpyAsync(ha, a->out_ids.p, (size_t)kk * 8, hipMemcpyDeviceToHost, sa));
@@ -1533,8 +1545,8 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
         ORAMA_HIP_TRY(hipMemcpyAsync(ha + (size_t)kk * 12, a->out_n.p, 4, hipMemcpyDeviceToHost, sa));
     }
     // ---- leg B, stage 1: BM25F accumulate + finalise (overlaps leg A)
-    PostQuery st;
-    ORAMA_TRY(post_stage1(p, bsc.s.get(), refs, n_refs, b, params, allow_bitmap, bitmap_bits, true, apply_omc, limit, &st));
+    if (!two_stage)
+        ORAMA_TRY(post_stage1(p, bsc.s.get(), refs, n_refs, b, params, allow_bitmap, bitmap_bits, true, apply_omc, limit, &st));
     // ---- join A; in-tree epilogue on the host: similarity, rescale, cut-off, per-doc sum (hit order)
     std::vector<uint64_t> vdoc;
     std::vector<float> vsc;
@@ -1652,7 +1664,7 @@ static int bm25_score_impl(orama_ctx* ctx, const orama_ntf_entry* entries, uint3
         docs.erase(std::unique(docs.begin(), docs.end()), docs.end());
     }
     const uint64_t n_docs = identity ? max_id + 1 : docs.size();
-    ScratchLease sc(ctx);
+    ScratchLease sc(ctx, kScratchRecords);
     ORAMA_TRY(sc.init());
     hipStream_t s = sc->stream;
     const uint64_t touched_cap = total;  // one slot per posting
@@ -1855,7 +1867,7 @@ int orama_hybrid_combine(orama_ctx* ctx, const uint64_t* vec_doc, const float* v
     std::sort(docs.begin(), docs.end());
     docs.erase(std::unique(docs.begin(), docs.end()), docs.end());
     const uint64_t n_docs = docs.size();
-    ScratchLease sc(ctx);
+    ScratchLease sc(ctx, kScratchRecords);
     ORAMA_TRY(sc.init());
     hipStream_t s = sc->stream;
     const uint64_t cand_cap = n_ft + n_vec;

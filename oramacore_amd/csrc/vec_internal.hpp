@@ -27,4 +27,11 @@ int vec_search_enqueue(orama_vec* v, Scratch* sc, const float* d_queries, uint32
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
                        uint32_t* d_out_n, hipStream_t s);
 
+// Two-stage exact search of a store with an fp16 shadow (vec_store.hip): usable for these host queries?
+bool vec_two_stage_usable(orama_vec* v, const float* queries, uint32_t q, uint32_t k);
+// Runs it on sc's stream with sc2 as the shadow stage's scratch; BLOCKS until the answers are in the device outputs.
+// Queries whose candidate list could not be proven complete are re-answered by the plain scan (also blocking).
+int vec_two_stage_search(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k,
+                         const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n);
+
 }  // namespace orama

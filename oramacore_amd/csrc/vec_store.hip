@@ -245,7 +245,6 @@ struct orama_vec {
     // carries no error bound (tiny norm / element beyond the fp16 range): searches then scan the fp32 rows.
     std::unique_ptr<orama_vec> shadow;
     std::mutex composite_mu;
-    std::shared_mutex composite_rw;  // shared: two-stage searches; exclusive: compaction of BOTH copies (row indices must agree)
     std::atomic<bool> shadow_ok{true};
     std::atomic<uint64_t> two_stage_queries{0}, two_stage_fallbacks{0};
 
@@ -661,8 +660,7 @@ int two_stage_search(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const fl
                      const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n,
                      hipStream_t s, uint8_t* h_redo) {
     orama_vec* sh = v->shadow.get();
-    std::shared_lock<std::shared_mutex> both(v->composite_rw);
-    std::shared_lock<std::shared_mutex> sl(sh->mu);
+    std::shared_lock<std::shared_mutex> sl(sh->mu);  // the caller holds v->mu shared (which also excludes a compaction of the pair)
     const View w = snapshot(v);
     View ws = snapshot(sh);
     ws.n_rows = std::min(ws.n_rows, w.n_rows);  // the shadow is written first: it may already hold unpublished rows
@@ -724,6 +722,37 @@ int vec_search_enqueue(orama_vec* v, Scratch* sc, const float* d_queries, uint32
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
                        uint32_t* d_out_n, hipStream_t s) {
     return search_enqueue(v, sc, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, s);
+}
+bool vec_two_stage_usable(orama_vec* v, const float* queries, uint32_t q, uint32_t k) {
+    if (!(v->shadow && v->ctx->two_stage && v->shadow_ok.load(std::memory_order_acquire) && k >= 1 &&
+          2 * (uint64_t)k <= kSelectMaxK))
+        return false;
+    for (uint32_t j = 0; j < q; ++j) {
+        // the same test the rows pass at insert (row_shadow_safe)
+        const float* x = queries + (size_t)j * v->dim;
+        float n2 = 0.0f, mx = 0.0f;
+        for (uint32_t i = 0; i < v->dim; ++i) {
+            n2 += x[i] * x[i];
+            mx = std::max(mx, std::fabs(x[i]));
+        }
+        if (!(n2 >= 1e-4f && mx < 6.0e4f)) return false;
+    }
+    return true;
+}
+int vec_two_stage_search(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k,
+                         const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n) {
+    hipStream_t s = sc->stream;
+    std::vector<uint8_t> redo(q, 0);
+    ORAMA_TRY(two_stage_search(v, sc, sc2, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, s, redo.data()));
+    v->two_stage_queries.fetch_add(q, std::memory_order_relaxed);
+    for (uint32_t j = 0; j < q; ++j) {
+        if (!redo[j]) continue;
+        v->two_stage_fallbacks.fetch_add(1, std::memory_order_relaxed);
+        ORAMA_TRY(search_enqueue(v, sc.s.get(), d_queries + (size_t)j * v->dim, 1, k, d_allow, allow_bits, d_out_ids + (size_t)j * k,
+                                 d_out_dist + (size_t)j * k, d_out_n + j, s));
+    }
+    ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    return ORAMA_OK;
 }
 }  // namespace orama
 
@@ -823,7 +852,7 @@ static int reserve_rows_locked(orama_vec* v, uint64_t need_rows, hipStream_t s) 
 
 static int vec_insert_one(orama_vec* v, const uint64_t* doc_ids, const float* rows, uint64_t n_rows, uint64_t* accepted);
 static int vec_delete_one(orama_vec* v, const uint64_t* doc_ids, uint64_t n);
-static int vec_compact_one(orama_vec* v, uint64_t version);
+static int vec_compact_one(orama_vec* v, uint64_t version, bool mu_held = false);
 static int vec_fill_synthetic_one(orama_vec* v, uint64_t n_rows, uint64_t seed, uint64_t first_doc_id);
 
 // fp16 image of a row with a usable error bound: elementwise relative error 2^-11 needs the elements inside the fp16
@@ -957,19 +986,23 @@ static int vec_delete_one(orama_vec* v, const uint64_t* doc_ids, uint64_t n) {
 int orama_vec_compact(orama_vec* v, uint64_t version) {
     ORAMA_REQUIRE(v, "null handle");
     if (!v->shadow) return vec_compact_one(v, version);
-    // both copies drop the same rows (the same deletes reached both): row indices stay aligned; a two-stage search holds
-    // composite_rw shared, so it never sees one copy compacted and the other not.
+    // both copies drop the same rows (the same deletes reached both), so the row indices stay aligned.  Every search of
+    // this store — two-stage or not — holds v->mu shared for its whole duration: taking it exclusively HERE, around both
+    // re-packs, means no search ever sees one copy compacted and the other not (and the lock order of a search,
+    // v->mu then shadow->mu, is the order used here).
     std::lock_guard<std::mutex> cl(v->composite_mu);
-    std::unique_lock<std::shared_mutex> both(v->composite_rw);  // no two-stage search while the halves are re-packed
+    ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
+    std::unique_lock<std::shared_mutex> lk(v->mu);
     ORAMA_TRY(vec_compact_one(v->shadow.get(), version));
-    return vec_compact_one(v, version);
+    return vec_compact_one(v, version, true);
 }
 
-static int vec_compact_one(orama_vec* v, uint64_t version) {
+static int vec_compact_one(orama_vec* v, uint64_t version, bool mu_held) {
     ORAMA_REQUIRE(v, "null handle");
     ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
     std::lock_guard<std::mutex> wl(v->write_mu);
-    std::unique_lock<std::shared_mutex> lk(v->mu);  // rows move: no scan may run (the reference's compact is exclusive too)
+    std::unique_lock<std::shared_mutex> lk(v->mu, std::defer_lock);  // rows move: no scan may run (the reference's compact is exclusive too)
+    if (!mu_held) lk.lock();
     v->version = version;
     const uint64_t n_old = v->n_rows.load(std::memory_order_acquire);
     if (v->n_dead.load(std::memory_order_acquire) == 0) return ORAMA_OK;
@@ -1069,9 +1102,7 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     std::shared_lock<std::shared_mutex> lk(v->mu);
     if (v->n_rows.load(std::memory_order_acquire) == 0) return ORAMA_OK;
     // fp32 rows + fp16 shadow: candidates from the shadow scan, exact distances from the fp32 rows (two_stage_search)
-    bool two_stage = v->shadow && v->ctx->two_stage && v->shadow_ok.load(std::memory_order_acquire) && 2 * (uint64_t)k <= kSelectMaxK;
-    if (two_stage)
-        for (uint32_t j = 0; j < q && two_stage; ++j) two_stage = row_shadow_safe(queries + (size_t)j * v->dim, v->dim);
+    const bool two_stage = vec_two_stage_usable(v, queries, q, k);
     ScratchLease sc(v->ctx), sc2(v->ctx);
     if (two_stage) ORAMA_TRY(ScratchLease::init_pair(sc, sc2));  // both at once: callers holding one set each cannot wait for each other
     else ORAMA_TRY(sc.init());
@@ -1087,11 +1118,9 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     ORAMA_TRY(sc->out_ids.reserve(nk * 8));
     ORAMA_TRY(sc->out_val.reserve(nk * 4));
     ORAMA_TRY(sc->out_n.reserve((size_t)q * 4));
-    std::vector<uint8_t> redo;
     if (two_stage) {
-        redo.assign(q, 0);
-        ORAMA_TRY(two_stage_search(v, sc, sc2, sc->query.as<float>(), q, k, d_allow, bitmap_bits, sc->out_ids.as<uint64_t>(),
-                                   sc->out_val.as<float>(), sc->out_n.as<uint32_t>(), s, redo.data()));
+        ORAMA_TRY(vec_two_stage_search(v, sc, sc2, sc->query.as<float>(), q, k, d_allow, bitmap_bits, sc->out_ids.as<uint64_t>(),
+                                       sc->out_val.as<float>(), sc->out_n.as<uint32_t>()));
     } else {
         ORAMA_TRY(search_enqueue(v, sc.s.get(), sc->query.as<float>(), q, k, d_allow, bitmap_bits,
                                  sc->out_ids.as<uint64_t>(), sc->out_val.as<float>(), sc->out_n.as<uint32_t>(), s));
@@ -1105,21 +1134,6 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     memcpy(out_ids, h, nk * 8);
     memcpy(out_dist, h + nk * 8, nk * 4);
     memcpy(out_n, h + nk * 12, (size_t)q * 4);
-    // queries whose candidate list could not be proven complete: the plain fp32 scan answers them
-    for (uint32_t j = 0; j < q && two_stage; ++j) {
-        if (!redo[j]) continue;
-        v->two_stage_fallbacks.fetch_add(1, std::memory_order_relaxed);
-        ORAMA_TRY(search_enqueue(v, sc.s.get(), sc->query.as<float>() + (size_t)j * v->dim, 1, k, d_allow, bitmap_bits,
-                                 sc->out_ids.as<uint64_t>(), sc->out_val.as<float>(), sc->out_n.as<uint32_t>(), s));
-        ORAMA_HIP_TRY(hipMemcpyAsync(h, sc->out_ids.p, (size_t)k * 8, hipMemcpyDeviceToHost, s));
-        ORAMA_HIP_TRY(hipMemcpyAsync(h + nk * 8, sc->out_val.p, (size_t)k * 4, hipMemcpyDeviceToHost, s));
-        ORAMA_HIP_TRY(hipMemcpyAsync(h + nk * 12, sc->out_n.p, 4, hipMemcpyDeviceToHost, s));
-        ORAMA_HIP_TRY(hipStreamSynchronize(s));
-        memcpy(out_ids + (size_t)j * k, h, (size_t)k * 8);
-        memcpy(out_dist + (size_t)j * k, h + nk * 8, (size_t)k * 4);
-        out_n[j] = *reinterpret_cast<const uint32_t*>(h + nk * 12);
-    }
-    if (two_stage) v->two_stage_queries.fetch_add(q, std::memory_order_relaxed);
     return ORAMA_OK;
 }
 

@@ -3,7 +3,8 @@
 // (src/collection_manager/sides/read/collection.rs:846-884).  Python threads cannot generate this load (the GIL
 // caps them near 20 K requests/s), hence a C++ driver.
 //   bench_serving bm25 [docs=10000000] [requests_per_thread=400] [threads=1,8,32,128]
-//   bench_serving hybrid [docs=10000000] [requests_per_thread=30] [threads=1,8,32,64]   (fp32 vectors + BM25F, min-max merge)
+//   bench_serving hybrid [docs=10000000] [requests_per_thread=30] [threads=1,8,32,64] [f32|shadow]   (fp32 vectors + BM25F,
+//                      min-max merge; shadow = the vector store also keeps an fp16 copy: two-stage exact vector leg)
 //   bench_serving vec  [rows=10000000] [requests_per_thread=100] [threads=8,64,256,512] [f16|f32|shadow]   (768 dims, top-100;
 //                      shadow = fp32 rows + fp16 shadow, exact fp32 answers by the two-stage plan)
 // Build: g++ -O2 -std=c++17 -I include scripts/native/bench_serving.cpp -L oramacore_amd/csrc -lorama_hip -pthread
@@ -140,16 +141,19 @@ int main(int argc, char** argv) {
     if (hybrid) {
         const uint32_t dim = 768;
         orama_vec* vec = nullptr;
-        CHECK(orama_vec_create(ctx, dim, ORAMA_METRIC_COSINE, ORAMA_DTYPE_F32, n_docs, &vec));
+        const bool shadow = argc > 5 && std::string(argv[5]) == "shadow";
+        CHECK(orama_vec_create(ctx, dim, ORAMA_METRIC_COSINE, shadow ? ORAMA_DTYPE_F32_SHADOW16 : ORAMA_DTYPE_F32, n_docs, &vec));
         CHECK(orama_vec_fill_synthetic(vec, n_docs, 0x5EED, 0));
         std::normal_distribution<float> g(0.f, 1.f);
         std::vector<float> qv((size_t)NQ * dim);
         for (auto& x : qv) x = g(rng);
+        printf("%s", shadow ? "vector store: fp32 rows + fp16 shadow (two-stage exact)\n" : "vector store: fp32 rows\n");
         printf("hybrid: + %llu x %u fp32 rows; a request = vector top-%u + BM25F + min-max merge + top-%u\n", (unsigned long long)n_docs, dim, K, K);
         for (int batched = 0; batched < 2; ++batched) {
             for (int nt : thread_counts) {
                 orama_batcher* vb = nullptr;
-                if (batched) CHECK(orama_batcher_create(vec, 8, 0, &vb));  // fp32: K1b shares a corpus pass among <= 8 queries
+                // plain fp32: K1b shares a corpus pass among <= 8 queries; with a shadow the fp16 scan takes 256
+                if (batched) CHECK(orama_batcher_create(vec, shadow ? 256 : 8, 0, &vb));
                 std::atomic<uint64_t> checksum{0};
                 auto worker = [&](int tid, int cnt) {
                     std::vector<uint64_t> ids(K), vid(K);

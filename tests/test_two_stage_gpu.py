@@ -175,3 +175,34 @@ def test_batcher_on_a_shadow_store(ctx):
     batcher.close()
     plain.close()
     shadow.close()
+
+
+def test_hybrid_search_on_a_shadow_store(ctx):
+    """orama_hybrid_search takes the two-stage plan for its vector leg: same (ids, scores, count) as with a plain store."""
+    from oramacore_amd import fulltext as ft
+
+    rng = np.random.default_rng(17)
+    dim, n = 256, 30_000
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64)
+    plain, shadow = pair(ctx, dim)
+    plain.insert_rows(ids, rows)
+    shadow.insert_rows(ids, rows)
+    lists = []
+    for l in range(6):
+        local = np.sort(rng.choice(n, size=int(rng.integers(200, 4000)), replace=False))
+        lists.append(ft.PostingList(field=0, docs=ids[local], tf=rng.integers(1, 5, size=len(local)),
+                                    field_len=rng.integers(5, 200, size=len(local))))
+    post = ft.PostingsStore(ctx)
+    post.build(ids, [60.0], lists)
+    before = shadow.info()["two_stage_queries"]
+    for i in range(6):
+        q = rng.standard_normal(dim).astype(np.float32)
+        refs = [(t, int(l), 1.0) for t, l in enumerate(rng.choice(6, size=3, replace=False))]
+        a = post.hybrid_search(plain, q, 50, 0.0, refs, 3, float(n), 40)
+        b = post.hybrid_search(shadow, q, 50, 0.0, refs, 3, float(n), 40)
+        assert a[2] == b[2] and a[0].tolist() == b[0].tolist() and np.array_equal(bits(a[1]), bits(b[1])), i
+    assert shadow.info()["two_stage_queries"] == before + 6
+    post.close()
+    plain.close()
+    shadow.close()
