@@ -585,8 +585,21 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
         p.out_n = out_n;  // borrowed as the running count
         ORAMA_TRY(launch_select(v->ctx, p, s));
         // 2. filter scan of the rest in super-chunks
-        for (uint64_t r0 = s1; r0 < n; r0 += chunk_rows) {
-            const uint64_t r1 = std::min<uint64_t>(n, r0 + chunk_rows);
+        // Super-chunks may GROW: the threshold tau_j only tightens between super-chunks, and the share of rows that pass
+        // it — each costs the epilogue's slow path for its whole wave — is k / (rows seen so far).  One chunk for the
+        // whole rest runs at the head's k / 131072 throughout; chunks that double (the next one as large as everything
+        // scanned before it) keep it near k / rows-so-far for the price of ~log2(N / S1) scan + select launches.
+        // That pays for many queries with a large k (the two-stage plan asks for k1 >= 228: 64 queries 5.4 -> 3.2 ms of
+        // scan) and costs otherwise (C3, k = 100: +0.4 ms of launches) — so it is used for q * k >= 8192 and k > 128
+        // (ORAMA_F16_CHUNK_GROW = 0 / 1 forces it off / on).
+        static const int grow_env = [] {
+            const char* e = std::getenv("ORAMA_F16_CHUNK_GROW");
+            return e ? std::atoi(e) : -1;
+        }();
+        const bool grow = grow_env >= 0 ? grow_env != 0 : ((uint64_t)gq * k >= 8192 && k > 128);
+        uint64_t this_chunk = grow ? std::min<uint64_t>(chunk_rows, std::max<uint64_t>(s1 & ~255ull, 1u << 17)) : chunk_rows;
+        for (uint64_t r0 = s1; r0 < n;) {
+            const uint64_t r1 = std::min<uint64_t>(n, r0 + this_chunk);
             ORAMA_TRY(launch_f16_seed_candidates(best_dist, best_row, out_n, gq, k, tau, cand_dist, cand_row,
                                                  cand_count, cand_stride, s));
             a.row_begin = r0;
@@ -621,6 +634,8 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
                 c.out_val = best_dist;
             }
             ORAMA_TRY(launch_select(v->ctx, c, s));
+            r0 = r1;
+            if (grow) this_chunk = std::min<uint64_t>(chunk_rows, r1 & ~255ull);  // as large as everything before it
         }
         q0 += gq;
     }
