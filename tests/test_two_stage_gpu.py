@@ -206,3 +206,49 @@ def test_hybrid_search_on_a_shadow_store(ctx):
     post.close()
     plain.close()
     shadow.close()
+
+
+def test_tiny_and_growing_stores(ctx):
+    """Fewer rows than candidates asked for; a store that grows past its reservation while searches run."""
+    import threading
+
+    rng = np.random.default_rng(21)
+    dim = 128
+    plain, shadow = pair(ctx, dim, reserve=64)
+    rows = rng.standard_normal((50, dim)).astype(np.float32)
+    ids = np.arange(50, dtype=np.uint64)
+    plain.insert_rows(ids, rows)
+    shadow.insert_rows(ids, rows)
+    q = rng.standard_normal((3, dim)).astype(np.float32)
+    for k in (1, 10, 50, 200):
+        same(plain, shadow, q, k, tag=("tiny", k))
+    # concurrent ingest: every answer must be sorted, complete and made of published documents only
+    stop = threading.Event()
+    errors = []
+
+    def searcher():
+        try:
+            while not stop.is_set():
+                i, d, c = shadow.storage_search(q[:1], 20)
+                assert c[0] == 20 and np.all(np.diff(d[0]) >= 0)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ths = [threading.Thread(target=searcher) for _ in range(3)]
+    for t in ths:
+        t.start()
+    base = 50
+    for slab in range(12):
+        more = rng.standard_normal((20_000, dim)).astype(np.float32)
+        mids = np.arange(base, base + 20_000, dtype=np.uint64)
+        shadow.insert_rows(mids, more)
+        plain.insert_rows(mids, more)
+        base += 20_000
+    stop.set()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    same(plain, shadow, q, 100, tag="after the ingest")
+    assert shadow.info()["num_rows"] == base
+    plain.close()
+    shadow.close()
