@@ -315,6 +315,7 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
     if (const char* e = std::getenv("ORAMA_F16_WIDE")) c->f16_wide = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_BM25_RANGES")) c->bm25_ranges = std::atoi(e) != 0;
     if (const char* e = std::getenv("ORAMA_TWO_STAGE")) c->two_stage = std::atoi(e) != 0;
+    if (const char* e = std::getenv("ORAMA_F16_SOLO")) c->f16_solo = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_KC")) c->f16_kc = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_NBUF")) c->f16_nbuf = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_MAX_INFLIGHT")) c->max_inflight = (uint32_t)std::max(2, std::atoi(e));

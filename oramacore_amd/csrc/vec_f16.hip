@@ -211,6 +211,273 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
     }
 }
 
+// ---------------------------------------------------------------- K1h: 1..4 queries without the matrix cores
+// The candidate stage of the two-stage plan scans the fp16 shadow for ONE query most of the time.  K2 pads that to a
+// 32-column MFMA tile and streams at 5.9 TB/s; this kernel keeps K2's data path (fragment-ordered rows streamed through
+// a register ring with counted waits) and replaces the MFMAs by v_dot2_f32_f16: lane l owns row l & 31 of the tile and
+// the k-half l >> 5 of every k-step — exactly the 8 halves one 16-byte load delivers — multiplies them with the query's
+// 8 halves of the same k-half (LDS, two distinct addresses per wave: broadcast reads) and keeps one f32 partial sum per
+// query; the two halves of a row meet through one cross-lane add per tile.  Used only where no bit-identity with K2 is
+// promised (F16ScanArgs::solo: the shadow scan — its error bound holds for any summation order).
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+template <int NQ, int KC, int NBUF>
+__global__ __launch_bounds__(kBlock) void vec_scan_f16_solo_kernel(F16ScanArgs a, uint32_t ksteps, uint64_t tile_bytes) {
+    constexpr int kChunk = KC;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t frag_total = ksteps * 2 * NQ;  // [k-step][k-half][query] x 16 B
+    float* qinv = reinterpret_cast<float*>(lds + (size_t)frag_total * 16);
+    for (uint32_t idx = tid; idx < frag_total; idx += kBlock) {
+        const uint32_t j = idx % NQ, kg = idx / NQ;  // kg = k-step * 2 + k-half
+        const uint32_t k0 = kg * 8;
+        h8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t k = k0 + e;
+            v[e] = (_Float16)((j < a.q && k < a.dim) ? a.queries[(size_t)j * a.dim + k] : 0.0f);
+        }
+        *reinterpret_cast<h8*>(lds + (size_t)idx * 16) = v;
+    }
+    __syncthreads();
+    if (tid < NQ) {  // |q| of the fp16-rounded query, f32 accumulation
+        float ss = 0.0f;
+        for (uint32_t k = 0; k < ksteps * 16; ++k) {
+            const float x = (float)reinterpret_cast<const _Float16*>(lds + (size_t)((k >> 3) * NQ + tid) * 16)[k & 7];
+            ss = fmaf(x, x, ss);
+        }
+        qinv[tid] = a.metric == ORAMA_METRIC_L2SQ ? ss : (ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f);
+    }
+    __syncthreads();
+    const bool l2 = a.metric == ORAMA_METRIC_L2SQ;
+    const uint32_t gw = uniform_u32(blockIdx.x * kWavesPerBlock + (tid >> 6));
+    const uint32_t gwaves = gridDim.x * kWavesPerBlock;
+    const uint64_t t_first = a.row_begin >> 5;
+    const uint64_t t_end = (a.row_end + 31) >> 5;
+    const uint64_t n_tiles = t_end - t_first;
+    if (gw >= n_tiles) return;
+    const uint64_t tile0 = t_first + gw;
+    const uint64_t tile_step = gwaves;
+    const uint64_t my_tiles = (n_tiles - gw + gwaves - 1) / gwaves;
+    const uint32_t nc = ksteps / kChunk;
+    const char* base = reinterpret_cast<const char*>(a.tiled);
+    const uint32_t half = (uint32_t)lane >> 5, rlane = (uint32_t)lane & 31u;
+
+    float acc[NQ];
+    f4 buf[NBUF][KC];
+    float nrm[NBUF];  // 1/|x| (or |x|^2) of this lane's row, re-read with every chunk: one more load per chunk, but in a
+                      // fixed place of the load stream, so the compiler keeps its counted waits (see load_chunk in K2)
+    uint64_t ld_tile = tile0;
+    uint32_t ld_c = 0;
+    uint64_t ld_more = my_tiles * nc - 1;
+    uint64_t cp_tile = tile0;
+    uint32_t cp_c = 0;
+    auto load_chunk = [&](f4* b, float* nr) {
+        const f4* p = reinterpret_cast<const f4*>(base + ld_tile * tile_bytes + (uint64_t)ld_c * kChunk * 1024) + lane;
+#pragma unroll
+        for (int s = 0; s < kChunk; ++s) b[s] = __builtin_nontemporal_load(p + s * 64);
+        *nr = a.inv_norm[ld_tile * 32 + rlane];
+        if (ld_more) {
+            --ld_more;
+            if (++ld_c == nc) {
+                ld_c = 0;
+                ld_tile += tile_step;
+            }
+        }
+    };
+    float qi[NQ], tau[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        qi[j] = qinv[j];
+        tau[j] = (a.tau && (uint32_t)j < a.q) ? a.tau[j] : 0.0f;
+    }
+    typedef const uint32_t __attribute__((address_space(4))) cu32;
+    auto epilogue = [&](uint64_t tile, float inv) {
+        const uint32_t dead_word = a.dead ? ((cu32*)(uintptr_t)a.dead)[tile] : 0u;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const float dot = acc[j] + __shfl_xor(acc[j], 32, 64);  // the two k-halves of the row
+            const uint64_t row = tile * 32 + rlane;
+            if (half != 0 || row >= a.row_end || (uint32_t)j >= a.q) continue;
+            bool excluded = (dead_word >> rlane) & 1u;
+            const float dist = l2 ? (qi[j] + inv) - 2.0f * dot : 1.0f - dot * (inv * qi[j]);
+            if (a.out_dense) {
+                if (!excluded && a.allow) {
+                    const uint64_t doc = a.row_doc[row];
+                    excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
+                }
+                a.out_dense[(uint64_t)j * a.dense_stride + (row - a.row_begin)] = excluded ? __builtin_nanf("") : dist;
+            } else if (!excluded && dist < tau[j]) {
+                if (a.allow) {
+                    const uint64_t doc = a.row_doc[row];
+                    excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
+                }
+                if (!excluded) {
+                    const uint32_t pos = atomicAdd(&a.cand_count[j], 1u);
+                    a.cand_dist[(uint64_t)j * a.cand_stride + pos] = dist;
+                    a.cand_row[(uint64_t)j * a.cand_stride + pos] = (uint32_t)row;
+                }
+            }
+        }
+    };
+    auto compute_chunk = [&](const f4* b, float nr) {
+        if (cp_c == 0) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) acc[j] = 0.0f;
+        }
+        const char* ql = lds + ((size_t)(cp_c * kChunk * 2 + half) * NQ) * 16;
+#pragma unroll
+        for (int s = 0; s < kChunk; ++s) {
+            const h8 av = as_h8(b[s]);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const h8 qv = *reinterpret_cast<const h8*>(ql + ((size_t)s * 2 * NQ + j) * 16);
+                float c = acc[j];
+                c = __builtin_amdgcn_fdot2(h2{av[0], av[1]}, h2{qv[0], qv[1]}, c, false);
+                c = __builtin_amdgcn_fdot2(h2{av[2], av[3]}, h2{qv[2], qv[3]}, c, false);
+                c = __builtin_amdgcn_fdot2(h2{av[4], av[5]}, h2{qv[4], qv[5]}, c, false);
+                c = __builtin_amdgcn_fdot2(h2{av[6], av[7]}, h2{qv[6], qv[7]}, c, false);
+                acc[j] = c;
+            }
+        }
+        if (++cp_c == nc) {
+            epilogue(cp_tile, nr);
+            cp_c = 0;
+            cp_tile += tile_step;
+        }
+    };
+    const uint64_t total = my_tiles * nc;
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) load_chunk(buf[b], &nrm[b]);
+    uint64_t g = 0;
+    for (; g + NBUF <= total; g += NBUF) {
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) {
+            load_chunk(buf[(b + NBUF - 1) % NBUF], &nrm[(b + NBUF - 1) % NBUF]);
+            compute_chunk(buf[b], nrm[b]);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) {
+        if (g + b < total) {
+            load_chunk(buf[(b + NBUF - 1) % NBUF], &nrm[(b + NBUF - 1) % NBUF]);
+            compute_chunk(buf[b], nrm[b]);
+        }
+    }
+}
+
+// K1h, second form (ORAMA_F16_SOLO=2): K1's loop shape instead of K2's register ring — a wave takes TWO tiles at a time,
+// issues one group of G loads per tile, multiplies, next group; no software pipeline, 256-thread blocks, several per CU.
+template <int NQ, int G>
+__global__ __launch_bounds__(256) void vec_scan_f16_solo2_kernel(F16ScanArgs a, uint32_t ksteps, uint64_t tile_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t frag_total = ksteps * 2 * NQ;
+    float* qinv = reinterpret_cast<float*>(lds + (size_t)frag_total * 16);
+    for (uint32_t idx = tid; idx < frag_total; idx += 256) {
+        const uint32_t j = idx % NQ, kg = idx / NQ;
+        const uint32_t k0 = kg * 8;
+        h8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t k = k0 + e;
+            v[e] = (_Float16)((j < a.q && k < a.dim) ? a.queries[(size_t)j * a.dim + k] : 0.0f);
+        }
+        *reinterpret_cast<h8*>(lds + (size_t)idx * 16) = v;
+    }
+    __syncthreads();
+    if (tid < NQ) {
+        float ss = 0.0f;
+        for (uint32_t k = 0; k < ksteps * 16; ++k) {
+            const float x = (float)reinterpret_cast<const _Float16*>(lds + (size_t)((k >> 3) * NQ + tid) * 16)[k & 7];
+            ss = fmaf(x, x, ss);
+        }
+        qinv[tid] = a.metric == ORAMA_METRIC_L2SQ ? ss : (ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f);
+    }
+    __syncthreads();
+    const bool l2 = a.metric == ORAMA_METRIC_L2SQ;
+    const uint32_t gw = uniform_u32(blockIdx.x * 4 + (tid >> 6));
+    const uint32_t gwaves = gridDim.x * 4;
+    const uint64_t t_first = a.row_begin >> 5;
+    const uint64_t t_end = (a.row_end + 31) >> 5;
+    const char* base = reinterpret_cast<const char*>(a.tiled);
+    const uint32_t half = (uint32_t)lane >> 5, rlane = (uint32_t)lane & 31u;
+    float qi[NQ], tau[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        qi[j] = qinv[j];
+        tau[j] = (a.tau && (uint32_t)j < a.q) ? a.tau[j] : 0.0f;
+    }
+    constexpr int TW = 2;  // tiles per wave iteration
+    for (uint64_t t0 = t_first + (uint64_t)gw * TW; t0 < t_end; t0 += (uint64_t)gwaves * TW) {
+        float acc[TW][NQ];
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) acc[t][j] = 0.0f;
+        for (uint32_t c0 = 0; c0 < ksteps; c0 += G) {
+            f4 x[TW][G];
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                const uint64_t tile = min(t0 + t, t_end - 1);  // the odd last tile is read twice, emitted once
+                const f4* p = reinterpret_cast<const f4*>(base + tile * tile_bytes + (uint64_t)c0 * 1024) + lane;
+#pragma unroll
+                for (int s = 0; s < G; ++s) x[t][s] = __builtin_nontemporal_load(p + s * 64);
+            }
+            const char* ql = lds + ((size_t)(c0 * 2 + half) * NQ) * 16;
+#pragma unroll
+            for (int s = 0; s < G; ++s) {
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    const h8 qv = *reinterpret_cast<const h8*>(ql + ((size_t)s * 2 * NQ + j) * 16);
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) {
+                        const h8 av = as_h8(x[t][s]);
+                        float c = acc[t][j];
+                        c = __builtin_amdgcn_fdot2(h2{av[0], av[1]}, h2{qv[0], qv[1]}, c, false);
+                        c = __builtin_amdgcn_fdot2(h2{av[2], av[3]}, h2{qv[2], qv[3]}, c, false);
+                        c = __builtin_amdgcn_fdot2(h2{av[4], av[5]}, h2{qv[4], qv[5]}, c, false);
+                        c = __builtin_amdgcn_fdot2(h2{av[6], av[7]}, h2{qv[6], qv[7]}, c, false);
+                        acc[t][j] = c;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            const uint64_t tile = t0 + t;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const float dot = acc[t][j] + __shfl_xor(acc[t][j], 32, 64);
+                const uint64_t row = tile * 32 + rlane;
+                if (tile >= t_end || half != 0 || row >= a.row_end || (uint32_t)j >= a.q) continue;
+                bool excluded = a.dead && ((a.dead[tile] >> rlane) & 1u);
+                const float inv = a.inv_norm[row];
+                const float dist = l2 ? (qi[j] + inv) - 2.0f * dot : 1.0f - dot * (inv * qi[j]);
+                if (a.out_dense) {
+                    if (!excluded && a.allow) {
+                        const uint64_t doc = a.row_doc[row];
+                        excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
+                    }
+                    a.out_dense[(uint64_t)j * a.dense_stride + (row - a.row_begin)] = excluded ? __builtin_nanf("") : dist;
+                } else if (!excluded && dist < tau[j]) {
+                    if (a.allow) {
+                        const uint64_t doc = a.row_doc[row];
+                        excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
+                    }
+                    if (!excluded) {
+                        const uint32_t pos = atomicAdd(&a.cand_count[j], 1u);
+                        a.cand_dist[(uint64_t)j * a.cand_stride + pos] = dist;
+                        a.cand_row[(uint64_t)j * a.cand_stride + pos] = (uint32_t)row;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- store / norms / gather
 __global__ __launch_bounds__(256) void f16_store_rows_kernel(char* __restrict__ tiled,
                                                              const float* __restrict__ src, uint64_t first,
@@ -358,6 +625,26 @@ int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream
     if (a.row_begin == a.row_end) return ORAMA_OK;
     const uint32_t kpad = f16_kpad(a.dim);
     const uint32_t ksteps = kpad / 16;
+    if (a.solo && a.q <= 4 && ksteps % 8 == 0) {  // K1h: no matrix cores for a handful of queries (shadow scans only)
+        ProfScope prof(&ctx->prof, "vec_scan_f16", stream);
+        const uint64_t tiles = ((a.row_end + 31) >> 5) - (a.row_begin >> 5);
+        const dim3 grid(blocks_for(tiles, kWavesPerBlock, (uint32_t)ctx->compute_units));
+        const int nq = a.q == 1 ? 1 : (a.q == 2 ? 2 : 4);
+        const size_t lds_bytes = (size_t)ksteps * 2 * nq * 16 + 16 * sizeof(float);
+        if (ctx->f16_solo == 2 && ksteps % 12 == 0 && nq <= 2) {  // K1's loop shape: 256-thread blocks, a few per CU
+            static const int bpc = [] { const char* e = std::getenv("ORAMA_F16_SOLO_BPC"); return e ? std::atoi(e) : 2; }();
+            const dim3 g2(blocks_for((tiles + 1) / 2, 4, (uint32_t)ctx->compute_units * (uint32_t)bpc));
+            if (nq == 1) hipLaunchKernelGGL((vec_scan_f16_solo2_kernel<1, 12>), g2, dim3(256), lds_bytes, stream, a, ksteps, f16_tile_bytes(a.dim));
+            else hipLaunchKernelGGL((vec_scan_f16_solo2_kernel<2, 12>), g2, dim3(256), lds_bytes, stream, a, ksteps, f16_tile_bytes(a.dim));
+            ORAMA_HIP_TRY(hipGetLastError());
+            return ORAMA_OK;
+        }
+        if (nq == 1) hipLaunchKernelGGL((vec_scan_f16_solo_kernel<1, 8, 3>), grid, dim3(kBlock), lds_bytes, stream, a, ksteps, f16_tile_bytes(a.dim));
+        else if (nq == 2) hipLaunchKernelGGL((vec_scan_f16_solo_kernel<2, 8, 3>), grid, dim3(kBlock), lds_bytes, stream, a, ksteps, f16_tile_bytes(a.dim));
+        else hipLaunchKernelGGL((vec_scan_f16_solo_kernel<4, 8, 3>), grid, dim3(kBlock), lds_bytes, stream, a, ksteps, f16_tile_bytes(a.dim));
+        ORAMA_HIP_TRY(hipGetLastError());
+        return ORAMA_OK;
+    }
     const int nqt = a.q <= 32 ? 1 : 2;
     const size_t lds_bytes = (size_t)ksteps * nqt * 1024 + 64 * sizeof(float);
     ORAMA_REQUIRE(lds_bytes <= 160 * 1024, "vec_scan_f16: dim %u too large for the LDS query tile", a.dim);

@@ -56,6 +56,9 @@ struct F16ScanArgs {
     uint32_t* cand_row = nullptr;
     uint32_t* cand_count = nullptr;  // q counters (pre-seeded by the caller)
     uint64_t cand_stride = 0;
+    // the caller promises no bit-identity with batched answers (the shadow scan of the two-stage plan): <= 4 queries take
+    // K1h, the dot-product kernel without MFMA
+    bool solo = false;
 };
 // K2. Algorithmic HBM traffic: (row_end - row_begin) * kpad * 2 bytes per launch (serves all q queries).
 int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream);

@@ -554,6 +554,7 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
         a.dead = w.dead;
         a.allow = d_allow;
         a.allow_bits = allow_bits;
+        a.solo = d_out_rows != nullptr && v->ctx->f16_solo;  // the shadow stage of the two-stage plan
         // 1. dense head
         a.row_begin = 0;
         a.row_end = s1;
