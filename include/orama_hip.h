@@ -97,7 +97,9 @@ int orama_ctx_set_f16_wide(orama_ctx* ctx, int mode);
  * partitioned scorer that takes whole query batches per launch (bm25_ranges.hip); 0 = K3, per-document records in HBM
  * (bm25_kernels.hip), which the hybrid / score-map / precomputed-ntf entry points always use.  Same results bit for bit. */
 int orama_ctx_set_bm25_ranges(orama_ctx* ctx, int on);
-/* ORAMA_DTYPE_F32_SHADOW16 stores: 1 (default) = two-stage search, 0 = always the plain fp32 scan (same results). */
+/* ORAMA_DTYPE_F32_SHADOW16 stores: 1 (default) = two-stage search where it pays (batches of more than 8 queries, or at
+ * least 4 GB of fp32 rows: below that the plain scan is faster than the second stage's launches), 2 = always two stages,
+ * 0 = always the plain fp32 scan.  Same results in every mode. */
 int orama_ctx_set_two_stage(orama_ctx* ctx, int on);
 
 /* Per-kernel HIP-event timing (used by bench.py's roofline leg).  When enabled, the library

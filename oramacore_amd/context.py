@@ -53,9 +53,10 @@ class Context:
     def set_f16_tuning(self, ksteps_per_chunk: int, ring_chunks: int) -> None:
         N.check(self._lib.orama_ctx_set_f16_tuning(self.handle, ksteps_per_chunk, ring_chunks))
 
-    def set_two_stage(self, on: bool) -> None:
-        """DTYPE_F32_SHADOW16 stores: True = fp16 candidates + fp32 decision (default), False = plain fp32 scan."""
-        N.check(self._lib.orama_ctx_set_two_stage(self.handle, 1 if on else 0))
+    def set_two_stage(self, on: bool, always: bool = False) -> None:
+        """DTYPE_F32_SHADOW16 stores: True = fp16 candidates + fp32 decision where it pays (default), False = plain fp32
+        scan; always=True takes the two stages for small stores too."""
+        N.check(self._lib.orama_ctx_set_two_stage(self.handle, (2 if always else 1) if on else 0))
 
     def set_bm25_ranges(self, on: bool) -> None:
         """Plain BM25 top-k searches: True = K3r range-partitioned batch scorer (default), False = K3 per-document records."""

@@ -203,7 +203,8 @@ struct orama_ctx {
     // 0 = always the per-document-record scorer K3 (ORAMA_BM25_RANGES, orama_ctx_set_bm25_ranges)
     int bm25_ranges = 1;
     // stores created as ORAMA_DTYPE_F32_SHADOW16 answer orama_vec_search in two stages (fp16 candidates, fp32 decision);
-    // 0 = always the plain fp32 scan (ORAMA_TWO_STAGE, orama_ctx_set_two_stage)
+    // 0 = always the plain fp32 scan, 2 = two stages also where the plain scan is expected to be faster (small stores
+    // with few queries) (ORAMA_TWO_STAGE, orama_ctx_set_two_stage)
     int two_stage = 1;
     int f16_solo = 2;    // shadow scans of <= 4 queries use K1h (dot products, no MFMA): 2 = K1-shaped loop where it applies, 1 = register ring; ORAMA_F16_SOLO=0: K2
     int f16_kc = 8, f16_nbuf = 3;   // K2 register ring: k-steps per chunk, chunks (ORAMA_F16_KC / ORAMA_F16_NBUF)

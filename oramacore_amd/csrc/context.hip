@@ -314,7 +314,7 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
     if (const char* e = std::getenv("ORAMA_F32_MULTI")) c->f32_multi = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_WIDE")) c->f16_wide = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_BM25_RANGES")) c->bm25_ranges = std::atoi(e) != 0;
-    if (const char* e = std::getenv("ORAMA_TWO_STAGE")) c->two_stage = std::atoi(e) != 0;
+    if (const char* e = std::getenv("ORAMA_TWO_STAGE")) c->two_stage = std::max(0, std::min(2, std::atoi(e)));
     if (const char* e = std::getenv("ORAMA_F16_SOLO")) c->f16_solo = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_KC")) c->f16_kc = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_NBUF")) c->f16_nbuf = std::atoi(e);
@@ -430,7 +430,8 @@ int orama_stream_synchronize(orama_ctx* ctx, void* stream) {
 
 int orama_ctx_set_two_stage(orama_ctx* ctx, int on) {
     ORAMA_REQUIRE(ctx, "null context");
-    ctx->two_stage = on != 0;
+    ORAMA_REQUIRE(on >= 0 && on <= 2, "two-stage mode %d outside [0, 2]", on);
+    ctx->two_stage = on;
     return ORAMA_OK;
 }
 

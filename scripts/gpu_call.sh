@@ -1,6 +1,7 @@
 #!/bin/bash
-O=gpurun_out/r02k1h
+O=gpurun_out/r02ts4
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-for cfg in "2 2" "2 3" "2 4" "1 0"; do set -- $cfg; echo "== ORAMA_F16_SOLO=$1 BPC=$2"; ORAMA_F16_SOLO=$1 ORAMA_F16_SOLO_BPC=$2 timeout 300 python scripts/two_stage_breakdown.py 2>&1 | tail -3 | head -1; done
-ORAMA_F16_SOLO=2 timeout 600 python -m pytest tests/test_two_stage_gpu.py -m gpu -x -q -p no:cacheprovider 2>&1 | grep "passed\|failed\|Error" | head -3
+( time timeout 900 python -m pytest tests/test_two_stage_gpu.py tests/test_full_size_gpu.py::test_ns_full_size_two_stage_equals_the_fp32_scan tests/test_abi.py -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; grep "passed\|failed\|Error" $O/pytest.log | head
+timeout 200 python bench.py --workload c2 --steps 200 --no-cpu-baseline 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c2', round(d['value']), d.get('two_stage_exact'))"

@@ -14,13 +14,13 @@ echo "== bench c5 per-GPU shard"; timeout 200 python bench.py --workload c5 --ro
 echo "== bench exchange (1 rank, RCCL inside the library)"; timeout 200 python bench.py --rows 1250000 --force-exchange --steps 200 --no-cpu-baseline > $O/bench_exchange_shard.json 2> $O/bench_exchange.err
 echo "== c4"; timeout 200 python scripts/bench_hybrid.py --steps 100 --warmup 5 > $O/bench_c4.json 2>$O/bench_c4.err
 cd /tmp
-echo "== rocprof ns"; timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_ns -o ns -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/rocprof_ns.log 2>&1; echo rc=$?
+echo "== rocprof ns"; timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_ns -o ns -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-two-stage > $O/rocprof_ns.log 2>&1; echo rc=$?
 echo "== rocprof c5 shard"; timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c5 -o c5 -- python $R/bench.py --workload c5 --rows 10000000 --steps 10 --warmup 2 --no-cpu-baseline > $O/rocprof_c5.log 2>&1; echo rc=$?
-echo "== rocprof c4"; timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c4 -o c4 -- python $R/scripts/bench_hybrid.py --steps 20 --warmup 3 --no-check > $O/rocprof_c4.log 2>&1; echo rc=$?
+echo "== rocprof c4"; timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c4 -o c4 -- python $R/scripts/bench_hybrid.py --steps 20 --warmup 3 --no-check --no-two-stage > $O/rocprof_c4.log 2>&1; echo rc=$?
 for C in FETCH_SIZE WRITE_SIZE; do
-  echo "== pmc ns $C"; timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_ns/$C -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/pmc_ns_$C.log 2>&1
+  echo "== pmc ns $C"; timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_ns/$C -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-two-stage > $O/pmc_ns_$C.log 2>&1
   echo "== pmc c5 $C"; timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_c5/$C -o p -- python $R/bench.py --workload c5 --rows 10000000 --steps 5 --warmup 2 --no-cpu-baseline > $O/pmc_c5_$C.log 2>&1
-  echo "== pmc c4 $C"; timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_c4/$C -o p -- python $R/scripts/bench_hybrid.py --steps 10 --warmup 2 --no-check > $O/pmc_c4_$C.log 2>&1
+  echo "== pmc c4 $C"; timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_c4/$C -o p -- python $R/scripts/bench_hybrid.py --steps 10 --warmup 2 --no-check --no-two-stage > $O/pmc_c4_$C.log 2>&1
 done
 echo "== pmc c5 L2 hit split"; timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --kernel-trace --output-format csv -d $O/pmc_c5/TCC -o p -- python $R/bench.py --workload c5 --rows 10000000 --steps 5 --warmup 2 --no-cpu-baseline > $O/pmc_c5_TCC.log 2>&1
 cd $R

@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def ctx():
     c = oa.Context(0)
+    c.set_two_stage(True, always=True)  # the stores here are far below the size where the plan is chosen by itself
     yield c
-    c.set_two_stage(True)
     c.close()
 
 
@@ -85,7 +85,7 @@ def test_equals_the_fp32_scan(ctx, dim):
     before = shadow.info()["two_stage_queries"]
     same(plain, shadow, q[:3], 10, tag="plan off")
     assert shadow.info()["two_stage_queries"] == before
-    ctx.set_two_stage(True)
+    ctx.set_two_stage(True, always=True)
     plain.close()
     shadow.close()
 
@@ -250,5 +250,28 @@ def test_tiny_and_growing_stores(ctx):
     assert not errors, errors
     same(plain, shadow, q, 100, tag="after the ingest")
     assert shadow.info()["num_rows"] == base
+    plain.close()
+    shadow.close()
+
+
+def test_the_plan_is_chosen_only_where_it_pays(ctx):
+    """Default mode: a small store answers up to 8 queries by the plain scan (cheaper than the second stage's launches)
+    and larger batches by the two stages."""
+    rng = np.random.default_rng(23)
+    dim, n = 128, 20_000
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    plain, shadow = pair(ctx, dim)
+    ids = np.arange(n, dtype=np.uint64)
+    plain.insert_rows(ids, rows)
+    shadow.insert_rows(ids, rows)
+    q = rng.standard_normal((20, dim)).astype(np.float32)
+    ctx.set_two_stage(True)
+    try:
+        same(plain, shadow, q[:8], 10)
+        assert shadow.info()["two_stage_queries"] == 0
+        same(plain, shadow, q, 10)
+        assert shadow.info()["two_stage_queries"] == 20
+    finally:
+        ctx.set_two_stage(True, always=True)
     plain.close()
     shadow.close()
