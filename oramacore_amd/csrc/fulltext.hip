@@ -496,7 +496,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         segs.clear();
         queries.assign(nq, RangeQuery{});
         lens.assign(nq, 0);
-        uint64_t virt = 0, bounds_entries = 0;
+        uint64_t virt = 0, bounds_entries = 0, max_bound_entries = 0;
         uint32_t max_ranges = 0;
         bool any_df = false;
         ORAMA_TRY(sc->h_misc.reserve((size_t)nq * kMaxTokens * 4 + 64));
@@ -549,6 +549,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                 segs[q.seg_begin + i].bounds_stride = ns;
             }
             bounds_entries += ((uint64_t)q.n_ranges + 1) * ns;
+            max_bound_entries = std::max<uint64_t>(max_bound_entries, ((uint64_t)q.n_ranges + 1) * ns);
             q.want_df = df_known ? 0u : 1u;
             any_df |= !df_known;
             // idf per token by the host libm (calculate_idf, bm25.rs:78-82; df.max(1), token_score.rs:275)
@@ -589,6 +590,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         rb.n_queries = nq;
         rb.total_virt = virt;
         rb.max_ranges = max_ranges;
+        rb.max_bound_entries = max_bound_entries;
         rb.post_doc = p->d_post_doc.as<uint32_t>();
         rb.post_val = p->d_post_val.as<uint32_t>();
         rb.bounds = sc->misc1.as<uint32_t>();

@@ -1,7 +1,6 @@
 #!/bin/bash
-O=gpurun_out/r02ts4
+O=gpurun_out/r02k3r7
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-( time timeout 900 python -m pytest tests/test_two_stage_gpu.py tests/test_full_size_gpu.py::test_ns_full_size_two_stage_equals_the_fp32_scan tests/test_abi.py -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; grep "passed\|failed\|Error" $O/pytest.log | head
-timeout 200 python bench.py --workload c2 --steps 200 --no-cpu-baseline 2>/dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c2', round(d['value']), d.get('two_stage_exact'))"
+( time timeout 600 python -m pytest tests/test_bm25_ranges_gpu.py tests/test_fulltext_gpu.py tests/test_random_gpu.py tests/test_post_append_gpu.py tests/test_sharded_fulltext_gpu.py "tests/test_full_size_gpu.py::test_c4_full_size_bm25_bit_exact" -m gpu -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; grep "passed\|failed\|Error" $O/pytest.log | head -4
+timeout 300 python scripts/bench_bm25_threads.py --threads 1,8 --scorers k3r > $O/bm25.log 2>&1; grep -v "^{" $O/bm25.log
