@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
 }  // namespace
 
 int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream) {
-    if (b.total_virt == 0 || b.n_queries == 0 || b.max_bound_entries == 0) return ORAMA_OK;
+    if (b.total_postings == 0 || b.n_queries == 0 || b.max_bound_entries == 0) return ORAMA_OK;
     ORAMA_REQUIRE(b.n_queries <= 65535, "bm25 ranges: batch too large");
     ProfScope prof(&ctx->prof, "bm25_range_bounds", stream);
     const uint64_t blocks = (b.max_bound_entries + kThreads - 1) / kThreads;
@@ -344,7 +344,7 @@ int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream)
 }
 
 int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStream_t stream) {
-    if (b.total_virt == 0 || b.n_queries == 0 || b.max_ranges == 0) return ORAMA_OK;
+    if (b.total_postings == 0 || b.n_queries == 0 || b.max_ranges == 0) return ORAMA_OK;
     ORAMA_REQUIRE(b.n_queries <= 65535, "bm25 ranges: batch too large");
     ProfScope prof(&ctx->prof, df_only ? "bm25_range_df" : "bm25_range_score", stream);
     const dim3 grid(b.max_ranges, b.n_queries);

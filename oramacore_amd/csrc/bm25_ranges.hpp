@@ -14,14 +14,8 @@ constexpr uint32_t kRangeMaxRefs = 256;  // non-empty posting lists per query (p
 // One (token, posting list) reference of one query of the batch.
 struct RangeSeg {
     uint64_t post_begin;  // first posting of the list inside the postings arrays
-    uint64_t virt_begin;  // first virtual posting of this reference inside the batch
-    uint64_t bounds_off;  // entry of (range 0, this reference): bounds are laid out [query][range][reference]
-    uint32_t bounds_stride;  // references of its query = distance between consecutive ranges of one reference
     uint32_t len;
-    uint32_t query;       // index of the query inside the batch
     uint32_t tok_rank;    // token << 10 | rank (position of the list among the token's lists)
-    uint32_t log_r;       // of its query
-    uint32_t n_ranges;    // of its query
     float boost;
     float avg_len;
 };
@@ -51,10 +45,10 @@ struct RangeResult {
 };
 
 struct RangeBatch {
-    const RangeSeg* segs = nullptr;      // sorted by virt_begin
+    const RangeSeg* segs = nullptr;      // grouped by query, in (token, reference) order
     const RangeQuery* queries = nullptr;
     uint32_t n_segs = 0, n_queries = 0;
-    uint64_t total_virt = 0;
+    uint64_t total_postings = 0;         // referenced by the whole batch
     uint32_t max_ranges = 0;             // grid.x of the scoring launch
     uint64_t max_bound_entries = 0;      // largest references x (ranges + 1) of a query: grid.x of the bounds launch
     const uint32_t* post_doc = nullptr;

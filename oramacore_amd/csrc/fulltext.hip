@@ -527,13 +527,8 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                     if (len == 0) continue;
                     RangeSeg g{};
                     g.post_begin = p->list_off[l];
-                    g.virt_begin = virt;
-                    g.bounds_off = 0;  // completed below, when the query's reference count is known
                     g.len = len;
-                    g.query = c;
                     g.tok_rank = (t << 10) | per_token[t];
-                    g.log_r = q.log_r;
-                    g.n_ranges = q.n_ranges;
                     g.boost = jb.refs[i].boost;
                     g.avg_len = p->avg_len[p->field_of_list[l]];
                     virt += len;
@@ -544,10 +539,6 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             }
             q.seg_end = (uint32_t)segs.size();
             const uint32_t ns = q.seg_end - q.seg_begin;
-            for (uint32_t i = 0; i < ns; ++i) {  // bounds of a query: [range][reference]
-                segs[q.seg_begin + i].bounds_off = q.bounds_base + i;
-                segs[q.seg_begin + i].bounds_stride = ns;
-            }
             bounds_entries += ((uint64_t)q.n_ranges + 1) * ns;
             max_bound_entries = std::max<uint64_t>(max_bound_entries, ((uint64_t)q.n_ranges + 1) * ns);
             q.want_df = df_known ? 0u : 1u;
@@ -588,7 +579,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         rb.queries = reinterpret_cast<const RangeQuery*>(d + seg_bytes);
         rb.n_segs = (uint32_t)segs.size();
         rb.n_queries = nq;
-        rb.total_virt = virt;
+        rb.total_postings = virt;
         rb.max_ranges = max_ranges;
         rb.max_bound_entries = max_bound_entries;
         rb.post_doc = p->d_post_doc.as<uint32_t>();
