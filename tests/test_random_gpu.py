@@ -126,6 +126,13 @@ def test_resident_postings_random(ix, top_k):
     assert count == len(od)
     assert ids.tolist() == td.tolist()
     assert bits(sc) == bits(ts)
+    if vmap is None:  # the plain search ran on the range-partitioned scorer (K3r): K3 must give the same answer
+        context().set_bm25_ranges(False)
+        try:
+            ids3, sc3, count3 = store.search(refs, n_tokens, float(n_docs), top_k, thr, allow=bm, apply_omc=bool(omc_ids))
+        finally:
+            context().set_bm25_ranges(True)
+        assert count3 == count and ids3.tolist() == ids.tolist() and bits(sc3) == bits(sc)
     store.close()
 
 
@@ -159,3 +166,42 @@ def test_vector_scan_random(n, d, nq, k, f16, use_filter, use_deletes, seed):
         assert m == min(k, int(live.sum()))
         util.assert_topk_sound((ids[qi, :m] - 3) // 2, dist[qi, :m], full, k, 1e-4, f"n={n} d={d} q{qi} f16={f16}")
     st_.close()
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+@given(st.integers(1, 3000), st.sampled_from([4, 64, 100, 128, 384, 768, 1000, 1024]), st.integers(1, 12), st.integers(1, 300),
+       st.booleans(), st.booleans(), st.integers(0, 2**31))
+def test_two_stage_equals_plain_scan_random(n, d, nq, k, use_filter, use_deletes, seed):
+    """fp32 rows + fp16 shadow against a plain fp32 store fed the same rows: ids, distance bits and counts."""
+    import util
+
+    ctx = context()
+    ctx.set_two_stage(True, always=True)
+    try:
+        rng = np.random.default_rng(seed)
+        corpus = util.gaussian_rows(n, d, seed=seed % 100003) * rng.uniform(0.2, 3.0, size=(n, 1)).astype(np.float32)
+        if n > 10:
+            corpus[n // 2] = corpus[n // 3]  # an exact duplicate: tie resolved by (doc, row) on both sides
+        doc_ids = np.arange(n, dtype=np.uint64) * 2 + 3
+        plain = oa.EmbeddingFieldStorage(ctx, dimensions=d, dtype=oa.DTYPE_F32)
+        shadow = oa.EmbeddingFieldStorage(ctx, dimensions=d, dtype=oa.DTYPE_F32_SHADOW16)
+        for st_ in (plain, shadow):
+            st_.insert_rows(doc_ids, corpus)
+        if use_deletes and n > 2:
+            for r in rng.choice(n, size=min(3, n - 1), replace=False):
+                plain.delete(int(doc_ids[r]))
+                shadow.delete(int(doc_ids[r]))
+        bm = oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[rng.random(n) < 0.7]) if use_filter else None
+        queries = util.gaussian_rows(nq, d, seed=(seed + 1) % 100003)
+        a = plain.storage_search(queries, k, bm)
+        b = shadow.storage_search(queries, k, bm)
+        assert a[2].tolist() == b[2].tolist()
+        for j in range(nq):
+            m = int(a[2][j])
+            assert a[0][j, :m].tolist() == b[0][j, :m].tolist(), (n, d, j)
+            assert a[1][j, :m].view(np.uint32).tolist() == b[1][j, :m].view(np.uint32).tolist(), (n, d, j)
+        assert shadow.info()["two_stage_queries"] == nq
+        plain.close()
+        shadow.close()
+    finally:
+        ctx.set_two_stage(True)
