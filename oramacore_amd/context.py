@@ -2,11 +2,34 @@
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 from . import _native as N
 
 
-class Context:
+class Owner:
+    """Handles die in dependency order: an owner closes what was created on it (stores on a context; batchers, score
+    maps and facet fields on a store) before it releases its own handle — also when the interpreter tears objects down
+    in arbitrary order at exit."""
+
+    def _adopt(self, child) -> None:
+        kids = self.__dict__.get("_children")
+        if kids is None:
+            kids = self.__dict__["_children"] = weakref.WeakSet()
+        kids.add(child)
+
+    def _close_children(self) -> None:
+        kids = self.__dict__.get("_children")
+        if kids:
+            for c in list(kids):
+                try:
+                    c.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            kids.clear()
+
+
+class Context(Owner):
     def __init__(self, device: int = 0):
         self._lib = N.load()
         h = C.c_void_p()
@@ -22,6 +45,7 @@ class Context:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
+            self._close_children()
             self._lib.orama_ctx_destroy(self._h)
             self._h = None
 

@@ -149,19 +149,28 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
                 const uint64_t row = tile * 32 + i;
                 if (row >= a.row_end || !jok) continue;
                 bool excluded = (dead_word >> i) & 1u;
-                if (!excluded && a.allow) {
-                    const uint64_t doc = a.row_doc[row];
-                    excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
-                }
                 const float inv = hi_half ? nrm_s[i0 + 4] : nrm_s[i0];
                 const float dist = l2 ? (qi + inv) - 2.0f * acc[qt][r] : 1.0f - acc[qt][r] * (inv * qi);
+                // the filter lookup (row -> DocumentId -> bitmap word: two dependent loads) is paid by every element in
+                // the dense mode, but only by the rows that pass the threshold in the filter mode (64 queries under the
+                // NOT-deleted filter: 5.0 -> 3.8 ms)
                 if (a.out_dense) {
+                    if (!excluded && a.allow) {
+                        const uint64_t doc = a.row_doc[row];
+                        excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
+                    }
                     a.out_dense[(uint64_t)j * a.dense_stride + (row - a.row_begin)] =
                         excluded ? __builtin_nanf("") : dist;
                 } else if (!excluded && dist < tau) {
-                    const uint32_t pos = atomicAdd(&a.cand_count[j], 1u);
-                    a.cand_dist[(uint64_t)j * a.cand_stride + pos] = dist;
-                    a.cand_row[(uint64_t)j * a.cand_stride + pos] = (uint32_t)row;
+                    if (a.allow) {
+                        const uint64_t doc = a.row_doc[row];
+                        excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
+                    }
+                    if (!excluded) {
+                        const uint32_t pos = atomicAdd(&a.cand_count[j], 1u);
+                        a.cand_dist[(uint64_t)j * a.cand_stride + pos] = dist;
+                        a.cand_row[(uint64_t)j * a.cand_stride + pos] = (uint32_t)row;
+                    }
                 }
             }
         }

@@ -17,7 +17,7 @@ from typing import Optional
 import numpy as np
 
 from . import _native as N
-from .context import Context
+from .context import Context, Owner
 
 
 class Model(enum.Enum):
@@ -107,6 +107,7 @@ class ResidentAllowBitmap:
         h = C.c_void_p()
         N.check(self._lib.orama_allow_create(ctx.handle, bitmap.words.ctypes.data, bitmap.n_bits, C.byref(h)))
         self._h = h
+        ctx._adopt(self)
 
     def ffi_args(self):
         return self._lib.orama_allow_token(self._h), self.n_bits
@@ -143,7 +144,7 @@ class VectorSearchParams:
     filtered_doc_ids: Optional[AllowBitmap] = None
 
 
-class EmbeddingFieldStorage:
+class EmbeddingFieldStorage(Owner):
     def __init__(self, ctx: Context, model: Model | None = None, *, dimensions: int | None = None,
                  metric: int = N.METRIC_COSINE, reserve_rows: int = 0, dtype: int = N.DTYPE_F32):
         self._lib = N.load()
@@ -155,9 +156,11 @@ class EmbeddingFieldStorage:
                                            C.byref(h)))
         self.dtype = int(dtype)
         self._h = h
+        ctx._adopt(self)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
+            self._close_children()  # batchers first
             self._lib.orama_vec_destroy(self._h)
             self._h = None
 
@@ -265,6 +268,7 @@ class SearchBatcher:
         h = C.c_void_p()
         N.check(self._lib.orama_batcher_create(storage.handle, int(max_batch), int(max_wait_us), C.byref(h)))
         self._h = h
+        storage._adopt(self)
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _native as N
-from .context import Context
+from .context import Context, Owner
 from .embedding_field import AllowBitmap
 
 K1_DEFAULT = 1.2  # token_score.rs:283
@@ -245,6 +245,8 @@ class ScoreMap:
         self._h = handle
         self.hits = hits  # (ids, scores, count) of the search that produced the map
         self._store = store  # keeps the store alive: the handle holds a read lock on it
+        if store is not None:
+            store._adopt(self)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -304,6 +306,8 @@ class FacetField:
     def __init__(self, lib, handle, n_buckets, store=None):
         self._lib, self._h, self.n_buckets = lib, handle, n_buckets
         self._store = store  # a field must not outlive the store it was resolved against
+        if store is not None:
+            store._adopt(self)
 
     @classmethod
     def buckets(cls, store: "PostingsStore", buckets: list) -> "FacetField":
@@ -337,7 +341,7 @@ class FacetField:
             pass
 
 
-class PostingsStore:
+class PostingsStore(Owner):
     """HBM-resident postings of one index (seam ii)."""
 
     def __init__(self, ctx: Context):
@@ -347,9 +351,11 @@ class PostingsStore:
         N.check(self._lib.orama_post_create(ctx.handle, C.byref(h)))
         self._h = h
         self.n_docs = 0
+        ctx._adopt(self)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
+            self._close_children()  # score maps, facet fields, staged queries, batchers hold locks / pointers into it
             self._lib.orama_post_destroy(self._h)
             self._h = None
 
@@ -545,7 +551,9 @@ class PostingsStore:
         N.check(self._lib.orama_post_query_begin(self._h, arr, len(refs), b, C.byref(params), bm_ptr, bm_bits,
                                                  1 if hybrid else 0, 1 if apply_omc else 0, int(n_vec_cap),
                                                  C.c_void_p(stream), C.c_void_p(d_df_ptr), C.byref(h)))
-        return StagedQuery(self._lib, h, top_k)
+        sq = StagedQuery(self._lib, h, top_k)
+        self._adopt(sq)
+        return sq
 
 
 def post_block_bytes(top_k: int) -> int:
@@ -583,6 +591,8 @@ class StagedQuery:
             self._lib.orama_post_query_end(self._h)
             self._h = None
 
+    close = end
+
     def __del__(self):
         try:
             self.end()
@@ -610,6 +620,7 @@ class TermDictionary:
         N.check(self._lib.orama_dict_create(ctx.handle, blob.ctypes.data if blob.size else None, off.ctypes.data,
                                             len(enc), C.byref(h)))
         self._h = h
+        ctx._adopt(self)
 
     def expand(self, token: str, exact: bool = False, tolerance: int = 0) -> list[int]:
         """Indexes (ascending) of the matching terms."""
@@ -649,6 +660,7 @@ class PostSearchBatcher:
         h = C.c_void_p()
         N.check(self._lib.orama_post_batcher_create(store._h, int(max_batch), int(max_wait_us), C.byref(h)))
         self._h = h
+        store._adopt(self)
 
     def close(self) -> None:
         if getattr(self, "_h", None):

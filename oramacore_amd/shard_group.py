@@ -31,6 +31,7 @@ class _BorrowedContext(Context):
         self.device = device
 
     def close(self) -> None:
+        self._close_children()
         self._h = None
 
 
@@ -70,6 +71,8 @@ class ShardGroup:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
+            for c in self._ctxs:
+                c.close()  # what lives on the group's contexts goes first
             self._lib.orama_shard_group_destroy(self._h)
             self._h = None
 

@@ -1,3 +1,6 @@
 #!/bin/bash
+O=gpurun_out/r02filt
+mkdir -p $O
 cd $GRAFT_REPO_ROOT
-for cfg in "1 2" "1 4" "1 8" "2 2" "4 1" "4 2"; do set -- $cfg; echo "== TW=$1 BPC=$2"; ORAMA_F16_SOLO_TW=$1 ORAMA_F16_SOLO_BPC=$2 timeout 300 python scripts/two_stage_breakdown.py 2>&1 | tail -3 | head -1; done
+timeout 600 python scripts/bench_filtered.py > $O/filtered.log 2>&1; tail -9 $O/filtered.log
+( time timeout 900 python -m pytest tests/test_vector_f16_gpu.py tests/test_two_stage_gpu.py tests/test_random_gpu.py tests/test_batcher_gpu.py tests/test_facets_gpu.py tests/test_shard_group_gpu.py -m gpu -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; grep "passed\|failed\|Error" $O/pytest.log | head -3
