@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
         const uint32_t doc = b.post_doc[p];
         uint32_t dropped = 0;
         if (b.allow) {  // collect_contributions_with_filter: filtered docs never reach the scorer
-            const uint64_t id = b.docs[doc];
+            const uint64_t id = b.docs ? b.docs[doc] : b.dense_base + doc;  // dense ids: no table lookup
             dropped = !(id < b.allow_bits && ((b.allow[id >> 6] >> (id & 63)) & 1ull));
         }
         uint32_t ntf_bits = 0;
@@ -199,7 +199,8 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
             run0 = lo;
         }
         constexpr unsigned long long kEnd = ~0ull;  // above every key (local documents use 15 bits)
-        for (uint32_t lvl = 0; (1u << lvl) < ns && !(b.debug & 1u); ++lvl) {
+        const bool skip_merge = (b.debug & 1u) || (DF_ONLY && q.want_df == 2u);
+        for (uint32_t lvl = 0; (1u << lvl) < ns && !skip_merge; ++lvl) {
             unsigned long long outv[kPerThread];
             if (o_begin < cap) {
                 uint32_t pair = run0 >> (lvl + 1);
@@ -252,11 +253,16 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     }
 
     if (DF_ONLY) {
-        // corpus_docs.len(): distinct (token, document) pairs among the kept postings (token_score.rs:262-275)
+        // corpus_docs.len(): distinct (token, document) pairs among the kept postings (token_score.rs:262-275).
+        // want_df == 2: every token has ONE list, so every kept posting is its own pair — counted as gathered, unmerged.
         for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
             const unsigned long long key = s[e];
             if (key_dropped(key)) continue;
             bool first = true;
+            if (q.want_df == 2u) {
+                atomicAdd(&df_lds[key_tok(key)], 1u);
+                continue;
+            }
             for (uint32_t j = e; j > 0; --j) {
                 const unsigned long long kj = s[j - 1];
                 if (key_doc_tok(kj) != key_doc_tok(key)) break;

@@ -29,7 +29,7 @@ struct RangeQuery {
     uint32_t n_tokens;
     uint32_t use_threshold, threshold;
     float k;
-    uint32_t want_df;     // count df on the device (filter, or a token with several lists)
+    uint32_t want_df;     // count df on the device: 1 = a token has several lists (distinct pairs), 2 = only a filter
     uint32_t pad;
     uint64_t pad2;
 };
@@ -54,7 +54,8 @@ struct RangeBatch {
     const uint32_t* post_doc = nullptr;
     const uint32_t* post_val = nullptr;
     uint32_t* bounds = nullptr;
-    const uint64_t* docs = nullptr;      // local idx -> DocumentId (filter)
+    const uint64_t* docs = nullptr;      // local idx -> DocumentId (filter); nullptr when the ids are dense_base + idx
+    uint64_t dense_base = 0;
     const uint64_t* allow = nullptr;
     uint64_t allow_bits = 0;
     float b = 0.75f;

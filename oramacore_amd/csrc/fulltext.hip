@@ -517,7 +517,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             lens[c] = (uint32_t)pd.total;
             max_ranges = std::max(max_ranges, q.n_ranges);
             uint32_t per_token[kMaxTokens] = {0}, df[kMaxTokens] = {0};
-            bool df_known = d_allow == nullptr;
+            bool df_known = d_allow == nullptr, multi_list = false;
             // references in (token, reference order): the rank of a list among its token's lists is its position
             for (uint32_t t = 0; t < q.n_tokens; ++t) {
                 for (uint32_t i = 0; i < jb.n_refs; ++i) {
@@ -533,7 +533,10 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                     g.avg_len = p->avg_len[p->field_of_list[l]];
                     virt += len;
                     segs.push_back(g);
-                    if (++per_token[t] > 1) df_known = false;
+                    if (++per_token[t] > 1) {
+                        df_known = false;
+                        multi_list = true;
+                    }
                     df[t] += len;
                 }
             }
@@ -541,7 +544,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             const uint32_t ns = q.seg_end - q.seg_begin;
             bounds_entries += ((uint64_t)q.n_ranges + 1) * ns;
             max_bound_entries = std::max<uint64_t>(max_bound_entries, ((uint64_t)q.n_ranges + 1) * ns);
-            q.want_df = df_known ? 0u : 1u;
+            q.want_df = df_known ? 0u : (multi_list ? 1u : 2u);
             any_df |= !df_known;
             // idf per token by the host libm (calculate_idf, bm25.rs:78-82; df.max(1), token_score.rs:275)
             for (uint32_t t = 0; t < kMaxTokens; ++t) {
@@ -585,7 +588,8 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         rb.post_doc = p->d_post_doc.as<uint32_t>();
         rb.post_val = p->d_post_val.as<uint32_t>();
         rb.bounds = sc->misc1.as<uint32_t>();
-        rb.docs = p->d_docs.as<uint64_t>();
+        rb.docs = p->dense ? nullptr : p->d_docs.as<uint64_t>();
+        rb.dense_base = p->dense_base;
         rb.allow = d_allow;
         rb.allow_bits = bitmap_bits;
         rb.b = b;
