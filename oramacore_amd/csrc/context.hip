@@ -104,7 +104,9 @@ int take_one(orama_ctx* c, std::unique_ptr<orama::Scratch>* out, int kind) {  //
 int orama_ctx::acquire(std::unique_ptr<orama::Scratch>* out, int kind) {
     std::unique_lock<std::mutex> g(pool_mu);
     ++waiting_one;
-    pool_cv.wait(g, [&] { return leased < max_inflight; });
+    // a caller that needs several sets at once goes first: single takers would otherwise grab every freed set and the
+    // multi-set caller (a request batcher's dispatcher, the hybrid search) would never see two free together
+    pool_cv.wait(g, [&] { return leased < max_inflight && waiting_pair == 0; });
     --waiting_one;
     ORAMA_TRY(take_one(this, out, kind));
     ++leased;
@@ -126,7 +128,8 @@ int orama_ctx::acquire_n(uint32_t n, std::unique_ptr<orama::Scratch>** outs, con
         }
     }
     leased += n;
-    if (leased < max_inflight && waiting_one) pool_cv.notify_one();
+    if (waiting_pair) pool_cv_pair.notify_one();
+    else if (leased < max_inflight && waiting_one) pool_cv.notify_one();
     return ORAMA_OK;
 }
 
@@ -175,9 +178,8 @@ void orama_ctx::release(std::unique_ptr<orama::Scratch> s) {
     }
     pool.push_back(std::move(s));
     if (leased) --leased;
-    if (waiting_pair && leased + 2 <= max_inflight) pool_cv_pair.notify_one();
+    if (waiting_pair) pool_cv_pair.notify_one();  // it re-checks; freed sets accumulate for it (singles hold back)
     else if (waiting_one) pool_cv.notify_one();
-    else if (waiting_pair) pool_cv_pair.notify_one();
 }
 
 namespace orama {
