@@ -93,9 +93,10 @@ int orama_ctx_set_f16_tuning(orama_ctx* ctx, int ksteps_per_chunk, int ring_chun
 /* Kernel used for fp16 batches of 65..256 queries per corpus pass: 0 = K2 in passes of 64, 1 = K2c (MFMA waves also
  * issue the LDS-DMA), 2 / 3 = K2d producer/consumer kernel, geometry 1 / 2 (vec_f16_pc.hip).  Default 2. */
 int orama_ctx_set_f16_wide(orama_ctx* ctx, int mode);
-/* Scorer of the plain (non-hybrid, top-k) BM25 search over a resident store: 1 (default) = K3r, the document-range
- * partitioned scorer that takes whole query batches per launch (bm25_ranges.hip); 0 = K3, per-document records in HBM
- * (bm25_kernels.hip), which the hybrid / score-map / precomputed-ntf entry points always use.  Same results bit for bit. */
+/* Scorer of the BM25 searches over a resident store: 1 (default) = K3r, the document-range partitioned scorer that takes
+ * whole query batches per launch (bm25_ranges.hip) — for the plain top-k search and, where no OMC applies, for
+ * orama_post_search_hybrid; 2 = K3r for the plain search only; 0 = K3, per-document records in HBM (bm25_kernels.hip),
+ * which the score-map / precomputed-ntf / fused-hybrid entry points always use.  Same results bit for bit. */
 int orama_ctx_set_bm25_ranges(orama_ctx* ctx, int on);
 /* ORAMA_DTYPE_F32_SHADOW16 stores: 1 (default) = two-stage search where it pays (batches of more than 8 queries, or at
  * least 4 GB of fp32 rows: below that the plain scan is faster than the second stage's launches), 2 = always two stages,

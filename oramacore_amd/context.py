@@ -82,9 +82,10 @@ class Context(Owner):
         scan; always=True takes the two stages for small stores too."""
         N.check(self._lib.orama_ctx_set_two_stage(self.handle, (2 if always else 1) if on else 0))
 
-    def set_bm25_ranges(self, on: bool) -> None:
-        """Plain BM25 top-k searches: True = K3r range-partitioned batch scorer (default), False = K3 per-document records."""
-        N.check(self._lib.orama_ctx_set_bm25_ranges(self.handle, 1 if on else 0))
+    def set_bm25_ranges(self, on: bool, hybrid: bool = True) -> None:
+        """BM25 searches: True = K3r range-partitioned batch scorer (default; hybrid=False keeps it to the plain top-k
+        search), False = K3 per-document records."""
+        N.check(self._lib.orama_ctx_set_bm25_ranges(self.handle, (1 if hybrid else 2) if on else 0))
 
     def set_f16_wide(self, mode: int) -> None:
         """0 = K2 passes of 64, 1 = K2c, 2 / 3 = K2d geometry 1 / 2 (orama_ctx_set_f16_wide)."""

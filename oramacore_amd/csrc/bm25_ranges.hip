@@ -72,6 +72,42 @@ __global__ __launch_bounds__(kThreads) void range_bounds_kernel(RangeBatch b) {
     b.bounds[q.bounds_base + e] = lo;
 }
 
+// The additions BM25Scorer performs for ONE document, fed its (token, ntf) contributions in (token, reference) order:
+// S_t = sum of the token's ntf (Iterator::sum from 0.0, weight 1.0), score += idf_t (k+1) S_t / (k + S_t) unless S_t is
+// not normal or the term is NaN, token mask for the threshold (bm25.rs:369-428, 484-524).  Shared by the range kernel
+// and the per-document kernel of the hybrid path so that both produce the same bits.
+struct DocFold {
+    float score = 0.0f;  // entry(key).or_insert(0.0)
+    uint32_t mask = 0u;
+    bool applied = false, have = false;
+    uint32_t tok = 0;
+    float sum = 0.0f;
+    __device__ __forceinline__ void close_token(const float* idf, float k, float k1) {
+        if (f32_is_normal(sum)) {
+            const float term = idf[tok] * k1 * sum / (k + sum);  // bm25f_score, bm25.rs:124-126
+            if (term == term) {
+                score = score + term * 1.0f;  // phrase boost 1.0
+                mask |= 1u << (tok & 31u);    // 1 << term_index on u32 (wrapping shift)
+                applied = true;
+            }
+        }
+    }
+    __device__ __forceinline__ void add(uint32_t t, float ntf, const float* idf, float k, float k1) {
+        if (have && t != tok) {
+            close_token(idf, k, k1);
+            sum = 0.0f;
+        }
+        tok = t;
+        have = true;
+        sum = sum + 1.0f * ntf;  // Iterator::sum() from 0.0, weight 1.0
+    }
+    // true: the document is in the score map (threshold passed); `score` is final (before OMC)
+    __device__ __forceinline__ bool finish(const float* idf, float k, float k1, uint32_t use_threshold, uint32_t threshold) {
+        if (have) close_token(idf, k, k1);
+        return applied && !(use_threshold && (uint32_t)__popc(mask) < threshold);
+    }
+};
+
 // key of the in-range merge: [local doc:15 | token:6 | rank:10 | dropped:1 | ntf bits:32] — the order of the upper
 // 31 bits is (document, token, list rank); a posting dropped by the filter keeps its place in its run.
 __device__ __forceinline__ uint32_t key_doc(unsigned long long k) { return (uint32_t)(k >> 49); }
@@ -90,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     __shared__ float seg_boost[kRangeMaxRefs], seg_avg[kRangeMaxRefs];
     __shared__ float idf[kMaxTokens];
     __shared__ uint32_t df_lds[kMaxTokens];
-    __shared__ uint32_t red[2];
+    __shared__ uint32_t red[4];
 
     const uint32_t qi = blockIdx.y;
     const RangeQuery q = b.queries[qi];
@@ -100,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     const uint32_t ns = q.seg_end - q.seg_begin;
     const RangeSeg* segs = b.segs + q.seg_begin;
 
-    if (threadIdx.x < 2) red[threadIdx.x] = 0;
+    if (threadIdx.x < 4) red[threadIdx.x] = 0;
     for (uint32_t t = threadIdx.x; t < kMaxTokens; t += kThreads) {
         df_lds[t] = 0;
         if (!DF_ONLY) idf[t] = t < q.n_tokens ? b.idf[(size_t)qi * kMaxTokens + t] : 0.0f;
@@ -281,47 +317,29 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
 
     const float k1 = q.k + 1.0f;
     unsigned long long* out = b.keys + q.key_off + slot_base;
-    uint32_t my_count = 0;
+    uint32_t my_count = 0, my_max = 0u, my_min_inv = 0u;
     for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
         const unsigned long long key = s[e];
         unsigned long long out_key = 0ull;
         if (!(b.debug & 2u) && (e == 0 || key_doc(s[e - 1]) != key_doc(key))) {
             // first posting of a document: fold its run (lists of a token in reference order, tokens ascending)
             const uint32_t dl = key_doc(key);
-            float score = 0.0f;  // entry(key).or_insert(0.0)
-            uint32_t mask = 0u;
-            bool applied = false, have = false;
-            uint32_t tok = 0;
-            float sum = 0.0f;
-            auto close_token = [&]() {
-                if (f32_is_normal(sum)) {
-                    const float term = idf[tok] * k1 * sum / (q.k + sum);  // bm25f_score, bm25.rs:124-126
-                    if (term == term) {
-                        score = score + term * 1.0f;  // phrase boost 1.0
-                        mask |= 1u << (tok & 31u);    // 1 << term_index on u32 (wrapping shift)
-                        applied = true;
-                    }
-                }
-            };
+            DocFold f;
             unsigned long long kj = key;
             for (uint32_t j = e;;) {
-                if (!key_dropped(kj)) {
-                    const uint32_t t = key_tok(kj);
-                    if (have && t != tok) {
-                        close_token();
-                        sum = 0.0f;
-                    }
-                    tok = t;
-                    have = true;
-                    sum = sum + 1.0f * __builtin_bit_cast(float, (uint32_t)kj);  // Iterator::sum() from 0.0, weight 1.0
-                }
+                if (!key_dropped(kj)) f.add(key_tok(kj), __builtin_bit_cast(float, (uint32_t)kj), idf, q.k, k1);
                 if (++j >= cap) break;
                 kj = s[j];
                 if (key_doc(kj) != dl) break;
             }
-            if (have) close_token();
-            if (applied && !(q.use_threshold && (uint32_t)__popc(mask) < q.threshold)) {
+            if (f.finish(idf, q.k, k1, q.use_threshold, q.threshold)) {
                 const uint32_t doc = doc0 + dl;
+                float score = f.score;
+                if (q.track_minmax && score == score) {  // hybrid: min / max of the full-text scores (before any OMC)
+                    const uint32_t ord = f32_to_ordered(score);
+                    my_max = max(my_max, ord);
+                    my_min_inv = max(my_min_inv, ~ord);
+                }
                 if (b.omc_dense) score = score * b.omc_dense[doc];
                 ++my_count;
                 if (score == score)  // a NaN score stays in the map (count) and is never selected
@@ -332,8 +350,65 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     }
     my_count = wave_sum_u32(my_count);
     if ((threadIdx.x & 63) == 0 && my_count) atomicAdd(&red[1], my_count);
+    if (q.track_minmax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, off, 64));
+            my_min_inv = max(my_min_inv, (uint32_t)__shfl_xor((int)my_min_inv, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (my_max) atomicMax(&red[2], my_max);
+            if (my_min_inv) atomicMax(&red[3], my_min_inv);
+        }
+    }
     __syncthreads();
-    if (threadIdx.x == 0 && red[1]) atomicAdd(&b.results[qi].count, red[1]);
+    if (threadIdx.x == 0) {
+        if (red[1]) atomicAdd(&b.results[qi].count, red[1]);
+        if (red[2]) atomicMax(&b.results[qi].max_key, red[2]);
+        if (red[3]) atomicMax(&b.results[qi].min_inv, red[3]);
+    }
+}
+
+// Hybrid path: the full-text score of given documents.  One thread per document walks the query's references in
+// (token, reference) order, finds the document in each list by binary search, and folds what it finds with DocFold.
+__global__ __launch_bounds__(kThreads) void range_score_docs_kernel(RangeBatch b, uint32_t qi, const uint32_t* __restrict__ docs,
+                                                                    uint32_t n, float* __restrict__ out_score,
+                                                                    uint32_t* __restrict__ out_present) {
+    __shared__ float idf[kMaxTokens];
+    const RangeQuery q = b.queries[qi];
+    for (uint32_t t = threadIdx.x; t < kMaxTokens; t += kThreads) idf[t] = t < q.n_tokens ? b.idf[(size_t)qi * kMaxTokens + t] : 0.0f;
+    __syncthreads();
+    const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t doc = docs[j];
+    bool allowed = true;
+    if (b.allow) {
+        const uint64_t id = b.docs ? b.docs[doc] : b.dense_base + doc;
+        allowed = id < b.allow_bits && ((b.allow[id >> 6] >> (id & 63)) & 1ull);
+    }
+    const float k1 = q.k + 1.0f, one_minus_b = 1.0f - b.b;
+    DocFold f;
+    if (allowed) {
+        for (uint32_t i = q.seg_begin; i < q.seg_end; ++i) {
+            const RangeSeg sg = b.segs[i];
+            const uint32_t* pd = b.post_doc + sg.post_begin;
+            uint32_t lo = 0, hi = sg.len;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (pd[mid] < doc) lo = mid + 1; else hi = mid;
+            }
+            if (lo < sg.len && pd[lo] == doc) {
+                const uint32_t val = b.post_val[sg.post_begin + lo];
+                const float tf = (float)(val >> 16);
+                const float len = (float)(val & 0xffffu);
+                const float ntf = sg.boost * (tf / (one_minus_b + b.b * (len / sg.avg_len)));
+                f.add(sg.tok_rank >> 10, ntf, idf, q.k, k1);
+            }
+        }
+    }
+    const bool present = f.finish(idf, q.k, k1, q.use_threshold, q.threshold);
+    out_score[j] = f.score;
+    out_present[j] = present ? 1u : 0u;
 }
 
 }  // namespace
@@ -356,6 +431,16 @@ int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStr
     const dim3 grid(b.max_ranges, b.n_queries);
     if (df_only) hipLaunchKernelGGL(range_score_kernel<true>, grid, dim3(kThreads), 0, stream, b);
     else hipLaunchKernelGGL(range_score_kernel<false>, grid, dim3(kThreads), 0, stream, b);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_range_score_docs(orama_ctx* ctx, const RangeBatch& b, uint32_t qi, const uint32_t* d_doc, uint32_t n, float* d_out_score,
+                            uint32_t* d_out_present, hipStream_t stream) {
+    (void)ctx;
+    if (n == 0) return ORAMA_OK;
+    hipLaunchKernelGGL(range_score_docs_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, b, qi, d_doc, n,
+                       d_out_score, d_out_present);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -30,7 +30,7 @@ struct RangeQuery {
     uint32_t use_threshold, threshold;
     float k;
     uint32_t want_df;     // count df on the device: 1 = a token has several lists (distinct pairs), 2 = only a filter
-    uint32_t pad;
+    uint32_t track_minmax; // hybrid: reduce the largest / smallest non-NaN score into the result words
     uint64_t pad2;
 };
 
@@ -42,6 +42,10 @@ struct RangeResult {
     uint32_t overflow;    // a range held more than kRangeCap postings: rerun with smaller ranges
     uint32_t pad1[31];
     uint32_t df[kMaxTokens];
+    uint32_t max_key;     // hybrid: ordered(largest non-NaN score), 0 = none
+    uint32_t pad2[31];
+    uint32_t min_inv;     // hybrid: ~ordered(smallest non-NaN score), 0 = none
+    uint32_t pad3[31];
 };
 
 struct RangeBatch {
@@ -70,5 +74,9 @@ struct RangeBatch {
 int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream);
 // df_only: count distinct (token, document) pairs into results[q].df for the queries that want it.
 int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStream_t stream);
+// Hybrid: the full-text score of `n` given documents (local indices) of query `qi`, by the same fold as the range kernel
+// (lists of a token in reference order, tokens ascending): out_score[j] / out_present[j] (in the score map or not).
+int launch_range_score_docs(orama_ctx* ctx, const RangeBatch& b, uint32_t qi, const uint32_t* d_doc, uint32_t n, float* d_out_score,
+                            uint32_t* d_out_present, hipStream_t stream);
 
 }  // namespace orama

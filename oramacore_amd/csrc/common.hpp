@@ -145,11 +145,12 @@ struct ProfScope {
 // ---------------------------------------------------------------- per-call scratch
 // One set per in-flight search: its own stream, device scratch and pinned staging, so that
 // concurrent orama_*_search calls never share mutable state (re-entrancy contract of the ABI).
-// Two kinds of set, never mixed in use: kScratchRecords sets carry K3's per-document records (1.4 GB at 10 M documents),
-// kScratchGeneral sets everything else (a wide fp16 batch sizes its candidate lists in GB as well).  A set that served
-// both would end up holding both — 32 such sets overrun the pool's byte budget and every release would free and every
-// query re-allocate and re-zero them.
-constexpr int kScratchGeneral = 0, kScratchRecords = 1;
+// Three kinds of set, never mixed in use: kScratchRecords sets carry K3's per-document records (1.4 GB at 10 M documents),
+// kScratchVector sets the buffers of vector searches (a wide fp16 batch sizes its candidate lists in GB), kScratchGeneral
+// sets everything else (the range scorer needs a few MB).  A set that served several of these would end up holding all
+// of their buffers — 32 such sets overrun the pool's byte budget — or, worse, keep being re-sized: a vector batch that
+// draws a set last used by a small full-text query re-allocates GBs (hipFree synchronises the device).
+constexpr int kScratchGeneral = 0, kScratchRecords = 1, kScratchVector = 2;
 
 struct Scratch {
     int kind = kScratchGeneral;
@@ -202,6 +203,7 @@ struct orama_ctx {
     // plain BM25 top-k searches of a resident store use the range-partitioned scorer (K3r, bm25_ranges.hip);
     // 0 = always the per-document-record scorer K3 (ORAMA_BM25_RANGES, orama_ctx_set_bm25_ranges)
     int bm25_ranges = 1;
+    int bm25_ranges_hybrid = 1;  // orama_post_search_hybrid on the range scorer where it applies (ORAMA_BM25_RANGES_HYBRID=0: K3)
     // stores created as ORAMA_DTYPE_F32_SHADOW16 answer orama_vec_search in two stages (fp16 candidates, fp32 decision);
     // 0 = always the plain fp32 scan, 2 = two stages also where the plain scan is expected to be faster (small stores
     // with few queries) (ORAMA_TWO_STAGE, orama_ctx_set_two_stage)

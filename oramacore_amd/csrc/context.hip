@@ -316,6 +316,7 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
     if (const char* e = std::getenv("ORAMA_F32_MULTI")) c->f32_multi = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_WIDE")) c->f16_wide = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_BM25_RANGES")) c->bm25_ranges = std::atoi(e) != 0;
+    if (const char* e = std::getenv("ORAMA_BM25_RANGES_HYBRID")) c->bm25_ranges_hybrid = std::atoi(e) != 0;
     if (const char* e = std::getenv("ORAMA_TWO_STAGE")) c->two_stage = std::max(0, std::min(2, std::atoi(e)));
     if (const char* e = std::getenv("ORAMA_F16_SOLO")) c->f16_solo = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_KC")) c->f16_kc = std::atoi(e);
@@ -439,7 +440,9 @@ int orama_ctx_set_two_stage(orama_ctx* ctx, int on) {
 
 int orama_ctx_set_bm25_ranges(orama_ctx* ctx, int on) {
     ORAMA_REQUIRE(ctx, "null context");
+    ORAMA_REQUIRE(on >= 0 && on <= 2, "bm25 ranges mode %d outside [0, 2]", on);
     ctx->bm25_ranges = on != 0;
+    ctx->bm25_ranges_hybrid = on == 1;
     return ORAMA_OK;
 }
 

@@ -416,6 +416,12 @@ struct RangeJob {
     float* out_scores;
     uint32_t* out_n;
     uint64_t* out_count;
+    // hybrid (normalize_and_combine with a vector map, token_score.rs:393-422): only as a batch of one
+    bool hybrid = false;
+    const uint64_t* vec_doc = nullptr;
+    const float* vec_score = nullptr;
+    uint32_t n_vec = 0;
+    bool* fallback = nullptr;  // set when the answer could not be proven exact from the candidates: run K3 instead
 };
 
 constexpr uint32_t kRangeBatchMax = 32;             // queries scored by one set of launches
@@ -448,6 +454,101 @@ uint32_t choose_log_r(uint64_t n_docs, uint64_t total_postings, uint32_t shrink)
     return lr > 3 * shrink ? lr - 3 * shrink : 0;
 }
 
+// Hybrid answer from the range scorer's outputs (a batch of one, no OMC): normalize_and_combine + count + top_n
+// (token_score.rs:393-422, search.rs:482, sort.rs:260-279) evaluated on the host over
+//   cand      the best k_asked = top_k + n_vec + 1 full-text documents by (raw score desc, doc asc),
+//   vft/vpr   the full-text score of every vector hit (same fold, range_score_docs_kernel) / whether it is in the map,
+//   res       count of the full-text map and the extremes of its non-NaN scores.
+// (s - min) / (max - min) is monotone in s, so the final top_k among full-text-only documents lies inside the raw
+// top-(top_k + n_vec + 1) — unless rounding maps the last candidate's score onto the k-th final score (then an unseen
+// document with a smaller id could tie its way in): that case is handed to the per-record scorer (*fallback).
+// Same f32 operations as K5's kernels (this translation unit is compiled with -ffp-contract=off).
+int hybrid_from_candidates(const RangeJob& jb, const RangeResult& res, const uint64_t* cand_id, const float* cand_score,
+                           uint32_t n_cand, uint32_t k_asked, const float* vft, const uint32_t* vpr) {
+    const uint32_t top_k = jb.params->top_k, nv = jb.n_vec;
+    float vmn, vmx;
+    vec_min_max(jb.vec_score, nv, &vmn, &vmx);
+    float mx = 0.0f, mn = 0.0f;  // fold(0.0, f32::max / f32::min) over both maps
+    if (vmx > mx) mx = vmx;
+    if (vmn < mn) mn = vmn;
+    auto ordered_to_f32 = [](uint32_t key) {
+        const uint32_t u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    if (res.max_key != 0u) {
+        const float v = ordered_to_f32(res.max_key);
+        if (v > mx) mx = v;
+    }
+    if (res.min_inv != 0u) {
+        const float v = ordered_to_f32(~res.min_inv);
+        if (v < mn) mn = v;
+    }
+    const float den = mx - mn;
+    struct Entry {
+        float score;
+        uint64_t doc;
+    };
+    std::vector<Entry> out;
+    out.reserve((size_t)n_cand + nv);
+    // vector hits: ft' + v' when the document is in the full-text map, 0.0 + v' otherwise
+    uint64_t count = res.count;
+    for (uint32_t j = 0; j < nv; ++j) {
+        const float v = (jb.vec_score[j] - mn) / den;
+        float sc;
+        if (vpr[j]) {
+            sc = (vft[j] - mn) / den;
+            sc = sc + v;
+        } else {
+            sc = 0.0f + v;
+            ++count;
+        }
+        out.push_back(Entry{sc, jb.vec_doc[j]});
+    }
+    // full-text-only candidates
+    float last_norm = 0.0f;
+    bool have_last = false;
+    for (uint32_t i = 0; i < n_cand; ++i) {
+        const float sn = (cand_score[i] - mn) / den;
+        if (i == n_cand - 1) {
+            last_norm = sn;
+            have_last = true;
+        }
+        bool is_vec = false;
+        for (uint32_t j = 0; j < nv && !is_vec; ++j) is_vec = jb.vec_doc[j] == cand_id[i];
+        if (!is_vec) out.push_back(Entry{sn, cand_id[i]});
+    }
+    // top_n: NaN never selected; score desc, DocumentId asc; -0.0 comes back as +0.0 (K4's key canonicalises the zero)
+    std::vector<Entry> sel;
+    sel.reserve(out.size());
+    for (Entry e : out)
+        if (e.score == e.score) {
+            if (e.score == 0.0f) e.score = 0.0f;
+            sel.push_back(e);
+        }
+    std::sort(sel.begin(), sel.end(), [](const Entry& a, const Entry& b) { return a.score > b.score || (a.score == b.score && a.doc < b.doc); });
+    const uint32_t n_out = (uint32_t)std::min<size_t>(sel.size(), top_k);
+    // exactness: were there full-text documents beyond the candidates that could still enter the top_k?
+    if (n_cand >= k_asked && have_last && top_k > 0) {
+        const bool full = sel.size() >= top_k;
+        // an unseen document normalises to <= last_norm; it cannot displace anything when the k-th final score is strictly above
+        if (!full || !(sel[top_k - 1].score > last_norm)) {
+            if (last_norm == last_norm) {  // NaN: nothing unseen can be selected either
+                *jb.fallback = true;
+                return ORAMA_OK;
+            }
+        }
+    }
+    for (uint32_t i = 0; i < n_out; ++i) {
+        jb.out_ids[i] = sel[i].doc;
+        jb.out_scores[i] = sel[i].score;
+    }
+    *jb.out_n = n_out;
+    if (jb.out_count) *jb.out_count = count;
+    return ORAMA_OK;
+}
+
 // Score `n_jobs` eligible queries (each validated by check_params and ranges_eligible) on sc->stream; synchronises.
 int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_t n_jobs, float b,
                        const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc) {
@@ -459,6 +560,19 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         uint32_t shrink;
         uint64_t total;
     };
+    // hybrid (a batch of one): the vector map as local document indices; a hit that is not a document of this index is the
+    // per-record scorer's business (it reports the error)
+    std::vector<uint32_t> vec_local;
+    if (n_jobs == 1 && jobs[0].hybrid) {
+        const RangeJob& jb = jobs[0];
+        *jb.fallback = false;
+        vec_local.resize(jb.n_vec);
+        for (uint32_t j = 0; j < jb.n_vec; ++j)
+            if (!p->local_of(jb.vec_doc[j], &vec_local[j])) {
+                *jb.fallback = true;
+                return ORAMA_OK;
+            }
+    }
     std::vector<Pending> pending;
     for (uint32_t j = 0; j < n_jobs; ++j) {
         const RangeJob& jb = jobs[j];
@@ -472,6 +586,10 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                           jb.params->n_tokens);
             ORAMA_REQUIRE(jb.refs[i].list < p->n_lists, "ref %u: list %u out of range", i, jb.refs[i].list);
             total += p->list_off[jb.refs[i].list + 1] - p->list_off[jb.refs[i].list];
+        }
+        if (!total && jb.hybrid) {  // no full-text side at all: the per-record path combines the vector map alone
+            *jb.fallback = true;
+            return ORAMA_OK;
         }
         if (total) pending.push_back({j, 0u, total});
     }
@@ -489,7 +607,10 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             const uint64_t mt = std::max(max_total, pending[i].total);
             if (!chunk.empty() && mt * (chunk.size() + 1) > kRangeKeyBudget) break;
             max_total = mt;
-            kmax = std::max(kmax, jobs[pending[i].job].params->top_k);
+            {
+                const RangeJob& jb = jobs[pending[i].job];
+                kmax = std::max(kmax, jb.hybrid ? jb.params->top_k + jb.n_vec + 1 : jb.params->top_k);
+            }
             chunk.push_back(i);
         }
         const uint32_t nq = (uint32_t)chunk.size();
@@ -514,6 +635,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             q.use_threshold = jb.params->use_threshold != 0;
             q.threshold = jb.params->threshold;
             q.k = jb.params->k;
+            q.track_minmax = jb.hybrid ? 1u : 0u;
             lens[c] = (uint32_t)pd.total;
             max_ranges = std::max(max_ranges, q.n_ranges);
             uint32_t per_token[kMaxTokens] = {0}, df[kMaxTokens] = {0};
@@ -631,6 +753,24 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         const char* h_val = h_ids + (size_t)nq * kk * 8;
         const char* h_n = h_val + (size_t)nq * kk * 4;
         ORAMA_HIP_TRY(hipMemcpyAsync(h_res, d_out, kmax ? out_bytes : res_bytes, hipMemcpyDeviceToHost, s));
+        const bool hybrid_job = n_jobs == 1 && jobs[0].hybrid;
+        const uint32_t nv = hybrid_job ? jobs[0].n_vec : 0;
+        float* h_vft = nullptr;       // full-text score of every vector hit ...
+        uint32_t* h_vpresent = nullptr;  // ... and whether it is in the full-text map at all
+        if (nv) {
+            ORAMA_TRY(sc->misc5.reserve((size_t)nv * 12));
+            ORAMA_TRY(sc->h_misc.reserve((size_t)nq * kMaxTokens * 4 + 4096 + (size_t)nv * 12));
+            char* hv = sc->h_misc.as<char>() + (size_t)nq * kMaxTokens * 4 + 4096;  // behind the idf staging
+            memcpy(hv, vec_local.data(), (size_t)nv * 4);
+            ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc5.p, hv, (size_t)nv * 4, hipMemcpyHostToDevice, s));
+            uint32_t* d_vidx = sc->misc5.as<uint32_t>();
+            float* d_vft = reinterpret_cast<float*>(d_vidx + nv);
+            uint32_t* d_vpr = d_vidx + 2 * (size_t)nv;
+            ORAMA_TRY(launch_range_score_docs(p->ctx, rb, 0, d_vidx, nv, d_vft, d_vpr, s));
+            ORAMA_HIP_TRY(hipMemcpyAsync(hv + (size_t)nv * 4, d_vft, (size_t)nv * 8, hipMemcpyDeviceToHost, s));
+            h_vft = reinterpret_cast<float*>(hv + (size_t)nv * 4);
+            h_vpresent = reinterpret_cast<uint32_t*>(hv + (size_t)nv * 8);
+        }
         ORAMA_HIP_TRY(hipStreamSynchronize(s));
         // hand the answers out; a query whose ranges overflowed stays pending with smaller ranges
         std::vector<Pending> still;
@@ -643,6 +783,11 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                 ORAMA_REQUIRE(queries[c].log_r > 0, "internal: a one-document range overflowed");
                 ++pd.shrink;
                 still.push_back(pd);
+                continue;
+            }
+            if (jb.hybrid) {
+                ORAMA_TRY(hybrid_from_candidates(jb, h_res[c], reinterpret_cast<const uint64_t*>(h_ids), reinterpret_cast<const float*>(h_val),
+                                                 kmax ? reinterpret_cast<const uint32_t*>(h_n)[0] : 0u, kmax, h_vft, h_vpresent));
                 continue;
             }
             if (jb.out_count) *jb.out_count = h_res[c].count;
@@ -672,7 +817,30 @@ int post_search_impl(orama_post* p, const orama_term_ref* refs, uint32_t n_refs,
     ORAMA_REQUIRE(!hybrid || n_vec == 0 || (vec_doc && vec_score), "null vector map");
     ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
     std::shared_lock<std::shared_mutex> lk(p->mu);
-    const bool by_ranges = !hybrid && ranges_eligible(p, refs, n_refs, params);
+    const bool eligible = ranges_eligible(p, refs, n_refs, params);
+    const bool by_ranges = !hybrid && eligible;
+    // hybrid on the range scorer: when no OMC applies (multipliers reorder documents arbitrarily: the candidate argument of
+    // hybrid_from_candidates would not hold) and the candidates fit one selection
+    const bool hybrid_by_ranges = hybrid && eligible && p->ctx->bm25_ranges_hybrid && !(apply_omc && p->has_omc) &&
+                                  (uint64_t)params->top_k + n_vec + 1 <= kSelectMaxK;
+    if (hybrid_by_ranges) {
+        ORAMA_TRY(check_params(params));
+        bool fallback = false;
+        {
+            ScratchLease scg(p->ctx, kScratchGeneral);
+            ORAMA_TRY(scg.init());
+            RangeJob job{refs, n_refs, params, out_ids, out_scores, out_n, out_count};
+            job.hybrid = true;
+            job.vec_doc = vec_doc;
+            job.vec_score = vec_score;
+            job.n_vec = n_vec;
+            job.fallback = &fallback;
+            ORAMA_TRY(post_search_ranges(p, scg.s.get(), &job, 1, b, allow_bitmap, bitmap_bits, 0));
+        }
+        if (!fallback) return ORAMA_OK;
+        *out_n = 0;
+        if (out_count) *out_count = 0;
+    }
     ScratchLease sc(p->ctx, by_ranges ? kScratchGeneral : kScratchRecords);
     ORAMA_TRY(sc.init());
     if (by_ranges) {
@@ -1507,7 +1675,7 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
     // a store with an fp16 shadow answers the vector leg with the two-stage plan (same answer, half the bytes scanned):
     // it needs a third scratch set, and blocks — so the full-text leg is enqueued first and runs beside it
     const bool two_stage = vec_rows(v) > 0 && limit > 0 && vec_two_stage_usable(v, query, 1, limit);
-    ScratchLease a(ctx), a2(ctx), bsc(ctx, kScratchRecords);
+    ScratchLease a(ctx, kScratchVector), a2(ctx, kScratchVector), bsc(ctx, kScratchRecords);
     if (two_stage) ORAMA_TRY(ScratchLease::init_three(a, a2, bsc));
     else ORAMA_TRY(ScratchLease::init_pair(a, bsc));
     // ---- leg A: vector scan + top-`limit` rows

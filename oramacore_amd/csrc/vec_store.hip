@@ -1123,7 +1123,7 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     if (v->n_rows.load(std::memory_order_acquire) == 0) return ORAMA_OK;
     // fp32 rows + fp16 shadow: candidates from the shadow scan, exact distances from the fp32 rows (two_stage_search)
     const bool two_stage = vec_two_stage_usable(v, queries, q, k);
-    ScratchLease sc(v->ctx), sc2(v->ctx);
+    ScratchLease sc(v->ctx, kScratchVector), sc2(v->ctx, kScratchVector);
     if (two_stage) ORAMA_TRY(ScratchLease::init_pair(sc, sc2));  // both at once: callers holding one set each cannot wait for each other
     else ORAMA_TRY(sc.init());
     hipStream_t s = sc->stream;

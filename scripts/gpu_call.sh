@@ -1,3 +1,6 @@
 #!/bin/bash
+O=gpurun_out/r02hyb
+mkdir -p $O
 cd $GRAFT_REPO_ROOT
-( timeout 900 python -m pytest tests/test_vector_gpu.py tests/test_batcher_gpu.py tests/test_token_score_gpu.py tests/test_fulltext_gpu.py tests/test_two_stage_gpu.py tests/test_post_append_gpu.py -m gpu -x -q -p no:cacheprovider ) 2>&1 | grep "passed\|failed\|rror" | head -3
+( time timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; grep "passed\|failed\|rror" $O/pytest.log | head -3
+timeout 400 scripts/native/bench_serving hybrid 10000000 40 128,512 shadow > $O/serving_hybrid_shadow2.log 2>&1; tail -4 $O/serving_hybrid_shadow2.log

@@ -258,3 +258,71 @@ def test_request_batcher_equals_direct_searches(ctx):
     assert len(ids) == 5
     batcher.close()
     corpus.store.close()
+
+
+def test_hybrid_on_the_range_scorer(ctx):
+    """orama_post_search_hybrid on K3r (no OMC): candidates + exact scores of the vector hits + host combine — against
+    the oracle's normalize_and_combine + top_n and against K3, bit for bit; cases that must fall back (ties at the cut,
+    OMC, empty full-text side) still answer correctly."""
+    rng = np.random.default_rng(31)
+    n_docs = 50_000
+    corpus = Corpus(ctx, n_docs, random_lists(rng, n_docs, 20, 2, 100, 8000), [90.0, 14.0], seed=32)
+    allow_mask = rng.random(n_docs) < 0.7
+    bm = oa.AllowBitmap(n_docs, np.nonzero(allow_mask)[0].astype(np.uint64))
+
+    def oracle(refs, n_tok, k, vec, thr=None, mask=None, omc=None):
+        fd, fs = orc.search_full_text(corpus.entries(refs, mask), n_tok, float(n_docs), 1.2, thr)
+        od, os_ = orc.normalize_and_combine(list(vec), list(vec.values()), fd, fs)
+        if omc:
+            os_ = orc.apply_omc(od, os_, list(omc), list(omc.values()))
+        td, ts = orc.top_n(od, os_, k)
+        return td, ts, len(od)
+
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for case in range(10):
+        n_tok = int(rng.integers(1, 6))
+        refs = [(t, int(l), float(F(rng.choice([1.0, 2.0])))) for t in range(n_tok)
+                for l in rng.choice(20, size=int(rng.integers(1, 3)), replace=False)]
+        fd, fs = orc.search_full_text(corpus.entries(refs), n_tok, float(n_docs), 1.2, None)
+        inside = rng.choice(fd, size=min(30, len(fd)), replace=False)
+        outside = np.setdiff1d(rng.choice(n_docs, size=40, replace=False).astype(np.uint64), fd)[:20]
+        vec = {int(d): float(F(s)) for d, s in zip(np.concatenate([inside, outside]), rng.uniform(-0.3, 1.0, size=len(inside) + len(outside)))}
+        for k in (1, 10, 100):
+            for filt in (False, True):
+                thr = None if case % 2 else 1
+                od, os_, ocount = oracle(refs, n_tok, k, vec, thr, allow_mask if filt else None)
+                for mode in (True, False):
+                    ctx.set_bm25_ranges(True, hybrid=mode)
+                    ids, sc, count = corpus.store.search(refs, n_tok, float(n_docs), k, thr, allow=bm if filt else None,
+                                                         vector=vec, apply_omc=False)
+                    assert count == ocount, (case, k, filt, mode)
+                    assert ids.tolist() == od.tolist(), (case, k, filt, mode)
+                    assert np.array_equal(bits(sc), bits(os_)), (case, k, filt, mode)
+    ctx.set_bm25_ranges(True)
+    ctx.prof_enable(False)
+    assert ctx.prof_get("bm25_range_score")[1] > 0  # the range scorer really served hybrid queries
+    # ties at the cut: every document has the same score — the candidate argument cannot decide, K3 answers
+    docs = np.arange(3000, dtype=np.int64)
+    flat = Corpus(ctx, 3000, [(0, docs)], [7.0], seed=1)
+    flat.lists[0] = (0, docs, np.ones(3000, dtype=np.int64), np.full(3000, 7, dtype=np.int64))
+    flat.store.build(flat.doc_ids, flat.avg, [ft.PostingList(field=0, docs=flat.doc_ids, tf=np.ones(3000), field_len=np.full(3000, 7))])
+    vec = {2999: 0.9, 5: 0.1}
+    ids, sc, count = flat.store.search([(0, 0, 1.0)], 1, 3000.0, 10, vector=vec, apply_omc=False)
+    fd, fs = orc.search_full_text(flat.entries([(0, 0, 1.0)]), 1, 3000.0, 1.2, None)
+    od, os_ = orc.normalize_and_combine(list(vec), list(vec.values()), fd, fs)
+    td, ts = orc.top_n(od, os_, 10)
+    assert count == len(od) and ids.tolist() == td.tolist() and np.array_equal(bits(sc), bits(ts))
+    # OMC applies -> K3; empty full-text side -> K3 (the vector map alone)
+    corpus.store.set_omc({int(corpus.doc_ids[7]): 3.0})
+    refs = [(0, 0, 1.0), (1, 3, 1.0)]
+    vec = {int(corpus.doc_ids[7]): 0.5, int(corpus.doc_ids[11]): 0.7}
+    od, os_, ocount = oracle(refs, 2, 20, vec, omc={int(corpus.doc_ids[7]): 3.0})
+    ids, sc, count = corpus.store.search(refs, 2, float(n_docs), 20, vector=vec, apply_omc=True)
+    assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
+    ids, sc, count = corpus.store.search([], 1, float(n_docs), 5, vector=vec, apply_omc=False)
+    od, os_ = orc.normalize_and_combine(list(vec), list(vec.values()), np.zeros(0, np.uint64), np.zeros(0, np.float32))
+    td, ts = orc.top_n(od, os_, 5)
+    assert count == 2 and ids.tolist() == td.tolist() and np.array_equal(bits(sc), bits(ts))
+    flat.store.close()
+    corpus.store.close()
