@@ -191,11 +191,11 @@ struct ScanTuning {
 struct orama_ctx {
     int device = 0;
     orama::ScanTuning scan_tuning;  // defaults from ORAMA_SCAN_* env, see orama_ctx_set_scan_tuning
-    // Experimental: K1 keeps per-wave top-k lists (k <= 128) in registers instead of writing dense distances
-    // (ORAMA_FUSED_TOPK=1).  Exact and tested, but measured SLOWER on MI355X (profiles/r01_fused_topk_experiment.md):
-    // the 64-bit shuffle re-reduction per insert lengthens each wave's latency-bound critical path and the LDS
-    // bitonic reduction of the wave lists costs more than the dense radix select — so it is off by default.
-    int fused_topk = 0;
+    // K1 keeps per-wave top-k lists (k <= 128) in registers instead of writing dense distances: 0 never, 1 always, 2 =
+    // for a single query over >= 8 GB of rows (ORAMA_FUSED_TOPK).  Exact (same answer as the dense path, tested).  Round 1
+    // measured it slower everywhere (profiles/r01_fused_topk_experiment.md: the LDS bitonic reduction of the wave lists);
+    // with the radix-select reduction of round 2 it wins at NS size: 4.51 -> 4.32 ms per scan.
+    int fused_topk = 2;
     int f32_multi = 1;   // K1b: fp32 batches of 2..8 queries share one corpus pass (ORAMA_F32_MULTI=0 disables)
     // fp16 batches of 65..256 queries share one corpus pass: 2 = K2d (dedicated loader waves, default), 3 = K2d second
     // geometry, 1 = K2c (round 1: MFMA waves issue the DMA), 0 = K2 in passes of 64 (ORAMA_F16_WIDE)

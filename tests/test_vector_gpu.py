@@ -293,7 +293,7 @@ def test_concurrent_searches_with_inserts_and_deletes(ctx):
 
 
 def test_experimental_fused_topk_path_is_exact(monkeypatch):
-    """ORAMA_FUSED_TOPK=1 (per-wave register top-k inside K1; off by default because it measured slower) must
+    """ORAMA_FUSED_TOPK=1 (per-wave register top-k inside K1; by default only for one query over a large corpus) must
     return exactly what the default dense path returns."""
     n, d = 30_000, 768
     corpus = util.gaussian_rows(n, d, seed=301)
