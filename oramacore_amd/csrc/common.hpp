@@ -192,7 +192,7 @@ struct orama_ctx {
     int device = 0;
     orama::ScanTuning scan_tuning;  // defaults from ORAMA_SCAN_* env, see orama_ctx_set_scan_tuning
     // K1 keeps per-wave top-k lists (k <= 128) in registers instead of writing dense distances: 0 never, 1 always, 2 =
-    // for a single query over >= 8 GB of rows (ORAMA_FUSED_TOPK).  Exact (same answer as the dense path, tested).  Round 1
+    // for a single query over >= 3 GB of rows (ORAMA_FUSED_TOPK).  Exact (same answer as the dense path, tested).  Round 1
     // measured it slower everywhere (profiles/r01_fused_topk_experiment.md: the LDS bitonic reduction of the wave lists);
     // with the radix-select reduction of round 2 it wins at NS size: 4.51 -> 4.32 ms per scan.
     int fused_topk = 2;

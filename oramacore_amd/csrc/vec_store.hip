@@ -399,9 +399,10 @@ int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_
     // fused_topk: 1 = always, 0 = never, 2 (default) = for ONE query over a large corpus: the dense path writes and
     // re-reads 4 B per row for K4 (40 MB at 10 M rows) and K1b does not apply to a single query — measured at NS
     // 4.51 -> 4.32 ms per scan (85 -> 89 % of the HBM roofline); on a 1 M x 384 corpus the per-wave lists and their
-    // reduction cost more than the 4 MB they save (0.24 -> 0.28 ms), so the rule asks for >= 8 GB of rows
+    // reduction cost more than the 4 MB they save (0.24 -> 0.28 ms); 1.25 M x 768 (3.8 GB, the 8-GPU shard) already gains 1.5 %, 2.5 M
+    // x 768 4.6 %: the rule asks for >= 3 GB of rows
     const bool fuse = v->ctx->fused_topk == 1 ||
-                      (v->ctx->fused_topk == 2 && q == 1 && n * (uint64_t)v->row_bytes() >= (8ull << 30));
+                      (v->ctx->fused_topk == 2 && q == 1 && n * (uint64_t)v->row_bytes() >= (3ull << 30));
     if (k <= kWaveListKeys && fuse) {
         // fused path: each K1 wave keeps its own best-k in registers; no dense distance array at all.
         ScanArgs a;
