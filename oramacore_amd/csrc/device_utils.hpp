@@ -169,4 +169,57 @@ struct WaveTopK {
     }
 };
 
+// The same list with SLOTS x 64 entries (lane l holds entries l, l + 64, ...): 256 keys for the candidate stage of the
+// two-stage search, which asks for max(2k, k + 128) rows.
+template <int SLOTS>
+struct WaveTopKN {
+    unsigned long long s[SLOTS];
+    unsigned long long thr = 0ull;
+    uint32_t count = 0;
+    uint32_t min_pos = 0;
+
+    __device__ __forceinline__ WaveTopKN() {
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) s[j] = 0ull;
+    }
+    __device__ __forceinline__ void recompute_min(uint32_t k, int lane) {
+        unsigned long long m = ~0ull;
+        uint32_t which = 0;
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j)
+            if ((uint32_t)lane + 64u * j < k && s[j] < m) {
+                m = s[j];
+                which = j;
+            }
+        unsigned long long w = m;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(w, off, 64);
+            w = o < w ? o : w;
+        }
+        thr = w;
+        const unsigned long long owners = __ballot(m == w);
+        const int fl = __ffsll((long long)owners) - 1;
+        min_pos = (uint32_t)fl + 64u * (uint32_t)__shfl((int)which, fl, 64);
+    }
+    __device__ __forceinline__ void set_slot(uint32_t pos, unsigned long long key, int lane) {
+        if ((uint32_t)lane == (pos & 63u)) {
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j)
+                if ((pos >> 6) == (uint32_t)j) s[j] = key;
+        }
+    }
+    // key must be wave-uniform; call only when (count < k || key > thr)
+    __device__ __forceinline__ void insert(unsigned long long key, uint32_t k, int lane) {
+        if (count < k) {
+            set_slot(count, key, lane);
+            ++count;
+            if (count == k) recompute_min(k, lane);
+        } else {
+            set_slot(min_pos, key, lane);
+            recompute_min(k, lane);
+        }
+    }
+};
+
 }  // namespace orama

@@ -487,6 +487,111 @@ __global__ __launch_bounds__(256) void vec_scan_f16_solo2_kernel(F16ScanArgs a, 
     }
 }
 
+// K1h fused: ONE query, the best `topk` <= 256 rows of every wave stay in registers (WaveTopKN<4>) — one launch over the
+// whole store instead of dense head + selection + filter scan + selection.
+template <int G>
+__global__ __launch_bounds__(256) void vec_scan_f16_solo_fused_kernel(F16ScanArgs a, uint32_t ksteps, uint64_t tile_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t frag_total = ksteps * 2;
+    float* qinv = reinterpret_cast<float*>(lds + (size_t)frag_total * 16);
+    for (uint32_t idx = tid; idx < frag_total; idx += 256) {
+        const uint32_t k0 = idx * 8;
+        h8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t k = k0 + e;
+            v[e] = (_Float16)(k < a.dim ? a.queries[k] : 0.0f);
+        }
+        *reinterpret_cast<h8*>(lds + (size_t)idx * 16) = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float ss = 0.0f;
+        for (uint32_t k = 0; k < ksteps * 16; ++k) {
+            const float x = (float)reinterpret_cast<const _Float16*>(lds + (size_t)(k >> 3) * 16)[k & 7];
+            ss = fmaf(x, x, ss);
+        }
+        qinv[0] = a.metric == ORAMA_METRIC_L2SQ ? ss : (ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f);
+    }
+    __syncthreads();
+    const bool l2 = a.metric == ORAMA_METRIC_L2SQ;
+    const uint32_t gw = uniform_u32(blockIdx.x * 4 + (tid >> 6));
+    const uint32_t gwaves = gridDim.x * 4;
+    const uint64_t t_first = a.row_begin >> 5;
+    const uint64_t t_end = (a.row_end + 31) >> 5;
+    const char* base = reinterpret_cast<const char*>(a.tiled);
+    const uint32_t half = (uint32_t)lane >> 5, rlane = (uint32_t)lane & 31u;
+    const float qi = qinv[0];
+    const uint32_t k = a.topk;
+    WaveTopKN<4> best;
+    constexpr int TW = 2;
+    for (uint64_t t0 = t_first + (uint64_t)gw * TW; t0 < t_end; t0 += (uint64_t)gwaves * TW) {
+        float acc[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[t] = 0.0f;
+        for (uint32_t c0 = 0; c0 < ksteps; c0 += G) {
+            f4 x[TW][G];
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                const uint64_t tile = min(t0 + t, t_end - 1);
+                const f4* p = reinterpret_cast<const f4*>(base + tile * tile_bytes + (uint64_t)c0 * 1024) + lane;
+#pragma unroll
+                for (int s = 0; s < G; ++s) x[t][s] = __builtin_nontemporal_load(p + s * 64);
+            }
+            const char* ql = lds + (size_t)(c0 * 2 + half) * 16;
+#pragma unroll
+            for (int s = 0; s < G; ++s) {
+                const h8 qv = *reinterpret_cast<const h8*>(ql + (size_t)s * 2 * 16);
+#pragma unroll
+                for (int t = 0; t < TW; ++t) {
+                    const h8 av = as_h8(x[t][s]);
+                    float c = acc[t];
+                    c = __builtin_amdgcn_fdot2(h2{av[0], av[1]}, h2{qv[0], qv[1]}, c, false);
+                    c = __builtin_amdgcn_fdot2(h2{av[2], av[3]}, h2{qv[2], qv[3]}, c, false);
+                    c = __builtin_amdgcn_fdot2(h2{av[4], av[5]}, h2{qv[4], qv[5]}, c, false);
+                    c = __builtin_amdgcn_fdot2(h2{av[6], av[7]}, h2{qv[6], qv[7]}, c, false);
+                    acc[t] = c;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            const uint64_t tile = t0 + t;
+            const float dot = acc[t] + __shfl_xor(acc[t], 32, 64);
+            const uint64_t row = tile * 32 + rlane;
+            bool live = tile < t_end && half == 0 && row < a.row_end;
+            if (live && a.dead) live = !((a.dead[tile] >> rlane) & 1u);
+            float dist = 0.0f;
+            if (live) {
+                const float inv = a.inv_norm[row];
+                dist = l2 ? (qi + inv) - 2.0f * dot : 1.0f - dot * (inv * qi);
+                live = dist == dist;
+            }
+            // smaller distance wins, then the lower row: key = ~ordered(d) << 32 | ~row (as K1's fused mode)
+            const unsigned long long key =
+                ((unsigned long long)(~f32_to_ordered(dist)) << 32) | (unsigned long long)(uint32_t)(~(uint32_t)row);
+            unsigned long long pending = __ballot(live && (best.count < k || key > best.thr));
+            while (pending) {
+                const int l = __ffsll((long long)pending) - 1;
+                pending &= pending - 1;
+                const unsigned long long kk = __shfl(key, l, 64);
+                bool ok = best.count < k || kk > best.thr;  // the threshold may have risen since the ballot
+                if (ok && a.allow) {  // the filter lookup only for rows that would enter the list
+                    const uint64_t rr = (uint64_t)(uint32_t)(~(uint32_t)kk);
+                    const uint64_t doc = a.row_doc[rr];
+                    ok = doc < a.allow_bits && ((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
+                }
+                if (ok) best.insert(kk, k, lane);
+            }
+        }
+    }
+    unsigned long long* out = a.wave_lists + (uint64_t)gw * kF16WaveListKeys;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[lane + 64 * j] = best.s[j];
+}
+
 // ---------------------------------------------------------------- store / norms / gather
 __global__ __launch_bounds__(256) void f16_store_rows_kernel(char* __restrict__ tiled,
                                                              const float* __restrict__ src, uint64_t first,
@@ -624,10 +729,30 @@ int launch_f16_gather_rows(const void* tiled, const uint64_t* d_row_idx, uint64_
     return ORAMA_OK;
 }
 
+uint32_t vec_scan_f16_fused_waves(orama_ctx* ctx, const F16ScanArgs& a) {
+    const uint32_t ksteps = f16_kpad(a.dim) / 16;
+    if (a.q != 1 || a.topk < 1 || a.topk > kF16WaveListKeys || ksteps % 12 != 0 || !a.tiled || !a.inv_norm || !a.queries) return 0;
+    const uint64_t tiles = ((a.row_end + 31) >> 5) - (a.row_begin >> 5);
+    if (tiles == 0) return 4;
+    return blocks_for((tiles + 1) / 2, 4, (uint32_t)ctx->compute_units * 2u) * 4u;
+}
+
 int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream) {
     ORAMA_REQUIRE(a.tiled && a.inv_norm && a.queries, "vec_scan_f16: bad arguments");
     ORAMA_REQUIRE(a.q >= 1 && a.q <= kF16MaxQ, "vec_scan_f16: q=%u outside [1, %u]", a.q, kF16MaxQ);
     ORAMA_REQUIRE((a.row_begin & 31) == 0 && a.row_begin <= a.row_end, "vec_scan_f16: bad row range");
+    if (a.wave_lists) {
+        const uint32_t waves = vec_scan_f16_fused_waves(ctx, a);
+        ORAMA_REQUIRE(waves > 0, "vec_scan_f16: the fused mode does not apply to these arguments");
+        if (a.row_begin == a.row_end) return ORAMA_OK;
+        ProfScope prof(&ctx->prof, "vec_scan_f16", stream);
+        const uint32_t ksteps = f16_kpad(a.dim) / 16;
+        const size_t lds_bytes = (size_t)ksteps * 2 * 16 + 16 * sizeof(float);
+        hipLaunchKernelGGL((vec_scan_f16_solo_fused_kernel<12>), dim3(waves / 4), dim3(256), lds_bytes, stream, a, ksteps,
+                           f16_tile_bytes(a.dim));
+        ORAMA_HIP_TRY(hipGetLastError());
+        return ORAMA_OK;
+    }
     ORAMA_REQUIRE(a.out_dense || (a.tau && a.cand_dist && a.cand_row && a.cand_count),
                   "vec_scan_f16: no output mode");
     ORAMA_REQUIRE(!a.allow || a.row_doc, "vec_scan_f16: filter needs row_doc");

@@ -59,9 +59,18 @@ struct F16ScanArgs {
     // the caller promises no bit-identity with batched answers (the shadow scan of the two-stage plan): <= 4 queries take
     // K1h, the dot-product kernel without MFMA
     bool solo = false;
+    // K1h fused mode (one query): every wave keeps its best `topk` <= 256 rows as keys ~ordered(distance) << 32 | ~row and
+    // writes 256 of them (0 = empty) to wave_lists[wave * 256 ...]; no dense output, no candidate lists
+    unsigned long long* wave_lists = nullptr;
+    uint32_t topk = 0;
 };
 // K2. Algorithmic HBM traffic: (row_end - row_begin) * kpad * 2 bytes per launch (serves all q queries).
 int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream);
+
+// Waves launch_vec_scan_f16 uses in the fused mode for `a` (= number of 256-key lists written); 0 when the fused mode
+// does not apply to these arguments.
+constexpr uint32_t kF16WaveListKeys = 256;
+uint32_t vec_scan_f16_fused_waves(orama_ctx* ctx, const F16ScanArgs& a);
 
 // K2c (vec_f16_wide.hip): the same scan for 65..256 queries per corpus pass — a register-blocked GEMM (block tile
 // 256 rows x 256 queries, corpus and query fragments staged through an LDS double buffer).  `d_query_frags`

@@ -503,6 +503,35 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
                        uint32_t* d_out_n, hipStream_t s, uint32_t* d_out_rows = nullptr) {
     const uint64_t n = w.n_rows;
+    if (d_out_rows && q == 1 && k <= kF16WaveListKeys && v->ctx->f16_solo == 2) {
+        // candidate stage of the two-stage plan for ONE query: K1h keeps every wave's best k rows in registers — one
+        // launch over the store + the key reduction, instead of dense head, selection, filter scan, selection
+        F16ScanArgs fa;
+        fa.tiled = w.rows;
+        fa.inv_norm = w.inv_norm;
+        fa.queries = d_queries;
+        fa.q = 1;
+        fa.dim = v->dim;
+        fa.metric = v->metric;
+        fa.n_rows = n;
+        fa.row_begin = 0;
+        fa.row_end = n;
+        fa.row_doc = w.row_doc;
+        fa.dead = w.dead;
+        fa.allow = d_allow;
+        fa.allow_bits = allow_bits;
+        fa.topk = k;
+        const uint32_t waves = vec_scan_f16_fused_waves(v->ctx, fa);
+        if (waves) {
+            const uint32_t n_keys = waves * kF16WaveListKeys;
+            ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * (size_t)n_keys));
+            ORAMA_TRY(sc->dist.reserve(keys_topk_scratch_keys(n_keys, 1, k) * 8 + 64));
+            fa.wave_lists = sc->sel_keys.as<unsigned long long>();
+            ORAMA_TRY(launch_vec_scan_f16(v->ctx, fa, s));
+            return launch_keys_topk(v->ctx, fa.wave_lists, n_keys, n_keys, 1, k, false, w.row_doc, sc->dist.as<unsigned long long>(),
+                                    d_out_rows, d_out_ids, d_out_dist, d_out_n, s);
+        }
+    }
     constexpr uint64_t kS1 = 131072;                 // dense head (rows), multiple of 32
     constexpr uint64_t kCandBudget = 6ull << 30;     // bytes of candidate lists per pass
     const uint32_t kpad_k = f16_kpad(v->dim);

@@ -1,6 +1,6 @@
 #!/bin/bash
+O=gpurun_out/r02k1hf
+mkdir -p $O
 cd $GRAFT_REPO_ROOT
-for rows in 1250000 2500000 5000000; do for f in 0 1; do
-ORAMA_FUSED_TOPK=$f timeout 200 python bench.py --rows $rows --steps 200 --warmup 10 --no-cpu-baseline --no-two-stage 2>/dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('rows $rows fused $f:', round(d['value'],1), 'QPS', round(d['ms_per_step'],4), 'ms/step | scan ms', round(d['roofline']['avg_launch_ms'],4), 'frac', round(d['roofline']['frac'],3))"
-done; done
+( time timeout 900 python -m pytest tests/test_two_stage_gpu.py tests/test_random_gpu.py tests/test_full_size_gpu.py::test_ns_full_size_two_stage_equals_the_fp32_scan tests/test_stress_gpu.py -m gpu -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; grep "passed\|failed\|rror" $O/pytest.log | head -5
+timeout 300 python scripts/two_stage_breakdown.py 2>&1 | tail -3
