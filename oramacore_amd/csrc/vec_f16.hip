@@ -487,9 +487,14 @@ __global__ __launch_bounds__(256) void vec_scan_f16_solo2_kernel(F16ScanArgs a, 
     }
 }
 
-// K1h fused: ONE query, the best `topk` <= 256 rows of every wave stay in registers (WaveTopKN<4>) — one launch over the
-// whole store instead of dense head + selection + filter scan + selection.
-template <int G>
+// K1h fused: ONE query, every wave keeps its best min(topk, 64) rows in registers (one key per lane) — one launch over
+// the whole store instead of dense head + selection + filter scan + selection.  A wave scans 1/2048 of the rows, so it
+// holds a fraction of a row of the global top-k on average; 64 slots (not topk = 228) cut the insertions — each one a
+// wave-wide min reduction — from ~920 to ~350 per wave (0.38 ms of a 2.6 ms scan).  Exactness does not rest on that
+// expectation: a wave that evicted anything reports the key of its worst kept row (wave_thr), and the caller treats the
+// answer as incomplete when that row ranks inside the global top-k (shadow_wave_check_kernel) — the two-stage plan then
+// answers the query by the fp32 scan, like any other candidate list it cannot prove complete.
+template <int G, int DBG>
 __global__ __launch_bounds__(256) void vec_scan_f16_solo_fused_kernel(F16ScanArgs a, uint32_t ksteps, uint64_t tile_bytes) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
@@ -524,13 +529,21 @@ __global__ __launch_bounds__(256) void vec_scan_f16_solo_fused_kernel(F16ScanArg
     const char* base = reinterpret_cast<const char*>(a.tiled);
     const uint32_t half = (uint32_t)lane >> 5, rlane = (uint32_t)lane & 31u;
     const float qi = qinv[0];
-    const uint32_t k = a.topk;
-    WaveTopKN<4> best;
+    const uint32_t k = a.topk < 64u ? a.topk : 64u;  // per-wave capacity
+    WaveTopKN<1> best;
     constexpr int TW = 2;
     for (uint64_t t0 = t_first + (uint64_t)gw * TW; t0 < t_end; t0 += (uint64_t)gwaves * TW) {
-        float acc[TW];
+        float acc[TW], inv_pre[TW];
+        uint32_t dead_pre[TW];
 #pragma unroll
-        for (int t = 0; t < TW; ++t) acc[t] = 0.0f;
+        for (int t = 0; t < TW; ++t) {
+            acc[t] = 0.0f;
+            // the row's norm and the tile's tombstone word are fetched NOW, under the tile's own loads: read in the
+            // epilogue they are a dependent miss every wave sits out (0.38 of 2.63 ms at 10 M rows)
+            const uint64_t tile = min(t0 + t, t_end - 1);
+            inv_pre[t] = a.inv_norm[tile * 32 + rlane];
+            dead_pre[t] = a.dead ? a.dead[tile] : 0u;
+        }
         for (uint32_t c0 = 0; c0 < ksteps; c0 += G) {
             f4 x[TW][G];
 #pragma unroll
@@ -543,7 +556,7 @@ __global__ __launch_bounds__(256) void vec_scan_f16_solo_fused_kernel(F16ScanArg
             const char* ql = lds + (size_t)(c0 * 2 + half) * 16;
 #pragma unroll
             for (int s = 0; s < G; ++s) {
-                const h8 qv = *reinterpret_cast<const h8*>(ql + (size_t)s * 2 * 16);
+                const h8 qv = (DBG & 1) ? h8{1, 1, 1, 1, 1, 1, 1, 1} : *reinterpret_cast<const h8*>(ql + (size_t)s * 2 * 16);
 #pragma unroll
                 for (int t = 0; t < TW; ++t) {
                     const h8 av = as_h8(x[t][s]);
@@ -562,10 +575,11 @@ __global__ __launch_bounds__(256) void vec_scan_f16_solo_fused_kernel(F16ScanArg
             const float dot = acc[t] + __shfl_xor(acc[t], 32, 64);
             const uint64_t row = tile * 32 + rlane;
             bool live = tile < t_end && half == 0 && row < a.row_end;
-            if (live && a.dead) live = !((a.dead[tile] >> rlane) & 1u);
+            if (DBG & 2) live = live && dot == 12345.678f;  // ablation: no epilogue work
+            if (live) live = !((dead_pre[t] >> rlane) & 1u);
             float dist = 0.0f;
             if (live) {
-                const float inv = a.inv_norm[row];
+                const float inv = inv_pre[t];
                 dist = l2 ? (qi + inv) - 2.0f * dot : 1.0f - dot * (inv * qi);
                 live = dist == dist;
             }
@@ -588,8 +602,28 @@ __global__ __launch_bounds__(256) void vec_scan_f16_solo_fused_kernel(F16ScanArg
         }
     }
     unsigned long long* out = a.wave_lists + (uint64_t)gw * kF16WaveListKeys;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[lane + 64 * j] = best.s[j];
+    out[lane] = best.s[0];
+    // full list = something may have been evicted: everything evicted ranks below thr
+    if (lane == 0 && a.wave_thr) a.wave_thr[gw] = (best.count >= k && k < a.topk) ? best.thr : 0ull;
+}
+
+// flag[0] |= 1 when a wave's worst kept row is at least as good as the k-th best of the merged result: rows it evicted
+// could belong to the top-k.  (Compared on the distance half of the keys: ties count as "could".)
+__global__ void shadow_wave_check_kernel(const unsigned long long* __restrict__ wave_thr, uint32_t waves,
+                                         const float* __restrict__ out_dist, const uint32_t* __restrict__ out_n, uint32_t k,
+                                         uint32_t* __restrict__ flag) {
+    __shared__ uint32_t bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    const uint32_t n = out_n[0];
+    // key of the k-th best distance (larger key = smaller distance); fewer than k results: every evicted row matters
+    const uint32_t kth_hi = n >= k ? ~f32_to_ordered(out_dist[k - 1]) : 0u;
+    for (uint32_t w = threadIdx.x; w < waves; w += blockDim.x) {
+        const unsigned long long t = wave_thr[w];
+        if (t != 0ull && (uint32_t)(t >> 32) >= kth_hi) bad = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) flag[0] = bad;
 }
 
 // ---------------------------------------------------------------- store / norms / gather
@@ -731,10 +765,17 @@ int launch_f16_gather_rows(const void* tiled, const uint64_t* d_row_idx, uint64_
 
 uint32_t vec_scan_f16_fused_waves(orama_ctx* ctx, const F16ScanArgs& a) {
     const uint32_t ksteps = f16_kpad(a.dim) / 16;
-    if (a.q != 1 || a.topk < 1 || a.topk > kF16WaveListKeys || ksteps % 12 != 0 || !a.tiled || !a.inv_norm || !a.queries) return 0;
+    if (a.q != 1 || a.topk < 1 || a.topk > kSelectMaxKeysFused || ksteps % 12 != 0 || !a.tiled || !a.inv_norm || !a.queries) return 0;
     const uint64_t tiles = ((a.row_end + 31) >> 5) - (a.row_begin >> 5);
     if (tiles == 0) return 4;
     return blocks_for((tiles + 1) / 2, 4, (uint32_t)ctx->compute_units * 2u) * 4u;
+}
+
+int launch_shadow_wave_check(const unsigned long long* d_wave_thr, uint32_t waves, const float* d_out_dist, const uint32_t* d_out_n,
+                             uint32_t k, uint32_t* d_flag, hipStream_t stream) {
+    hipLaunchKernelGGL(shadow_wave_check_kernel, dim3(1), dim3(256), 0, stream, d_wave_thr, waves, d_out_dist, d_out_n, k, d_flag);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
 }
 
 int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream) {
@@ -748,7 +789,11 @@ int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream
         ProfScope prof(&ctx->prof, "vec_scan_f16", stream);
         const uint32_t ksteps = f16_kpad(a.dim) / 16;
         const size_t lds_bytes = (size_t)ksteps * 2 * 16 + 16 * sizeof(float);
-        hipLaunchKernelGGL((vec_scan_f16_solo_fused_kernel<12>), dim3(waves / 4), dim3(256), lds_bytes, stream, a, ksteps,
+        static const int dbg = [] { const char* e = std::getenv("ORAMA_K1H_DBG"); return e ? std::atoi(e) : 0; }();
+        if (dbg == 1) hipLaunchKernelGGL((vec_scan_f16_solo_fused_kernel<12, 1>), dim3(waves / 4), dim3(256), lds_bytes, stream, a, ksteps, f16_tile_bytes(a.dim));
+        else if (dbg == 2) hipLaunchKernelGGL((vec_scan_f16_solo_fused_kernel<12, 2>), dim3(waves / 4), dim3(256), lds_bytes, stream, a, ksteps, f16_tile_bytes(a.dim));
+        else if (dbg == 3) hipLaunchKernelGGL((vec_scan_f16_solo_fused_kernel<12, 3>), dim3(waves / 4), dim3(256), lds_bytes, stream, a, ksteps, f16_tile_bytes(a.dim));
+        else hipLaunchKernelGGL((vec_scan_f16_solo_fused_kernel<12, 0>), dim3(waves / 4), dim3(256), lds_bytes, stream, a, ksteps,
                            f16_tile_bytes(a.dim));
         ORAMA_HIP_TRY(hipGetLastError());
         return ORAMA_OK;

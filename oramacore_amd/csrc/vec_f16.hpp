@@ -59,9 +59,11 @@ struct F16ScanArgs {
     // the caller promises no bit-identity with batched answers (the shadow scan of the two-stage plan): <= 4 queries take
     // K1h, the dot-product kernel without MFMA
     bool solo = false;
-    // K1h fused mode (one query): every wave keeps its best `topk` <= 256 rows as keys ~ordered(distance) << 32 | ~row and
-    // writes 256 of them (0 = empty) to wave_lists[wave * 256 ...]; no dense output, no candidate lists
+    // K1h fused mode (one query): every wave keeps its best min(topk, 64) rows as keys ~ordered(distance) << 32 | ~row and
+    // writes them (0 = empty) to wave_lists[wave * 64 ...]; a wave that evicted a row writes the key of its worst kept
+    // row to wave_thr[wave] (0 otherwise) — see launch_shadow_wave_check.  No dense output, no candidate lists.
     unsigned long long* wave_lists = nullptr;
+    unsigned long long* wave_thr = nullptr;
     uint32_t topk = 0;
 };
 // K2. Algorithmic HBM traffic: (row_end - row_begin) * kpad * 2 bytes per launch (serves all q queries).
@@ -69,8 +71,12 @@ int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream
 
 // Waves launch_vec_scan_f16 uses in the fused mode for `a` (= number of 256-key lists written); 0 when the fused mode
 // does not apply to these arguments.
-constexpr uint32_t kF16WaveListKeys = 256;
+constexpr uint32_t kF16WaveListKeys = 64;
+constexpr uint32_t kSelectMaxKeysFused = 4096;  // topk the fused mode accepts (the merged result is cut there)
 uint32_t vec_scan_f16_fused_waves(orama_ctx* ctx, const F16ScanArgs& a);
+// flag[0] = 1 when rows evicted by a wave could belong to the k best of the merged result (d_out_dist ascending, d_out_n[0])
+int launch_shadow_wave_check(const unsigned long long* d_wave_thr, uint32_t waves, const float* d_out_dist, const uint32_t* d_out_n,
+                             uint32_t k, uint32_t* d_flag, hipStream_t stream);
 
 // K2c (vec_f16_wide.hip): the same scan for 65..256 queries per corpus pass — a register-blocked GEMM (block tile
 // 256 rows x 256 queries, corpus and query fragments staged through an LDS double buffer).  `d_query_frags`

@@ -430,7 +430,8 @@ __global__ __launch_bounds__(kScanThreads) void rerank_f32_kernel(const float* _
 // flag[j] = 1 when the candidate list of query j may miss a row of the exact top-k: the list is full (n == k1) and its
 // last shadow distance lies within `band` of the k-th one.  shadow_dist: ascending per query.
 __global__ void shadow_band_kernel(const float* __restrict__ shadow_dist, const uint32_t* __restrict__ n, uint32_t q,
-                                   uint32_t k, uint32_t k1, float band, uint32_t* __restrict__ flag) {
+                                   uint32_t k, uint32_t k1, float band, uint32_t* __restrict__ flag,
+                                   const uint32_t* __restrict__ also) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= q) return;
     uint32_t f = 0;
@@ -439,6 +440,7 @@ __global__ void shadow_band_kernel(const float* __restrict__ shadow_dist, const 
         const float last = shadow_dist[(uint64_t)j * k1 + (k1 - 1)];
         f = !(last > tau + band);  // also when either is NaN
     }
+    if (also && also[j]) f = 1;  // the candidate stage flagged its own list
     flag[j] = f;
 }
 }  // namespace
@@ -459,8 +461,9 @@ int launch_rerank_f32(const float* corpus, const float* inv_norm, uint32_t dim, 
 }
 
 int launch_shadow_band(const float* d_shadow_dist, const uint32_t* d_n, uint32_t q, uint32_t k, uint32_t k1, float band,
-                       uint32_t* d_flag, hipStream_t stream) {
-    hipLaunchKernelGGL(shadow_band_kernel, dim3((q + 63) / 64), dim3(64), 0, stream, d_shadow_dist, d_n, q, k, k1, band, d_flag);
+                       uint32_t* d_flag, hipStream_t stream, const uint32_t* d_also) {
+    hipLaunchKernelGGL(shadow_band_kernel, dim3((q + 63) / 64), dim3(64), 0, stream, d_shadow_dist, d_n, q, k, k1, band, d_flag,
+                       d_also);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -62,7 +62,7 @@ int launch_rerank_f32(const float* corpus, const float* inv_norm, uint32_t dim, 
                       const uint32_t* d_cand_rows, const uint32_t* d_cand_n, uint32_t stride, float* d_out_dist,
                       hipStream_t stream);
 int launch_shadow_band(const float* d_shadow_dist, const uint32_t* d_n, uint32_t q, uint32_t k, uint32_t k1, float band,
-                       uint32_t* d_flag, hipStream_t stream);
+                       uint32_t* d_flag, hipStream_t stream, const uint32_t* d_also = nullptr);
 
 // ids[i] = first + i
 int launch_iota_u64(uint64_t* d_ids, uint64_t n, uint64_t first, hipStream_t stream);

@@ -501,9 +501,10 @@ int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_
 // candidate appends (expected k·ln(N/S1) per query on unordered data).
 int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
-                       uint32_t* d_out_n, hipStream_t s, uint32_t* d_out_rows = nullptr) {
+                       uint32_t* d_out_n, hipStream_t s, uint32_t* d_out_rows = nullptr, uint32_t* d_inexact = nullptr) {
     const uint64_t n = w.n_rows;
-    if (d_out_rows && q == 1 && k <= kF16WaveListKeys && v->ctx->f16_solo == 2) {
+    if (d_inexact) ORAMA_HIP_TRY(hipMemsetAsync(d_inexact, 0, (size_t)q * 4, s));
+    if (d_out_rows && q == 1 && v->ctx->f16_solo == 2 && (d_inexact || k <= kF16WaveListKeys)) {
         // candidate stage of the two-stage plan for ONE query: K1h keeps every wave's best k rows in registers — one
         // launch over the store + the key reduction, instead of dense head, selection, filter scan, selection
         F16ScanArgs fa;
@@ -526,10 +527,15 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
             const uint32_t n_keys = waves * kF16WaveListKeys;
             ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * (size_t)n_keys));
             ORAMA_TRY(sc->dist.reserve(keys_topk_scratch_keys(n_keys, 1, k) * 8 + 64));
+            ORAMA_TRY(sc->misc0.reserve((size_t)waves * 8));
             fa.wave_lists = sc->sel_keys.as<unsigned long long>();
+            fa.wave_thr = sc->misc0.as<unsigned long long>();
             ORAMA_TRY(launch_vec_scan_f16(v->ctx, fa, s));
-            return launch_keys_topk(v->ctx, fa.wave_lists, n_keys, n_keys, 1, k, false, w.row_doc, sc->dist.as<unsigned long long>(),
-                                    d_out_rows, d_out_ids, d_out_dist, d_out_n, s);
+            ORAMA_TRY(launch_keys_topk(v->ctx, fa.wave_lists, n_keys, n_keys, 1, k, false, w.row_doc, sc->dist.as<unsigned long long>(),
+                                       d_out_rows, d_out_ids, d_out_dist, d_out_n, s));
+            // a wave keeps 64 rows: did one of them evict a row that belongs to the k best?  (never with k <= 64)
+            if (k > kF16WaveListKeys) ORAMA_TRY(launch_shadow_wave_check(fa.wave_thr, waves, d_out_dist, d_out_n, k, d_inexact, s));
+            return ORAMA_OK;
         }
     }
     constexpr uint64_t kS1 = 131072;                 // dense head (rows), multiple of 32
@@ -726,12 +732,13 @@ int two_stage_search(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const fl
     ORAMA_TRY(sc2->out_ids.reserve(n1 * 8));
     ORAMA_TRY(sc2->out_val.reserve(n1 * 4));
     ORAMA_TRY(sc2->out_idx.reserve(n1 * 4));
-    ORAMA_TRY(sc2->out_n.reserve((size_t)q * 4 * 2));
+    ORAMA_TRY(sc2->out_n.reserve((size_t)q * 4 * 3));
     uint32_t* d_n1 = sc2->out_n.as<uint32_t>();
     uint32_t* d_flag = d_n1 + q;
+    uint32_t* d_inexact = d_n1 + 2 * (size_t)q;  // stage 1 itself could not prove its list (K1h's 64 rows per wave)
     ORAMA_TRY(search_enqueue_f16(sh, ws, sc2.s.get(), d_queries, q, k1, d_allow, allow_bits, sc2->out_ids.as<uint64_t>(),
-                                 sc2->out_val.as<float>(), d_n1, s, sc2->out_idx.as<uint32_t>()));
-    ORAMA_TRY(launch_shadow_band(sc2->out_val.as<float>(), d_n1, q, k, k1, 2.0f * kShadowEps, d_flag, s));
+                                 sc2->out_val.as<float>(), d_n1, s, sc2->out_idx.as<uint32_t>(), d_inexact));
+    ORAMA_TRY(launch_shadow_band(sc2->out_val.as<float>(), d_n1, q, k, k1, 2.0f * kShadowEps, d_flag, s, d_inexact));
     // stage 2: exact distances of the candidates, then the final order
     ORAMA_TRY(sc->dist.reserve(n1 * 4));
     ORAMA_TRY(launch_rerank_f32(static_cast<const float*>(w.rows), w.inv_norm, v->dim, d_queries, q, sc2->out_idx.as<uint32_t>(),

@@ -263,3 +263,37 @@ def test_c4_full_size_hybrid_bit_exact(ctx):
         assert np.array_equal(h_sc.view(np.uint32), ts.view(np.uint32)), trial
     post.close()
     vec.close()
+
+
+def test_two_stage_candidates_crowded_into_one_wave(ctx):
+    """The one-query candidate stage keeps 64 rows per wave.  70 near-copies of the query are planted 131 072 rows apart —
+    the stride at which the same wave of the 2 048-wave grid comes round again — so one wave must evict rows that
+    belong to the answer: the stage has to notice (wave_thr check) and the plan has to fall back to the fp32 scan."""
+    d, k, stride, n_plant = 384, 10, 131072, 70
+    rng = np.random.default_rng(41)
+    q = rng.standard_normal(d).astype(np.float32)
+    plant = (q[None, :] + rng.standard_normal((n_plant, d)).astype(np.float32) * np.float32(0.02)).astype(np.float32)
+    stores = []
+    for dt in (oa.DTYPE_F32, oa.DTYPE_F32_SHADOW16):
+        st = oa.EmbeddingFieldStorage(ctx, dimensions=d, reserve_rows=n_plant * stride + 16, dtype=dt)
+        for i in range(n_plant):
+            st.fill_synthetic(stride - 1, seed=1000 + i, first_doc_id=i * stride)
+            st.insert_rows(np.array([i * stride + stride - 1], dtype=np.uint64), plant[i:i + 1])
+        assert st.info()["num_rows"] == n_plant * stride
+        stores.append(st)
+    plain, shadow = stores
+    for kk in (k, 64):
+        a = plain.storage_search(q, kk)
+        b = shadow.storage_search(q, kk)
+        assert a[2].tolist() == b[2].tolist() and a[0].tolist() == b[0].tolist()
+        assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        assert set((a[0][0] % stride).tolist()) == {stride - 1}  # the planted rows are the answer
+    info = shadow.info()
+    assert info["two_stage_queries"] == 2 and info["two_stage_fallbacks"] == 2
+    # a query that is not crowded takes no fallback
+    other = rng.standard_normal(d).astype(np.float32)
+    a, b = plain.storage_search(other, 100), shadow.storage_search(other, 100)
+    assert a[0].tolist() == b[0].tolist() and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    assert shadow.info()["two_stage_fallbacks"] == 2
+    plain.close()
+    shadow.close()
