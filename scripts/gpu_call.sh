@@ -1,6 +1,10 @@
 #!/bin/bash
-O=gpurun_out/r02k1hf
+O=gpurun_out/r02fin3
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-( time timeout 900 python -m pytest tests/test_two_stage_gpu.py tests/test_random_gpu.py tests/test_full_size_gpu.py::test_ns_full_size_two_stage_equals_the_fp32_scan tests/test_full_size_gpu.py::test_two_stage_candidates_crowded_into_one_wave tests/test_stress_gpu.py -m gpu -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; grep "passed\|failed\|rror" $O/pytest.log | head -5; grep -B5 "^E " $O/pytest.log | head -30
-for d in 0 2; do ORAMA_K1H_DBG=$d timeout 300 python scripts/two_stage_breakdown.py 2>&1 | tail -3 | head -1; done
+timeout 600 python scripts/bench_two_stage.py > $O/bench_two_stage.log 2>&1; grep -v "^{" $O/bench_two_stage.log | tail -5
+timeout 400 python bench.py --steps 50 --warmup 5 > $O/bench_ns.json 2> $O/bench_ns.err; python -c "
+import json; d=json.loads(open('$O/bench_ns.json').read().strip().splitlines()[-1]); print('ns', round(d['value'],1), 'frac', round(d['roofline']['frac'],3), 'two_stage', round(d['two_stage_exact']['value'],1), 'b64', round(d['two_stage_exact']['batch64_queries_per_s']), 'fallbacks', d['two_stage_exact']['fallbacks'])"
+timeout 400 python scripts/bench_hybrid.py --steps 100 --warmup 5 > $O/bench_c4.json 2>$O/bench_c4.err; python -c "
+import json; d=json.load(open('$O/bench_c4.json')); print('c4 hybrid', round(d['value'],1), 'two-stage', round(d['hybrid_two_stage_exact']['value'],1), 'bm25 batch', round(d['bm25_only']['value']))"
+timeout 300 scripts/native/bench_serving vec 10000000 100 1,64,512 shadow > $O/serving_shadow.log 2>&1; tail -7 $O/serving_shadow.log
