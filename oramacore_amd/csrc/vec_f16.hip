@@ -37,7 +37,8 @@ constexpr int kWavesPerBlock = kBlock / 64;
 
 __device__ __forceinline__ h8 as_h8(f4 v) { return __builtin_bit_cast(h8, v); }
 
-template <int NQT, int KC, int NBUF>
+// DENSE: the launch writes every distance (the head of the store) instead of appending the rows under the thresholds.
+template <int NQT, int KC, int NBUF, bool DENSE>
 __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uint32_t ksteps, uint64_t tile_bytes) {
     constexpr int kChunk = KC;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -102,6 +103,34 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
     // it): with a fixed number of loads between a chunk's issue and its use, the compiler's s_waitcnt pass
     // emits counted vmcnt(N) waits that leave the NBUF-1 prefetched chunks in flight.  (Conditional loads made
     // it fall back to vmcnt(<KC), which drained the ring before every chunk: 5.4 → see profiles/.)
+    // Tile metadata (1/|x| or |x|^2 of the 32 rows + the tombstone word) travels with the corpus stream: every load
+    // group also moves the 256-byte metadata record of the tile of the NEXT chunk straight into LDS
+    // (global_load_lds_dword: no destination registers, counted by vmcnt like the chunk loads, in order).  When the
+    // compiler's counted wait for the last register of chunk g has passed, everything issued in group g-1 has landed,
+    // so the epilogue of chunk g reads the record group g-1 wrote.  NBUF + 1 slots: group g + NBUF - 1 is issued just
+    // before chunk g is multiplied and must not overwrite the record that chunk's epilogue is about to read.
+    // (Scalar loads issued at epilogue time stalled the wave for a full memory latency per tile: 0.58 of 3.0 ms at
+    // 10 M x 768, 64 queries — profiles/r02_k2_epilogue.log.)
+    constexpr int kMetaSlots = NBUF + 1;
+    char* meta = lds + (size_t)frag_total * 16 + 64 * sizeof(float) + (size_t)(tid >> 6) * kMetaSlots * kF16MetaBytes;
+    const uint32_t meta_addr = uniform_u32((uint32_t)(size_t)(__attribute__((address_space(3))) char*)meta);
+    uint32_t m_w = 0, m_r = 0;  // next slot to write / to read (wave-uniform)
+    const uint32_t* meta_norm = reinterpret_cast<const uint32_t*>(a.inv_norm) + (lane & 31);
+    const bool meta_dead_lane = lane == 32 && a.dead != nullptr;
+    auto load_meta = [&]() {
+        const uint32_t* src = meta_dead_lane ? a.dead + ld_tile : meta_norm + ld_tile * 32;
+        // An asm statement, not __builtin_amdgcn_global_load_lds: the compiler's wait-count pass makes every later
+        // LDS read that may alias an LDS-DMA destination (here: the fragment reads of the MFMA loop) wait for the DMA,
+        // which turned the counted waits of the ring into one vmcnt(0) drain per cycle.  Unseen by that pass, the DMA
+        // only makes its counted waits stricter by the <= NBUF records in flight (completion is in order).
+        // m0 is an input operand ("{m0}"): the compiler materialises it and knows it is live; the s_nop is the wait
+        // state gfx9 wants between a write of m0 and an LDS-DMA instruction reading it.
+        asm volatile("s_nop 0\n\tglobal_load_lds_dword %0, off"
+                     :
+                     : "v"(src), "{m0}"(meta_addr + m_w * kF16MetaBytes)
+                     : "memory");
+        m_w = m_w + 1 == kMetaSlots ? 0 : m_w + 1;
+    };
     auto load_chunk = [&](f4* b) {
         const f4* p = reinterpret_cast<const f4*>(base + ld_tile * tile_bytes + (uint64_t)ld_c * kChunk * 1024) + lane;
 #pragma unroll
@@ -113,6 +142,7 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
                 ld_tile += tile_step;
             }
         }
+        load_meta();
     };
 
     // per-lane constants of the epilogue: this lane's query column per tile, its 1/|q| and threshold
@@ -123,54 +153,172 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
         qi_reg[qt] = qinv[j];
         tau_reg[qt] = (a.tau && j < a.q) ? a.tau[j] : 0.0f;
     }
-    // Tile metadata (1/|x| of the 32 rows, tombstone word) comes through SCALAR loads (constant address space,
-    // wave-uniform address → s_load, counted by lgkmcnt): a vector load here would sit in the in-order vmcnt
-    // queue behind the prefetched corpus chunks and force them to drain at every tile.
-    typedef const float __attribute__((address_space(4))) cfloat;
-    typedef const uint32_t __attribute__((address_space(4))) cu32;
+    // Rows that pass the threshold are STAGED per wave in LDS (distance, row, query) and appended to the per-query
+    // candidate lists when the staging area is full — with ONE global atomic instruction per flush, however many rows
+    // it holds.  The append needs the value a global atomic returns, and on this ISA that wait (vmcnt, in order) is
+    // also a wait for every corpus load the wave has in flight, behind a memory system the scan keeps saturated:
+    // appended from the epilogue directly, ~1.5 passing rows per tile drained the prefetch ring at nearly every tile
+    // (0.45 of 3.0 ms at 10 M x 768, 64 queries, k = 100), and flushing 64 rows per atomic instruction still cost 0.36
+    // (profiles/r02_k2_epilogue.log).  A flush ranks the staged rows within their query through an LDS histogram
+    // (ds_add_rtn: lgkmcnt, not vmcnt), lane j reserves the hist[j] slots of query j's list with one atomic, and the
+    // rows go to base[j] + rank.  The staging area takes what LDS is left (a.stage_cap entries of 12 bytes, >= 128):
+    // at 768 dimensions a wave stages 512 rows and most waves flush once, when their tiles are done.  With a filter,
+    // the lookup (row -> DocumentId -> bitmap word: two dependent loads with the same problem) happens here as well.
+    const uint32_t cap = a.stage_cap;
+    // (wave-uniform offsets, made so explicitly: as per-lane values the three base addresses were spilled to scratch
+    // memory and every staged row waited for their reloads)
+    const uint32_t wave_in_block = uniform_u32((uint32_t)tid >> 6);
+    const uint32_t side_off = uniform_u32(frag_total * 16 + 64 * (uint32_t)sizeof(float) +
+                                          (uint32_t)kWavesPerBlock * kMetaSlots * kF16MetaBytes);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(lds + side_off + wave_in_block * 256u);
+    uint32_t* stage = reinterpret_cast<uint32_t*>(lds + side_off + (uint32_t)kWavesPerBlock * 256u + wave_in_block * 12u * cap);
+    uint32_t staged = 0;  // wave-uniform
+    // The lanes of the wave exchange data through LDS here (rows staged by one lane are appended by another, bins
+    // counted by many lanes are read by one): wavefront-scope atomics and fences keep the compiler from treating the
+    // wave's LDS as one thread's private memory (it had forwarded this lane's `hist[lane] = 0` to its own read of the
+    // bin for lanes without a staged row).  They cost nothing: one wave's LDS operations execute in order.
+    auto wave_fence = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); };
+    auto bin_load = [](const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
+    auto bin_store = [](uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
+    auto flush = [&]() {
+        bin_store(&hist[lane], 0u);
+        wave_fence();
+        for (uint32_t i = lane; i < staged; i += 64) {
+            const uint32_t j = stage[2 * cap + i];
+            bool keep = !(a.dbg & 2u);
+            if (a.allow) {
+                const uint64_t doc = a.row_doc[stage[cap + i]];
+                keep = keep && doc < a.allow_bits && ((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
+            }
+            // query | rank within the query
+            stage[2 * cap + i] =
+                keep ? (j | (__hip_atomic_fetch_add(&hist[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) << 6)) : ~0u;
+        }
+        wave_fence();
+        const uint32_t mine = bin_load(&hist[lane]);
+        bin_store(&hist[lane], mine ? atomicAdd(&a.cand_count[lane], mine) : 0u);  // lane = query: first slot of its rows
+        wave_fence();
+        for (uint32_t i = lane; i < staged; i += 64) {
+            const uint32_t jr = stage[2 * cap + i];
+            if (jr == ~0u) continue;
+            const uint32_t j = jr & 63u;
+            const uint64_t pos = (uint64_t)j * a.cand_stride + bin_load(&hist[j]) + (jr >> 6);
+            a.cand_dist[pos] = __uint_as_float(stage[i]);
+            a.cand_row[pos] = stage[cap + i];
+        }
+        wave_fence();
+        staged = 0;
+    };
 
     auto epilogue = [&](uint64_t tile) {
-        cfloat* cn = (cfloat*)(uintptr_t)(a.inv_norm + tile * 32);
-        float nrm_s[32];
+        // this lane's 16 accumulator rows are (r & 3) + 8 (r >> 2) + 4 hi_half: four 16-byte LDS reads of the record.
+        // The statement takes an accumulator as a (never used) operand so that it stays behind the tile's last MFMA
+        // and with it behind the counted wait described above.
+        f4 n4[4];
+        uint32_t dead_word;
+        {
+            const uint32_t rec = meta_addr + m_r * kF16MetaBytes;
+            const uint32_t mine = rec + ((lane >> 5) ? 16u : 0u);
+            asm volatile(
+                "ds_read_b128 %0, %5\n\t"
+                "ds_read_b128 %1, %5 offset:32\n\t"
+                "ds_read_b128 %2, %5 offset:64\n\t"
+                "ds_read_b128 %3, %5 offset:96\n\t"
+                "ds_read_b32 %4, %6 offset:128\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(n4[0]), "=&v"(n4[1]), "=&v"(n4[2]), "=&v"(n4[3]), "=&v"(dead_word)
+                : "v"(mine), "v"(rec), "v"(acc[NQT - 1][15]));
+            if (!a.dead) dead_word = 0u;
+        }
+        const uint32_t hi4 = (lane >> 5) ? 4u : 0u;
+        const bool full = tile * 32 + 32 <= a.row_end;  // wave-uniform: only the last tile of the store is partial
+        f16v nrmv;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) nrm_s[i] = cn[i];
-        const uint32_t dead_word = a.dead ? ((cu32*)(uintptr_t)a.dead)[tile] : 0u;
-        const bool hi_half = (lane >> 5) != 0;
+        for (int r = 0; r < 16; ++r) nrmv[r] = n4[r >> 2][r & 3];
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) {
             const uint32_t j = qt * 32 + (lane & 31);
-            const bool jok = j < a.q;
+            const bool live = j < a.q;  // (a predicate, not a branch: the staging below is wave-synchronous)
+            if (DENSE && !live) continue;
             const float qi = qi_reg[qt];
             const float tau = tau_reg[qt];
+            // |q|^2 + |x|^2 - 2 q.x, or 1 - q.x / (|q||x|): written as the fused operations the compiler contracts the
+            // plain expressions to (2 q.x is exact, so the first is the same number either way) — explicit, so that the
+            // slow path below shares no sub-expression with the fast path above it (see there)
+            auto dist_of = [&](float dot, float n, float qv) -> float {
+                return l2 ? __builtin_fmaf(-2.0f, dot, qv + n) : __builtin_fmaf(-dot, n * qv, 1.0f);
+            };
+            auto distance = [&](int r) -> float { return dist_of(acc[qt][r], nrmv[r], qi); };
+            if constexpr (DENSE) {  // the head of the store: every distance is written, NaN = excluded
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i0 = (r & 3) + 8 * (r >> 2);
-                const uint32_t i = (uint32_t)i0 + (hi_half ? 4u : 0u);
-                const uint64_t row = tile * 32 + i;
-                if (row >= a.row_end || !jok) continue;
-                bool excluded = (dead_word >> i) & 1u;
-                const float inv = hi_half ? nrm_s[i0 + 4] : nrm_s[i0];
-                const float dist = l2 ? (qi + inv) - 2.0f * acc[qt][r] : 1.0f - acc[qt][r] * (inv * qi);
-                // the filter lookup (row -> DocumentId -> bitmap word: two dependent loads) is paid by every element in
-                // the dense mode, but only by the rows that pass the threshold in the filter mode (64 queries under the
-                // NOT-deleted filter: 5.0 -> 3.8 ms)
-                if (a.out_dense) {
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t i = (uint32_t)((r & 3) + 8 * (r >> 2)) + hi4;
+                    const uint64_t row = tile * 32 + i;
+                    if (!full && row >= a.row_end) continue;
+                    bool excluded = (dead_word >> i) & 1u;
                     if (!excluded && a.allow) {
                         const uint64_t doc = a.row_doc[row];
                         excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
                     }
                     a.out_dense[(uint64_t)j * a.dense_stride + (row - a.row_begin)] =
-                        excluded ? __builtin_nanf("") : dist;
-                } else if (!excluded && dist < tau) {
-                    if (a.allow) {
-                        const uint64_t doc = a.row_doc[row];
-                        excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
-                    }
-                    if (!excluded) {
-                        const uint32_t pos = atomicAdd(&a.cand_count[j], 1u);
-                        a.cand_dist[(uint64_t)j * a.cand_stride + pos] = dist;
-                        a.cand_row[(uint64_t)j * a.cand_stride + pos] = (uint32_t)row;
-                    }
+                        excluded ? __builtin_nanf("") : distance(r);
+                }
+                continue;
+            }
+            // filter mode, fast reject: almost no row beats the running k-th best distance, so take the minimum of the
+            // 16 distances first and look closer only when it passes.
+            if (a.dbg & 8u) {  // timing ablation: metadata read only
+                if (nrmv[0] + nrmv[5] + nrmv[10] + nrmv[15] == 12345.678f) a.cand_count[0] = 1;
+                continue;
+            }
+            float best = __builtin_huge_valf();
+            if (l2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) best = fminf(best, __builtin_fmaf(-2.0f, acc[qt][r], qi + nrmv[r]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) best = fminf(best, __builtin_fmaf(-acc[qt][r], nrmv[r] * qi, 1.0f));
+            }
+            if (a.dbg & 4u) {  // timing ablation: fast reject only, never the slow path
+                if (best == 12345.678f) a.cand_count[0] = 1;
+                continue;
+            }
+            // (a wave-uniform decision from here on: the staging below uses ballots)
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(live && best < tau) == 0, 1)) continue;
+            // which of this lane's 16 elements pass: threshold, tombstone, row range
+            // (the distances are computed again, from operands the compiler cannot see through: kept from the fast path
+            // above — or hoisted into it — the 16 values would live in scratch memory: stores on every tile, loads here)
+            float qi_s = qi;
+            asm volatile("" : "+v"(qi_s));
+            const uint32_t dw = dead_word >> hi4;
+            uint32_t m = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t i = (uint32_t)((r & 3) + 8 * (r >> 2));
+                const float d = dist_of(acc[qt][r], nrmv[r], qi_s);
+                const bool pass = live && d < tau && !((dw >> i) & 1u) && (full || tile * 32 + i + hi4 < a.row_end);
+                m |= (pass ? 1u : 0u) << r;
+            }
+            // element by element with a wave-uniform index (a per-lane index into the accumulators would go through
+            // scratch memory, whose loads wait on vmcnt like the appends this staging exists to avoid)
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r) {
+                const bool mine = (m >> r) & 1u;
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(mine);
+                if (!bal) continue;
+                if (mine) {
+                    const float sa = acc[qt][r], sn = nrmv[r];
+                    const float dist = dist_of(sa, sn, qi_s);
+                    const uint32_t pos =
+                        staged + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    stage[pos] = __float_as_uint(dist);
+                    stage[cap + pos] = (uint32_t)(tile * 32) + (uint32_t)((r & 3) + 8 * (r >> 2)) + hi4;
+                    stage[2 * cap + pos] = j;
+                }
+                staged = uniform_u32(staged + (uint32_t)__popcll(bal));
+                if (staged > cap - 64) {
+                    wave_fence();
+                    flush();
                 }
             }
         }
@@ -193,14 +341,26 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
                 acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[qt], 0, 0, 0);
             }
         }
-        if (++cp_c == nc) {
-            epilogue(cp_tile);
+        const bool tile_done = ++cp_c == nc;
+        if (tile_done) {
+            if (a.dbg & 1u) {  // timing ablation: no epilogue (the accumulators stay live through a never-true store)
+                float sum = 0.0f;
+#pragma unroll
+                for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum += acc[qt][r];
+                if (sum == 12345.678f) a.cand_count[0] = 1;
+            } else {
+                epilogue(cp_tile);
+            }
             cp_c = 0;
             cp_tile += tile_step;
         }
+        m_r = m_r + 1 == kMetaSlots ? 0 : m_r + 1;
     };
 
     const uint64_t total = my_tiles * nc;
+    load_meta();  // the record of the first tile (the one "group -1" would have brought)
 #pragma unroll
     for (int b = 0; b < NBUF - 1; ++b) load_chunk(buf[b]);
     uint64_t g = 0;
@@ -217,6 +377,10 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
             load_chunk(buf[(b + NBUF - 1) % NBUF]);
             compute_chunk(buf[b]);
         }
+    }
+    if (!DENSE && staged) {
+        wave_fence();
+        flush();
     }
 }
 
@@ -778,7 +942,10 @@ int launch_shadow_wave_check(const unsigned long long* d_wave_thr, uint32_t wave
     return ORAMA_OK;
 }
 
-int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream) {
+int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a_in, hipStream_t stream) {
+    static const uint32_t k2dbg = [] { const char* e = std::getenv("ORAMA_K2_DBG"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    F16ScanArgs a = a_in;
+    if (!a.out_dense && !a.wave_lists) a.dbg = k2dbg;  // timing ablation of the filter-mode launches
     ORAMA_REQUIRE(a.tiled && a.inv_norm && a.queries, "vec_scan_f16: bad arguments");
     ORAMA_REQUIRE(a.q >= 1 && a.q <= kF16MaxQ, "vec_scan_f16: q=%u outside [1, %u]", a.q, kF16MaxQ);
     ORAMA_REQUIRE((a.row_begin & 31) == 0 && a.row_begin <= a.row_end, "vec_scan_f16: bad row range");
@@ -825,8 +992,9 @@ int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream
         return ORAMA_OK;
     }
     const int nqt = a.q <= 32 ? 1 : 2;
-    const size_t lds_bytes = (size_t)ksteps * nqt * 1024 + 64 * sizeof(float);
-    ORAMA_REQUIRE(lds_bytes <= 160 * 1024, "vec_scan_f16: dim %u too large for the LDS query tile", a.dim);
+    a.stage_cap = vec_scan_f16_stage_entries(a.dim, nqt);
+    const size_t lds_bytes = vec_scan_f16_lds_bytes(a.dim, nqt, a.stage_cap);
+    ORAMA_REQUIRE(a.stage_cap >= 128 && lds_bytes <= kF16LdsLimit, "vec_scan_f16: dim %u too large for the LDS query tile", a.dim);
     ProfScope prof(&ctx->prof, "vec_scan_f16", stream);
     const uint64_t tiles = ((a.row_end + 31) >> 5) - (a.row_begin >> 5);
     const dim3 grid(blocks_for(tiles, kWavesPerBlock, (uint32_t)ctx->compute_units));
@@ -837,12 +1005,18 @@ int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream
     do {                                                                                                   \
         static bool attr_done = false;                                                                     \
         if (!attr_done) {                                                                                  \
-            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_kernel<NQT_, KC_, NB_>), \
+            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_kernel<NQT_, KC_, NB_, false>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
+            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_kernel<NQT_, KC_, NB_, true>), \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
             attr_done = true;                                                                              \
         }                                                                                                  \
-        hipLaunchKernelGGL((vec_scan_f16_kernel<NQT_, KC_, NB_>), grid, dim3(kBlock), lds_bytes, stream, a, ksteps, \
-                           f16_tile_bytes(a.dim));                                                         \
+        if (a.out_dense)                                                                                   \
+            hipLaunchKernelGGL((vec_scan_f16_kernel<NQT_, KC_, NB_, true>), grid, dim3(kBlock), lds_bytes, stream, a, \
+                               ksteps, f16_tile_bytes(a.dim));                                             \
+        else                                                                                               \
+            hipLaunchKernelGGL((vec_scan_f16_kernel<NQT_, KC_, NB_, false>), grid, dim3(kBlock), lds_bytes, stream, a, \
+                               ksteps, f16_tile_bytes(a.dim));                                             \
     } while (0)
 #define ORAMA_F16_DISPATCH(NQT_)                                  \
     do {                                                          \

@@ -19,6 +19,23 @@ inline uint64_t f16_tile_bytes(uint32_t dim) { return (uint64_t)f16_kpad(dim) * 
 inline uint64_t f16_tiles(uint64_t rows) { return (rows + 31) / 32; }
 
 constexpr uint32_t kF16MaxQ = 64;  // queries per corpus pass (2 MFMA column tiles); larger batches loop
+constexpr uint32_t kF16MetaBytes = 256;  // tile metadata record in LDS: 32 norms, the tombstone word, padding
+// LDS of the K2 kernel: the batch's B fragments, 1/|q|, and per wave (8 of them) a ring of <= 5 metadata records, a
+// 64-bin histogram and a staging area of `stage_entries` passing rows (12 bytes each) on their way to the candidate lists
+constexpr size_t kF16LdsLimit = 160 * 1024;
+inline size_t vec_scan_f16_lds_bytes(uint32_t dim, int nqt, uint32_t stage_entries) {
+    return (size_t)(f16_kpad(dim) / 16) * (size_t)nqt * 1024 + 64 * sizeof(float) + 8 * (5 * kF16MetaBytes + 256) +
+           8 * 3 * (size_t)stage_entries * sizeof(uint32_t);
+}
+// the staging area takes the LDS the fragments leave, in steps of 64 entries, 128..1024 (0: not even 128 fit)
+inline uint32_t vec_scan_f16_stage_entries(uint32_t dim, int nqt) {
+    const size_t fixed = vec_scan_f16_lds_bytes(dim, nqt, 0);
+    if (fixed >= kF16LdsLimit) return 0;
+    const size_t e = ((kF16LdsLimit - fixed) / (8 * 3 * sizeof(uint32_t))) & ~(size_t)63;
+    return e < 128 ? 0u : (uint32_t)(e > 1024 ? 1024 : e);
+}
+// queries one K2 pass can take at this dimension: 64 while two column tiles of fragments fit the 160 KiB of LDS
+inline uint32_t vec_scan_f16_max_q(uint32_t dim) { return vec_scan_f16_stage_entries(dim, 2) ? kF16MaxQ : 32; }
 
 // rows [first, first+n) of `src` (f32 row-major [n][dim]) → fp16 (RNE) into the tiled store.
 int launch_f16_store_rows(void* tiled, const float* src, uint64_t first, uint64_t n, uint32_t dim,
@@ -65,6 +82,8 @@ struct F16ScanArgs {
     unsigned long long* wave_lists = nullptr;
     unsigned long long* wave_thr = nullptr;
     uint32_t topk = 0;
+    uint32_t stage_cap = 0;  // set by the launcher: vec_scan_f16_stage_entries
+    uint32_t dbg = 0;  // timing ablations (ORAMA_K2_DBG): 1 no epilogue (K2), 2 no candidate appends (K2, K2d)
 };
 // K2. Algorithmic HBM traffic: (row_end - row_begin) * kpad * 2 bytes per launch (serves all q queries).
 int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream);

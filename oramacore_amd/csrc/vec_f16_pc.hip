@@ -255,7 +255,7 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_pc_kernel(F16ScanArg
                         }
                         a.out_dense[(uint64_t)col * a.dense_stride + (row - a.row_begin)] =
                             excluded ? __builtin_nanf("") : dist;
-                    } else if (!excluded && dist < tau) {
+                    } else if (!excluded && dist < tau && !(a.dbg & 2u)) {
                         if (a.allow) {  // only rows that pass the threshold pay for the filter lookup
                             const uint64_t doc = a.row_doc[row];
                             excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
@@ -388,7 +388,10 @@ using PcD = PcCfg<3, 2, 2, 4, 4, 2, 5, 1>;
 // <= 128 queries: half the query tiles — 8 consumers of 2 x 2 tiles, block tile 256 rows x 128 queries, ring of 5
 using PcA2 = PcCfg<2, 2, 4, 2, 4, 2, 5, 1>;
 
-int launch_vec_scan_f16_pc(orama_ctx* ctx, const F16ScanArgs& a, void* d_query_frags, hipStream_t stream, int geometry) {
+int launch_vec_scan_f16_pc(orama_ctx* ctx, const F16ScanArgs& a_in, void* d_query_frags, hipStream_t stream, int geometry) {
+    static const uint32_t k2dbg = [] { const char* e = std::getenv("ORAMA_K2_DBG"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    F16ScanArgs a = a_in;
+    if (!a.out_dense) a.dbg = k2dbg & 2u;  // timing ablation: no candidate appends
     ORAMA_REQUIRE(a.tiled && a.inv_norm && a.queries && d_query_frags, "vec_scan_f16_pc: bad arguments");
     ORAMA_REQUIRE(a.q >= 1 && a.q <= kF16WideMaxQ, "vec_scan_f16_pc: q=%u outside [1, %u]", a.q, kF16WideMaxQ);
     ORAMA_REQUIRE((a.row_begin & 31) == 0 && a.row_begin <= a.row_end, "vec_scan_f16_pc: bad row range");

@@ -544,7 +544,7 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
     for (uint32_t q0 = 0; q0 < q;) {
         // <= 64 queries: K2 (whole batch as LDS-resident B fragments); more: K2c (GEMM-tiled, <= 256 per pass)
         const bool wide = v->ctx->f16_wide && (q - q0) > kF16MaxQ && (kpad_k / 16) % 2 == 0;
-        const uint32_t gq = std::min<uint32_t>(wide ? kF16WideMaxQ : kF16MaxQ, q - q0);
+        const uint32_t gq = std::min<uint32_t>(wide ? kF16WideMaxQ : vec_scan_f16_max_q(v->dim), q - q0);
         if (wide) ORAMA_TRY(sc->f16_bfrag.reserve(f16_wide_query_bytes(v->dim)));
         bool wide_prepared = false;
         auto scan = [&](const F16ScanArgs& args) -> int {
@@ -639,8 +639,13 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
             const char* e = std::getenv("ORAMA_F16_CHUNK_GROW");
             return e ? std::atoi(e) : -1;
         }();
+        static const uint64_t grow_factor = [] {
+            const char* e = std::getenv("ORAMA_F16_GROW_FACTOR");
+            return e ? (uint64_t)std::max(2, std::atoi(e)) : 2ull;
+        }();
         const bool grow = grow_env >= 0 ? grow_env != 0 : ((uint64_t)gq * k >= 8192 && k > 128);
-        uint64_t this_chunk = grow ? std::min<uint64_t>(chunk_rows, std::max<uint64_t>(s1 & ~255ull, 1u << 17)) : chunk_rows;
+        uint64_t this_chunk =
+            grow ? std::min<uint64_t>(chunk_rows, (grow_factor - 1) * std::max<uint64_t>(s1 & ~255ull, 1u << 17)) : chunk_rows;
         for (uint64_t r0 = s1; r0 < n;) {
             const uint64_t r1 = std::min<uint64_t>(n, r0 + this_chunk);
             ORAMA_TRY(launch_f16_seed_candidates(best_dist, best_row, out_n, gq, k, tau, cand_dist, cand_row,
@@ -678,7 +683,7 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
             }
             ORAMA_TRY(launch_select(v->ctx, c, s));
             r0 = r1;
-            if (grow) this_chunk = std::min<uint64_t>(chunk_rows, r1 & ~255ull);  // as large as everything before it
+            if (grow) this_chunk = std::min<uint64_t>(chunk_rows, (grow_factor - 1) * (r1 & ~255ull));
         }
         q0 += gq;
     }

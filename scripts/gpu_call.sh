@@ -1,10 +1,6 @@
 #!/bin/bash
-O=gpurun_out/r02fin3
-mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout 600 python scripts/bench_two_stage.py > $O/bench_two_stage.log 2>&1; grep -v "^{" $O/bench_two_stage.log | tail -5
-timeout 400 python bench.py --steps 50 --warmup 5 > $O/bench_ns.json 2> $O/bench_ns.err; python -c "
-import json; d=json.loads(open('$O/bench_ns.json').read().strip().splitlines()[-1]); print('ns', round(d['value'],1), 'frac', round(d['roofline']['frac'],3), 'two_stage', round(d['two_stage_exact']['value'],1), 'b64', round(d['two_stage_exact']['batch64_queries_per_s']), 'fallbacks', d['two_stage_exact']['fallbacks'])"
-timeout 400 python scripts/bench_hybrid.py --steps 100 --warmup 5 > $O/bench_c4.json 2>$O/bench_c4.err; python -c "
-import json; d=json.load(open('$O/bench_c4.json')); print('c4 hybrid', round(d['value'],1), 'two-stage', round(d['hybrid_two_stage_exact']['value'],1), 'bm25 batch', round(d['bm25_only']['value']))"
-timeout 300 scripts/native/bench_serving vec 10000000 100 1,64,512 shadow > $O/serving_shadow.log 2>&1; tail -7 $O/serving_shadow.log
+mkdir -p gpurun_out/k2e
+timeout 600 python -m pytest tests/test_vector_f16_gpu.py tests/test_two_stage_gpu.py tests/test_random_gpu.py -m gpu -x -q -p no:cacheprovider 2>&1 | tail -5
+for d in 0 2 0 2; do echo "== ORAMA_K2_DBG=$d"; ORAMA_K2_DBG=$d timeout 300 python scripts/k2_epilogue_ablation.py 2>&1 | tail -2 | head -1; done | tee gpurun_out/k2e/ablation6.log
+for f in 0 16; do echo "== grow $f";  if [ $f = 0 ]; then export ORAMA_F16_CHUNK_GROW=0; else export ORAMA_F16_CHUNK_GROW=1 ORAMA_F16_GROW_FACTOR=$f; fi; timeout 300 python bench.py --workload c3 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'])"; done | tee gpurun_out/k2e/grow4.log
