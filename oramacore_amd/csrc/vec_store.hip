@@ -629,12 +629,14 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
         ORAMA_TRY(launch_select(v->ctx, p, s));
         // 2. filter scan of the rest in super-chunks
         // Super-chunks may GROW: the threshold tau_j only tightens between super-chunks, and the share of rows that pass
-        // it — each costs the epilogue's slow path for its whole wave — is k / (rows seen so far).  One chunk for the
-        // whole rest runs at the head's k / 131072 throughout; chunks that double (the next one as large as everything
-        // scanned before it) keep it near k / rows-so-far for the price of ~log2(N / S1) scan + select launches.
-        // That pays for many queries with a large k (the two-stage plan asks for k1 >= 228: 64 queries 5.4 -> 3.2 ms of
-        // scan) and costs otherwise (C3, k = 100: +0.4 ms of launches) — so it is used for q * k >= 8192 and k > 128
-        // (ORAMA_F16_CHUNK_GROW = 0 / 1 forces it off / on).
+        // it is k / (rows seen so far).  One chunk for the whole rest runs at the head's k / 131072 throughout; chunks
+        // that grow geometrically (the next one (factor - 1) times everything scanned before it) keep it near
+        // k / rows-so-far for the price of ~log_factor(N / S1) scan + select launches.  What a passing row costs
+        // depends on the kernel: K2 (<= 64 queries) stages passing rows in LDS and appends them in bulk, so it no longer
+        // cares (two-stage, 64 queries, k1 = 228: 2.97 ms without growth, 3.35 with); the wide kernels append row by
+        // row from the epilogue, and there growth pays for many queries with a large k (256 queries: 7.87 vs 8.17 ms).
+        // So: wide batches with q * k >= 8192 and k > 128 (ORAMA_F16_CHUNK_GROW = 0 / 1 forces it off / on,
+        // ORAMA_F16_GROW_FACTOR sets the factor, default 2).
         static const int grow_env = [] {
             const char* e = std::getenv("ORAMA_F16_CHUNK_GROW");
             return e ? std::atoi(e) : -1;
@@ -643,7 +645,7 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
             const char* e = std::getenv("ORAMA_F16_GROW_FACTOR");
             return e ? (uint64_t)std::max(2, std::atoi(e)) : 2ull;
         }();
-        const bool grow = grow_env >= 0 ? grow_env != 0 : ((uint64_t)gq * k >= 8192 && k > 128);
+        const bool grow = grow_env >= 0 ? grow_env != 0 : (wide && (uint64_t)gq * k >= 8192 && k > 128);
         uint64_t this_chunk =
             grow ? std::min<uint64_t>(chunk_rows, (grow_factor - 1) * std::max<uint64_t>(s1 & ~255ull, 1u << 17)) : chunk_rows;
         for (uint64_t r0 = s1; r0 < n;) {

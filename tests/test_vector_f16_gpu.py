@@ -181,3 +181,49 @@ def test_l2_metric_on_fp16_storage(ctx, nq):
         full = orc.distances(c16, q16(queries[qi]), metric=1).astype(np.float64)
         util.assert_topk_sound(ids[qi, :cnt[qi]], dist[qi, :cnt[qi]], full, k, 3e-4, f"l2 f16 q{qi}")
     st.close()
+
+
+def _crowd(n, d, nq, seed):
+    """A corpus ordered by INCREASING similarity to a crowd of near-identical queries: in the filter region every
+    row beats every query's running threshold, so a 32-row tile hands 32 x nq rows to the staging area."""
+    rng = np.random.default_rng(seed)
+    centre = rng.standard_normal(d).astype(np.float32)
+    queries = (centre[None, :] + 0.01 * rng.standard_normal((nq, d))).astype(np.float32)
+    corpus = util.gaussian_rows(n, d, seed=seed + 1)
+    c16 = q16(corpus)
+    sim = c16 @ q16(centre) / np.linalg.norm(c16, axis=1)
+    return corpus[np.argsort(sim, kind="stable")], queries
+
+
+@pytest.mark.parametrize("d,nq", [(64, 64), (1024, 64), (2048, 40), (768, 33)])
+def test_filter_path_every_row_passes_for_every_query(ctx, d, nq):
+    """The worst case for the per-wave staging of passing rows: full tiles of candidates for all
+    queries at once, at dimensions where the staging area is large (64: 1 024 rows per wave), the smallest it gets
+    with two column tiles (1 024: 192 rows) and where 64 queries no longer fit one pass (2 048: passes of 32)."""
+    n = 131_072 + 6_000
+    corpus, queries = _crowd(n, d, nq, seed=900 + d)
+    st = make_store(ctx, corpus)
+    check(st, q16(corpus), queries, 100, what=f"crowd d={d} nq={nq}")
+    st.close()
+
+
+def test_filter_path_crowd_with_deletes_and_allow_bitmap(ctx):
+    """Same crowd, with tombstones and an allow bitmap in the filter region: the bitmap lookup happens when the
+    staged rows are flushed, the tombstone test when they are staged."""
+    n, d, nq = 131_072 + 9_000, 128, 64
+    corpus, queries = _crowd(n, d, nq, seed=77)
+    st = make_store(ctx, corpus)
+    dead = np.arange(131_072 + 5, n, 97, dtype=np.int64)
+    for r in dead:
+        st.delete(int(r))
+    mask = np.arange(n) % 5 != 1
+    allow = oa.AllowBitmap.from_mask(mask)
+    ids, dist, cnt = st.storage_search(queries, 50, allow)
+    c16 = q16(corpus)
+    for qi in (0, 1, 31, 32, 47, 63):
+        full = orc.distances(c16, q16(queries[qi])).astype(np.float64)
+        full[dead] = np.nan
+        full[~mask] = np.nan
+        m = int(cnt[qi])
+        util.assert_topk_sound(ids[qi, :m], dist[qi, :m], full, 50, TOL, f"crowd dead+filter q{qi}")
+    st.close()
