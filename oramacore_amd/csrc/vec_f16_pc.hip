@@ -78,7 +78,16 @@ struct PcCfg {
     static constexpr int kStageBytes = F * 1024;
     static constexpr int kMetaOff = NBUF * kStageBytes;
     static constexpr int kMetaBytes = 2 * 1024;        // 1/|x| (or |x|^2) of the block tile's rows, double-buffered
-    static constexpr int kLdsBytes = kMetaOff + kMetaBytes;
+    static constexpr int kDeadOff = kMetaOff + kMetaBytes;  // tombstone words of the block tile's row tiles, double-buffered
+    static constexpr int kDeadBytes = 2 * 256;             // (a 64-lane dword DMA writes 256 bytes)
+    static constexpr int kQOff = kDeadOff + kDeadBytes;     // 1/|q| (or |q|^2) and the threshold of every query column
+    static constexpr int kQBytes = 2 * 256 * 4;
+    // per consumer wave: a 64-bin histogram and kStageCap staged rows (distance, row: 4 bytes each; column: 1 byte)
+    static constexpr int kStageCap = 96;
+    static constexpr int kStageOff = kQOff + kQBytes;
+    static constexpr int kWaveStage = 256 + kStageCap * 9 + (16 - (kStageCap * 9) % 16) % 16;
+    static constexpr int kLdsBytes = kStageOff + NC * kWaveStage;
+    static_assert(kQTiles * 32 <= 256, "query metadata is two 1-KiB arrays");
     static_assert(IPS_MIN * (D > 1 ? D - 1 : 1) < 64, "counted vmcnt wait must fit 6 bits");
     static_assert(D >= 1 && KS >= 1, "ring of at least two stages");
     static_assert(kRowTiles * 32 <= 256, "tile metadata is one 1-KiB DMA");
@@ -86,7 +95,16 @@ struct PcCfg {
     static_assert(kThreads <= 1024, "workgroup size");
 };
 
-template <class C, int DBG>
+// 4 bytes per lane, global -> LDS (lane l's dword lands at m0 + 4 l); per-lane 64-bit addresses
+__device__ __forceinline__ void pc_dma4(const void* src, uint32_t lds_addr_uniform) {
+    asm volatile("s_nop 0\n\tglobal_load_lds_dword %0, off"
+                 :
+                 : "v"(src), "{m0}"(lds_addr_uniform)
+                 : "memory");
+}
+
+// DENSE: the launch writes every distance (the head of the store) instead of keeping the rows under the thresholds.
+template <class C, int DBG, bool DENSE>
 __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_pc_kernel(F16ScanArgs a, const char* __restrict__ bfrag,
                                                                       const float* __restrict__ qinv,
                                                                       uint32_t ksteps, uint64_t tile_bytes,
@@ -108,6 +126,14 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_pc_kernel(F16ScanArg
     const uint32_t S = ksteps / KS;                                                 // stages per block tile
     const uint64_t total = my_bt * S;
     const float* inv_lds = reinterpret_cast<const float*>(lds + C::kMetaOff);      // [2][256]
+    const uint32_t* dead_lds = reinterpret_cast<const uint32_t*>(lds + C::kDeadOff);  // [2][64], the first kRowTiles used
+    float* q_lds = reinterpret_cast<float*>(lds + C::kQOff);                        // [256] 1/|q|, [256] threshold
+    // per-column constants of the epilogue: read from LDS there (lgkmcnt) — as global loads they cost every consumer
+    // a memory round trip per block tile.  Visible to everybody after the first stage barrier.
+    for (uint32_t c = tid; c < 256u; c += C::kThreads) {
+        q_lds[c] = c < a.q ? qinv[c] : 0.0f;
+        q_lds[256 + c] = (a.tau && c < a.q) ? a.tau[c] : 0.0f;
+    }
 
     if (w >= NC) {
         // ================================================================= loader wave
@@ -146,6 +172,11 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_pc_kernel(F16ScanArg
                 // store read the zero-initialised padding of the array)
                 pc_dma16((uint64_t)(uintptr_t)a.inv_norm + (t_first + ld_bt * C::kRowTiles) * 128, vlane,
                          lds_base + C::kMetaOff + ld_par * 1024);
+                if (a.dead) {  // and the tombstone words of its row tiles (lanes past the last tile re-read it)
+                    uint64_t tl = t_first + ld_bt * C::kRowTiles + ((uint32_t)lane < (uint32_t)C::kRowTiles ? lane : C::kRowTiles - 1);
+                    if (tl >= t_end) tl = t_end - 1;
+                    pc_dma4(a.dead + tl, lds_base + C::kDeadOff + ld_par * 256);
+                }
             }
             const bool clamp = partial_last && ld_bt == n_bt - 1;  // the last block tile may hold fewer row tiles
 #pragma unroll
@@ -208,7 +239,57 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_pc_kernel(F16ScanArg
     const bool l2 = a.metric == ORAMA_METRIC_L2SQ;
 
     f16v acc[RT][CT];
-    typedef const uint32_t __attribute__((address_space(4))) cu32;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    // ---- filter mode: rows under the thresholds are staged per consumer wave in LDS and appended in bulk with ONE
+    // global atomic instruction per flush (K2's scheme, vec_f16.hip: an LDS histogram ranks the staged rows within
+    // their query column; lane c reserves column c's slots).  A consumer owns CT x 32 <= 64 columns.
+    constexpr uint32_t kCap = C::kStageCap;
+    const uint32_t stage_off = uniform_u32((uint32_t)C::kStageOff + (uint32_t)w * (uint32_t)C::kWaveStage);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(lds + stage_off);
+    uint32_t* st_dist = hist + 64;
+    uint32_t* st_row = st_dist + kCap;
+    uint8_t* st_col = reinterpret_cast<uint8_t*>(st_row + kCap);
+    const uint32_t col0 = (uint32_t)(wq * CT) * 32;  // first query column of this consumer
+    uint32_t staged = 0;                              // wave-uniform
+    auto wave_fence = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); };
+    auto bin_load = [](const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
+    auto bin_store = [](uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
+    auto flush = [&]() {
+        wave_fence();
+        bin_store(&hist[lane], 0u);
+        wave_fence();
+        uint32_t rank[(kCap + 63) / 64];
+#pragma unroll
+        for (uint32_t t = 0; t < (kCap + 63) / 64; ++t) {
+            const uint32_t i = t * 64 + lane;
+            rank[t] = ~0u;
+            if (i < staged) {
+                bool keep = !(a.dbg & 2u);
+                if (a.allow) {
+                    const uint64_t doc = a.row_doc[st_row[i]];
+                    keep = keep && doc < a.allow_bits && ((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
+                }
+                if (keep) rank[t] = __hip_atomic_fetch_add(&hist[st_col[i]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        wave_fence();
+        const uint32_t mine = bin_load(&hist[lane]);
+        bin_store(&hist[lane], mine ? atomicAdd(&a.cand_count[col0 + lane], mine) : 0u);
+        wave_fence();
+#pragma unroll
+        for (uint32_t t = 0; t < (kCap + 63) / 64; ++t) {
+            const uint32_t i = t * 64 + lane;
+            if (i < staged && rank[t] != ~0u) {
+                const uint32_t c = st_col[i];
+                const uint64_t pos = (uint64_t)(col0 + c) * a.cand_stride + bin_load(&hist[c]) + rank[t];
+                a.cand_dist[pos] = __uint_as_float(st_dist[i]);
+                a.cand_row[pos] = st_row[i];
+            }
+        }
+        wave_fence();
+        staged = 0;
+    };
+
     auto epilogue = [&](uint64_t bt, uint32_t par) {
         const uint32_t hi = (lane >> 5) ? 4u : 0u;
 #pragma unroll
@@ -216,56 +297,90 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_pc_kernel(F16ScanArg
             const uint32_t tl = (uint32_t)(wr * RT + i);
             const uint64_t tile = t_first + bt * C::kRowTiles + tl;
             if (tile >= t_end) continue;  // wave-uniform
-            const uint32_t dead_word = a.dead ? ((cu32*)(uintptr_t)a.dead)[tile] : 0u;  // scalar load
-            float nrm[16];
+            const uint32_t dead_word = a.dead ? dead_lds[par * 64 + tl] : 0u;
+            // this lane's 16 accumulator rows are (r & 3) + 8 (r >> 2) + hi: four 16-byte reads of the tile's norms
+            f16v nrmv;
+            {
+                const f4* np = reinterpret_cast<const f4*>(inv_lds + par * 256 + tl * 32 + hi);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) nrm[r] = inv_lds[par * 256 + tl * 32 + (r & 3) + 8 * (r >> 2) + hi];
-            const bool full = tile * 32 + 32 <= a.row_end;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f4 v = np[2 * g4];
 #pragma unroll
-            for (int j = 0; j < CT; ++j) {
-                const uint32_t col = (uint32_t)(wq * CT + j) * 32 + (lane & 31);
-                if (col >= a.q) continue;
-                // per-lane constants of the query column, re-read per block tile (L2 hits) instead of living in
-                // registers across the K loop: the loop runs at the edge of the register budget
-                const float qi = qinv[col];
-                const float tau = a.tau ? a.tau[col] : 0.0f;
-                // cosine: 1 - s (1/|x|)(1/|q|);  L2: (|q|^2 + |x|^2) - 2 s   (nrm / qi hold the squared norms then)
-                auto distance = [&](int r) -> float {
-                    return l2 ? (qi + nrm[r]) - 2.0f * acc[i][j][r] : 1.0f - acc[i][j][r] * (nrm[r] * qi);
-                };
-                if (!a.out_dense) {
-                    // filter mode, fast reject: almost no row beats the running k-th best distance, so take the
-                    // minimum of the 16 distances first and look closer only when it passes
-                    float best = __builtin_huge_valf();
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) best = fminf(best, distance(r));
-                    if (!(best < tau)) continue;
+                    for (int e = 0; e < 4; ++e) nrmv[4 * g4 + e] = v[e];
                 }
+            }
+            const bool full = tile * 32 + 32 <= a.row_end;
+            // bit r: accumulator row r of this lane is a live row of the store (branch-free: as short-circuit tests
+            // the 16 partial results went through scratch memory)
+            uint32_t rowmask = 0;
+            if (!DENSE) {
+                const uint32_t dw = dead_word >> hi;
+                const uint32_t left = full ? 32u : (uint32_t)(a.row_end - tile * 32);  // rows of the tile inside the store
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const uint32_t ri = (uint32_t)((r & 3) + 8 * (r >> 2)) + hi;
-                    const uint64_t row = tile * 32 + ri;
-                    if (!full && row >= a.row_end) continue;
-                    const float dist = distance(r);
-                    bool excluded = (dead_word >> ri) & 1u;
-                    if (a.out_dense) {
+                    const uint32_t ri = (uint32_t)((r & 3) + 8 * (r >> 2));
+                    rowmask |= ((~(dw >> ri)) & (ri + hi < left ? 1u : 0u) & 1u) << r;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const uint32_t cl = (uint32_t)j * 32 + (lane & 31);  // column inside this consumer's group
+                const uint32_t col = col0 + cl;
+                const bool live = col < a.q;
+                if (DENSE && !live) continue;
+                const float qi = q_lds[col];
+                const float tau = q_lds[256 + col];
+                // cosine: 1 - s (1/|x|)(1/|q|);  L2: (|q|^2 + |x|^2) - 2 s   (nrm / qi hold the squared norms then) —
+                // as the fused operations the compiler contracts the plain expressions to (vec_f16.hip)
+                auto dist_of = [&](float dot, float n, float qv) -> float {
+                    return l2 ? __builtin_fmaf(-2.0f, dot, qv + n) : __builtin_fmaf(-dot, n * qv, 1.0f);
+                };
+                if constexpr (DENSE) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t ri = (uint32_t)((r & 3) + 8 * (r >> 2)) + hi;
+                        const uint64_t row = tile * 32 + ri;
+                        if (!full && row >= a.row_end) continue;
+                        bool excluded = (dead_word >> ri) & 1u;
                         if (!excluded && a.allow) {
                             const uint64_t doc = a.row_doc[row];
                             excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
                         }
                         a.out_dense[(uint64_t)col * a.dense_stride + (row - a.row_begin)] =
-                            excluded ? __builtin_nanf("") : dist;
-                    } else if (!excluded && dist < tau && !(a.dbg & 2u)) {
-                        if (a.allow) {  // only rows that pass the threshold pay for the filter lookup
-                            const uint64_t doc = a.row_doc[row];
-                            excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
-                        }
-                        if (!excluded) {
-                            const uint32_t pos = atomicAdd(&a.cand_count[col], 1u);
-                            a.cand_dist[(uint64_t)col * a.cand_stride + pos] = dist;
-                            a.cand_row[(uint64_t)col * a.cand_stride + pos] = (uint32_t)row;
-                        }
+                            excluded ? __builtin_nanf("") : dist_of(acc[i][j][r], nrmv[r], qi);
                     }
+                    continue;
+                }
+                // fast reject: the minimum of the 16 distances against the threshold, one ballot
+                float best = __builtin_huge_valf();
+                if (l2) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) best = fminf(best, __builtin_fmaf(-2.0f, acc[i][j][r], qi + nrmv[r]));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) best = fminf(best, __builtin_fmaf(-acc[i][j][r], nrmv[r] * qi, 1.0f));
+                }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(live && best < tau) == 0, 1)) continue;
+                float qi_s = qi;  // (an operand the optimiser cannot see through: nothing is kept from the fast path)
+                asm volatile("" : "+v"(qi_s));
+                uint32_t m = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m |= (dist_of(acc[i][j][r], nrmv[r], qi_s) < tau ? 1u : 0u) << r;
+                m = live ? (m & rowmask) : 0u;
+#pragma unroll 1
+                for (int r = 0; r < 16; ++r) {  // wave-uniform index into the accumulators
+                    const bool mine = (m >> r) & 1u;
+                    const uint64_t bal = __builtin_amdgcn_ballot_w64(mine);
+                    if (!bal) continue;
+                    if (mine) {
+                        const uint32_t pos =
+                            staged + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                        st_dist[pos] = __float_as_uint(dist_of(acc[i][j][r], nrmv[r], qi_s));
+                        st_row[pos] = (uint32_t)(tile * 32) + (uint32_t)((r & 3) + 8 * (r >> 2)) + hi;
+                        st_col[pos] = (uint8_t)cl;
+                    }
+                    staged = uniform_u32(staged + (uint32_t)__popcll(bal));
+                    if (staged > kCap - 64) flush();
                 }
             }
         }
@@ -347,6 +462,7 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_pc_kernel(F16ScanArg
         }
         buf = buf == NBUF - 1 ? 0 : buf + 1;
     }
+    if (!DENSE && staged) flush();
     if (TRACE && w == 0 && lane == 0) trace[8192 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
 }
 
@@ -355,7 +471,9 @@ int pc_launch(orama_ctx* ctx, const F16ScanArgs& a, const char* bfrag, const flo
               hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_pc_kernel<C, DBG>),
+        ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_pc_kernel<C, DBG, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_pc_kernel<C, DBG, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
@@ -368,8 +486,12 @@ int pc_launch(orama_ctx* ctx, const F16ScanArgs& a, const char* bfrag, const flo
         if (e) trace = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 16));
         ORAMA_REQUIRE(trace, "trace build needs ORAMA_K2D_TRACE");
     }
-    hipLaunchKernelGGL((vec_scan_f16_pc_kernel<C, DBG>), dim3((uint32_t)blocks), dim3(C::kThreads), C::kLdsBytes, stream,
-                       a, bfrag, qinv, ksteps, f16_tile_bytes(a.dim), trace);
+    if (a.out_dense)
+        hipLaunchKernelGGL((vec_scan_f16_pc_kernel<C, DBG, true>), dim3((uint32_t)blocks), dim3(C::kThreads), C::kLdsBytes,
+                           stream, a, bfrag, qinv, ksteps, f16_tile_bytes(a.dim), trace);
+    else
+        hipLaunchKernelGGL((vec_scan_f16_pc_kernel<C, DBG, false>), dim3((uint32_t)blocks), dim3(C::kThreads), C::kLdsBytes,
+                           stream, a, bfrag, qinv, ksteps, f16_tile_bytes(a.dim), trace);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }
@@ -414,6 +536,7 @@ int launch_vec_scan_f16_pc(orama_ctx* ctx, const F16ScanArgs& a_in, void* d_quer
             case 4: return pc_launch<PcB, 4>(ctx, a, bfrag, qinv, ksteps, stream);    // corpus DMA + compute
             case 16: return pc_launch<PcB, 16>(ctx, a, bfrag, qinv, ksteps, stream);  // full kernel + timeline stamps
             case 25: return pc_launch<PcB, 25>(ctx, a, bfrag, qinv, ksteps, stream);  // DMA only + stamps
+            case 32: return pc_launch<PcB, 32>(ctx, a, bfrag, qinv, ksteps, stream);  // everything but the epilogue
             default: break;
         }
     }
