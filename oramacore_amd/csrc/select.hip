@@ -13,6 +13,9 @@
 // N x D x 4 B corpus pass (0.5 % at D = 768).
 #include "select.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_utils.hpp"
 
 namespace orama {
@@ -495,6 +498,167 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
     for (uint32_t i = taken + threadIdx.x; i < k; i += blockDim.x) o[i] = 0ull;
 }
 
+// ---------------------------------------------------------------- (value, index) lists in two launches
+// The candidate lists of the fp16 scans (a few thousand entries per query, length known on the device only) went
+// through the general selection: memset + 6 x (histogram + scan) + collect + sort = 15 launches of 2-15 us with a
+// 6-11 us gap before each (~0.2 ms), 5-8 times per wide batch; this form takes 36 + 39 us.  (Not used for dense lists:
+// 131 072 values x 256 queries take 227 + 82 us here against ~150 us of histogram passes.)  This kernel is
+// keys_reduce_kernel's LDS radix select applied to keys built on the fly from (value, index) pairs: list `qi` is split
+// into gridDim.x contiguous ranges, a workgroup walks its range in rounds of up to 8192 keys, carrying its best k along
+// (the keys of a round sit in registers while the survivors are compacted to the front of the LDS array), and writes
+// its best k; keys_final_kernel then orders gridDim.x * k <= 4096 survivors.  Exact for any list length (a list of
+// millions of entries just takes more rounds).  NaN values become empty keys.
+__device__ unsigned long long lds_keys_threshold(unsigned long long* s, uint32_t cnt, uint32_t k, uint32_t* hist,
+                                                 unsigned long long* red_max, unsigned long long* red_min,
+                                                 uint32_t* red_nz, uint32_t* sel /* bin, above, cnt */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long mx = 0ull, mn = ~0ull;
+    uint32_t nz = 0;
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const unsigned long long key = s[i];
+        if (key) {
+            ++nz;
+            mx = key > mx ? key : mx;
+            mn = key < mn ? key : mn;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(mx, off, 64), b = __shfl_xor(mn, off, 64);
+        mx = a > mx ? a : mx;
+        mn = b < mn ? b : mn;
+        nz += __shfl_xor(nz, off, 64);
+    }
+    __syncthreads();  // the reduction arrays may still be read by a previous call
+    if (lane == 0) {
+        red_max[wave] = mx;
+        red_min[wave] = mn;
+        red_nz[wave] = nz;
+    }
+    __syncthreads();
+    mx = 0ull, mn = ~0ull, nz = 0;
+    for (uint32_t w = 0; w < kSortThreads / 64; ++w) {
+        mx = red_max[w] > mx ? red_max[w] : mx;
+        mn = red_min[w] < mn ? red_min[w] : mn;
+        nz += red_nz[w];
+    }
+    if (nz <= k) return 1ull;  // take every non-empty key
+    uint32_t low = 64u - (uint32_t)__builtin_clzll(mx ^ mn);  // mx != mn: nz > k >= 1 unique keys
+    unsigned long long prefix = low >= 64u ? 0ull : (mx >> low) << low;
+    uint32_t need = k;
+    for (;;) {
+        const uint32_t d = low < 8u ? low : 8u;
+        const uint32_t shift = low - d;
+        const unsigned long long above_mask = low >= 64u ? 0ull : ~0ull << low;
+        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const unsigned long long key = s[i];
+            if (key && (key & above_mask) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & ((1u << d) - 1u)], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t c[4], tot = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                c[j] = hist[lane * 4 + j];
+                tot += c[j];
+            }
+            uint32_t incl = tot;  // keys in the bins of this lane and of the lanes above it
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y = __shfl_down(incl, off, 64);
+                if (lane + off < 64) incl += y;
+            }
+            uint32_t above = incl - tot;
+            if (above < need && need <= incl) {  // exactly one lane: the k-th key lies in its bins
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    if (above + c[j] >= need) {
+                        sel[0] = (uint32_t)lane * 4 + j;
+                        sel[1] = above;
+                        sel[2] = c[j];
+                        break;
+                    }
+                    above += c[j];
+                }
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned long long)sel[0] << shift;
+        need -= sel[1];
+        low = shift;
+        const bool whole = sel[2] == need;
+        __syncthreads();  // sel is rewritten by the next round
+        if (whole || low == 0) break;
+    }
+    return prefix;  // keys >= prefix: exactly k of them (unique keys)
+}
+
+__global__ __launch_bounds__(kSortThreads) void pairs_reduce_kernel(const float* __restrict__ vals,
+                                                                    const uint32_t* __restrict__ idx, uint64_t stride,
+                                                                    const uint32_t* __restrict__ n_dev, uint32_t n_max,
+                                                                    bool descending, uint32_t k,
+                                                                    unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long s[kKeysChunk];
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
+    __shared__ uint32_t red_nz[kSortThreads / 64];
+    __shared__ uint32_t sel[3], cursor;
+    const uint32_t qi = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = n_dev ? min(n_max, n_dev[qi]) : n_max;
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+    uint32_t pos = min(n, blockIdx.x * per);
+    const uint32_t end = min(n, pos + per);
+    const float* v = vals + (uint64_t)qi * stride;
+    const uint32_t* ix = idx ? idx + (uint64_t)qi * stride : nullptr;
+    unsigned long long* o = out + ((uint64_t)qi * gridDim.x + blockIdx.x) * k;
+    uint32_t kept = 0;
+    constexpr uint32_t kPerThread = kKeysChunk / kSortThreads;
+    for (;;) {
+        const uint32_t take = min(kKeysChunk - kept, end - pos);
+        for (uint32_t i = threadIdx.x; i < take; i += blockDim.x) {
+            const float x = v[pos + i];
+            s[kept + i] = x == x ? make_key(x, ix ? ix[pos + i] : pos + i, descending) : 0ull;
+        }
+        const uint32_t cnt = kept + take;
+        pos += take;
+        if (threadIdx.x == 0) cursor = 0;
+        __syncthreads();
+        const unsigned long long thr = lds_keys_threshold(s, cnt, k, hist, red_max, red_min, red_nz, sel);
+        const bool last = pos >= end;
+        // survivors: to the output (last round) or to the front of `s` (the round's keys wait in registers meanwhile)
+        unsigned long long mine[kPerThread];
+#pragma unroll
+        for (uint32_t t = 0; t < kPerThread; ++t) {
+            const uint32_t i = t * blockDim.x + threadIdx.x;
+            mine[t] = i < cnt ? s[i] : 0ull;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t t = 0; t < kPerThread; ++t) {
+            const bool tk = mine[t] >= thr;  // thr >= 1: empties never
+            const unsigned long long m = __ballot(tk);
+            uint32_t base = 0;
+            if (lane == 0 && m) base = atomicAdd(&cursor, (uint32_t)__popcll(m));
+            base = __shfl(base, 0, 64);
+            if (tk) {
+                const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (p < k) {
+                    if (last) o[p] = mine[t];
+                    else s[p] = mine[t];
+                }
+            }
+        }
+        __syncthreads();
+        kept = min(cursor, k);
+        __syncthreads();  // cursor is reset by the next round
+        if (last) break;
+    }
+    for (uint32_t i = kept + threadIdx.x; i < k; i += blockDim.x) o[i] = 0ull;
+}
+
 // Final ordering of <= 4096 keys: (value, 64-bit id asc, idx asc), empties (0) dropped.
 __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned long long* __restrict__ keys,
                                                                   uint32_t n_keys, uint64_t in_stride,
@@ -577,6 +741,11 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
     return ORAMA_OK;
 }
 
+static bool select_pairs_enabled() {
+    static const bool on = [] { const char* e = std::getenv("ORAMA_SELECT_PAIRS"); return !e || std::atoi(e) != 0; }();
+    return on;
+}
+
 int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
     ORAMA_REQUIRE(p.k >= 1, "top-k: k is 0");
     ORAMA_SUPPORT(p.k <= kSelectMaxK, "top-k: k=%u outside [1, %u]", p.k, kSelectMaxK);
@@ -593,6 +762,21 @@ int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
         return ORAMA_OK;
     }
     ORAMA_REQUIRE(p.state && p.keys, "top-k: scratch missing");
+    const uint64_t expect = p.n_hint ? p.n_hint : p.n;
+    if (p.n_dev && p.keys_capacity >= (uint64_t)p.q * kSelectMaxK && expect <= 16ull * kKeysChunk && select_pairs_enabled()) {
+        // (value, index) lists in two launches: `parts` workgroups per list keep their best k, one orders parts * k keys
+        // (lists expected to be longer than 16 chunks keep the histogram passes, which spread one list over the chip)
+        uint32_t parts = kSelectMaxK / p.k;
+        parts = std::min<uint32_t>(parts, (uint32_t)std::max<uint64_t>(1, (expect + kKeysChunk - 1) / kKeysChunk));
+        parts = std::min<uint32_t>(parts, 16u);
+        hipLaunchKernelGGL(pairs_reduce_kernel, dim3(parts, p.q), dim3(kSortThreads), 0, stream, p.vals, p.idx, p.stride,
+                           p.n_dev, p.n, p.descending, p.k, p.keys);
+        hipLaunchKernelGGL(keys_final_kernel, dim3(p.q), dim3(kSortThreads), 0, stream, p.keys, parts * p.k,
+                           (uint64_t)parts * p.k, nullptr, p.k, p.descending, p.id_map, p.out_idx, p.out_ids, p.out_val,
+                           p.out_n);
+        ORAMA_HIP_TRY(hipGetLastError());
+        return ORAMA_OK;
+    }
     ORAMA_HIP_TRY(hipMemsetAsync(p.state, 0, sizeof(SelectState) * (size_t)p.q, stream));
     uint32_t blocks = ceil_div_u32(p.n_hint ? p.n_hint : p.n, kHistThreads * 16);
     uint32_t max_blocks = (uint32_t)ctx->compute_units * 8u;

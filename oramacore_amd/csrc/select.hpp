@@ -37,6 +37,7 @@ struct SelectPlan {
     // scratch (HBM)
     SelectState* state = nullptr;     // q entries
     unsigned long long* keys = nullptr;  // q x k
+    uint64_t keys_capacity = 0;          // keys `keys` can hold; >= q x 4096 enables the two-launch form for short lists
     // output (HBM): q x k each, out_n: q
     uint32_t* out_idx = nullptr;      // nullable
     uint64_t* out_ids = nullptr;      // nullable (id_map[idx] or idx)

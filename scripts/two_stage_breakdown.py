@@ -13,7 +13,8 @@ n, dim, k = 10_000_000, 768, 100
 st = oa.EmbeddingFieldStorage(ctx, dimensions=dim, dtype=oa.DTYPE_F32_SHADOW16, reserve_rows=n)
 st.fill_synthetic(n, seed=0x5EED)
 rng = np.random.default_rng(1)
-for qb in (1, 8, 64):
+import os
+for qb in [int(x) for x in os.environ.get("QB", "1,8,64,256").split(",")]:
     qs = rng.standard_normal((12, qb, dim)).astype(np.float32)
     st.storage_search(qs[0], k)
     ctx.prof_reset()
