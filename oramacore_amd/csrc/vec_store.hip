@@ -629,15 +629,13 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
         p.out_n = out_n;  // borrowed as the running count
         ORAMA_TRY(launch_select(v->ctx, p, s));
         // 2. filter scan of the rest in super-chunks
-        // Super-chunks may GROW: the threshold tau_j only tightens between super-chunks, and the share of rows that pass
-        // it is k / (rows seen so far).  One chunk for the whole rest runs at the head's k / 131072 throughout; chunks
-        // that grow geometrically (the next one (factor - 1) times everything scanned before it) keep it near
-        // k / rows-so-far for the price of ~log_factor(N / S1) scan + select launches.  What a passing row costs
-        // depends on the kernel: K2 (<= 64 queries) stages passing rows in LDS and appends them in bulk, so it no longer
-        // cares (two-stage, 64 queries, k1 = 228: 2.97 ms without growth, 3.35 with); the wide kernels append row by
-        // row from the epilogue, and there growth pays for many queries with a large k (256 queries: 7.87 vs 8.17 ms).
-        // So: wide batches with q * k >= 8192 and k > 128 (ORAMA_F16_CHUNK_GROW = 0 / 1 forces it off / on,
-        // ORAMA_F16_GROW_FACTOR sets the factor, default 2).
+        // Super-chunks may GROW geometrically (ORAMA_F16_CHUNK_GROW=1; the next one (ORAMA_F16_GROW_FACTOR - 1) times
+        // everything scanned before it): the threshold tau_j only tightens between super-chunks, so growth keeps the share
+        // of passing rows near k / rows-so-far instead of the head's k / 131072, for the price of ~log(N / S1) more scan +
+        // select launches.  That paid while a passing row drained its wave's prefetch ring (64 queries with 228
+        // candidates each: 5.4 -> 3.2 ms of scan).  Since K2 and K2d stage passing rows in LDS and append them in bulk it
+        // costs more than it saves at every batch size measured (two-stage: 100 queries 4.87 -> 3.88 ms without growth,
+        // 128: 4.41 -> 3.94, 200: 6.10 -> 5.67, 64: 3.35 -> 2.97) and is OFF by default.
         static const int grow_env = [] {
             const char* e = std::getenv("ORAMA_F16_CHUNK_GROW");
             return e ? std::atoi(e) : -1;
@@ -646,7 +644,7 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
             const char* e = std::getenv("ORAMA_F16_GROW_FACTOR");
             return e ? (uint64_t)std::max(2, std::atoi(e)) : 2ull;
         }();
-        const bool grow = grow_env >= 0 ? grow_env != 0 : (wide && (uint64_t)gq * k >= 8192 && k > 128);
+        const bool grow = grow_env > 0;
         uint64_t this_chunk =
             grow ? std::min<uint64_t>(chunk_rows, (grow_factor - 1) * std::max<uint64_t>(s1 & ~255ull, 1u << 17)) : chunk_rows;
         for (uint64_t r0 = s1; r0 < n;) {
