@@ -142,7 +142,7 @@ def two_stage_leg(oa, ctx, plain, dim, n_local, k, qb, queries_h, lo, rank) -> d
             "batch64_queries_per_s": 5 * 64 / el64, "identical_to_fp32_scan": identical,
             "fallbacks": int(info["two_stage_fallbacks"]), "queries": int(info["two_stage_queries"]),
             "hbm_bytes": int(info["hbm_bytes"]),
-            "note": "fp32 rows + fp16 shadow (ORAMA_DTYPE_F32_SHADOW16): the fp16 scan proposes max(2k, k+128) candidates, "
+            "note": "fp32 rows + fp16 shadow (ORAMA_DTYPE_F32_SHADOW16): the fp16 scan proposes max(2k, k+256) candidates, "
                     "K1's arithmetic on the fp32 rows decides; a query whose candidate list cannot be proven complete "
                     "falls back to the fp32 scan; results bit-identical to the plain store (DESIGN.md K1s)"}
 
