@@ -227,3 +227,44 @@ def test_filter_path_crowd_with_deletes_and_allow_bitmap(ctx):
         m = int(cnt[qi])
         util.assert_topk_sound(ids[qi, :m], dist[qi, :m], full, 50, TOL, f"crowd dead+filter q{qi}")
     st.close()
+
+
+_CHUNK_SCRIPT = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import oramacore_amd as oa
+ctx = oa.Context(0)
+n, d, k = 1_300_000, 64, 50
+st = oa.EmbeddingFieldStorage(ctx, dimensions=d, dtype=oa.DTYPE_F16, reserve_rows=n)
+st.fill_synthetic(n, seed=0xABCD)
+rng = np.random.default_rng(5)
+out = {}
+for nq in (3, 64, 70):
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ids, dist, cnt = st.storage_search(q, k)
+    h = hashlib.sha256()
+    h.update(ids.tobytes()); h.update(dist.tobytes()); h.update(cnt.tobytes())
+    out[str(nq)] = h.hexdigest()
+print(json.dumps(out))
+"""
+
+
+def test_super_chunks_and_growing_chunks_give_the_same_answer(tmp_path):
+    """The filter scan runs in super-chunks (candidate budget) that may grow geometrically; both are decided by
+    environment variables read once per process, so each variant runs in its own process: one chunk (default budget),
+    two chunks of >= 1 M rows (1 MiB budget), and growing chunks (131 072, 262 144, ... rows) — for K2 (3 and 64
+    queries) and the wide kernel (70).  Ids, distance bits and counts must be identical."""
+    import json, os, subprocess, sys
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parent.parent)
+    script = tmp_path / "chunks.py"
+    script.write_text(_CHUNK_SCRIPT)
+    outs = []
+    for extra in ({}, {"ORAMA_F16_CAND_MIB": "1"}, {"ORAMA_F16_CAND_MIB": "1", "ORAMA_F16_CHUNK_GROW": "1"}):
+        env = dict(os.environ)
+        env.update(extra)
+        r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1] == outs[2], outs
