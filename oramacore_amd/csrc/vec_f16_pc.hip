@@ -83,8 +83,12 @@ struct PcCfg {
     static constexpr int kQOff = kDeadOff + kDeadBytes;     // 1/|q| (or |q|^2) and the threshold of every query column
     static constexpr int kQBytes = 2 * 256 * 4;
     // per consumer wave: a 64-bin histogram and kStageCap staged rows (distance, row: 4 bytes each; column: 1 byte)
-    static constexpr int kStageCap = 96;
     static constexpr int kStageOff = kQOff + kQBytes;
+    // what LDS is left after the ring, per consumer wave: 256 bytes of histogram + 9 bytes per staged row, in steps of
+    // 32 rows, 96 (64 to take + a flush threshold of 32) .. 1024
+    static constexpr int kStageFit = ((160 * 1024 - kStageOff) / NC - 256) / 9 / 32 * 32;
+    static constexpr int kStageCap = kStageFit > 1024 ? 1024 : kStageFit;
+    static_assert(kStageCap >= 96, "no room for the staging area");
     static constexpr int kWaveStage = 256 + kStageCap * 9 + (16 - (kStageCap * 9) % 16) % 16;
     static constexpr int kLdsBytes = kStageOff + NC * kWaveStage;
     static_assert(kQTiles * 32 <= 256, "query metadata is two 1-KiB arrays");
@@ -502,7 +506,8 @@ int pc_launch(orama_ctx* ctx, const F16ScanArgs& a, const char* bfrag, const flo
 //   1: 12 consumers of 2 x 2 tiles (fragment prefetch) + 4 loaders = 16 waves (<= 128 VGPRs), block tile 192 rows x
 //      256 queries, stages of 2 k-steps (28 KiB), ring of 5                                 — the default
 //   2: 8 consumers of 3 x 2 tiles (fragment prefetch) + 4 loaders = 12 waves (<= 168 VGPRs), block tile 192 x 256
-// Tried and dropped (profiles/r02_k2d_geometries.md): 8 consumers of 2 x 4 tiles at <= 168 VGPRs (the allocator
+// Tried and dropped (profiles/r02_k2d_geometries.md): PcB with a ring of 4 and 384 staged rows per wave instead of 96
+// (no difference: 4.55 vs 4.52 ms), 8 consumers of 2 x 4 tiles at <= 168 VGPRs (the allocator
 // spills accumulators inside the K loop: 12.2 ms), 4 consumers of 2 x 4 tiles + 4 loaders (128 x 256 block tile,
 // twice the query-fragment traffic: 6.4 ms), 3 x 2 tiles without fragment prefetch (6.2 ms).
 using PcB = PcCfg<2, 2, 3, 4, 4, 2, 5, 1>;
