@@ -32,7 +32,8 @@
  *     < 2^32 - 1 postings (row / local-document indices are 32-bit on the device; DocumentIds are
  *     64-bit everywhere).  Vector dimensions <= 65536.
  *   - fp16 query batches: any q; 65..256 queries share one corpus pass, larger batches run in
- *     passes of 256.
+ *     passes of 256.  Up to 64 queries run as one pass of the LDS-resident form while their fragments fit
+ *     (dimensions <= 1024), as passes of 32 above that (dimensions <= 2048 for fp16 storage).
  */
 #ifndef ORAMA_HIP_H
 #define ORAMA_HIP_H

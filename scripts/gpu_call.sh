@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/meas
-for w in 2 4 2 4; do
-  echo "== ORAMA_F16_WIDE=$w"; ORAMA_F16_WIDE=$w QB=256 timeout 300 python scripts/two_stage_breakdown.py 2>&1 | tail -1
-  ORAMA_F16_WIDE=$w timeout 200 python bench.py --workload c5 --rows 10000000 --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c5 shard', round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['frac'],3))"
-done | tee gpurun_out/meas/pcb4.log
+mkdir -p gpurun_out/final
+( time timeout 1500 python -m pytest tests/ -q -m gpu -p no:cacheprovider -x ) 2>&1 | tail -8 | tee gpurun_out/final/pytest_gpu.log
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee -a gpurun_out/final/pytest_gpu.log
+timeout 300 python bench.py 2>&1 | tail -1 > gpurun_out/final/bench_default.json; python -c "
+import json; d=json.loads(open('gpurun_out/final/bench_default.json').read()); print('bench', round(d['value'],1), d['ms_per_step'], round(d['roofline']['frac'],4), d['two_stage_exact']['value'], d['cpu_baseline']['value'])"
