@@ -1,7 +1,11 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/final
-( time timeout 1500 python -m pytest tests/ -q -m gpu -p no:cacheprovider -x ) 2>&1 | tail -8 | tee gpurun_out/final/pytest_gpu.log
-timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee -a gpurun_out/final/pytest_gpu.log
-timeout 300 python bench.py 2>&1 | tail -1 > gpurun_out/final/bench_default.json; python -c "
-import json; d=json.loads(open('gpurun_out/final/bench_default.json').read()); print('bench', round(d['value'],1), d['ms_per_step'], round(d['roofline']['frac'],4), d['two_stage_exact']['value'], d['cpu_baseline']['value'])"
+R=$PWD; O=$R/gpurun_out/meas; mkdir -p $O
+export LD_LIBRARY_PATH=$PWD/oramacore_amd/csrc
+echo "== serving bm25"; timeout 300 scripts/native/bench_serving bm25 10000000 1500 32,128,512 2>&1 | tee $O/serving_bm25.log | tail -8
+cd /tmp; export TMPDIR=/tmp
+QB=1 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_ts1 -o ts -- python $R/scripts/two_stage_breakdown.py > $O/rocprof_ts1.log 2>&1; echo rc=$?
+cd $R
+python scripts/rocpd_summary.py $(find $O/prof_ts1 -name "*results.db" | head -1) > $O/ts1_kernel_stats.md 2>$O/ts1.err
+find $O -name "*.db" -delete
+head -12 $O/ts1_kernel_stats.md | cut -c1-180
