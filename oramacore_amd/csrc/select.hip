@@ -608,9 +608,9 @@ __global__ __launch_bounds__(kSortThreads) void pairs_reduce_kernel(const float*
     const uint32_t qi = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const uint32_t n = n_dev ? min(n_max, n_dev[qi]) : n_max;
-    const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
-    uint32_t pos = min(n, blockIdx.x * per);
-    const uint32_t end = min(n, pos + per);
+    const uint64_t per = ((uint64_t)n + gridDim.x - 1) / gridDim.x;  // (64-bit: n may be close to 2^32)
+    uint32_t pos = (uint32_t)min((uint64_t)n, blockIdx.x * per);
+    const uint32_t end = (uint32_t)min((uint64_t)n, (uint64_t)pos + per);
     const float* v = vals + (uint64_t)qi * stride;
     const uint32_t* ix = idx ? idx + (uint64_t)qi * stride : nullptr;
     unsigned long long* o = out + ((uint64_t)qi * gridDim.x + blockIdx.x) * k;
