@@ -11,7 +11,8 @@ t0 = rows[0][1]
 prev_end = rows[0][1]
 busy = 0
 for name, start, end in rows:
-    short = name.split("(")[0].split("::")[-1][:40]
+    short = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("orama::", "")
+    short = short.split("<")[0].split("(")[0][:40]
     print(f"{(start - t0) / 1e3:10.1f} us  +{(end - start) / 1e3:8.1f} us  gap {max(0, start - prev_end) / 1e3:7.1f} us  {short}")
     busy += end - start
     prev_end = max(prev_end, end)
