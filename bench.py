@@ -150,19 +150,23 @@ def two_stage_leg(oa, ctx, plain, dim, n_local, k, qb, queries_h, lo, rank) -> d
 def main():
     args = parse_args()
     import oramacore_amd as oa
-    from oramacore_amd.launch import RankEnv, ShardPlan, exchange_unique_id
+    from oramacore_amd.launch import RankEnv, ShardPlan, device_for, exchange_unique_id, self_launch
     from oramacore_amd.shard_group import FORCE_RCCL, ShardGroup
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher — N ranks of this script, one per GPU (the same process
+        # model as under torch.distributed.run; rank 0 prints the JSON line)
+        raise SystemExit(self_launch(args.gpus, [str(Path(__file__).resolve()), *sys.argv[1:]]))
     env = RankEnv.from_env()
     world, rank, local_rank = env.world, env.rank, env.local_rank
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # The exchange (RCCL all-gather of the per-shard candidates + K6) runs inside liborama_hip.so: one process per
     # GPU, rank 0 makes the communicator id and hands it to the others over a localhost socket.  No torch here.
     if world > 1:
         uid = exchange_unique_id(env, ShardGroup.unique_id)
-        group = ShardGroup.from_rank(uid, rank, world, local_rank)
+        group = ShardGroup.from_rank(uid, rank, world, device_for(local_rank))
     else:
         group = ShardGroup([local_rank], flags=FORCE_RCCL if args.force_exchange else 0)
     ctx = group.ctx(0)

@@ -80,6 +80,9 @@ int orama_abi_version(void);
 const char* orama_last_error(void);
 
 /* ------------------------------------------------------------------ context */
+/* GPUs visible to this process (what a shim sizes its shard group with; the reference has no counterpart — its
+ * ReadSide is one CPU process, src/collection_manager/sides/read/mod.rs:621-738). */
+int orama_device_count(int* out);
 int orama_ctx_create(int device_ordinal, orama_ctx** out);
 void orama_ctx_destroy(orama_ctx* ctx);
 int orama_ctx_synchronize(orama_ctx* ctx);

@@ -218,6 +218,7 @@ def _declare(lib: C.CDLL) -> None:
                              u64p],
         "orama_top_n": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u32p],
     }
+    sig["orama_device_count"] = [C.POINTER(C.c_int)]
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

@@ -58,6 +58,34 @@ void clear_error();
         }                                   \
     } while (0)
 
+// ---------------------------------------------------------------- current device
+// The HIP "current device" is per-thread state that belongs to the CALLER (a Rust host may run its own HIP code on the
+// same thread): every entry point selects its context's device for the duration of the call and puts the caller's
+// device back when it returns.
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    DeviceScope() {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    }
+    explicit DeviceScope(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device);
+        else prev = -1;  // nothing to put back
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+    ~DeviceScope() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define ORAMA_CAT2_(a, b) a##b
+#define ORAMA_CAT_(a, b) ORAMA_CAT2_(a, b)
+// select `device` until the end of the enclosing scope (fails the call like ORAMA_HIP_TRY)
+#define ORAMA_ON_DEVICE(device)                                        \
+    ::orama::DeviceScope ORAMA_CAT_(dev_scope__, __LINE__)(device);    \
+    ORAMA_HIP_TRY(ORAMA_CAT_(dev_scope__, __LINE__).err)
+
 // ---------------------------------------------------------------- device / pinned buffers
 struct DevBuf {
     void* p = nullptr;

@@ -170,7 +170,7 @@ void orama_ctx::release(std::unique_ptr<orama::Scratch> s) {
     size_t pooled = 0;
     for (const auto& q : pool) pooled += scratch_bytes(*q);
     if (pooled + scratch_bytes(*s) > scratch_pool_budget()) {
-        (void)hipSetDevice(device);
+        ::orama::DeviceScope ORAMA_CAT_(dev_scope__, __LINE__)(device);
         if (s->stream) (void)hipStreamSynchronize(s->stream);
         for (orama::DevBuf* d : {&s->dist, &s->sel_keys, &s->out_ids, &s->bitmap, &s->misc0, &s->misc1, &s->misc2, &s->misc3,
                                  &s->misc4, &s->misc5, &s->bm25_acc, &s->bm25_emit})
@@ -229,7 +229,7 @@ int orama_allow_create(orama_ctx* ctx, const uint64_t* words, uint64_t bitmap_bi
     ORAMA_REQUIRE(ctx && out, "null argument");
     *out = nullptr;
     ORAMA_REQUIRE(bitmap_bits == 0 || words, "null words");
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     std::unique_ptr<orama_allow> a(new (std::nothrow) orama_allow());
     if (!a) {
         orama::set_error("out of host memory");
@@ -250,7 +250,7 @@ int orama_allow_create(orama_ctx* ctx, const uint64_t* words, uint64_t bitmap_bi
 
 void orama_allow_destroy(orama_allow* a) {
     if (!a) return;
-    (void)hipSetDevice(a->ctx->device);
+    ::orama::DeviceScope ORAMA_CAT_(dev_scope__, __LINE__)(a->ctx->device);
     (void)hipDeviceSynchronize();  // searches still reading the bitmap
     {
         std::lock_guard<std::mutex> g(a->ctx->allow_mu);
@@ -266,7 +266,7 @@ const uint64_t* orama_allow_token(const orama_allow* a) {
 int orama_allow_set(orama_allow* a, const uint64_t* doc_ids, uint64_t n, int allowed) {
     ORAMA_REQUIRE(a && (n == 0 || doc_ids), "null argument");
     if (n == 0) return ORAMA_OK;
-    ORAMA_HIP_TRY(hipSetDevice(a->ctx->device));
+    ORAMA_ON_DEVICE(a->ctx->device);
     for (uint64_t i = 0; i < n; ++i)
         ORAMA_REQUIRE(doc_ids[i] < a->bits, "doc id %llu outside the bitmap (%llu bits)",
                       (unsigned long long)doc_ids[i], (unsigned long long)a->bits);
@@ -291,6 +291,20 @@ int orama_abi_version(void) { return ORAMA_ABI_VERSION; }
 
 const char* orama_last_error(void) { return orama::g_err; }
 
+int orama_device_count(int* out) {
+    ORAMA_REQUIRE(out != nullptr, "orama_device_count: out is NULL");
+    *out = 0;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        orama::set_error("no HIP device available (%s) — liborama_hip has no CPU fallback",
+                         e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return ORAMA_ERR_HIP;
+    }
+    *out = count;
+    return ORAMA_OK;
+}
+
 int orama_ctx_create(int device_ordinal, orama_ctx** out) {
     ORAMA_REQUIRE(out != nullptr, "orama_ctx_create: out is NULL");
     *out = nullptr;
@@ -303,7 +317,7 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
     }
     ORAMA_REQUIRE(device_ordinal >= 0 && device_ordinal < count, "device %d out of range [0,%d)",
                   device_ordinal, count);
-    ORAMA_HIP_TRY(hipSetDevice(device_ordinal));
+    ORAMA_ON_DEVICE(device_ordinal);
     hipDeviceProp_t prop;
     ORAMA_HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
     orama_ctx* c = new (std::nothrow) orama_ctx();
@@ -332,14 +346,14 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
 
 void orama_ctx_destroy(orama_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    ::orama::DeviceScope ORAMA_CAT_(dev_scope__, __LINE__)(ctx->device);
     (void)hipDeviceSynchronize();
     delete ctx;
 }
 
 int orama_ctx_synchronize(orama_ctx* ctx) {
     ORAMA_REQUIRE(ctx, "null ctx");
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     ORAMA_HIP_TRY(hipDeviceSynchronize());
     return ORAMA_OK;
 }
@@ -379,21 +393,21 @@ int orama_ctx_set_f16_tuning(orama_ctx* ctx, int ksteps_per_chunk, int ring_chun
 int orama_dev_malloc(orama_ctx* ctx, uint64_t bytes, void** out) {
     ORAMA_REQUIRE(ctx && out, "null argument");
     *out = nullptr;
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     ORAMA_HIP_TRY(hipMalloc(out, bytes ? (size_t)bytes : 8));
     return ORAMA_OK;
 }
 
 void orama_dev_free(orama_ctx* ctx, void* d_ptr) {
     if (!ctx || !d_ptr) return;
-    (void)hipSetDevice(ctx->device);
+    ::orama::DeviceScope ORAMA_CAT_(dev_scope__, __LINE__)(ctx->device);
     (void)hipFree(d_ptr);
 }
 
 int orama_dev_upload(orama_ctx* ctx, void* d_dst, uint64_t offset, const void* src, uint64_t bytes) {
     ORAMA_REQUIRE(ctx && (bytes == 0 || (d_dst && src)), "null argument");
     if (bytes == 0) return ORAMA_OK;
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     ORAMA_HIP_TRY(hipMemcpy(static_cast<char*>(d_dst) + offset, src, (size_t)bytes, hipMemcpyHostToDevice));
     return ORAMA_OK;
 }
@@ -401,7 +415,7 @@ int orama_dev_upload(orama_ctx* ctx, void* d_dst, uint64_t offset, const void* s
 int orama_dev_download(orama_ctx* ctx, const void* d_src, uint64_t offset, void* dst, uint64_t bytes) {
     ORAMA_REQUIRE(ctx && (bytes == 0 || (d_src && dst)), "null argument");
     if (bytes == 0) return ORAMA_OK;
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     ORAMA_HIP_TRY(hipMemcpy(dst, static_cast<const char*>(d_src) + offset, (size_t)bytes, hipMemcpyDeviceToHost));
     return ORAMA_OK;
 }
@@ -409,7 +423,7 @@ int orama_dev_download(orama_ctx* ctx, const void* d_src, uint64_t offset, void*
 int orama_stream_create(orama_ctx* ctx, int high_priority, void** out_stream) {
     ORAMA_REQUIRE(ctx && out_stream, "null argument");
     *out_stream = nullptr;
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     int lo = 0, hi = 0;  // numerically lower = higher priority
     ORAMA_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
     hipStream_t s = nullptr;
@@ -420,13 +434,13 @@ int orama_stream_create(orama_ctx* ctx, int high_priority, void** out_stream) {
 
 void orama_stream_destroy(orama_ctx* ctx, void* stream) {
     if (!ctx || !stream) return;
-    (void)hipSetDevice(ctx->device);
+    ::orama::DeviceScope ORAMA_CAT_(dev_scope__, __LINE__)(ctx->device);
     (void)hipStreamDestroy(static_cast<hipStream_t>(stream));
 }
 
 int orama_stream_synchronize(orama_ctx* ctx, void* stream) {
     ORAMA_REQUIRE(ctx, "null ctx");
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     ORAMA_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return ORAMA_OK;
 }
@@ -461,14 +475,14 @@ int orama_prof_enable(orama_ctx* ctx, int on) {
 
 int orama_prof_reset(orama_ctx* ctx) {
     ORAMA_REQUIRE(ctx, "null ctx");
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     ctx->prof.reset();
     return ORAMA_OK;
 }
 
 int orama_prof_get(orama_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches) {
     ORAMA_REQUIRE(ctx && kernel, "null argument");
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     ctx->prof.resolve();
     std::lock_guard<std::mutex> g(ctx->prof.mu);
     auto it = ctx->prof.acc.find(kernel);

@@ -100,7 +100,7 @@ int orama_dict_create(orama_ctx* ctx, const uint8_t* blob, const uint32_t* offse
             ORAMA_REQUIRE(c < 0 || (c == 0 && la < lb), "terms must be strictly ascending (term %u)", i);
         }
     }
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     std::unique_ptr<orama_dict> d(new (std::nothrow) orama_dict());
     if (!d) {
         set_error("out of host memory");
@@ -119,7 +119,7 @@ int orama_dict_create(orama_ctx* ctx, const uint8_t* blob, const uint32_t* offse
 
 void orama_dict_destroy(orama_dict* d) {
     if (!d) return;
-    (void)hipSetDevice(d->ctx->device);
+    ::orama::DeviceScope ORAMA_CAT_(dev_scope__, __LINE__)(d->ctx->device);
     (void)hipDeviceSynchronize();
     delete d;
 }
@@ -131,7 +131,7 @@ int orama_dict_expand(orama_dict* d, const uint8_t* token, uint32_t token_len, i
     ORAMA_REQUIRE(capacity == 0 || out_terms, "null output");
     ORAMA_REQUIRE(token_len <= kMaxToken, "token longer than %u bytes", kMaxToken);
     if (d->n_terms == 0) return ORAMA_OK;
-    ORAMA_HIP_TRY(hipSetDevice(d->ctx->device));
+    ORAMA_ON_DEVICE(d->ctx->device);
     ScratchLease sc(d->ctx);
     ORAMA_TRY(sc.init());
     hipStream_t s = sc->stream;

@@ -815,7 +815,7 @@ int post_search_impl(orama_post* p, const orama_term_ref* refs, uint32_t n_refs,
     if (out_count) *out_count = 0;
     ORAMA_REQUIRE(params->top_k == 0 || (out_ids && out_scores), "null output");
     ORAMA_REQUIRE(!hybrid || n_vec == 0 || (vec_doc && vec_score), "null vector map");
-    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    ORAMA_ON_DEVICE(p->ctx->device);
     std::shared_lock<std::shared_mutex> lk(p->mu);
     const bool eligible = ranges_eligible(p, refs, n_refs, params);
     const bool by_ranges = !hybrid && eligible;
@@ -872,7 +872,7 @@ int orama_post_create(orama_ctx* ctx, orama_post** out) {
 
 void orama_post_destroy(orama_post* p) {
     if (!p) return;
-    (void)hipSetDevice(p->ctx->device);
+    ::orama::DeviceScope ORAMA_CAT_(dev_scope__, __LINE__)(p->ctx->device);
     (void)hipDeviceSynchronize();
     delete p;
 }
@@ -890,7 +890,7 @@ int orama_post_build(orama_post* p, const uint64_t* docs, uint64_t n_docs, uint3
         ORAMA_REQUIRE(docs[i - 1] < docs[i], "docs must be strictly ascending (position %llu)", (unsigned long long)i);
     const uint64_t n_post = n_lists ? list_off[n_lists] : 0;
     ORAMA_REQUIRE(n_post == 0 || (post_doc && post_tf && post_len), "null postings");
-    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    ORAMA_ON_DEVICE(p->ctx->device);
     std::unique_lock<std::shared_mutex> lk(p->mu);
     const bool dense = n_docs > 0 && docs[n_docs - 1] - docs[0] == n_docs - 1;
     std::vector<uint32_t> pd((size_t)n_post), pv((size_t)n_post);
@@ -959,7 +959,7 @@ int orama_post_append(orama_post* p, const uint64_t* docs, uint64_t n_new, const
     ORAMA_REQUIRE(n_lists_new == 0 || (field_of_list && list_off), "null list table");
     ORAMA_REQUIRE(p->n_fields > 0, "orama_post_append needs a built store (orama_post_build first)");
     ORAMA_REQUIRE(avg_field_len, "null avg_field_len");
-    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    ORAMA_ON_DEVICE(p->ctx->device);
     std::unique_lock<std::shared_mutex> lk(p->mu);
     const uint64_t n_old = p->n_docs, n_all = n_old + n_new;
     ORAMA_SUPPORT(n_all < 0xffffffffull, "postings store limited to 2^32-1 documents");
@@ -1057,7 +1057,7 @@ int orama_post_fill_synthetic(orama_post* p, uint64_t n_docs, uint64_t first_doc
     ORAMA_REQUIRE(p, "null handle");
     ORAMA_REQUIRE(n_docs >= 1 && n_docs < 0xffffffffull, "n_docs out of range");
     ORAMA_REQUIRE(n_lists >= 1 && ranks, "null ranks");
-    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    ORAMA_ON_DEVICE(p->ctx->device);
     std::unique_lock<std::shared_mutex> lk(p->mu);
     ScratchLease sc(p->ctx);
     ORAMA_TRY(sc.init());
@@ -1119,7 +1119,7 @@ int orama_post_fill_synthetic(orama_post* p, uint64_t n_docs, uint64_t first_doc
 int orama_post_get_list(orama_post* p, uint32_t list, uint64_t capacity, uint64_t* out_doc, uint32_t* out_tf,
                         uint32_t* out_len, uint64_t* out_n) {
     ORAMA_REQUIRE(p && out_n, "null argument");
-    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    ORAMA_ON_DEVICE(p->ctx->device);
     std::shared_lock<std::shared_mutex> lk(p->mu);
     ORAMA_REQUIRE(list < p->n_lists, "list %u out of range", list);
     const uint64_t b = p->list_off[list], n = p->list_off[list + 1] - b;
@@ -1151,7 +1151,7 @@ int orama_post_info(orama_post* p, uint64_t* n_docs, uint32_t* n_lists, uint64_t
 int orama_post_set_omc(orama_post* p, const uint64_t* omc_doc, const float* omc_mul, uint64_t n) {
     ORAMA_REQUIRE(p, "null handle");
     ORAMA_REQUIRE(n == 0 || (omc_doc && omc_mul), "null argument");
-    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    ORAMA_ON_DEVICE(p->ctx->device);
     std::unique_lock<std::shared_mutex> lk(p->mu);
     if (n == 0) {
         p->has_omc = false;
@@ -1214,7 +1214,7 @@ int orama_post_search_batch(orama_post* p, const orama_post_query_desc* queries,
                                         out_ids ? out_ids + (size_t)i * stride_k : nullptr,
                                         out_scores ? out_scores + (size_t)i * stride_k : nullptr, &out_n[i], &counts[j]});
             }
-            ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+            ORAMA_ON_DEVICE(p->ctx->device);
             std::shared_lock<std::shared_mutex> lk(p->mu);
             ScratchLease sc(p->ctx);
             ORAMA_TRY(sc.init());
@@ -1329,7 +1329,7 @@ int orama_post_search_scores(orama_post* p, const orama_term_ref* refs, uint32_t
     if (out_count) *out_count = 0;
     ORAMA_REQUIRE(params->top_k == 0 || (out_ids && out_scores), "null output");
     ORAMA_REQUIRE(!hybrid || n_vec == 0 || (vec_doc && vec_score), "null vector map");
-    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    ORAMA_ON_DEVICE(p->ctx->device);
     std::unique_ptr<orama_scores> h(new (std::nothrow) orama_scores(p));
     if (!h) {
         set_error("out of host memory");
@@ -1351,7 +1351,7 @@ int orama_post_search_scores(orama_post* p, const orama_term_ref* refs, uint32_t
 
 void orama_scores_destroy(orama_scores* sm) {
     if (!sm) return;
-    (void)hipSetDevice(sm->p->ctx->device);
+    ::orama::DeviceScope ORAMA_CAT_(dev_scope__, __LINE__)(sm->p->ctx->device);
     if (sm->lease.s) (void)hipStreamSynchronize(sm->lease.s->stream);
     delete sm;
 }
@@ -1368,7 +1368,7 @@ int orama_scores_export(orama_scores* sm, uint64_t capacity, uint64_t* out_ids, 
     if (capacity == 0 || sm->count == 0) return ORAMA_OK;
     ORAMA_REQUIRE(capacity >= sm->count && out_ids && out_scores, "capacity %llu < map size %llu",
                   (unsigned long long)capacity, (unsigned long long)sm->count);
-    ORAMA_HIP_TRY(hipSetDevice(sm->p->ctx->device));
+    ORAMA_ON_DEVICE(sm->p->ctx->device);
     std::lock_guard<std::mutex> g(sm->mu);
     hipStream_t s = sm->lease.s->stream;
     ORAMA_TRY(sm->tmp_a.reserve((size_t)sm->count * 8));
@@ -1385,7 +1385,7 @@ int orama_scores_export(orama_scores* sm, uint64_t capacity, uint64_t* out_ids, 
 int orama_scores_lookup(orama_scores* sm, const uint64_t* doc_ids, uint32_t n, float* out_scores, uint8_t* out_present) {
     ORAMA_REQUIRE(sm && (n == 0 || (doc_ids && out_scores && out_present)), "null argument");
     if (n == 0) return ORAMA_OK;
-    ORAMA_HIP_TRY(hipSetDevice(sm->p->ctx->device));
+    ORAMA_ON_DEVICE(sm->p->ctx->device);
     std::lock_guard<std::mutex> g(sm->mu);
     hipStream_t s = sm->lease.s->stream;
     std::vector<uint32_t> local(n);
@@ -1410,7 +1410,7 @@ int orama_facet_field_create_buckets(orama_post* index, const uint64_t* bucket_o
     ORAMA_REQUIRE(n == 0 || bucket_docs, "null bucket docs");
     for (uint32_t b = 0; b < n_buckets; ++b)
         ORAMA_REQUIRE(bucket_off[b] <= bucket_off[b + 1], "bucket offsets must be non-decreasing");
-    ORAMA_HIP_TRY(hipSetDevice(index->ctx->device));
+    ORAMA_ON_DEVICE(index->ctx->device);
     std::shared_lock<std::shared_mutex> lk(index->mu);
     std::unique_ptr<orama_facet_field> f(new (std::nothrow) orama_facet_field());
     if (!f) {
@@ -1440,7 +1440,7 @@ int orama_facet_field_create_numbers(orama_post* index, const uint64_t* docs, co
                                      orama_facet_field** out) {
     ORAMA_REQUIRE(index && out && (n == 0 || (docs && values)), "null argument");
     *out = nullptr;
-    ORAMA_HIP_TRY(hipSetDevice(index->ctx->device));
+    ORAMA_ON_DEVICE(index->ctx->device);
     std::shared_lock<std::shared_mutex> lk(index->mu);
     std::unique_ptr<orama_facet_field> f(new (std::nothrow) orama_facet_field());
     if (!f) {
@@ -1467,7 +1467,7 @@ int orama_facet_field_create_numbers(orama_post* index, const uint64_t* docs, co
 
 void orama_facet_field_destroy(orama_facet_field* f) {
     if (!f) return;
-    (void)hipSetDevice(f->device);
+    ::orama::DeviceScope ORAMA_CAT_(dev_scope__, __LINE__)(f->device);
     (void)hipDeviceSynchronize();
     delete f;
 }
@@ -1476,7 +1476,7 @@ int orama_facet_count(orama_scores* sm, orama_facet_field* f, uint64_t* out_coun
     ORAMA_TRY(check_field(sm, f, false));
     if (f->n_buckets == 0) return ORAMA_OK;
     ORAMA_REQUIRE(out_counts, "null output");
-    ORAMA_HIP_TRY(hipSetDevice(sm->p->ctx->device));
+    ORAMA_ON_DEVICE(sm->p->ctx->device);
     std::lock_guard<std::mutex> g(sm->mu);
     hipStream_t s = sm->lease.s->stream;
     ORAMA_TRY(sm->tmp_a.reserve((size_t)f->n_buckets * 8));
@@ -1492,7 +1492,7 @@ int orama_facet_count_ranges(orama_scores* sm, orama_facet_field* f, const doubl
     ORAMA_TRY(check_field(sm, f, true));
     if (n_ranges == 0) return ORAMA_OK;
     ORAMA_REQUIRE(from && to && out_counts, "null argument");
-    ORAMA_HIP_TRY(hipSetDevice(sm->p->ctx->device));
+    ORAMA_ON_DEVICE(sm->p->ctx->device);
     std::lock_guard<std::mutex> g(sm->mu);
     hipStream_t s = sm->lease.s->stream;
     // ranges in chunks of 64 (the kernel keeps them in LDS)
@@ -1518,7 +1518,7 @@ int orama_group_top(orama_scores* sm, orama_facet_field* f, uint32_t max_results
     ORAMA_REQUIRE(out_ids && out_scores && out_n, "null output");
     ORAMA_REQUIRE(max_results >= 1, "max_results is 0");
     ORAMA_SUPPORT(max_results <= kGroupMaxK, "max_results %u outside [1, %u]", max_results, kGroupMaxK);
-    ORAMA_HIP_TRY(hipSetDevice(sm->p->ctx->device));
+    ORAMA_ON_DEVICE(sm->p->ctx->device);
     std::lock_guard<std::mutex> g(sm->mu);
     hipStream_t s = sm->lease.s->stream;
     const size_t nk = (size_t)f->n_buckets * max_results;
@@ -1561,7 +1561,7 @@ int orama_post_query_begin(orama_post* p, const orama_term_ref* refs, uint32_t n
     ORAMA_REQUIRE(p && params && d_df && out, "null argument");
     *out = nullptr;
     ORAMA_REQUIRE(params->top_k >= 1, "staged query: top_k must be >= 1");
-    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    ORAMA_ON_DEVICE(p->ctx->device);
     std::unique_ptr<orama_post_query> q(new (std::nothrow) orama_post_query(p));
     if (!q) {
         set_error("out of host memory");
@@ -1585,7 +1585,7 @@ int orama_post_query_score(orama_post_query* q, const uint32_t* df_global, int64
     ORAMA_REQUIRE(q->stage == 1, "staged query: score called out of order");
     ORAMA_REQUIRE(!q->st.hybrid || d_minmax, "staged query: hybrid needs the min/max exchange buffer");
     orama_post* p = q->p;
-    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    ORAMA_ON_DEVICE(p->ctx->device);
     Scratch* sc = q->lease.s.get();
     hipStream_t s = sc->stream;
     // idf by the host libm from the GLOBAL df and N (calculate_idf, bm25.rs:78-82; df.max(1), token_score.rs:275)
@@ -1607,7 +1607,7 @@ int orama_post_query_finish(orama_post_query* q, const int64_t* d_minmax_global,
     ORAMA_REQUIRE(q && d_block, "null argument");
     ORAMA_REQUIRE(q->stage == 2, "staged query: finish called out of order");
     orama_post* p = q->p;
-    ORAMA_HIP_TRY(hipSetDevice(p->ctx->device));
+    ORAMA_ON_DEVICE(p->ctx->device);
     Scratch* sc = q->lease.s.get();
     hipStream_t s = sc->stream;
     if (q->st.hybrid) {
@@ -1639,7 +1639,7 @@ int orama_post_merge_blocks_device(orama_ctx* ctx, const void* d_blocks, uint32_
                                    uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_n,
                                    uint64_t* d_out_count, void* hip_stream) {
     ORAMA_REQUIRE(ctx && d_blocks && d_out_ids && d_out_scores && d_out_n && d_out_count, "null argument");
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const uint64_t stride = orama_post_block_bytes(top_k);
     ORAMA_TRY(launch_merge_blocks(ctx, d_blocks, stride, lists, 1, top_k, true, d_out_ids, d_out_scores, d_out_n, s));
@@ -1669,7 +1669,7 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
     ORAMA_SUPPORT(limit <= kSelectMaxK, "limit %u exceeds the supported maximum %u", limit, kSelectMaxK);
     orama_ctx* ctx = p->ctx;
     ORAMA_REQUIRE(vec_ctx(v) == ctx, "vector store and postings store live on different contexts");
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     VecSharedLock vlk(v);
     std::shared_lock<std::shared_mutex> lk(p->mu);
     // a store with an fp16 shadow answers the vector leg with the two-stage plan (same answer, half the bytes scanned):
@@ -1763,7 +1763,7 @@ static int bm25_score_impl(orama_ctx* ctx, const orama_ntf_entry* entries, uint3
     const orama_bm25_params* params = &params_copy;
     ORAMA_REQUIRE(n_entries == 0 || entries, "null entries");
     ORAMA_REQUIRE(params->top_k == 0 || (out_ids && out_scores), "null output");
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     // The reference scorer accepts the same (doc, ntf) key several times for one token — add_field pushes onto a
     // Vec per key (bm25.rs:355-366) and finalize sums them in push order — so a per_doc_ntf list may repeat a doc
     // (a prefix / fuzzy expansion inside the third-party store could emit one pair per matched term).  The
@@ -2023,7 +2023,7 @@ int orama_hybrid_combine(orama_ctx* ctx, const uint64_t* vec_doc, const float* v
     ORAMA_REQUIRE(top_k == 0 || (out_ids && out_scores), "null output");
     ORAMA_SUPPORT(n_vec + n_ft < 0xffffffffull, "maps too large");
     if (n_vec + n_ft == 0) return ORAMA_OK;
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     // local doc space = sorted union of both key sets
     std::vector<uint64_t> docs;
     docs.reserve((size_t)(n_vec + n_ft));
@@ -2089,7 +2089,7 @@ int orama_top_n(orama_ctx* ctx, const uint64_t* doc, const float* score, uint64_
     ORAMA_REQUIRE(doc && score && out_ids && out_scores, "null argument");
     ORAMA_SUPPORT(top_k <= kSelectMaxK, "top_k %u exceeds the supported maximum %u", top_k, kSelectMaxK);
     ORAMA_SUPPORT(n < 0xffffffffull, "top_n limited to 2^32-1 entries");
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     ScratchLease sc(ctx);
     ORAMA_TRY(sc.init());
     hipStream_t s = sc->stream;

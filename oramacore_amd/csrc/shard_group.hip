@@ -63,9 +63,19 @@ int load_rccl(Rccl** out) {
     static std::mutex mu;
     std::lock_guard<std::mutex> g(mu);
     if (!r.h) {
+        // ORAMA_RCCL_LIB names another library with RCCL's C signatures (tests/mock_rccl: a shared-memory loopback that
+        // lets several ranks share the one GPU of a test box, which real RCCL refuses)
+        const char* override_lib = getenv("ORAMA_RCCL_LIB");
+        if (override_lib && *override_lib) {
+            r.h = dlopen(override_lib, RTLD_NOW | RTLD_LOCAL);
+            if (!r.h) {
+                set_error("ORAMA_RCCL_LIB=%s: %s", override_lib, dlerror());
+                return ORAMA_ERR_UNSUPPORTED;
+            }
+        }
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (r.h) break;
+            r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!r.h) {
             set_error("RCCL not found (dlopen librccl.so.1: %s) — multi-GPU groups need it", dlerror());
@@ -286,6 +296,7 @@ int orama_shard_unique_id(void* out_id128) {
 
 int orama_shard_group_create(const int* devices, uint32_t n_shards, uint32_t flags, orama_shard_group** out) {
     ORAMA_REQUIRE(devices && out && n_shards >= 1 && n_shards <= 64, "bad shard group arguments");
+    DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     *out = nullptr;
     bool all_same = true, all_distinct = true;
     for (uint32_t i = 0; i < n_shards; ++i)
@@ -294,7 +305,10 @@ int orama_shard_group_create(const int* devices, uint32_t n_shards, uint32_t fla
             else all_same = false;
         }
     ORAMA_REQUIRE(all_same || all_distinct, "shard devices must be all distinct (one shard per GPU) or all the same");
-    const bool colocated = all_same && !(n_shards == 1 && (flags & ORAMA_SHARD_FORCE_RCCL));
+    // several shards on one device normally use the device-local exchange; ORAMA_SHARD_FORCE_RCCL takes the
+    // communicator path anyway (one rank: real RCCL; several ranks on one device: only a loopback transport named by
+    // ORAMA_RCCL_LIB accepts that — real RCCL reports the duplicate device from ncclCommInitAll)
+    const bool colocated = all_same && !(flags & ORAMA_SHARD_FORCE_RCCL);
     std::unique_ptr<orama_shard_group> g(new (std::nothrow) orama_shard_group());
     if (!g) {
         set_error("out of host memory");
@@ -320,6 +334,7 @@ int orama_shard_group_create(const int* devices, uint32_t n_shards, uint32_t fla
 
 int orama_shard_group_create_rank(const void* id128, int rank, int world, int device, orama_shard_group** out) {
     ORAMA_REQUIRE(id128 && out && world >= 1 && rank >= 0 && rank < world, "bad shard group arguments");
+    DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     *out = nullptr;
     std::unique_ptr<orama_shard_group> g(new (std::nothrow) orama_shard_group());
     if (!g) {
@@ -343,6 +358,7 @@ int orama_shard_group_create_rank(const void* id128, int rank, int world, int de
 
 void orama_shard_group_destroy(orama_shard_group* g) {
     if (!g) return;
+    DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     for (auto& sp : g->local) {
         (void)hipSetDevice(sp->device);
         (void)hipDeviceSynchronize();
@@ -386,6 +402,7 @@ int orama_shard_group_info(orama_shard_group* g, uint32_t* world, uint32_t* n_lo
 // Barrier over every shard of the group: local devices drained, one word all-reduced, drained again.
 int orama_shard_group_barrier(orama_shard_group* g) {
     ORAMA_REQUIRE(g, "null group");
+    DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     std::lock_guard<std::mutex> lk(g->mu);
     for (auto& sp : g->local) {
         ORAMA_HIP_TRY(hipSetDevice(sp->device));
@@ -408,6 +425,7 @@ int orama_shard_group_barrier(orama_shard_group* g) {
 // max over all ranks of one host double (bench.py: the slowest rank's elapsed time)
 int orama_shard_group_allreduce_max_f64(orama_shard_group* g, double* inout) {
     ORAMA_REQUIRE(g && inout, "null argument");
+    DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     if (g->colocated || g->world == (int)n_local(g)) return ORAMA_OK;  // one process holds every shard
     std::lock_guard<std::mutex> lk(g->mu);
     ShardLocal& s = L(g, 0);
@@ -425,6 +443,7 @@ int orama_shard_vec_search(orama_shard_group* g, orama_vec* const* shards, const
                            const uint64_t* const* allow_bitmaps, uint64_t bitmap_bits, uint64_t* out_ids,
                            float* out_dist, uint32_t* out_n) {
     ORAMA_TRY(check_group_args(g, shards));
+    DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     ORAMA_REQUIRE(queries && q >= 1 && out_ids && out_dist && out_n, "null argument");
     for (uint32_t j = 0; j < q; ++j) out_n[j] = 0;
     if (k == 0) return ORAMA_OK;
@@ -484,6 +503,7 @@ int orama_shard_post_search(orama_shard_group* g, orama_post* const* shards, con
                             const float* vec_score, uint32_t n_vec, uint64_t* out_ids, float* out_scores,
                             uint32_t* out_n, uint64_t* out_count) {
     ORAMA_TRY(check_group_args(g, shards));
+    DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     ORAMA_REQUIRE(params && out_n, "null argument");
     *out_n = 0;
     if (out_count) *out_count = 0;
@@ -642,6 +662,10 @@ struct SessionLocal {
     hipStream_t scan = nullptr;
     std::vector<hipStream_t> tail;
     std::vector<DevBuf> gathered, out_ids, out_val, out_n, d_n;
+    // the session's own events (the group's are used by the one-call searches): per slot, "this shard's block is
+    // written" and — co-located groups, shard 0 only — "the merge of this slot has read the shared gathered buffer"
+    std::vector<hipEvent_t> ev_block, ev_merged;
+    std::vector<char> merged_recorded;
 };
 struct orama_shard_session {
     orama_shard_group* g = nullptr;
@@ -658,6 +682,7 @@ int orama_shard_session_create(orama_shard_group* g, orama_vec* const* shards, c
                                uint32_t q_per_step, uint32_t k, uint32_t n_slots, int force_exchange,
                                orama_shard_session** out) {
     ORAMA_TRY(check_group_args(g, shards));
+    DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     ORAMA_REQUIRE(queries && out && q_per_step >= 1 && n_queries >= q_per_step && k >= 1 && n_slots >= 1 && n_slots <= 8,
                   "bad session arguments");
     ORAMA_SUPPORT(k <= kSelectMaxK && (uint64_t)g->world * k <= kSelectMaxK, "limit %u x %d shards exceeds the merge capacity", k,
@@ -696,7 +721,12 @@ int orama_shard_session_create(orama_shard_group* g, orama_vec* const* shards, c
         sl.out_val = std::vector<DevBuf>(n_slots);
         sl.out_n = std::vector<DevBuf>(n_slots);
         sl.d_n = std::vector<DevBuf>(n_slots);
+        sl.ev_block.assign(n_slots, nullptr);
+        sl.ev_merged.assign(n_slots, nullptr);
+        sl.merged_recorded.assign(n_slots, 0);
         for (uint32_t t = 0; t < n_slots; ++t) {
+            ORAMA_HIP_TRY(hipEventCreateWithFlags(&sl.ev_block[t], hipEventDisableTiming));
+            ORAMA_HIP_TRY(hipEventCreateWithFlags(&sl.ev_merged[t], hipEventDisableTiming));
             ORAMA_HIP_TRY(hipStreamCreateWithPriority(&sl.tail[t], hipStreamNonBlocking, n_slots > 1 ? hi : lo));
             ORAMA_TRY(sl.gathered[t].reserve(s->nb * (size_t)g->world));
             ORAMA_TRY(sl.out_ids[t].reserve((size_t)q_per_step * k * 8));
@@ -711,12 +741,17 @@ int orama_shard_session_create(orama_shard_group* g, orama_vec* const* shards, c
 
 void orama_shard_session_destroy(orama_shard_session* s) {
     if (!s) return;
+    DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     for (uint32_t i = 0; i < s->local.size(); ++i) {
         (void)hipSetDevice(L(s->g, i).device);
         (void)hipDeviceSynchronize();
         if (s->local[i]->scan) (void)hipStreamDestroy(s->local[i]->scan);
         for (hipStream_t t : s->local[i]->tail)
             if (t) (void)hipStreamDestroy(t);
+        for (hipEvent_t e : s->local[i]->ev_block)
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : s->local[i]->ev_merged)
+            if (e) (void)hipEventDestroy(e);
     }
     delete s;
 }
@@ -724,7 +759,10 @@ void orama_shard_session_destroy(orama_shard_session* s) {
 // Enqueue step `step`: queries [step*q, (step+1)*q) (modulo the resident set) -> slot step % n_slots.
 int orama_shard_session_step(orama_shard_session* s, uint32_t step) {
     ORAMA_REQUIRE(s, "null session");
+    DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     orama_shard_group* g = s->g;
+    // collectives of a session step and of the one-call searches must not interleave differently on different ranks
+    std::lock_guard<std::mutex> lk(g->mu);
     const uint32_t slot = step % s->n_slots;
     const uint32_t steps_resident = s->n_queries / s->q;
     const size_t qoff = (size_t)(step % steps_resident) * s->q * s->dim;
@@ -735,6 +773,12 @@ int orama_shard_session_step(orama_shard_session* s, uint32_t step) {
         SessionLocal& sl = *s->local[i];
         ORAMA_HIP_TRY(hipSetDevice(L(g, i).device));
         char* dst = s->exchange ? gathered(i) + (size_t)slot_of(g, i) * s->nb : sl.gathered[slot].as<char>();
+        // co-located groups share shard 0's gathered buffer: a block may only be overwritten once the previous merge of
+        // this slot has read it
+        if (s->exchange && g->colocated && i > 0 && s->local[0]->merged_recorded[slot]) {
+            ORAMA_HIP_TRY(hipStreamWaitEvent(sl.tail[slot], s->local[0]->ev_merged[slot], 0));
+            if (s->n_slots > 1) ORAMA_HIP_TRY(hipStreamWaitEvent(sl.scan, s->local[0]->ev_merged[slot], 0));
+        }
         if (s->n_slots > 1)
             ORAMA_TRY(orama_vec_search_packed_device2(s->shards[i], sl.queries.as<float>() + qoff, s->q, s->k, nullptr, 0, dst,
                                                       sl.d_n[slot].as<uint32_t>(), sl.scan, sl.tail[slot]));
@@ -745,8 +789,8 @@ int orama_shard_session_step(orama_shard_session* s, uint32_t step) {
     if (!s->exchange) return ORAMA_OK;  // single shard: the block IS the answer ([q*k ids][q*k distances])
     if (g->colocated) {
         for (uint32_t i = 1; i < nl; ++i) {
-            ORAMA_HIP_TRY(hipEventRecord(L(g, i).ev, s->local[i]->tail[slot]));
-            ORAMA_HIP_TRY(hipStreamWaitEvent(s->local[0]->tail[slot], L(g, i).ev, 0));
+            ORAMA_HIP_TRY(hipEventRecord(s->local[i]->ev_block[slot], s->local[i]->tail[slot]));
+            ORAMA_HIP_TRY(hipStreamWaitEvent(s->local[0]->tail[slot], s->local[i]->ev_block[slot], 0));
         }
     } else {
         Rccl* r = g->rccl;
@@ -766,12 +810,17 @@ int orama_shard_session_step(orama_shard_session* s, uint32_t step) {
         ORAMA_HIP_TRY(hipSetDevice(L(g, i).device));
         ORAMA_TRY(launch_merge_packed(L(g, i).ctx, gathered(i), (uint32_t)g->world, s->q, s->k, sl.out_ids[slot].as<uint64_t>(),
                                       sl.out_val[slot].as<float>(), sl.out_n[slot].as<uint32_t>(), sl.tail[slot]));
+        if (g->colocated) {
+            ORAMA_HIP_TRY(hipEventRecord(sl.ev_merged[slot], sl.tail[slot]));
+            sl.merged_recorded[slot] = 1;
+        }
     }
     return ORAMA_OK;
 }
 
 int orama_shard_session_sync(orama_shard_session* s) {
     ORAMA_REQUIRE(s, "null session");
+    DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     for (uint32_t i = 0; i < s->local.size(); ++i) {
         ORAMA_HIP_TRY(hipSetDevice(L(s->g, i).device));
         ORAMA_HIP_TRY(hipStreamSynchronize(s->local[i]->scan));
@@ -783,6 +832,7 @@ int orama_shard_session_sync(orama_shard_session* s) {
 // Result of the last step that used `slot` (call after orama_shard_session_sync): q x k ids / distances, q counts.
 int orama_shard_session_result(orama_shard_session* s, uint32_t slot, uint64_t* out_ids, float* out_dist, uint32_t* out_n) {
     ORAMA_REQUIRE(s && out_ids && out_dist && out_n && slot < s->n_slots, "bad argument");
+    DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     SessionLocal& sl = *s->local[0];
     ORAMA_HIP_TRY(hipSetDevice(L(s->g, 0).device));
     const size_t nk = (size_t)s->q * s->k;

@@ -864,7 +864,7 @@ int orama_vec_create(orama_ctx* ctx, uint32_t dim, int metric, int dtype, uint64
         set_error("f16 storage: dimensions %u > 2048 exceed the LDS query tile", dim);
         return ORAMA_ERR_UNSUPPORTED;
     }
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     orama_vec* v = new (std::nothrow) orama_vec();
     if (!v) {
         set_error("out of host memory");
@@ -890,7 +890,7 @@ int orama_vec_create(orama_ctx* ctx, uint32_t dim, int metric, int dtype, uint64
 
 void orama_vec_destroy(orama_vec* v) {
     if (!v) return;
-    (void)hipSetDevice(v->ctx->device);
+    ::orama::DeviceScope ORAMA_CAT_(dev_scope__, __LINE__)(v->ctx->device);
     (void)hipDeviceSynchronize();
     delete v;
 }
@@ -977,7 +977,7 @@ static int vec_insert_one(orama_vec* v, const uint64_t* doc_ids, const float* ro
     if (accepted) *accepted = 0;
     if (n_rows == 0) return ORAMA_OK;
     ORAMA_REQUIRE(doc_ids && rows, "null input");
-    ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
+    ORAMA_ON_DEVICE(v->ctx->device);
     std::lock_guard<std::mutex> wl(v->write_mu);  // one writer; searches keep running on the published snapshot
     ScratchLease sc(v->ctx);
     ORAMA_TRY(sc.init());
@@ -1031,7 +1031,7 @@ static int vec_delete_one(orama_vec* v, const uint64_t* doc_ids, uint64_t n) {
     if (n == 0) return ORAMA_OK;
     ORAMA_REQUIRE(doc_ids, "null input");
     ORAMA_REQUIRE(n < 0xffffffffull, "too many ids in one delete");
-    ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
+    ORAMA_ON_DEVICE(v->ctx->device);
     std::lock_guard<std::mutex> wl(v->write_mu);
     std::shared_lock<std::shared_mutex> r(v->mu);  // searches keep running; each sees the tombstones or not
     const uint64_t rows = v->n_rows.load(std::memory_order_acquire);
@@ -1068,7 +1068,7 @@ int orama_vec_compact(orama_vec* v, uint64_t version) {
     // re-packs, means no search ever sees one copy compacted and the other not (and the lock order of a search,
     // v->mu then shadow->mu, is the order used here).
     std::lock_guard<std::mutex> cl(v->composite_mu);
-    ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
+    ORAMA_ON_DEVICE(v->ctx->device);
     std::unique_lock<std::shared_mutex> lk(v->mu);
     ORAMA_TRY(vec_compact_one(v->shadow.get(), version));
     return vec_compact_one(v, version, true);
@@ -1076,7 +1076,7 @@ int orama_vec_compact(orama_vec* v, uint64_t version) {
 
 static int vec_compact_one(orama_vec* v, uint64_t version, bool mu_held) {
     ORAMA_REQUIRE(v, "null handle");
-    ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
+    ORAMA_ON_DEVICE(v->ctx->device);
     std::lock_guard<std::mutex> wl(v->write_mu);
     std::unique_lock<std::shared_mutex> lk(v->mu, std::defer_lock);  // rows move: no scan may run (the reference's compact is exclusive too)
     if (!mu_held) lk.lock();
@@ -1175,7 +1175,7 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     for (uint32_t i = 0; i < q; ++i) out_n[i] = 0;
     if (k == 0) return ORAMA_OK;  // limit 0: empty result, like the reference's CappedHeap(0)
     ORAMA_SUPPORT(k <= kSelectMaxK, "limit %u exceeds the supported maximum %u", k, kSelectMaxK);
-    ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
+    ORAMA_ON_DEVICE(v->ctx->device);
     std::shared_lock<std::shared_mutex> lk(v->mu);
     if (v->n_rows.load(std::memory_order_acquire) == 0) return ORAMA_OK;
     // fp32 rows + fp16 shadow: candidates from the shadow scan, exact distances from the fp32 rows (two_stage_search)
@@ -1222,7 +1222,7 @@ int orama_vec_search_device(orama_vec* v, const float* d_queries, uint32_t q, ui
     ORAMA_REQUIRE(q >= 1 && d_queries && d_out_ids && d_out_dist && d_out_n, "null argument");
     ORAMA_REQUIRE(k >= 1, "limit is 0");
     ORAMA_SUPPORT(k <= kSelectMaxK, "limit %u outside [1, %u]", k, kSelectMaxK);
-    ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
+    ORAMA_ON_DEVICE(v->ctx->device);
     hipStream_t s = (hipStream_t)hip_stream;
     std::shared_lock<std::shared_mutex> lk(v->mu);
     Scratch* sc = nullptr;
@@ -1242,7 +1242,7 @@ int orama_vec_search_packed_device2(orama_vec* v, const float* d_queries, uint32
     ORAMA_REQUIRE(q >= 1 && d_queries && d_out_n, "null argument");
     ORAMA_REQUIRE(k >= 1, "limit is 0");
     ORAMA_SUPPORT(k <= kSelectMaxK, "limit %u outside [1, %u]", k, kSelectMaxK);
-    ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
+    ORAMA_ON_DEVICE(v->ctx->device);
     hipStream_t s = (hipStream_t)tail_stream, ss = (hipStream_t)scan_stream;
     std::shared_lock<std::shared_mutex> lk(v->mu);
     Scratch* sc = nullptr;
@@ -1261,7 +1261,7 @@ int orama_merge_candidates_device(orama_ctx* ctx, const uint64_t* d_ids, const f
                                   uint32_t lists, uint32_t q, uint32_t k, uint64_t* d_out_ids,
                                   float* d_out_dist, uint32_t* d_out_n, void* hip_stream) {
     ORAMA_REQUIRE(ctx && d_ids && d_dist && d_out_ids && d_out_dist, "null argument");
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     return launch_merge_candidates(ctx, d_ids, d_dist, lists, q, k, d_out_ids, d_out_dist, d_out_n,
                                    (hipStream_t)hip_stream);
 }
@@ -1282,7 +1282,7 @@ int orama_merge_packed_device(orama_ctx* ctx, const void* d_packed_blocks, uint3
                               uint32_t k, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n,
                               void* hip_stream) {
     ORAMA_REQUIRE(ctx && d_packed_blocks && d_out_ids && d_out_dist, "null argument");
-    ORAMA_HIP_TRY(hipSetDevice(ctx->device));
+    ORAMA_ON_DEVICE(ctx->device);
     return launch_merge_packed(ctx, d_packed_blocks, lists, q, k, d_out_ids, d_out_dist, d_out_n,
                                (hipStream_t)hip_stream);
 }
@@ -1298,7 +1298,7 @@ int orama_vec_fill_synthetic(orama_vec* v, uint64_t n_rows, uint64_t seed, uint6
 static int vec_fill_synthetic_one(orama_vec* v, uint64_t n_rows, uint64_t seed, uint64_t first_doc_id) {
     ORAMA_REQUIRE(v, "null handle");
     if (n_rows == 0) return ORAMA_OK;
-    ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
+    ORAMA_ON_DEVICE(v->ctx->device);
     std::lock_guard<std::mutex> wl(v->write_mu);
     ScratchLease sc(v->ctx);
     ORAMA_TRY(sc.init());
@@ -1334,7 +1334,7 @@ int orama_vec_get_rows(orama_vec* v, const uint64_t* row_idx, uint64_t n, float*
     ORAMA_REQUIRE(v, "null handle");
     if (n == 0) return ORAMA_OK;
     ORAMA_REQUIRE(row_idx && out_rows, "null argument");
-    ORAMA_HIP_TRY(hipSetDevice(v->ctx->device));
+    ORAMA_ON_DEVICE(v->ctx->device);
     std::shared_lock<std::shared_mutex> lk(v->mu);
     const uint64_t rows = v->n_rows.load(std::memory_order_acquire);
     for (uint64_t i = 0; i < n; ++i)

@@ -44,6 +44,60 @@ class ShardPlan:
         return hi - lo
 
 
+def device_for(local_rank: int) -> int:
+    """The GPU of a local rank: its own one.  A box with fewer GPUs than ranks can only run the job on a loopback
+    transport (ORAMA_RCCL_LIB — tests/mock_rccl; real RCCL refuses two ranks on one device): ranks then share GPUs."""
+    import ctypes as C
+
+    from . import _native as N
+
+    n = C.c_int()
+    N.check(N.load().orama_device_count(C.byref(n)))
+    if local_rank < n.value:
+        return local_rank
+    if not os.environ.get("ORAMA_RCCL_LIB"):
+        raise RuntimeError(f"local rank {local_rank} needs its own GPU, this box shows {n.value} "
+                           "(ranks may share a GPU only on a loopback transport: ORAMA_RCCL_LIB)")
+    return local_rank % n.value
+
+
+def self_launch(n_ranks: int, argv: list[str], timeout: float | None = None) -> int:
+    """`python bench.py --gpus N` without an external launcher: start N copies of the calling script, one rank per GPU,
+    with the RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment `torch.distributed.run` would give them.  Rank 0
+    inherits stdout (its JSON line stays the last line); the other ranks' stdout goes to stderr.  Returns the worst
+    exit code; a rank that dies takes the others down instead of leaving them in a collective."""
+    import subprocess
+    import sys
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, *argv], env=env, stdout=None if r == 0 else sys.stderr))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    worst = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                for q in alive:
+                    q.terminate()
+        if deadline is not None and time.monotonic() > deadline:
+            for q in alive:
+                q.kill()
+            return worst or 124
+        time.sleep(0.05)
+    return worst
+
+
 def _ports(env: RankEnv):
     # a short deterministic sequence next to the launcher's own rendezvous port (which is in use)
     base = env.master_port + 1

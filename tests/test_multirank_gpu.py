@@ -1,0 +1,155 @@
+"""The shard group's exchange with MORE THAN ONE RANK (VERDICT r02 "missing" #1).
+
+The box has one GPU and real RCCL refuses two ranks on one device, so these jobs run on tests/mock_rccl — a library
+with RCCL's nine C signatures that moves the bytes through shared memory (ORAMA_RCCL_LIB).  Everything above the
+transport is the product: `world` separate PROCESSES each create their rank with orama_shard_group_create_rank
+(ncclCommInitRank; rank0 > 0, slot_of(), the index-wide df / min-max / count reductions across real processes), or ONE
+process holds every shard with its own communicator (orama_shard_group_create + ORAMA_SHARD_FORCE_RCCL:
+ncclCommInitAll, collectives inside ncclGroupStart/End).
+
+Bar: every rank returns the single-store answer over the union, bit for bit (ids, distance / score bits, counts) —
+vector fp32 / fp16 (1, 5 and 256 queries), filters, k beyond a shard, the pipelined session, full-text with threshold /
+filter / OMC, hybrid through the staged path and through the one-call path — and full-text also equals the oracle.
+"""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import multirank_worker as W
+import oramacore_amd as oa
+from oramacore_amd import _native as N
+from oramacore_amd import fulltext as ft
+from test_fulltext_gpu import bits, oracle_topk
+from test_oracle_golden import bm25_synth_entries
+
+pytestmark = pytest.mark.gpu
+
+HERE = Path(__file__).resolve().parent
+MOCK = HERE / "mock_rccl" / "libmock_rccl.so"
+
+
+@pytest.fixture(scope="module")
+def expected(ctx):
+    """The single-store answers (one store over the union of the shards), computed once."""
+    e = {}
+    rows, doc_ids, qs = W.vector_data()
+    for name, dtype in (("f32", N.DTYPE_F32), ("f16", N.DTYPE_F16)):
+        st = oa.EmbeddingFieldStorage(ctx, dimensions=W.VEC_D, dtype=dtype)
+        st.insert_rows(doc_ids, rows)
+        for tag, q in (("solo", qs[0]), ("tie", qs[3]), ("batch", qs)):
+            e[f"vec_{name}_{tag}"] = st.storage_search(q, W.K)
+        bm = oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[(np.arange(W.VEC_N) % 3) != 1])
+        e[f"vec_{name}_filter"] = st.storage_search(qs[1], W.K, bm)
+        for world in (2, 3):
+            e[f"vec_{name}_bigk_w{world}"] = st.storage_search(qs[2], 4096 // world)
+        if name == "f32":
+            e["sess"] = st.storage_search(qs[:4], 20)
+        st.close()
+    rows, doc_ids, qs = W.wide_data()
+    st = oa.EmbeddingFieldStorage(ctx, dimensions=W.WIDE_D, dtype=N.DTYPE_F16)
+    st.insert_rows(doc_ids, rows)
+    e["wide"] = st.storage_search(qs, 100)
+    st.close()
+
+    meta, fields, doc_ids, allow = W.text_data()
+    post, list_id = W.build_text_shard(ctx, meta, fields, doc_ids, 0, meta["n_docs"])
+    bm = oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[allow])
+    vec = W.text_vector_map(doc_ids)
+    total = float(meta["n_docs"])
+    for ci in W.TEXT_CASES:
+        case = meta["cases"][ci]
+        refs = W.refs_of(meta, list_id, case)
+        n_tok = len(case["terms"])
+        e[f"text{ci}"] = post.search(refs, n_tok, total, 50, threshold=case["threshold"], allow=bm if case["filter"] else None)
+        # ... which is itself the oracle's answer
+        entries = bm25_synth_entries(meta, fields, case, doc_ids, allow)
+        od, os_, ocount = oracle_topk(entries, n_tok, meta["n_docs"], 50, case["threshold"])
+        assert e[f"text{ci}"][2] == ocount and e[f"text{ci}"][0].tolist() == od.tolist()
+        assert np.array_equal(bits(e[f"text{ci}"][1]), bits(os_))
+        e[f"hyb{ci}"] = post.search(refs, n_tok, total, 30, threshold=case["threshold"], vector=vec, apply_omc=False)
+    post.set_omc({int(doc_ids[3]): 2.0, int(doc_ids[-2]): 4.0, int(doc_ids[5000]): 0.5})
+    case = meta["cases"][12]
+    e["omc"] = post.search(W.refs_of(meta, list_id, case), len(case["terms"]), total, 100)
+    post.set_omc({})
+    hrows = W.util.gaussian_rows(meta["n_docs"], 128, seed=51)
+    vst = oa.EmbeddingFieldStorage(ctx, dimensions=128)
+    vst.insert_rows(doc_ids, hrows)
+    hq = hrows[17] + 0.3 * hrows[meta["n_docs"] - 5]
+    refs = W.refs_of(meta, list_id, case)
+    for tag, (limit, sim) in (("a", (10, 0.0)), ("b", (40, 0.05))):
+        e[f"onecall_{tag}"] = post.hybrid_search(vst, hq, limit, sim, refs, len(case["terms"]), total, 30)
+    vst.close()
+    post.close()
+    return e
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def check_rank(got, e, world, form, rank):
+    what = f"{form} rank {rank}/{world}"
+    for name in ("f32", "f16"):
+        for tag in ("solo", "tie", "batch", "filter"):
+            ids, dist, cnt = e[f"vec_{name}_{tag}"]
+            key = f"vec_{name}_{tag}"
+            assert same(got[key + "_cnt"], cnt) and same(got[key + "_ids"], ids) and same(got[key + "_dist"], dist), (what, key)
+        ids, dist, cnt = e[f"vec_{name}_bigk_w{world}"]
+        key = f"vec_{name}_bigk"
+        assert same(got[key + "_cnt"], cnt) and same(got[key + "_ids"], ids) and same(got[key + "_dist"], dist), (what, key)
+    s_ids, s_dist, _ = e["sess"]
+    for slot, qi in ((0, 0), (1, 1)):  # steps 4 and 5 of 6 over 4 resident queries
+        assert same(got[f"sess_slot{slot}_ids"][0], s_ids[qi]) and same(got[f"sess_slot{slot}_dist"][0], s_dist[qi]), (what, slot)
+        assert got[f"sess_slot{slot}_cnt"][0] == 20
+    ids, dist, cnt = e["wide"]
+    assert same(got["wide_cnt"], cnt) and same(got["wide_ids"], ids) and same(got["wide_dist"], dist), (what, "wide")
+    for key in [f"text{ci}" for ci in W.TEXT_CASES] + [f"hyb{ci}" for ci in W.TEXT_CASES] + ["omc", "onecall_a", "onecall_b"]:
+        ids, sc, count = e[key]
+        assert int(got[key + "_count"]) == count, (what, key)
+        assert got[key + "_ids"].tolist() == ids.tolist(), (what, key)
+        assert np.array_equal(bits(got[key + "_sc"]), bits(sc)), (what, key)
+    # one process per rank: max over ranks of (1 + rank); one process holding every shard: nothing to reduce
+    assert float(got["allreduce_max"]) == (float(world) if form == "rank" else 1.0), what
+
+
+def run_workers(form, world, tmp_path):
+    if not MOCK.exists():
+        subprocess.run(["make", "-C", str(MOCK.parent)], check=True, capture_output=True)
+    env = dict(os.environ, ORAMA_RCCL_LIB=str(MOCK), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MOCK_RCCL_HOST_BUFFERS", None)
+    uid = (f"/orama_mock_test_{os.getpid()}_{form}_{world}".encode()).ljust(128, b"\0")
+    n_procs = world if form == "rank" else 1
+    outs = [tmp_path / f"{form}_{world}_{r}.npz" for r in range(n_procs)]
+    procs = [subprocess.Popen([sys.executable, str(HERE / "multirank_worker.py"), form, str(r), str(world), uid.hex(), str(outs[r])],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(n_procs)]
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(out)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"{form} rank {r}/{world} failed:\n" + logs[r][-4000:]
+    return [np.load(o) for o in outs]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_process_per_rank(expected, world, tmp_path):
+    """orama_shard_group_create_rank: `world` processes, one shard each, every rank holds the global answer."""
+    for rank, got in enumerate(run_workers("rank", world, tmp_path)):
+        check_rank(got, expected, world, "rank", rank)
+
+
+@pytest.mark.parametrize("world", [3])
+def test_one_process_all_ranks_grouped_collectives(expected, world, tmp_path):
+    """orama_shard_group_create + ORAMA_SHARD_FORCE_RCCL: one process, one communicator per shard, ncclGroupStart/End."""
+    (got,) = run_workers("initall", world, tmp_path)
+    check_rank(got, expected, world, "initall", 0)
