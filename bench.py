@@ -5,27 +5,38 @@ Metric (BASELINE.json): queries/sec of the single-query cosine top-100 scan over
 corpus (the north-star shape, 30.72 GB — fits one GPU), at 1/2/4/8 GPUs; HBM GB/s of the scan
 kernel against the gfx950 peak; the CPU restatement of the reference timed beside it.
 
-A "step" is one query: one pass of K1 (distance scan) over the rank's shard + K4 (top-100) + — for
+A "step" is one query batch: one pass of the distance scan over the rank's shard + K4 (top-100) + — for
 N > 1 — one RCCL all-gather of the per-shard candidates + K6 (merge).  Corpus and queries are
 resident in HBM before the timed region; results stay in HBM (the host-buffer API, which adds the
 PCIe hop, is timed separately and reported as `latency_ms_p50_host_api`).
 
+`value` is the north-star workload.  At N = 1 the same run then times the other BASELINE configurations and
+reports them as `configs: {c4, c2, c3, c5_shard}` — each with its own ms_per_step, roofline (HIP events on the
+launching stream + SURVEY §8(d) algorithmic bytes) and post-run oracle check (`--configs none` skips them).
+
 No torch in this process: buffers, streams and the RCCL exchange live inside liborama_hip.so
-(orama_shard_*); under torch.distributed.run the ranks only read RANK / LOCAL_RANK / WORLD_SIZE /
-MASTER_* from the environment and pass the 128-byte communicator id over a localhost socket.
+(orama_shard_*).  N > 1 is one process per GPU: under torch.distributed.run the ranks read RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment; a plain `python bench.py --gpus N` starts the N ranks itself
+(oramacore_amd/launch.py).  The 128-byte communicator id travels over a localhost socket.
 
 Strong scaling: the 10 M rows are split statically over the N ranks, so queries/sec
 should grow ~linearly with N.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|c2|c3] [--rows R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|c2|c3|c5] [--rows R] [--configs ...]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -35,6 +46,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+MFMA_F16_PEAK_TFLOPS = 2500.0
 
 WORKLOADS = {
     # name: (rows, dim, k, queries per step, storage dtype, description)
@@ -45,6 +57,7 @@ WORKLOADS = {
     "c5": (80_000_000, 768, 100, 256, "f16", "80M x 768 fp16 embeddings sharded over the ranks, batch-256 queries, "
                                              "MFMA scan + top-100 + RCCL all-gather (BASELINE configs[4])"),
 }
+EXTRA_CONFIGS = ("c4", "c2", "c3", "c5_shard")
 
 
 def parse_args():
@@ -62,9 +75,16 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are issued on round-robin (independent queries: the tiny top-k / "
                          "all-gather / merge kernels of step i overlap the corpus scan of step i+1)")
+    ap.add_argument("--configs", default="all",
+                    help="extra BASELINE configurations timed after the north-star leg at N = 1: 'all', 'none' or a comma "
+                         "list of " + ",".join(EXTRA_CONFIGS))
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic live (two short rocprofv3 --pmc passes of `--pmc-child`)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(store, dim: int, n_total: int, k: int, sample_rows: int) -> dict:
     """The oracle (C restatement of the reference algorithm — NOT the reference binary) timed on this
     host: sequential-f32 cosine distances over a bounded sample of the same corpus + top-k, single
@@ -103,6 +123,8 @@ def cpu_baseline(store, dim: int, n_total: int, k: int, sample_rows: int) -> dic
         "gbytes_per_s": rows_per_s_1 * dim * 4 / 1e9,
         "all_cores": {"value": rows_per_s_all / n_total, "cores": cores,
                       "gbytes_per_s": rows_per_s_all * dim * 4 / 1e9},
+        "note": "a scalar restatement, not the reference's (un-vendored, presumably SIMD) crate: a reported baseline, not a "
+                "speed-up claim",
     }
 
 
@@ -147,8 +169,349 @@ def two_stage_leg(oa, ctx, plain, dim, n_local, k, qb, queries_h, lo, rank) -> d
                     "falls back to the fp32 scan; results bit-identical to the plain store (DESIGN.md K1s)"}
 
 
+# ---------------------------------------------------------------------------------------------- vector legs
+def check_vector_result(store, ids_all, dst_all, cnt, queries_last, k, qb, lo, hi, f16) -> None:
+    """Post-run check of one step against the oracle (outside the timed region): sorted, exact on re-computation from
+    the stored rows, and no row of a random sample of the shard beats the reported k-th distance unless it was returned
+    (the size-independent property of SURVEY §8c).  Raises instead of letting a wrong number be printed."""
+    from oracle import oracle as orc  # checker only
+
+    n_local = hi - lo
+    assert np.all(cnt == k), "bench result incomplete"
+    for qi in sorted({0, qb - 1}):
+        ids_h, dst_h = ids_all[qi], dst_all[qi]
+        assert np.all(np.diff(dst_h) >= 0), "bench result not sorted"
+        qv = queries_last[qi]
+        if f16:  # the fp16 path scores the fp16-rounded query against the stored fp16 rows
+            qv = qv.astype(np.float16).astype(np.float32)
+        mine = (ids_h >= lo) & (ids_h < hi)
+        if mine.any():
+            rows, _ = store.get_rows((ids_h[mine] - np.uint64(lo)).astype(np.uint64))
+            od = orc.distances(rows, qv)
+            err = float(np.max(np.abs(od - dst_h[mine])))
+            assert err <= 1e-4, f"bench parity check failed: {err}"
+        srng = np.random.default_rng(1234 + qi)
+        sample = srng.choice(n_local, size=min(20_000, n_local), replace=False).astype(np.uint64)
+        srows, sdocs = store.get_rows(sample)
+        sd = orc.distances(srows, qv, threads=8)
+        inside = set(ids_h.tolist())
+        missed = [int(dd) for dd, x in zip(sdocs.tolist(), sd.tolist()) if x < dst_h[-1] - 2e-4 and int(dd) not in inside]
+        assert not missed, f"bench parity check failed: rows {missed[:5]} beat the reported k-th distance"
+
+
+def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=False, rank=0, world=1, lo=0, hi=None,
+               store=None, valid=True, desc=None):
+    """One vector workload through the pipelined shard session: returns (bench-line dict, store, host queries)."""
+    _, dim, k, qb, dtype, wdesc = WORKLOADS[name]
+    desc = desc or wdesc
+    hi = n_total if hi is None else hi
+    n_local = hi - lo
+    f16 = dtype == "f16"
+    ctx = group.ctx(0)
+    t_fill = 0.0
+    if store is None:
+        store = oa.EmbeddingFieldStorage(ctx, dimensions=dim, reserve_rows=n_local, dtype=oa.DTYPE_F16 if f16 else oa.DTYPE_F32)
+        t_fill = time.perf_counter()
+        store.fill_synthetic(n_local, seed=0xC0FFEE + rank, first_doc_id=lo)
+        t_fill = time.perf_counter() - t_fill
+
+    total_b = warmup + steps  # batches
+    rng = np.random.default_rng(0xBEEF)
+    queries_h = rng.standard_normal((total_b * qb, dim)).astype(np.float32)
+    # Stream plan (inside the session): ONE scan stream (corpus scans of consecutive steps run back to back, never
+    # concurrently, so each keeps the whole HBM bandwidth) + `--streams` high-priority tail streams used round-robin
+    # for top-k / all-gather / merge, which are launch-bound and overlap the next step's scan.
+    # fp16 workloads: the scan and its threshold-filter selections depend on each other step by step and all run on the
+    # tail stream, so a second slot would only make two corpus scans share the HBM bandwidth (and inflate the per-launch
+    # durations the roofline is computed from) — one slot.
+    n_streams = 1 if f16 else max(1, streams)
+    sess = group.session([store], queries_h, qb, k, n_slots=n_streams, force_exchange=force_exchange)
+
+    def barrier():
+        sess.sync()
+        group.barrier()  # local devices drained + one all-reduced word over RCCL + drained again
+
+    for i in range(warmup):
+        sess.step(i)
+    barrier()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(warmup, total_b):
+        sess.step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    elapsed = group.allreduce_max(elapsed)  # the slowest rank's time
+
+    ids_all, dst_all, cnt = sess.result((total_b - 1) % n_streams)
+    check_vector_result(store, ids_all, dst_all, cnt, queries_h[(total_b - 1) * qb:total_b * qb], k, qb, lo, hi, f16)
+
+    kern = "vec_scan_f16" if f16 else "vec_scan_f32"
+    scan_ms, scan_n = ctx.prof_get(kern)
+    sel_ms, _ = ctx.prof_get("topk_select")
+    kpad = (dim + 127) // 128 * 128
+    bytes_per_step = n_local * (kpad * 2 if f16 else dim * 4)  # one corpus pass per step (SURVEY §8d)
+    launches_per_step = max(scan_n, 1) / steps
+    alg_bytes = bytes_per_step / launches_per_step
+    avg_scan_s = scan_ms / max(scan_n, 1) / 1e3
+    achieved = alg_bytes / avg_scan_s / 1e9 if scan_n else 0.0
+    out = {
+        "metric": f"queries/sec, cosine top-{k} scan ({n_total // 1_000_000}M x {dim} {dtype}) — HBM GB/s vs peak in "
+                  "`roofline`",
+        "value": steps * qb / elapsed,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": dtype,
+        "data": "synthetic",
+        "config": {"workload": desc, "rows_total": n_total, "rows_per_gpu": n_local, "dim": dim, "k": k,
+                   "queries_per_step": qb, "parallelism": f"row-shard x{world} + all-gather(top-k) over RCCL (inside "
+                   "liborama_hip.so, one process per GPU)" if world > 1 else "single GPU", "streams": n_streams,
+                   "valid": bool(valid)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": ("vec_scan_f16_pc_kernel" if f16 and qb > 64 else kern + "_kernel"),
+                     "alg_bytes_per_launch": alg_bytes,
+                     "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_n,
+                     "scan_launches_per_step": launches_per_step,
+                     "topk_select_ms_per_step": sel_ms / steps},
+        "parity_check": "last step vs oracle: distances recomputed from the rows (<= 1e-4), no better row among 20 000 "
+                        "sampled rows of the shard",
+        "fill_seconds": t_fill,
+    }
+    if f16:
+        flops = 2.0 * qb * n_local * kpad * steps
+        out["roofline"]["mfma_tflops"] = flops / (scan_ms / 1e3) / 1e12 if scan_ms else 0.0
+        out["roofline"]["mfma_peak_tflops_dense_f16"] = MFMA_F16_PEAK_TFLOPS
+        out["roofline"]["mfma_frac"] = out["roofline"]["mfma_tflops"] / MFMA_F16_PEAK_TFLOPS
+    sess.close()
+    return out, store, queries_h
+
+
+def host_api_latency(store, queries_h, qb, k, n=50) -> dict:
+    lat = []
+    for i in range(min(n, queries_h.shape[0] // qb)):
+        t1 = time.perf_counter()
+        store.storage_search(queries_h[i * qb:(i + 1) * qb], k)
+        lat.append((time.perf_counter() - t1) * 1e3)
+    return {"latency_ms_p50_host_api": float(np.percentile(lat, 50)), "latency_ms_p95_host_api": float(np.percentile(lat, 95))}
+
+
+# ---------------------------------------------------------------------------------------------- C4: hybrid
+def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12) -> dict:
+    """BASELINE configs[3]: 10 M-doc BM25F (12-token queries) + the 10 M x 768 fp32 scan, min-max merge, top-100.
+    `vec` is the north-star store (same rows).  Synthetic postings per SURVEY §8d, generated in HBM."""
+    from oramacore_amd import fulltext as ft
+
+    T = tokens
+    rng = np.random.default_rng(0xB26)
+    ranks = np.unique(np.exp(rng.uniform(np.log(100), np.log(100000), size=n_lists)).astype(np.uint32))
+    post = ft.PostingsStore(ctx)
+    t0 = time.perf_counter()
+    n_post = post.fill_synthetic(n, ranks, seed=0xB25)
+    t_fill = time.perf_counter() - t0
+    info = post.info()
+    total = warmup + steps
+    qv = np.random.default_rng(0xBEEF).standard_normal((total, dim)).astype(np.float32)
+    qlists = [rng.choice(len(ranks), size=T, replace=False) for _ in range(total)]
+    refs = [[(t, int(l), 1.0) for t, l in enumerate(ql)] for ql in qlists]
+
+    def hybrid(i):  # one call: vector leg and BM25 leg overlap on two HIP streams
+        return post.hybrid_search(vec, qv[i], k, 0.0, refs[i], T, float(n), k)
+
+    for i in range(warmup):
+        hybrid(i)
+    ctx.synchronize()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(warmup, total):
+        h_ids, h_sc, h_count = hybrid(i)
+    ctx.synchronize()
+    el_h = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    scan_ms, scan_n = ctx.prof_get("vec_scan_f32")
+
+    # BM25 alone: the batch entry (K3r scores 32 queries per set of launches) and single-query calls
+    batch_q = [(refs[i], T, None) for i in range(warmup, total)] * max(1, 1024 // max(steps, 1))
+    post.search_batch(batch_q[:64], float(n), k)
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    b_res = post.search_batch(batch_q, float(n), k)
+    el_bb = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    kb_ms, _ = ctx.prof_get("bm25_range_bounds")
+    kd_ms, _ = ctx.prof_get("bm25_range_df")
+    ks_ms, _ = ctx.prof_get("bm25_range_score")
+    kt_ms, _ = ctx.prof_get("topk_select")
+    t0 = time.perf_counter()
+    for i in range(warmup, total):
+        b_ids, b_sc, b_count = post.search(refs[i], T, float(n), k)
+    el_b = time.perf_counter() - t0
+    assert b_res[steps - 1][0].tolist() == b_ids.tolist() and b_res[steps - 1][2] == b_count
+
+    # SURVEY §8(d) bytes of the full-text leg: 8 B per posting of the query's lists + 4 B per distinct document touched
+    lens = {}
+    postings_q, docs_q = [], []
+    for j, i in enumerate(range(warmup, total)):
+        for l in qlists[i]:
+            if l not in lens:
+                lens[l] = len(post.get_list(int(l))[0])
+        postings_q.append(sum(lens[l] for l in qlists[i]))
+        docs_q.append(b_res[j][2])  # `count` = distinct documents with a score (no threshold, no filter)
+    avg_postings, avg_docs = float(np.mean(postings_q)), float(np.mean(docs_q))
+    bm25_alg_bytes = avg_postings * 8 + avg_docs * 4
+    dev_us = (kb_ms + kd_ms + ks_ms + kt_ms) * 1e3 / len(batch_q)
+    bm25_achieved = bm25_alg_bytes / (dev_us * 1e-6) / 1e9 if dev_us else 0.0
+
+    # ---- parity of the last BM25 and hybrid query against the oracle (checker only)
+    from oracle import oracle as orc
+
+    i = total - 1
+    entries = []
+    for t, l in enumerate(qlists[i]):
+        d, tf, ln = post.get_list(int(l))
+        b_, avg_ = np.float32(0.75), np.float32(info["avg_field_length"])  # bm25.rs:99-110 in f32, vectorised
+        ntf = np.float32(1.0) * (tf.astype(np.float32) / ((np.float32(1.0) - b_) + b_ * (ln.astype(np.float32) / avg_)))
+        entries.append((t, d, ntf))
+    od, os_ = orc.search_full_text(entries, T, float(n), 1.2, None)
+    td, ts = orc.top_n(od, os_, k)
+    reps, t_cpu0 = 0, time.perf_counter()
+    while time.perf_counter() - t_cpu0 < 3.0:
+        orc.top_n(*orc.search_full_text(entries, T, float(n), 1.2, None), k)
+        reps += 1
+    cpu_bm25 = {"value": reps / (time.perf_counter() - t_cpu0), "unit": "queries/s", "cores": 1, "kind": "port",
+                "sample": f"oracle search_full_text + top_n on the last query's contributions ({sum(len(e[1]) for e in entries)} "
+                          "postings, ntf precomputed), repeated >= 3 s"}
+    assert b_count == len(od) and b_ids.tolist() == td.tolist(), "BM25 ids differ from the oracle"
+    assert np.array_equal(b_sc.view(np.uint32), ts.view(np.uint32)), "BM25 scores differ from the oracle"
+    ids, dist, _ = vec.storage_search(qv[i], k)
+    sim = (np.float32(1.0) - dist[0]).astype(np.float32)
+    cd, cs = orc.normalize_and_combine(ids[0], sim, od, os_)
+    hd, hs = orc.top_n(cd, cs, k)
+    assert h_count == len(cd) and h_ids.tolist() == hd.tolist(), "hybrid ids differ from the oracle"
+    assert np.array_equal(h_sc.view(np.uint32), hs.view(np.uint32)), "hybrid scores differ from the oracle"
+    post.close()
+
+    alg_vec = n * dim * 4
+    avg_scan_s = scan_ms / max(scan_n, 1) / 1e3
+    achieved = alg_vec / avg_scan_s / 1e9 if scan_n else 0.0
+    return {
+        "metric": "queries/sec, hybrid search: 10M-doc BM25F (12 tokens) + 10M x 768 fp32 cosine scan, min-max merge, top-100",
+        "value": steps / el_h, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": el_h / steps * 1e3,
+        "dtype": "f32",
+        "config": {"workload": "Hybrid: 10M docs BM25 (12 terms/query) + 10M x 768 vector, min-max merge (BASELINE configs[3])",
+                   "docs": n, "dim": dim, "k": k, "tokens_per_query": T, "posting_lists": int(len(ranks)),
+                   "postings_resident": int(n_post), "avg_postings_per_query": avg_postings,
+                   "avg_docs_touched_per_query": avg_docs, "valid": n == 10_000_000 and dim == 768},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "vec_scan_f32_kernel",
+                     "alg_bytes_per_launch": alg_vec, "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_n,
+                     "note": "a hybrid query = the fp32 scan (dominant) + the full-text leg on a second stream"},
+        "bm25_only": {"value": len(batch_q) / el_bb, "unit": "queries/s",
+                      "note": "orama_post_search_batch, one caller: K3r scores 32 queries per set of launches",
+                      "single_query_calls": {"value": steps / el_b, "unit": "queries/s", "ms_per_query": el_b / steps * 1e3},
+                      "roofline": {"bound": "hbm", "achieved": bm25_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": bm25_achieved / HBM_PEAK_GBS, "traffic": None,
+                                   "kernel": "range_bounds + range_score + keys_topk (K3r)",
+                                   "alg_bytes_per_query": bm25_alg_bytes,
+                                   "alg_bytes_definition": "SURVEY §8(d): 8 B per posting of the query's lists + 4 B per "
+                                                           "distinct document touched",
+                                   "device_us_per_query": dev_us,
+                                   "device_us_by_kernel": {"range_bounds": kb_ms * 1e3 / len(batch_q),
+                                                           "range_df": kd_ms * 1e3 / len(batch_q),
+                                                           "range_score": ks_ms * 1e3 / len(batch_q),
+                                                           "topk_select": kt_ms * 1e3 / len(batch_q)},
+                                   "note": "latency / LDS-bound merge of sorted runs, not a streaming kernel (DESIGN K3r)"},
+                      "cpu_baseline": cpu_bm25},
+        "postings_fill_seconds": t_fill,
+        "parity_check": "bit-exact vs oracle (last query): BM25 ids/scores/count, hybrid ids/scores/count",
+    }
+
+
+# ---------------------------------------------------------------------------------------------- live HBM traffic
+def being_profiled() -> bool:
+    return any("rocprof" in os.environ.get(v, "").lower() for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+
+
+def pmc_child(args) -> None:
+    """What the PMC passes run: the workload's store and a few scans — nothing else."""
+    import oramacore_amd as oa
+    from oramacore_amd.shard_group import ShardGroup
+
+    n_total, dim, k, qb, dtype, _ = WORKLOADS[args.workload]
+    n_total = args.rows or n_total
+    group = ShardGroup([0])
+    store = oa.EmbeddingFieldStorage(group.ctx(0), dimensions=dim, reserve_rows=n_total,
+                                     dtype=oa.DTYPE_F16 if dtype == "f16" else oa.DTYPE_F32)
+    store.fill_synthetic(n_total, seed=0xC0FFEE, first_doc_id=0)
+    qs = np.random.default_rng(0xBEEF).standard_normal((4 * qb, dim)).astype(np.float32)
+    sess = group.session([store], qs, qb, k, n_slots=1)
+    for i in range(4):
+        sess.step(i)
+    sess.sync()
+    sess.close()
+    store.close()
+    group.close()
+
+
+def measure_traffic(args, kernel_substr: str, alg_bytes: float) -> dict | None:
+    """HBM bytes per launch of the scan kernel from the PMC counters, measured in THIS run as MI355X_MICROARCH.md's
+    HBM section prescribes: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (kernel trace only),
+    values in KiB, FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced streaming reads)."""
+    exe = shutil.which("rocprofv3")
+    if args.no_pmc or being_profiled() or not exe:
+        return None
+    med = {}
+    with tempfile.TemporaryDirectory(prefix="orama_pmc_") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, str(Path(__file__).resolve()), "--pmc-child", "--workload", args.workload]
+            if args.rows:
+                cmd += ["--rows", str(args.rows)]
+            try:
+                r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), capture_output=True, text=True, timeout=300)
+            except subprocess.TimeoutExpired:
+                return None
+            vals = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path, newline="") as f:
+                    for row in csv.DictReader(f):
+                        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                return None
+            med[counter] = statistics.median(vals)
+    read_b, write_b = med["FETCH_SIZE"] * 1024 * 2, med["WRITE_SIZE"] * 1024
+    return {"traffic": read_b + write_b, "traffic_unit": "bytes/launch",
+            "traffic_source": "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate, kernel "
+                              "trace only) of `bench.py --pmc-child`; KiB units, FETCH_SIZE x2 per MI355X_MICROARCH.md",
+            "traffic_over_algorithmic": (read_b + write_b) / alg_bytes}
+
+
+def committed_traffic(workload: str) -> dict | None:
+    pmc_files = sorted((ROOT / "profiles").glob(f"r*_pmc_{workload}_vec_scan.json"))
+    if not pmc_files:
+        return None
+    rec = json.loads(pmc_files[-1].read_text())
+    return {"traffic": rec.get("traffic_bytes_per_launch"), "traffic_unit": "bytes/launch",
+            "traffic_source": f"NOT measured in this run — profiles/{pmc_files[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                              "passes of this command; FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
+
+
+# ---------------------------------------------------------------------------------------------- main
 def main():
     args = parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
     import oramacore_amd as oa
     from oramacore_amd.launch import RankEnv, ShardPlan, device_for, exchange_unique_id, self_launch
     from oramacore_amd.shard_group import FORCE_RCCL, ShardGroup
@@ -174,152 +537,65 @@ def main():
     n_total, dim, k, qb, dtype, desc = WORKLOADS[args.workload]
     if args.rows:
         n_total = args.rows
-    plan = ShardPlan(n_total, world)
-    lo, hi = plan.range(rank)
-    n_local = hi - lo
+    lo, hi = ShardPlan(n_total, world).range(rank)
     f16 = dtype == "f16"
+    out, store, queries_h = vector_leg(oa, group, args.workload, n_total, args.steps, args.warmup, args.streams,
+                                       force_exchange=args.force_exchange, rank=rank, world=world, lo=lo, hi=hi,
+                                       valid=not bool(args.rows))
+    if f16 and qb > 64:
+        out["roofline"]["note"] = ("K2d (producer/consumer GEMM tiles, 256 queries per pass): the corpus crosses HBM once "
+                                   "per batch (DESIGN.md K2d)")
 
-    store = oa.EmbeddingFieldStorage(ctx, dimensions=dim, reserve_rows=n_local,
-                                     dtype=oa.DTYPE_F16 if f16 else oa.DTYPE_F32)
-    t_fill = time.perf_counter()
-    store.fill_synthetic(n_local, seed=0xC0FFEE + rank, first_doc_id=lo)
-    t_fill = time.perf_counter() - t_fill
-
-    total_b = args.warmup + args.steps  # batches
-    rng = np.random.default_rng(0xBEEF)
-    queries_h = rng.standard_normal((total_b * qb, dim)).astype(np.float32)
-    # Stream plan (inside the session): ONE scan stream (corpus scans of consecutive steps run back to back, never
-    # concurrently, so each keeps the whole HBM bandwidth) + `--streams` high-priority tail streams used round-robin
-    # for top-k / all-gather / merge, which are launch-bound and overlap the next step's scan.
-    # fp16 workloads: the scan and its threshold-filter selections depend on each other step by step and all run on the
-    # tail stream, so a second slot would only make two corpus scans share the HBM bandwidth (and inflate the per-launch
-    # durations the roofline is computed from) — one slot.
-    n_streams = 1 if f16 else max(1, args.streams)
-    sess = group.session([store], queries_h, qb, k, n_slots=n_streams, force_exchange=args.force_exchange)
-
-    def barrier():
-        sess.sync()
-        group.barrier()  # local devices drained + one all-reduced word over RCCL + drained again
-
-    for i in range(args.warmup):
-        sess.step(i)
-    barrier()
-    ctx.prof_reset()
-    ctx.prof_enable(True)
-    t0 = time.perf_counter()
-    for i in range(args.warmup, total_b):
-        sess.step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.prof_enable(False)
-    elapsed = group.allreduce_max(elapsed)  # the slowest rank's time
-
-    # ---- sanity of the last step (outside the timed region): sorted, exact on re-computation, nothing missed
-    ids_all, dst_all, cnt = sess.result((total_b - 1) % n_streams)
-    assert np.all(cnt == k), "bench result incomplete"
-    from oracle import oracle as orc  # checker only
-
-    for qi in sorted({0, qb - 1}):
-        ids_h, dst_h = ids_all[qi], dst_all[qi]
-        assert np.all(np.diff(dst_h) >= 0), "bench result not sorted"
-        mine = (ids_h >= lo) & (ids_h < hi)
-        if mine.any():
-            rows, _ = store.get_rows((ids_h[mine] - np.uint64(lo)).astype(np.uint64))
-            qv = queries_h[(total_b - 1) * qb + qi]
-            if f16:  # the fp16 path scores the fp16-rounded query against the stored fp16 rows
-                qv = qv.astype(np.float16).astype(np.float32)
-            od = orc.distances(rows, qv)
-            err = float(np.max(np.abs(od - dst_h[mine])))
-            assert err <= 1e-4, f"bench parity check failed: {err}"
-        # "no better row was missed": no row of a random sample of this rank's shard beats the reported k-th
-        # distance unless it is in the result (size-independent property, SURVEY §8c / tests/test_full_size_gpu.py)
-        srng = np.random.default_rng(1234 + qi)
-        sample = srng.choice(n_local, size=min(20_000, n_local), replace=False).astype(np.uint64)
-        srows, sdocs = store.get_rows(sample)
-        qv = queries_h[(total_b - 1) * qb + qi]
-        if f16:
-            qv = qv.astype(np.float16).astype(np.float32)
-        sd = orc.distances(srows, qv, threads=8)
-        inside = set(ids_h.tolist())
-        missed = [int(dd) for dd, x in zip(sdocs.tolist(), sd.tolist()) if x < dst_h[-1] - 2e-4 and int(dd) not in inside]
-        assert not missed, f"bench parity check failed: rows {missed[:5]} beat the reported k-th distance"
-
-    kern = "vec_scan_f16" if f16 else "vec_scan_f32"
-    scan_ms, scan_n = ctx.prof_get(kern)
-    sel_ms, sel_n = ctx.prof_get("topk_select")
-    kpad = (dim + 127) // 128 * 128
-    bytes_per_step = n_local * (kpad * 2 if f16 else dim * 4)  # one corpus pass per step
-    launches_per_step = max(scan_n, 1) / args.steps
-    alg_bytes = bytes_per_step / launches_per_step
-    avg_scan_s = scan_ms / max(scan_n, 1) / 1e3
-    achieved = alg_bytes / avg_scan_s / 1e9 if scan_n else 0.0
-
-    traffic, traffic_src = None, None
-    pmc_files = sorted((ROOT / "profiles").glob(f"r*_pmc_{args.workload}_vec_scan.json"))
-    if pmc_files and not args.rows and world == 1:
-        rec = json.loads(pmc_files[-1].read_text())
-        traffic = rec.get("traffic_bytes_per_launch")
-        traffic_src = f"profiles/{pmc_files[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
-                      "FETCH_SIZE x2 per MI355X_MICROARCH.md)"
-
-    out = {
-        "metric": f"queries/sec, cosine top-{k} scan ({n_total // 1_000_000}M x {dim} {dtype}) — HBM GB/s vs peak in "
-                  "`roofline`",
-        "value": args.steps * qb / elapsed,
-        "unit": "queries/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": dtype,
-        "data": "synthetic",
-        "config": {"workload": desc, "rows_total": n_total, "rows_per_gpu": n_local, "dim": dim, "k": k,
-                   "queries_per_step": qb, "parallelism": f"row-shard x{world} + all-gather(top-k) over RCCL (inside "
-                   "liborama_hip.so, one process per GPU)" if world > 1 else "single GPU", "streams": n_streams,
-                   "valid": not bool(args.rows)},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                     "kernel": ("vec_scan_f16_pc_kernel" if f16 and qb > 64 else kern + "_kernel"),
-                     "alg_bytes_per_launch": alg_bytes,
-                     "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_n,
-                     "scan_launches_per_step": launches_per_step,
-                     "topk_select_ms_per_step": sel_ms / args.steps},
-        "fill_seconds": t_fill,
-    }
-    if f16:
-        flops = 2.0 * qb * n_local * kpad * args.steps
-        out["roofline"]["mfma_tflops"] = flops / (scan_ms / 1e3) / 1e12 if scan_ms else 0.0
-        out["roofline"]["mfma_peak_tflops_dense_f16"] = 2500.0
-        out["roofline"]["mfma_frac"] = out["roofline"]["mfma_tflops"] / 2500.0
-        if qb > 64:
-            out["roofline"]["note"] = ("K2d (producer/consumer GEMM tiles, 256 queries per pass): the corpus crosses HBM once "
-                                       "per batch; with the matrix pipes and the HBM stream both active the part sits at "
-                                       "its package-power limit (DESIGN.md K2d, profiles/r02_power_probe.log)")
-
-    if rank == 0 and world == 1:
-        # host-buffer API latency (adds the PCIe hop for the query and the k results)
-        lat = []
-        for i in range(min(50, total_b)):
-            t1 = time.perf_counter()
-            store.storage_search(queries_h[i * qb:(i + 1) * qb], k)
-            lat.append((time.perf_counter() - t1) * 1e3)
-        out["latency_ms_p50_host_api"] = float(np.percentile(lat, 50))
-        out["latency_ms_p95_host_api"] = float(np.percentile(lat, 95))
+    solo = rank == 0 and world == 1
+    if solo:
+        out.update(host_api_latency(store, queries_h, qb, k))  # adds the PCIe hop for the query and the k results
         if not args.no_cpu_baseline and not f16:
             out["cpu_baseline"] = cpu_baseline(store, dim, n_total, k, args.cpu_sample_rows)
+        want = EXTRA_CONFIGS if args.configs == "all" else () if args.configs == "none" else tuple(
+            c for c in args.configs.split(",") if c)
+        configs = {}
+        if args.workload == "ns" and not args.rows:
+            if "c4" in want:  # shares the north-star rows
+                configs["c4"] = hybrid_leg(oa, ctx, store, n_total, dim, k, steps=max(10, min(args.steps, 40)), warmup=3)
         if not f16 and not args.no_two_stage and vec_two_stage_ok(dim, k):
             # NOT part of `value`: the same corpus in a store that also keeps an fp16 copy of its rows (+50 % HBM).  The
             # fp16 scan proposes candidates, the fp32 rows decide; the answers are compared with the plain store's here.
-            out["two_stage_exact"] = two_stage_leg(oa, ctx, store, dim, n_local, k, qb, queries_h, lo, rank)
+            out["two_stage_exact"] = two_stage_leg(oa, ctx, store, dim, hi - lo, k, qb, queries_h, lo, rank)
+        store.close()
+        store = None
+        if args.workload == "ns" and not args.rows:
+            if "c2" in want:
+                configs["c2"], st, _ = vector_leg(oa, group, "c2", WORKLOADS["c2"][0], 200, 10, args.streams)
+                st.close()
+            st16 = None
+            if "c3" in want:
+                configs["c3"], st16, qh = vector_leg(oa, group, "c3", WORKLOADS["c3"][0], 30, 3, 1)
+                configs["c3"].update(host_api_latency(st16, qh, 64, k, n=10))
+            if "c5_shard" in want:
+                # the per-GPU shard of BASELINE configs[4]: 10 M of the 80 M x 768 fp16 rows, all 256 queries of a batch
+                # (the rows are the ones C3 scans: the same store serves both legs)
+                configs["c5_shard"], st16, _ = vector_leg(
+                    oa, group, "c5", 10_000_000, 20, 3, 1, store=st16,
+                    desc="per-GPU shard (10M rows) of: " + WORKLOADS["c5"][5])
+                configs["c5_shard"]["config"]["note"] = ("one of the eight 10 M-row shards of configs[4] on one GPU; the 8-GPU "
+                                                         "job adds one 307 KB all-gather + merge per batch")
+            if st16 is not None:
+                st16.close()
+        if configs:
+            out["configs"] = configs
     device_name = ctx.device_info()["name"]
-    sess.close()
-    store.close()
+    if store is not None:
+        store.close()
     group.barrier()
     group.close()
+    if solo:
+        # HBM traffic of the dominant kernel from the PMC counters — measured now (two short profiler passes of this
+        # script's --pmc-child mode, after this process has released the GPU), else the committed record, labelled
+        kern = "vec_scan_f16" if f16 else "vec_scan_f32"
+        t = measure_traffic(args, kern, out["roofline"]["alg_bytes_per_launch"]) or (
+            None if args.rows else committed_traffic(args.workload))
+        if t:
+            out["roofline"].update(t)
     if rank == 0:
         out["device"] = device_name
         # RCCL writes its version banner through C stdio (fully buffered when stdout is a pipe): push it out first

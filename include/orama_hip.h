@@ -31,6 +31,12 @@
  *   - a vector store holds < 2^32 - 16 rows, a postings store < 2^32 - 1 documents, one query references
  *     < 2^32 - 1 postings (row / local-document indices are 32-bit on the device; DocumentIds are
  *     64-bit everywhere).  Vector dimensions <= 65536.
+ *   - Concurrency bound: every search / insert leases per-call scratch (stream + buffers) from its context; at most
+ *     ORAMA_MAX_INFLIGHT (default 32) sets are out at a time, further callers wait their turn, and a caller that waited
+ *     ORAMA_ACQUIRE_TIMEOUT_MS (default 30 000) without getting its sets fails with ORAMA_ERR_BUSY — nothing was started,
+ *     the request can be retried.  Sets kept by long-lived handles (orama_scores) do NOT count against the bound, so open
+ *     score maps can never starve the searches; a co-located shard group takes one set per shard per call, so it holds at
+ *     most ORAMA_MAX_INFLIGHT / 2 shards (orama_shard_group_create refuses more).
  *   - fp16 query batches: any q; 65..256 queries share one corpus pass, larger batches run in
  *     passes of 256.  Up to 64 queries run as one pass of the LDS-resident form while their fragments fit
  *     (dimensions <= 1024), as passes of 32 above that (dimensions <= 2048 for fp16 storage).
@@ -53,6 +59,7 @@ extern "C" {
 #define ORAMA_ERR_HIP 2         /* HIP runtime failure / no device */
 #define ORAMA_ERR_OOM 3         /* device or host allocation failed */
 #define ORAMA_ERR_UNSUPPORTED 4 /* valid request outside the implemented envelope */
+#define ORAMA_ERR_BUSY 5        /* the call could not get its per-call scratch sets in time (see "Concurrency bound") */
 
 /* DistanceMetric — oramacore_fields::embedding::DistanceMetric; the reference hard-codes Cosine
  * (src/collection_manager/sides/read/index/embedding_field.rs:66,88).  L2 is a build-side extension. */
@@ -64,7 +71,7 @@ extern "C" {
 #define ORAMA_DTYPE_F32 0
 #define ORAMA_DTYPE_F16 1
 /* fp32 rows PLUS an fp16 copy of the same rows ("shadow", +50 % HBM): orama_vec_search (and the request batcher on top
- * of it) runs in two stages — the shadow scan (half the bytes; MFMA for query batches) proposes max(2k, k + 128)
+ * of it) runs in two stages — the shadow scan (half the bytes; MFMA for query batches) proposes max(2k, k + 256)
  * candidates, the fp32 rows give their exact distances and the final order.  The answer is the fp32 scan's, bit for bit:
  * a query whose candidate list cannot be PROVEN to contain the exact top-k (error bound of the fp16 image, see
  * DESIGN §4 K1s) is answered by the plain fp32 scan instead.  Cosine metric, dimensions % 4 == 0 and <= 1024, k <= 2048;
@@ -364,6 +371,13 @@ typedef struct {
 int orama_post_search_batch(orama_post* p, const orama_post_query_desc* queries, uint32_t n_queries, float b,
                             const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc, uint32_t max_parallel,
                             uint32_t stride_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count);
+/* Same, plus one status per query.  Queries of a batch are independent: a query that is malformed, outside the envelope
+ * (ORAMA_ERR_UNSUPPORTED) or invalidated by a rebuild gets its own status and out_n = 0, every other query is answered.
+ * Both forms return the first failing query's status (message: orama_last_error) and still complete the rest. */
+int orama_post_search_batch_status(orama_post* p, const orama_post_query_desc* queries, uint32_t n_queries, float b,
+                                   const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc, uint32_t max_parallel,
+                                   uint32_t stride_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
+                                   uint64_t* out_count, int* out_status);
 
 /* Request batcher for full-text searches (the BM25 side of orama_batcher_*).  The reference serves
  * every request alone (search_full_text is reached from many tokio workers, src/collection_manager/sides/read/

@@ -17,6 +17,7 @@ ORAMA_ERR_INVALID = 1
 ORAMA_ERR_HIP = 2
 ORAMA_ERR_OOM = 3
 ORAMA_ERR_UNSUPPORTED = 4
+ORAMA_ERR_BUSY = 5
 
 METRIC_COSINE = 0
 METRIC_L2SQ = 1
@@ -174,6 +175,8 @@ def _declare(lib: C.CDLL) -> None:
                               C.c_uint64, C.c_int, vp, vp, u32p, u64p],
         "orama_post_search_batch": [vp, C.POINTER(PostQueryDesc), C.c_uint32, C.c_float, vp, C.c_uint64, C.c_int, C.c_uint32,
                                     C.c_uint32, vp, vp, vp, vp],
+        "orama_post_search_batch_status": [vp, C.POINTER(PostQueryDesc), C.c_uint32, C.c_float, vp, C.c_uint64, C.c_int, C.c_uint32,
+                                    C.c_uint32, vp, vp, vp, vp, vp],
         "orama_post_batcher_create": [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)],
         "orama_post_batcher_search": [vp, C.POINTER(TermRef), C.c_uint32, C.c_float, C.POINTER(Bm25Params), vp,
                                       C.c_uint64, C.c_int, vp, vp, u32p, u64p],

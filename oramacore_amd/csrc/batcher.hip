@@ -113,11 +113,25 @@ struct orama_batcher {
                                       dist.data(), cnt.data());
                 if (st != ORAMA_OK) err = orama_last_error();  // this thread's error slot
             }
+            // a failed pass is repeated one request at a time, so that only the request that cannot be served sees an
+            // error (one query outside the envelope must not fail the callers coalesced with it)
+            std::vector<int> sts(q, st);
+            std::vector<std::string> errs(q, err);
+            if (st != ORAMA_OK && q > 1) {
+                for (uint32_t i = 0; i < q; ++i) {
+                    sts[i] = ORAMA_OK;
+                    if (batch[i]->k == 0) continue;
+                    sts[i] = orama_vec_search(v, &queries[(size_t)i * dim], 1, batch[i]->k, batch[0]->allow, batch[0]->allow_bits,
+                                              &ids[(size_t)i * kmax], &dist[(size_t)i * kmax], &cnt[i]);
+                    if (sts[i] != ORAMA_OK) errs[i] = orama_last_error();
+                }
+            }
             pass.unlock();
             for (uint32_t i = 0; i < q; ++i) {
                 Request* r = batch[i];
+                const int st = sts[i];
                 r->status = st;
-                r->error = err;
+                r->error = errs[i];
                 if (st == ORAMA_OK) {
                     const uint32_t n = std::min(cnt[i], r->k);
                     memcpy(r->out_ids, &ids[(size_t)i * kmax], (size_t)n * 8);
@@ -251,6 +265,7 @@ struct orama_post_batcher {
         std::vector<uint64_t> ids, counts;
         std::vector<float> scores;
         std::vector<uint32_t> ns;
+        std::vector<int> sts;
         for (;;) {
             batch.clear();
             {
@@ -289,14 +304,22 @@ struct orama_post_batcher {
             scores.assign((size_t)q * stride, 0.f);
             ns.assign(q, 0);
             counts.assign(q, 0);
-            int st = orama_post_search_batch(p, descs.data(), q, batch[0]->b, batch[0]->allow, batch[0]->allow_bits,
-                                             batch[0]->apply_omc, 8, stride, ids.data(), scores.data(), ns.data(), counts.data());
+            // one status per request: a request that is outside the envelope, or invalidated by a rebuild between its
+            // validation and this dispatch, fails alone — the callers coalesced with it get their answers
+            sts.assign(q, ORAMA_OK);
+            const int bst = orama_post_search_batch_status(p, descs.data(), q, batch[0]->b, batch[0]->allow, batch[0]->allow_bits,
+                                                           batch[0]->apply_omc, 8, stride, ids.data(), scores.data(), ns.data(),
+                                                           counts.data(), sts.data());
             std::string err;
-            if (st != ORAMA_OK) err = orama_last_error();  // this thread's error slot
+            if (bst != ORAMA_OK) err = orama_last_error();  // this thread's error slot: the first failing query's message
+            bool all_failed = bst != ORAMA_OK;
+            for (uint32_t i = 0; i < q && all_failed; ++i) all_failed = sts[i] != ORAMA_OK;
             for (uint32_t i = 0; i < q; ++i) {
                 PostRequest* r = batch[i];
+                // a batch-level failure (bad shared arguments) leaves every status at its initial value: report it to all
+                const int st = (bst != ORAMA_OK && all_failed && sts[i] == ORAMA_OK) ? bst : sts[i];
                 r->status = st;
-                r->error = err;
+                if (st != ORAMA_OK) r->error = err;
                 if (st == ORAMA_OK) {
                     const uint32_t n = std::min(ns[i], r->desc.params.top_k);
                     if (n) {

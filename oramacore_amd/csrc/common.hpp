@@ -247,7 +247,10 @@ struct orama_ctx {
     uint32_t waiting_one = 0, waiting_pair = 0;
     std::vector<std::unique_ptr<orama::Scratch>> pool;
     uint32_t leased = 0;  // scratch sets out on lease; bounded by max_inflight (callers beyond it wait their turn)
+    uint32_t held = 0;    // sets kept by long-lived handles (orama_scores): NOT counted against max_inflight — a handle is
+                          // released by its owner, not by the end of a call, so counting it could starve every search
     uint32_t max_inflight = 32;
+    uint32_t acquire_timeout_ms = 30000;  // a caller that cannot get its sets within this fails with ORAMA_ERR_BUSY
     // resident allow-bitmaps (orama_allow_*): device pointer -> bits; a search whose `allow_bitmap` argument is one
     // of these pointers uses it in place instead of uploading host words
     std::mutex allow_mu;
@@ -259,7 +262,9 @@ struct orama_ctx {
     // one set each can never wait for each other.
     int acquire2(std::unique_ptr<orama::Scratch>* a, std::unique_ptr<orama::Scratch>* b);
     int acquire_n(uint32_t n, std::unique_ptr<orama::Scratch>** outs, const int* kinds = nullptr);
-    void release(std::unique_ptr<orama::Scratch> s);
+    void release(std::unique_ptr<orama::Scratch> s, bool detached = false);
+    // A leased set becomes handle-held: it stops counting against max_inflight (waiters are woken).
+    void detach_one();
 };
 
 namespace orama {
@@ -267,7 +272,15 @@ struct ScratchLease {
     orama_ctx* ctx;
     std::unique_ptr<Scratch> s;
     int kind;
+    bool detached = false;
     explicit ScratchLease(orama_ctx* c, int k = kScratchGeneral) : ctx(c), kind(k) {}
+    // the set outlives the call (a handle keeps it): stop counting it against the in-flight bound
+    void detach() {
+        if (s && !detached) {
+            ctx->detach_one();
+            detached = true;
+        }
+    }
     int init() { return ctx->acquire(&s, kind); }
     static int init_pair(ScratchLease& a, ScratchLease& b) {
         std::unique_ptr<Scratch>* outs[2] = {&a.s, &b.s};
@@ -280,7 +293,7 @@ struct ScratchLease {
         return a.ctx->acquire_n(3, outs, kinds);
     }
     ~ScratchLease() {
-        if (s) ctx->release(std::move(s));
+        if (s) ctx->release(std::move(s), detached);
     }
     Scratch* operator->() { return s.get(); }
 };

@@ -3,6 +3,8 @@
 #include <cstdlib>
 #include <memory>
 
+#include <chrono>
+
 #include "common.hpp"
 #include "vec_kernels.hpp"
 
@@ -106,8 +108,14 @@ int orama_ctx::acquire(std::unique_ptr<orama::Scratch>* out, int kind) {
     ++waiting_one;
     // a caller that needs several sets at once goes first: single takers would otherwise grab every freed set and the
     // multi-set caller (a request batcher's dispatcher, the hybrid search) would never see two free together
-    pool_cv.wait(g, [&] { return leased < max_inflight && waiting_pair == 0; });
+    const bool ok = pool_cv.wait_for(g, std::chrono::milliseconds(acquire_timeout_ms),
+                                     [&] { return leased < max_inflight && waiting_pair == 0; });
     --waiting_one;
+    if (!ok) {
+        orama::set_error("all %u scratch sets of this context stayed leased for %u ms (ORAMA_MAX_INFLIGHT / "
+                         "ORAMA_ACQUIRE_TIMEOUT_MS): the call was not started", max_inflight, acquire_timeout_ms);
+        return ORAMA_ERR_BUSY;
+    }
     ORAMA_TRY(take_one(this, out, kind));
     ++leased;
     if (leased < max_inflight && waiting_one) pool_cv.notify_one();  // capacity left: pass the baton
@@ -118,8 +126,15 @@ int orama_ctx::acquire_n(uint32_t n, std::unique_ptr<orama::Scratch>** outs, con
     std::unique_lock<std::mutex> g(pool_mu);
     const uint32_t need = std::min(n, max_inflight);  // a pool smaller than the request would wait for ever
     ++waiting_pair;
-    pool_cv_pair.wait(g, [&] { return leased + need <= max_inflight; });
+    const bool ok = pool_cv_pair.wait_for(g, std::chrono::milliseconds(acquire_timeout_ms),
+                                          [&] { return leased + need <= max_inflight; });
     --waiting_pair;
+    if (!ok) {
+        if (waiting_pair == 0 && leased < max_inflight && waiting_one) pool_cv.notify_one();  // singles held back for us
+        orama::set_error("%u scratch sets were not free together within %u ms (%u of %u leased; ORAMA_MAX_INFLIGHT / "
+                         "ORAMA_ACQUIRE_TIMEOUT_MS): the call was not started", n, acquire_timeout_ms, leased, max_inflight);
+        return ORAMA_ERR_BUSY;
+    }
     for (uint32_t i = 0; i < n; ++i) {
         const int st = take_one(this, outs[i], kinds ? kinds[i] : orama::kScratchGeneral);
         if (st != ORAMA_OK) {
@@ -165,7 +180,15 @@ size_t scratch_pool_budget() {
 // (ORAMA_SCRATCH_POOL_MIB, default 64 GiB of the 288) the set being returned gives its large buffers back to the driver
 // and keeps only its stream and small buffers.  (A budget below what the steady concurrency needs makes every query
 // re-allocate and re-zero its accumulator: 10 K -> 0.5 K queries/s at 8 threads with an 8 GiB budget.)
-void orama_ctx::release(std::unique_ptr<orama::Scratch> s) {
+void orama_ctx::detach_one() {
+    std::lock_guard<std::mutex> g(pool_mu);
+    if (leased) --leased;
+    ++held;
+    if (waiting_pair) pool_cv_pair.notify_one();
+    else if (waiting_one) pool_cv.notify_one();
+}
+
+void orama_ctx::release(std::unique_ptr<orama::Scratch> s, bool detached) {
     std::lock_guard<std::mutex> g(pool_mu);
     size_t pooled = 0;
     for (const auto& q : pool) pooled += scratch_bytes(*q);
@@ -177,7 +200,11 @@ void orama_ctx::release(std::unique_ptr<orama::Scratch> s) {
             if (d->cap > ((size_t)16 << 20)) d->release();
     }
     pool.push_back(std::move(s));
-    if (leased) --leased;
+    if (detached) {
+        if (held) --held;
+    } else if (leased) {
+        --leased;
+    }
     if (waiting_pair) pool_cv_pair.notify_one();  // it re-checks; freed sets accumulate for it (singles hold back)
     else if (waiting_one) pool_cv.notify_one();
 }
@@ -336,6 +363,7 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
     if (const char* e = std::getenv("ORAMA_F16_KC")) c->f16_kc = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_NBUF")) c->f16_nbuf = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_MAX_INFLIGHT")) c->max_inflight = (uint32_t)std::max(2, std::atoi(e));
+    if (const char* e = std::getenv("ORAMA_ACQUIRE_TIMEOUT_MS")) c->acquire_timeout_ms = (uint32_t)std::max(1, std::atoi(e));
     c->device = device_ordinal;
     c->compute_units = prop.multiProcessorCount;
     c->hbm_bytes = (uint64_t)prop.totalGlobalMem;

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(kGroupThreads) void group_top_kernel(ScoreMapDev m,
     if (threadIdx.x == 0) out_n[g] = n;
 }
 
-// the whole map as (DocumentId, score) pairs, in candidate-list order (position order is deterministic)
+// the whole map as (DocumentId, score) pairs.  The ORDER of the pairs is unspecified (slots are handed out by an atomic
+// cursor) — like iterating the reference's HashMap<DocumentId, f32>; callers that need an order sort by id.
 __global__ __launch_bounds__(kThreads) void scores_export_kernel(ScoreMapDev m, uint32_t list_len, uint64_t* __restrict__ out_ids,
                                                                  float* __restrict__ out_scores, uint32_t* __restrict__ cursor) {
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < list_len; i += gridDim.x * kThreads) {

@@ -1182,15 +1182,23 @@ int orama_post_search(orama_post* p, const orama_term_ref* refs, uint32_t n_refs
 // plain top-k over sorted resident lists — the normal case) are scored 32 at a time by ONE set of launches; the others
 // are pulled off a shared counter by a handful of worker threads that run the per-query path, each on its own stream +
 // scratch set, so that their launch-bound kernels overlap on the device.
-int orama_post_search_batch(orama_post* p, const orama_post_query_desc* queries, uint32_t n_queries, float b,
-                            const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc, uint32_t max_parallel,
-                            uint32_t stride_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count) {
+// Queries of a batch are independent: a query that fails (malformed, outside the envelope, invalidated by a rebuild
+// between validation and dispatch) gets its own status and out_n = 0; every other query is still answered.
+static int post_search_batch_impl(orama_post* p, const orama_post_query_desc* queries, uint32_t n_queries, float b,
+                                  const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc, uint32_t max_parallel,
+                                  uint32_t stride_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
+                                  uint64_t* out_count, int* out_status) {
     ORAMA_REQUIRE(p && (n_queries == 0 || (queries && out_n)), "null argument");
     if (n_queries == 0) return ORAMA_OK;
-    for (uint32_t i = 0; i < n_queries; ++i)
-        ORAMA_REQUIRE(queries[i].params.top_k <= stride_k, "query %u: top_k %u exceeds the output stride %u", i,
-                      queries[i].params.top_k, stride_k);
     ORAMA_REQUIRE(stride_k == 0 || (out_ids && out_scores), "null output");
+    std::vector<int> status(n_queries, ORAMA_OK);
+    std::vector<std::string> errors(n_queries);
+    auto fail = [&](uint32_t i, int st) {
+        status[i] = st;
+        errors[i] = orama_last_error();  // the calling thread's error slot
+        out_n[i] = 0;
+        if (out_count) out_count[i] = 0;
+    };
     // queries that fit the range-partitioned scorer (K3r) are scored together by one set of launches per 32 queries;
     // the rest (or all of them when K3r is switched off) run the per-query path on worker threads
     std::vector<uint32_t> rest;
@@ -1198,65 +1206,106 @@ int orama_post_search_batch(orama_post* p, const orama_post_query_desc* queries,
         std::vector<RangeJob> jobs;
         std::vector<uint64_t> counts;
         std::vector<uint32_t> owner;
-        {
-            std::shared_lock<std::shared_mutex> lk(p->mu);
-            for (uint32_t i = 0; i < n_queries; ++i) {
-                if (ranges_eligible(p, queries[i].refs, queries[i].n_refs, &queries[i].params)) owner.push_back(i);
-                else rest.push_back(i);
+        // ONE shared lock from the eligibility test to the end of the range scorer: a rebuild or an append in between
+        // could otherwise invalidate what ranges_eligible checked (list count, postings < 2^31 — the LDS tables of
+        // range_score_kernel are sized by it)
+        std::shared_lock<std::shared_mutex> lk(p->mu);
+        for (uint32_t i = 0; i < n_queries; ++i) {
+            out_n[i] = 0;
+            if (out_count) out_count[i] = 0;
+            if (queries[i].params.top_k > stride_k) {
+                set_error("query %u: top_k %u exceeds the output stride %u", i, queries[i].params.top_k, stride_k);
+                fail(i, ORAMA_ERR_INVALID);
+                continue;
             }
+            if (!ranges_eligible(p, queries[i].refs, queries[i].n_refs, &queries[i].params)) {
+                rest.push_back(i);
+                continue;
+            }
+            const int st = check_params(&queries[i].params);
+            if (st != ORAMA_OK) fail(i, st);
+            else owner.push_back(i);
         }
         if (!owner.empty()) {
             counts.assign(owner.size(), 0);
             for (size_t j = 0; j < owner.size(); ++j) {
                 const uint32_t i = owner[j];
-                ORAMA_TRY(check_params(&queries[i].params));
                 jobs.push_back(RangeJob{queries[i].refs, queries[i].n_refs, &queries[i].params,
                                         out_ids ? out_ids + (size_t)i * stride_k : nullptr,
                                         out_scores ? out_scores + (size_t)i * stride_k : nullptr, &out_n[i], &counts[j]});
             }
-            ORAMA_ON_DEVICE(p->ctx->device);
-            std::shared_lock<std::shared_mutex> lk(p->mu);
-            ScratchLease sc(p->ctx);
-            ORAMA_TRY(sc.init());
-            ORAMA_TRY(post_search_ranges(p, sc.s.get(), jobs.data(), (uint32_t)jobs.size(), b, allow_bitmap, bitmap_bits,
-                                         apply_omc));
-            if (out_count)
-                for (size_t j = 0; j < owner.size(); ++j) out_count[owner[j]] = counts[j];
-        }
-    }
-    if (rest.empty()) return ORAMA_OK;
-    const uint32_t n_rest = (uint32_t)rest.size();
-    const uint32_t workers = std::max(1u, std::min(std::min(max_parallel ? max_parallel : 8u, n_rest), 64u));
-    std::atomic<uint32_t> next{0};
-    std::atomic<int> first_status{ORAMA_OK};
-    std::string first_error;
-    std::mutex err_mu;
-    auto work = [&]() {
-        for (;;) {
-            const uint32_t r = next.fetch_add(1);
-            if (r >= n_rest || first_status.load() != ORAMA_OK) return;
-            const uint32_t i = rest[r];
-            uint64_t cnt = 0;
-            const int st = post_search_impl(p, queries[i].refs, queries[i].n_refs, b, &queries[i].params, allow_bitmap,
-                                            bitmap_bits, nullptr, nullptr, 0, false, apply_omc,
-                                            out_ids ? out_ids + (size_t)i * stride_k : nullptr,
-                                            out_scores ? out_scores + (size_t)i * stride_k : nullptr, &out_n[i], &cnt);
-            if (out_count) out_count[i] = cnt;
-            if (st != ORAMA_OK) {
-                std::lock_guard<std::mutex> g(err_mu);
-                if (first_status.load() == ORAMA_OK) {
-                    first_status.store(st);
-                    first_error = orama_last_error();  // this worker's error slot
+            auto run = [&]() -> int {
+                ORAMA_ON_DEVICE(p->ctx->device);
+                ScratchLease sc(p->ctx);
+                ORAMA_TRY(sc.init());
+                return post_search_ranges(p, sc.s.get(), jobs.data(), (uint32_t)jobs.size(), b, allow_bitmap,
+                                                 bitmap_bits, apply_omc);
+            };
+            if (run() == ORAMA_OK) {
+                if (out_count)
+                    for (size_t j = 0; j < owner.size(); ++j) out_count[owner[j]] = counts[j];
+            } else {
+                // the set of launches failed as a whole: every query of it is answered (or refused) on its own below
+                for (uint32_t i : owner) {
+                    out_n[i] = 0;
+                    rest.push_back(i);
                 }
             }
         }
-    };
-    std::vector<std::thread> pool;
-    for (uint32_t w = 1; w < workers; ++w) pool.emplace_back(work);
-    work();  // the caller is worker 0
-    for (auto& t : pool) t.join();
-    if (first_status.load() != ORAMA_OK) set_error("%s", first_error.c_str());
-    return first_status.load();
+    }
+    if (!rest.empty()) {
+        const uint32_t n_rest = (uint32_t)rest.size();
+        const uint32_t workers = std::max(1u, std::min(std::min(max_parallel ? max_parallel : 8u, n_rest), 64u));
+        std::atomic<uint32_t> next{0};
+        std::mutex err_mu;
+        auto work = [&]() {
+            for (;;) {
+                const uint32_t r = next.fetch_add(1);
+                if (r >= n_rest) return;
+                const uint32_t i = rest[r];
+                uint64_t cnt = 0;
+                const int st = post_search_impl(p, queries[i].refs, queries[i].n_refs, b, &queries[i].params, allow_bitmap,
+                                                bitmap_bits, nullptr, nullptr, 0, false, apply_omc,
+                                                out_ids ? out_ids + (size_t)i * stride_k : nullptr,
+                                                out_scores ? out_scores + (size_t)i * stride_k : nullptr, &out_n[i], &cnt);
+                if (st == ORAMA_OK) {
+                    if (out_count) out_count[i] = cnt;
+                } else {
+                    std::lock_guard<std::mutex> g(err_mu);
+                    fail(i, st);  // this worker's error slot
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (uint32_t w = 1; w < workers; ++w) pool.emplace_back(work);
+        work();  // the caller is worker 0
+        for (auto& t : pool) t.join();
+    }
+    int first = ORAMA_OK;
+    for (uint32_t i = 0; i < n_queries; ++i) {
+        if (out_status) out_status[i] = status[i];
+        if (first == ORAMA_OK && status[i] != ORAMA_OK) {
+            first = status[i];
+            set_error("query %u: %s", i, errors[i].c_str());
+        }
+    }
+    return first;
+}
+
+int orama_post_search_batch(orama_post* p, const orama_post_query_desc* queries, uint32_t n_queries, float b,
+                            const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc, uint32_t max_parallel,
+                            uint32_t stride_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count) {
+    return post_search_batch_impl(p, queries, n_queries, b, allow_bitmap, bitmap_bits, apply_omc, max_parallel, stride_k,
+                                  out_ids, out_scores, out_n, out_count, nullptr);
+}
+
+int orama_post_search_batch_status(orama_post* p, const orama_post_query_desc* queries, uint32_t n_queries, float b,
+                                   const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc, uint32_t max_parallel,
+                                   uint32_t stride_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
+                                   uint64_t* out_count, int* out_status) {
+    ORAMA_REQUIRE(n_queries == 0 || out_status, "null status array");
+    return post_search_batch_impl(p, queries, n_queries, b, allow_bitmap, bitmap_bits, apply_omc, max_parallel, stride_k,
+                                  out_ids, out_scores, out_n, out_count, out_status);
 }
 
 int orama_post_search_hybrid(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, float b,
@@ -1345,6 +1394,7 @@ int orama_post_search_scores(orama_post* p, const orama_term_ref* refs, uint32_t
     h->count = count;
     h->generation = p->generation;
     if (out_count) *out_count = count;
+    h->lease.detach();  // the handle keeps the set until orama_scores_destroy: it no longer counts as an in-flight call
     *out_map = h.release();
     return ORAMA_OK;
 }

@@ -309,6 +309,9 @@ int orama_shard_group_create(const int* devices, uint32_t n_shards, uint32_t fla
     // communicator path anyway (one rank: real RCCL; several ranks on one device: only a loopback transport named by
     // ORAMA_RCCL_LIB accepts that — real RCCL reports the duplicate device from ncclCommInitAll)
     const bool colocated = all_same && !(flags & ORAMA_SHARD_FORCE_RCCL);
+    // co-located shards share ONE context and a sharded call leases one scratch set per shard: more shards than half the
+    // context's in-flight bound could never be served beside anything else (ORAMA_MAX_INFLIGHT, default 32)
+    ORAMA_SUPPORT(!colocated || n_shards <= 16, "a co-located group holds at most 16 shards (%u asked)", n_shards);
     std::unique_ptr<orama_shard_group> g(new (std::nothrow) orama_shard_group());
     if (!g) {
         set_error("out of host memory");

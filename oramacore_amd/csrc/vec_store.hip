@@ -963,10 +963,18 @@ int orama_vec_insert(orama_vec* v, const uint64_t* doc_ids, const float* rows, u
     }
     // shadow first: a search clamps the shadow's row count to this store's published count
     uint64_t a0 = 0, a1 = 0;
-    ORAMA_TRY(vec_insert_one(v->shadow.get(), doc_ids, rows, n_rows, &a0));
-    ORAMA_TRY(vec_insert_one(v, doc_ids, rows, n_rows, &a1));
-    ORAMA_REQUIRE(a0 == a1, "internal: the fp16 shadow accepted %llu rows, the store %llu", (unsigned long long)a0,
-                  (unsigned long long)a1);
+    const int st0 = vec_insert_one(v->shadow.get(), doc_ids, rows, n_rows, &a0);
+    const int st1 = st0 == ORAMA_OK ? vec_insert_one(v, doc_ids, rows, n_rows, &a1) : ORAMA_OK;
+    // The two-stage plan reranks shadow row i from fp32 row i: the two copies must hold the same rows at the same
+    // indices.  A failed insert (OOM, a HIP error) may have published some slabs in one copy only; from then on the
+    // indices disagree, so the plan is switched off for good and every search runs the plain fp32 scan.
+    if (st0 != ORAMA_OK || st1 != ORAMA_OK || a0 != a1 ||
+        v->shadow->n_rows.load(std::memory_order_acquire) != v->n_rows.load(std::memory_order_acquire))
+        v->shadow_ok.store(false, std::memory_order_release);
+    ORAMA_TRY(st0);
+    ORAMA_TRY(st1);
+    ORAMA_REQUIRE(a0 == a1, "internal: the fp16 shadow accepted %llu rows, the store %llu (two-stage plan switched off)",
+                  (unsigned long long)a0, (unsigned long long)a1);
     if (accepted) *accepted = a1;
     return ORAMA_OK;
 }

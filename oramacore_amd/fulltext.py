@@ -494,11 +494,13 @@ class PostingsStore(Owner):
         N.check(self._lib.orama_post_set_avg_len(self._h, avg.ctypes.data, avg.shape[0]))
 
     def search_batch(self, queries, total_documents: float, top_k: int, allow: AllowBitmap | None = None,
-                     apply_omc: bool = True, max_parallel: int = 8, b: float = B_DEFAULT, k: float = K1_DEFAULT):
+                     apply_omc: bool = True, max_parallel: int = 8, b: float = B_DEFAULT, k: float = K1_DEFAULT,
+                     statuses: bool = False):
         """queries: list of (refs, n_tokens, threshold | None[, top_k of this query <= top_k]).  One call
         (orama_post_search_batch): queries are scored 32 at a time by the range-partitioned scorer; those it does not
         take run on `max_parallel` library threads.  Returns a list of (ids, scores, count), each identical to `search`
-        of that query."""
+        of that query.  With `statuses` (orama_post_search_batch_status) nothing is raised for a failing query: the
+        result is (list, status array) and a failed query's entry is empty."""
         nq = len(queries)
         descs = (N.PostQueryDesc * max(nq, 1))()
         keep = []
@@ -514,10 +516,18 @@ class PostingsStore(Owner):
         out_n = np.zeros(max(nq, 1), dtype=np.uint32)
         out_count = np.zeros(max(nq, 1), dtype=np.uint64)
         bm_ptr, bm_bits = allow.ffi_args() if allow is not None else (None, 0)
-        N.check(self._lib.orama_post_search_batch(self._h, descs, nq, b, bm_ptr, bm_bits, 1 if apply_omc else 0,
-                                                  int(max_parallel), max(top_k, 1), out_ids.ctypes.data,
-                                                  out_sc.ctypes.data, out_n.ctypes.data, out_count.ctypes.data))
-        return [(out_ids[i, : out_n[i]].copy(), out_sc[i, : out_n[i]].copy(), int(out_count[i])) for i in range(nq)]
+        if statuses:
+            st = np.zeros(max(nq, 1), dtype=np.int32)
+            self._lib.orama_post_search_batch_status(self._h, descs, nq, b, bm_ptr, bm_bits, 1 if apply_omc else 0,
+                                                     int(max_parallel), max(top_k, 1), out_ids.ctypes.data,
+                                                     out_sc.ctypes.data, out_n.ctypes.data, out_count.ctypes.data,
+                                                     st.ctypes.data)
+        else:
+            N.check(self._lib.orama_post_search_batch(self._h, descs, nq, b, bm_ptr, bm_bits, 1 if apply_omc else 0,
+                                                      int(max_parallel), max(top_k, 1), out_ids.ctypes.data,
+                                                      out_sc.ctypes.data, out_n.ctypes.data, out_count.ctypes.data))
+        res = [(out_ids[i, : out_n[i]].copy(), out_sc[i, : out_n[i]].copy(), int(out_count[i])) for i in range(nq)]
+        return (res, st[:nq]) if statuses else res
 
     def search_scores(self, refs, n_tokens: int, total_documents: float, top_k: int, threshold=None,
                       allow: AllowBitmap | None = None, apply_omc: bool = True, b: float = B_DEFAULT,

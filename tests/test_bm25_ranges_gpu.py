@@ -326,3 +326,45 @@ def test_hybrid_on_the_range_scorer(ctx):
     assert count == 2 and ids.tolist() == td.tolist() and np.array_equal(bits(sc), bits(ts))
     flat.store.close()
     corpus.store.close()
+
+
+def test_a_failing_query_fails_alone(ctx):
+    """queries of a batch are independent.  A malformed query (list out of range, token index >= n_tokens,
+    top_k above the stride) gets its own status; every other query of the batch is answered exactly as alone."""
+    rng = np.random.default_rng(17)
+    n_docs = 8_000
+    corpus = Corpus(ctx, n_docs, random_lists(rng, n_docs, 12, 2, 50, 2000), [60.0, 12.0], seed=18)
+    good = [([(t, int(rng.integers(0, 12)), 1.0) for t in range(3)], 3, None, 10) for _ in range(40)]
+    bad = {5: ([(0, 99, 1.0)], 1, None, 10),             # list 99 does not exist
+           17: ([(3, 1, 1.0)], 2, None, 10),             # token 3 of a 2-token query
+           33: ([(0, 1, 1.0)], 1, None, 65)}             # top_k above the output stride (64)
+    queries = [bad.get(i, g) for i, g in enumerate(good)]
+    res, st = corpus.store.search_batch(queries, float(n_docs), 64, statuses=True)
+    for i, ((refs, n_tok, thr, k), (ids, sc, count)) in enumerate(zip(queries, res)):
+        if i in bad:
+            assert st[i] == oa._native.ORAMA_ERR_INVALID and len(ids) == 0 and count == 0, i
+            continue
+        assert st[i] == 0
+        od, os_, ocount = corpus.oracle(refs, n_tok, k, thr)
+        assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_)), i
+    # the single-status form reports the first failure and has still answered the rest
+    with pytest.raises(oa.OramaError, match="query 5"):
+        corpus.store.search_batch(queries, float(n_docs), 64)
+    corpus.store.close()
+
+
+def test_open_score_maps_do_not_starve_searches(ctx):
+    """an orama_scores handle keeps its scratch set until it is destroyed; such sets do not count against
+    the context's in-flight bound (32), so 40 open handles leave every other call servable."""
+    rng = np.random.default_rng(19)
+    n_docs = 3_000
+    corpus = Corpus(ctx, n_docs, random_lists(rng, n_docs, 6, 1, 50, 900), [40.0], seed=20)
+    refs = [(0, 0, 1.0), (1, 3, 1.0)]
+    maps = [corpus.store.search_scores(refs, 2, float(n_docs), 5) for _ in range(40)]
+    ids, sc, count = corpus.store.search(refs, 2, float(n_docs), 10)       # would wait for ever if handles counted
+    od, os_, ocount = corpus.oracle(refs, 2, 10)
+    assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
+    assert len(maps[39]) == ocount
+    for m in maps:
+        m.close()
+    corpus.store.close()

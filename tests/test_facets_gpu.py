@@ -120,6 +120,26 @@ def test_facet_counts_and_group_tops_equal_oracle(ctx, hybrid):
     post.close()
 
 
+def test_number_facet_counts_every_stored_number(ctx):
+    """The declared rule for number facets (assumption 7): `calculate_facet` is
+    `filter(Between).filter(contains_key).count()` with no de-duplication in-tree (number_field.rs:368-387), so a
+    document holding two numbers inside one range is counted twice, one number in each of two ranges once in both."""
+    d = np.arange(10, dtype=np.uint64)
+    post = ft.PostingsStore(ctx)
+    post.build(d, [5.0], [ft.PostingList(field=0, docs=d[:6], tf=np.ones(6, dtype=np.uint32), field_len=np.full(6, 5, np.uint32))])
+    sm = post.search_scores([(0, 0, 1.0)], 1, 10.0, 10)  # map = docs 0..5
+    ndocs = np.array([1, 1, 2, 2, 7, 7, 3], dtype=np.uint64)       # doc 7 is not in the map
+    nvals = np.array([10.0, 20.0, 10.0, 500.0, 10.0, 11.0, 100.0])
+    fld = ft.FacetField.numbers(post, ndocs, nvals)
+    got = sm.facet_count_ranges(fld, [(0, 100), (400, 600), (100, 100), (1000, 2000)])
+    assert got.tolist() == [2 + 1 + 1, 1, 1, 0]
+    assert got.tolist() == orc.facet_count_ranges(np.arange(6, dtype=np.uint64), ndocs, nvals,
+                                                  [(0, 100), (400, 600), (100, 100), (1000, 2000)]).tolist()
+    fld.close()
+    sm.close()
+    post.close()
+
+
 def test_group_top_large_bucket_and_nan_scores(ctx):
     """One group holding every document (rounds of the LDS-resident running top-k), max_results at the limit, and a
     map whose scores are all NaN (hybrid with max == min): groups come back empty, facet counts still count."""
