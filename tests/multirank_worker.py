@@ -162,7 +162,7 @@ def run_job(group: ShardGroup, shard_ids: list[int], world: int) -> dict:
     bm = oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[allow])
     res = [bm.to_device(group.ctx(li)) for li in range(nl)]
     vec = text_vector_map(doc_ids)
-    omc = {int(doc_ids[3]): 2.0, int(doc_ids[-2]): 4.0, int(doc_ids[5000]): 0.5}
+    omc = {int(doc_ids[3]): 2.0, int(doc_ids[-2]): 4.0, int(doc_ids[1000]): 0.5}
     for ci in TEXT_CASES:
         case = meta["cases"][ci]
         refs = refs_of(meta, list_id, case)

@@ -71,7 +71,7 @@ def expected(ctx):
         assert e[f"text{ci}"][2] == ocount and e[f"text{ci}"][0].tolist() == od.tolist()
         assert np.array_equal(bits(e[f"text{ci}"][1]), bits(os_))
         e[f"hyb{ci}"] = post.search(refs, n_tok, total, 30, threshold=case["threshold"], vector=vec, apply_omc=False)
-    post.set_omc({int(doc_ids[3]): 2.0, int(doc_ids[-2]): 4.0, int(doc_ids[5000]): 0.5})
+    post.set_omc({int(doc_ids[3]): 2.0, int(doc_ids[-2]): 4.0, int(doc_ids[1000]): 0.5})
     case = meta["cases"][12]
     e["omc"] = post.search(W.refs_of(meta, list_id, case), len(case["terms"]), total, 100)
     post.set_omc({})
