@@ -116,6 +116,12 @@ int launch_f16_prepare_queries(const float* d_queries, uint32_t q, uint32_t dim,
 // 2: 8 consumers of 3 x 2 tiles + 4 loaders.
 int launch_vec_scan_f16_pc(orama_ctx* ctx, const F16ScanArgs& a, void* d_query_frags, hipStream_t stream, int geometry);
 
+// K2q (vec_f16_qs.hip): the wide-batch scan with the queries stationary in registers — every wave keeps ONE 32-query
+// tile's B fragments for all k-steps in VGPRs, LDS holds only the corpus ring, the global->LDS traffic is the corpus once.
+// kpad <= 768 and 129..256 queries (vec_scan_f16_qs_supports); same arguments as K2d, the fragments must have been prepared.
+bool vec_scan_f16_qs_supports(uint32_t dim, uint32_t q);
+int launch_vec_scan_f16_qs(orama_ctx* ctx, const F16ScanArgs& a, void* d_query_frags, hipStream_t stream);
+
 // tau[j] = k-th best distance of list j when the list is full, else +inf; and seed the candidate lists
 // with the current best entries: cand[j][0..n_j) = (dist, row), cand_count[j] = n_j.
 int launch_f16_seed_candidates(const float* best_dist, const uint32_t* best_row, const uint32_t* best_n,

@@ -552,8 +552,12 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
             if (!wide_prepared)
                 ORAMA_TRY(launch_f16_prepare_queries(args.queries, args.q, args.dim, args.metric, sc->f16_bfrag.p, s));
             wide_prepared = true;
-            // f16_wide: 1 = K2c (MFMA waves also issue the DMA), 2.. = K2d (dedicated loader waves), geometry f16_wide-1
-            if (v->ctx->f16_wide >= 2) return launch_vec_scan_f16_pc(v->ctx, args, sc->f16_bfrag.p, s, v->ctx->f16_wide - 1);
+            // f16_wide: 1 = K2c (MFMA waves also issue the DMA), 2 / 3 = K2d (dedicated loader waves, geometry 1 / 2),
+            // 4 = K2q (queries stationary in registers; rows wider than its register budget and batches of <= 128 take K2d)
+            if (v->ctx->f16_wide >= 4 && vec_scan_f16_qs_supports(args.dim, args.q))
+                return launch_vec_scan_f16_qs(v->ctx, args, sc->f16_bfrag.p, s);
+            if (v->ctx->f16_wide >= 2)
+                return launch_vec_scan_f16_pc(v->ctx, args, sc->f16_bfrag.p, s, v->ctx->f16_wide >= 4 ? 1 : v->ctx->f16_wide - 1);
             return launch_vec_scan_f16_wide(v->ctx, args, sc->f16_bfrag.p, false, s);
         };
         const uint64_t s1 = std::min<uint64_t>(n, kS1);

@@ -143,17 +143,23 @@ def test_wide_batches_equal_solo_queries(ctx, d):
         st.delete(doc)
     bm = oa.AllowBitmap.from_mask((np.arange(2 * n + 2) % 7) != 3)
     queries = util.gaussian_rows(256, d, seed=60 + d)
-    for allow in (None, bm, None, None):  # repeated: the K2c pipeline is asynchronous (LDS DMA ring) — catch races
-        picks = (0, 31, 32, 63, 64, 69, 96, 100, 127, 128, 160, 199, 224, 255)
-        solo = {i: st.storage_search(queries[i], 30, allow) for i in picks}
-        for nq in (65, 70, 128, 129, 200, 256):
-            ids, dist, cnt = st.storage_search(queries[:nq], 30, allow)
-            assert cnt.tolist() == [30] * nq
-            for i in picks:
-                if i >= nq:
-                    continue
-                assert np.array_equal(ids[i], solo[i][0][0]), (nq, i)
-                assert np.array_equal(dist[i].view(np.uint32), solo[i][1][0].view(np.uint32)), (nq, i)
+    picks = (0, 31, 32, 63, 64, 69, 96, 100, 127, 128, 160, 199, 224, 255)
+    solos = {id(allow): {i: st.storage_search(queries[i], 30, allow) for i in picks} for allow in (None, bm)}
+    # every wide form: 4 = K2q (queries stationary in registers, the default), 2 / 3 = K2d geometries, 1 = K2c
+    for mode in (4, 2, 3, 1):
+        ctx.set_f16_wide(mode)
+        # repeated: the pipelines are asynchronous (LDS DMA rings) — catch races
+        for allow in ((None, bm, None, None) if mode == 4 else (None, bm)):
+            solo = solos[id(allow)]
+            for nq in ((65, 70, 128, 129, 200, 256) if mode == 4 else (70, 128, 256)):
+                ids, dist, cnt = st.storage_search(queries[:nq], 30, allow)
+                assert cnt.tolist() == [30] * nq
+                for i in picks:
+                    if i >= nq:
+                        continue
+                    assert np.array_equal(ids[i], solo[i][0][0]), (mode, nq, i)
+                    assert np.array_equal(dist[i].view(np.uint32), solo[i][1][0].view(np.uint32)), (mode, nq, i)
+    ctx.set_f16_wide(4)
     c16 = q16(corpus)
     ids, dist, cnt = st.storage_search(queries[:70], 30)
     for qi in (0, 69):
