@@ -103,7 +103,8 @@ int orama_ctx_set_scan_tuning(orama_ctx* ctx, int rows_per_wave, int blocks_per_
 int orama_ctx_set_f16_tuning(orama_ctx* ctx, int ksteps_per_chunk, int ring_chunks);
 /* Kernel used for fp16 batches of 65..256 queries per corpus pass: 0 = K2 in passes of 64, 1 = K2c (MFMA waves also
  * issue the LDS-DMA), 2 / 3 = K2d producer/consumer kernel, geometry 1 / 2 (vec_f16_pc.hip), 4 = K2q, queries
- * stationary in registers (vec_f16_qs.hip; rows wider than 768 dimensions take K2d).  Default 4.  Same results. */
+ * stationary in registers (vec_f16_qs.hip; batches of <= 128 and rows wider than 768 dimensions take K2d), 5 = K2h,
+ * two query tiles per wave with the K loop split over a wave pair (vec_f16_kh.hip).  Default 4.  Same results. */
 int orama_ctx_set_f16_wide(orama_ctx* ctx, int mode);
 /* Scorer of the BM25 searches over a resident store: 1 (default) = K3r, the document-range partitioned scorer that takes
  * whole query batches per launch (bm25_ranges.hip) — for the plain top-k search and, where no OMC applies, for

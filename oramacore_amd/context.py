@@ -88,7 +88,7 @@ class Context(Owner):
         N.check(self._lib.orama_ctx_set_bm25_ranges(self.handle, (1 if hybrid else 2) if on else 0))
 
     def set_f16_wide(self, mode: int) -> None:
-        """0 = K2 passes of 64, 1 = K2c, 2 / 3 = K2d geometry 1 / 2, 4 = K2q (default) (orama_ctx_set_f16_wide)."""
+        """0 = K2 passes of 64, 1 = K2c, 2 / 3 = K2d geometry 1 / 2, 4 = K2q (default), 5 = K2h (orama_ctx_set_f16_wide)."""
         N.check(self._lib.orama_ctx_set_f16_wide(self.handle, int(mode)))
 
     # --- HIP-event profiler (bench.py roofline leg)

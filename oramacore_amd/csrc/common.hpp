@@ -225,9 +225,10 @@ struct orama_ctx {
     // with the radix-select reduction of round 2 it wins at NS size: 4.51 -> 4.32 ms per scan.
     int fused_topk = 2;
     int f32_multi = 1;   // K1b: fp32 batches of 2..8 queries share one corpus pass (ORAMA_F32_MULTI=0 disables)
-    // fp16 batches of 65..256 queries share one corpus pass: 4 = K2q (queries stationary in registers, default; rows wider
-    // than 768 dimensions take K2d), 2 = K2d (dedicated loader waves), 3 = K2d second geometry, 1 = K2c (round 1: MFMA
-    // waves issue the DMA), 0 = K2 in passes of 64 (ORAMA_F16_WIDE)
+    // fp16 batches of 65..256 queries share one corpus pass: 4 = K2q (queries stationary in registers, default; batches of
+    // <= 128 and rows wider than 768 dimensions take K2d), 5 = K2h (K loop split over a wave pair), 2 = K2d (dedicated
+    // loader waves), 3 = K2d second geometry, 1 = K2c (round 1: MFMA waves issue the DMA), 0 = K2 in passes of 64
+    // (ORAMA_F16_WIDE)
     int f16_wide = 4;
     // plain BM25 top-k searches of a resident store use the range-partitioned scorer (K3r, bm25_ranges.hip);
     // 0 = always the per-document-record scorer K3 (ORAMA_BM25_RANGES, orama_ctx_set_bm25_ranges)

@@ -490,7 +490,7 @@ int orama_ctx_set_bm25_ranges(orama_ctx* ctx, int on) {
 
 int orama_ctx_set_f16_wide(orama_ctx* ctx, int mode) {
     ORAMA_REQUIRE(ctx, "null ctx");
-    ORAMA_REQUIRE(mode >= 0 && mode <= 4, "f16 wide mode %d outside [0, 4]", mode);
+    ORAMA_REQUIRE(mode >= 0 && mode <= 5, "f16 wide mode %d outside [0, 5]", mode);
     ctx->f16_wide = mode;
     return ORAMA_OK;
 }

@@ -122,6 +122,12 @@ int launch_vec_scan_f16_pc(orama_ctx* ctx, const F16ScanArgs& a, void* d_query_f
 bool vec_scan_f16_qs_supports(uint32_t dim, uint32_t q);
 int launch_vec_scan_f16_qs(orama_ctx* ctx, const F16ScanArgs& a, void* d_query_frags, hipStream_t stream);
 
+// K2h (vec_f16_kh.hip): queries stationary in registers, two query tiles per wave, the K loop of a tile split over two waves
+// that hand the accumulators on through LDS (one accumulator chain per output element, as everywhere else).  kpad a
+// multiple of 256 and <= 768, 129..256 queries (vec_scan_f16_kh_supports); same arguments as K2d.
+bool vec_scan_f16_kh_supports(uint32_t dim, uint32_t q);
+int launch_vec_scan_f16_kh(orama_ctx* ctx, const F16ScanArgs& a, void* d_query_frags, hipStream_t stream);
+
 // tau[j] = k-th best distance of list j when the list is full, else +inf; and seed the candidate lists
 // with the current best entries: cand[j][0..n_j) = (dist, row), cand_count[j] = n_j.
 int launch_f16_seed_candidates(const float* best_dist, const uint32_t* best_row, const uint32_t* best_n,

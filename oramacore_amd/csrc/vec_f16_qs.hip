@@ -30,59 +30,13 @@
 #include <type_traits>
 
 #include "device_utils.hpp"
+#include "vec_f16_async.hpp"
 
 namespace orama {
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-// 16 bytes per lane, global -> LDS, asynchronous (counted by vmcnt); lane l's data lands at LDS address m0 + 16 l.
-// m0 is an INPUT operand of the statement: the compiler materialises it and knows it is live; the leading s_nop is the
-// wait state gfx9 wants between a write of m0 and an LDS-DMA instruction reading it.
-__device__ __forceinline__ void qs_dma16_nt(uint64_t saddr_uniform, uint32_t voff, uint32_t lds_addr_uniform) {
-    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
-                 :
-                 : "v"(voff), "s"(saddr_uniform), "{m0}"(lds_addr_uniform)
-                 : "memory");
-}
-// 4 bytes per lane (lane l's dword lands at m0 + 4 l), from saddr + the lane's 32-bit byte offset (no 64-bit per-lane
-// pointer: such a pointer is loop-invariant, gets hoisted and then spilled next to the 192 fragment registers)
-__device__ __forceinline__ void qs_dma4(uint64_t saddr_uniform, uint32_t voff, uint32_t lds_addr_uniform) {
-    asm volatile("s_nop 0\n\tglobal_load_lds_dword %0, %1"
-                 :
-                 : "v"(voff), "s"(saddr_uniform), "{m0}"(lds_addr_uniform)
-                 : "memory");
-}
-// a wave-uniform 64-bit value that the compiler cannot know to be uniform (read from LDS): into scalar registers
-__device__ __forceinline__ uint64_t qs_uniform_u64(uint64_t v) {
-    return (uint64_t)uniform_u32((uint32_t)v) | ((uint64_t)uniform_u32((uint32_t)(v >> 32)) << 32);
-}
-// OR over the 64 lanes of a wave (wave-uniform result): the DPP steps of wave_sum (device_utils.hpp) within each row of 16
-// lanes, then the four row values through readlane
-template <int CTRL>
-__device__ __forceinline__ uint32_t qs_dpp_u32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
-__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
-    v |= qs_dpp_u32<0xB1>(v);
-    v |= qs_dpp_u32<0x4E>(v);
-    v |= qs_dpp_u32<0x141>(v);
-    v |= qs_dpp_u32<0x140>(v);
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
-           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-}
-template <int N>
-__device__ __forceinline__ void qs_wait_vmcnt() {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter on gfx9");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-// The stage barrier.  A raw s_barrier, not __syncthreads(): the fence of the latter drains lgkmcnt (the fragment reads
-// that run ahead across the barrier) and may drain vmcnt (the prefetch ring).  Nothing needs to be waited for here: the
-// reads of the buffer that is re-filled after this barrier fed MFMAs the wave has already issued, so they have returned.
-__device__ __forceinline__ void qs_stage_barrier() { asm volatile("s_barrier" ::: "memory"); }
+using namespace f16async;
 
 // KSTEPS = kpad / 16; NQT = 32-query tiles per block tile (8 or 4); KS k-steps per stage; NBUF stages in the ring
 template <int KSTEPS_, int NQT_, int KS_, int NBUF_, bool LAGGED_ = true, int RTW_ = 1, int P_ = 2>
@@ -112,7 +66,7 @@ struct QsCfg {
     static constexpr int kDeadOff = kMetaOff + kMetaBytes;         // [MB][64] tombstone words (a 64-lane dword DMA)
     static constexpr int kDeadBytes = MB * 256;
     static constexpr int kQOff = kDeadOff + kDeadBytes;            // [256] 1/|q| (or |q|^2), [256] threshold
-    static constexpr int kQBytes = 2 * 256 * 4;
+    static constexpr int kQBytes = 3 * 256 * 4;                  // + the fast-reject bound of the cosine form
     static constexpr int kFlushOff = kQOff + kQBytes;              // FlushArgs: what only a flush needs of the kernel arguments
     static constexpr int kStageOff = kFlushOff + 64;               // per wave: 64-bin histogram + kStageCap staged rows
     static constexpr int kStageFit = ((160 * 1024 - kStageOff) / kWaves - 256) / 12 / 16 * 16;  // 12 bytes per staged row
@@ -129,21 +83,6 @@ struct QsCfg {
     static_assert(kStageCap >= 64, "no room for the staging area (one accumulator row of a wave may pass 64 rows)");
     static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 };
-
-// The arguments only a flush reads.  Kept in LDS: as kernel arguments they would sit in 14 SGPRs for the whole launch, the
-// kernel runs out of SGPRs, and SGPR spills take vector registers the query fragments need (a fragment then lives in
-// scratch memory and every reload of it waits for the whole prefetch ring: vmcnt is in order).
-struct QsFlushArgs {
-    float* cand_dist;
-    uint32_t* cand_row;
-    uint32_t* cand_count;
-    uint64_t cand_stride;
-    const uint64_t* row_doc;
-    const uint64_t* allow;
-    uint64_t allow_bits;
-    uint32_t no_appends;
-};
-static_assert(sizeof(QsFlushArgs) <= 64, "FlushArgs slot");
 
 // DBG bits (timing ablations, ORAMA_K2C_DBG): 1 no MFMA, 2 no DMA, 8 no LDS fragment reads, 32 no epilogue, 16 = block 0 records
 // s_memtime stamps per step (waves 0 and 4: arrival at the barrier, release, DMA issued, stage multiplied, epilogue done —
@@ -174,6 +113,23 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_qs_kernel(F16ScanArg
     for (uint32_t i = tid; i < 256u; i += C::kThreads) {
         q_lds[i] = i < a.q ? qinv[i] : 0.0f;
         q_lds[256 + i] = (a.tau && i < a.q) ? a.tau[i] : -__builtin_huge_valf();
+        // Fast-reject bound of the cosine form.  A row passes iff fma(-s, fl(n qi), 1) < tau (s = the dot product, n = 1/|x|,
+        // qi = 1/|q|).  That implies s n qi > 1 - tau - 4e-7 (one rounding of the fma, |tau| <= 2), hence — two more
+        // roundings, fl(n qi) and fl(s n) — fl(s n) > (1 - tau - 1e-6) / qi for qi > 0: a tile none of whose rows reaches
+        // that bound (lowered by another 1e-6 relative for the division's own rounding) has no passing row.  One multiply
+        // and a running maximum per element instead of multiply, fma and minimum: the epilogue's arithmetic is VALU work
+        // beside a matrix pipe that already takes the package to its power limit (profiles/r03_power_energy.md).
+        float bound = __builtin_huge_valf();  // nothing passes: a column beyond the batch
+        if (a.tau && i < a.q) {
+            const float qv = qinv[i], tv = a.tau[i];
+            if (qv > 0.0f) {
+                bound = (1.0f - tv - 1e-6f) / qv;
+                bound -= fabsf(bound) * 1e-6f;
+            } else {
+                bound = 1.0f < tv ? -__builtin_huge_valf() : __builtin_huge_valf();  // a zero query is at distance 1 from every row
+            }
+        }
+        q_lds[512 + i] = bound;
     }
     QsFlushArgs* fl = reinterpret_cast<QsFlushArgs*>(lds + C::kFlushOff);
     if (!DENSE && tid == 0) {
@@ -192,6 +148,12 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_qs_kernel(F16ScanArg
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks)
         bq[ks] = *reinterpret_cast<const h8*>(bfrag + ((size_t)c * KSTEPS + ks) * 1024 + (size_t)lane * 16);
+    // The fragments are HERE before anything else is issued, and the compiler is told so: otherwise it keeps counting these
+    // loads as pending and may plant `s_waitcnt vmcnt(N)` in front of their first uses inside the K loop, where vmcnt also
+    // counts the DMA of the prefetch ring it knows nothing about: each of those waits would drain the ring.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(bq[ks]));
 
     // ---- loader state: fragment t = w + 8 j of a stage is row tile t / KS of the block tile, k-step t % KS of the stage
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -361,13 +323,23 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_qs_kernel(F16ScanArg
                 }
                 continue;
             } else {
-                // fast reject: the minimum of the 16 distances against the threshold, one ballot
-                float best = __builtin_huge_valf();
+                // fast reject, one ballot: the minimum of the 16 distances against the threshold (L2) / the maximum of the 16
+                // similarities s n against the column's bound (cosine: see q_lds[512 ..])
+                if constexpr (L2) {
+                    float best = __builtin_huge_valf();
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
+                    for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) best = fminf(best, dist_of(acc[i][4 * g4 + e], nv[g4][e], qi));
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(best < tau) == 0, 1)) continue;
+                        for (int e = 0; e < 4; ++e) best = fminf(best, dist_of(acc[i][4 * g4 + e], nv[g4][e], qi));
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(best < tau) == 0, 1)) continue;
+                } else {
+                    float top = -__builtin_huge_valf();
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) top = fmaxf(top, acc[i][4 * g4 + e] * nv[g4][e]);
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(top > q_lds[512 + col]) == 0, 1)) continue;
+                }
                 // slow path: bit r of m = accumulator row r of this lane passes (recomputed through an operand the
                 // optimiser cannot see through: nothing but the norms is kept from the fast path)
                 const uint32_t left = full ? 32u : (uint32_t)(a.row_end - (uint64_t)tile * 32);  // rows of the tile inside the store
@@ -579,9 +551,9 @@ int qs_launch(orama_ctx* ctx, const F16ScanArgs& a, const char* bfrag, const flo
 // drain the prefetch ring (vmcnt is in order).  Stages of 16 k-steps where kpad allows (16 KiB, 3 per block tile at 768
 // dimensions), else of 8.
 template <int KSTEPS>
-using QsWide = QsCfg<KSTEPS, 8, (KSTEPS % 16 == 0 ? 16 : 8), (KSTEPS % 16 == 0 ? 9 : 16)>;
+using QsWide = QsCfg<KSTEPS, 8, (KSTEPS % 16 == 0 ? 16 : 8), (KSTEPS == 48 ? 9 : (KSTEPS % 16 == 0 ? 8 : 14))>;
 template <int KSTEPS>
-using QsLock = QsCfg<KSTEPS, 8, (KSTEPS % 16 == 0 ? 16 : 8), (KSTEPS % 16 == 0 ? 8 : 16), false>;  // all waves in lock step (ORAMA_QS_LAG=0)
+using QsLock = QsCfg<KSTEPS, 8, (KSTEPS % 16 == 0 ? 16 : 8), (KSTEPS % 16 == 0 ? 8 : 14), false>;  // all waves in lock step (ORAMA_QS_LAG=0)
 
 template <int KSTEPS>
 int qs_dispatch(orama_ctx* ctx, const F16ScanArgs& a, const char* bfrag, const float* qinv, hipStream_t stream, int dbg) {

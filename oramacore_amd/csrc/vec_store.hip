@@ -553,11 +553,14 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
                 ORAMA_TRY(launch_f16_prepare_queries(args.queries, args.q, args.dim, args.metric, sc->f16_bfrag.p, s));
             wide_prepared = true;
             // f16_wide: 1 = K2c (MFMA waves also issue the DMA), 2 / 3 = K2d (dedicated loader waves, geometry 1 / 2),
-            // 4 = K2q (queries stationary in registers; rows wider than its register budget and batches of <= 128 take K2d)
-            if (v->ctx->f16_wide >= 4 && vec_scan_f16_qs_supports(args.dim, args.q))
-                return launch_vec_scan_f16_qs(v->ctx, args, sc->f16_bfrag.p, s);
-            if (v->ctx->f16_wide >= 2)
-                return launch_vec_scan_f16_pc(v->ctx, args, sc->f16_bfrag.p, s, v->ctx->f16_wide >= 4 ? 1 : v->ctx->f16_wide - 1);
+            // 4 = K2q where it applies (queries stationary in registers, one query tile per wave: 129..256 queries, rows of
+            // <= 768 dimensions) and K2d for everything else; 5 = K2h first (two query tiles per wave, the K loop split over a
+            // wave pair — same energy per pass as K2q and K2d, a little slower: kept as the experiment it is,
+            // profiles/r03_power_energy.md)
+            const int fw = v->ctx->f16_wide;
+            if (fw == 5 && vec_scan_f16_kh_supports(args.dim, args.q)) return launch_vec_scan_f16_kh(v->ctx, args, sc->f16_bfrag.p, s);
+            if (fw >= 4 && vec_scan_f16_qs_supports(args.dim, args.q)) return launch_vec_scan_f16_qs(v->ctx, args, sc->f16_bfrag.p, s);
+            if (fw >= 2) return launch_vec_scan_f16_pc(v->ctx, args, sc->f16_bfrag.p, s, fw >= 4 ? 1 : fw - 1);
             return launch_vec_scan_f16_wide(v->ctx, args, sc->f16_bfrag.p, false, s);
         };
         const uint64_t s1 = std::min<uint64_t>(n, kS1);

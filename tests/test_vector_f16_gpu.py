@@ -145,8 +145,9 @@ def test_wide_batches_equal_solo_queries(ctx, d):
     queries = util.gaussian_rows(256, d, seed=60 + d)
     picks = (0, 31, 32, 63, 64, 69, 96, 100, 127, 128, 160, 199, 224, 255)
     solos = {id(allow): {i: st.storage_search(queries[i], 30, allow) for i in picks} for allow in (None, bm)}
-    # every wide form: 4 = K2q (queries stationary in registers, the default), 2 / 3 = K2d geometries, 1 = K2c
-    for mode in (4, 2, 3, 1):
+    # every wide form: 4 = K2q (queries stationary in registers, the default), 5 = K2h (K loop split over a wave pair),
+    # 2 / 3 = K2d geometries, 1 = K2c
+    for mode in (4, 5, 2, 3, 1):
         ctx.set_f16_wide(mode)
         # repeated: the pipelines are asynchronous (LDS DMA rings) — catch races
         for allow in ((None, bm, None, None) if mode == 4 else (None, bm)):
