@@ -276,7 +276,7 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
                    "valid": bool(valid)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": ("vec_scan_f16_pc_kernel" if f16 and qb > 64 else kern + "_kernel"),
+                     "kernel": (("vec_scan_f16_qs_kernel" if qb > 128 and dim <= 768 else "vec_scan_f16_pc_kernel") if f16 and qb > 64 else kern + "_kernel"),
                      "alg_bytes_per_launch": alg_bytes,
                      "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_n,
                      "scan_launches_per_step": launches_per_step,

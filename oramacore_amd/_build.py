@@ -8,7 +8,9 @@ without a GPU, so this is also the CPU-side "does it build" check.
 from __future__ import annotations
 
 import hashlib
+import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -29,6 +31,9 @@ COMMON_FLAGS = [
     "-fPIC",
     "-Wall",
     "-Wno-unused-result",
+    # one remark block per kernel (registers, scratch, LDS, occupancy): parsed into csrc/build/<tu>.resources.json, which
+    # tests/test_kernel_resources.py reads — a scan kernel that spills is a build regression, not a profile finding
+    "-Rpass-analysis=kernel-resource-usage",
     f"-I{INCLUDE}",
     f"-I{CSRC}",
 ]
@@ -59,6 +64,44 @@ def _fingerprint() -> str:
     return h.hexdigest()
 
 
+_REMARK = re.compile(r"remark: (?:[^:]+:\d+:\d+: )?\s*(Function Name|SGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Dynamic Stack|"
+                     r"Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]): (\S+)")
+_KEYS = {"SGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
+         "Dynamic Stack": "dynamic_stack", "Occupancy [waves/SIMD]": "occupancy_waves_per_simd", "SGPRs Spill": "sgpr_spills",
+         "VGPRs Spill": "vgpr_spills", "LDS Size [bytes/block]": "lds_bytes_per_block"}
+
+
+def parse_resource_remarks(stderr: str) -> tuple[list[dict], str]:
+    """(kernels, everything else): the -Rpass-analysis=kernel-resource-usage blocks of one compile as records
+    {name (mangled), vgprs, agprs, sgprs, scratch_bytes_per_lane, dynamic_stack, occupancy_waves_per_simd, ...}."""
+    kernels: list[dict] = []
+    rest = []
+    in_remark = False
+    for line in stderr.splitlines():
+        m = _REMARK.search(line)
+        if not m:
+            if "[-Rpass-analysis=kernel-resource-usage]" in line:
+                in_remark = True
+            elif in_remark and re.match(r"\s*\d*\s*\|", line):
+                pass  # the source line / caret a remark is printed with
+            else:
+                in_remark = False
+                rest.append(line)
+            continue
+        in_remark = True
+        key, val = m.group(1), m.group(2)
+        if key == "Function Name":
+            kernels.append({"name": val})
+        elif kernels:
+            kernels[-1][_KEYS[key]] = (val == "True") if key == "Dynamic Stack" else int(val)
+    return kernels, "\n".join(rest)
+
+
+def kernel_resources() -> dict[str, list[dict]]:
+    """{translation unit: [kernel record, ...]} of the library as last built (csrc/build/*.resources.json)."""
+    return {p.name[: -len(".resources.json")]: json.loads(p.read_text()) for p in sorted(OBJ_DIR.glob("*.resources.json"))}
+
+
 def native_is_fresh() -> bool:
     stamp = OBJ_DIR / "fingerprint"
     return LIB.exists() and stamp.exists() and stamp.read_text() == _fingerprint()
@@ -78,8 +121,10 @@ def build_native(force: bool = False, verbose: bool = True) -> Path:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
-        if verbose and r.stderr.strip():
-            sys.stderr.write(r.stderr)
+        kernels, rest = parse_resource_remarks(r.stderr)
+        (OBJ_DIR / (src.stem + ".resources.json")).write_text(json.dumps(kernels, indent=1))
+        if verbose and rest.strip():
+            sys.stderr.write(rest + "\n")
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:

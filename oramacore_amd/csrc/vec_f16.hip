@@ -21,14 +21,16 @@
 #include <cstdlib>
 
 #include "device_utils.hpp"
+#include "vec_f16_async.hpp"
 
 namespace orama {
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef float f4 __attribute__((ext_vector_type(4)));
+using f16async::f16v;
+using f16async::f4;
+using f16async::h8;
+using f16async::wave_or_u32;
 
 constexpr int kBlock = 512;          // 8 waves: 2 per SIMD
 constexpr int kWavesPerBlock = kBlock / 64;
@@ -210,7 +212,11 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
         staged = 0;
     };
 
-    auto epilogue = [&](uint64_t tile) {
+    // Filter mode: `start` = 16 qt + r of the first accumulator row still to be looked at; returns 16 NQT when the tile is
+    // done, else the position at which the staging area ran full — the caller flushes (at a point where nothing of the
+    // epilogue is live: inlined into the row loop the flush needs registers the prefetch ring does not leave, and a spilled
+    // value's reload waits for the whole ring: vmcnt is in order) and calls again.  Dense mode: always done.
+    auto epilogue = [&](uint64_t tile, uint32_t start) -> uint32_t {
         // this lane's 16 accumulator rows are (r & 3) + 8 (r >> 2) + 4 hi_half: four 16-byte LDS reads of the record.
         // The statement takes an accumulator as a (never used) operand so that it stays behind the tile's last MFMA
         // and with it behind the counted wait described above.
@@ -232,11 +238,10 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
         }
         const uint32_t hi4 = (lane >> 5) ? 4u : 0u;
         const bool full = tile * 32 + 32 <= a.row_end;  // wave-uniform: only the last tile of the store is partial
-        f16v nrmv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) nrmv[r] = n4[r >> 2][r & 3];
+        const uint32_t left = full ? 32u : (uint32_t)(a.row_end - tile * 32);  // rows of the tile inside the store
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) {
+            if (!DENSE && (uint32_t)(qt + 1) * 16u <= start) continue;  // done before the flush
             const uint32_t j = qt * 32 + (lane & 31);
             const bool live = j < a.q;  // (a predicate, not a branch: the staging below is wave-synchronous)
             if (DENSE && !live) continue;
@@ -248,7 +253,6 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
             auto dist_of = [&](float dot, float n, float qv) -> float {
                 return l2 ? __builtin_fmaf(-2.0f, dot, qv + n) : __builtin_fmaf(-dot, n * qv, 1.0f);
             };
-            auto distance = [&](int r) -> float { return dist_of(acc[qt][r], nrmv[r], qi); };
             if constexpr (DENSE) {  // the head of the store: every distance is written, NaN = excluded
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -261,23 +265,23 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
                         excluded = doc >= a.allow_bits || !((a.allow[doc >> 6] >> (doc & 63)) & 1ull);
                     }
                     a.out_dense[(uint64_t)j * a.dense_stride + (row - a.row_begin)] =
-                        excluded ? __builtin_nanf("") : distance(r);
+                        excluded ? __builtin_nanf("") : dist_of(acc[qt][r], n4[r >> 2][r & 3], qi);
                 }
                 continue;
             }
             // filter mode, fast reject: almost no row beats the running k-th best distance, so take the minimum of the
             // 16 distances first and look closer only when it passes.
             if (a.dbg & 8u) {  // timing ablation: metadata read only
-                if (nrmv[0] + nrmv[5] + nrmv[10] + nrmv[15] == 12345.678f) a.cand_count[0] = 1;
+                if (n4[0][0] + n4[1][1] + n4[2][2] + n4[3][3] == 12345.678f) a.cand_count[0] = 1;
                 continue;
             }
             float best = __builtin_huge_valf();
             if (l2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) best = fminf(best, __builtin_fmaf(-2.0f, acc[qt][r], qi + nrmv[r]));
+                for (int r = 0; r < 16; ++r) best = fminf(best, __builtin_fmaf(-2.0f, acc[qt][r], qi + n4[r >> 2][r & 3]));
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) best = fminf(best, __builtin_fmaf(-acc[qt][r], nrmv[r] * qi, 1.0f));
+                for (int r = 0; r < 16; ++r) best = fminf(best, __builtin_fmaf(-acc[qt][r], n4[r >> 2][r & 3] * qi, 1.0f));
             }
             if (a.dbg & 4u) {  // timing ablation: fast reject only, never the slow path
                 if (best == 12345.678f) a.cand_count[0] = 1;
@@ -290,37 +294,52 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
             // above — or hoisted into it — the 16 values would live in scratch memory: stores on every tile, loads here)
             float qi_s = qi;
             asm volatile("" : "+v"(qi_s));
-            const uint32_t dw = dead_word >> hi4;
+            const uint32_t alive = (~dead_word & (left >= 32u ? ~0u : ((1u << left) - 1u))) >> hi4;
             uint32_t m = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t i = (uint32_t)((r & 3) + 8 * (r >> 2));
-                const float d = dist_of(acc[qt][r], nrmv[r], qi_s);
-                const bool pass = live && d < tau && !((dw >> i) & 1u) && (full || tile * 32 + i + hi4 < a.row_end);
-                m |= (pass ? 1u : 0u) << r;
+                const float d = dist_of(acc[qt][r], n4[r >> 2][r & 3], qi_s);
+                m |= ((live && d < tau ? 1u : 0u) & (alive >> i)) << r;
             }
+            // the accumulator rows somebody passes (usually one or two of the 16): OR over the wave, then only those —
             // element by element with a wave-uniform index (a per-lane index into the accumulators would go through
             // scratch memory, whose loads wait on vmcnt like the appends this staging exists to avoid)
+            uint32_t any = wave_or_u32(m);
+            if (start > (uint32_t)qt * 16u) any &= ~0u << (start - (uint32_t)qt * 16u);  // resuming after a flush
 #pragma unroll 1
-            for (int r = 0; r < 16; ++r) {
+            while (any) {
+                const uint32_t r = (uint32_t)__builtin_ctz(any);
                 const bool mine = (m >> r) & 1u;
                 const uint64_t bal = __builtin_amdgcn_ballot_w64(mine);
-                if (!bal) continue;
+                const uint32_t n_pass = (uint32_t)__popcll(bal);
+                if (staged + n_pass > cap) return (uint32_t)qt * 16u + r;  // no room: flush, then resume here
+                any &= any - 1u;
                 if (mine) {
-                    const float sa = acc[qt][r], sn = nrmv[r];
-                    const float dist = dist_of(sa, sn, qi_s);
+                    // (the norm of this one row again, from the record in LDS: a run-time index into the four norm
+                    // registers quads would put them in scratch memory)
+                    const float nr = *reinterpret_cast<const float*>(meta + (size_t)m_r * kF16MetaBytes + (size_t)(((r & 3u) + 8u * (r >> 2)) + hi4) * 4);
+                    const float dist = dist_of(acc[qt][r], nr, qi_s);
                     const uint32_t pos =
                         staged + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                     stage[pos] = __float_as_uint(dist);
-                    stage[cap + pos] = (uint32_t)(tile * 32) + (uint32_t)((r & 3) + 8 * (r >> 2)) + hi4;
+                    stage[cap + pos] = (uint32_t)(tile * 32) + ((r & 3u) + 8u * (r >> 2)) + hi4;
                     stage[2 * cap + pos] = j;
                 }
-                staged = uniform_u32(staged + (uint32_t)__popcll(bal));
-                if (staged > cap - 64) {
-                    wave_fence();
-                    flush();
-                }
+                staged = uniform_u32(staged + n_pass);
             }
+        }
+        return 16u * NQT;
+    };
+    auto finish_tile = [&](uint64_t tile) {
+        uint32_t at = 0;
+        while ((at = epilogue(tile, at)) < 16u * NQT) {
+            wave_fence();
+            flush();
+        }
+        if (!DENSE && staged > cap - 64) {  // keep a tile's usual few rows' worth of room
+            wave_fence();
+            flush();
         }
     };
 
@@ -353,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
                     for (int r = 0; r < 16; ++r) sum += acc[qt][r];
                 if (sum == 12345.678f) a.cand_count[0] = 1;
             } else {
-                epilogue(cp_tile);
+                finish_tile(cp_tile);
             }
             cp_c = 0;
             cp_tile += tile_step;
@@ -365,19 +384,14 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f16_kernel(F16ScanArgs a, uin
     load_meta();  // the record of the first tile (the one "group -1" would have brought)
 #pragma unroll
     for (int b = 0; b < NBUF - 1; ++b) load_chunk(buf[b]);
-    uint64_t g = 0;
-    for (; g + NBUF <= total; g += NBUF) {
+    // ONE loop, no separate tail: the loads are unconditional anyway (past the end the cursor re-reads the wave's last chunk),
+    // so the last trip just skips the chunks that do not exist.  (A tail that picked the ring up where the loop left it made
+    // the register allocator carry the prologue's chunks around the loop in scratch memory.)
+    for (uint64_t g = 0; g < total; g += NBUF) {
 #pragma unroll
         for (int b = 0; b < NBUF; ++b) {
             load_chunk(buf[(b + NBUF - 1) % NBUF]);
-            compute_chunk(buf[b]);
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < NBUF - 1; ++b) {  // tail: total - g < NBUF chunks, already in flight
-        if (g + b < total) {
-            load_chunk(buf[(b + NBUF - 1) % NBUF]);
-            compute_chunk(buf[b]);
+            if (g + b < total) compute_chunk(buf[b]);
         }
     }
     if (!DENSE && staged) {

@@ -30,13 +30,15 @@
 #include <type_traits>
 
 #include "device_utils.hpp"
+#include "vec_f16_async.hpp"
 
 namespace orama {
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f16v __attribute__((ext_vector_type(16)));
+using f16async::f16v;
+using f16async::h8;
+using f16async::wave_or_u32;
 
 // 16 bytes per lane, global -> LDS, asynchronous (counted by vmcnt); lane l's data lands at LDS address m0 + 16 l.
 // m0 is an INPUT operand of the statement ("{m0}"): the compiler materialises it and knows it is live; the leading
@@ -294,18 +296,24 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_pc_kernel(F16ScanArg
         staged = 0;
     };
 
-    auto epilogue = [&](uint64_t bt, uint32_t par) {
+    // Filter mode: `start` = 16 (i CT + j) + r of the first accumulator row still to be looked at; returns 16 RT CT when the
+    // block tile is done, else the position at which the staging area ran full — the caller flushes (at a point where nothing
+    // of the epilogue is live: inlined into the row loop the flush cost the default geometry 8 bytes of scratch per lane,
+    // and a spilled value's reload waits on vmcnt) and calls again.  Dense mode: always done.
+    auto epilogue = [&](uint64_t bt, uint32_t par, uint32_t start) -> uint32_t {
         const uint32_t hi = (lane >> 5) ? 4u : 0u;
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             const uint32_t tl = (uint32_t)(wr * RT + i);
             const uint64_t tile = t_first + bt * C::kRowTiles + tl;
             if (tile >= t_end) continue;  // wave-uniform
+            if (!DENSE && (uint32_t)(i + 1) * CT * 16u <= start) continue;  // done before the flush
             const uint32_t dead_word = a.dead ? dead_lds[par * 64 + tl] : 0u;
             // this lane's 16 accumulator rows are (r & 3) + 8 (r >> 2) + hi: four 16-byte reads of the tile's norms
+            const float* nrm = inv_lds + par * 256 + tl * 32 + hi;
             f16v nrmv;
             {
-                const f4* np = reinterpret_cast<const f4*>(inv_lds + par * 256 + tl * 32 + hi);
+                const f4* np = reinterpret_cast<const f4*>(nrm);
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f4 v = np[2 * g4];
@@ -314,20 +322,10 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_pc_kernel(F16ScanArg
                 }
             }
             const bool full = tile * 32 + 32 <= a.row_end;
-            // bit r: accumulator row r of this lane is a live row of the store (branch-free: as short-circuit tests
-            // the 16 partial results went through scratch memory)
-            uint32_t rowmask = 0;
-            if (!DENSE) {
-                const uint32_t dw = dead_word >> hi;
-                const uint32_t left = full ? 32u : (uint32_t)(a.row_end - tile * 32);  // rows of the tile inside the store
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t ri = (uint32_t)((r & 3) + 8 * (r >> 2));
-                    rowmask |= ((~(dw >> ri)) & (ri + hi < left ? 1u : 0u) & 1u) << r;
-                }
-            }
+            const uint32_t left = full ? 32u : (uint32_t)(a.row_end - tile * 32);  // rows of the tile inside the store
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
+                if (!DENSE && (uint32_t)(i * CT + j + 1) * 16u <= start) continue;  // done before the flush
                 const uint32_t cl = (uint32_t)j * 32 + (lane & 31);  // column inside this consumer's group
                 const uint32_t col = col0 + cl;
                 const bool live = col < a.q;
@@ -367,27 +365,41 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_pc_kernel(F16ScanArg
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(live && best < tau) == 0, 1)) continue;
                 float qi_s = qi;  // (an operand the optimiser cannot see through: nothing is kept from the fast path)
                 asm volatile("" : "+v"(qi_s));
+                const uint32_t alive = (~dead_word & (left >= 32u ? ~0u : ((1u << left) - 1u))) >> hi;
                 uint32_t m = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m |= (dist_of(acc[i][j][r], nrmv[r], qi_s) < tau ? 1u : 0u) << r;
-                m = live ? (m & rowmask) : 0u;
+                for (int r = 0; r < 16; ++r)
+                    m |= ((live && dist_of(acc[i][j][r], nrmv[r], qi_s) < tau ? 1u : 0u) & (alive >> ((r & 3) + 8 * (r >> 2)))) << r;
+                // the accumulator rows somebody passes (usually one or two of the 16): OR over the wave, then only those, with
+                // a wave-uniform index into the accumulators
+                uint32_t any = wave_or_u32(m);
+                const uint32_t base = (uint32_t)(i * CT + j) * 16u;
+                if (start > base) any &= ~0u << (start - base);  // resuming after a flush
 #pragma unroll 1
-                for (int r = 0; r < 16; ++r) {  // wave-uniform index into the accumulators
+                while (any) {
+                    const uint32_t r = (uint32_t)__builtin_ctz(any);
                     const bool mine = (m >> r) & 1u;
                     const uint64_t bal = __builtin_amdgcn_ballot_w64(mine);
-                    if (!bal) continue;
+                    const uint32_t n_pass = (uint32_t)__popcll(bal);
+                    if (staged + n_pass > kCap) return base + r;  // no room: flush, then resume here
+                    any &= any - 1u;
                     if (mine) {
                         const uint32_t pos =
                             staged + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                        st_dist[pos] = __float_as_uint(dist_of(acc[i][j][r], nrmv[r], qi_s));
-                        st_row[pos] = (uint32_t)(tile * 32) + (uint32_t)((r & 3) + 8 * (r >> 2)) + hi;
+                        st_dist[pos] = __float_as_uint(dist_of(acc[i][j][r], nrm[(r & 3u) + 8u * (r >> 2)], qi_s));
+                        st_row[pos] = (uint32_t)(tile * 32) + ((r & 3u) + 8u * (r >> 2)) + hi;
                         st_col[pos] = (uint8_t)cl;
                     }
-                    staged = uniform_u32(staged + (uint32_t)__popcll(bal));
-                    if (staged > kCap - 64) flush();
+                    staged = uniform_u32(staged + n_pass);
                 }
             }
         }
+        return 16u * RT * CT;
+    };
+    auto finish_tile = [&](uint64_t bt, uint32_t par) {
+        uint32_t at = 0;
+        while ((at = epilogue(bt, par, at)) < 16u * RT * CT) flush();
+        if (!DENSE && staged > kCap - 64) flush();  // room for a block tile's usual few rows
     };
 
     const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -448,7 +460,7 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_pc_kernel(F16ScanArg
         if (tr) trace[g * 8 + 5] = __builtin_amdgcn_s_memtime();
         if (++cp_s == S) {
             if (DBG == 0 || DBG == 16) {
-                epilogue(cp_bt, cp_par);
+                finish_tile(cp_bt, cp_par);
                 if (tr) trace[g * 8 + 6] = __builtin_amdgcn_s_memtime();
             } else {  // ablation builds: keep every accumulator alive
                 float sum = 0.0f;
@@ -470,15 +482,16 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_pc_kernel(F16ScanArg
     if (TRACE && w == 0 && lane == 0) trace[8192 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
 }
 
-template <class C, int DBG>
+template <class C, int DBG, bool WITH_DENSE = true>
 int pc_launch(orama_ctx* ctx, const F16ScanArgs& a, const char* bfrag, const float* qinv, uint32_t ksteps,
               hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
         ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_pc_kernel<C, DBG, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_pc_kernel<C, DBG, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if constexpr (WITH_DENSE)
+            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f16_pc_kernel<C, DBG, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     const uint64_t tiles = ((a.row_end + 31) >> 5) - (a.row_begin >> 5);
@@ -490,10 +503,13 @@ int pc_launch(orama_ctx* ctx, const F16ScanArgs& a, const char* bfrag, const flo
         if (e) trace = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 16));
         ORAMA_REQUIRE(trace, "trace build needs ORAMA_K2D_TRACE");
     }
-    if (a.out_dense)
-        hipLaunchKernelGGL((vec_scan_f16_pc_kernel<C, DBG, true>), dim3((uint32_t)blocks), dim3(C::kThreads), C::kLdsBytes,
-                           stream, a, bfrag, qinv, ksteps, f16_tile_bytes(a.dim), trace);
-    else
+    if (a.out_dense) {
+        if constexpr (WITH_DENSE)
+            hipLaunchKernelGGL((vec_scan_f16_pc_kernel<C, DBG, true>), dim3((uint32_t)blocks), dim3(C::kThreads), C::kLdsBytes,
+                               stream, a, bfrag, qinv, ksteps, f16_tile_bytes(a.dim), trace);
+        else
+            ORAMA_REQUIRE(false, "this geometry has no dense form");
+    } else
         hipLaunchKernelGGL((vec_scan_f16_pc_kernel<C, DBG, false>), dim3((uint32_t)blocks), dim3(C::kThreads), C::kLdsBytes,
                            stream, a, bfrag, qinv, ksteps, f16_tile_bytes(a.dim), trace);
     ORAMA_HIP_TRY(hipGetLastError());
@@ -546,7 +562,8 @@ int launch_vec_scan_f16_pc(orama_ctx* ctx, const F16ScanArgs& a_in, void* d_quer
         }
     }
     if (a.q <= 128) return pc_launch<PcA2, 0>(ctx, a, bfrag, qinv, ksteps, stream);
-    if (geometry == 2) return pc_launch<PcD, 0>(ctx, a, bfrag, qinv, ksteps, stream);
+    // (the 3x2 ablation geometry's dense form needs 16 bytes of scratch per lane: dense output always takes the default one)
+    if (geometry == 2 && !a.out_dense) return pc_launch<PcD, 0, false>(ctx, a, bfrag, qinv, ksteps, stream);
     return pc_launch<PcB, 0>(ctx, a, bfrag, qinv, ksteps, stream);
 }
 
