@@ -132,10 +132,15 @@ def vec_two_stage_ok(dim: int, k: int) -> bool:
     return dim % 4 == 0 and dim <= 1024 and 2 * k <= 4096
 
 
-def two_stage_leg(oa, ctx, plain, dim, n_local, k, qb, queries_h, lo, rank) -> dict:
-    """Host-buffer API, one call per query batch: plain fp32 store vs fp32 rows + fp16 shadow (DTYPE_F32_SHADOW16)."""
+def shadow_store(oa, ctx, dim, n_local, lo, rank):
+    """The north-star rows again, in a store that also keeps an fp16 copy of them (DTYPE_F32_SHADOW16, +50 % HBM)."""
     st = oa.EmbeddingFieldStorage(ctx, dimensions=dim, reserve_rows=n_local, dtype=oa.DTYPE_F32_SHADOW16)
     st.fill_synthetic(n_local, seed=0xC0FFEE + rank, first_doc_id=lo)
+    return st
+
+
+def two_stage_leg(oa, ctx, plain, st, dim, k, qb, queries_h) -> dict:
+    """Host-buffer API, one call per query batch: plain fp32 store vs fp32 rows + fp16 shadow (`st`, closed here)."""
     nq = min(40, queries_h.shape[0] // qb)
     identical = True
     for i in range(3):
@@ -304,9 +309,10 @@ def host_api_latency(store, queries_h, qb, k, n=50) -> dict:
 
 
 # ---------------------------------------------------------------------------------------------- C4: hybrid
-def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12) -> dict:
+def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, shadow=None) -> dict:
     """BASELINE configs[3]: 10 M-doc BM25F (12-token queries) + the 10 M x 768 fp32 scan, min-max merge, top-100.
-    `vec` is the north-star store (same rows).  Synthetic postings per SURVEY §8d, generated in HBM."""
+    `vec` is the north-star store (same rows), `shadow` the same rows with an fp16 copy (the vector leg takes the
+    two-stage plan there; answers must be identical).  Synthetic postings per SURVEY §8d, generated in HBM."""
     from oramacore_amd import fulltext as ft
 
     T = tokens
@@ -322,31 +328,61 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12) 
     qlists = [rng.choice(len(ranks), size=T, replace=False) for _ in range(total)]
     refs = [[(t, int(l), 1.0) for t, l in enumerate(ql)] for ql in qlists]
 
-    def hybrid(i):  # one call: vector leg and BM25 leg overlap on two HIP streams
-        return post.hybrid_search(vec, qv[i], k, 0.0, refs[i], T, float(n), k)
+    def hybrid(i, store=vec):  # one call: vector leg and BM25 leg overlap on two HIP streams
+        return post.hybrid_search(store, qv[i], k, 0.0, refs[i], T, float(n), k)
 
     for i in range(warmup):
         hybrid(i)
     ctx.synchronize()
     ctx.prof_reset()
     ctx.prof_enable(True)
+    plain_results = []
     t0 = time.perf_counter()
     for i in range(warmup, total):
         h_ids, h_sc, h_count = hybrid(i)
+        plain_results.append((h_ids, h_sc, h_count))
     ctx.synchronize()
     el_h = time.perf_counter() - t0
     ctx.prof_enable(False)
     scan_ms, scan_n = ctx.prof_get("vec_scan_f32")
+    k3_launches = ctx.prof_get("bm25_accumulate")[1]  # 0 = every query took the range scorer + candidate tail
+    shadow_out = None
+    if shadow is not None:
+        for i in range(warmup):
+            hybrid(i, shadow)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        s_results = [hybrid(i, shadow) for i in range(warmup, total)]
+        ctx.synchronize()
+        el_s = time.perf_counter() - t0
+        same = all(a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+                   for a, b in zip(plain_results, s_results))
+        assert same, "hybrid answers on the shadow store differ from the plain store's"
+        shadow_out = {"value": steps / el_s, "unit": "queries/s", "ms_per_step": el_s / steps * 1e3,
+                      "identical_to_plain_store": same,
+                      "note": "same call on the store with an fp16 shadow: the vector leg is the two-stage plan"}
 
     # BM25 alone: the batch entry (K3r scores 32 queries per set of launches) and single-query calls
-    batch_q = [(refs[i], T, None) for i in range(warmup, total)] * max(1, 1024 // max(steps, 1))
+    batch_q = [(refs[i], T, None) for i in range(warmup, total)] * max(1, 2048 // max(steps, 1))
     post.search_batch(batch_q[:64], float(n), k)
+    prep = post.prepare_batch(batch_q, float(n), k)  # descriptors marshalled once, as a native caller holds them
+    prep.run()
+    t0 = time.perf_counter()
+    prep.run()
+    el_bb = time.perf_counter() - t0
+    b_res = prep.results()
+    t0 = time.perf_counter()
+    post.search_batch(batch_q, float(n), k)
+    el_bb_py = time.perf_counter() - t0
+    # device time per query: chunks of 32 one at a time (a longer batch double-buffers its chunks on two streams, and
+    # concurrent kernels stretch each other's event-to-event durations)
+    chunks = [post.prepare_batch(batch_q[i:i + 32], float(n), k) for i in range(0, min(len(batch_q), 512), 32)]
     ctx.prof_reset()
     ctx.prof_enable(True)
-    t0 = time.perf_counter()
-    b_res = post.search_batch(batch_q, float(n), k)
-    el_bb = time.perf_counter() - t0
+    for c in chunks:
+        c.run()
     ctx.prof_enable(False)
+    n_dev_q = sum(c.nq for c in chunks)
     kb_ms, _ = ctx.prof_get("bm25_range_bounds")
     kd_ms, _ = ctx.prof_get("bm25_range_df")
     ks_ms, _ = ctx.prof_get("bm25_range_score")
@@ -368,7 +404,7 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12) 
         docs_q.append(b_res[j][2])  # `count` = distinct documents with a score (no threshold, no filter)
     avg_postings, avg_docs = float(np.mean(postings_q)), float(np.mean(docs_q))
     bm25_alg_bytes = avg_postings * 8 + avg_docs * 4
-    dev_us = (kb_ms + kd_ms + ks_ms + kt_ms) * 1e3 / len(batch_q)
+    dev_us = (kb_ms + kd_ms + ks_ms + kt_ms) * 1e3 / n_dev_q
     bm25_achieved = bm25_alg_bytes / (dev_us * 1e-6) / 1e9 if dev_us else 0.0
 
     # ---- parity of the last BM25 and hybrid query against the oracle (checker only)
@@ -415,8 +451,14 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12) 
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "vec_scan_f32_kernel",
                      "alg_bytes_per_launch": alg_vec, "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_n,
                      "note": "a hybrid query = the fp32 scan (dominant) + the full-text leg on a second stream"},
+        "full_text_leg": ("range scorer (K3r) beside the scan + candidate tail after it" if k3_launches == 0 else
+                          f"per-record scorer (K3) used by {k3_launches} launches"),
+        "shadow_store": shadow_out,
         "bm25_only": {"value": len(batch_q) / el_bb, "unit": "queries/s",
-                      "note": "orama_post_search_batch, one caller: K3r scores 32 queries per set of launches",
+                      "note": "one orama_post_search_batch call over %d queries, descriptors built beforehand: K3r scores 32 queries "
+                              "per set of launches, two sets in flight" % len(batch_q),
+                      "through_python_wrapper": {"value": len(batch_q) / el_bb_py, "unit": "queries/s",
+                                                 "note": "search_batch(): + ctypes marshalling of every query and result"},
                       "single_query_calls": {"value": steps / el_b, "unit": "queries/s", "ms_per_query": el_b / steps * 1e3},
                       "roofline": {"bound": "hbm", "achieved": bm25_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": bm25_achieved / HBM_PEAK_GBS, "traffic": None,
@@ -425,10 +467,10 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12) 
                                    "alg_bytes_definition": "SURVEY §8(d): 8 B per posting of the query's lists + 4 B per "
                                                            "distinct document touched",
                                    "device_us_per_query": dev_us,
-                                   "device_us_by_kernel": {"range_bounds": kb_ms * 1e3 / len(batch_q),
-                                                           "range_df": kd_ms * 1e3 / len(batch_q),
-                                                           "range_score": ks_ms * 1e3 / len(batch_q),
-                                                           "topk_select": kt_ms * 1e3 / len(batch_q)},
+                                   "device_us_by_kernel": {"range_bounds": kb_ms * 1e3 / n_dev_q,
+                                                           "range_df": kd_ms * 1e3 / n_dev_q,
+                                                           "range_score": ks_ms * 1e3 / n_dev_q,
+                                                           "topk_select": kt_ms * 1e3 / n_dev_q},
                                    "note": "latency / LDS-bound merge of sorted runs, not a streaming kernel (DESIGN K3r)"},
                       "cpu_baseline": cpu_bm25},
         "postings_fill_seconds": t_fill,
@@ -554,13 +596,16 @@ def main():
         want = EXTRA_CONFIGS if args.configs == "all" else () if args.configs == "none" else tuple(
             c for c in args.configs.split(",") if c)
         configs = {}
+        # NOT part of `value`: the same corpus in a store that also keeps an fp16 copy of its rows (+50 % HBM).  The
+        # fp16 scan proposes candidates, the fp32 rows decide; the answers are compared with the plain store's.
+        shadow = (shadow_store(oa, ctx, dim, hi - lo, lo, rank)
+                  if not f16 and not args.no_two_stage and vec_two_stage_ok(dim, k) else None)
         if args.workload == "ns" and not args.rows:
             if "c4" in want:  # shares the north-star rows
-                configs["c4"] = hybrid_leg(oa, ctx, store, n_total, dim, k, steps=max(10, min(args.steps, 40)), warmup=3)
-        if not f16 and not args.no_two_stage and vec_two_stage_ok(dim, k):
-            # NOT part of `value`: the same corpus in a store that also keeps an fp16 copy of its rows (+50 % HBM).  The
-            # fp16 scan proposes candidates, the fp32 rows decide; the answers are compared with the plain store's here.
-            out["two_stage_exact"] = two_stage_leg(oa, ctx, store, dim, hi - lo, k, qb, queries_h, lo, rank)
+                configs["c4"] = hybrid_leg(oa, ctx, store, n_total, dim, k, steps=max(10, min(args.steps, 40)), warmup=3,
+                                           shadow=shadow)
+        if shadow is not None:
+            out["two_stage_exact"] = two_stage_leg(oa, ctx, store, shadow, dim, k, qb, queries_h)
         store.close()
         store = None
         if args.workload == "ns" and not args.rows:

@@ -8,8 +8,10 @@
 //        and never moves postings over PCIe.
 // Both run the same kernels (bm25_kernels.hip) and the same top-k (select.hip).
 #include <algorithm>
+#include <functional>
 #include <atomic>
 #include <cmath>
+#include <deque>
 #include <shared_mutex>
 #include <string>
 #include <thread>
@@ -422,6 +424,12 @@ struct RangeJob {
     const float* vec_score = nullptr;
     uint32_t n_vec = 0;
     bool* fallback = nullptr;  // set when the answer could not be proven exact from the candidates: run K3 instead
+    // the one-call hybrid search (orama_hybrid_search): the vector map does not exist yet when the full-text leg starts.
+    // The range scorer enqueues bounds + scores + the raw top-(top_k + n_vec_max + 1) and only then asks for the map — the
+    // provider joins the vector leg, which ran beside all of that — so that the work left after the scan is one tiny
+    // per-document launch and a merge of <= top_k + 2 n_vec_max + 1 entries on the host (DESIGN.md K5 "hybrid tail").
+    std::function<int(const uint64_t** doc, const float** score, uint32_t* n)> vec_provider;
+    uint32_t n_vec_max = 0;
 };
 
 constexpr uint32_t kRangeBatchMax = 32;             // queries scored by one set of launches
@@ -550,11 +558,11 @@ int hybrid_from_candidates(const RangeJob& jb, const RangeResult& res, const uin
 }
 
 // Score `n_jobs` eligible queries (each validated by check_params and ranges_eligible) on sc->stream; synchronises.
+// With a second set (`sc2`) the sets of launches are double-buffered: while the device scores one chunk of 32 queries, the
+// host builds and uploads the tables of the next one on the other set's stream (the host side of a chunk — reference
+// tables, idf by libm, the upload — costs about as much wall time as its launches take on the device).
 int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_t n_jobs, float b,
-                       const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc) {
-    hipStream_t s = sc->stream;
-    const uint64_t* d_allow = nullptr;
-    ORAMA_TRY(resolve_allow(p->ctx, sc, allow_bitmap, bitmap_bits, s, &d_allow));
+                       const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc, Scratch* sc2 = nullptr) {
     struct Pending {
         uint32_t job;
         uint32_t shrink;
@@ -563,17 +571,27 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
     // hybrid (a batch of one): the vector map as local document indices; a hit that is not a document of this index is the
     // per-record scorer's business (it reports the error)
     std::vector<uint32_t> vec_local;
-    if (n_jobs == 1 && jobs[0].hybrid) {
-        const RangeJob& jb = jobs[0];
-        *jb.fallback = false;
-        vec_local.resize(jb.n_vec);
-        for (uint32_t j = 0; j < jb.n_vec; ++j)
-            if (!p->local_of(jb.vec_doc[j], &vec_local[j])) {
-                *jb.fallback = true;
-                return ORAMA_OK;
-            }
+    RangeJob hj;  // the hybrid job with its vector map filled in
+    bool have_map = false;
+    auto take_map = [&]() -> int {
+        if (have_map) return ORAMA_OK;
+        hj = jobs[0];
+        if (hj.vec_provider) ORAMA_TRY(hj.vec_provider(&hj.vec_doc, &hj.vec_score, &hj.n_vec));
+        have_map = true;
+        vec_local.resize(hj.n_vec);
+        for (uint32_t j = 0; j < hj.n_vec; ++j)
+            if (!p->local_of(hj.vec_doc[j], &vec_local[j])) *hj.fallback = true;
+        return ORAMA_OK;
+    };
+    const bool hybrid_job = n_jobs == 1 && jobs[0].hybrid;
+    if (hybrid_job) {
+        *jobs[0].fallback = false;
+        if (!jobs[0].vec_provider) {
+            ORAMA_TRY(take_map());
+            if (*hj.fallback) return ORAMA_OK;
+        }
     }
-    std::vector<Pending> pending;
+    std::deque<Pending> pending;
     for (uint32_t j = 0; j < n_jobs; ++j) {
         const RangeJob& jb = jobs[j];
         *jb.out_n = 0;
@@ -595,38 +613,66 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
     }
     ORAMA_REQUIRE(p->n_docs > 0 || pending.empty(), "postings store is empty (orama_post_build not called)");
 
-    std::vector<RangeSeg> segs;
-    std::vector<RangeQuery> queries;
-    std::vector<uint32_t> lens, chunk;
-    while (!pending.empty()) {
-        // next chunk: up to kRangeBatchMax queries whose padded key lists fit the budget
-        chunk.clear();
+    // One set of launches: up to kRangeBatchMax queries whose padded key lists fit the budget.
+    struct Chunk {
+        Scratch* sc = nullptr;
+        const uint64_t* d_allow = nullptr;
+        bool allow_resolved = false;
+        std::vector<Pending> members;
+        std::vector<RangeSeg> segs;
+        std::vector<RangeQuery> queries;
+        std::vector<uint32_t> lens;
+        uint32_t nq = 0, kmax = 0, kk = 1;
         uint64_t max_total = 0;
-        uint32_t kmax = 0;
-        for (uint32_t i = 0; i < pending.size() && chunk.size() < kRangeBatchMax; ++i) {
-            const uint64_t mt = std::max(max_total, pending[i].total);
-            if (!chunk.empty() && mt * (chunk.size() + 1) > kRangeKeyBudget) break;
-            max_total = mt;
-            {
-                const RangeJob& jb = jobs[pending[i].job];
-                kmax = std::max(kmax, jb.hybrid ? jb.params->top_k + jb.n_vec + 1 : jb.params->top_k);
-            }
-            chunk.push_back(i);
+        size_t res_bytes = 0;
+        RangeBatch rb;
+        RangeResult* h_res = nullptr;
+    };
+    Chunk slots[2];
+    slots[0].sc = sc;
+    slots[1].sc = sc2;
+    const uint32_t n_slots = sc2 && !hybrid_job ? 2u : 1u;
+
+    // build the chunk's tables, upload them, enqueue bounds + scores + top-k + the read-back on the chunk's stream
+    auto enqueue = [&](Chunk& c) -> int {
+        Scratch* sc = c.sc;
+        hipStream_t s = sc->stream;
+        if (!c.allow_resolved) {
+            ORAMA_TRY(resolve_allow(p->ctx, sc, allow_bitmap, bitmap_bits, s, &c.d_allow));
+            c.allow_resolved = true;
         }
-        const uint32_t nq = (uint32_t)chunk.size();
+        const uint64_t* d_allow = c.d_allow;
+        c.members.clear();
+        c.max_total = 0;
+        c.kmax = 0;
+        while (!pending.empty() && c.members.size() < kRangeBatchMax) {
+            const Pending& pd = pending.front();
+            const uint64_t mt = std::max(c.max_total, pd.total);
+            if (!c.members.empty() && mt * (c.members.size() + 1) > kRangeKeyBudget) break;
+            c.max_total = mt;
+            const RangeJob& jb = jobs[pd.job];
+            c.kmax = std::max(c.kmax, jb.hybrid ? jb.params->top_k + (jb.vec_provider ? jb.n_vec_max : jb.n_vec) + 1 : jb.params->top_k);
+            c.members.push_back(pd);
+            pending.pop_front();
+        }
+        const uint32_t nq = c.nq = (uint32_t)c.members.size();
+        const uint64_t max_total = c.max_total;
+        std::vector<RangeSeg>& segs = c.segs;
+        std::vector<RangeQuery>& queries = c.queries;
         segs.clear();
         queries.assign(nq, RangeQuery{});
-        lens.assign(nq, 0);
+        c.lens.assign(nq, 0);
         uint64_t virt = 0, bounds_entries = 0, max_bound_entries = 0;
         uint32_t max_ranges = 0;
         bool any_df = false;
-        ORAMA_TRY(sc->h_misc.reserve((size_t)nq * kMaxTokens * 4 + 64));
+        // (+ the hybrid job's vector hits: sized now so that nothing is re-allocated behind the scan)
+        ORAMA_TRY(sc->h_misc.reserve((size_t)nq * kMaxTokens * 4 + 4096 + (size_t)(c.kmax + 1) * 12));
         float* h_idf = sc->h_misc.as<float>();
-        for (uint32_t c = 0; c < nq; ++c) {
-            const Pending& pd = pending[chunk[c]];
+        for (uint32_t ci = 0; ci < nq; ++ci) {
+            const Pending& pd = c.members[ci];
             const RangeJob& jb = jobs[pd.job];
-            RangeQuery& q = queries[c];
-            q.key_off = (uint64_t)c * max_total;
+            RangeQuery& q = queries[ci];
+            q.key_off = (uint64_t)ci * max_total;
             q.bounds_base = bounds_entries;
             q.seg_begin = (uint32_t)segs.size();
             q.log_r = choose_log_r(p->n_docs, pd.total, pd.shrink);
@@ -636,7 +682,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             q.threshold = jb.params->threshold;
             q.k = jb.params->k;
             q.track_minmax = jb.hybrid ? 1u : 0u;
-            lens[c] = (uint32_t)pd.total;
+            c.lens[ci] = (uint32_t)pd.total;
             max_ranges = std::max(max_ranges, q.n_ranges);
             uint32_t per_token[kMaxTokens] = {0}, df[kMaxTokens] = {0};
             bool df_known = d_allow == nullptr, multi_list = false;
@@ -671,7 +717,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             // idf per token by the host libm (calculate_idf, bm25.rs:78-82; df.max(1), token_score.rs:275)
             for (uint32_t t = 0; t < kMaxTokens; ++t) {
                 const float d = (float)(df[t] < 1 ? 1u : df[t]);
-                h_idf[(size_t)c * kMaxTokens + t] =
+                h_idf[(size_t)ci * kMaxTokens + t] =
                     t < q.n_tokens ? log1pf((jb.params->total_documents - d + 0.5f) / (d + 0.5f)) : 0.0f;
             }
         }
@@ -686,20 +732,21 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         memcpy(h, segs.data(), segs.size() * sizeof(RangeSeg));
         memcpy(h + seg_bytes, queries.data(), (size_t)nq * sizeof(RangeQuery));
         memcpy(h + seg_bytes + q_bytes, h_idf, idf_bytes);
-        memcpy(h + seg_bytes + q_bytes + idf_bytes, lens.data(), (size_t)nq * 4);
+        memcpy(h + seg_bytes + q_bytes + idf_bytes, c.lens.data(), (size_t)nq * 4);
         ORAMA_TRY(sc->misc0.reserve(seg_bytes + q_bytes + idf_bytes + len_bytes));
         ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, h, seg_bytes + q_bytes + idf_bytes + len_bytes, hipMemcpyHostToDevice, s));
         ORAMA_TRY(sc->misc1.reserve((size_t)bounds_entries * 4));
-        // device results in ONE block: [RangeResult x nq | ids | scores | n]  -> one read-back per round
-        const uint32_t kk = std::max(kmax, 1u);
-        const size_t res_bytes = (size_t)nq * sizeof(RangeResult);
+        // device results in ONE block: [RangeResult x nq | ids | scores | n]  -> one read-back per chunk
+        const uint32_t kk = c.kk = std::max(c.kmax, 1u);
+        const size_t res_bytes = c.res_bytes = (size_t)nq * sizeof(RangeResult);
         const size_t out_bytes = res_bytes + (size_t)nq * kk * 12 + (size_t)nq * 4;
         ORAMA_TRY(sc->misc2.reserve(out_bytes));
         ORAMA_TRY(sc->misc3.reserve((size_t)nq * max_total * 8));
         ORAMA_HIP_TRY(hipMemsetAsync(sc->misc2.p, 0, res_bytes, s));
         char* d = sc->misc0.as<char>();
         float* d_idf = reinterpret_cast<float*>(d + seg_bytes + q_bytes);
-        RangeBatch rb;
+        RangeBatch& rb = c.rb;
+        rb = RangeBatch{};
         rb.segs = reinterpret_cast<const RangeSeg*>(d);
         rb.queries = reinterpret_cast<const RangeQuery*>(d + seg_bytes);
         rb.n_segs = (uint32_t)segs.size();
@@ -722,18 +769,18 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         if (const char* e = std::getenv("ORAMA_K3R_DBG")) rb.debug = (uint32_t)std::atoi(e);
         ORAMA_TRY(launch_range_bounds(p->ctx, rb, s));
         ORAMA_TRY(sc->h_out.reserve(out_bytes + 64));
-        RangeResult* h_res = sc->h_out.as<RangeResult>();
+        RangeResult* h_res = c.h_res = sc->h_out.as<RangeResult>();
         if (any_df) {
             // df counted on the device (filter, or tokens with several lists): one read-back, then idf by the host libm
             ORAMA_TRY(launch_range_score(p->ctx, rb, true, s));
             ORAMA_HIP_TRY(hipMemcpyAsync(h_res, sc->misc2.p, res_bytes, hipMemcpyDeviceToHost, s));
             ORAMA_HIP_TRY(hipStreamSynchronize(s));
-            for (uint32_t c = 0; c < nq; ++c) {
-                if (!queries[c].want_df) continue;
-                const orama_bm25_params* pr = jobs[pending[chunk[c]].job].params;
-                for (uint32_t t = 0; t < queries[c].n_tokens; ++t) {
-                    const float dd = (float)(h_res[c].df[t] < 1 ? 1u : h_res[c].df[t]);
-                    h_idf[(size_t)c * kMaxTokens + t] = log1pf((pr->total_documents - dd + 0.5f) / (dd + 0.5f));
+            for (uint32_t ci = 0; ci < nq; ++ci) {
+                if (!queries[ci].want_df) continue;
+                const orama_bm25_params* pr = jobs[c.members[ci].job].params;
+                for (uint32_t t = 0; t < queries[ci].n_tokens; ++t) {
+                    const float dd = (float)(h_res[ci].df[t] < 1 ? 1u : h_res[ci].df[t]);
+                    h_idf[(size_t)ci * kMaxTokens + t] = log1pf((pr->total_documents - dd + 0.5f) / (dd + 0.5f));
                 }
             }
             ORAMA_HIP_TRY(hipMemcpyAsync(d_idf, h_idf, idf_bytes, hipMemcpyHostToDevice, s));
@@ -743,66 +790,87 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         uint64_t* d_ids = reinterpret_cast<uint64_t*>(d_out + res_bytes);
         float* d_val = reinterpret_cast<float*>(d_out + res_bytes + (size_t)nq * kk * 8);
         uint32_t* d_n = reinterpret_cast<uint32_t*>(d_out + res_bytes + (size_t)nq * kk * 12);
-        if (kmax) {
-            ORAMA_TRY(sc->misc4.reserve((size_t)keys_topk_scratch_keys((uint32_t)max_total, nq, kmax) * 8 + 8));
-            ORAMA_TRY(launch_keys_topk(p->ctx, rb.keys, (uint32_t)max_total, max_total, nq, kmax, true, p->d_docs.as<uint64_t>(),
+        if (c.kmax) {
+            ORAMA_TRY(sc->misc4.reserve((size_t)keys_topk_scratch_keys((uint32_t)max_total, nq, c.kmax) * 8 + 8));
+            ORAMA_TRY(launch_keys_topk(p->ctx, rb.keys, (uint32_t)max_total, max_total, nq, c.kmax, true, p->d_docs.as<uint64_t>(),
                                        sc->misc4.as<unsigned long long>(), nullptr, d_ids, d_val, d_n, s,
                                        reinterpret_cast<const uint32_t*>(d + seg_bytes + q_bytes + idf_bytes)));
         }
-        const char* h_ids = reinterpret_cast<const char*>(h_res) + res_bytes;
+        ORAMA_HIP_TRY(hipMemcpyAsync(h_res, d_out, c.kmax ? out_bytes : res_bytes, hipMemcpyDeviceToHost, s));
+        return ORAMA_OK;
+    };
+
+    // wait for the chunk; hand the answers out; a query whose ranges overflowed goes back to `pending` with smaller ranges
+    auto complete = [&](Chunk& c) -> int {
+        Scratch* sc = c.sc;
+        hipStream_t s = sc->stream;
+        const uint32_t nq = c.nq, kk = c.kk;
+        const RangeResult* h_res = c.h_res;
+        const char* h_ids = reinterpret_cast<const char*>(h_res) + c.res_bytes;
         const char* h_val = h_ids + (size_t)nq * kk * 8;
         const char* h_n = h_val + (size_t)nq * kk * 4;
-        ORAMA_HIP_TRY(hipMemcpyAsync(h_res, d_out, kmax ? out_bytes : res_bytes, hipMemcpyDeviceToHost, s));
-        const bool hybrid_job = n_jobs == 1 && jobs[0].hybrid;
-        const uint32_t nv = hybrid_job ? jobs[0].n_vec : 0;
-        float* h_vft = nullptr;       // full-text score of every vector hit ...
+        uint32_t nv = 0;
+        float* h_vft = nullptr;          // full-text score of every vector hit ...
         uint32_t* h_vpresent = nullptr;  // ... and whether it is in the full-text map at all
+        if (hybrid_job) {  // (one-call form: this is where the vector leg is joined — everything above ran beside it)
+            ORAMA_TRY(take_map());
+            if (*hj.fallback) {
+                ORAMA_HIP_TRY(hipStreamSynchronize(s));
+                return ORAMA_OK;
+            }
+            nv = hj.n_vec;
+        }
         if (nv) {
-            ORAMA_TRY(sc->misc5.reserve((size_t)nv * 12));
+            // the kernel reads the <= limit document indices from, and writes the scores to, pinned host memory directly:
+            // two copy commands fewer on the critical path behind the scan (a few hundred bytes each way)
             ORAMA_TRY(sc->h_misc.reserve((size_t)nq * kMaxTokens * 4 + 4096 + (size_t)nv * 12));
             char* hv = sc->h_misc.as<char>() + (size_t)nq * kMaxTokens * 4 + 4096;  // behind the idf staging
             memcpy(hv, vec_local.data(), (size_t)nv * 4);
-            ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc5.p, hv, (size_t)nv * 4, hipMemcpyHostToDevice, s));
-            uint32_t* d_vidx = sc->misc5.as<uint32_t>();
-            float* d_vft = reinterpret_cast<float*>(d_vidx + nv);
-            uint32_t* d_vpr = d_vidx + 2 * (size_t)nv;
-            ORAMA_TRY(launch_range_score_docs(p->ctx, rb, 0, d_vidx, nv, d_vft, d_vpr, s));
-            ORAMA_HIP_TRY(hipMemcpyAsync(hv + (size_t)nv * 4, d_vft, (size_t)nv * 8, hipMemcpyDeviceToHost, s));
             h_vft = reinterpret_cast<float*>(hv + (size_t)nv * 4);
             h_vpresent = reinterpret_cast<uint32_t*>(hv + (size_t)nv * 8);
+            ORAMA_TRY(launch_range_score_docs(p->ctx, c.rb, 0, reinterpret_cast<const uint32_t*>(hv), nv, h_vft, h_vpresent, s));
         }
         ORAMA_HIP_TRY(hipStreamSynchronize(s));
-        // hand the answers out; a query whose ranges overflowed stays pending with smaller ranges
-        std::vector<Pending> still;
-        std::vector<char> in_chunk(pending.size(), 0);
-        for (uint32_t c = 0; c < nq; ++c) {
-            in_chunk[chunk[c]] = 1;
-            Pending pd = pending[chunk[c]];
+        for (uint32_t ci = 0; ci < nq; ++ci) {
+            Pending pd = c.members[ci];
             const RangeJob& jb = jobs[pd.job];
-            if (h_res[c].overflow) {
-                ORAMA_REQUIRE(queries[c].log_r > 0, "internal: a one-document range overflowed");
+            if (h_res[ci].overflow) {
+                ORAMA_REQUIRE(c.queries[ci].log_r > 0, "internal: a one-document range overflowed");
                 ++pd.shrink;
-                still.push_back(pd);
+                pending.push_back(pd);
                 continue;
             }
             if (jb.hybrid) {
-                ORAMA_TRY(hybrid_from_candidates(jb, h_res[c], reinterpret_cast<const uint64_t*>(h_ids), reinterpret_cast<const float*>(h_val),
-                                                 kmax ? reinterpret_cast<const uint32_t*>(h_n)[0] : 0u, kmax, h_vft, h_vpresent));
+                ORAMA_TRY(hybrid_from_candidates(hj, h_res[ci], reinterpret_cast<const uint64_t*>(h_ids), reinterpret_cast<const float*>(h_val),
+                                                 c.kmax ? reinterpret_cast<const uint32_t*>(h_n)[0] : 0u, c.kmax, h_vft, h_vpresent));
                 continue;
             }
-            if (jb.out_count) *jb.out_count = h_res[c].count;
+            if (jb.out_count) *jb.out_count = h_res[ci].count;
             if (jb.params->top_k) {
-                const uint32_t n = std::min(reinterpret_cast<const uint32_t*>(h_n)[c], jb.params->top_k);
-                memcpy(jb.out_ids, h_ids + (size_t)c * kk * 8, (size_t)n * 8);
-                memcpy(jb.out_scores, h_val + (size_t)c * kk * 4, (size_t)n * 4);
+                const uint32_t n = std::min(reinterpret_cast<const uint32_t*>(h_n)[ci], jb.params->top_k);
+                memcpy(jb.out_ids, h_ids + (size_t)ci * kk * 8, (size_t)n * 8);
+                memcpy(jb.out_scores, h_val + (size_t)ci * kk * 4, (size_t)n * 4);
                 *jb.out_n = n;
             }
         }
-        for (uint32_t i = 0; i < pending.size(); ++i)
-            if (!in_chunk[i]) still.push_back(pending[i]);
-        pending.swap(still);
+        return ORAMA_OK;
+    };
+
+    uint32_t head = 0, inflight = 0;
+    int rc = ORAMA_OK;
+    while (rc == ORAMA_OK && (!pending.empty() || inflight)) {
+        while (rc == ORAMA_OK && inflight < n_slots && !pending.empty()) {
+            rc = enqueue(slots[(head + inflight) % n_slots]);
+            ++inflight;  // (a chunk that failed half-way may still have launches on its stream: drained below)
+        }
+        if (rc != ORAMA_OK) break;
+        rc = complete(slots[head]);
+        head = (head + 1) % n_slots;
+        --inflight;
     }
-    return ORAMA_OK;
+    if (rc != ORAMA_OK)  // nothing of the call stays in flight behind an error
+        for (uint32_t i = 0; i < n_slots; ++i) (void)hipStreamSynchronize(slots[i].sc->stream);
+    return rc;
 }
 
 int post_search_impl(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, float b,
@@ -1236,10 +1304,12 @@ static int post_search_batch_impl(orama_post* p, const orama_post_query_desc* qu
             }
             auto run = [&]() -> int {
                 ORAMA_ON_DEVICE(p->ctx->device);
-                ScratchLease sc(p->ctx);
-                ORAMA_TRY(sc.init());
-                return post_search_ranges(p, sc.s.get(), jobs.data(), (uint32_t)jobs.size(), b, allow_bitmap,
-                                                 bitmap_bits, apply_omc);
+                ScratchLease sc(p->ctx), sc2(p->ctx);
+                const bool two = jobs.size() > kRangeBatchMax;  // more than one set of launches: double-buffered
+                if (two) ORAMA_TRY(ScratchLease::init_pair(sc, sc2));
+                else ORAMA_TRY(sc.init());
+                return post_search_ranges(p, sc.s.get(), jobs.data(), (uint32_t)jobs.size(), b, allow_bitmap, bitmap_bits, apply_omc,
+                                          two ? sc2.s.get() : nullptr);
             };
             if (run() == ORAMA_OK) {
                 if (out_count)
@@ -1722,51 +1792,44 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
     ORAMA_ON_DEVICE(ctx->device);
     VecSharedLock vlk(v);
     std::shared_lock<std::shared_mutex> lk(p->mu);
-    // a store with an fp16 shadow answers the vector leg with the two-stage plan (same answer, half the bytes scanned):
-    // it needs a third scratch set, and blocks — so the full-text leg is enqueued first and runs beside it
+    // a store with an fp16 shadow answers the vector leg with the two-stage plan (same answer, half the bytes scanned): it
+    // needs a second vector set; its blocking half (VecTwoStage::finish) runs when the leg is joined
     const bool two_stage = vec_rows(v) > 0 && limit > 0 && vec_two_stage_usable(v, query, 1, limit);
-    ScratchLease a(ctx, kScratchVector), a2(ctx, kScratchVector), bsc(ctx, kScratchRecords);
-    if (two_stage) ORAMA_TRY(ScratchLease::init_three(a, a2, bsc));
-    else ORAMA_TRY(ScratchLease::init_pair(a, bsc));
-    // ---- leg A: vector scan + top-`limit` rows
     const uint32_t dim = vec_dim(v);
     const bool have_rows = vec_rows(v) > 0 && limit > 0;
     const uint32_t kk = limit ? limit : 1;
-    hipStream_t sa = a->stream;
-    char* ha = nullptr;
-    PostQuery st;
-    if (two_stage)  // leg B, stage 1 first
-        ORAMA_TRY(post_stage1(p, bsc.s.get(), refs, n_refs, b, params, allow_bitmap, bitmap_bits, true, apply_omc, limit, &st));
-    if (have_rows) {
+    // ---- leg A: vector scan + top-`limit` rows on a's stream; the read-back lands in a->h_out
+    auto vector_leg = [&](ScratchLease& a, ScratchLease& a2, VecTwoStage& ts) -> int {
+        if (!have_rows) return ORAMA_OK;
+        hipStream_t sa = a->stream;
         ORAMA_TRY(a->query.reserve((size_t)dim * 4));
         ORAMA_TRY(a->h_in.reserve((size_t)dim * 4));
         memcpy(a->h_in.p, query, (size_t)dim * 4);
         ORAMA_HIP_TRY(hipMemcpyAsync(a->query.p, a->h_in.p, (size_t)dim * 4, hipMemcpyHostToDevice, sa));
         const uint64_t* d_allow = nullptr;
         ORAMA_TRY(resolve_allow(ctx, a.s.get(), allow_bitmap, bitmap_bits, sa, &d_allow));
-        ORAMA_TRY(a->out_ids.reserve((size_t)kk * 8));
-        ORAMA_TRY(a->out_val.reserve((size_t)kk * 4));
-        ORAMA_TRY(a->out_n.reserve(4));
-        if (two_stage)
-            ORAMA_TRY(vec_two_stage_search(v, a, a2, a->query.as<float>(), 1, limit, d_allow, bitmap_bits, a->out_ids.as<uint64_t>(),
-                                           a->out_val.as<float>(), a->out_n.as<uint32_t>()));
-        else
-            ORAMA_TRY(vec_search_enqueue(v, a.s.get(), a->query.as<float>(), 1, limit, d_allow, bitmap_bits,
-                                         a->out_ids.as<uint64_t>(), a->out_val.as<float>(), a->out_n.as<uint32_t>(), sa));
-        ORAMA_TRY(a->h_out.reserve((size_t)kk * 12 + 4));
-        ha = a->h_out.as<char>();
-        ORAMA_HIP_TRY(hipMemcpyAsync(ha, a->out_ids.p, (size_t)kk * 8, hipMemcpyDeviceToHost, sa));
-        ORAMA_HIP_TRY(hipMemcpyAsync(ha + (size_t)kk * 8, a->out_val.p, (size_t)kk * 4, hipMemcpyDeviceToHost, sa));
-        ORAMA_HIP_TRY(hipMemcpyAsync(ha + (size_t)kk * 12, a->out_n.p, 4, hipMemcpyDeviceToHost, sa));
-    }
-    // ---- leg B, stage 1: BM25F accumulate + finalise (overlaps leg A)
-    if (!two_stage)
-        ORAMA_TRY(post_stage1(p, bsc.s.get(), refs, n_refs, b, params, allow_bitmap, bitmap_bits, true, apply_omc, limit, &st));
+        // results in one block [ids | distances | n]: one read-back
+        ORAMA_TRY(a->out_ids.reserve((size_t)kk * 12 + 8));
+        uint64_t* d_ids = a->out_ids.as<uint64_t>();
+        float* d_dist = reinterpret_cast<float*>(d_ids + kk);
+        uint32_t* d_n = reinterpret_cast<uint32_t*>(d_dist + kk);
+        ORAMA_TRY(a->h_out.reserve((size_t)kk * 12 + 8));
+        if (two_stage) return ts.begin(v, a, a2, a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n);
+        ORAMA_TRY(vec_search_enqueue(v, a.s.get(), a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n, sa));
+        ORAMA_HIP_TRY(hipMemcpyAsync(a->h_out.p, d_ids, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, sa));
+        return ORAMA_OK;
+    };
     // ---- join A; in-tree epilogue on the host: similarity, rescale, cut-off, per-doc sum (hit order)
     std::vector<uint64_t> vdoc;
     std::vector<float> vsc;
-    if (have_rows) {
-        ORAMA_HIP_TRY(hipStreamSynchronize(sa));
+    auto join_vector_leg = [&](ScratchLease& a, VecTwoStage& ts) -> int {
+        if (!have_rows) return ORAMA_OK;
+        if (two_stage) {  // (an unproven candidate list is re-answered by the plain scan in here)
+            ORAMA_TRY(ts.finish());
+            ORAMA_HIP_TRY(hipMemcpyAsync(a->h_out.p, a->out_ids.p, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, a->stream));
+        }
+        ORAMA_HIP_TRY(hipStreamSynchronize(a->stream));
+        const char* ha = a->h_out.as<char>();
         const uint64_t* ids = reinterpret_cast<const uint64_t*>(ha);
         const float* dist = reinterpret_cast<const float*>(ha + (size_t)kk * 8);
         const uint32_t n = *reinterpret_cast<const uint32_t*>(ha + (size_t)kk * 12);
@@ -1790,7 +1853,70 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
             }
             vsc[j] = vsc[j] + score;
         }
+        return ORAMA_OK;
+    };
+
+    // ---- the full-text leg on the range scorer (K3r), the hybrid tail on <= top_k + 2 limit + 1 candidates: no OMC
+    // (multipliers reorder documents arbitrarily), references that fit the sort key, candidates that fit one selection
+    const bool by_ranges = ranges_eligible(p, refs, n_refs, params) && ctx->bm25_ranges_hybrid && !(apply_omc && p->has_omc) &&
+                           (uint64_t)params->top_k + limit + 1 <= kSelectMaxK;
+    if (by_ranges) {
+        ORAMA_TRY(check_params(params));
+        bool fallback = false, joined = false;
+        {
+            ScratchLease a(ctx, kScratchVector), a2(ctx, kScratchVector), g(ctx, kScratchGeneral);
+            if (two_stage) ORAMA_TRY(ScratchLease::init_three(a, a2, g));
+            else ORAMA_TRY(ScratchLease::init_pair(a, g));
+            VecTwoStage ts;
+            ORAMA_TRY(vector_leg(a, a2, ts));
+            RangeJob job{refs, n_refs, params, out_ids, out_scores, out_n, out_count};
+            job.hybrid = true;
+            job.fallback = &fallback;
+            job.n_vec_max = have_rows ? limit : 0;
+            job.vec_provider = [&](const uint64_t** doc, const float** score, uint32_t* n) -> int {
+                if (!joined) {
+                    ORAMA_TRY(join_vector_leg(a, ts));
+                    joined = true;
+                }
+                *doc = vdoc.data();
+                *score = vsc.data();
+                *n = (uint32_t)vdoc.size();
+                return ORAMA_OK;
+            };
+            const int rc = post_search_ranges(p, g.s.get(), &job, 1, b, allow_bitmap, bitmap_bits, 0);
+            if (rc != ORAMA_OK) {
+                if (!joined && have_rows) (void)hipStreamSynchronize(a->stream);  // nothing of the call stays in flight
+                return rc;
+            }
+            if (!fallback) return ORAMA_OK;
+            if (!joined) {  // (no full-text side at all: the scorer never asked for the map)
+                const uint64_t* d_;
+                const float* s_;
+                uint32_t n_;
+                ORAMA_TRY(job.vec_provider(&d_, &s_, &n_));
+            }
+        }
+        // the candidates could not prove the answer (or a vector hit is not a document of the index): the per-record scorer
+        // combines the whole maps.  Every set of the first attempt is back in the pool before this one is drawn.
+        *out_n = 0;
+        if (out_count) *out_count = 0;
+        ScratchLease rsc(ctx, kScratchRecords);
+        ORAMA_TRY(rsc.init());
+        PostQuery st;
+        ORAMA_TRY(post_stage1(p, rsc.s.get(), refs, n_refs, b, params, allow_bitmap, bitmap_bits, true, apply_omc, (uint32_t)vdoc.size(), &st));
+        return post_stage2(p, rsc.s.get(), st, params, vdoc.data(), vsc.data(), (uint32_t)vdoc.size(), out_ids, out_scores, out_n, out_count);
     }
+
+    // ---- the full-text leg on the per-record scorer (K3): stage 1 beside the scan, combine + count + top-k after it
+    ScratchLease a(ctx, kScratchVector), a2(ctx, kScratchVector), bsc(ctx, kScratchRecords);
+    if (two_stage) ORAMA_TRY(ScratchLease::init_three(a, a2, bsc));
+    else ORAMA_TRY(ScratchLease::init_pair(a, bsc));
+    PostQuery st;
+    VecTwoStage ts;
+    ORAMA_TRY(vector_leg(a, a2, ts));
+    // ---- leg B, stage 1: BM25F accumulate + finalise (overlaps leg A)
+    ORAMA_TRY(post_stage1(p, bsc.s.get(), refs, n_refs, b, params, allow_bitmap, bitmap_bits, true, apply_omc, limit, &st));
+    ORAMA_TRY(join_vector_leg(a, ts));
     // ---- leg B, stage 2: combine + OMC + count + top-k
     return post_stage2(p, bsc.s.get(), st, params, vdoc.data(), vsc.data(), (uint32_t)vdoc.size(), out_ids, out_scores,
                        out_n, out_count);

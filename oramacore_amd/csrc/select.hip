@@ -669,9 +669,64 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
                                                                   uint32_t* out_n) {
     __shared__ SortLds s;
     __shared__ uint32_t valid_s;
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
+    __shared__ uint32_t red_nz[kSortThreads / 64];
+    __shared__ uint32_t sel[3], cursor;
     const uint32_t qi = blockIdx.x;
+    const int lane = threadIdx.x & 63;
     const unsigned long long* in = keys + (uint64_t)qi * in_stride;
     if (n_per_list) n_keys = min(n_keys, n_per_list[qi]);
+    if (n_keys > 2 * next_pow2(k)) {
+        // Many more candidates than answers (32 chunks x 100 survivors of a scan's wave lists: 3 200 keys for 100 results):
+        // ordering all of them is a 4 096-element bitonic sort with a 64-bit id gather per element, 80 us of a 4.4 ms query.
+        // The k best BY KEY are cut out first — the radix threshold of the reduction levels, so that the cut among equal
+        // values keeps the lowest indices exactly as every level before this one does (DESIGN.md §3 rule 4) — and only
+        // those are ordered by (value, id, index).
+        unsigned long long* kb = reinterpret_cast<unsigned long long*>(s.id);  // (the key buffer aliases the id column)
+        for (uint32_t i = threadIdx.x; i < n_keys; i += blockDim.x) kb[i] = in[i];
+        if (threadIdx.x == 0) cursor = 0;
+        __syncthreads();
+        const unsigned long long thr = lds_keys_threshold(kb, n_keys, k, hist, red_max, red_min, red_nz, sel);
+        constexpr uint32_t kPerThread = kSelectMaxK / kSortThreads;
+        unsigned long long mine[kPerThread];
+#pragma unroll
+        for (uint32_t t = 0; t < kPerThread; ++t) {
+            const uint32_t i = t * blockDim.x + threadIdx.x;
+            mine[t] = i < n_keys ? kb[i] : 0ull;
+        }
+        __syncthreads();  // every key is in a register: the id column may be written
+#pragma unroll
+        for (uint32_t t = 0; t < kPerThread; ++t) {
+            const bool tk = mine[t] >= thr;  // thr >= 1: empties never
+            const unsigned long long m = __ballot(tk);
+            uint32_t base = 0;
+            if (lane == 0 && m) base = atomicAdd(&cursor, (uint32_t)__popcll(m));
+            base = __shfl(base, 0, 64);
+            if (tk) {
+                const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (p < k) {
+                    const uint32_t ix = ~(uint32_t)mine[t];
+                    s.hi[p] = (uint32_t)(mine[t] >> 32);
+                    s.idx[p] = ix;
+                    s.id[p] = id_map ? id_map[ix] : (uint64_t)ix;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t count = min(cursor, k);
+        const uint32_t p2 = next_pow2(max(count, 1u));
+        for (uint32_t i = count + threadIdx.x; i < p2; i += blockDim.x) {
+            s.hi[i] = 0;
+            s.idx[i] = 0xffffffffu;
+            s.id[i] = ~0ull;
+        }
+        __syncthreads();
+        lds_bitonic_sort(s, p2);
+        write_sorted(s, count, k, descending, out_idx ? out_idx + (uint64_t)qi * k : nullptr,
+                     out_ids ? out_ids + (uint64_t)qi * k : nullptr, out_val + (uint64_t)qi * k, out_n ? out_n + qi : nullptr);
+        return;
+    }
     const uint32_t p2 = next_pow2(max(n_keys, 1u));
     if (threadIdx.x == 0) valid_s = 0;
     __syncthreads();

@@ -34,4 +34,33 @@ bool vec_two_stage_usable(orama_vec* v, const float* queries, uint32_t q, uint32
 int vec_two_stage_search(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k,
                          const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n);
 
+
+// The same in two halves, for a caller with other work to enqueue beside the scan (the one-call hybrid search): begin()
+// only enqueues (stage 1, the completeness proof, the re-rank and the selection) and keeps the shadow store's read lock;
+// finish() blocks, re-answers the unproven queries with the plain scan and releases the lock.
+class VecTwoStage {
+   public:
+    VecTwoStage() = default;
+    ~VecTwoStage();
+    VecTwoStage(const VecTwoStage&) = delete;
+    VecTwoStage& operator=(const VecTwoStage&) = delete;
+    int begin(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k, const uint64_t* d_allow,
+              uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n);
+    int finish();
+
+   private:
+    void unlock();
+    orama_vec* v_ = nullptr;
+    void* locked_ = nullptr;  // the shadow store's std::shared_mutex while its read lock is held
+    Scratch *sc_ = nullptr, *sc2_ = nullptr;
+    const float* d_queries_ = nullptr;
+    uint32_t q_ = 0, k_ = 0;
+    const uint64_t* d_allow_ = nullptr;
+    uint64_t allow_bits_ = 0;
+    uint64_t* d_out_ids_ = nullptr;
+    float* d_out_dist_ = nullptr;
+    uint32_t* d_out_n_ = nullptr;
+    bool flags_pending_ = false;
+};
+
 }  // namespace orama

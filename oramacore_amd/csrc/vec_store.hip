@@ -730,9 +730,11 @@ constexpr float kShadowEps = 2.5e-3f;
 
 int two_stage_search(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k,
                      const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n,
-                     hipStream_t s, uint8_t* h_redo) {
+                     hipStream_t s, bool* flags_pending) {
+    // (the caller holds the shadow's mu shared — and v->mu shared, which also excludes a compaction of the pair — until
+    // the launches below have completed)
     orama_vec* sh = v->shadow.get();
-    std::shared_lock<std::shared_mutex> sl(sh->mu);  // the caller holds v->mu shared (which also excludes a compaction of the pair)
+    *flags_pending = false;
     const View w = snapshot(v);
     View ws = snapshot(sh);
     ws.n_rows = std::min(ws.n_rows, w.n_rows);  // the shadow is written first: it may already hold unpublished rows
@@ -784,9 +786,7 @@ int two_stage_search(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const fl
     ORAMA_TRY(launch_select(v->ctx, p, s));
     ORAMA_TRY(sc2->h_out.reserve((size_t)q * 4));
     ORAMA_HIP_TRY(hipMemcpyAsync(sc2->h_out.p, d_flag, (size_t)q * 4, hipMemcpyDeviceToHost, s));
-    ORAMA_HIP_TRY(hipStreamSynchronize(s));
-    const uint32_t* hf = sc2->h_out.as<uint32_t>();
-    for (uint32_t j = 0; j < q; ++j) h_redo[j] = hf[j] ? 1 : 0;
+    *flags_pending = true;  // sc2->h_out holds one word per query once `s` has drained: non-zero = not proven
     return ORAMA_OK;
 }
 
@@ -823,20 +823,50 @@ bool vec_two_stage_usable(orama_vec* v, const float* queries, uint32_t q, uint32
     }
     return true;
 }
+VecTwoStage::~VecTwoStage() {
+    if (locked_) {  // begin() without finish() (an error in between): nothing of the call may stay in flight
+        (void)hipStreamSynchronize(sc_->stream);
+        unlock();
+    }
+}
+void VecTwoStage::unlock() {
+    if (locked_) static_cast<std::shared_mutex*>(locked_)->unlock_shared();
+    locked_ = nullptr;
+}
+int VecTwoStage::begin(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k,
+                       const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n) {
+    ORAMA_REQUIRE(!locked_, "internal: two-stage search begun twice");
+    v_ = v, sc_ = sc.s.get(), sc2_ = sc2.s.get(), d_queries_ = d_queries, q_ = q, k_ = k, d_allow_ = d_allow, allow_bits_ = allow_bits;
+    d_out_ids_ = d_out_ids, d_out_dist_ = d_out_dist, d_out_n_ = d_out_n;
+    v->shadow->mu.lock_shared();
+    locked_ = &v->shadow->mu;
+    return two_stage_search(v, sc, sc2, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, sc->stream, &flags_pending_);
+}
+int VecTwoStage::finish() {
+    ORAMA_REQUIRE(locked_, "internal: two-stage search not begun");
+    hipStream_t s = sc_->stream;
+    const hipError_t e = hipStreamSynchronize(s);
+    unlock();
+    ORAMA_HIP_TRY(e);
+    v_->two_stage_queries.fetch_add(q_, std::memory_order_relaxed);
+    if (!flags_pending_) return ORAMA_OK;
+    const uint32_t* hf = sc2_->h_out.as<uint32_t>();
+    bool any = false;
+    for (uint32_t j = 0; j < q_; ++j) {
+        if (!hf[j]) continue;
+        any = true;
+        v_->two_stage_fallbacks.fetch_add(1, std::memory_order_relaxed);
+        ORAMA_TRY(search_enqueue(v_, sc_, d_queries_ + (size_t)j * v_->dim, 1, k_, d_allow_, allow_bits_, d_out_ids_ + (size_t)j * k_,
+                                 d_out_dist_ + (size_t)j * k_, d_out_n_ + j, s));
+    }
+    if (any) ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    return ORAMA_OK;
+}
 int vec_two_stage_search(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k,
                          const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n) {
-    hipStream_t s = sc->stream;
-    std::vector<uint8_t> redo(q, 0);
-    ORAMA_TRY(two_stage_search(v, sc, sc2, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, s, redo.data()));
-    v->two_stage_queries.fetch_add(q, std::memory_order_relaxed);
-    for (uint32_t j = 0; j < q; ++j) {
-        if (!redo[j]) continue;
-        v->two_stage_fallbacks.fetch_add(1, std::memory_order_relaxed);
-        ORAMA_TRY(search_enqueue(v, sc.s.get(), d_queries + (size_t)j * v->dim, 1, k, d_allow, allow_bits, d_out_ids + (size_t)j * k,
-                                 d_out_dist + (size_t)j * k, d_out_n + j, s));
-    }
-    ORAMA_HIP_TRY(hipStreamSynchronize(s));
-    return ORAMA_OK;
+    VecTwoStage call;
+    ORAMA_TRY(call.begin(v, sc, sc2, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n));
+    return call.finish();
 }
 }  // namespace orama
 

@@ -341,6 +341,50 @@ class FacetField:
             pass
 
 
+class PreparedBatch:
+    """Marshalled arguments of one orama_post_search_batch call (see PostingsStore.prepare_batch)."""
+
+    def __init__(self, store, queries, total_documents, top_k, allow, apply_omc, max_parallel, b, k):
+        self._store = store
+        nq = self.nq = len(queries)
+        self._descs = (N.PostQueryDesc * max(nq, 1))()
+        self._keep = []
+        for i, qd in enumerate(queries):
+            refs, n_tokens, thr = qd[0], qd[1], qd[2]
+            arr = store._refs(refs)
+            self._keep.append(arr)
+            self._descs[i].refs = C.cast(arr, C.POINTER(N.TermRef))
+            self._descs[i].n_refs = len(refs)
+            self._descs[i].params = _params(total_documents, n_tokens, thr, qd[3] if len(qd) > 3 else top_k, k)
+        self._stride = max(top_k, 1)
+        self.out_ids = np.zeros((max(nq, 1), self._stride), dtype=np.uint64)
+        self.out_sc = np.zeros((max(nq, 1), self._stride), dtype=np.float32)
+        self.out_n = np.zeros(max(nq, 1), dtype=np.uint32)
+        self.out_count = np.zeros(max(nq, 1), dtype=np.uint64)
+        self._allow = allow
+        self._args = (b, 1 if apply_omc else 0, int(max_parallel))
+
+    def run(self, statuses: bool = False):
+        """One library call.  With `statuses` nothing is raised for a failing query: returns the status array."""
+        lib, st_ = self._store._lib, self._store
+        bm_ptr, bm_bits = self._allow.ffi_args() if self._allow is not None else (None, 0)
+        b, omc, par = self._args
+        if statuses:
+            st = np.zeros(max(self.nq, 1), dtype=np.int32)
+            lib.orama_post_search_batch_status(st_._h, self._descs, self.nq, b, bm_ptr, bm_bits, omc, par, self._stride,
+                                               self.out_ids.ctypes.data, self.out_sc.ctypes.data, self.out_n.ctypes.data,
+                                               self.out_count.ctypes.data, st.ctypes.data)
+            return st[: self.nq]
+        N.check(lib.orama_post_search_batch(st_._h, self._descs, self.nq, b, bm_ptr, bm_bits, omc, par, self._stride,
+                                            self.out_ids.ctypes.data, self.out_sc.ctypes.data, self.out_n.ctypes.data,
+                                            self.out_count.ctypes.data))
+        return None
+
+    def results(self):
+        return [(self.out_ids[i, : self.out_n[i]].copy(), self.out_sc[i, : self.out_n[i]].copy(), int(self.out_count[i]))
+                for i in range(self.nq)]
+
+
 class PostingsStore(Owner):
     """HBM-resident postings of one index (seam ii)."""
 
@@ -501,33 +545,15 @@ class PostingsStore(Owner):
         take run on `max_parallel` library threads.  Returns a list of (ids, scores, count), each identical to `search`
         of that query.  With `statuses` (orama_post_search_batch_status) nothing is raised for a failing query: the
         result is (list, status array) and a failed query's entry is empty."""
-        nq = len(queries)
-        descs = (N.PostQueryDesc * max(nq, 1))()
-        keep = []
-        for i, qd in enumerate(queries):
-            refs, n_tokens, thr = qd[0], qd[1], qd[2]
-            arr = self._refs(refs)
-            keep.append(arr)
-            descs[i].refs = C.cast(arr, C.POINTER(N.TermRef))
-            descs[i].n_refs = len(refs)
-            descs[i].params = _params(total_documents, n_tokens, thr, qd[3] if len(qd) > 3 else top_k, k)
-        out_ids = np.zeros((max(nq, 1), max(top_k, 1)), dtype=np.uint64)
-        out_sc = np.zeros((max(nq, 1), max(top_k, 1)), dtype=np.float32)
-        out_n = np.zeros(max(nq, 1), dtype=np.uint32)
-        out_count = np.zeros(max(nq, 1), dtype=np.uint64)
-        bm_ptr, bm_bits = allow.ffi_args() if allow is not None else (None, 0)
-        if statuses:
-            st = np.zeros(max(nq, 1), dtype=np.int32)
-            self._lib.orama_post_search_batch_status(self._h, descs, nq, b, bm_ptr, bm_bits, 1 if apply_omc else 0,
-                                                     int(max_parallel), max(top_k, 1), out_ids.ctypes.data,
-                                                     out_sc.ctypes.data, out_n.ctypes.data, out_count.ctypes.data,
-                                                     st.ctypes.data)
-        else:
-            N.check(self._lib.orama_post_search_batch(self._h, descs, nq, b, bm_ptr, bm_bits, 1 if apply_omc else 0,
-                                                      int(max_parallel), max(top_k, 1), out_ids.ctypes.data,
-                                                      out_sc.ctypes.data, out_n.ctypes.data, out_count.ctypes.data))
-        res = [(out_ids[i, : out_n[i]].copy(), out_sc[i, : out_n[i]].copy(), int(out_count[i])) for i in range(nq)]
-        return (res, st[:nq]) if statuses else res
+        prep = self.prepare_batch(queries, total_documents, top_k, allow, apply_omc, max_parallel, b, k)
+        st = prep.run(statuses)
+        return (prep.results(), st) if statuses else prep.results()
+
+    def prepare_batch(self, queries, total_documents: float, top_k: int, allow: AllowBitmap | None = None,
+                      apply_omc: bool = True, max_parallel: int = 8, b: float = B_DEFAULT, k: float = K1_DEFAULT) -> "PreparedBatch":
+        """The descriptor array of `search_batch` built once (what a native caller holds anyway): `.run()` is the bare
+        orama_post_search_batch call, `.results()` the list `search_batch` returns."""
+        return PreparedBatch(self, queries, total_documents, top_k, allow, apply_omc, max_parallel, b, k)
 
     def search_scores(self, refs, n_tokens: int, total_documents: float, top_k: int, threshold=None,
                       allow: AllowBitmap | None = None, apply_omc: bool = True, b: float = B_DEFAULT,

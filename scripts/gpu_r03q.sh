@@ -1,0 +1,15 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+R=$PWD
+O=$R/gpurun_out/r03q
+mkdir -p $O
+timeout 600 python bench.py --no-pmc --configs c4 --no-cpu-baseline 2>&1 | tail -1 > $O/bench_c4.json
+python - <<'PY'
+import json
+d=json.load(open("gpurun_out/r03q/bench_c4.json"))
+c=d["configs"]["c4"]
+print("NS", d["value"], "two-stage", d["two_stage_exact"]["value"])
+print("C4", c["value"], c["ms_per_step"], c["shadow_store"]["value"])
+b=c["bm25_only"]
+print("BM25 batch", b["value"], "py", b["through_python_wrapper"]["value"], "single", b["single_query_calls"], "dev us", b["roofline"]["device_us_per_query"], b["roofline"]["device_us_by_kernel"])
+PY

@@ -368,3 +368,87 @@ def test_open_score_maps_do_not_starve_searches(ctx):
     for m in maps:
         m.close()
     corpus.store.close()
+
+
+def test_one_call_hybrid_search_on_the_range_scorer(ctx):
+    """orama_hybrid_search with its full-text leg on K3r and the tail on candidates (raw top-(k + limit + 1) selected
+    while the scan runs, the vector hits scored by document afterwards): against the oracle and against the same call
+    on K3's per-document records, bit for bit — plain and shadow (two-stage) vector stores, E5 rescale, cut-off,
+    filter, several rows per document, k and limit from 1 to 300; ties at the cut and OMC fall back and still answer."""
+    import util
+
+    rng = np.random.default_rng(77)
+    n_docs, dim = 30_000, 64
+    corpus = Corpus(ctx, n_docs, random_lists(rng, n_docs, 16, 2, 200, 6000), [80.0, 12.0], doc_ids=np.arange(n_docs, dtype=np.uint64) * 3 + 5, seed=78)
+    rows = util.gaussian_rows(n_docs + 4000, dim, seed=79)
+    row_doc = np.concatenate([corpus.doc_ids, corpus.doc_ids[rng.choice(n_docs, size=4000, replace=False)]])  # some documents own two rows
+    allow_mask = rng.random(n_docs) < 0.6
+    bm = oa.AllowBitmap(int(corpus.doc_ids.max()) + 1, corpus.doc_ids[allow_mask])
+    stores = {"plain": oa.EmbeddingFieldStorage(ctx, dimensions=dim), "shadow": oa.EmbeddingFieldStorage(ctx, dimensions=dim, dtype=oa._native.DTYPE_F32_SHADOW16)}
+    for st in stores.values():
+        st.insert_rows(row_doc, rows)
+
+    served = 0
+    for case in range(8):
+        n_tok = int(rng.integers(1, 5))
+        refs = [(t, int(l), float(F(rng.choice([1.0, 1.5])))) for t in range(n_tok) for l in rng.choice(16, size=int(rng.integers(1, 3)), replace=False)]
+        q = (rows[int(rng.integers(len(rows)))] + F(0.4) * rows[int(rng.integers(len(rows)))]).astype(F)
+        k, limit = [(10, 10), (1, 300), (100, 100), (300, 1), (25, 40), (100, 7), (5, 64), (50, 200)][case]
+        sim, e5, filt = [(0.0, False, False), (0.0, False, True), (0.5, False, False), (0.0, True, False)][case % 4]
+        thr = 1 if case == 5 else None
+        got = {}
+        for name, st in stores.items():
+            for mode in (True, False):
+                ctx.set_bm25_ranges(True, hybrid=mode)
+                ctx.prof_reset()
+                ctx.prof_enable(True)
+                got[name, mode] = corpus.store.hybrid_search(st, q, limit, sim, refs, n_tok, float(n_docs), k, thr, allow=bm if filt else None, rescale_e5=e5)
+                ctx.prof_enable(False)
+                if mode:
+                    served += ctx.prof_get("bm25_range_score")[1] > 0 and ctx.prof_get("bm25_accumulate")[1] == 0
+                else:
+                    assert ctx.prof_get("bm25_accumulate")[1] > 0
+        ids0, sc0, cnt0 = got["plain", False]
+        for key, (ids, sc, cnt) in got.items():
+            assert cnt == cnt0 and ids.tolist() == ids0.tolist() and np.array_equal(bits(sc), bits(sc0)), (case, key)
+        # ... and the oracle's combine over the oracle's epilogue of the library's own vector hits (the scan itself is
+        # checked against the oracle in test_vector_gpu.py)
+        h_ids, h_dist, h_n = stores["plain"].storage_search(q, limit, bm if filt else None)
+        vec = orc.embedding_epilogue(h_ids[0][: h_n[0]], h_dist[0][: h_n[0]], e5, sim)
+        fd, fs = orc.search_full_text(corpus.entries(refs, allow_mask if filt else None), n_tok, float(n_docs), 1.2, thr)
+        od, os_ = orc.normalize_and_combine(list(vec), [float(v) for v in vec.values()], fd, fs)
+        td, ts = orc.top_n(od, os_, k)
+        assert cnt0 == len(od) and ids0.tolist() == td.tolist(), case
+        assert np.array_equal(bits(sc0), bits(ts)), case
+    assert served >= 14  # the range scorer answered (nearly) every eligible call without the per-record scorer
+    ctx.set_bm25_ranges(True)
+
+    # ties at the cut -> the candidates cannot prove the answer -> the per-record scorer answers, same result
+    docs = np.arange(3000, dtype=np.int64)
+    flat = Corpus(ctx, 3000, [(0, docs)], [7.0], seed=1)
+    flat.store.build(flat.doc_ids, flat.avg, [ft.PostingList(field=0, docs=flat.doc_ids, tf=np.ones(3000), field_len=np.full(3000, 7))])
+    fv = oa.EmbeddingFieldStorage(ctx, dimensions=dim)
+    fv.insert_rows(flat.doc_ids, rows[:3000])
+    res = {}
+    for mode in (True, False):
+        ctx.set_bm25_ranges(True, hybrid=mode)
+        res[mode] = flat.store.hybrid_search(fv, rows[17], 5, 0.0, [(0, 0, 1.0)], 1, 3000.0, 10)
+    assert res[True][2] == res[False][2] == 3000 and res[True][0].tolist() == res[False][0].tolist()
+    assert np.array_equal(bits(res[True][1]), bits(res[False][1]))
+    # OMC -> per-record scorer; no full-text side -> the vector map alone
+    ctx.set_bm25_ranges(True)
+    flat.store.set_omc({11: 4.0})
+    a = flat.store.hybrid_search(fv, rows[17], 5, 0.0, [(0, 0, 1.0)], 1, 3000.0, 10, apply_omc=True)
+    assert 11 in a[0].tolist()
+    flat.store.set_omc({})
+    e = flat.store.hybrid_search(fv, rows[17], 5, 0.0, [], 1, 3000.0, 10)
+    assert e[2] == 5 and e[0][0] == 17
+    # a vector hit that is not a document of the index: the per-record scorer's error, not a wrong answer
+    fv.insert_rows(np.array([999_999], dtype=np.uint64), rows[17:18] * F(1.0))
+    with pytest.raises(oa.OramaError):
+        flat.store.hybrid_search(fv, rows[17], 5, 0.0, [(0, 0, 1.0)], 1, 3000.0, 10)
+    fv.close()
+    flat.store.close()
+    for st in stores.values():
+        st.close()
+    corpus.store.close()
