@@ -50,6 +50,10 @@ __device__ __forceinline__ bool f32_is_normal(float x) {
 // 17 list elements per entry instead of all of them, and the upper levels of every search stay in cache: 0.7 us.)
 __global__ __launch_bounds__(kThreads) void range_bounds_kernel(RangeBatch b) {
     const uint32_t qi = blockIdx.y;
+    // the query's result words start at zero: cleared here, by the first launch of the set, instead of by a fill command
+    // of their own in front of it
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < sizeof(RangeResult) / 4; i += kThreads) reinterpret_cast<uint32_t*>(&b.results[qi])[i] = 0u;
     const RangeQuery q = b.queries[qi];
     const uint32_t ns = q.seg_end - q.seg_begin;
     const uint64_t entries = (uint64_t)ns * (q.n_ranges + 1u);
@@ -438,7 +442,10 @@ __global__ __launch_bounds__(kThreads) void range_score_docs_kernel(RangeBatch b
 }  // namespace
 
 int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream) {
-    if (b.total_postings == 0 || b.n_queries == 0 || b.max_bound_entries == 0) return ORAMA_OK;
+    if (b.total_postings == 0 || b.n_queries == 0 || b.max_bound_entries == 0) {
+        if (b.n_queries) ORAMA_HIP_TRY(hipMemsetAsync(b.results, 0, (size_t)b.n_queries * sizeof(RangeResult), stream));
+        return ORAMA_OK;
+    }
     ORAMA_REQUIRE(b.n_queries <= 65535, "bm25 ranges: batch too large");
     ProfScope prof(&ctx->prof, "bm25_range_bounds", stream);
     const uint64_t blocks = (b.max_bound_entries + kThreads - 1) / kThreads;

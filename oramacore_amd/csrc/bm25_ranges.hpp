@@ -70,7 +70,7 @@ struct RangeBatch {
     uint32_t debug = 0;  // timing ablations (ORAMA_K3R_DBG): 1 skip the merge, 2 skip the fold, 4 stop after the bounds loads
 };
 
-// bounds[query][r][reference] = postings of the reference whose document lies in a range < r.
+// bounds[query][r][reference] = postings of the reference whose document lies in a range < r.  Also zeroes `results`.
 int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream);
 // df_only: count distinct (token, document) pairs into results[q].df for the queries that want it.
 int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStream_t stream);

@@ -742,7 +742,6 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         const size_t out_bytes = res_bytes + (size_t)nq * kk * 12 + (size_t)nq * 4;
         ORAMA_TRY(sc->misc2.reserve(out_bytes));
         ORAMA_TRY(sc->misc3.reserve((size_t)nq * max_total * 8));
-        ORAMA_HIP_TRY(hipMemsetAsync(sc->misc2.p, 0, res_bytes, s));
         char* d = sc->misc0.as<char>();
         float* d_idf = reinterpret_cast<float*>(d + seg_bytes + q_bytes);
         RangeBatch& rb = c.rb;

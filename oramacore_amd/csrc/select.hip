@@ -683,19 +683,21 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
         // The k best BY KEY are cut out first — the radix threshold of the reduction levels, so that the cut among equal
         // values keeps the lowest indices exactly as every level before this one does (DESIGN.md §3 rule 4) — and only
         // those are ordered by (value, id, index).
-        unsigned long long* kb = reinterpret_cast<unsigned long long*>(s.id);  // (the key buffer aliases the id column)
+        // (the key buffer aliases the whole record array: 8 192 keys — two reduction chunks' worth, see keys_final_capacity)
+        unsigned long long* kb = reinterpret_cast<unsigned long long*>(&s);
         for (uint32_t i = threadIdx.x; i < n_keys; i += blockDim.x) kb[i] = in[i];
         if (threadIdx.x == 0) cursor = 0;
         __syncthreads();
         const unsigned long long thr = lds_keys_threshold(kb, n_keys, k, hist, red_max, red_min, red_nz, sel);
-        constexpr uint32_t kPerThread = kSelectMaxK / kSortThreads;
+        constexpr uint32_t kPerThread = kKeysChunk / kSortThreads;
+        static_assert(sizeof(SortLds) >= kKeysChunk * 8, "the key buffer must fit the record array");
         unsigned long long mine[kPerThread];
 #pragma unroll
         for (uint32_t t = 0; t < kPerThread; ++t) {
             const uint32_t i = t * blockDim.x + threadIdx.x;
             mine[t] = i < n_keys ? kb[i] : 0ull;
         }
-        __syncthreads();  // every key is in a register: the id column may be written
+        __syncthreads();  // every key is in a register: the records may be written
 #pragma unroll
         for (uint32_t t = 0; t < kPerThread; ++t) {
             const bool tk = mine[t] >= thr;  // thr >= 1: empties never
@@ -756,10 +758,18 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
 
 }  // namespace
 
+// Keys the final kernel takes: a full sort handles 4 096 records; when the k best are cut out first (more than two sorts'
+// worth of candidates, see keys_final_kernel) the candidates only pass through the key buffer, which holds 8 192.
+static uint32_t keys_final_capacity(uint32_t k) {
+    uint32_t p2 = 2;
+    while (p2 < k) p2 <<= 1;
+    return 2 * p2 < kSelectMaxK ? kKeysChunk : kSelectMaxK;
+}
+
 uint64_t keys_topk_scratch_keys(uint32_t n_keys, uint32_t q, uint32_t k) {
     uint64_t total = 0;
     uint32_t n = n_keys;
-    while (n > kSelectMaxK) {
+    while (n > keys_final_capacity(k)) {
         const uint32_t chunks = (n + kKeysChunk - 1) / kKeysChunk;
         total += (uint64_t)q * chunks * k;
         n = chunks * k;
@@ -778,7 +788,7 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
     uint32_t n = n_keys;
     unsigned long long* tmp = d_tmp;
     const uint32_t* n_per_list = d_n_per_list;  // applies to the caller's lists only; reduced levels are full
-    while (n > kSelectMaxK) {
+    while (n > keys_final_capacity(k)) {
         ORAMA_REQUIRE(tmp, "keys top-k: scratch missing");
         const uint32_t chunks = (n + kKeysChunk - 1) / kKeysChunk;
         const uint64_t out_stride = (uint64_t)chunks * k;

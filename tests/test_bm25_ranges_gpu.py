@@ -452,3 +452,76 @@ def test_one_call_hybrid_search_on_the_range_scorer(ctx):
     for st in stores.values():
         st.close()
     corpus.store.close()
+
+
+def test_large_lists_and_multi_chunk_batches(ctx):
+    """A 600 000-document store with lists of up to 200 000 postings (hundreds of ranges per query, key lists of several
+    reduction chunks): K3r == K3 == the oracle, bit for bit — plain, thresholds, filter, OMC, hybrid, k from 1 to 300 —
+    and a batch of 70 queries (three sets of launches, two in flight at a time on two scratch sets) == the same queries
+    one by one; 300 000 documents with one and the same score keep the (score desc, DocumentId asc) cut."""
+    rng = np.random.default_rng(91)
+    n_docs = 600_000
+    sizes = [200_000, 120_000, 90_000, 60_000, 40_000, 30_000, 20_000, 9_000, 3_000, 500]
+    lists = [(i % 2, np.sort(rng.choice(n_docs, size=sz, replace=False))) for i, sz in enumerate(sizes)]
+    corpus = Corpus(ctx, n_docs, lists, [70.0, 11.0], seed=92)
+    allow_mask = rng.random(n_docs) < 0.5
+    bm = oa.AllowBitmap(n_docs, np.nonzero(allow_mask)[0].astype(np.uint64))
+    omc = {int(d): float(F(m)) for d, m in zip(rng.choice(n_docs, size=50, replace=False), rng.uniform(0.5, 40.0, size=50))}
+
+    def run(refs, n_tok, k, thr=None, filt=False, use_omc=False):
+        return corpus.store.search(refs, n_tok, float(n_docs), k, thr, allow=bm if filt else None, apply_omc=use_omc)
+
+    cases = [
+        ([(0, 0, 1.0), (1, 1, 1.0), (2, 3, 2.0)], 3, 100, None, False, False),
+        ([(0, 0, 1.0), (1, 2, 1.0), (2, 4, 1.0), (3, 7, 1.5)], 4, 10, 2, False, False),
+        ([(0, 1, 1.0), (0, 2, 1.0), (1, 0, 1.0)], 2, 256, None, False, False),  # two lists of one token: df on the device
+        ([(0, 0, 1.0), (1, 1, 1.0)], 2, 1, None, True, False),
+        ([(0, 0, 1.0), (1, 5, 1.0), (2, 9, 1.0)], 3, 50, None, False, True),
+        ([(0, 3, 1.0), (1, 6, 1.0)], 2, 300, None, False, False),
+        ([(0, 8, 1.0), (1, 9, 1.0)], 2, 20, None, False, False),
+    ]
+    for ci, (refs, n_tok, k, thr, filt, use_omc) in enumerate(cases):
+        corpus.store.set_omc(omc if use_omc else {})
+        od, os_, ocount = corpus.oracle(refs, n_tok, k, thr, allow_mask if filt else None, omc if use_omc else None)
+        got = {}
+        for name, on in (("k3r", True), ("k3", False)):
+            ctx.set_bm25_ranges(on)
+            got[name] = run(refs, n_tok, k, thr, filt, use_omc)
+        for name, (ids, sc, count) in got.items():
+            assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_)), (ci, name)
+    corpus.store.set_omc({})
+    # hybrid (k + n_vec + 1 candidates)
+    ctx.set_bm25_ranges(True)
+    refs = [(0, 0, 1.0), (1, 1, 1.0), (2, 2, 1.0)]
+    fd, fs = orc.search_full_text(corpus.entries(refs), 3, float(n_docs), 1.2, None)
+    vec = {int(d): float(F(s)) for d, s in zip(np.concatenate([rng.choice(fd, 40, replace=False), rng.choice(n_docs, 30, replace=False).astype(np.uint64)]),
+                                               rng.uniform(0.0, 1.0, size=70))}
+    od, os_ = orc.normalize_and_combine(list(vec), list(vec.values()), fd, fs)
+    td, ts = orc.top_n(od, os_, 60)
+    ids, sc, count = corpus.store.search(refs, 3, float(n_docs), 60, vector=vec, apply_omc=False)
+    assert count == len(od) and ids.tolist() == td.tolist() and np.array_equal(bits(sc), bits(ts))
+    # a batch over three chunks, eligible and small queries interleaved
+    queries = []
+    for i in range(70):
+        if i % 3 == 2:
+            queries.append(([(0, 8, 1.0), (1, 9, 1.0)], 2, None, 5 + i))
+        else:
+            queries.append(([(0, int(i % 4), 1.0), (1, 4 + int(i % 3), 1.0)], 2, 1 if i % 5 == 0 else None, 1 + (i * 7) % 200))
+    ctx.set_bm25_ranges(True)
+    a = corpus.store.search_batch(queries, float(n_docs), 256)
+    b = [corpus.store.search(refs, n_tok, float(n_docs), k, thr) for refs, n_tok, thr, k in queries]
+    for i, ((ia, sa, ca), (ib, sb, cb)) in enumerate(zip(a, b)):
+        assert ca == cb and ia.tolist() == ib.tolist() and np.array_equal(bits(sa), bits(sb)), i
+        if i < 6:
+            refs, n_tok, thr, k = queries[i]
+            od, os_, ocount = corpus.oracle(refs, n_tok, k, thr)
+            assert ca == ocount and ia.tolist() == od.tolist() and np.array_equal(bits(sa), bits(os_)), i
+    corpus.store.close()
+    # every document scores the same
+    n_flat = 300_000
+    docs = np.arange(n_flat, dtype=np.int64)
+    flat = Corpus(ctx, n_flat, [(0, docs)], [7.0], seed=1)
+    flat.store.build(flat.doc_ids, flat.avg, [ft.PostingList(field=0, docs=flat.doc_ids, tf=np.ones(n_flat), field_len=np.full(n_flat, 7))])
+    ids, sc, count = flat.store.search([(0, 0, 1.0)], 1, float(n_flat), 25)
+    assert count == n_flat and ids.tolist() == list(range(25)) and len(set(bits(sc).tolist())) == 1
+    flat.store.close()
