@@ -581,6 +581,22 @@ int orama_shard_hybrid_search(orama_shard_group* g, orama_vec* const* vec_shards
                               const uint64_t* const* allow_bitmaps, uint64_t bitmap_bits, int apply_omc,
                               uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count);
 
+/* Concurrency: a group whose shards all live in this process (both orama_shard_group_create forms) serves up to
+ * ORAMA_SHARD_LANES (default 8) sharded calls at a time — each on its own exchange streams and buffers; only the issue
+ * of a collective is serialised.  A one-process-per-rank group serves one call at a time (the callers of different
+ * processes could order concurrent calls differently).  Matches the re-entrancy `search(&self)` assumes
+ * (src/collection_manager/sides/read/collection.rs:846-884).
+ * The request micro-batcher in front of a group: like orama_batcher_create, every pass is one orama_shard_vec_search
+ * over `shards` (the group's local shards, in rank order); orama_batcher_search_filtered then takes, in place of the
+ * bitmap words, the address of the caller's array of resident per-shard tokens (const uint64_t* const*; requests
+ * carrying the same array share a pass).  The group and the stores must outlive the batcher. */
+/* Sharded calls the group can run side by side, and how many lanes (exchange streams + buffers per local shard) it has
+ * made so far. */
+int orama_shard_group_lanes(orama_shard_group* g, uint32_t* max_lanes, uint32_t* lanes_created);
+int orama_batcher_create_group(orama_shard_group* g, orama_vec* const* shards, uint32_t max_batch, uint32_t max_wait_us,
+                               orama_batcher** out);
+
+
 /* Pipelined vector-search session (serving loop / bench.py): `n_queries` queries resident in HBM on every local
  * device; orama_shard_session_step(s, i) enqueues step i — queries [i*q, (i+1)*q) modulo the resident set — without
  * host synchronisation: corpus scans of consecutive steps run back to back on ONE scan stream per device, the

@@ -157,6 +157,8 @@ def _declare(lib: C.CDLL) -> None:
         "orama_dict_create": [vp, vp, vp, C.c_uint32, C.POINTER(vp)],
         "orama_dict_expand": [vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, vp, u32p],
         "orama_batcher_create": [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)],
+        "orama_batcher_create_group": [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)],
+        "orama_shard_group_lanes": [vp, u32p, u32p],
         "orama_batcher_search": [vp, vp, C.c_uint32, vp, vp, u32p],
         "orama_batcher_search_filtered": [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, u32p],
         "orama_batcher_stats": [vp, u64p, u64p, u32p],

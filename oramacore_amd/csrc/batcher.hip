@@ -50,6 +50,10 @@ struct Request {
 
 struct orama_batcher {
     orama_vec* v = nullptr;
+    // a batcher in front of a SHARD GROUP (orama_batcher_create_group): passes go through orama_shard_vec_search over
+    // `shards`; a request's filter is then the caller's array of resident per-shard tokens (grouped by its address)
+    orama_shard_group* group = nullptr;
+    std::vector<orama_vec*> shards;
     uint32_t dim = 0;
     uint32_t max_batch = 64;
     uint32_t max_wait_us = 0;
@@ -108,9 +112,14 @@ struct orama_batcher {
             cnt.assign(q, 0);
             int st = ORAMA_OK;
             std::string err;
+            auto pass_search = [&](const float* qs, uint32_t nq, uint32_t k, uint64_t* o_ids, float* o_dist, uint32_t* o_n) -> int {
+                if (group)
+                    return orama_shard_vec_search(group, shards.data(), qs, nq, k, reinterpret_cast<const uint64_t* const*>(batch[0]->allow),
+                                                  batch[0]->allow_bits, o_ids, o_dist, o_n);
+                return orama_vec_search(v, qs, nq, k, batch[0]->allow, batch[0]->allow_bits, o_ids, o_dist, o_n);
+            };
             if (kmax > 0) {
-                st = orama_vec_search(v, queries.data(), q, kmax, batch[0]->allow, batch[0]->allow_bits, ids.data(),
-                                      dist.data(), cnt.data());
+                st = pass_search(queries.data(), q, kmax, ids.data(), dist.data(), cnt.data());
                 if (st != ORAMA_OK) err = orama_last_error();  // this thread's error slot
             }
             // a failed pass is repeated one request at a time, so that only the request that cannot be served sees an
@@ -121,8 +130,7 @@ struct orama_batcher {
                 for (uint32_t i = 0; i < q; ++i) {
                     sts[i] = ORAMA_OK;
                     if (batch[i]->k == 0) continue;
-                    sts[i] = orama_vec_search(v, &queries[(size_t)i * dim], 1, batch[i]->k, batch[0]->allow, batch[0]->allow_bits,
-                                              &ids[(size_t)i * kmax], &dist[(size_t)i * kmax], &cnt[i]);
+                    sts[i] = pass_search(&queries[(size_t)i * dim], 1, batch[i]->k, &ids[(size_t)i * kmax], &dist[(size_t)i * kmax], &cnt[i]);
                     if (sts[i] != ORAMA_OK) errs[i] = orama_last_error();
                 }
             }
@@ -159,6 +167,30 @@ int orama_batcher_create(orama_vec* v, uint32_t max_batch, uint32_t max_wait_us,
     }
     b->v = v;
     b->dim = vec_dim(v);
+    b->max_batch = max_batch;
+    b->max_wait_us = max_wait_us;
+    for (int w = 0; w < 2; ++w) b->workers.emplace_back([b] { b->run(); });
+    *out = b;
+    return ORAMA_OK;
+}
+
+int orama_batcher_create_group(orama_shard_group* g, orama_vec* const* shards, uint32_t max_batch, uint32_t max_wait_us,
+                               orama_batcher** out) {
+    ORAMA_REQUIRE(g && shards && out, "null argument");
+    *out = nullptr;
+    ORAMA_REQUIRE(max_batch >= 1 && max_batch <= 1024, "max_batch %u outside [1, 1024]", max_batch);
+    uint32_t world = 0, n_local = 0;
+    ORAMA_TRY(orama_shard_group_info(g, &world, &n_local, nullptr, nullptr));
+    for (uint32_t i = 0; i < n_local; ++i) ORAMA_REQUIRE(shards[i], "null shard %u", i);
+    orama_batcher* b = new (std::nothrow) orama_batcher();
+    if (!b) {
+        set_error("out of host memory");
+        return ORAMA_ERR_OOM;
+    }
+    b->group = g;
+    b->shards.assign(shards, shards + n_local);
+    b->v = shards[0];
+    b->dim = vec_dim(shards[0]);
     b->max_batch = max_batch;
     b->max_wait_us = max_wait_us;
     for (int w = 0; w < 2; ++w) b->workers.emplace_back([b] { b->run(); });

@@ -26,6 +26,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -146,19 +147,49 @@ struct ShardLocal {
     hipEvent_t ev = nullptr;
 };
 
+// A LANE is the per-call half of the group: for every local shard an exchange stream, its event and the exchange
+// buffers.  `local` is lane 0 and also owns what the lanes share (contexts, communicators); further lanes are made on
+// demand.  A sharded call leases one lane for its whole duration (both legs of a hybrid search included), so that
+// concurrent callers — the reference serves `search(&self)` from many workers at once, read/collection.rs:846-884 —
+// run side by side on different streams and buffers.  What has to stay ordered is only the ISSUE of a collective: every
+// rank must see the collectives of its communicator in the same order.
+//   * all shards in this process (co-located, or one process driving several GPUs): up to `max_lanes` calls in flight; a
+//     collective is issued for all local ranks inside one critical section (issue_mu), so the order is the same on
+//     every communicator by construction;
+//   * one process per rank: which call comes first is decided by the callers of each process, and concurrent calls could
+//     be ordered differently on different ranks — one lane, i.e. one sharded call at a time, as before.
+struct ShardLane {
+    std::vector<std::unique_ptr<ShardLocal>> local;
+};
+
 struct orama_shard_group {
     Rccl* rccl = nullptr;  // null in the co-located mode
     bool colocated = false;
     int world = 1;         // shards of the index over all processes
     int rank0 = 0;         // global index of local shard 0
-    std::vector<std::unique_ptr<ShardLocal>> local;
-    std::mutex mu;         // one sharded call at a time: collectives must be issued in the same order everywhere
-    // co-located mode: ONE gathered / df / minmax buffer shared by all local shards (lives in local[0])
+    std::vector<std::unique_ptr<ShardLocal>> local;    // lane 0
+    std::vector<std::unique_ptr<ShardLane>> lanes;     // lanes 1 ..
+    std::vector<char> lane_busy;                       // [lane]
+    std::mutex lane_mu;
+    std::condition_variable lane_cv;
+    uint32_t max_lanes = 1;
+    std::mutex issue_mu;   // GroupStart .. GroupEnd of one collective
+    // co-located mode: ONE gathered / df / minmax buffer per lane shared by all local shards (lives in the lane's shard 0)
 };
 
 namespace {
 
-ShardLocal& L(orama_shard_group* g, uint32_t i) { return *g->local[i]; }
+// the lane the calling thread holds (a lease is re-entrant: orama_shard_hybrid_search runs both its legs on one lane)
+struct LaneTls {
+    orama_shard_group* g = nullptr;
+    uint32_t lane = 0, depth = 0;
+};
+thread_local LaneTls tl_lane;
+
+ShardLocal& L(orama_shard_group* g, uint32_t i) {
+    if (tl_lane.g == g && tl_lane.lane > 0) return *g->lanes[tl_lane.lane - 1]->local[i];
+    return *g->local[i];
+}
 uint32_t n_local(orama_shard_group* g) { return (uint32_t)g->local.size(); }
 
 int init_local(ShardLocal& s, orama_ctx* shared_ctx) {
@@ -173,6 +204,108 @@ int init_local(ShardLocal& s, orama_ctx* shared_ctx) {
     ORAMA_HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     ORAMA_HIP_TRY(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
     return ORAMA_OK;
+}
+
+// stream + event of one shard of a further lane (context, device and communicator are lane 0's)
+int init_lane_local(ShardLocal& s, const ShardLocal& owner) {
+    s.ctx = owner.ctx;
+    s.owns_ctx = false;
+    s.device = owner.device;
+    s.comm = owner.comm;
+    ORAMA_HIP_TRY(hipSetDevice(s.device));
+    ORAMA_HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    ORAMA_HIP_TRY(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    return ORAMA_OK;
+}
+
+void free_lane_local(ShardLocal& s) {
+    (void)hipSetDevice(s.device);
+    s.queries.release();
+    s.gathered.release();
+    s.out_ids.release();
+    s.out_val.release();
+    s.out_n.release();
+    s.out_count.release();
+    s.d_n.release();
+    s.df.release();
+    s.minmax.release();
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.ev) (void)hipEventDestroy(s.ev);
+    s.stream = nullptr;
+    s.ev = nullptr;
+}
+
+// One lane of the group for the duration of a sharded call (the caller's DeviceScope is already in place).
+class LaneLease {
+   public:
+    explicit LaneLease(orama_shard_group* g) : g_(g) {}
+    LaneLease(const LaneLease&) = delete;
+    LaneLease& operator=(const LaneLease&) = delete;
+    int init() {
+        if (tl_lane.g == g_) {  // nested call of the same thread: same lane
+            ++tl_lane.depth;
+            held_ = true;
+            return ORAMA_OK;
+        }
+        ORAMA_REQUIRE(tl_lane.g == nullptr, "a sharded call of another group is in progress on this thread");
+        std::unique_lock<std::mutex> lk(g_->lane_mu);
+        uint32_t lane = 0;
+        for (;;) {
+            bool found = false;
+            for (uint32_t l = 0; l < g_->lane_busy.size() && !found; ++l)
+                if (!g_->lane_busy[l]) lane = l, found = true;
+            if (found) break;
+            if (g_->lane_busy.size() < g_->max_lanes) {  // another lane: streams + events now, buffers as the calls size them
+                std::unique_ptr<ShardLane> ln(new ShardLane());
+                for (uint32_t i = 0; i < g_->local.size(); ++i) {
+                    ln->local.emplace_back(new ShardLocal());
+                    const int st = init_lane_local(*ln->local.back(), *g_->local[i]);
+                    if (st != ORAMA_OK) {
+                        for (auto& sp : ln->local) free_lane_local(*sp);
+                        return st;
+                    }
+                }
+                g_->lanes.push_back(std::move(ln));
+                g_->lane_busy.push_back(0);
+                lane = (uint32_t)g_->lane_busy.size() - 1;
+                break;
+            }
+            g_->lane_cv.wait(lk);
+        }
+        g_->lane_busy[lane] = 1;
+        tl_lane.g = g_;
+        tl_lane.lane = lane;
+        tl_lane.depth = 1;
+        held_ = true;
+        return ORAMA_OK;
+    }
+    ~LaneLease() {
+        if (!held_) return;
+        if (--tl_lane.depth > 0) return;
+        {
+            std::lock_guard<std::mutex> lk(g_->lane_mu);
+            g_->lane_busy[tl_lane.lane] = 0;
+        }
+        tl_lane = LaneTls{};
+        g_->lane_cv.notify_one();
+    }
+
+   private:
+    orama_shard_group* g_;
+    bool held_ = false;
+};
+#define ORAMA_LEASE_LANE(g) \
+    LaneLease lane_lease__(g); \
+    ORAMA_TRY(lane_lease__.init())
+
+void init_lanes(orama_shard_group* g) {
+    g->lane_busy.assign(1, 0);
+    g->max_lanes = 1;
+    if (g->world == (int)g->local.size()) {  // every rank of the group lives in this process
+        const char* e = getenv("ORAMA_SHARD_LANES");
+        const long v = e ? atol(e) : 8;
+        g->max_lanes = (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
+    }
 }
 
 // The gathered buffer a shard's block is written into / merged from, and the slot of local shard i inside it.
@@ -202,6 +335,7 @@ int exchange_all_gather(orama_shard_group* g, size_t block_bytes) {
         return ORAMA_OK;
     }
     Rccl* r = g->rccl;
+    std::lock_guard<std::mutex> issue(g->issue_mu);
     if (n_local(g) > 1) ORAMA_NCCL_TRY(r, r->GroupStart());
     for (uint32_t i = 0; i < n_local(g); ++i) {
         ShardLocal& s = L(g, i);
@@ -236,6 +370,7 @@ int exchange_all_reduce(orama_shard_group* g, bool df, uint32_t count) {
         return ORAMA_OK;
     }
     Rccl* r = g->rccl;
+    std::lock_guard<std::mutex> issue(g->issue_mu);
     if (n_local(g) > 1) ORAMA_NCCL_TRY(r, r->GroupStart());
     for (uint32_t i = 0; i < n_local(g); ++i) {
         ShardLocal& s = L(g, i);
@@ -331,6 +466,7 @@ int orama_shard_group_create(const int* devices, uint32_t n_shards, uint32_t fla
         ORAMA_NCCL_TRY(g->rccl, g->rccl->CommInitAll(comms.data(), (int)n_shards, devices));
         for (uint32_t i = 0; i < n_shards; ++i) g->local[i]->comm = comms[i];
     }
+    init_lanes(g.get());
     *out = g.release();
     return ORAMA_OK;
 }
@@ -355,6 +491,7 @@ int orama_shard_group_create_rank(const void* id128, int rank, int world, int de
     memcpy(id.internal, id128, 128);
     ORAMA_HIP_TRY(hipSetDevice(device));
     ORAMA_NCCL_TRY(g->rccl, g->rccl->CommInitRank(&g->local[0]->comm, world, id, rank));
+    init_lanes(g.get());
     *out = g.release();
     return ORAMA_OK;
 }
@@ -366,6 +503,8 @@ void orama_shard_group_destroy(orama_shard_group* g) {
         (void)hipSetDevice(sp->device);
         (void)hipDeviceSynchronize();
     }
+    for (auto& ln : g->lanes)
+        for (auto& sp : ln->local) free_lane_local(*sp);
     for (auto& sp : g->local) {
         ShardLocal& s = *sp;
         (void)hipSetDevice(s.device);
@@ -402,11 +541,19 @@ int orama_shard_group_info(orama_shard_group* g, uint32_t* world, uint32_t* n_lo
     return ORAMA_OK;
 }
 
+int orama_shard_group_lanes(orama_shard_group* g, uint32_t* max_lanes, uint32_t* lanes_created) {
+    ORAMA_REQUIRE(g, "null group");
+    std::lock_guard<std::mutex> lk(g->lane_mu);
+    if (max_lanes) *max_lanes = g->max_lanes;
+    if (lanes_created) *lanes_created = (uint32_t)g->lane_busy.size();
+    return ORAMA_OK;
+}
+
 // Barrier over every shard of the group: local devices drained, one word all-reduced, drained again.
 int orama_shard_group_barrier(orama_shard_group* g) {
     ORAMA_REQUIRE(g, "null group");
     DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
-    std::lock_guard<std::mutex> lk(g->mu);
+    ORAMA_LEASE_LANE(g);
     for (auto& sp : g->local) {
         ORAMA_HIP_TRY(hipSetDevice(sp->device));
         ORAMA_HIP_TRY(hipDeviceSynchronize());
@@ -430,7 +577,7 @@ int orama_shard_group_allreduce_max_f64(orama_shard_group* g, double* inout) {
     ORAMA_REQUIRE(g && inout, "null argument");
     DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     if (g->colocated || g->world == (int)n_local(g)) return ORAMA_OK;  // one process holds every shard
-    std::lock_guard<std::mutex> lk(g->mu);
+    ORAMA_LEASE_LANE(g);
     ShardLocal& s = L(g, 0);
     ORAMA_HIP_TRY(hipSetDevice(s.device));
     ORAMA_TRY(s.minmax.reserve(16));
@@ -452,7 +599,7 @@ int orama_shard_vec_search(orama_shard_group* g, orama_vec* const* shards, const
     if (k == 0) return ORAMA_OK;
     ORAMA_SUPPORT(k <= kSelectMaxK && (uint64_t)g->world * k <= kSelectMaxK, "limit %u x %d shards exceeds the merge capacity %u",
                   k, g->world, kSelectMaxK);
-    std::lock_guard<std::mutex> lk(g->mu);
+    ORAMA_LEASE_LANE(g);
     const size_t nb = (size_t)packed_block_bytes(q, k);
     ORAMA_TRY(reserve_gathered(g, nb));
     orama_vec_info_t info;
@@ -518,7 +665,7 @@ int orama_shard_post_search(orama_shard_group* g, orama_post* const* shards, con
     ORAMA_SUPPORT(params->n_tokens <= kMaxTokens, "n_tokens %u outside [1, %u]", params->n_tokens,
                   kMaxTokens);
     ORAMA_REQUIRE(!hybrid || n_vec == 0 || (vec_doc && vec_score), "null vector map");
-    std::lock_guard<std::mutex> lk(g->mu);
+    ORAMA_LEASE_LANE(g);
     const size_t nb = (size_t)orama_post_block_bytes(k);
     ORAMA_TRY(reserve_gathered(g, nb));
     ORAMA_TRY(reserve_small(g));
@@ -624,6 +771,10 @@ int orama_shard_hybrid_search(orama_shard_group* g, orama_vec* const* vec_shards
                               const uint64_t* const* allow_bitmaps, uint64_t bitmap_bits, int apply_omc,
                               uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint64_t* out_count) {
     ORAMA_REQUIRE(g && vec_shards && post_shards && query && params && out_n, "null argument");
+    DeviceScope caller_device__;
+    // ONE lane for both legs: with one process per rank nothing of another call may slip between the collectives of the
+    // vector leg and those of the full-text leg on one rank and not on another
+    ORAMA_LEASE_LANE(g);
     std::vector<uint64_t> ids(limit ? limit : 1);
     std::vector<float> dist(limit ? limit : 1);
     uint32_t n = 0;
@@ -764,8 +915,9 @@ int orama_shard_session_step(orama_shard_session* s, uint32_t step) {
     ORAMA_REQUIRE(s, "null session");
     DeviceScope caller_device__;  // inner hipSetDevice calls walk the local shards; the caller's device comes back on return
     orama_shard_group* g = s->g;
-    // collectives of a session step and of the one-call searches must not interleave differently on different ranks
-    std::lock_guard<std::mutex> lk(g->mu);
+    // collectives of a session step and of the one-call searches must not interleave differently on different ranks: with one
+    // process per rank the step takes the group's only lane; otherwise the issue lock below orders them
+    ORAMA_LEASE_LANE(g);
     const uint32_t slot = step % s->n_slots;
     const uint32_t steps_resident = s->n_queries / s->q;
     const size_t qoff = (size_t)(step % steps_resident) * s->q * s->dim;
@@ -797,6 +949,7 @@ int orama_shard_session_step(orama_shard_session* s, uint32_t step) {
         }
     } else {
         Rccl* r = g->rccl;
+        std::lock_guard<std::mutex> issue(g->issue_mu);
         if (nl > 1) ORAMA_NCCL_TRY(r, r->GroupStart());
         for (uint32_t i = 0; i < nl; ++i) {
             ORAMA_HIP_TRY(hipSetDevice(L(g, i).device));

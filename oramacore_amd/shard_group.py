@@ -158,6 +158,54 @@ class ShardGroup:
     def session(self, stores, queries, q_per_step: int, k: int, n_slots: int = 2, force_exchange: bool = False):
         return ShardSession(self, stores, queries, q_per_step, k, n_slots, force_exchange)
 
+    def lanes(self) -> dict:
+        """Sharded calls the group runs side by side (max) and the lanes made so far (orama_shard_group_lanes)."""
+        mx, made = C.c_uint32(), C.c_uint32()
+        N.check(self._lib.orama_shard_group_lanes(self._h, C.byref(mx), C.byref(made)))
+        return {"max": mx.value, "created": made.value}
+
+    def batcher(self, stores, max_batch: int = 64, max_wait_us: int = 0) -> "GroupSearchBatcher":
+        return GroupSearchBatcher(self, stores, max_batch, max_wait_us)
+
+
+class GroupSearchBatcher:
+    """Request micro-batcher in front of a shard group (orama_batcher_create_group): concurrent single-query callers
+    share sharded passes.  `search` blocks like vec_search(q = 1)."""
+
+    def __init__(self, group: ShardGroup, stores, max_batch: int, max_wait_us: int):
+        self._lib = group._lib
+        self.group, self.stores = group, list(stores)
+        self.dim = stores[0].dim
+        h = C.c_void_p()
+        N.check(self._lib.orama_batcher_create_group(group._h, group._handles(stores), int(max_batch), int(max_wait_us), C.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.orama_batcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def search(self, target, limit: int):
+        t = np.ascontiguousarray(np.asarray(target, dtype=np.float32).reshape(self.dim))
+        k = int(limit)
+        ids = np.zeros(max(k, 1), dtype=np.uint64)
+        dist = np.zeros(max(k, 1), dtype=np.float32)
+        n = C.c_uint32()
+        N.check(self._lib.orama_batcher_search(self._h, t.ctypes.data, k, ids.ctypes.data, dist.ctypes.data, C.byref(n)))
+        return ids[: n.value], dist[: n.value]
+
+    def stats(self) -> dict:
+        r, b, l = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        N.check(self._lib.orama_batcher_stats(self._h, C.byref(r), C.byref(b), C.byref(l)))
+        return {"requests": r.value, "batches": b.value, "largest_batch": l.value,
+                "mean_batch": (r.value / b.value) if b.value else 0.0}
+
 
 class ShardSession:
     """Pipelined vector-search steps over resident queries (orama_shard_session_*): bench.py's timed loop."""

@@ -5,7 +5,9 @@
 //   bench_serving bm25 [docs=10000000] [requests_per_thread=400] [threads=1,8,32,128]
 //   bench_serving hybrid [docs=10000000] [requests_per_thread=30] [threads=1,8,32,64] [f32|shadow]   (fp32 vectors + BM25F,
 //                      min-max merge; shadow = the vector store also keeps an fp16 copy: two-stage exact vector leg)
-//   bench_serving vec  [rows=10000000] [requests_per_thread=100] [threads=8,64,256,512] [f16|f32|shadow]   (768 dims, top-100;
+//   bench_serving vec  [rows=10000000] [requests_per_thread=100] [threads=8,64,256,512] [f16|f32|shadow] [shards=1]   (768 dims, top-100;
+//                      shards > 1: the rows split over a co-located shard GROUP on this GPU — orama_shard_vec_search from
+//                      every caller thread / orama_batcher_create_group — against the single store of shards = 1;
 //                      shadow = fp32 rows + fp16 shadow, exact fp32 answers by the two-stage plan)
 // Build: g++ -O2 -std=c++17 -I include scripts/native/bench_serving.cpp -L oramacore_amd/csrc -lorama_hip -pthread
 #include <algorithm>
@@ -52,18 +54,37 @@ int main(int argc, char** argv) {
         orama_vec* vec = nullptr;
         const std::string dts = argc > 5 ? argv[5] : "f16";
         const int dt = dts == "f32" ? ORAMA_DTYPE_F32 : dts == "shadow" ? ORAMA_DTYPE_F32_SHADOW16 : ORAMA_DTYPE_F16;
-        CHECK(orama_vec_create(ctx, dim, ORAMA_METRIC_COSINE, dt, n_docs, &vec));
-        CHECK(orama_vec_fill_synthetic(vec, n_docs, 0x5EED, 0));
+        const int n_shards = argc > 6 ? std::max(1, atoi(argv[6])) : 1;
+        orama_shard_group* group = nullptr;
+        std::vector<orama_vec*> shards;
+        if (n_shards > 1) {
+            std::vector<int> devs((size_t)n_shards, 0);
+            CHECK(orama_shard_group_create(devs.data(), (uint32_t)n_shards, 0, &group));
+            const uint64_t per = n_docs / (uint64_t)n_shards;
+            for (int s = 0; s < n_shards; ++s) {
+                orama_vec* sv = nullptr;
+                const uint64_t rows = s == n_shards - 1 ? n_docs - per * (uint64_t)(n_shards - 1) : per;
+                CHECK(orama_vec_create(orama_shard_group_ctx(group, (uint32_t)s), dim, ORAMA_METRIC_COSINE, dt, rows, &sv));
+                CHECK(orama_vec_fill_synthetic(sv, rows, 0x5EED + (uint64_t)s, per * (uint64_t)s));
+                shards.push_back(sv);
+            }
+            vec = shards[0];
+        } else {
+            CHECK(orama_vec_create(ctx, dim, ORAMA_METRIC_COSINE, dt, n_docs, &vec));
+            CHECK(orama_vec_fill_synthetic(vec, n_docs, 0x5EED, 0));
+        }
         std::mt19937_64 rng(0xBEEF);
         std::normal_distribution<float> g(0.f, 1.f);
         std::vector<float> qv((size_t)NQ * dim);
         for (auto& x : qv) x = g(rng);
-        printf("vec: %llu x %u rows (%s store), top-%u, single-query requests\n", (unsigned long long)n_docs, dim, dts.c_str(), K);
+        printf("vec: %llu x %u rows (%s store%s), top-%u, single-query requests\n", (unsigned long long)n_docs, dim, dts.c_str(),
+               n_shards > 1 ? (", " + std::to_string(n_shards) + " co-located shards in one group").c_str() : "", K);
         for (int batched = 0; batched < 2; ++batched) {
             for (int nt : thread_counts) {
                 if (!batched && nt > 64) continue;  // direct calls: one corpus pass per request
                 orama_batcher* batcher = nullptr;
-                if (batched) CHECK(orama_batcher_create(vec, dt == ORAMA_DTYPE_F32 ? 8 : 256, 0, &batcher));
+                if (batched && group) CHECK(orama_batcher_create_group(group, shards.data(), dt == ORAMA_DTYPE_F32 ? 8 : 256, 0, &batcher));
+                else if (batched) CHECK(orama_batcher_create(vec, dt == ORAMA_DTYPE_F32 ? 8 : 256, 0, &batcher));
                 const int count = batched ? per_thread : std::max(4, per_thread / 8);
                 std::atomic<uint64_t> checksum{0};
                 auto worker = [&](int tid, int cnt) {
@@ -74,6 +95,7 @@ int main(int argc, char** argv) {
                         const float* q = &qv[(size_t)((tid * 131 + i) % NQ) * dim];
                         uint32_t n = 0;
                         if (batched) CHECK(orama_batcher_search(batcher, q, K, ids.data(), dist.data(), &n));
+                        else if (group) CHECK(orama_shard_vec_search(group, shards.data(), q, 1, K, nullptr, 0, ids.data(), dist.data(), &n));
                         else CHECK(orama_vec_search(vec, q, 1, K, nullptr, 0, ids.data(), dist.data(), &n));
                         acc += ids[0];
                     }
@@ -92,14 +114,23 @@ int main(int argc, char** argv) {
                     CHECK(orama_batcher_stats(batcher, &req, &bat, &largest));
                     orama_batcher_destroy(batcher);
                 }
-                printf("%-28s %4d caller threads: %9.0f requests/s", batched ? "orama_batcher_search" : "orama_vec_search (direct)", nt,
+                printf("%-28s %4d caller threads: %9.0f requests/s",
+                       batched ? "orama_batcher_search" : (group ? "orama_shard_vec_search" : "orama_vec_search (direct)"), nt,
                        (double)nt * count / el);
                 if (batched) printf("   (mean batch %.1f, largest %u)", bat ? (double)req / (double)bat : 0.0, largest);
                 printf("   checksum %llu\n", (unsigned long long)checksum.load());
                 fflush(stdout);
             }
         }
-        orama_vec_destroy(vec);
+        if (group) {
+            uint32_t max_lanes = 0, lanes = 0;
+            CHECK(orama_shard_group_lanes(group, &max_lanes, &lanes));
+            printf("group: %u of at most %u lanes made\n", lanes, max_lanes);
+            for (orama_vec* sv : shards) orama_vec_destroy(sv);
+            orama_shard_group_destroy(group);
+        } else {
+            orama_vec_destroy(vec);
+        }
         orama_ctx_destroy(ctx);
         return 0;
     }

@@ -165,3 +165,97 @@ def test_colocated_hybrid_in_one_call(ctx):
     for s in vecs + posts + [single_vec, single_post]:
         s.close()
     group.close()
+
+
+def test_concurrent_callers_on_a_colocated_group(ctx):
+    """Many threads at once on ONE 4-shard group (the re-entrancy `search(&self)` assumes, read/collection.rs:846-884):
+    vector searches of 1..20 queries, full-text, hybrid, requests through the group's batcher and a pipelined session —
+    every answer bit-identical to the single store's, no deadlock; the group really ran calls side by side (more than
+    one lane in use)."""
+    import threading
+
+    n, d, n_tok = 4000, 128, 3
+    rng = np.random.default_rng(18)
+    rows = util.gaussian_rows(n, d, seed=19)
+    doc_ids = np.arange(n, dtype=np.uint64) * 2 + 7
+    lens = rng.integers(5, 100, size=n).astype(np.uint32)
+    avg = float(lens.mean())
+    pos = [np.sort(rng.choice(n, size=sz, replace=False)) for sz in (1500, 900, 400)]
+    tfs = [rng.integers(1, 4, size=len(p)).astype(np.uint32) for p in pos]
+    single_vec = oa.EmbeddingFieldStorage(ctx, dimensions=d)
+    single_vec.insert_rows(doc_ids, rows)
+    single_post = ft.PostingsStore(ctx)
+    single_post.build(doc_ids, [avg], [ft.PostingList(field=0, docs=doc_ids[p], tf=t, field_len=lens[p]) for p, t in zip(pos, tfs)])
+    cuts = [0, 1000, 2100, 3000, n]
+    group = ShardGroup([0, 0, 0, 0])
+    vecs = build_vec_shards(group, rows, doc_ids, cuts)
+    posts = []
+    for g in range(4):
+        lo, hi = cuts[g], cuts[g + 1]
+        lists = []
+        for p, t in zip(pos, tfs):
+            m = (p >= lo) & (p < hi)
+            lists.append(ft.PostingList(field=0, docs=doc_ids[p[m]], tf=t[m], field_len=lens[p[m]]))
+        ps = ft.PostingsStore(group.ctx(g))
+        ps.build(doc_ids[lo:hi], [avg], lists)
+        posts.append(ps)
+    refs = [(t, t, 1.0) for t in range(n_tok)]
+    queries = util.gaussian_rows(64, d, seed=23)
+    # expected answers from the single stores
+    e_vec = {nq: single_vec.storage_search(queries[:nq], 10) for nq in (1, 5, 20)}
+    e_one = [single_vec.storage_search(queries[i], 7) for i in range(16)]
+    e_post = single_post.search(refs, n_tok, float(n), 25)
+    e_hyb = [single_post.hybrid_search(single_vec, queries[i], 12, 0.0, refs, n_tok, float(n), 20) for i in range(8)]
+    batcher = group.batcher(vecs, max_batch=32)
+    errors, done = [], {"vec": 0, "post": 0, "hyb": 0, "bat": 0}
+    lock = threading.Lock()
+    deadline = [None]
+
+    def same(a, b):
+        return np.array_equal(np.asarray(a[0]), np.asarray(b[0])) and np.array_equal(np.asarray(a[1]).view(np.uint32), np.asarray(b[1]).view(np.uint32))
+
+    def worker(kind, seed):
+        import time
+        r = np.random.default_rng(seed)
+        try:
+            while time.monotonic() < deadline[0] and not errors:
+                if kind == "vec":
+                    nq = int(r.choice([1, 5, 20]))
+                    got = group.vec_search(vecs, queries[:nq], 10)
+                    assert same(got, e_vec[nq]) and np.array_equal(got[2], e_vec[nq][2])
+                elif kind == "post":
+                    got = group.post_search(posts, refs, n_tok, float(n), 25)
+                    assert got[2] == e_post[2] and same(got, e_post)
+                elif kind == "hyb":
+                    i = int(r.integers(8))
+                    got = group.hybrid_search(vecs, posts, queries[i], 12, 0.0, refs, n_tok, float(n), 20)
+                    assert got[2] == e_hyb[i][2] and same(got, e_hyb[i])
+                else:
+                    i = int(r.integers(16))
+                    ids, dist = batcher.search(queries[i], 7)
+                    assert np.array_equal(ids, e_one[i][0][0]) and np.array_equal(dist.view(np.uint32), e_one[i][1][0].view(np.uint32))
+                with lock:
+                    done[kind] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append((kind, repr(e)))
+
+    import time
+    deadline[0] = time.monotonic() + 4.0
+    threads = [threading.Thread(target=worker, args=(kind, 100 + i)) for i, kind in
+               enumerate(["vec"] * 4 + ["post"] * 3 + ["hyb"] * 3 + ["bat"] * 6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a caller is stuck"
+    assert not errors, errors[:3]
+    assert all(v > 0 for v in done.values()), done
+    assert batcher.stats()["requests"] == done["bat"]
+    lanes = group.lanes()
+    assert lanes["max"] >= 2 and lanes["created"] >= 2, lanes
+    batcher.close()
+    for s in posts + vecs:
+        s.close()
+    single_post.close()
+    single_vec.close()
+    group.close()
