@@ -186,7 +186,10 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     if (cap > kRangeCap) {
         // the query is rerun with smaller ranges; its slots still reach the batch's top-k, so they must be empty
         if (!DF_ONLY)
-            for (uint32_t e = threadIdx.x; e < cap; e += kThreads) b.keys[q.key_off + slot_base + e] = 0ull;
+            for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
+                b.keys[q.key_off + slot_base + e] = 0ull;
+                if (b.map_idx) b.map_idx[slot_base + e] = 0xffffffffu;
+            }
         if (threadIdx.x == 0) b.results[qi].overflow = 1;
         return;
     }
@@ -325,6 +328,8 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
         const unsigned long long key = s[e];
         unsigned long long out_key = 0ull;
+        uint32_t map_doc = 0xffffffffu;  // the document whose map entry this slot holds (score-map mode)
+        float map_score = 0.0f;
         if (!(b.debug & 2u) && (e == 0 || key_doc(s[e - 1]) != key_doc(key))) {
             // first posting of a document: fold its run (lists of a token in reference order, tokens ascending)
             const uint32_t dl = key_doc(key);
@@ -346,11 +351,23 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
                 }
                 if (b.omc_dense) score = score * b.omc_dense[doc];
                 ++my_count;
+                map_doc = doc;
+                map_score = score;
                 if (score == score)  // a NaN score stays in the map (count) and is never selected
                     out_key = ((unsigned long long)f32_to_ordered(score) << 32) | (unsigned long long)(~doc);
             }
         }
         out[e] = out_key;
+        if (b.map_idx) {
+            // score-map mode (a batch of ONE query): slot = position of the entry in the map's candidate list, the
+            // per-document table points back at it (ScoreMapDev, facets.hip) — NaN scores included, they count
+            const uint32_t pos = slot_base + e;
+            b.map_idx[pos] = map_doc;
+            if (map_doc != 0xffffffffu) {
+                b.map_score[pos] = map_score;
+                b.map_emit[map_doc] = ((unsigned long long)b.map_epoch << 32) | pos;
+            }
+        }
     }
     my_count = wave_sum_u32(my_count);
     if ((threadIdx.x & 63) == 0 && my_count) atomicAdd(&red[1], my_count);

@@ -67,6 +67,13 @@ struct RangeBatch {
     const float* omc_dense = nullptr;
     unsigned long long* keys = nullptr;  // ordered(score) << 32 | ~local doc; 0 = empty
     RangeResult* results = nullptr;
+    // score-map mode (n_queries == 1): besides its key, every slot gets the map entry it stands for — map_idx[slot] = local
+    // document (0xffffffff: none), map_score[slot] = its score (after OMC; NaN stays), map_emit[document] = epoch << 32 | slot:
+    // the candidate list + position index facets / groups / export / lookup read (ScoreMapDev, bm25_kernels.hpp)
+    uint32_t* map_idx = nullptr;
+    float* map_score = nullptr;
+    unsigned long long* map_emit = nullptr;
+    uint32_t map_epoch = 0;
     uint32_t debug = 0;  // timing ablations (ORAMA_K3R_DBG): 1 skip the merge, 2 skip the fold, 4 stop after the bounds loads
 };
 

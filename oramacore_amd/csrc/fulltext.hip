@@ -430,6 +430,9 @@ struct RangeJob {
     // per-document launch and a merge of <= top_k + 2 n_vec_max + 1 entries on the host (DESIGN.md K5 "hybrid tail").
     std::function<int(const uint64_t** doc, const float** score, uint32_t* n)> vec_provider;
     uint32_t n_vec_max = 0;
+    // score-map mode (a batch of one, not hybrid): leave the whole map behind in the scratch set — see RangeBatch::map_idx
+    QueryBuffers* map = nullptr;
+    uint32_t* map_list_len = nullptr;
 };
 
 constexpr uint32_t kRangeBatchMax = 32;             // queries scored by one set of launches
@@ -765,6 +768,28 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         rb.omc_dense = (apply_omc && p->has_omc) ? p->d_omc.as<float>() : nullptr;
         rb.keys = sc->misc3.as<unsigned long long>();
         rb.results = sc->misc2.as<RangeResult>();
+        if (n_jobs == 1 && jobs[0].map) {
+            // the per-document table is the set's epoch-stamped one (shared with the per-record scorer's use of the set)
+            ORAMA_TRY(reserve_zeroed(sc->bm25_emit, (size_t)p->n_docs * 8, s));
+            if (sc->bm25_epoch == 0xffffffffu) {  // wrap: forget every stamp
+                if (sc->bm25_acc.p) ORAMA_HIP_TRY(hipMemsetAsync(sc->bm25_acc.p, 0, sc->bm25_acc.cap, s));
+                ORAMA_HIP_TRY(hipMemsetAsync(sc->bm25_emit.p, 0, sc->bm25_emit.cap, s));
+                sc->bm25_epoch = 0;
+            }
+            ORAMA_TRY(sc->misc5.reserve((size_t)max_total * 4));
+            ORAMA_TRY(sc->dist.reserve((size_t)max_total * 4));
+            rb.map_idx = sc->misc5.as<uint32_t>();
+            rb.map_score = sc->dist.as<float>();
+            rb.map_emit = sc->bm25_emit.as<unsigned long long>();
+            rb.map_epoch = ++sc->bm25_epoch;
+            QueryBuffers* m = jobs[0].map;
+            *m = QueryBuffers{};
+            m->cand_score = rb.map_score;
+            m->cand_idx = rb.map_idx;
+            m->emit = rb.map_emit;
+            m->epoch = rb.map_epoch;
+            *jobs[0].map_list_len = (uint32_t)max_total;
+        }
         if (const char* e = std::getenv("ORAMA_K3R_DBG")) rb.debug = (uint32_t)std::atoi(e);
         ORAMA_TRY(launch_range_bounds(p->ctx, rb, s));
         ORAMA_TRY(sc->h_out.reserve(out_bytes + 64));
@@ -1455,11 +1480,26 @@ int orama_post_search_scores(orama_post* p, const orama_term_ref* refs, uint32_t
     }
     ORAMA_TRY(h->lease.init());
     Scratch* sc = h->lease.s.get();
-    ORAMA_TRY(post_stage1(p, sc, refs, n_refs, b, params, allow_bitmap, bitmap_bits, hybrid != 0, apply_omc, hybrid ? n_vec : 0,
-                          &h->st));
     uint64_t count = 0;
-    ORAMA_TRY(post_stage2(p, sc, h->st, params, vec_doc, vec_score, hybrid ? n_vec : 0, out_ids, out_scores, out_n, &count));
-    ORAMA_HIP_TRY(hipMemcpy(&h->list_len, &h->st.qb.state->list_len, 4, hipMemcpyDeviceToHost));
+    // The full-text map on the range scorer (K3r): the candidate list + position index come out of the scoring launch itself
+    // — 8 bytes per document of the index (the epoch-stamped position table) + 16 per referenced posting, instead of the
+    // per-record scorer's 136 bytes per document (1.4 GB at 10 M documents).  Hybrid maps (every score is rewritten by
+    // normalize_and_combine, vector-only documents join) and queries the range scorer does not take stay on K3.
+    uint64_t total_postings = 0;
+    for (uint32_t i = 0; i < n_refs && refs; ++i)
+        if (refs[i].list < p->n_lists) total_postings += p->list_off[refs[i].list + 1] - p->list_off[refs[i].list];
+    if (!hybrid && total_postings > 0 && ranges_eligible(p, refs, n_refs, params)) {
+        ORAMA_TRY(check_params(params));
+        RangeJob job{refs, n_refs, params, out_ids, out_scores, out_n, &count};
+        job.map = &h->st.qb;
+        job.map_list_len = &h->list_len;
+        ORAMA_TRY(post_search_ranges(p, sc, &job, 1, b, allow_bitmap, bitmap_bits, apply_omc));
+    } else {
+        ORAMA_TRY(post_stage1(p, sc, refs, n_refs, b, params, allow_bitmap, bitmap_bits, hybrid != 0, apply_omc, hybrid ? n_vec : 0,
+                              &h->st));
+        ORAMA_TRY(post_stage2(p, sc, h->st, params, vec_doc, vec_score, hybrid ? n_vec : 0, out_ids, out_scores, out_n, &count));
+        ORAMA_HIP_TRY(hipMemcpy(&h->list_len, &h->st.qb.state->list_len, 4, hipMemcpyDeviceToHost));
+    }
     h->count = count;
     h->generation = p->generation;
     if (out_count) *out_count = count;

@@ -18,6 +18,15 @@ pytestmark = pytest.mark.gpu
 F = np.float32
 
 
+@pytest.fixture(autouse=True, params=["k3r", "k3"])
+def scorer(request, ctx):
+    """Every test runs with the score map built by the range scorer (K3r: candidate list + position index out of the
+    scoring launch, where the query is eligible) and by the per-record scorer (K3)."""
+    ctx.set_bm25_ranges(request.param == "k3r")
+    yield request.param
+    ctx.set_bm25_ranges(True)
+
+
 def build_store(ctx, n_docs, n_tok, rng, id_mul=1, id_add=0):
     doc_ids = np.arange(n_docs, dtype=np.uint64) * np.uint64(id_mul) + np.uint64(id_add)
     lens = rng.integers(5, 200, size=n_docs).astype(np.uint32)
@@ -34,12 +43,16 @@ def build_store(ctx, n_docs, n_tok, rng, id_mul=1, id_add=0):
     return post, doc_ids, entries
 
 
-def test_score_map_export_and_lookup_any_size(ctx):
+def test_score_map_export_and_lookup_any_size(ctx, scorer):
     rng = np.random.default_rng(1)
     n_docs, n_tok = 60_000, 4  # the map has tens of thousands of entries: far beyond the old 4096 cap
     post, doc_ids, entries = build_store(ctx, n_docs, n_tok, rng, id_mul=3, id_add=11)
     refs = [(t, t, 1.0) for t in range(n_tok)]
+    ctx.prof_reset()
+    ctx.prof_enable(True)
     sm = post.search_scores(refs, n_tok, float(n_docs), 50)
+    ctx.prof_enable(False)
+    assert (ctx.prof_get("bm25_range_score")[1] > 0) == (scorer == "k3r") and (ctx.prof_get("bm25_accumulate")[1] > 0) == (scorer == "k3")
     od, os_ = orc.search_full_text(entries, n_tok, float(n_docs), 1.2, None)
     assert len(sm) == len(od) == sm.hits[2] and len(od) > 20_000
     got = sm.to_dict()
