@@ -1,4 +1,9 @@
-"""Multi-GPU path: static corpus sharding + ONE all-gather of per-shard top-k candidates.
+"""TEST DOUBLE (not part of the product): the round-1 torch.distributed form of the sharded search, kept so that the
+exchange protocol (packed blocks, one all-gather, deterministic merge; df / min-max reductions) stays covered by
+world_size-2 gloo processes on a CPU-only box.  The product's exchange lives in liborama_hip.so (shard_group.hip) and is
+tested with >1 rank in tests/test_multirank_gpu.py and tests/test_mock_rccl.py.
+
+Multi-GPU path: static corpus sharding + ONE all-gather of per-shard top-k candidates.
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  Rows are
 partitioned into contiguous doc-id ranges; every rank scans its shard for the whole
@@ -20,7 +25,7 @@ from dataclasses import dataclass
 import torch
 import torch.distributed as dist
 
-from . import _native as N
+from oramacore_amd import _native as N
 
 PAD_ID = (1 << 64) - 1
 

@@ -16,7 +16,7 @@ import torch.multiprocessing as mp
 import util
 from oracle import oracle as orc
 from oramacore_amd import _native as N
-from oramacore_amd.sharded import PAD_ID, ShardedSearcher, ShardPlan, block_views, packed_block_bytes
+from sharded_gloo_double import PAD_ID, ShardedSearcher, ShardPlan, block_views, packed_block_bytes
 
 
 class OracleOps:
@@ -133,7 +133,7 @@ def test_packed_block_layout_matches_the_abi():
 
 
 # ===================================================================== full-text / hybrid over a sharded index
-from oramacore_amd.sharded import ShardedFulltextSearcher, post_block_bytes  # noqa: E402
+from sharded_gloo_double import ShardedFulltextSearcher, post_block_bytes  # noqa: E402
 
 F = np.float32
 
