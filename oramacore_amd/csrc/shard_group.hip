@@ -34,6 +34,7 @@
 #include "bm25_kernels.hpp"
 #include "common.hpp"
 #include "select.hpp"
+#include "vec_internal.hpp"
 
 using namespace orama;
 
@@ -605,9 +606,38 @@ int orama_shard_vec_search(orama_shard_group* g, orama_vec* const* shards, const
     orama_vec_info_t info;
     ORAMA_TRY(orama_vec_info(shards[0], &info));
     const size_t qbytes = (size_t)q * info.dimensions * sizeof(float);
-    for (uint32_t i = 0; i < n_local(g); ++i) {
-        ShardLocal& s = L(g, i);
+    const uint32_t nl = n_local(g);
+    // Shards that keep an fp16 shadow of their rows answer with the two-stage exact plan (fp16 scan proposes, fp32 rows
+    // decide — the fp32 scan's answer bit for bit, half the bytes scanned): begun on every shard before any is waited for.
+    // The plan needs two vector scratch sets per shard; the sets of one context are taken together (never hold some and
+    // wait for more).
+    std::vector<char> two_stage(nl, 0);
+    for (uint32_t i = 0; i < nl; ++i) {
         ORAMA_REQUIRE(shards[i], "null shard %u", i);
+        two_stage[i] = vec_rows(shards[i]) > 0 && vec_two_stage_usable(shards[i], queries, q, k);
+    }
+    std::vector<std::unique_ptr<ScratchLease>> lease_a(nl), lease_b(nl);
+    for (uint32_t i = 0; i < nl; ++i) {
+        if (!two_stage[i] || lease_a[i]) continue;
+        orama_ctx* cx = L(g, i).ctx;
+        std::vector<uint32_t> members;
+        for (uint32_t j = i; j < nl; ++j)
+            if (two_stage[j] && L(g, j).ctx == cx) members.push_back(j);
+        std::vector<std::unique_ptr<Scratch>*> outs;
+        std::vector<int> kinds(2 * members.size(), kScratchVector);
+        for (uint32_t j : members) {
+            lease_a[j].reset(new ScratchLease(cx, kScratchVector));
+            lease_b[j].reset(new ScratchLease(cx, kScratchVector));
+            outs.push_back(&lease_a[j]->s);
+            outs.push_back(&lease_b[j]->s);
+        }
+        ORAMA_HIP_TRY(hipSetDevice(L(g, i).device));
+        ORAMA_TRY(cx->acquire_n((uint32_t)outs.size(), outs.data(), kinds.data()));
+    }
+    std::vector<std::unique_ptr<VecSharedLock>> vlocks(nl);
+    std::vector<std::unique_ptr<VecTwoStage>> plans(nl);  // (destroyed before the leases above: a plan drains its stream)
+    for (uint32_t i = 0; i < nl; ++i) {
+        ShardLocal& s = L(g, i);
         ORAMA_HIP_TRY(hipSetDevice(s.device));
         ORAMA_TRY(s.queries.reserve(qbytes));
         ORAMA_TRY(s.d_n.reserve((size_t)q * 4));
@@ -617,10 +647,28 @@ int orama_shard_vec_search(orama_shard_group* g, orama_vec* const* shards, const
         const uint64_t* allow = allow_bitmaps ? allow_bitmaps[i] : nullptr;
         ORAMA_REQUIRE(!allow || is_resident_allow(s.ctx, allow),
                       "sharded search takes RESIDENT allow bitmaps (orama_allow_token), one per local shard");
-        ORAMA_TRY(orama_vec_search_packed_device(shards[i], s.queries.as<float>(), q, k, allow, allow ? bitmap_bits : 0,
-                                                 gathered_of(g, i) + (size_t)slot_of(g, i) * nb, s.d_n.as<uint32_t>(),
-                                                 s.stream));
+        char* block = gathered_of(g, i) + (size_t)slot_of(g, i) * nb;
+        if (two_stage[i]) {
+            // the plan runs on its scratch set's stream: behind the query upload
+            ORAMA_HIP_TRY(hipEventRecord(s.ev, s.stream));
+            ORAMA_HIP_TRY(hipStreamWaitEvent((*lease_a[i])->stream, s.ev, 0));
+            vlocks[i].reset(new VecSharedLock(shards[i]));
+            plans[i].reset(new VecTwoStage());
+            ORAMA_TRY(plans[i]->begin(shards[i], *lease_a[i], *lease_b[i], s.queries.as<float>(), q, k, allow, allow ? bitmap_bits : 0,
+                                      reinterpret_cast<uint64_t*>(block), reinterpret_cast<float*>(block + (size_t)q * k * 8),
+                                      s.d_n.as<uint32_t>()));
+        } else {
+            ORAMA_TRY(orama_vec_search_packed_device(shards[i], s.queries.as<float>(), q, k, allow, allow ? bitmap_bits : 0, block,
+                                                     s.d_n.as<uint32_t>(), s.stream));
+        }
     }
+    for (uint32_t i = 0; i < nl; ++i)
+        if (plans[i]) {  // blocks; an unproven candidate list is re-answered by the plain scan in here
+            ORAMA_HIP_TRY(hipSetDevice(L(g, i).device));
+            ORAMA_TRY(plans[i]->finish());
+            plans[i].reset();
+            vlocks[i].reset();
+        }
     ORAMA_TRY(exchange_all_gather(g, nb));
     // K6 on local shard 0 (every rank holds the same gathered buffer, so every rank returns the same answer)
     ShardLocal& s0 = L(g, 0);

@@ -259,3 +259,42 @@ def test_concurrent_callers_on_a_colocated_group(ctx):
     single_post.close()
     single_vec.close()
     group.close()
+
+
+def test_shadow_store_shards_take_the_two_stage_plan(ctx):
+    """Shards that keep an fp16 shadow answer a sharded search with the two-stage exact plan (begun on every shard, then
+    joined): same (ids, distance bits, counts) as ONE plain fp32 store over the union — 1, 5 and 70 queries, a filter, near
+    duplicates that force the proof to fail (the plain scan re-answers those queries) — and the plan really ran."""
+    n, d, k = 9000, 128, 40
+    rows = util.gaussian_rows(n, d, seed=31)
+    rows[2000:2300] = rows[100] + np.float32(1e-4) * util.gaussian_rows(300, d, seed=32)  # 300 near-duplicates of row 100
+    doc_ids = np.arange(n, dtype=np.uint64) * 2 + 1
+    single = oa.EmbeddingFieldStorage(ctx, dimensions=d)
+    single.insert_rows(doc_ids, rows)
+    cuts = [0, 2500, 5200, n]
+    group = ShardGroup([0, 0, 0])
+    for g in range(3):
+        group.ctx(g).set_two_stage(True, always=True)
+    shards = build_vec_shards(group, rows, doc_ids, cuts, dtype=N.DTYPE_F32_SHADOW16)
+    qs = util.gaussian_rows(70, d, seed=33)
+    qs[3] = rows[100]  # its top-40 are the near-duplicates: more candidates inside the error band than the list holds
+    for nq in (1, 5, 70):
+        got = group.vec_search(shards, qs[:nq], k)
+        exp = single.storage_search(qs[:nq], k)
+        assert np.array_equal(got[2], exp[2]) and np.array_equal(got[0], exp[0]), nq
+        assert np.array_equal(got[1].view(np.uint32), exp[1].view(np.uint32)), nq
+    keep = (np.arange(n) % 3) != 0
+    bm_single = oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[keep])
+    toks = [oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[keep]).to_device(group.ctx(g)) for g in range(3)]
+    got = group.vec_search(shards, qs[:5], k, allow=toks)
+    exp = single.storage_search(qs[:5], k, bm_single)
+    assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1].view(np.uint32), exp[1].view(np.uint32))
+    infos = [s.info() for s in shards]
+    assert all(i["two_stage_queries"] >= 81 for i in infos), infos
+    assert sum(i["two_stage_fallbacks"] for i in infos) >= 1, infos  # the near-duplicate query on the shard that owns them
+    for t in toks:
+        t.close()
+    for s in shards:
+        s.close()
+    single.close()
+    group.close()
