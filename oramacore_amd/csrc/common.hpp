@@ -239,7 +239,10 @@ struct orama_ctx {
     // with few queries) (ORAMA_TWO_STAGE, orama_ctx_set_two_stage)
     int two_stage = 1;
     int f16_solo = 2;    // shadow scans of <= 4 queries use K1h (dot products, no MFMA): 2 = K1-shaped loop where it applies, 1 = register ring; ORAMA_F16_SOLO=0: K2
-    int f16_kc = 8, f16_nbuf = 3;   // K2 register ring: k-steps per chunk, chunks (ORAMA_F16_KC / ORAMA_F16_NBUF)
+    // K2 register ring: k-steps per chunk, chunks (ORAMA_F16_KC / ORAMA_F16_NBUF).  8 x 2 since round 3: with the kernel free
+    // of scratch the shallow ring fits three waves per SIMD (130-158 VGPRs) and that is worth more than a third chunk in
+    // flight (16 queries: 2.29 vs 2.37 ms per pass, 64 queries: equal; profiles/r03_k2_ring_sweep.log)
+    int f16_kc = 8, f16_nbuf = 2;
     int compute_units = 0;
     uint64_t hbm_bytes = 0;
     char name[256] = {0};
