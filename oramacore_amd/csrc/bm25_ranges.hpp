@@ -46,6 +46,8 @@ struct RangeResult {
     uint32_t pad2[31];
     uint32_t min_inv;     // hybrid: ~ordered(smallest non-NaN score), 0 = none
     uint32_t pad3[31];
+    unsigned long long topk_tau;  // running bound of the key list's top-k reduction (launch_keys_topk, zero at launch)
+    uint32_t pad4[30];
 };
 
 struct RangeBatch {

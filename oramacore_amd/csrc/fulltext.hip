@@ -818,7 +818,8 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             ORAMA_TRY(sc->misc4.reserve((size_t)keys_topk_scratch_keys((uint32_t)max_total, nq, c.kmax) * 8 + 8));
             ORAMA_TRY(launch_keys_topk(p->ctx, rb.keys, (uint32_t)max_total, max_total, nq, c.kmax, true, p->d_docs.as<uint64_t>(),
                                        sc->misc4.as<unsigned long long>(), nullptr, d_ids, d_val, d_n, s,
-                                       reinterpret_cast<const uint32_t*>(d + seg_bytes + q_bytes + idf_bytes)));
+                                       reinterpret_cast<const uint32_t*>(d + seg_bytes + q_bytes + idf_bytes), &rb.results[0].topk_tau,
+                                       (uint32_t)(sizeof(RangeResult) / 8)));
         }
         ORAMA_HIP_TRY(hipMemcpyAsync(h_res, d_out, c.kmax ? out_bytes : res_bytes, hipMemcpyDeviceToHost, s));
         return ORAMA_OK;

@@ -377,17 +377,25 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
                                                                    uint32_t n_keys, uint64_t in_stride,
                                                                    const uint32_t* __restrict__ n_per_list,
                                                                    uint32_t k, unsigned long long* __restrict__ out,
-                                                                   uint64_t out_stride) {
+                                                                   uint64_t out_stride, unsigned long long* tau = nullptr,
+                                                                   uint32_t tau_stride = 0) {
     __shared__ unsigned long long s[kKeysChunk];
     __shared__ uint32_t hist[256];
     __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
-    __shared__ uint32_t red_nz[kSortThreads / 64];
+    __shared__ uint32_t red_nz[kSortThreads / 64], red_ge[kSortThreads / 64];
     __shared__ uint32_t sel_bin, sel_above, sel_cnt, cursor;
-    const uint32_t qi = blockIdx.y;
+    // with a bound the grid is (lists, chunks): workgroups are dispatched list-fastest, so the first wave of workgroups
+    // holds the first chunks of EVERY list and the later chunks of each list find a bound (chunk-fastest, a list's chunks
+    // would all start together and none would)
+    const uint32_t qi = tau ? blockIdx.x : blockIdx.y, chunk = tau ? blockIdx.y : blockIdx.x;
+    // A list's chunks share a running bound (tau, zero at launch): every workgroup that had to select publishes the k-th best
+    // key of its chunk — a lower bound of the list's k-th best — and a chunk with at most k keys at or above the bound
+    // hands those out without selecting anything.  Workgroups of a list start in waves; all but the first wave find a bound.
+    const unsigned long long tau0 = tau ? __hip_atomic_load(tau + (uint64_t)qi * tau_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     const unsigned long long* in = keys + (uint64_t)qi * in_stride;
-    const uint32_t begin = blockIdx.x * kKeysChunk;
+    const uint32_t begin = chunk * kKeysChunk;
     if (n_per_list) n_keys = min(n_keys, n_per_list[qi]);  // lists shorter than the stride: the tail is not read
-    unsigned long long* o = out + (uint64_t)qi * out_stride + (uint64_t)blockIdx.x * k;
+    unsigned long long* o = out + (uint64_t)qi * out_stride + (uint64_t)chunk * k;
     if (begin >= n_keys) {
         for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = 0ull;
         return;
@@ -395,12 +403,13 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
     const uint32_t cnt = min(kKeysChunk, n_keys - begin);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long mx = 0ull, mn = ~0ull;
-    uint32_t nz = 0;
+    uint32_t nz = 0, ge = 0;
     for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
         const unsigned long long key = in[begin + i];
         s[i] = key;
         if (key) {
             ++nz;
+            ge += key >= tau0;
             mx = key > mx ? key : mx;
             mn = key < mn ? key : mn;
         }
@@ -411,22 +420,27 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
         mx = a > mx ? a : mx;
         mn = b < mn ? b : mn;
         nz += __shfl_xor(nz, off, 64);
+        ge += __shfl_xor(ge, off, 64);
     }
     if (lane == 0) {
         red_max[wave] = mx;
         red_min[wave] = mn;
         red_nz[wave] = nz;
+        red_ge[wave] = ge;
     }
     if (threadIdx.x == 0) cursor = 0;
     __syncthreads();
-    mx = 0ull, mn = ~0ull, nz = 0;
+    mx = 0ull, mn = ~0ull, nz = 0, ge = 0;
     for (uint32_t w = 0; w < kSortThreads / 64; ++w) {
         mx = red_max[w] > mx ? red_max[w] : mx;
         mn = red_min[w] < mn ? red_min[w] : mn;
         nz += red_nz[w];
+        ge += red_ge[w];
     }
     unsigned long long thr = 1ull;  // take every non-empty key
-    if (nz > k) {
+    if (tau0 > 1ull && ge <= k) {
+        thr = tau0;  // nothing below the bound can be among the list's best k, and what is left fits the output
+    } else if (nz > k) {
         // bits above `low` are common to all non-empty keys; the k-th largest is searched below them
         uint32_t low = 64u - (uint32_t)__builtin_clzll(mx ^ mn);  // mx != mn: nz > k >= 1 unique keys
         unsigned long long prefix = low >= 64u ? 0ull : (mx >> low) << low;
@@ -478,6 +492,7 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
             if (whole || low == 0) break;
         }
         thr = prefix;  // keys >= thr: exactly k of them (unique keys)
+        if (tau && threadIdx.x == 0) atomicMax(tau + (uint64_t)qi * tau_stride, thr);
     }
     // compact the selected keys (order is irrelevant here): one LDS atomic per wave and pass
     for (uint32_t i0 = 0; i0 < cnt; i0 += blockDim.x) {
@@ -780,7 +795,8 @@ uint64_t keys_topk_scratch_keys(uint32_t n_keys, uint32_t q, uint32_t k) {
 int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t n_keys, uint64_t stride,
                      uint32_t q, uint32_t k, bool descending, const uint64_t* id_map,
                      unsigned long long* d_tmp, uint32_t* out_idx, uint64_t* out_ids, float* out_val,
-                     uint32_t* out_n, hipStream_t stream, const uint32_t* d_n_per_list) {
+                     uint32_t* out_n, hipStream_t stream, const uint32_t* d_n_per_list, unsigned long long* d_tau,
+                     uint32_t tau_stride) {
     ORAMA_REQUIRE(k >= 1 && k <= kSelectMaxK && q >= 1 && d_keys && out_val, "keys top-k: bad arguments");
     ProfScope prof(&ctx->prof, "topk_select", stream);
     const unsigned long long* cur = d_keys;
@@ -792,8 +808,9 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
         ORAMA_REQUIRE(tmp, "keys top-k: scratch missing");
         const uint32_t chunks = (n + kKeysChunk - 1) / kKeysChunk;
         const uint64_t out_stride = (uint64_t)chunks * k;
-        hipLaunchKernelGGL(keys_reduce_kernel, dim3(chunks, q), dim3(kSortThreads), 0, stream, cur, n, cur_stride,
-                           n_per_list, k, tmp, out_stride);
+        hipLaunchKernelGGL(keys_reduce_kernel, d_tau ? dim3(q, chunks) : dim3(chunks, q), dim3(kSortThreads), 0, stream, cur, n,
+                           cur_stride, n_per_list, k, tmp, out_stride, d_tau, tau_stride);
+        d_tau = nullptr;  // (a bound belongs to the caller's lists: the next level starts without one)
         cur = tmp;
         cur_stride = out_stride;
         n = chunks * k;
