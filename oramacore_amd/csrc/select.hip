@@ -382,15 +382,17 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
     __shared__ unsigned long long s[kKeysChunk];
     __shared__ uint32_t hist[256];
     __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
-    __shared__ uint32_t red_nz[kSortThreads / 64], red_ge[kSortThreads / 64];
+    __shared__ uint32_t red_nz[kSortThreads / 64];
     __shared__ uint32_t sel_bin, sel_above, sel_cnt, cursor;
     // with a bound the grid is (lists, chunks): workgroups are dispatched list-fastest, so the first wave of workgroups
     // holds the first chunks of EVERY list and the later chunks of each list find a bound (chunk-fastest, a list's chunks
     // would all start together and none would)
     const uint32_t qi = tau ? blockIdx.x : blockIdx.y, chunk = tau ? blockIdx.y : blockIdx.x;
     // A list's chunks share a running bound (tau, zero at launch): every workgroup that had to select publishes the k-th best
-    // key of its chunk — a lower bound of the list's k-th best — and a chunk with at most k keys at or above the bound
-    // hands those out without selecting anything.  Workgroups of a list start in waves; all but the first wave find a bound.
+    // key of its chunk — a lower bound of the list's k-th best — and a chunk treats what lies below the bound it finds as
+    // empty: about k of its 8 192 keys are left, the histogram rounds (LDS atomics that pile onto a few bins, since the
+    // scores of one query share their leading bits) run over those, or not at all when at most k are left.  Workgroups of a
+    // list start in waves; all but the first wave find a bound.
     const unsigned long long tau0 = tau ? __hip_atomic_load(tau + (uint64_t)qi * tau_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     const unsigned long long* in = keys + (uint64_t)qi * in_stride;
     const uint32_t begin = chunk * kKeysChunk;
@@ -403,13 +405,13 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
     const uint32_t cnt = min(kKeysChunk, n_keys - begin);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long mx = 0ull, mn = ~0ull;
-    uint32_t nz = 0, ge = 0;
+    uint32_t nz = 0;
     for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const unsigned long long key = in[begin + i];
+        unsigned long long key = in[begin + i];
+        if (key < tau0) key = 0ull;  // cannot be among the list's best k
         s[i] = key;
         if (key) {
             ++nz;
-            ge += key >= tau0;
             mx = key > mx ? key : mx;
             mn = key < mn ? key : mn;
         }
@@ -420,27 +422,22 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
         mx = a > mx ? a : mx;
         mn = b < mn ? b : mn;
         nz += __shfl_xor(nz, off, 64);
-        ge += __shfl_xor(ge, off, 64);
     }
     if (lane == 0) {
         red_max[wave] = mx;
         red_min[wave] = mn;
         red_nz[wave] = nz;
-        red_ge[wave] = ge;
     }
     if (threadIdx.x == 0) cursor = 0;
     __syncthreads();
-    mx = 0ull, mn = ~0ull, nz = 0, ge = 0;
+    mx = 0ull, mn = ~0ull, nz = 0;
     for (uint32_t w = 0; w < kSortThreads / 64; ++w) {
         mx = red_max[w] > mx ? red_max[w] : mx;
         mn = red_min[w] < mn ? red_min[w] : mn;
         nz += red_nz[w];
-        ge += red_ge[w];
     }
     unsigned long long thr = 1ull;  // take every non-empty key
-    if (tau0 > 1ull && ge <= k) {
-        thr = tau0;  // nothing below the bound can be among the list's best k, and what is left fits the output
-    } else if (nz > k) {
+    if (nz > k) {
         // bits above `low` are common to all non-empty keys; the k-th largest is searched below them
         uint32_t low = 64u - (uint32_t)__builtin_clzll(mx ^ mn);  // mx != mn: nz > k >= 1 unique keys
         unsigned long long prefix = low >= 64u ? 0ull : (mx >> low) << low;
