@@ -592,6 +592,21 @@ int orama_shard_hybrid_search(orama_shard_group* g, orama_vec* const* vec_shards
  * over `shards` (the group's local shards, in rank order); orama_batcher_search_filtered then takes, in place of the
  * bitmap words, the address of the caller's array of resident per-shard tokens (const uint64_t* const*; requests
  * carrying the same array share a pass).  The group and the stores must outlive the batcher. */
+/* orama_post_search_batch_status over the document shards of one index (`shards`: the group's local shards in rank order,
+ * built as for orama_shard_post_search).  When every shard of the group lives in this process, queries with one posting
+ * list per token and no filter are scored by the range scorer on all shards side by side — the index-wide df is the sum of
+ * the shards' list lengths, known on the host, so no collective runs — and merged on the host; every other query is
+ * answered by orama_shard_post_search, one at a time.  allow_bitmaps: NULL or one resident token per local shard.
+ * Results per query as orama_post_search over the union of the shards, bit for bit; out_status may be NULL. */
+int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shards, const orama_post_query_desc* queries,
+                                  uint32_t n_queries, float b, const uint64_t* const* allow_bitmaps, uint64_t bitmap_bits,
+                                  int apply_omc, uint32_t stride_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
+                                  uint64_t* out_count, int* out_status);
+/* The full-text request batcher in front of a group: like orama_post_batcher_create, every dispatch is one
+ * orama_shard_post_search_batch.  A request's filter, if any, is the address of the caller's array of resident per-shard
+ * tokens.  The group and the stores must outlive the batcher. */
+int orama_post_batcher_create_group(orama_shard_group* g, orama_post* const* shards, uint32_t max_batch, uint32_t max_wait_us,
+                                    orama_post_batcher** out);
 /* Sharded calls the group can run side by side, and how many lanes (exchange streams + buffers per local shard) it has
  * made so far. */
 int orama_shard_group_lanes(orama_shard_group* g, uint32_t* max_lanes, uint32_t* lanes_created);

@@ -180,6 +180,9 @@ def _declare(lib: C.CDLL) -> None:
         "orama_post_search_batch_status": [vp, C.POINTER(PostQueryDesc), C.c_uint32, C.c_float, vp, C.c_uint64, C.c_int, C.c_uint32,
                                     C.c_uint32, vp, vp, vp, vp, vp],
         "orama_post_batcher_create": [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)],
+        "orama_post_batcher_create_group": [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)],
+        "orama_shard_post_search_batch": [vp, vp, C.POINTER(PostQueryDesc), C.c_uint32, C.c_float, vp, C.c_uint64, C.c_int,
+                                          C.c_uint32, vp, vp, vp, vp, vp],
         "orama_post_batcher_search": [vp, C.POINTER(TermRef), C.c_uint32, C.c_float, C.POINTER(Bm25Params), vp,
                                       C.c_uint64, C.c_int, vp, vp, u32p, u64p],
         "orama_post_batcher_stats": [vp, u64p, u64p, u32p],

@@ -281,6 +281,9 @@ struct PostRequest {
 
 struct orama_post_batcher {
     orama_post* p = nullptr;
+    // in front of a shard group (orama_post_batcher_create_group): dispatches go through orama_shard_post_search_batch
+    orama_shard_group* group = nullptr;
+    std::vector<orama_post*> shards;
     uint32_t max_batch = 64;
     uint32_t max_wait_us = 0;
     std::mutex mu;
@@ -339,9 +342,14 @@ struct orama_post_batcher {
             // one status per request: a request that is outside the envelope, or invalidated by a rebuild between its
             // validation and this dispatch, fails alone — the callers coalesced with it get their answers
             sts.assign(q, ORAMA_OK);
-            const int bst = orama_post_search_batch_status(p, descs.data(), q, batch[0]->b, batch[0]->allow, batch[0]->allow_bits,
-                                                           batch[0]->apply_omc, 8, stride, ids.data(), scores.data(), ns.data(),
-                                                           counts.data(), sts.data());
+            const int bst =
+                group ? orama_shard_post_search_batch(group, shards.data(), descs.data(), q, batch[0]->b,
+                                                      reinterpret_cast<const uint64_t* const*>(batch[0]->allow), batch[0]->allow_bits,
+                                                      batch[0]->apply_omc, stride, ids.data(), scores.data(), ns.data(), counts.data(),
+                                                      sts.data())
+                      : orama_post_search_batch_status(p, descs.data(), q, batch[0]->b, batch[0]->allow, batch[0]->allow_bits,
+                                                       batch[0]->apply_omc, 8, stride, ids.data(), scores.data(), ns.data(),
+                                                       counts.data(), sts.data());
             std::string err;
             if (bst != ORAMA_OK) err = orama_last_error();  // this thread's error slot: the first failing query's message
             bool all_failed = bst != ORAMA_OK;
@@ -381,6 +389,29 @@ int orama_post_batcher_create(orama_post* p, uint32_t max_batch, uint32_t max_wa
         return ORAMA_ERR_OOM;
     }
     b->p = p;
+    b->max_batch = max_batch;
+    b->max_wait_us = max_wait_us;
+    for (int w = 0; w < 2; ++w) b->workers.emplace_back([b] { b->run(); });
+    *out = b;
+    return ORAMA_OK;
+}
+
+int orama_post_batcher_create_group(orama_shard_group* g, orama_post* const* shards, uint32_t max_batch, uint32_t max_wait_us,
+                                    orama_post_batcher** out) {
+    ORAMA_REQUIRE(g && shards && out, "null argument");
+    *out = nullptr;
+    ORAMA_REQUIRE(max_batch >= 1 && max_batch <= 4096, "max_batch %u outside [1, 4096]", max_batch);
+    uint32_t n_local = 0;
+    ORAMA_TRY(orama_shard_group_info(g, nullptr, &n_local, nullptr, nullptr));
+    for (uint32_t i = 0; i < n_local; ++i) ORAMA_REQUIRE(shards[i], "null shard %u", i);
+    orama_post_batcher* b = new (std::nothrow) orama_post_batcher();
+    if (!b) {
+        set_error("out of host memory");
+        return ORAMA_ERR_OOM;
+    }
+    b->group = g;
+    b->shards.assign(shards, shards + n_local);
+    b->p = shards[0];
     b->max_batch = max_batch;
     b->max_wait_us = max_wait_us;
     for (int w = 0; w < 2; ++w) b->workers.emplace_back([b] { b->run(); });

@@ -430,6 +430,9 @@ struct RangeJob {
     // per-document launch and a merge of <= top_k + 2 n_vec_max + 1 entries on the host (DESIGN.md K5 "hybrid tail").
     std::function<int(const uint64_t** doc, const float** score, uint32_t* n)> vec_provider;
     uint32_t n_vec_max = 0;
+    // sharded batches (orama_shard_post_search_batch): the index-wide document frequency of every token (kMaxTokens words) —
+    // idf comes from it instead of from this shard's list lengths (corpus_docs.len() over the whole index, token_score.rs:262-275)
+    const uint32_t* df_global = nullptr;
     // score-map mode (a batch of one, not hybrid): leave the whole map behind in the scratch set — see RangeBatch::map_idx
     QueryBuffers* map = nullptr;
     uint32_t* map_list_len = nullptr;
@@ -715,6 +718,10 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             const uint32_t ns = q.seg_end - q.seg_begin;
             bounds_entries += ((uint64_t)q.n_ranges + 1) * ns;
             max_bound_entries = std::max<uint64_t>(max_bound_entries, ((uint64_t)q.n_ranges + 1) * ns);
+            if (jb.df_global) {
+                ORAMA_REQUIRE(df_known, "internal: an index-wide df was given for a query whose df must be counted");
+                for (uint32_t t = 0; t < kMaxTokens; ++t) df[t] = jb.df_global[t];
+            }
             q.want_df = df_known ? 0u : (multi_list ? 1u : 2u);
             any_df |= !df_known;
             // idf per token by the host libm (calculate_idf, bm25.rs:78-82; df.max(1), token_score.rs:275)
@@ -2405,6 +2412,163 @@ int orama_hybrid_rrf(orama_ctx* ctx, const uint64_t* vec_doc, const float* vec_s
     }
     *out_n = n;
     return ORAMA_OK;
+}
+
+
+// ------------------------------------------------------------------ full-text batches over a shard group
+// orama_post_search_batch for an index sharded by document range when EVERY shard lives in this process (a
+// co-located group, or one process driving several GPUs).  The reference reads one index-wide quantity before it scores —
+// df per token = corpus_docs.len() (token_score.rs:262-275); with one posting list per token and no filter that is the sum
+// of the shards' list lengths, known on the host: no collective.  Every shard then scores the whole batch with the range
+// scorer (K3r, idf from the index-wide df; shards run side by side on their own threads, streams and scratch sets), and the
+// host merges the shards' top-k lists by (score desc, DocumentId asc) and sums their counts (sort.rs:260-279,
+// search.rs:482).  Queries outside that envelope (a filter, several lists per token, a reference the range scorer does
+// not take, a group with ranks in other processes) are answered one by one by orama_shard_post_search.  Same answers as
+// orama_post_search_batch over the union of the shards, bit for bit.
+int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shards, const orama_post_query_desc* queries,
+                                  uint32_t n_queries, float b, const uint64_t* const* allow_bitmaps, uint64_t bitmap_bits,
+                                  int apply_omc, uint32_t stride_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
+                                  uint64_t* out_count, int* out_status) {
+    ORAMA_REQUIRE(g && shards && (n_queries == 0 || (queries && out_n)), "null argument");
+    if (n_queries == 0) return ORAMA_OK;
+    ORAMA_REQUIRE(stride_k >= 1 && out_ids && out_scores, "null output");
+    uint32_t world = 0, nl = 0;
+    ORAMA_TRY(orama_shard_group_info(g, &world, &nl, nullptr, nullptr));
+    for (uint32_t i = 0; i < nl; ++i) ORAMA_REQUIRE(shards[i], "null shard %u", i);
+    std::vector<int> status(n_queries, ORAMA_OK);
+    std::vector<std::string> errors(n_queries);
+    for (uint32_t j = 0; j < n_queries; ++j) {
+        out_n[j] = 0;
+        if (out_count) out_count[j] = 0;
+    }
+    std::vector<uint32_t> fast, slow;
+    std::vector<uint32_t> df_global;  // [fast index][kMaxTokens]
+    {
+        // every shard stays read-locked from the eligibility test to its last launch
+        std::vector<std::shared_lock<std::shared_mutex>> locks;
+        for (uint32_t i = 0; i < nl; ++i) locks.emplace_back(shards[i]->mu);
+        for (uint32_t j = 0; j < n_queries; ++j) {
+            const orama_post_query_desc& qd = queries[j];
+            if (qd.params.top_k > stride_k || qd.params.top_k == 0) {
+                set_error("query %u: top_k %u outside [1, stride %u]", j, qd.params.top_k, stride_k);
+                status[j] = ORAMA_ERR_INVALID;
+                errors[j] = orama_last_error();
+                continue;
+            }
+            bool ok = world == nl && !allow_bitmaps && check_params(&qd.params) == ORAMA_OK;
+            uint32_t lists_of_token[kMaxTokens] = {0};
+            uint32_t df[kMaxTokens] = {0};
+            for (uint32_t i = 0; i < nl && ok; ++i) ok = ranges_eligible(shards[i], qd.refs, qd.n_refs, &qd.params);
+            for (uint32_t r = 0; r < qd.n_refs && ok; ++r) {
+                const orama_term_ref& ref = qd.refs[r];
+                if (ref.token >= qd.params.n_tokens) {
+                    ok = false;  // (the one-by-one path reports it)
+                    break;
+                }
+                uint64_t len = 0;
+                for (uint32_t i = 0; i < nl; ++i) len += shards[i]->list_off[ref.list + 1] - shards[i]->list_off[ref.list];
+                if (len == 0) continue;
+                if (++lists_of_token[ref.token] > 1 || len > 0xffffffffull) ok = false;
+                df[ref.token] = (uint32_t)len;
+            }
+            if (ok) {
+                fast.push_back(j);
+                df_global.insert(df_global.end(), df, df + kMaxTokens);
+            } else {
+                slow.push_back(j);
+            }
+        }
+        if (!fast.empty()) {
+            const size_t nf = fast.size();
+            std::vector<uint64_t> s_ids((size_t)nl * nf * stride_k);
+            std::vector<float> s_sc((size_t)nl * nf * stride_k);
+            std::vector<uint32_t> s_n((size_t)nl * nf, 0);
+            std::vector<uint64_t> s_cnt((size_t)nl * nf, 0);
+            std::vector<int> shard_status(nl, ORAMA_OK);
+            std::vector<std::string> shard_error(nl);
+            auto run_shard = [&](uint32_t i) {
+                orama_post* p = shards[i];
+                auto body = [&]() -> int {
+                    ORAMA_ON_DEVICE(p->ctx->device);
+                    std::vector<RangeJob> jobs;
+                    jobs.reserve(nf);
+                    for (size_t f = 0; f < nf; ++f) {
+                        const orama_post_query_desc& qd = queries[fast[f]];
+                        const size_t o = ((size_t)i * nf + f);
+                        RangeJob job{qd.refs, qd.n_refs, &qd.params, &s_ids[o * stride_k], &s_sc[o * stride_k], &s_n[o], &s_cnt[o]};
+                        job.df_global = &df_global[f * kMaxTokens];
+                        jobs.push_back(job);
+                    }
+                    ScratchLease sc(p->ctx), sc2(p->ctx);
+                    const bool two = jobs.size() > kRangeBatchMax;
+                    if (two) ORAMA_TRY(ScratchLease::init_pair(sc, sc2));
+                    else ORAMA_TRY(sc.init());
+                    return post_search_ranges(p, sc.s.get(), jobs.data(), (uint32_t)jobs.size(), b, nullptr, 0, apply_omc,
+                                              two ? sc2.s.get() : nullptr);
+                };
+                shard_status[i] = body();
+                if (shard_status[i] != ORAMA_OK) shard_error[i] = orama_last_error();  // this thread's slot
+            };
+            std::vector<std::thread> pool;
+            for (uint32_t i = 1; i < nl; ++i) pool.emplace_back(run_shard, i);
+            run_shard(0);
+            for (auto& t : pool) t.join();
+            bool all_ok = true;
+            for (uint32_t i = 0; i < nl; ++i) all_ok = all_ok && shard_status[i] == ORAMA_OK;
+            if (!all_ok) {
+                // a set of launches failed as a whole on some shard: every query of it is answered (or refused) on its own
+                slow.insert(slow.end(), fast.begin(), fast.end());
+            } else {
+                struct Hit {
+                    float score;
+                    uint64_t id;
+                };
+                std::vector<Hit> hits;
+                for (size_t f = 0; f < nf; ++f) {
+                    const uint32_t j = fast[f], k = queries[j].params.top_k;
+                    hits.clear();
+                    uint64_t count = 0;
+                    for (uint32_t i = 0; i < nl; ++i) {
+                        const size_t o = (size_t)i * nf + f;
+                        count += s_cnt[o];
+                        for (uint32_t e = 0; e < s_n[o]; ++e) hits.push_back(Hit{s_sc[o * stride_k + e], s_ids[o * stride_k + e]});
+                    }
+                    std::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& c) { return a.score > c.score || (a.score == c.score && a.id < c.id); });
+                    const uint32_t n = (uint32_t)std::min<size_t>(hits.size(), k);
+                    for (uint32_t e = 0; e < n; ++e) {
+                        out_ids[(size_t)j * stride_k + e] = hits[e].id;
+                        out_scores[(size_t)j * stride_k + e] = hits[e].score;
+                    }
+                    out_n[j] = n;
+                    if (out_count) out_count[j] = count;
+                }
+            }
+        }
+    }
+    // (the shard locks are released: the staged query below takes them itself)
+    for (uint32_t j : slow) {
+        const orama_post_query_desc& qd = queries[j];
+        uint64_t cnt = 0;
+        const int st = orama_shard_post_search(g, shards, qd.refs, qd.n_refs, b, &qd.params, allow_bitmaps, bitmap_bits, apply_omc, 0,
+                                               nullptr, nullptr, 0, out_ids + (size_t)j * stride_k, out_scores + (size_t)j * stride_k,
+                                               &out_n[j], &cnt);
+        if (st == ORAMA_OK) {
+            if (out_count) out_count[j] = cnt;
+        } else {
+            status[j] = st;
+            errors[j] = orama_last_error();
+            out_n[j] = 0;
+        }
+    }
+    int first = ORAMA_OK;
+    for (uint32_t j = 0; j < n_queries; ++j) {
+        if (out_status) out_status[j] = status[j];
+        if (first == ORAMA_OK && status[j] != ORAMA_OK) {
+            first = status[j];
+            set_error("query %u: %s", j, errors[j].c_str());
+        }
+    }
+    return first;
 }
 
 }  // extern "C"

@@ -690,11 +690,18 @@ class PostSearchBatcher:
     are scored 32 at a time by the range-partitioned scorer.  `search` has PostingsStore.search's arguments and
     results (non-hybrid)."""
 
-    def __init__(self, store: PostingsStore, max_batch: int = 256, max_wait_us: int = 0):
+    def __init__(self, store: PostingsStore, max_batch: int = 256, max_wait_us: int = 0, group=None, shards=None):
+        """group + shards: the batcher in front of a shard group (orama_post_batcher_create_group); `store` is then any one
+        of the shards (it marshals the references)."""
         self._lib = N.load()
         self.store = store
         h = C.c_void_p()
-        N.check(self._lib.orama_post_batcher_create(store._h, int(max_batch), int(max_wait_us), C.byref(h)))
+        if group is not None:
+            self._group, self._shards = group, list(shards)
+            N.check(self._lib.orama_post_batcher_create_group(group._h, group._handles(shards), int(max_batch), int(max_wait_us),
+                                                              C.byref(h)))
+        else:
+            N.check(self._lib.orama_post_batcher_create(store._h, int(max_batch), int(max_wait_us), C.byref(h)))
         self._h = h
         store._adopt(self)
 

@@ -158,6 +158,29 @@ class ShardGroup:
     def session(self, stores, queries, q_per_step: int, k: int, n_slots: int = 2, force_exchange: bool = False):
         return ShardSession(self, stores, queries, q_per_step, k, n_slots, force_exchange)
 
+    def post_search_batch(self, stores, queries, total_documents: float, top_k: int, allow=None, apply_omc: bool = True,
+                          b: float = B_DEFAULT, k: float = K1_DEFAULT, statuses: bool = False):
+        """orama_shard_post_search_batch: `queries` as PostingsStore.search_batch (refs, n_tokens, threshold | None[, top_k]);
+        returns the list of (ids, scores, count) — and the status array with `statuses`."""
+        from .fulltext import PreparedBatch
+
+        prep = PreparedBatch(stores[0], queries, total_documents, top_k, None, apply_omc, 0, b, k)
+        toks, bits = self._allow(allow)
+        st = np.zeros(max(prep.nq, 1), dtype=np.int32)
+        rc = self._lib.orama_shard_post_search_batch(self._h, self._handles(stores), prep._descs, prep.nq, b, toks, bits,
+                                                     1 if apply_omc else 0, prep._stride, prep.out_ids.ctypes.data,
+                                                     prep.out_sc.ctypes.data, prep.out_n.ctypes.data, prep.out_count.ctypes.data,
+                                                     st.ctypes.data)
+        if not statuses:
+            N.check(rc)
+            return prep.results()
+        return prep.results(), st[: prep.nq]
+
+    def post_batcher(self, stores, max_batch: int = 256, max_wait_us: int = 0):
+        from .fulltext import PostSearchBatcher
+
+        return PostSearchBatcher(stores[0], max_batch, max_wait_us, group=self, shards=stores)
+
     def lanes(self) -> dict:
         """Sharded calls the group runs side by side (max) and the lanes made so far (orama_shard_group_lanes)."""
         mx, made = C.c_uint32(), C.c_uint32()

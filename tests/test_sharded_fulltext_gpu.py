@@ -169,3 +169,102 @@ def test_staged_query_order_is_enforced(ctx, synth):
     q.end()
     stream.close()
     stores[0].close()
+
+
+def test_sharded_fulltext_batches_equal_the_single_store(ctx):
+    """orama_shard_post_search_batch over 3 ragged co-located shards == orama_post_search_batch over the union, bit for bit:
+    queries the range scorer takes on every shard with the index-wide df summed on the host (one list per token, no filter;
+    70 of them: three sets of launches per shard, shards side by side), and queries that go one by one through the staged
+    sharded query (two lists for a token, a filter); thresholds, OMC, k from 1 to 150; a malformed query fails alone.
+    The group's full-text request batcher answers the same from concurrent callers."""
+    import threading
+
+    from oramacore_amd.shard_group import ShardGroup
+
+    rng = np.random.default_rng(41)
+    n, n_lists = 30_000, 10
+    doc_ids = np.arange(n, dtype=np.uint64) * 3 + 2
+    lens = rng.integers(5, 300, size=n).astype(np.uint32)
+    avg = float(lens.mean())
+    pos = [np.sort(rng.choice(n, size=int(sz), replace=False)) for sz in rng.integers(200, 9000, size=n_lists)]
+    tfs = [rng.integers(1, 6, size=len(p)).astype(np.uint32) for p in pos]
+    single = ft.PostingsStore(ctx)
+    single.build(doc_ids, [avg], [ft.PostingList(field=0, docs=doc_ids[p], tf=t, field_len=lens[p]) for p, t in zip(pos, tfs)])
+    omc = {int(doc_ids[i]): float(np.float32(m)) for i, m in zip(rng.choice(n, size=40, replace=False), rng.uniform(0.2, 30.0, size=40))}
+    single.set_omc(omc)
+    cuts = [0, 7000, 19000, n]
+    group = ShardGroup([0, 0, 0])
+    shards = []
+    for g in range(3):
+        lo, hi = cuts[g], cuts[g + 1]
+        lists = []
+        for p, t in zip(pos, tfs):
+            m = (p >= lo) & (p < hi)
+            lists.append(ft.PostingList(field=0, docs=doc_ids[p[m]], tf=t[m], field_len=lens[p[m]]))
+        ps = ft.PostingsStore(group.ctx(g))
+        ps.build(doc_ids[lo:hi], [avg], lists)  # index-wide average length
+        ps.set_omc({d: m for d, m in omc.items() if doc_ids[lo] <= d <= doc_ids[hi - 1]})
+        shards.append(ps)
+    queries = []
+    for i in range(70):
+        n_tok = 1 + i % 4
+        ls = rng.choice(n_lists, size=n_tok, replace=False)
+        refs = [(t, int(l), float(np.float32(1.0 + 0.5 * (i % 3)))) for t, l in enumerate(ls)]
+        queries.append((refs, n_tok, (1 if n_tok > 1 and i % 5 == 0 else None), [1, 10, 50, 150][i % 4]))
+    queries.append(([(0, 1, 1.0), (0, 2, 1.0), (1, 3, 1.0)], 2, None, 25))  # two lists for token 0: one by one
+    queries.append(([(0, 4, 1.0)], 1, None, 10))
+    for use_omc in (False, True):
+        exp = single.search_batch(queries, float(n), 150, apply_omc=use_omc)
+        got = group.post_search_batch(shards, queries, float(n), 150, apply_omc=use_omc)
+        for i, ((gi, gs, gc), (ei, es, ec)) in enumerate(zip(got, exp)):
+            assert gc == ec and gi.tolist() == ei.tolist(), (use_omc, i)
+            assert np.array_equal(gs.view(np.uint32), es.view(np.uint32)), (use_omc, i)
+    # the eligible queries really ran on the range scorer, without a per-record launch
+    gctx = group.ctx(0)
+    gctx.prof_reset()
+    gctx.prof_enable(True)
+    group.post_search_batch(shards, queries[:70], float(n), 150)
+    gctx.prof_enable(False)
+    assert gctx.prof_get("bm25_range_score")[1] >= 9 and gctx.prof_get("bm25_accumulate")[1] == 0  # 3 shards x 3 sets of launches
+    # a filter: every query goes through the staged sharded query
+    keep = (np.arange(n) % 4) != 1
+    bm = oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[keep])
+    toks = [oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[keep]).to_device(group.ctx(g)) for g in range(3)]
+    exp = single.search_batch(queries[:6], float(n), 150, allow=bm)
+    got = group.post_search_batch(shards, queries[:6], float(n), 150, allow=toks)
+    for (gi, gs, gc), (ei, es, ec) in zip(got, exp):
+        assert gc == ec and gi.tolist() == ei.tolist() and np.array_equal(gs.view(np.uint32), es.view(np.uint32))
+    # a malformed query (token index beyond n_tokens) fails alone
+    bad = queries[:3] + [([(5, 0, 1.0)], 2, None, 5)] + queries[3:5]
+    res, st = group.post_search_batch(shards, bad, float(n), 150, statuses=True)
+    assert st.tolist() == [0, 0, 0, oa._native.ORAMA_ERR_INVALID, 0, 0] and len(res[3][0]) == 0
+    exp = single.search_batch(queries[:5], float(n), 150)
+    for (gi, gs, gc), (ei, es, ec) in zip(res[:3] + res[4:], exp):
+        assert gc == ec and gi.tolist() == ei.tolist()
+    # the request batcher in front of the group, concurrent callers
+    batcher = group.post_batcher(shards, max_batch=64)
+    exp = single.search_batch(queries[:40], float(n), 150)
+    errors = []
+
+    def caller(i):
+        try:
+            refs, n_tok, thr, k = queries[i]
+            ids, sc, cnt = batcher.search(refs, n_tok, float(n), k, thr)
+            assert cnt == exp[i][2] and ids.tolist() == exp[i][0].tolist() and np.array_equal(sc.view(np.uint32), exp[i][1].view(np.uint32))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=caller, args=(i,)) for i in range(40)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors[:3]
+    assert batcher.stats()["requests"] == 40
+    batcher.close()
+    for t in toks:
+        t.close()
+    for s in shards:
+        s.close()
+    single.close()
+    group.close()
