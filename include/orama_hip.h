@@ -591,7 +591,8 @@ int orama_shard_hybrid_search(orama_shard_group* g, orama_vec* const* vec_shards
  * The request micro-batcher in front of a group: like orama_batcher_create, every pass is one orama_shard_vec_search
  * over `shards` (the group's local shards, in rank order); orama_batcher_search_filtered then takes, in place of the
  * bitmap words, the address of the caller's array of resident per-shard tokens (const uint64_t* const*; requests
- * carrying the same array share a pass).  The group and the stores must outlive the batcher. */
+ * carrying the same array share a pass).  Every shard of the group must live in this process (ORAMA_ERR_UNSUPPORTED
+ * otherwise: processes would form different batches).  The group and the stores must outlive the batcher. */
 /* orama_post_search_batch_status over the document shards of one index (`shards`: the group's local shards in rank order,
  * built as for orama_shard_post_search).  When every shard of the group lives in this process, queries with one posting
  * list per token and no filter are scored by the range scorer on all shards side by side — the index-wide df is the sum of
@@ -604,7 +605,7 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
                                   uint64_t* out_count, int* out_status);
 /* The full-text request batcher in front of a group: like orama_post_batcher_create, every dispatch is one
  * orama_shard_post_search_batch.  A request's filter, if any, is the address of the caller's array of resident per-shard
- * tokens.  The group and the stores must outlive the batcher. */
+ * tokens.  Every shard of the group must live in this process.  The group and the stores must outlive the batcher. */
 int orama_post_batcher_create_group(orama_shard_group* g, orama_post* const* shards, uint32_t max_batch, uint32_t max_wait_us,
                                     orama_post_batcher** out);
 /* Sharded calls the group can run side by side, and how many lanes (exchange streams + buffers per local shard) it has

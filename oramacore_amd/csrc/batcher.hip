@@ -181,6 +181,9 @@ int orama_batcher_create_group(orama_shard_group* g, orama_vec* const* shards, u
     ORAMA_REQUIRE(max_batch >= 1 && max_batch <= 1024, "max_batch %u outside [1, 1024]", max_batch);
     uint32_t world = 0, n_local = 0;
     ORAMA_TRY(orama_shard_group_info(g, &world, &n_local, nullptr, nullptr));
+    // batches form from whatever requests have arrived: with ranks in other processes every process would form different
+    // batches and issue different collectives
+    ORAMA_SUPPORT(world == n_local, "a request batcher needs every shard of the group in this process (%u of %u are local)", n_local, world);
     for (uint32_t i = 0; i < n_local; ++i) ORAMA_REQUIRE(shards[i], "null shard %u", i);
     orama_batcher* b = new (std::nothrow) orama_batcher();
     if (!b) {
@@ -401,8 +404,9 @@ int orama_post_batcher_create_group(orama_shard_group* g, orama_post* const* sha
     ORAMA_REQUIRE(g && shards && out, "null argument");
     *out = nullptr;
     ORAMA_REQUIRE(max_batch >= 1 && max_batch <= 4096, "max_batch %u outside [1, 4096]", max_batch);
-    uint32_t n_local = 0;
-    ORAMA_TRY(orama_shard_group_info(g, nullptr, &n_local, nullptr, nullptr));
+    uint32_t world = 0, n_local = 0;
+    ORAMA_TRY(orama_shard_group_info(g, &world, &n_local, nullptr, nullptr));
+    ORAMA_SUPPORT(world == n_local, "a request batcher needs every shard of the group in this process (%u of %u are local)", n_local, world);
     for (uint32_t i = 0; i < n_local; ++i) ORAMA_REQUIRE(shards[i], "null shard %u", i);
     orama_post_batcher* b = new (std::nothrow) orama_post_batcher();
     if (!b) {

@@ -71,6 +71,9 @@ def expected(ctx):
         assert e[f"text{ci}"][2] == ocount and e[f"text{ci}"][0].tolist() == od.tolist()
         assert np.array_equal(bits(e[f"text{ci}"][1]), bits(os_))
         e[f"hyb{ci}"] = post.search(refs, n_tok, total, 30, threshold=case["threshold"], vector=vec, apply_omc=False)
+    batch = [(W.refs_of(meta, list_id, meta["cases"][ci]), len(meta["cases"][ci]["terms"]), meta["cases"][ci]["threshold"]) for ci in W.TEXT_CASES]
+    for bi, r in enumerate(post.search_batch(batch, total, 40)):
+        e[f"batch{bi}"] = r
     post.set_omc({int(doc_ids[3]): 2.0, int(doc_ids[-2]): 4.0, int(doc_ids[1000]): 0.5})
     case = meta["cases"][12]
     e["omc"] = post.search(W.refs_of(meta, list_id, case), len(case["terms"]), total, 100)
@@ -108,7 +111,9 @@ def check_rank(got, e, world, form, rank):
         assert got[f"sess_slot{slot}_cnt"][0] == 20
     ids, dist, cnt = e["wide"]
     assert same(got["wide_cnt"], cnt) and same(got["wide_ids"], ids) and same(got["wide_dist"], dist), (what, "wide")
-    for key in [f"text{ci}" for ci in W.TEXT_CASES] + [f"hyb{ci}" for ci in W.TEXT_CASES] + ["omc", "onecall_a", "onecall_b"]:
+    assert int(got["batcher_refused"]) == (1 if form == "rank" else 0), what
+    for key in ([f"text{ci}" for ci in W.TEXT_CASES] + [f"hyb{ci}" for ci in W.TEXT_CASES] + ["omc", "onecall_a", "onecall_b"] +
+                [f"batch{bi}" for bi in range(len(W.TEXT_CASES))]):
         ids, sc, count = e[key]
         assert int(got[key + "_count"]) == count, (what, key)
         assert got[key + "_ids"].tolist() == ids.tolist(), (what, key)
