@@ -6,7 +6,7 @@
 // union of a query's lists is a k-way merge, and a merge can be cut anywhere in DOCUMENT space:
 //
 //   range_bounds_kernel   one lower-bound search per (list, range boundary): where does each list cross the range boundaries
-//                         (range = 2^log_r consecutive local documents, log_r chosen per query so that a range
+//                         (range = `width` consecutive local documents, chosen per query so that a range
 //                         holds 512..1024 postings on average).  bounds[list][r] = postings of the list in ranges < r.
 //   range_score_kernel    one workgroup per (range, query): gathers the <= 2048 postings of its range from the
 //                         lists (coalesced: each list contributes one contiguous, already sorted run), computes the
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kThreads) void range_bounds_kernel(RangeBatch b) {
     if (r >= q.n_ranges) {
         lo = len;
     } else if (r > 0) {
-        const uint32_t target = r << q.log_r;  // first document of range r (n_docs < 2^32)
+        const uint32_t target = r * q.width;  // first document of range r (n_docs < 2^32)
         const uint32_t* pd = b.post_doc + sg->post_begin;
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     // gather: element e belongs to the reference whose [seg_off[i], seg_off[i+1]) holds it; runs are sorted by
     // document, so by key
     const float one_minus_b = 1.0f - b.b;
-    const uint32_t doc0 = r << q.log_r;
+    const uint32_t doc0 = r * q.width;
     for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
         uint32_t lo = 0, hi = ns;
         while (hi - lo > 1) {
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kThreads) void range_score_docs_kernel(RangeBatch b
     }
     const float k1 = q.k + 1.0f, one_minus_b = 1.0f - b.b;
     const uint32_t ns = q.seg_end - q.seg_begin;
-    const uint32_t r = doc >> q.log_r;
+    const uint32_t r = doc / q.width;
     const uint32_t* bnd = b.bounds + q.bounds_base + (uint64_t)r * ns;
     for (uint32_t base = 0; base < ns; base += 64) {
         const uint32_t i = base + lane;

@@ -8,7 +8,7 @@
 namespace orama {
 
 constexpr uint32_t kRangeCap = 2048;     // postings one workgroup merges in LDS
-constexpr uint32_t kRangeMaxLogR = 15;   // documents per range <= 32768 (local document in 16 key bits; 0xffff.. = dropped)
+constexpr uint32_t kRangeMaxWidth = 32768;  // documents per range (the local document takes 15 bits of the merge key)
 constexpr uint32_t kRangeMaxRefs = 256;  // non-empty posting lists per query (per-reference tables live in LDS)
 
 // One (token, posting list) reference of one query of the batch.
@@ -24,7 +24,7 @@ struct RangeQuery {
     uint64_t key_off;     // first slot of this query in the key buffer (one slot per referenced posting)
     uint64_t bounds_base; // first bounds entry of this query
     uint32_t seg_begin, seg_end;
-    uint32_t log_r;       // a range = 2^log_r consecutive local documents
+    uint32_t width;       // a range = `width` consecutive local documents (1 .. kRangeMaxWidth, any value)
     uint32_t n_ranges;
     uint32_t n_tokens;
     uint32_t use_threshold, threshold;
