@@ -621,6 +621,11 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         if (total) pending.push_back({j, 0u, total});
     }
     ORAMA_REQUIRE(p->n_docs > 0 || pending.empty(), "postings store is empty (orama_post_build not called)");
+    // Queries of similar length share a set of launches: the launches of a chunk are sized by its longest query (grid of the
+    // scoring launch, stride of the key lists, chunks of the top-k reduction), and a workgroup that finds nothing to do still
+    // has to be launched — and, in the reduction, to write its k empty outputs.
+    if (pending.size() > kRangeBatchMax)
+        std::stable_sort(pending.begin(), pending.end(), [](const Pending& a, const Pending& c) { return a.total > c.total; });
 
     // One set of launches: up to kRangeBatchMax queries whose padded key lists fit the budget.
     struct Chunk {

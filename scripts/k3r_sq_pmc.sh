@@ -15,11 +15,12 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
 done
 cd $R
 python - <<'PY'
-import csv, glob, statistics, collections
+import csv, glob, statistics, collections, os
+KERNEL = os.environ.get("KERNEL", "range_score_kernel")
 vals = collections.defaultdict(list)
 for path in glob.glob("gpurun_out/k3r_sq/*/*counter_collection.csv"):
     for row in csv.DictReader(open(path, newline="")):
-        if "range_score_kernel" in row["Kernel_Name"]:
+        if KERNEL in row["Kernel_Name"]:
             vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(vals):
     print(f"{k:28s} {statistics.median(vals[k]):16.0f}   (launches {len(vals[k])})")
