@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -248,8 +249,15 @@ struct orama_ctx {
     char name[256] = {0};
     orama::Profiler prof;
     std::mutex pool_mu;
-    std::condition_variable pool_cv, pool_cv_pair;  // callers waiting for one set / for two sets
-    uint32_t waiting_one = 0, waiting_pair = 0;
+    // callers waiting for their sets, first come first served — each on its own condition variable (a release wakes exactly
+    // the caller whose turn it is; see orama_ctx::acquire_n)
+    struct PoolWaiter {
+        uint32_t need = 0;
+        bool granted = false;
+        std::condition_variable cv;
+    };
+    std::deque<PoolWaiter*> pool_waiters;
+    void grant_waiters();  // pool_mu held
     std::vector<std::unique_ptr<orama::Scratch>> pool;
     uint32_t leased = 0;  // scratch sets out on lease; bounded by max_inflight (callers beyond it wait their turn)
     uint32_t held = 0;    // sets kept by long-lived handles (orama_scores): NOT counted against max_inflight — a handle is

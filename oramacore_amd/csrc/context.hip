@@ -100,51 +100,61 @@ int take_one(orama_ctx* c, std::unique_ptr<orama::Scratch>* out, int kind) {  //
 }
 }  // namespace
 
-// Waiters are woken one at a time (a release frees ONE set; waking every waiter costs a context switch per waiting
-// thread and query: 128 callers of a 32-set pool ran at a quarter of the rate of 32 callers).  Callers that need two sets
-// (the fused hybrid search) wait on their own condition variable and go first when two sets are free.
-int orama_ctx::acquire(std::unique_ptr<orama::Scratch>* out, int kind) {
-    std::unique_lock<std::mutex> g(pool_mu);
-    ++waiting_one;
-    // a caller that needs several sets at once goes first: single takers would otherwise grab every freed set and the
-    // multi-set caller (a request batcher's dispatcher, the hybrid search) would never see two free together
-    const bool ok = pool_cv.wait_for(g, std::chrono::milliseconds(acquire_timeout_ms),
-                                     [&] { return leased < max_inflight && waiting_pair == 0; });
-    --waiting_one;
-    if (!ok) {
-        orama::set_error("all %u scratch sets of this context stayed leased for %u ms (ORAMA_MAX_INFLIGHT / "
-                         "ORAMA_ACQUIRE_TIMEOUT_MS): the call was not started", max_inflight, acquire_timeout_ms);
-        return ORAMA_ERR_BUSY;
+// The bound on sets in flight is served FIRST COME, FIRST SERVED.  Every waiter sleeps on its own condition variable in a
+// queue; whoever returns capacity (release, detach_one, a waiter that timed out) grants it to the head of the queue for as
+// long as the head's request fits, and wakes exactly the granted callers.  (Rounds 1-2 woke "one waiter" of a shared
+// condition variable and let multi-set callers go before single-set ones: with 512 callers of the one-call hybrid search
+// — three sets each, ten calls in flight — the wake-up order starved some callers until their 30 s timeout while the pool
+// was turning over 450 times a second, and a single-set caller could not run at all while any multi-set caller waited.)
+// A request for several sets is granted as a whole, so callers never hold some sets while waiting for others.
+void orama_ctx::grant_waiters() {
+    while (!pool_waiters.empty() && leased + pool_waiters.front()->need <= max_inflight) {
+        PoolWaiter* w = pool_waiters.front();
+        pool_waiters.pop_front();
+        leased += w->need;  // reserved for it: it takes its sets when it wakes
+        w->granted = true;
+        w->cv.notify_one();
     }
-    ORAMA_TRY(take_one(this, out, kind));
-    ++leased;
-    if (leased < max_inflight && waiting_one) pool_cv.notify_one();  // capacity left: pass the baton
-    return ORAMA_OK;
+}
+
+int orama_ctx::acquire(std::unique_ptr<orama::Scratch>* out, int kind) {
+    std::unique_ptr<orama::Scratch>* outs[1] = {out};
+    return acquire_n(1, outs, &kind);
 }
 
 int orama_ctx::acquire_n(uint32_t n, std::unique_ptr<orama::Scratch>** outs, const int* kinds) {
     std::unique_lock<std::mutex> g(pool_mu);
     const uint32_t need = std::min(n, max_inflight);  // a pool smaller than the request would wait for ever
-    ++waiting_pair;
-    const bool ok = pool_cv_pair.wait_for(g, std::chrono::milliseconds(acquire_timeout_ms),
-                                          [&] { return leased + need <= max_inflight; });
-    --waiting_pair;
-    if (!ok) {
-        if (waiting_pair == 0 && leased < max_inflight && waiting_one) pool_cv.notify_one();  // singles held back for us
-        orama::set_error("%u scratch sets were not free together within %u ms (%u of %u leased; ORAMA_MAX_INFLIGHT / "
-                         "ORAMA_ACQUIRE_TIMEOUT_MS): the call was not started", n, acquire_timeout_ms, leased, max_inflight);
-        return ORAMA_ERR_BUSY;
+    if (pool_waiters.empty() && leased + need <= max_inflight) {
+        leased += need;
+    } else {
+        PoolWaiter w;
+        w.need = need;
+        pool_waiters.push_back(&w);
+        const bool ok = w.cv.wait_for(g, std::chrono::milliseconds(acquire_timeout_ms), [&] { return w.granted; });
+        if (!ok) {
+            for (auto it = pool_waiters.begin(); it != pool_waiters.end(); ++it)
+                if (*it == &w) {
+                    pool_waiters.erase(it);
+                    break;
+                }
+            grant_waiters();  // (the queue's head may have been this caller: what is free may fit the next one)
+            orama::set_error("%u scratch set(s) did not come free within %u ms (%u of %u leased, %zu callers waiting; "
+                             "ORAMA_MAX_INFLIGHT / ORAMA_ACQUIRE_TIMEOUT_MS): the call was not started", n, acquire_timeout_ms,
+                             leased, max_inflight, pool_waiters.size());
+            return ORAMA_ERR_BUSY;
+        }
     }
     for (uint32_t i = 0; i < n; ++i) {
         const int st = take_one(this, outs[i], kinds ? kinds[i] : orama::kScratchGeneral);
         if (st != ORAMA_OK) {
             for (uint32_t j = 0; j < i; ++j) pool.push_back(std::move(*outs[j]));
+            leased -= need;
+            grant_waiters();
             return st;
         }
     }
-    leased += n;
-    if (waiting_pair) pool_cv_pair.notify_one();
-    else if (leased < max_inflight && waiting_one) pool_cv.notify_one();
+    leased += n - need;
     return ORAMA_OK;
 }
 
@@ -184,8 +194,7 @@ void orama_ctx::detach_one() {
     std::lock_guard<std::mutex> g(pool_mu);
     if (leased) --leased;
     ++held;
-    if (waiting_pair) pool_cv_pair.notify_one();
-    else if (waiting_one) pool_cv.notify_one();
+    grant_waiters();
 }
 
 void orama_ctx::release(std::unique_ptr<orama::Scratch> s, bool detached) {
@@ -205,8 +214,7 @@ void orama_ctx::release(std::unique_ptr<orama::Scratch> s, bool detached) {
     } else if (leased) {
         --leased;
     }
-    if (waiting_pair) pool_cv_pair.notify_one();  // it re-checks; freed sets accumulate for it (singles hold back)
-    else if (waiting_one) pool_cv.notify_one();
+    grant_waiters();
 }
 
 namespace orama {
