@@ -471,7 +471,7 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
                                                            "range_df": kd_ms * 1e3 / n_dev_q,
                                                            "range_score": ks_ms * 1e3 / n_dev_q,
                                                            "topk_select": kt_ms * 1e3 / n_dev_q},
-                                   "note": "latency / LDS-bound merge of sorted runs, not a streaming kernel (DESIGN K3r)"},
+                                   "note": "the scoring launch is bound by VALU issue (~550 lane instructions per posting: IEEE divisions for bit-exact ntf, four merge levels, the fold), not by HBM: profiles/r03_k3r_sq_counters.md, DESIGN K3r"},
                       "cpu_baseline": cpu_bm25},
         "postings_fill_seconds": t_fill,
         "parity_check": "bit-exact vs oracle (last query): BM25 ids/scores/count, hybrid ids/scores/count",
