@@ -39,7 +39,19 @@ COMMON_FLAGS = [
 ]
 # Translation units whose f32 arithmetic must round exactly like the scalar reference
 # (BM25F scores must be bit-identical to the scalar f32 evaluation): no FMA contraction.
-EXACT_FP = {"fulltext.hip", "bm25_kernels.hip", "bm25_ranges.hip"}
+EXACT_FP = {"fulltext.hip", "bm25_kernels.hip", "bm25_ranges.hip", "bm25_ranges_merge.hip"}
+# Superseded kernels kept for A/B measurements only — K2c (round-1 wide fp16 scan), K2h (K-split wave pairs, 6 % slower than
+# K2q) and the round-3 merge-tree form of K3r's scoring launch.  They are compiled and linked only when the environment says
+# ORAMA_COMPARISON_KERNELS=1 at build time; the product library does not contain them.
+COMPARISON_UNITS = {"vec_f16_wide.hip", "vec_f16_kh.hip", "bm25_ranges_merge.hip"}
+
+
+def comparison_build() -> bool:
+    return os.environ.get("ORAMA_COMPARISON_KERNELS", "0") == "1"
+
+
+def _flags() -> list[str]:
+    return [*COMMON_FLAGS, f"-DORAMA_COMPARISON_KERNELS={1 if comparison_build() else 0}"]
 
 
 def _hipcc() -> str:
@@ -50,7 +62,7 @@ def _hipcc() -> str:
 
 
 def _sources() -> list[Path]:
-    return sorted(CSRC.glob("*.hip"))
+    return sorted(p for p in CSRC.glob("*.hip") if comparison_build() or p.name not in COMPARISON_UNITS)
 
 
 def _fingerprint() -> str:
@@ -60,7 +72,7 @@ def _fingerprint() -> str:
         h.update(p.read_bytes())
     # flags without the checkout-specific include paths: the tree is shipped to the GPU box under another root, and a
     # path in the fingerprint would force a rebuild there on every run
-    h.update(" ".join(f for f in COMMON_FLAGS if not f.startswith("-I")).encode())
+    h.update(" ".join(f for f in _flags() if not f.startswith("-I")).encode())
     return h.hexdigest()
 
 
@@ -115,7 +127,7 @@ def build_native(force: bool = False, verbose: bool = True) -> Path:
 
     def compile_one(src: Path) -> Path:
         obj = OBJ_DIR / (src.stem + ".o")
-        flags = list(COMMON_FLAGS)
+        flags = _flags()
         flags.append("-ffp-contract=off" if src.name in EXACT_FP else "-ffp-contract=fast")
         cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -127,6 +139,10 @@ def build_native(force: bool = False, verbose: bool = True) -> Path:
             sys.stderr.write(rest + "\n")
         return obj
 
+    keep = {src.stem for src in _sources()}
+    for stale in list(OBJ_DIR.glob("*.o")) + list(OBJ_DIR.glob("*.resources.json")):  # units of the other build flavour
+        if stale.name.split(".")[0] not in keep:
+            stale.unlink()
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, _sources()))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs), "-lpthread", "-ldl"]

@@ -3,21 +3,34 @@
 // K3 (bm25_kernels.hip) scatters every posting into a per-document record in HBM (random 64-byte read-modify-writes
 // into a table of n_docs records) and walks the records again to finalise: ~130 B of random HBM traffic per posting
 // and ~20 small launches per query.  Posting lists are sorted by document (orama_post_build checks it), so the
-// union of a query's lists is a k-way merge, and a merge can be cut anywhere in DOCUMENT space:
+// union of a query's lists can be cut anywhere in DOCUMENT space:
 //
 //   range_bounds_kernel   one lower-bound search per (list, range boundary): where does each list cross the range boundaries
 //                         (range = `width` consecutive local documents, chosen per query so that a range
-//                         holds 512..1024 postings on average).  bounds[list][r] = postings of the list in ranges < r.
-//   range_score_kernel    one workgroup per (range, query): gathers the <= 2048 postings of its range from the
-//                         lists (coalesced: each list contributes one contiguous, already sorted run), computes the
-//                         normalised tf, merges the runs by (document, token, list rank) in LDS — a merge tree by
-//                         ranking, log2(lists) levels — and the first thread of every
-//                         document walks its run IN ORDER — lists of a token in reference order, tokens ascending —
-//                         exactly the additions BM25Scorer::add / get_scores perform (bm25.rs:369-428), so scores
-//                         are bit-identical to K3 and to the CPU restatement.  Output: one 64-bit key
-//                         ordered(score) << 32 | ~document per scored document, at the slot of its first posting
+//                         holds ~1 280 postings on average).  bounds[list][r] = postings of the list in ranges < r.
+//   range_score_kernel    one workgroup per (query, range) pair that exists (1-D grid).  SORT-FREE since round 4:
+//                           1. gather the <= 2 048 postings of the range (each list contributes one contiguous run:
+//                              coalesced), mark each posting's local document in an LDS bitmap (one bit per document of the range);
+//                           2. popcount prefix over the bitmap words = dense rank of every touched document;
+//                           3. every posting ORs its token into its document's presence mask (one 64-bit word per rank);
+//                           4. a document whose mask has ONE token of a one-list token is a singleton (97 % of the documents
+//                              of a 12-token query): its posting's thread scores it on the spot — score = 0.0 + idf (k+1) S / (k + S) —
+//                              and writes its key.  The other documents get popcount(mask) cells (LDS cursor, one
+//                              returning atomic per such document), their postings add their normalised tf into the cell of
+//                              their token — lists of one token in reference order, a barrier only between ranks of a token —
+//                              and one thread per document folds the cells with tokens ascending.
+//                         Those are exactly the additions BM25Scorer::add / get_scores perform (bm25.rs:369-428) in the
+//                         same order, so scores are bit-identical to K3, to the round-3 merge-tree form of this kernel
+//                         (bm25_ranges_merge.hip, comparison builds) and to the CPU restatement.  Output: one 64-bit key
+//                         ordered(score) << 32 | ~document per scored document, at the slot of one of its postings
 //                         (slot base of a range = sum of its bounds: no cursor, no atomics), 0 elsewhere.
 //   launch_keys_topk      (select.hip) exact top-k over the key lists of the whole batch.
+//
+// Round 3's form sorted the postings of a range by (document, token, rank) with a merge tree of 64-bit keys: 8.6 VALU
+// wave-instructions per posting (profiles/r03_k3r_sq_counters.md), every SIMD issuing for the whole launch.  Nothing is
+// sorted here: a posting costs one run lookup, two LDS atomics without return, one rank computation and — for the 97 % —
+// one IEEE division.  The normalised tf's query-independent part tf / (1 - b + b len / avglen) is stored per posting by the
+// store (same operations, same bits; recomputed when the average lengths move), which removes two more divisions.
 //
 // HBM traffic: 8 B per posting read by the score kernel + 8 B per posting written and read once by the top-k (the
 // bounds searches touch ~17 elements per list and range).
@@ -31,33 +44,28 @@
 // Compiled with -ffp-contract=off (see bm25_kernels.hip).
 #include "bm25_ranges.hpp"
 
-#include "device_utils.hpp"
+#include "bm25_ranges_dev.hpp"
 
 namespace orama {
 
 namespace {
 
-constexpr int kThreads = 256;
-
-__device__ __forceinline__ bool f32_is_normal(float x) {
-    const uint32_t e = (__builtin_bit_cast(uint32_t, x) >> 23) & 0xffu;
-    return e != 0u && e != 0xffu;
-}
+constexpr int kBoundsThreads = 256;
 
 // bounds[query][range][reference]: one thread per entry does a lower-bound search of the range's first document in
 // the reference's (document-sorted) list.  (The first form of this kernel walked every referenced posting — one
 // thread per posting, 19 M threads per 32-query batch — to find the crossings: 3.9 us per query; the searches touch
 // 17 list elements per entry instead of all of them, and the upper levels of every search stay in cache: 0.7 us.)
-__global__ __launch_bounds__(kThreads) void range_bounds_kernel(RangeBatch b) {
+__global__ __launch_bounds__(kBoundsThreads) void range_bounds_kernel(RangeBatch b) {
     const uint32_t qi = blockIdx.y;
     // the query's result words start at zero: cleared here, by the first launch of the set, instead of by a fill command
     // of their own in front of it
     if (blockIdx.x == 0)
-        for (uint32_t i = threadIdx.x; i < sizeof(RangeResult) / 4; i += kThreads) reinterpret_cast<uint32_t*>(&b.results[qi])[i] = 0u;
+        for (uint32_t i = threadIdx.x; i < sizeof(RangeResult) / 4; i += kBoundsThreads) reinterpret_cast<uint32_t*>(&b.results[qi])[i] = 0u;
     const RangeQuery q = b.queries[qi];
     const uint32_t ns = q.seg_end - q.seg_begin;
     const uint64_t entries = (uint64_t)ns * (q.n_ranges + 1u);
-    const uint64_t e = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    const uint64_t e = (uint64_t)blockIdx.x * kBoundsThreads + threadIdx.x;
     if (e >= entries) return;
     const uint32_t r = (uint32_t)(e / ns), i = (uint32_t)(e - (uint64_t)r * ns);
     const RangeSeg* sg = b.segs + q.seg_begin + i;
@@ -76,71 +84,79 @@ __global__ __launch_bounds__(kThreads) void range_bounds_kernel(RangeBatch b) {
     b.bounds[q.bounds_base + e] = lo;
 }
 
-// The additions BM25Scorer performs for ONE document, fed its (token, ntf) contributions in (token, reference) order:
-// S_t = sum of the token's ntf (Iterator::sum from 0.0, weight 1.0), score += idf_t (k+1) S_t / (k + S_t) unless S_t is
-// not normal or the term is NaN, token mask for the threshold (bm25.rs:369-428, 484-524).  Shared by the range kernel
-// and the per-document kernel of the hybrid path so that both produce the same bits.
-struct DocFold {
-    float score = 0.0f;  // entry(key).or_insert(0.0)
-    uint32_t mask = 0u;
-    bool applied = false, have = false;
-    uint32_t tok = 0;
-    float sum = 0.0f;
-    __device__ __forceinline__ void close_token(const float* idf, float k, float k1) {
-        if (f32_is_normal(sum)) {
-            const float term = idf[tok] * k1 * sum / (k + sum);  // bm25f_score, bm25.rs:124-126
-            if (term == term) {
-                score = score + term * 1.0f;  // phrase boost 1.0
-                mask |= 1u << (tok & 31u);    // 1 << term_index on u32 (wrapping shift)
-                applied = true;
-            }
-        }
-    }
-    __device__ __forceinline__ void add(uint32_t t, float ntf, const float* idf, float k, float k1) {
-        if (have && t != tok) {
-            close_token(idf, k, k1);
-            sum = 0.0f;
-        }
-        tok = t;
-        have = true;
-        sum = sum + 1.0f * ntf;  // Iterator::sum() from 0.0, weight 1.0
-    }
-    // true: the document is in the score map (threshold passed); `score` is final (before OMC)
-    __device__ __forceinline__ bool finish(const float* idf, float k, float k1, uint32_t use_threshold, uint32_t threshold) {
-        if (have) close_token(idf, k, k1);
-        return applied && !(use_threshold && (uint32_t)__popc(mask) < threshold);
-    }
-};
+// ---------------------------------------------------------------------------------------------- the scoring launch
+constexpr int kThreads = 512;                              // eight waves: 4 workgroups of ~39 KB LDS fill a CU's 32 wave slots
+constexpr int kWaves = kThreads / 64;
+constexpr int kPerThread = kRangeCap / kThreads;           // postings a thread carries in registers across the phases
+constexpr uint32_t kBitWords = kRangeMaxWidth / 32;        // bitmap words of the widest range
+constexpr int kWordsPerThread = kBitWords / kThreads;
+constexpr uint32_t kNoCell = 0xffffu;                      // cell_base of a singleton document
+constexpr uint32_t kInMap = 0x8000u;                       // cell_base flag set by the fold: the document is in the score map
+static_assert(kRangeCap % kThreads == 0 && kBitWords % kThreads == 0, "phase loops are unrolled over whole threads");
+static_assert(kRangeCap <= 0x7fffu, "cells and posting slots are stored in 15 bits");
 
-// key of the in-range merge: [local doc:15 | token:6 | rank:10 | dropped:1 | ntf bits:32] — the order of the upper
-// 31 bits is (document, token, list rank); a posting dropped by the filter keeps its place in its run.
-__device__ __forceinline__ uint32_t key_doc(unsigned long long k) { return (uint32_t)(k >> 49); }
-__device__ __forceinline__ uint32_t key_tok(unsigned long long k) { return (uint32_t)(k >> 43) & 63u; }
-__device__ __forceinline__ uint32_t key_doc_tok(unsigned long long k) { return (uint32_t)(k >> 43); }
-__device__ __forceinline__ bool key_dropped(unsigned long long k) { return (k >> 32) & 1ull; }
-
-constexpr int kPerThread = kRangeCap / kThreads;  // merge elements a thread carries in registers
+// packed per-posting state: [local doc:15 | run (reference) index:8 | pad | kept:1 (bit 31)]
+__device__ __forceinline__ uint32_t pk_make(uint32_t dl, uint32_t seg) { return 0x80000000u | (seg << 15) | dl; }
+__device__ __forceinline__ bool pk_kept(uint32_t pk) { return (pk >> 31) != 0u; }
+__device__ __forceinline__ uint32_t pk_dl(uint32_t pk) { return pk & 0x7fffu; }
+__device__ __forceinline__ uint32_t pk_seg(uint32_t pk) { return (pk >> 15) & 0xffu; }
 
 template <bool DF_ONLY>
 __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
-    __shared__ unsigned long long s[kRangeCap];
+    // region A: the range's document bitmap + the exclusive popcount prefix of its words; once every posting knows its
+    // document's rank both are dead and the region holds the cells of the multi-posting documents
+    __shared__ uint32_t region_a[2 * kBitWords];
+    uint32_t* const bitmap = region_a;
+    uint32_t* const word_rank = region_a + kBitWords;
+    float* const cellv = reinterpret_cast<float*>(region_a);
+    static_assert(sizeof(region_a) >= kRangeCap * sizeof(float), "cells alias the bitmap region");
+    __shared__ unsigned long long dmask[kRangeCap];        // per touched document (by rank): tokens present
+    __shared__ uint16_t cell_base[kRangeCap];              // per touched document: first cell | kInMap, kNoCell = singleton
+    __shared__ uint16_t owner[kRangeCap];                  // per cell: the posting slot that reports the document (first cell only)
     __shared__ unsigned long long seg_pos[kRangeMaxRefs];  // first posting of each reference inside this range
     __shared__ uint32_t seg_off[kRangeMaxRefs + 1];        // start of each reference's run among the gathered postings
-    __shared__ uint32_t seg_key[kRangeMaxRefs];            // token << 11 | rank << 1
+    __shared__ uint32_t seg_key[kRangeMaxRefs];            // token << 10 | rank
     __shared__ float seg_boost[kRangeMaxRefs], seg_avg[kRangeMaxRefs];
     __shared__ float idf[kMaxTokens];
     __shared__ uint32_t df_lds[kMaxTokens];
-    __shared__ uint32_t red[4];
+    __shared__ uint32_t wave_tot[kWaves];
+    __shared__ uint32_t red[4];                            // slot base, count, max key, ~min key
+    __shared__ unsigned long long multi_tok;               // tokens with more than one list
+    __shared__ uint32_t max_rank, cell_cursor;
 
-    const uint32_t qi = blockIdx.y;
+    // (query, range) of this workgroup: the batch's pairs laid end to end
+    uint32_t qi = 0;
+    {
+        uint32_t lo = 0, hi = b.n_queries;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (b.range_start[mid] <= blockIdx.x) lo = mid; else hi = mid;
+        }
+        qi = lo;
+    }
     const RangeQuery q = b.queries[qi];
-    const uint32_t r = blockIdx.x;
+    const uint32_t r = blockIdx.x - b.range_start[qi];
     if (r >= q.n_ranges) return;
     if (DF_ONLY && !q.want_df) return;
     const uint32_t ns = q.seg_end - q.seg_begin;
     const RangeSeg* segs = b.segs + q.seg_begin;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 
+    const bool count_each = DF_ONLY && q.want_df == 2u;  // every token has ONE list: a kept posting is its own (token, document) pair
+    const uint32_t n_words = (min(q.width, kRangeMaxWidth) + 31u) >> 5;
     if (threadIdx.x < 4) red[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        multi_tok = 0ull;
+        max_rank = 0u;
+        cell_cursor = 0u;
+    }
+    if (!count_each) {  // (cleared two barriers before the gather's atomics)
+#pragma unroll
+        for (int n = 0; n < kWordsPerThread; ++n) {
+            const uint32_t w = threadIdx.x + n * kThreads;
+            if (w < n_words) bitmap[w] = 0u;
+        }
+    }
     for (uint32_t t = threadIdx.x; t < kMaxTokens; t += kThreads) {
         df_lds[t] = 0;
         if (!DF_ONLY) idf[t] = t < q.n_tokens ? b.idf[(size_t)qi * kMaxTokens + t] : 0.0f;
@@ -156,13 +172,18 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
         const RangeSeg sg = segs[i];
         seg_pos[i] = sg.post_begin + b0;
         seg_off[i + 1] = b1 - b0;
-        seg_key[i] = sg.tok_rank << 1;
+        seg_key[i] = sg.tok_rank;
         seg_boost[i] = sg.boost;
         seg_avg[i] = sg.avg_len;
         base_part += b0;
+        const uint32_t rank = sg.tok_rank & 1023u;
+        if (rank) {
+            atomicOr(&multi_tok, 1ull << (sg.tok_rank >> 10));
+            atomicMax(&max_rank, rank);
+        }
     }
     base_part = wave_sum_u32(base_part);
-    if ((threadIdx.x & 63) == 0 && base_part) atomicAdd(&red[0], base_part);
+    if (lane == 0 && base_part) atomicAdd(&red[0], base_part);
     __syncthreads();
     if (threadIdx.x < 64) {  // inclusive scan of the run lengths by one wave, 64 references at a time
         uint32_t carry = 0;
@@ -181,7 +202,7 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     }
     __syncthreads();
     const uint32_t cap = seg_off[ns];
-    if (cap == 0 || (b.debug & 4u)) return;
+    if (cap == 0) return;
     const uint32_t slot_base = red[0];
     if (cap > kRangeCap) {
         // the query is rerun with smaller ranges; its slots still reach the batch's top-k, so they must be empty
@@ -193,170 +214,177 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
         if (threadIdx.x == 0) b.results[qi].overflow = 1;
         return;
     }
-
-    // gather: element e belongs to the reference whose [seg_off[i], seg_off[i+1]) holds it; runs are sorted by
-    // document, so by key
-    const float one_minus_b = 1.0f - b.b;
     const uint32_t doc0 = r * q.width;
-    for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
-        uint32_t lo = 0, hi = ns;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (seg_off[mid] <= e) lo = mid; else hi = mid;
-        }
-        const uint64_t p = seg_pos[lo] + (e - seg_off[lo]);
-        const uint32_t doc = b.post_doc[p];
-        uint32_t dropped = 0;
-        if (b.allow) {  // collect_contributions_with_filter: filtered docs never reach the scorer
-            const uint64_t id = b.docs ? b.docs[doc] : b.dense_base + doc;  // dense ids: no table lookup
-            dropped = !(id < b.allow_bits && ((b.allow[id >> 6] >> (id & 63)) & 1ull));
-        }
-        uint32_t ntf_bits = 0;
-        if (!DF_ONLY) {
-            const uint32_t val = b.post_val[p];
-            const float tf = (float)(val >> 16);
-            const float len = (float)(val & 0xffffu);
-            const float ntf = seg_boost[lo] * (tf / (one_minus_b + b.b * (len / seg_avg[lo])));
-            ntf_bits = __builtin_bit_cast(uint32_t, ntf);
-        }
-        s[e] = ((unsigned long long)(((doc - doc0) << 17) | seg_key[lo] | dropped) << 32) | ntf_bits;
-    }
-    __syncthreads();
-    // merge tree over the runs: at level l the sorted groups are 2^l consecutive references; neighbouring groups are
-    // merged pairwise (merge path): a thread produces K = ceil(cap / 256) CONSECUTIVE outputs — one binary search
-    // along its diagonal finds how many elements of each group precede its first output, then it merges sequentially
-    // (one LDS read per output).  The spans of the groups never change, only the order inside them, so a thread's
-    // first output stays in the pair of the run it started in.  The upper 32 bits of a key are unique: no ties.
-    // Outputs travel through registers: produce everything, barrier, write in place, barrier.
-    {
-        const uint32_t K = (cap + kThreads - 1) / kThreads;  // 1..kPerThread
-        const uint32_t o_begin = threadIdx.x * K;
-        const uint32_t o_end = min(cap, o_begin + K);
-        uint32_t run0 = 0;
-        if (o_begin < cap) {
-            uint32_t lo = 0, hi = ns;
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (seg_off[mid] <= o_begin) lo = mid; else hi = mid;
-            }
-            run0 = lo;
-        }
-        constexpr unsigned long long kEnd = ~0ull;  // above every key (local documents use 15 bits)
-        const bool skip_merge = (b.debug & 1u) || (DF_ONLY && q.want_df == 2u);
-        for (uint32_t lvl = 0; (1u << lvl) < ns && !skip_merge; ++lvl) {
-            unsigned long long outv[kPerThread];
-            if (o_begin < cap) {
-                uint32_t pair = run0 >> (lvl + 1);
-                uint32_t sa = seg_off[min(ns, (2u * pair) << lvl)];
-                uint32_t sm = seg_off[min(ns, (2u * pair + 1u) << lvl)];
-                uint32_t sb = seg_off[min(ns, (2u * pair + 2u) << lvl)];
-                // merge path: i elements of the left group and diag - i of the right one precede output o_begin
-                const uint32_t diag = o_begin - sa, len_a = sm - sa, len_b = sb - sm;
-                uint32_t lo = diag > len_b ? diag - len_b : 0u, hi = min(diag, len_a);
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (s[sa + mid] < s[sm + (diag - 1u - mid)]) lo = mid + 1u; else hi = mid;
-                }
-                uint32_t i = sa + lo, j = sm + (diag - lo);
-                unsigned long long ka = i < sm ? s[i] : kEnd, kb = j < sb ? s[j] : kEnd;
-                uint32_t o = o_begin;
+    if (!count_each) {
 #pragma unroll
-                for (int n = 0; n < kPerThread; ++n) {
-                    outv[n] = 0ull;
-                    if ((uint32_t)n >= K) break;  // (workgroup-uniform: a range of <= 1 024 postings skips half the unrolled steps)
-                    if (o < o_end) {
-                        while (o >= sb) {  // the outputs continue in the next pair, from its beginning
-                            ++pair;
-                            sa = sb;
-                            sm = seg_off[min(ns, (2u * pair + 1u) << lvl)];
-                            sb = seg_off[min(ns, (2u * pair + 2u) << lvl)];
-                            i = sa;
-                            j = sm;
-                            ka = i < sm ? s[i] : kEnd;
-                            kb = j < sb ? s[j] : kEnd;
+        for (int n = 0; n < kPerThread; ++n) {
+            const uint32_t e = threadIdx.x + n * kThreads;
+            if (e < cap) dmask[e] = 0ull;  // (touched documents <= postings)
+        }
+    }
+
+    // ---- 1. gather: element e belongs to the reference whose [seg_off[i], seg_off[i+1]) holds it
+    uint32_t pk[kPerThread];  // local document, run, kept
+    float pv[kPerThread];     // normalised tf (boost included)
+    {
+        unsigned long long pos[kPerThread];
+        uint32_t run[kPerThread];
+#pragma unroll
+        for (int n = 0; n < kPerThread; ++n) {
+            const uint32_t e = threadIdx.x + n * kThreads;
+            pos[n] = 0ull;
+            run[n] = 0u;
+            if (e < cap) {
+                uint32_t lo = 0, hi = ns;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (seg_off[mid] <= e) lo = mid; else hi = mid;
+                }
+                run[n] = lo;
+                pos[n] = seg_pos[lo] + (e - seg_off[lo]);
+            }
+        }
+        uint32_t doc[kPerThread], val[kPerThread];
+#pragma unroll
+        for (int n = 0; n < kPerThread; ++n) {
+            const uint32_t e = threadIdx.x + n * kThreads;
+            doc[n] = 0u;
+            val[n] = 0u;
+            if (e < cap) {
+                doc[n] = b.post_doc[pos[n]];
+                if (!DF_ONLY) val[n] = b.post_ntf ? __builtin_bit_cast(uint32_t, b.post_ntf[pos[n]]) : b.post_val[pos[n]];
+            }
+        }
+        const float one_minus_b = 1.0f - b.b;
+#pragma unroll
+        for (int n = 0; n < kPerThread; ++n) {
+            const uint32_t e = threadIdx.x + n * kThreads;
+            pk[n] = 0u;
+            pv[n] = 0.0f;
+            if (e < cap) {
+                bool kept = true;
+                if (b.allow) {  // collect_contributions_with_filter: filtered docs never reach the scorer
+                    const uint64_t id = b.docs ? b.docs[doc[n]] : b.dense_base + doc[n];  // dense ids: no table lookup
+                    kept = id < b.allow_bits && ((b.allow[id >> 6] >> (id & 63)) & 1ull);
+                }
+                if (kept) {
+                    const uint32_t dl = doc[n] - doc0;
+                    pk[n] = pk_make(dl, run[n]);
+                    if (count_each) {
+                        atomicAdd(&df_lds[seg_key[run[n]] >> 10], 1u);
+                    } else {
+                        atomicOr(&bitmap[dl >> 5], 1u << (dl & 31u));
+                        if (!DF_ONLY) {
+                            const float pre = b.post_ntf ? __builtin_bit_cast(float, val[n])
+                                                         : ntf_pre_of(val[n], one_minus_b, b.b, seg_avg[run[n]]);
+                            pv[n] = seg_boost[run[n]] * pre;
                         }
-                        if (kb < ka) {
-                            outv[n] = kb;
-                            ++j;
-                            kb = j < sb ? s[j] : kEnd;
-                        } else {
-                            outv[n] = ka;
-                            ++i;
-                            ka = i < sm ? s[i] : kEnd;
-                        }
-                        ++o;
                     }
                 }
             }
-            __syncthreads();
-#pragma unroll
-            for (int n = 0; n < kPerThread; ++n)
-                if ((uint32_t)n < K && o_begin + (uint32_t)n < o_end) s[o_begin + n] = outv[n];
-            __syncthreads();
         }
     }
-
-    if (DF_ONLY) {
-        // corpus_docs.len(): distinct (token, document) pairs among the kept postings (token_score.rs:262-275).
-        // want_df == 2: every token has ONE list, so every kept posting is its own pair — counted as gathered, unmerged.
-        for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
-            const unsigned long long key = s[e];
-            if (key_dropped(key)) continue;
-            bool first = true;
-            if (q.want_df == 2u) {
-                atomicAdd(&df_lds[key_tok(key)], 1u);
-                continue;
-            }
-            for (uint32_t j = e; j > 0; --j) {
-                const unsigned long long kj = s[j - 1];
-                if (key_doc_tok(kj) != key_doc_tok(key)) break;
-                if (!key_dropped(kj)) {
-                    first = false;
-                    break;
-                }
-            }
-            if (first) atomicAdd(&df_lds[key_tok(key)], 1u);
-        }
-        __syncthreads();
+    __syncthreads();
+    if (count_each) {
         for (uint32_t t = threadIdx.x; t < q.n_tokens; t += kThreads)
             if (df_lds[t]) atomicAdd(&b.results[qi].df[t], df_lds[t]);
         return;
     }
 
+    // ---- 2. rank of every touched document = set bits before its own: exclusive popcount prefix over the bitmap words
+    {
+        uint32_t cnt[kWordsPerThread], sum = 0;
+#pragma unroll
+        for (int n = 0; n < kWordsPerThread; ++n) {
+            const uint32_t w = threadIdx.x * kWordsPerThread + n;  // consecutive words per thread: one scan
+            cnt[n] = w < n_words ? (uint32_t)__popc(bitmap[w]) : 0u;
+            sum += cnt[n];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(incl, off, 64);
+            if ((int)lane >= off) incl += y;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t excl = incl - sum;
+        for (uint32_t w = 0; w < wave; ++w) excl += wave_tot[w];
+#pragma unroll
+        for (int n = 0; n < kWordsPerThread; ++n) {
+            const uint32_t w = threadIdx.x * kWordsPerThread + n;
+            if (w < n_words) word_rank[w] = excl;
+            excl += cnt[n];
+        }
+    }
+    __syncthreads();
+    uint32_t n_touched = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) n_touched += wave_tot[w];
+
+    // ---- 3. every kept posting: rank of its document, its token into the document's presence mask
+    uint32_t prank[kPerThread];
+#pragma unroll
+    for (int n = 0; n < kPerThread; ++n) {
+        prank[n] = 0u;
+        if (pk_kept(pk[n])) {
+            const uint32_t dl = pk_dl(pk[n]);
+            const uint32_t rank = word_rank[dl >> 5] + (uint32_t)__popc(bitmap[dl >> 5] & ((1u << (dl & 31u)) - 1u));
+            prank[n] = rank;
+            const uint32_t tok = seg_key[pk_seg(pk[n])] >> 10;
+            if (DF_ONLY) {
+                // corpus_docs.len(): distinct (token, document) pairs among the kept postings (token_score.rs:262-275)
+                const unsigned long long old = atomicOr(&dmask[rank], 1ull << tok);
+                if (!((old >> tok) & 1ull)) atomicAdd(&df_lds[tok], 1u);
+            } else {
+                atomicOr(&dmask[rank], 1ull << tok);
+            }
+        }
+    }
+    __syncthreads();
+    if (DF_ONLY) {
+        for (uint32_t t = threadIdx.x; t < q.n_tokens; t += kThreads)
+            if (df_lds[t]) atomicAdd(&b.results[qi].df[t], df_lds[t]);
+        return;
+    }
+
+    // ---- 4. cells for the documents that are not singletons: popcount(mask) cells each, handed out by an LDS cursor
+    const unsigned long long multi = multi_tok;
+    const uint32_t ranks = max_rank;  // a token has at most ranks + 1 lists
+    for (uint32_t d = threadIdx.x; d < n_touched; d += kThreads) {
+        const unsigned long long m = dmask[d];
+        uint32_t cb = kNoCell;
+        if ((m & (m - 1ull)) != 0ull || (m & multi) != 0ull) cb = atomicAdd(&cell_cursor, (uint32_t)__popcll(m));
+        cell_base[d] = (uint16_t)cb;
+    }
+    __syncthreads();  // (the bitmap and its prefix are dead from here on: region A holds the cells)
+    const uint32_t n_cells = cell_cursor;
+    if (ranks != 0u && n_cells != 0u) {  // cells that several lists add into start from 0.0 (Iterator::sum)
+        for (uint32_t c = threadIdx.x; c < n_cells; c += kThreads) cellv[c] = 0.0f;
+        __syncthreads();
+    }
+
     const float k1 = q.k + 1.0f;
     unsigned long long* out = b.keys + q.key_off + slot_base;
     uint32_t my_count = 0, my_max = 0u, my_min_inv = 0u;
-    for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
-        const unsigned long long key = s[e];
+    // the document of slot e is final: its key (0 = not in the map or NaN), its map entry in score-map mode
+    auto report = [&](uint32_t e, uint32_t dl, float score, bool in_map) {
         unsigned long long out_key = 0ull;
         uint32_t map_doc = 0xffffffffu;  // the document whose map entry this slot holds (score-map mode)
         float map_score = 0.0f;
-        if (!(b.debug & 2u) && (e == 0 || key_doc(s[e - 1]) != key_doc(key))) {
-            // first posting of a document: fold its run (lists of a token in reference order, tokens ascending)
-            const uint32_t dl = key_doc(key);
-            DocFold f;
-            unsigned long long kj = key;
-            for (uint32_t j = e;;) {
-                if (!key_dropped(kj)) f.add(key_tok(kj), __builtin_bit_cast(float, (uint32_t)kj), idf, q.k, k1);
-                if (++j >= cap) break;
-                kj = s[j];
-                if (key_doc(kj) != dl) break;
+        if (in_map) {
+            const uint32_t doc = doc0 + dl;
+            if (q.track_minmax && score == score) {  // hybrid: min / max of the full-text scores (before any OMC)
+                const uint32_t ord = f32_to_ordered(score);
+                my_max = max(my_max, ord);
+                my_min_inv = max(my_min_inv, ~ord);
             }
-            if (f.finish(idf, q.k, k1, q.use_threshold, q.threshold)) {
-                const uint32_t doc = doc0 + dl;
-                float score = f.score;
-                if (q.track_minmax && score == score) {  // hybrid: min / max of the full-text scores (before any OMC)
-                    const uint32_t ord = f32_to_ordered(score);
-                    my_max = max(my_max, ord);
-                    my_min_inv = max(my_min_inv, ~ord);
-                }
-                if (b.omc_dense) score = score * b.omc_dense[doc];
-                ++my_count;
-                map_doc = doc;
-                map_score = score;
-                if (score == score)  // a NaN score stays in the map (count) and is never selected
-                    out_key = ((unsigned long long)f32_to_ordered(score) << 32) | (unsigned long long)(~doc);
-            }
+            if (b.omc_dense) score = score * b.omc_dense[doc];
+            ++my_count;
+            map_doc = doc;
+            map_score = score;
+            if (score == score)  // a NaN score stays in the map (count) and is never selected
+                out_key = ((unsigned long long)f32_to_ordered(score) << 32) | (unsigned long long)(~doc);
         }
         out[e] = out_key;
         if (b.map_idx) {
@@ -369,16 +397,89 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
                 b.map_emit[map_doc] = ((unsigned long long)b.map_epoch << 32) | pos;
             }
         }
+    };
+
+    // ---- 5. singletons are scored by their posting's thread; the others park their normalised tf in their token's cell
+    uint32_t pcell[kPerThread];  // the document's first cell (kNoCell: reported already / dropped)
+#pragma unroll
+    for (int n = 0; n < kPerThread; ++n) {
+        const uint32_t e = threadIdx.x + n * kThreads;
+        pcell[n] = kNoCell;
+        if (e >= cap) continue;
+        if (!pk_kept(pk[n])) {
+            report(e, 0u, 0.0f, false);
+            continue;
+        }
+        const uint32_t cb = cell_base[prank[n]];
+        const uint32_t key = seg_key[pk_seg(pk[n])];
+        const uint32_t tok = key >> 10;
+        if (cb == kNoCell) {
+            DocFold f;
+            f.add(tok, pv[n], idf, q.k, k1);
+            const bool in_map = f.finish(idf, q.k, k1, q.use_threshold, q.threshold);
+            report(e, pk_dl(pk[n]), f.score, in_map);
+            continue;
+        }
+        pcell[n] = cb;
+        const unsigned long long m = dmask[prank[n]];
+        const uint32_t c = cb + (uint32_t)__popcll(m & ((1ull << tok) - 1ull));
+        if (c == cb) owner[cb] = (uint16_t)e;  // any posting of the document's first token reports it
+        if (ranks == 0u) cellv[c] = 0.0f + 1.0f * pv[n];  // the token's only list
     }
+    if (ranks != 0u && n_cells != 0u) {
+        // lists of one token add in reference order (a document is at most once in a list: no two postings of a pass share a cell)
+        for (uint32_t p = 0; p <= ranks; ++p) {
+#pragma unroll
+            for (int n = 0; n < kPerThread; ++n) {
+                if (pcell[n] == kNoCell) continue;
+                const uint32_t key = seg_key[pk_seg(pk[n])];
+                if ((key & 1023u) != p) continue;
+                const uint32_t tok = key >> 10;
+                const unsigned long long m = dmask[prank[n]];
+                const uint32_t c = pcell[n] + (uint32_t)__popcll(m & ((1ull << tok) - 1ull));
+                cellv[c] = cellv[c] + 1.0f * pv[n];
+            }
+            __syncthreads();
+        }
+    }
+    if (n_cells != 0u) {  // (workgroup-uniform)
+        __syncthreads();
+        // ---- 6. one thread per multi-posting document folds its cells, tokens ascending
+        for (uint32_t d = threadIdx.x; d < n_touched; d += kThreads) {
+            const uint32_t cb = cell_base[d];
+            if (cb == kNoCell) continue;
+            unsigned long long m = dmask[d];
+            DocFold f;
+            for (uint32_t i = 0; m != 0ull; ++i) {
+                const uint32_t tok = (uint32_t)__ffsll((long long)m) - 1u;
+                m &= m - 1ull;
+                f.add_summed(tok, cellv[cb + i], idf, q.k, k1);
+            }
+            const bool in_map = f.finish(idf, q.k, k1, q.use_threshold, q.threshold);
+            cellv[cb] = f.score;
+            if (in_map) cell_base[d] = (uint16_t)(cb | kInMap);
+        }
+        __syncthreads();
+        // ---- 7. the posting that owns the document's first cell reports it, its other postings leave their slots empty
+#pragma unroll
+        for (int n = 0; n < kPerThread; ++n) {
+            if (pcell[n] == kNoCell) continue;
+            const uint32_t e = threadIdx.x + n * kThreads;
+            const uint32_t cb = pcell[n];
+            if (owner[cb] == (uint16_t)e) report(e, pk_dl(pk[n]), cellv[cb], (cell_base[prank[n]] & kInMap) != 0u);
+            else report(e, 0u, 0.0f, false);
+        }
+    }
+
     my_count = wave_sum_u32(my_count);
-    if ((threadIdx.x & 63) == 0 && my_count) atomicAdd(&red[1], my_count);
+    if (lane == 0 && my_count) atomicAdd(&red[1], my_count);
     if (q.track_minmax) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, off, 64));
             my_min_inv = max(my_min_inv, (uint32_t)__shfl_xor((int)my_min_inv, off, 64));
         }
-        if ((threadIdx.x & 63) == 0) {
+        if (lane == 0) {
             if (my_max) atomicMax(&red[2], my_max);
             if (my_min_inv) atomicMax(&red[3], my_min_inv);
         }
@@ -397,18 +498,19 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
 // (token, reference) order with DocFold, the additions of the range kernel.  (One thread per document walking all its
 // references took 46 us for 100 documents x 12 lists of ~50 K postings: 200 dependent loads in a row, after the scan,
 // on the critical path of a hybrid query; this form takes one search's worth.)
-__global__ __launch_bounds__(kThreads) void range_score_docs_kernel(RangeBatch b, uint32_t qi, const uint32_t* __restrict__ docs,
-                                                                    uint32_t n, float* __restrict__ out_score,
-                                                                    uint32_t* __restrict__ out_present) {
-    constexpr uint32_t kWaves = kThreads / 64;
+constexpr int kDocsThreads = 256;
+__global__ __launch_bounds__(kDocsThreads) void range_score_docs_kernel(RangeBatch b, uint32_t qi, const uint32_t* __restrict__ docs,
+                                                                        uint32_t n, float* __restrict__ out_score,
+                                                                        uint32_t* __restrict__ out_present) {
+    constexpr uint32_t kDocWaves = kDocsThreads / 64;
     __shared__ float idf[kMaxTokens];
-    __shared__ float found_ntf[kWaves][kRangeMaxRefs];
-    __shared__ unsigned long long found_mask[kWaves][kRangeMaxRefs / 64];
+    __shared__ float found_ntf[kDocWaves][kRangeMaxRefs];
+    __shared__ unsigned long long found_mask[kDocWaves][kRangeMaxRefs / 64];
     const RangeQuery q = b.queries[qi];
-    for (uint32_t t = threadIdx.x; t < kMaxTokens; t += kThreads) idf[t] = t < q.n_tokens ? b.idf[(size_t)qi * kMaxTokens + t] : 0.0f;
+    for (uint32_t t = threadIdx.x; t < kMaxTokens; t += kDocsThreads) idf[t] = t < q.n_tokens ? b.idf[(size_t)qi * kMaxTokens + t] : 0.0f;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const uint32_t j = blockIdx.x * kWaves + w;
+    const uint32_t j = blockIdx.x * kDocWaves + w;
     if (j >= n) return;  // (wave-uniform; no block-wide barrier below)
     const uint32_t doc = docs[j];
     bool allowed = true;
@@ -434,10 +536,9 @@ __global__ __launch_bounds__(kThreads) void range_score_docs_kernel(RangeBatch b
                 if (pd[mid] < doc) lo = mid + 1; else hi = mid;
             }
             if (lo < end && pd[lo] == doc) {
-                const uint32_t val = b.post_val[sg.post_begin + lo];
-                const float tf = (float)(val >> 16);
-                const float len = (float)(val & 0xffffu);
-                ntf = sg.boost * (tf / (one_minus_b + b.b * (len / sg.avg_len)));
+                const float pre = b.post_ntf ? b.post_ntf[sg.post_begin + lo]
+                                             : ntf_pre_of(b.post_val[sg.post_begin + lo], one_minus_b, b.b, sg.avg_len);
+                ntf = sg.boost * pre;
                 hit = true;
             }
         }
@@ -457,6 +558,22 @@ __global__ __launch_bounds__(kThreads) void range_score_docs_kernel(RangeBatch b
     }
 }
 
+// post_ntf of every posting: one thread per posting finds its list (upper-bound search in the offsets: the list table of
+// a 2^20-term vocabulary stays in L2) and divides exactly as the scoring kernels would.
+__global__ __launch_bounds__(256) void ntf_precompute_kernel(const uint32_t* __restrict__ post_val, float* __restrict__ post_ntf,
+                                                             const uint64_t* __restrict__ list_off, const float* __restrict__ list_avg,
+                                                             uint32_t n_lists, uint64_t n_postings, float b) {
+    const float one_minus_b = 1.0f - b;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_postings; i += (uint64_t)gridDim.x * 256) {
+        uint32_t lo = 0, hi = n_lists;  // the last list with list_off[l] <= i is the one that holds posting i (empty lists share an offset)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (list_off[mid] <= i) lo = mid; else hi = mid;
+        }
+        post_ntf[i] = ntf_pre_of(post_val[i], one_minus_b, b, list_avg[lo]);
+    }
+}
+
 }  // namespace
 
 int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream) {
@@ -464,22 +581,26 @@ int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream)
         if (b.n_queries) ORAMA_HIP_TRY(hipMemsetAsync(b.results, 0, (size_t)b.n_queries * sizeof(RangeResult), stream));
         return ORAMA_OK;
     }
-    ORAMA_REQUIRE(b.n_queries <= 65535, "bm25 ranges: batch too large");
+    ORAMA_REQUIRE(b.n_queries <= kRangeBatchMax, "bm25 ranges: batch too large");
     ProfScope prof(&ctx->prof, "bm25_range_bounds", stream);
-    const uint64_t blocks = (b.max_bound_entries + kThreads - 1) / kThreads;
+    const uint64_t blocks = (b.max_bound_entries + kBoundsThreads - 1) / kBoundsThreads;
     ORAMA_SUPPORT(blocks < 0x7fffffffull, "bm25 ranges: batch references too many postings");
-    hipLaunchKernelGGL(range_bounds_kernel, dim3((uint32_t)blocks, b.n_queries), dim3(kThreads), 0, stream, b);
+    hipLaunchKernelGGL(range_bounds_kernel, dim3((uint32_t)blocks, b.n_queries), dim3(kBoundsThreads), 0, stream, b);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }
 
 int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStream_t stream) {
     if (b.total_postings == 0 || b.n_queries == 0 || b.max_ranges == 0) return ORAMA_OK;
-    ORAMA_REQUIRE(b.n_queries <= 65535, "bm25 ranges: batch too large");
+    ORAMA_REQUIRE(b.n_queries <= kRangeBatchMax, "bm25 ranges: batch too large");
+#if ORAMA_COMPARISON_KERNELS
+    if (ctx->k3r_merge) return launch_range_score_merge(ctx, b, df_only, stream);
+#endif
     ProfScope prof(&ctx->prof, df_only ? "bm25_range_df" : "bm25_range_score", stream);
-    const dim3 grid(b.max_ranges, b.n_queries);
-    if (df_only) hipLaunchKernelGGL(range_score_kernel<true>, grid, dim3(kThreads), 0, stream, b);
-    else hipLaunchKernelGGL(range_score_kernel<false>, grid, dim3(kThreads), 0, stream, b);
+    const uint32_t grid = b.range_start[b.n_queries];
+    ORAMA_REQUIRE(grid >= b.max_ranges, "internal: range_start table not filled");
+    if (df_only) hipLaunchKernelGGL(range_score_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, b);
+    else hipLaunchKernelGGL(range_score_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, b);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }
@@ -488,8 +609,18 @@ int launch_range_score_docs(orama_ctx* ctx, const RangeBatch& b, uint32_t qi, co
                             uint32_t* d_out_present, hipStream_t stream) {
     (void)ctx;
     if (n == 0) return ORAMA_OK;
-    hipLaunchKernelGGL(range_score_docs_kernel, dim3((n + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, stream, b, qi, d_doc, n,
-                       d_out_score, d_out_present);
+    hipLaunchKernelGGL(range_score_docs_kernel, dim3((n + kDocsThreads / 64 - 1) / (kDocsThreads / 64)), dim3(kDocsThreads), 0, stream, b, qi,
+                       d_doc, n, d_out_score, d_out_present);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_ntf_precompute(const uint32_t* post_val, float* post_ntf, const uint64_t* d_list_off, const float* d_list_avg,
+                          uint32_t n_lists, uint64_t n_postings, float b, hipStream_t stream) {
+    if (n_postings == 0 || n_lists == 0) return ORAMA_OK;
+    const uint64_t blocks = std::min<uint64_t>((n_postings + 255) / 256, 256ull * 64);
+    hipLaunchKernelGGL(ntf_precompute_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, post_val, post_ntf, d_list_off, d_list_avg,
+                       n_lists, n_postings, b);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

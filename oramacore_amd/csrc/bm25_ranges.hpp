@@ -7,9 +7,10 @@
 
 namespace orama {
 
-constexpr uint32_t kRangeCap = 2048;     // postings one workgroup merges in LDS
-constexpr uint32_t kRangeMaxWidth = 32768;  // documents per range (the local document takes 15 bits of the merge key)
+constexpr uint32_t kRangeCap = 2048;     // postings one workgroup scores in LDS
+constexpr uint32_t kRangeMaxWidth = 32768;  // documents per range (one bit each in the workgroup's LDS bitmap)
 constexpr uint32_t kRangeMaxRefs = 256;  // non-empty posting lists per query (per-reference tables live in LDS)
+constexpr uint32_t kRangeBatchMax = 32;  // queries scored by one set of launches
 
 // One (token, posting list) reference of one query of the batch.
 struct RangeSeg {
@@ -55,10 +56,16 @@ struct RangeBatch {
     const RangeQuery* queries = nullptr;
     uint32_t n_segs = 0, n_queries = 0;
     uint64_t total_postings = 0;         // referenced by the whole batch
-    uint32_t max_ranges = 0;             // grid.x of the scoring launch
+    uint32_t max_ranges = 0;             // most ranges of a query of the batch
+    // the scoring launch is a 1-D grid over the (query, range) pairs that exist: workgroup w scores range
+    // w - range_start[q] of the query q with range_start[q] <= w < range_start[q + 1]
+    uint32_t range_start[kRangeBatchMax + 1] = {0};
     uint64_t max_bound_entries = 0;      // largest references x (ranges + 1) of a query: grid.x of the bounds launch
     const uint32_t* post_doc = nullptr;
     const uint32_t* post_val = nullptr;
+    // tf / ((1 - b) + b * len / avg_len) per posting, stored by the store for ITS b and average lengths (nullptr when the
+    // query's b differs: the kernels then divide themselves — same operations, same bits)
+    const float* post_ntf = nullptr;
     uint32_t* bounds = nullptr;
     const uint64_t* docs = nullptr;      // local idx -> DocumentId (filter); nullptr when the ids are dense_base + idx
     uint64_t dense_base = 0;
@@ -76,13 +83,21 @@ struct RangeBatch {
     float* map_score = nullptr;
     unsigned long long* map_emit = nullptr;
     uint32_t map_epoch = 0;
-    uint32_t debug = 0;  // timing ablations (ORAMA_K3R_DBG): 1 skip the merge, 2 skip the fold, 4 stop after the bounds loads
+    uint32_t debug = 0;  // comparison build only (ORAMA_K3R_DBG): 1 skip the merge, 2 skip the fold, 4 stop after the bounds loads
 };
 
 // bounds[query][r][reference] = postings of the reference whose document lies in a range < r.  Also zeroes `results`.
 int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream);
 // df_only: count distinct (token, document) pairs into results[q].df for the queries that want it.
 int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStream_t stream);
+#if ORAMA_COMPARISON_KERNELS
+// The round-2/3 scoring launch (bm25_ranges_merge.hip: 64-bit keys merged by a merge tree in LDS), kept for A/B runs only.
+int launch_range_score_merge(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStream_t stream);
+#endif
+// post_ntf[i] = tf_i / ((1 - b) + b * len_i / avg_len[list of i]) for every posting of the store (list_off: n_lists + 1
+// offsets, list_avg: the average length of each list's field; both on the device).
+int launch_ntf_precompute(const uint32_t* post_val, float* post_ntf, const uint64_t* d_list_off, const float* d_list_avg,
+                          uint32_t n_lists, uint64_t n_postings, float b, hipStream_t stream);
 // Hybrid: the full-text score of `n` given documents (local indices) of query `qi`, by the same fold as the range kernel
 // (lists of a token in reference order, tokens ascending): out_score[j] / out_present[j] (in the score map or not).
 int launch_range_score_docs(orama_ctx* ctx, const RangeBatch& b, uint32_t qi, const uint32_t* d_doc, uint32_t n, float* d_out_score,

@@ -235,6 +235,7 @@ struct orama_ctx {
     // 0 = always the per-document-record scorer K3 (ORAMA_BM25_RANGES, orama_ctx_set_bm25_ranges)
     int bm25_ranges = 1;
     int bm25_ranges_hybrid = 1;  // orama_post_search_hybrid on the range scorer where it applies (ORAMA_BM25_RANGES_HYBRID=0: K3)
+    int k3r_merge = 0;  // comparison builds only (ORAMA_COMPARISON_KERNELS=1): ORAMA_K3R_MERGE=1 scores ranges with the round-3 merge tree
     // stores created as ORAMA_DTYPE_F32_SHADOW16 answer orama_vec_search in two stages (fp16 candidates, fp32 decision);
     // 0 = always the plain fp32 scan, 2 = two stages also where the plain scan is expected to be faster (small stores
     // with few queries) (ORAMA_TWO_STAGE, orama_ctx_set_two_stage)

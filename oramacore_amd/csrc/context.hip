@@ -364,8 +364,14 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
     if (const char* e = std::getenv("ORAMA_FUSED_TOPK")) c->fused_topk = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F32_MULTI")) c->f32_multi = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_WIDE")) c->f16_wide = std::atoi(e);
+#if !ORAMA_COMPARISON_KERNELS
+    if (c->f16_wide == 1 || c->f16_wide == 5) c->f16_wide = 4;  // K2c / K2h are not in this build
+#endif
     if (const char* e = std::getenv("ORAMA_BM25_RANGES")) c->bm25_ranges = std::atoi(e) != 0;
     if (const char* e = std::getenv("ORAMA_BM25_RANGES_HYBRID")) c->bm25_ranges_hybrid = std::atoi(e) != 0;
+#if ORAMA_COMPARISON_KERNELS
+    if (const char* e = std::getenv("ORAMA_K3R_MERGE")) c->k3r_merge = std::atoi(e) != 0;
+#endif
     if (const char* e = std::getenv("ORAMA_TWO_STAGE")) c->two_stage = std::max(0, std::min(2, std::atoi(e)));
     if (const char* e = std::getenv("ORAMA_F16_SOLO")) c->f16_solo = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_F16_KC")) c->f16_kc = std::atoi(e);
@@ -499,6 +505,9 @@ int orama_ctx_set_bm25_ranges(orama_ctx* ctx, int on) {
 int orama_ctx_set_f16_wide(orama_ctx* ctx, int mode) {
     ORAMA_REQUIRE(ctx, "null ctx");
     ORAMA_REQUIRE(mode >= 0 && mode <= 5, "f16 wide mode %d outside [0, 5]", mode);
+#if !ORAMA_COMPARISON_KERNELS
+    ORAMA_SUPPORT(mode != 1 && mode != 5, "f16 wide mode %d (K2c / K2h) exists in comparison builds only (ORAMA_COMPARISON_KERNELS=1)", mode);
+#endif
     ctx->f16_wide = mode;
     return ORAMA_OK;
 }

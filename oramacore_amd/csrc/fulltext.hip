@@ -188,11 +188,40 @@ struct orama_post {
     std::vector<uint32_t> field_of_list;
     std::vector<uint64_t> list_off;
     DevBuf d_docs, d_post_doc, d_post_val, d_omc;
+    // tf / ((1 - b) + b * len / avg_len) of every posting for b = ntf_b and the CURRENT average lengths: the query-independent
+    // part of the normalised tf, divided once per posting at build / append / set_avg_len instead of once per posting and
+    // query (same f32 operations in the same order as the kernels' own division: same bits).  A search with another b
+    // divides in the kernel.  +4 B per posting.
+    DevBuf d_post_ntf;
+    float ntf_b = 0.75f;  // Bm25Params::default().b
+    bool ntf_valid = false;
     bool has_omc = false;
     uint64_t generation = 0;  // bumped by every rebuild of the doc table: facet fields resolved against an older one are stale
 };
 
 namespace {
+
+// (Re)compute p->d_post_ntf for the store's current postings and average lengths.  Caller holds p->mu exclusively.
+int refresh_post_ntf(orama_post* p) {
+    p->ntf_valid = false;
+    if (p->n_postings == 0 || p->n_lists == 0) return ORAMA_OK;
+    const size_t need = (size_t)p->n_postings * 4;
+    if (need > p->d_post_ntf.cap) ORAMA_TRY(p->d_post_ntf.reserve(need + need / 4));  // (appends grow the arrays with the same slack)
+    // list table on the device for the duration of the pass: [offsets u64 x (n_lists + 1) | field average f32 x n_lists]
+    const size_t off_bytes = ((size_t)p->n_lists + 1) * 8;
+    DevBuf table;
+    ORAMA_TRY(table.reserve(off_bytes + (size_t)p->n_lists * 4));
+    std::vector<float> list_avg(p->n_lists);
+    for (uint32_t l = 0; l < p->n_lists; ++l) list_avg[l] = p->avg_len[p->field_of_list[l]];
+    ORAMA_HIP_TRY(hipMemcpy(table.p, p->list_off.data(), off_bytes, hipMemcpyHostToDevice));
+    ORAMA_HIP_TRY(hipMemcpy(table.as<char>() + off_bytes, list_avg.data(), (size_t)p->n_lists * 4, hipMemcpyHostToDevice));
+    ORAMA_TRY(launch_ntf_precompute(p->d_post_val.as<uint32_t>(), p->d_post_ntf.as<float>(), table.as<uint64_t>(),
+                                    reinterpret_cast<const float*>(table.as<char>() + off_bytes), p->n_lists, p->n_postings, p->ntf_b,
+                                    nullptr));
+    ORAMA_HIP_TRY(hipDeviceSynchronize());
+    p->ntf_valid = true;
+    return ORAMA_OK;
+}
 
 // State of one resident-postings query between its two stages.
 struct PostQuery {
@@ -438,7 +467,6 @@ struct RangeJob {
     uint32_t* map_list_len = nullptr;
 };
 
-constexpr uint32_t kRangeBatchMax = 32;             // queries scored by one set of launches
 constexpr uint64_t kRangeKeyBudget = 1ull << 28;    // key slots (8 B each) one set of launches may use
 
 // The plain top-k search of the resident store can take the K3r path when its references fit the sort key.
@@ -770,9 +798,16 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         rb.n_queries = nq;
         rb.total_postings = virt;
         rb.max_ranges = max_ranges;
+        uint64_t pairs = 0;  // (query, range) pairs = workgroups of the scoring launch
+        for (uint32_t ci = 0; ci < nq; ++ci) {
+            pairs += queries[ci].n_ranges;
+            ORAMA_SUPPORT(pairs < 0x7fffffffull, "query batch needs too many document ranges");
+            rb.range_start[ci + 1] = (uint32_t)pairs;
+        }
         rb.max_bound_entries = max_bound_entries;
         rb.post_doc = p->d_post_doc.as<uint32_t>();
         rb.post_val = p->d_post_val.as<uint32_t>();
+        rb.post_ntf = (p->ntf_valid && b == p->ntf_b) ? p->d_post_ntf.as<float>() : nullptr;
         rb.bounds = sc->misc1.as<uint32_t>();
         rb.docs = p->dense ? nullptr : p->d_docs.as<uint64_t>();
         rb.dense_base = p->dense_base;
@@ -1055,7 +1090,7 @@ int orama_post_build(orama_post* p, const uint64_t* docs, uint64_t n_docs, uint3
     p->has_omc = false;
     p->d_omc.release();
     ++p->generation;
-    return ORAMA_OK;
+    return refresh_post_ntf(p);
 }
 
 // Live update between commits: new documents + delta posting lists appended in place.
@@ -1157,7 +1192,9 @@ int orama_post_append(orama_post* p, const uint64_t* docs, uint64_t n_new, const
         p->h_docs.swap(all_docs);
     }
     p->avg_len.assign(avg_field_len, avg_field_len + p->n_fields);
-    return ORAMA_OK;
+    // the averages moved with the new documents: every stored quotient is stale (one streaming pass over the postings,
+    // beside the device-to-device copies this call already makes when the arrays grow)
+    return refresh_post_ntf(p);
 }
 
 int orama_post_fill_synthetic(orama_post* p, uint64_t n_docs, uint64_t first_doc_id, uint32_t n_lists,
@@ -1221,7 +1258,7 @@ int orama_post_fill_synthetic(orama_post* p, uint64_t n_docs, uint64_t first_doc
     p->d_omc.release();
     ++p->generation;
     if (out_total_postings) *out_total_postings = total;
-    return ORAMA_OK;
+    return refresh_post_ntf(p);
 }
 
 int orama_post_get_list(orama_post* p, uint32_t list, uint64_t capacity, uint64_t* out_doc, uint32_t* out_tf,
@@ -1826,8 +1863,9 @@ int orama_post_set_avg_len(orama_post* p, const float* avg_field_len, uint32_t n
     ORAMA_REQUIRE(p && avg_field_len, "null argument");
     std::unique_lock<std::shared_mutex> lk(p->mu);
     ORAMA_REQUIRE(n_fields == p->n_fields, "expected %u field averages, got %u", p->n_fields, n_fields);
+    ORAMA_ON_DEVICE(p->ctx->device);
     p->avg_len.assign(avg_field_len, avg_field_len + n_fields);
-    return ORAMA_OK;
+    return refresh_post_ntf(p);
 }
 
 // search_hybrid (token_score.rs:357-387) as ONE call: the vector leg (K1/K2 + K4 on its own HIP stream) and

@@ -29,6 +29,8 @@
 // kpad must be a multiple of 256 (whole sub-stages per half) and <= 768; other rows take K2q / K2d.
 #include "vec_f16.hpp"
 
+#if ORAMA_COMPARISON_KERNELS  // K2h is a comparison kernel (6 % slower than K2q): not part of the product library (see _build.py)
+
 #include <cstdlib>
 #include <type_traits>
 
@@ -522,3 +524,5 @@ int launch_vec_scan_f16_kh(orama_ctx* ctx, const F16ScanArgs& a_in, void* d_quer
 }
 
 }  // namespace orama
+
+#endif  // ORAMA_COMPARISON_KERNELS

@@ -23,6 +23,8 @@
 // distances to solo queries.
 #include "vec_f16.hpp"
 
+#if ORAMA_COMPARISON_KERNELS  // K2c is a superseded comparison kernel: not part of the product library (see _build.py)
+
 #include <cstdlib>
 
 #include "device_utils.hpp"
@@ -74,40 +76,6 @@ __device__ __forceinline__ void dma16_nt(uint64_t saddr_uniform, uint32_t voff, 
                  :
                  : "v"(voff), "s"(saddr_uniform), "{m0}"(lds_addr_uniform)
                  : "memory");
-}
-
-// queries (f32) -> fp16 B fragments [query tile 0..7][k-step][lane][8 halves] + 1/|q| of the rounded query
-__global__ __launch_bounds__(256) void f16_prepare_queries_kernel(const float* __restrict__ queries, uint32_t q,
-                                                                  uint32_t dim, uint32_t ksteps, bool l2,
-                                                                  char* __restrict__ bfrag, float* __restrict__ qinv) {
-    const uint32_t frag_total = 8u * ksteps * 64u;
-    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < frag_total; idx += gridDim.x * blockDim.x) {
-        const uint32_t qt = idx / (ksteps * 64u);
-        const uint32_t rem = idx - qt * (ksteps * 64u);
-        const uint32_t ks = rem >> 6, l = rem & 63;
-        const uint32_t j = qt * 32 + (l & 31);
-        const uint32_t k0 = ks * 16 + (l >> 5) * 8;
-        h8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const uint32_t k = k0 + e;
-            const float x = (j < q && k < dim) ? queries[(size_t)j * dim + k] : 0.0f;
-            v[e] = (_Float16)x;
-        }
-        *reinterpret_cast<h8*>(bfrag + (size_t)idx * 16) = v;
-    }
-    // |q| of the fp16-rounded query, f32 accumulation in k order (the order K2 uses)
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < 256) {
-        float ss = 0.0f;
-        if (j < q) {
-            for (uint32_t k = 0; k < ksteps * 16; ++k) {
-                const float x = k < dim ? (float)(_Float16)queries[(size_t)j * dim + k] : 0.0f;
-                ss = fmaf(x, x, ss);
-            }
-        }
-        qinv[j] = l2 ? ss : (ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f);
-    }
 }
 
 // DBG (ablation builds, ORAMA_K2C_DBG, results are garbage — timing only): bit 0 no MFMAs, bit 1 no DMA at all,
@@ -361,20 +329,6 @@ __global__ __launch_bounds__(kWB) void vec_scan_f16_wide_kernel(F16ScanArgs a, c
 
 }  // namespace
 
-int launch_f16_prepare_queries(const float* d_queries, uint32_t q, uint32_t dim, int metric, void* d_query_frags,
-                               hipStream_t stream) {
-    ORAMA_REQUIRE(d_queries && d_query_frags && q >= 1 && q <= kF16WideMaxQ, "f16_prepare_queries: bad arguments");
-    const uint32_t ksteps = f16_kpad(dim) / 16;
-    char* bfrag = reinterpret_cast<char*>(d_query_frags);
-    float* qinv = reinterpret_cast<float*>(bfrag + (size_t)8 * ksteps * 1024);
-    hipLaunchKernelGGL(f16_prepare_queries_kernel, dim3(64), dim3(256), 0, stream, d_queries, q, dim, ksteps,
-                       metric == ORAMA_METRIC_L2SQ, bfrag, qinv);
-    ORAMA_HIP_TRY(hipGetLastError());
-    return ORAMA_OK;
-}
-
-size_t f16_wide_query_bytes(uint32_t dim) { return (size_t)8 * (f16_kpad(dim) / 16) * 1024 + 256 * sizeof(float); }
-
 int launch_vec_scan_f16_wide(orama_ctx* ctx, const F16ScanArgs& a, void* d_query_frags, bool prepare,
                              hipStream_t stream) {
     ORAMA_REQUIRE(a.tiled && a.inv_norm && a.queries && d_query_frags, "vec_scan_f16_wide: bad arguments");
@@ -435,3 +389,5 @@ int launch_vec_scan_f16_wide(orama_ctx* ctx, const F16ScanArgs& a, void* d_query
 }
 
 }  // namespace orama
+
+#endif  // ORAMA_COMPARISON_KERNELS

@@ -557,11 +557,14 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
             // <= 768 dimensions) and K2d for everything else; 5 = K2h first (two query tiles per wave, the K loop split over a
             // wave pair — same energy per pass as K2q and K2d, a little slower: kept as the experiment it is,
             // profiles/r03_power_energy.md)
+            // (modes 1 and 5 exist in comparison builds only — ORAMA_COMPARISON_KERNELS=1; orama_ctx_set_f16_wide refuses them otherwise)
             const int fw = v->ctx->f16_wide;
+#if ORAMA_COMPARISON_KERNELS
             if (fw == 5 && vec_scan_f16_kh_supports(args.dim, args.q)) return launch_vec_scan_f16_kh(v->ctx, args, sc->f16_bfrag.p, s);
+            if (fw == 1) return launch_vec_scan_f16_wide(v->ctx, args, sc->f16_bfrag.p, false, s);
+#endif
             if (fw >= 4 && vec_scan_f16_qs_supports(args.dim, args.q)) return launch_vec_scan_f16_qs(v->ctx, args, sc->f16_bfrag.p, s);
-            if (fw >= 2) return launch_vec_scan_f16_pc(v->ctx, args, sc->f16_bfrag.p, s, fw >= 4 ? 1 : fw - 1);
-            return launch_vec_scan_f16_wide(v->ctx, args, sc->f16_bfrag.p, false, s);
+            return launch_vec_scan_f16_pc(v->ctx, args, sc->f16_bfrag.p, s, fw == 3 ? 2 : 1);
         };
         const uint64_t s1 = std::min<uint64_t>(n, kS1);
         // super-chunk size: gq * (rows + k) * 8 B <= budget
