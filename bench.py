@@ -81,6 +81,14 @@ def parse_args():
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure roofline.traffic live (two short rocprofv3 --pmc passes of `--pmc-child`)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dump-result", default="",
+                    help="every rank writes the last step's queries and answer (ids, distances, counts) to "
+                         "<path>.rank<r>.npz after the timed region (multi-rank parity tests compare the ranks)")
+    ap.add_argument("--f16-slots", type=int, default=1,
+                    help="fp16 workloads: steps in flight (each slot is one stream carrying its scans AND selections; the scans of two "
+                         "slots cannot overlap — every scan kernel fills all CUs — but the launch-bound selections of one slot run beside "
+                         "the other slot's work; measured in profiles/, default 1)")
+    ap.add_argument("--no-preflight", action="store_true", help="self-launched N > 1: skip the pre-launch check of devices and RCCL")
     return ap.parse_args()
 
 
@@ -205,7 +213,7 @@ def check_vector_result(store, ids_all, dst_all, cnt, queries_last, k, qb, lo, h
 
 
 def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=False, rank=0, world=1, lo=0, hi=None,
-               store=None, valid=True, desc=None):
+               store=None, valid=True, desc=None, dump="", f16_slots=1):
     """One vector workload through the pipelined shard session: returns (bench-line dict, store, host queries)."""
     _, dim, k, qb, dtype, wdesc = WORKLOADS[name]
     desc = desc or wdesc
@@ -229,7 +237,7 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
     # fp16 workloads: the scan and its threshold-filter selections depend on each other step by step and all run on the
     # tail stream, so a second slot would only make two corpus scans share the HBM bandwidth (and inflate the per-launch
     # durations the roofline is computed from) — one slot.
-    n_streams = 1 if f16 else max(1, streams)
+    n_streams = max(1, f16_slots) if f16 else max(1, streams)
     sess = group.session([store], queries_h, qb, k, n_slots=n_streams, force_exchange=force_exchange)
 
     def barrier():
@@ -251,6 +259,9 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
 
     ids_all, dst_all, cnt = sess.result((total_b - 1) % n_streams)
     check_vector_result(store, ids_all, dst_all, cnt, queries_h[(total_b - 1) * qb:total_b * qb], k, qb, lo, hi, f16)
+    if dump:
+        np.savez(f"{dump}.rank{rank}.npz", ids=ids_all, dist=dst_all, cnt=cnt, queries=queries_h[(total_b - 1) * qb:total_b * qb],
+                 lo=lo, hi=hi, world=world)
 
     kern = "vec_scan_f16" if f16 else "vec_scan_f32"
     scan_ms, scan_n = ctx.prof_get(kern)
@@ -555,12 +566,19 @@ def main():
     if args.pmc_child:
         return pmc_child(args)
     import oramacore_amd as oa
-    from oramacore_amd.launch import RankEnv, ShardPlan, device_for, exchange_unique_id, self_launch
+    from oramacore_amd.launch import RankEnv, ShardPlan, device_for, exchange_unique_id, preflight, self_launch
     from oramacore_amd.shard_group import FORCE_RCCL, ShardGroup
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher — N ranks of this script, one per GPU (the same process
-        # model as under torch.distributed.run; rank 0 prints the JSON line)
+        # model as under torch.distributed.run; rank 0 prints the JSON line).  Checked first, in a throw-away child: enough
+        # devices (or a loopback transport), RCCL resolvable — a launch that cannot work says why in ONE JSON line instead
+        # of N tracebacks.
+        if not args.no_preflight:
+            pf = preflight(args.gpus)
+            if not pf["ok"]:
+                print(json.dumps({"error": "preflight: " + pf["error"], "n_gpus": args.gpus, "preflight": pf}), flush=True)
+                raise SystemExit(2)
         raise SystemExit(self_launch(args.gpus, [str(Path(__file__).resolve()), *sys.argv[1:]]))
     env = RankEnv.from_env()
     world, rank, local_rank = env.world, env.rank, env.local_rank
@@ -571,10 +589,22 @@ def main():
     # GPU, rank 0 makes the communicator id and hands it to the others over a localhost socket.  No torch here.
     if world > 1:
         uid = exchange_unique_id(env, ShardGroup.unique_id)
-        group = ShardGroup.from_rank(uid, rank, world, device_for(local_rank))
+        device = device_for(local_rank)
+        group = ShardGroup.from_rank(uid, rank, world, device)
     else:
+        device = local_rank
         group = ShardGroup([local_rank], flags=FORCE_RCCL if args.force_exchange else 0)
     ctx = group.ctx(0)
+    # who is in the job, as the communicator itself reports it: one all-reduce(max) per rank slot carries that rank's device
+    # ordinal and pid to everybody (a rank that is missing, or two ranks that believe they are the same one, show up here
+    # — and in `n_gpus` — instead of as a plausible-looking number)
+    ranks_seen = []
+    for r in range(world):
+        dev = group.allreduce_max(float(device + 1) if r == rank else 0.0)
+        pid = group.allreduce_max(float(os.getpid()) if r == rank else 0.0)
+        ranks_seen.append({"rank": r, "device": int(dev) - 1, "pid": int(pid)})
+    if group.world != world or any(e["device"] < 0 for e in ranks_seen):
+        raise SystemExit(f"bench.py: communicator reports world {group.world}, ranks {ranks_seen} — expected {world} ranks")
 
     n_total, dim, k, qb, dtype, desc = WORKLOADS[args.workload]
     if args.rows:
@@ -583,7 +613,11 @@ def main():
     f16 = dtype == "f16"
     out, store, queries_h = vector_leg(oa, group, args.workload, n_total, args.steps, args.warmup, args.streams,
                                        force_exchange=args.force_exchange, rank=rank, world=world, lo=lo, hi=hi,
-                                       valid=not bool(args.rows))
+                                       valid=not bool(args.rows), dump=args.dump_result, f16_slots=args.f16_slots)
+    out["config"]["ranks_seen"] = ranks_seen
+    out["config"]["comm_world"] = group.world
+    out["config"]["exchange"] = ("rccl" + (" (ORAMA_RCCL_LIB loopback: " + os.path.basename(os.environ["ORAMA_RCCL_LIB"]) + ")"
+                                           if os.environ.get("ORAMA_RCCL_LIB") else "")) if group.uses_rccl else "none (one shard)"
     if f16 and qb > 64:
         out["roofline"]["note"] = ("K2d (producer/consumer GEMM tiles, 256 queries per pass): the corpus crosses HBM once "
                                    "per batch (DESIGN.md K2d)")

@@ -22,6 +22,10 @@ CSRC = ROOT / "oramacore_amd" / "csrc"
 INCLUDE = ROOT / "include"
 LIB = CSRC / "liborama_hip.so"
 OBJ_DIR = CSRC / "build"
+# the comparison flavour (ORAMA_COMPARISON_KERNELS=1 in the environment) is a SEPARATE library with its own object directory:
+# building or loading it never touches the product library
+LIB_CMP = CSRC / "liborama_hip_cmp.so"
+OBJ_DIR_CMP = CSRC / "build_cmp"
 
 ARCH = "gfx950"
 COMMON_FLAGS = [
@@ -48,6 +52,14 @@ COMPARISON_UNITS = {"vec_f16_wide.hip", "vec_f16_kh.hip", "bm25_ranges_merge.hip
 
 def comparison_build() -> bool:
     return os.environ.get("ORAMA_COMPARISON_KERNELS", "0") == "1"
+
+
+def lib_path() -> Path:
+    return LIB_CMP if comparison_build() else LIB
+
+
+def obj_dir() -> Path:
+    return OBJ_DIR_CMP if comparison_build() else OBJ_DIR
 
 
 def _flags() -> list[str]:
@@ -111,15 +123,16 @@ def parse_resource_remarks(stderr: str) -> tuple[list[dict], str]:
 
 def kernel_resources() -> dict[str, list[dict]]:
     """{translation unit: [kernel record, ...]} of the library as last built (csrc/build/*.resources.json)."""
-    return {p.name[: -len(".resources.json")]: json.loads(p.read_text()) for p in sorted(OBJ_DIR.glob("*.resources.json"))}
+    return {p.name[: -len(".resources.json")]: json.loads(p.read_text()) for p in sorted(obj_dir().glob("*.resources.json"))}
 
 
 def native_is_fresh() -> bool:
-    stamp = OBJ_DIR / "fingerprint"
-    return LIB.exists() and stamp.exists() and stamp.read_text() == _fingerprint()
+    stamp = obj_dir() / "fingerprint"
+    return lib_path().exists() and stamp.exists() and stamp.read_text() == _fingerprint()
 
 
 def build_native(force: bool = False, verbose: bool = True) -> Path:
+    LIB, OBJ_DIR = lib_path(), obj_dir()  # (of the flavour the environment names)
     if not force and native_is_fresh():
         return LIB
     hipcc = _hipcc()

@@ -99,7 +99,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
+    path = _build.lib_path()  # liborama_hip.so; liborama_hip_cmp.so when ORAMA_COMPARISON_KERNELS=1 asks for the A/B flavour
     if build_if_missing and not _build.native_is_fresh():
         try:
             _build.build_native()

@@ -122,11 +122,15 @@ struct orama_batcher {
                 st = pass_search(queries.data(), q, kmax, ids.data(), dist.data(), cnt.data());
                 if (st != ORAMA_OK) err = orama_last_error();  // this thread's error slot
             }
-            // a failed pass is repeated one request at a time, so that only the request that cannot be served sees an
-            // error (one query outside the envelope must not fail the callers coalesced with it)
+            // a pass that failed for a reason ONE request can be responsible for (a bad argument, a shape outside the
+            // envelope) is repeated one request at a time, so that only the request that cannot be served sees the error.
+            // A systemic failure — the scratch pool saturated (BUSY after the acquire timeout), the device, memory — would
+            // fail every retry the same way, each waiting out the timeout again while the pass lock is held: it goes to
+            // every caller of the batch at once.
             std::vector<int> sts(q, st);
             std::vector<std::string> errs(q, err);
-            if (st != ORAMA_OK && q > 1) {
+            const bool query_specific = st == ORAMA_ERR_INVALID || st == ORAMA_ERR_UNSUPPORTED;
+            if (st != ORAMA_OK && q > 1 && query_specific) {
                 for (uint32_t i = 0; i < q; ++i) {
                     sts[i] = ORAMA_OK;
                     if (batch[i]->k == 0) continue;
@@ -344,7 +348,8 @@ struct orama_post_batcher {
             counts.assign(q, 0);
             // one status per request: a request that is outside the envelope, or invalidated by a rebuild between its
             // validation and this dispatch, fails alone — the callers coalesced with it get their answers
-            sts.assign(q, ORAMA_OK);
+            constexpr int kNoStatus = -1;  // (never a status of the ABI: "the dispatch did not reach this request")
+            sts.assign(q, kNoStatus);
             const int bst =
                 group ? orama_shard_post_search_batch(group, shards.data(), descs.data(), q, batch[0]->b,
                                                       reinterpret_cast<const uint64_t* const*>(batch[0]->allow), batch[0]->allow_bits,
@@ -355,12 +360,11 @@ struct orama_post_batcher {
                                                        counts.data(), sts.data());
             std::string err;
             if (bst != ORAMA_OK) err = orama_last_error();  // this thread's error slot: the first failing query's message
-            bool all_failed = bst != ORAMA_OK;
-            for (uint32_t i = 0; i < q && all_failed; ++i) all_failed = sts[i] != ORAMA_OK;
             for (uint32_t i = 0; i < q; ++i) {
                 PostRequest* r = batch[i];
-                // a batch-level failure (bad shared arguments) leaves every status at its initial value: report it to all
-                const int st = (bst != ORAMA_OK && all_failed && sts[i] == ORAMA_OK) ? bst : sts[i];
+                // a request the dispatch never wrote a status for: the call failed before it got there (bad shared
+                // arguments, the group's info call) — it shares the call's status; a call that succeeded wrote every status
+                const int st = sts[i] == kNoStatus ? (bst != ORAMA_OK ? bst : ORAMA_OK) : sts[i];
                 r->status = st;
                 if (st != ORAMA_OK) r->error = err;
                 if (st == ORAMA_OK) {

@@ -1388,15 +1388,20 @@ static int post_search_batch_impl(orama_post* p, const orama_post_query_desc* qu
                 return post_search_ranges(p, sc.s.get(), jobs.data(), (uint32_t)jobs.size(), b, allow_bitmap, bitmap_bits, apply_omc,
                                           two ? sc2.s.get() : nullptr);
             };
-            if (run() == ORAMA_OK) {
+            const int run_st = run();
+            if (run_st == ORAMA_OK) {
                 if (out_count)
                     for (size_t j = 0; j < owner.size(); ++j) out_count[owner[j]] = counts[j];
-            } else {
-                // the set of launches failed as a whole: every query of it is answered (or refused) on its own below
+            } else if (run_st == ORAMA_ERR_INVALID || run_st == ORAMA_ERR_UNSUPPORTED) {
+                // one query can be responsible for that: every query of the set is answered (or refused) on its own below
                 for (uint32_t i : owner) {
                     out_n[i] = 0;
                     rest.push_back(i);
                 }
+            } else {
+                // systemic (scratch pool saturated — BUSY after the acquire timeout —, the device, memory): the per-query
+                // path would fail the same way, one timeout after the other; every query of the set gets the status now
+                for (uint32_t i : owner) fail(i, run_st);
             }
         }
     }

@@ -61,24 +61,107 @@ def device_for(local_rank: int) -> int:
     return local_rank % n.value
 
 
-def self_launch(n_ranks: int, argv: list[str], timeout: float | None = None) -> int:
-    """`python bench.py --gpus N` without an external launcher: start N copies of the calling script, one rank per GPU,
-    with the RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment `torch.distributed.run` would give them.  Rank 0
-    inherits stdout (its JSON line stays the last line); the other ranks' stdout goes to stderr.  Returns the worst
-    exit code; a rank that dies takes the others down instead of leaving them in a collective."""
+def preflight(n_ranks: int, timeout: float = 120.0) -> dict:
+    """What a multi-rank launch needs, checked in a throw-away child process BEFORE any rank starts (the launcher itself
+    never touches the GPU runtime): the library loads, the box shows at least `n_ranks` devices (or the transport is a
+    loopback one, ORAMA_RCCL_LIB, on which ranks may share GPUs), RCCL resolves and can make a communicator id.
+    Returns {"ok", "devices", "rccl", "loopback", "error"}."""
+    import json
     import subprocess
     import sys
 
+    code = ("import ctypes as C, json, os\n"
+            "from oramacore_amd import _native as N\n"
+            "out = {'devices': 0, 'rccl': False, 'loopback': bool(os.environ.get('ORAMA_RCCL_LIB')), 'error': ''}\n"
+            "try:\n"
+            "    lib = N.load(); n = C.c_int(); N.check(lib.orama_device_count(C.byref(n))); out['devices'] = n.value\n"
+            "    buf = C.create_string_buffer(128); N.check(lib.orama_shard_unique_id(buf)); out['rccl'] = True\n"
+            "except Exception as e:\n"
+            "    out['error'] = str(e)[:500]\n"
+            "print('PREFLIGHT ' + json.dumps(out))\n")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"ok": False, "devices": 0, "rccl": False, "loopback": False, "error": f"preflight timed out after {timeout:.0f} s"}
+    out = None
+    for line in r.stdout.splitlines():
+        if line.startswith("PREFLIGHT "):
+            out = json.loads(line[len("PREFLIGHT "):])
+    if out is None:
+        return {"ok": False, "devices": 0, "rccl": False, "loopback": False,
+                "error": f"preflight child exited {r.returncode}: {(r.stderr or r.stdout)[-500:]}"}
+    if not out["error"] and out["devices"] < n_ranks and not out["loopback"]:
+        out["error"] = (f"{n_ranks} ranks need {n_ranks} GPUs, this box shows {out['devices']} (ranks may share a GPU only on a "
+                        "loopback transport: ORAMA_RCCL_LIB)")
+    out["ok"] = not out["error"]
+    return out
+
+
+def _free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
+        return s.getsockname()[1]
+
+
+def self_launch(n_ranks: int, argv: list[str], timeout: float | None = None, grace: float = 10.0) -> int:
+    """`python bench.py --gpus N` without an external launcher: start N copies of the calling script, one rank per GPU,
+    with the RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment `torch.distributed.run` would give them.  Rank 0
+    inherits stdout (its JSON line stays the last line); the other ranks' stdout goes to stderr.  Every rank's stderr
+    is teed into a temporary file so that a failure can be REPORTED: when a rank dies (or the timeout strikes) the other
+    ranks get SIGTERM, then SIGKILL after `grace` seconds, and the launcher prints one JSON line
+    {"error": ..., "failed_rank": r, "rank_stderr_tail": {...}} as the last line of stdout.  Returns the worst exit code.
+
+    The rendezvous port is only a hint: rank 0 binds the first free port of a short sequence next to it and the others
+    probe the same sequence (exchange_unique_id), so a port taken between this probe and rank 0's bind costs a retry,
+    not the job."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    import threading
+
+    port = _free_port()
+    tmp = tempfile.mkdtemp(prefix="orama_launch_")
+    procs, logs, tees = [], [], []
+
+    def tee(pipe, path):
+        with open(path, "wb") as f:
+            for chunk in iter(lambda: pipe.readline(), b""):
+                f.write(chunk)
+                f.flush()
+                try:
+                    sys.stderr.buffer.write(chunk)
+                    sys.stderr.buffer.flush()
+                except Exception:  # noqa: BLE001 - stderr closed: keep the file
+                    pass
+
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, *argv], env=env, stdout=None if r == 0 else sys.stderr))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the host driver supports nothing else); the user's value wins
+        p = subprocess.Popen([sys.executable, *argv], env=env, stdout=None if r == 0 else sys.stderr, stderr=subprocess.PIPE)
+        procs.append(p)
+        logs.append(os.path.join(tmp, f"rank{r}.stderr"))
+        t = threading.Thread(target=tee, args=(p.stderr, logs[-1]), daemon=True)
+        t.start()
+        tees.append(t)
+
+    def stop_others(alive):
+        for q in alive:
+            q.terminate()
+        t_end = time.monotonic() + grace
+        while any(q.poll() is None for q in alive) and time.monotonic() < t_end:
+            time.sleep(0.05)
+        for q in alive:
+            if q.poll() is None:
+                q.kill()
+
     deadline = None if timeout is None else time.monotonic() + timeout
-    worst = 0
+    worst, failed_rank, reason = 0, None, ""
     alive = list(procs)
     while alive:
         for p in list(alive):
@@ -86,15 +169,28 @@ def self_launch(n_ranks: int, argv: list[str], timeout: float | None = None) -> 
             if rc is None:
                 continue
             alive.remove(p)
-            if rc != 0:
-                worst = worst or rc
-                for q in alive:
-                    q.terminate()
-        if deadline is not None and time.monotonic() > deadline:
-            for q in alive:
-                q.kill()
-            return worst or 124
+            if rc != 0 and not worst:
+                worst, failed_rank, reason = rc, procs.index(p), f"rank {procs.index(p)} exited with status {rc}"
+                stop_others(alive)
+        if alive and deadline is not None and time.monotonic() > deadline:
+            worst, reason = worst or 124, reason or f"timeout after {timeout:.0f} s"
+            stop_others(alive)
         time.sleep(0.05)
+    for t in tees:
+        t.join(timeout=2.0)
+    if worst:
+        tails = {}
+        for r, path in enumerate(logs):
+            try:
+                with open(path, "rb") as f:
+                    tails[f"rank{r}"] = f.read()[-1500:].decode(errors="replace")
+            except OSError:
+                tails[f"rank{r}"] = ""
+        sys.stdout.flush()
+        print(json.dumps({"error": reason, "failed_rank": failed_rank, "n_gpus": n_ranks, "rank_stderr_tail": tails}), flush=True)
+    import shutil
+
+    shutil.rmtree(tmp, ignore_errors=True)
     return worst
 
 

@@ -11,7 +11,7 @@ from oramacore_amd import _build, _native as N
 def test_library_builds_and_loads():
     lib = N.load()
     assert lib.orama_abi_version() == 1
-    assert _build.LIB.exists()
+    assert _build.lib_path().exists()
 
 
 def test_every_declared_symbol_is_exported():

@@ -44,7 +44,7 @@ def expected(ctx):
             e[f"vec_{name}_{tag}"] = st.storage_search(q, W.K)
         bm = oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[(np.arange(W.VEC_N) % 3) != 1])
         e[f"vec_{name}_filter"] = st.storage_search(qs[1], W.K, bm)
-        for world in (2, 3):
+        for world in (2, 3, 8):
             e[f"vec_{name}_bigk_w{world}"] = st.storage_search(qs[2], 4096 // world)
         if name == "f32":
             e["sess"] = st.storage_search(qs[:4], 20)
@@ -146,14 +146,14 @@ def run_workers(form, world, tmp_path):
     return [np.load(o) for o in outs]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_one_process_per_rank(expected, world, tmp_path):
     """orama_shard_group_create_rank: `world` processes, one shard each, every rank holds the global answer."""
     for rank, got in enumerate(run_workers("rank", world, tmp_path)):
         check_rank(got, expected, world, "rank", rank)
 
 
-@pytest.mark.parametrize("world", [3])
+@pytest.mark.parametrize("world", [3, 8])
 def test_one_process_all_ranks_grouped_collectives(expected, world, tmp_path):
     """orama_shard_group_create + ORAMA_SHARD_FORCE_RCCL: one process, one communicator per shard, ncclGroupStart/End."""
     (got,) = run_workers("initall", world, tmp_path)
