@@ -70,7 +70,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the RCCL all-gather + merge even with one rank (plumbing test)")
-    ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000,
+                    help="rows of the corpus the CPU baseline legs scan (3 GB at 768 dimensions: beyond the host's caches, like the "
+                         "30 GB corpus the QPS is extrapolated to)")
     ap.add_argument("--no-two-stage", action="store_true", help="skip the fp32 + fp16-shadow leg (N = 1, fp32 workloads)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are issued on round-robin (independent queries: the tiny top-k / "
@@ -120,7 +122,32 @@ def cpu_baseline(store, dim: int, n_total: int, k: int, sample_rows: int) -> dic
 
     cores = os.cpu_count() or 1
     rows_per_s_1 = run(1, 8.0)
-    rows_per_s_all = run(cores, 6.0)
+    rows_per_s_all = run(cores, 4.0)
+
+    # BASELINE.md §3's "fast CPU" leg: the same scan as a CPU implementation would write it — -O3 -march=native, 8 independent
+    # FMA accumulators per row (vectorised), row-parallel — compiled on THIS host (oracle/cpu_fast.py).  Not order-exact
+    # (agrees with the oracle to ~1e-6); a thread-scaling line shows where the host's DRAM bandwidth saturates.
+    from oracle import cpu_fast as cf
+
+    err = float(np.max(np.abs(cf.distances(rows[:20000], qs[0], 1) - orc.distances(rows[:20000], qs[0]))))
+
+    def run_fast(threads: int, min_seconds: float):
+        t0 = time.perf_counter()
+        passes = 0
+        while True:
+            d = cf.distances(rows, qs[passes % len(qs)], threads)
+            np.argpartition(d, min(k, sample_rows - 1))[:k]
+            passes += 1
+            el = time.perf_counter() - t0
+            if el >= min_seconds and passes >= 3:
+                return sample_rows * passes / el
+
+    ladder = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, 128, cores) if t <= cores})
+    scaling = []
+    for t in ladder:
+        rps = run_fast(t, 2.0 if t == 1 else 1.0)
+        scaling.append({"threads": t, "value": rps / n_total, "gbytes_per_s": rps * dim * 4 / 1e9})
+    best = max(scaling, key=lambda e: e["value"])
     return {
         "value": rows_per_s_1 / n_total,
         "unit": "queries/s",
@@ -131,9 +158,89 @@ def cpu_baseline(store, dim: int, n_total: int, k: int, sample_rows: int) -> dic
         "gbytes_per_s": rows_per_s_1 * dim * 4 / 1e9,
         "all_cores": {"value": rows_per_s_all / n_total, "cores": cores,
                       "gbytes_per_s": rows_per_s_all * dim * 4 / 1e9},
-        "note": "a scalar restatement, not the reference's (un-vendored, presumably SIMD) crate: a reported baseline, not a "
-                "speed-up claim",
+        "fast": {"value": best["value"], "unit": "queries/s", "cores": best["threads"], "kind": "port",
+                 "gbytes_per_s": best["gbytes_per_s"], "single_thread": scaling[0], "thread_scaling": scaling,
+                 "build": "gcc " + cf.build_flags() + " on this host", "max_abs_diff_vs_order_exact_oracle": err,
+                 "sample": f"oracle/orama_cpu_fast.c cpf_distances_f32 (8 FMA accumulators per row, vectorised; fast CPU, NOT "
+                           f"order-exact) + top-{k} over the same {sample_rows} rows, >= 1 s per thread count; the best "
+                           "thread count is quoted"},
+        "note": "restatements of the reference's algorithm, not the reference's (un-vendored, presumably SIMD) crate: reported "
+                "baselines, never a speed-up claim.  `value` is the order-exact scalar oracle on one thread (the reference runs "
+                "one search on one tokio worker); `fast` is what -O3 -march=native + all cores buy on this host",
     }
+
+
+class ClockSampler:
+    """Shader clock and package power of GPU `device` while a leg runs, read straight from sysfs by a side thread (no
+    rocm-smi process: a sample costs microseconds, so even the 90 ms north-star region gets dozens).  Everything is optional:
+    on a box without the files the record says so instead of failing the bench.  VERDICT r03 #7: rocprofv3 sets of the same
+    kernel differed by 5 % between runs — the clock the chip sustained under its power cap is the missing column."""
+
+    def __init__(self, device: int = 0, period_s: float = 0.002):
+        import threading
+
+        self.period = period_s
+        self.power_file = self.sclk_file = self.freq_file = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/power1_*"))]
+        if device < len(cards):
+            base = cards[device]
+            for name in ("power1_average", "power1_input"):
+                hits = glob.glob(os.path.join(base, "hwmon/hwmon*/" + name))
+                if hits:
+                    self.power_file = hits[0]
+                    break
+            hits = glob.glob(os.path.join(base, "hwmon/hwmon*/freq1_input"))
+            self.freq_file = hits[0] if hits else None
+            f = os.path.join(base, "pp_dpm_sclk")
+            self.sclk_file = f if os.path.exists(f) else None
+        self.samples_w, self.samples_mhz = [], []
+        self._stop = threading.Event()
+        self._thread = None
+
+    def _read(self):
+        try:
+            if self.power_file:
+                self.samples_w.append(int(open(self.power_file).read().strip()) / 1e6)
+        except (OSError, ValueError):
+            pass
+        try:
+            if self.freq_file:
+                self.samples_mhz.append(int(open(self.freq_file).read().strip()) / 1e6)
+            elif self.sclk_file:
+                for line in open(self.sclk_file).read().splitlines():
+                    if line.rstrip().endswith("*"):
+                        self.samples_mhz.append(float(line.split(":")[1].strip().split("M")[0]))
+        except (OSError, ValueError, IndexError):
+            pass
+
+    def __enter__(self):
+        import threading
+
+        if self.power_file or self.freq_file or self.sclk_file:
+            def loop():
+                while not self._stop.is_set():
+                    self._read()
+                    time.sleep(self.period)
+            self._thread = threading.Thread(target=loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread:
+            self._thread.join(timeout=1.0)
+
+    def summary(self) -> dict:
+        if not self.samples_w and not self.samples_mhz:
+            return {"available": False}
+        out = {"available": True, "samples": max(len(self.samples_w), len(self.samples_mhz)), "source": "sysfs hwmon / pp_dpm_sclk"}
+        if self.samples_mhz:
+            out.update(sclk_mhz_median=float(np.median(self.samples_mhz)), sclk_mhz_min=float(np.min(self.samples_mhz)),
+                       sclk_mhz_max=float(np.max(self.samples_mhz)))
+        if self.samples_w:
+            out.update(power_w_mean=float(np.mean(self.samples_w)), power_w_max=float(np.max(self.samples_w)))
+        return out
 
 
 def vec_two_stage_ok(dim: int, k: int) -> bool:
@@ -213,7 +320,7 @@ def check_vector_result(store, ids_all, dst_all, cnt, queries_last, k, qb, lo, h
 
 
 def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=False, rank=0, world=1, lo=0, hi=None,
-               store=None, valid=True, desc=None, dump="", f16_slots=1):
+               store=None, valid=True, desc=None, dump="", f16_slots=1, device=0):
     """One vector workload through the pipelined shard session: returns (bench-line dict, store, host queries)."""
     _, dim, k, qb, dtype, wdesc = WORKLOADS[name]
     desc = desc or wdesc
@@ -249,11 +356,12 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
     barrier()
     ctx.prof_reset()
     ctx.prof_enable(True)
-    t0 = time.perf_counter()
-    for i in range(warmup, total_b):
-        sess.step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with ClockSampler(device) as clocks:
+        t0 = time.perf_counter()
+        for i in range(warmup, total_b):
+            sess.step(i)
+        barrier()
+        elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
     elapsed = group.allreduce_max(elapsed)  # the slowest rank's time
 
@@ -296,7 +404,8 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
                      "alg_bytes_per_launch": alg_bytes,
                      "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_n,
                      "scan_launches_per_step": launches_per_step,
-                     "topk_select_ms_per_step": sel_ms / steps},
+                     "topk_select_ms_per_step": sel_ms / steps,
+                     "clocks_during_timed_region": clocks.summary()},
         "parity_check": "last step vs oracle: distances recomputed from the rows (<= 1e-4), no better row among 20 000 "
                         "sampled rows of the shard",
         "fill_seconds": t_fill,
@@ -431,12 +540,28 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
     od, os_ = orc.search_full_text(entries, T, float(n), 1.2, None)
     td, ts = orc.top_n(od, os_, k)
     reps, t_cpu0 = 0, time.perf_counter()
-    while time.perf_counter() - t_cpu0 < 3.0:
+    while time.perf_counter() - t_cpu0 < 2.0:
         orc.top_n(*orc.search_full_text(entries, T, float(n), 1.2, None), k)
         reps += 1
+    qsort_qps = reps / (time.perf_counter() - t_cpu0)
+    # the loop the reference actually runs (token_score.rs:257-300): hash maps, not a sort — oracle/orama_cpu_fast.c, compiled
+    # -O3 -march=native on this host; its answer must equal the oracle's bit for bit before its rate is quoted
+    from oracle import cpu_fast as cf
+
+    f_ids, f_sc, f_count = cf.bm25_hashmap(entries, T, float(n), 1.2, None, k)
+    assert f_count == len(od) and f_ids.tolist() == td.tolist() and np.array_equal(f_sc.view(np.uint32), ts.view(np.uint32)), \
+        "CPU hash-map baseline differs from the oracle"
+    reps, t_cpu0 = 0, time.perf_counter()
+    while time.perf_counter() - t_cpu0 < 3.0:
+        cf.bm25_hashmap(entries, T, float(n), 1.2, None, k)
+        reps += 1
     cpu_bm25 = {"value": reps / (time.perf_counter() - t_cpu0), "unit": "queries/s", "cores": 1, "kind": "port",
-                "sample": f"oracle search_full_text + top_n on the last query's contributions ({sum(len(e[1]) for e in entries)} "
-                          "postings, ntf precomputed), repeated >= 3 s"}
+                "sample": f"oracle/orama_cpu_fast.c cpf_bm25_hashmap on the last query's contributions ({sum(len(e[1]) for e in entries)} "
+                          "postings, ntf precomputed): per-token hash map doc -> sum, finalize_term into the document hash map, "
+                          "bounded-heap top_n — the reference's loop (token_score.rs:257-300) with a cheaper hash than std's SipHash; "
+                          "bit-identical to the oracle; repeated >= 3 s",
+                "build": "gcc " + cf.build_flags() + " on this host",
+                "order_exact_oracle_qsort_form": {"value": qsort_qps, "unit": "queries/s", "cores": 1}}
     assert b_count == len(od) and b_ids.tolist() == td.tolist(), "BM25 ids differ from the oracle"
     assert np.array_equal(b_sc.view(np.uint32), ts.view(np.uint32)), "BM25 scores differ from the oracle"
     ids, dist, _ = vec.storage_search(qv[i], k)
@@ -613,7 +738,7 @@ def main():
     f16 = dtype == "f16"
     out, store, queries_h = vector_leg(oa, group, args.workload, n_total, args.steps, args.warmup, args.streams,
                                        force_exchange=args.force_exchange, rank=rank, world=world, lo=lo, hi=hi,
-                                       valid=not bool(args.rows), dump=args.dump_result, f16_slots=args.f16_slots)
+                                       valid=not bool(args.rows), dump=args.dump_result, f16_slots=args.f16_slots, device=device)
     out["config"]["ranks_seen"] = ranks_seen
     out["config"]["comm_world"] = group.world
     out["config"]["exchange"] = ("rccl" + (" (ORAMA_RCCL_LIB loopback: " + os.path.basename(os.environ["ORAMA_RCCL_LIB"]) + ")"

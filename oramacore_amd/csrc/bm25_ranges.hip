@@ -85,209 +85,138 @@ __global__ __launch_bounds__(kBoundsThreads) void range_bounds_kernel(RangeBatch
 }
 
 // ---------------------------------------------------------------------------------------------- the scoring launch
-constexpr int kThreads = 512;                              // eight waves: 4 workgroups of ~39 KB LDS fill a CU's 32 wave slots
+// The launch is bound by VALU ISSUE (profiles/r04_k3r_sq_counters_v*.md: SQ_ACTIVE_INST_VALU = the whole launch on every
+// SIMD, one wave instruction per 4 cycles), so the kernel is written for few vector instructions per posting:
+//   * 4 fat waves per workgroup (a lane carries up to 8 postings through the phases in registers): per-wave fixed work —
+//     tables, scans, reductions — is paid once per 320 postings instead of once per 160;
+//   * wave 0 alone loads the range's tables, scans the run lengths and builds a 32-element block -> run table (the other
+//     waves clear the bitmap and the presence masks meanwhile): a posting finds its run with one table read instead of a
+//     binary search of its own;
+//   * the rarely taken paths (3 % of the documents of a 12-token query have more than one posting) are kept out of the
+//     per-posting code: a multi-posting document's postings only park their value in a cell; the documents themselves are
+//     listed densely and folded + reported by as many lanes as there are such documents;
+//   * reductions through LDS atomics without return (one instruction) instead of cross-lane shuffles (~30).
+constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kPerThread = kRangeCap / kThreads;           // postings a thread carries in registers across the phases
+static_assert(kRangeCap / kThreads == 8, "a lane carries at most 8 postings through the phases (score_body<.., 8>)");
 constexpr uint32_t kBitWords = kRangeMaxWidth / 32;        // bitmap words of the widest range
 constexpr int kWordsPerThread = kBitWords / kThreads;
+constexpr uint32_t kBlkShift = 5, kBlocks = kRangeCap >> kBlkShift;  // run lookup table: one entry per 32 gathered postings
 constexpr uint32_t kNoCell = 0xffffu;                      // cell_base of a singleton document
-constexpr uint32_t kInMap = 0x8000u;                       // cell_base flag set by the fold: the document is in the score map
 static_assert(kRangeCap % kThreads == 0 && kBitWords % kThreads == 0, "phase loops are unrolled over whole threads");
-static_assert(kRangeCap <= 0x7fffu, "cells and posting slots are stored in 15 bits");
+static_assert(kRangeCap <= 0x8000u && kRangeMaxWidth <= 0x10000u, "posting slot and local document share one 32-bit word");
+static_assert(kBlocks <= 64, "the block table is built by one wave");
 
-// packed per-posting state: [local doc:15 | run (reference) index:8 | pad | kept:1 (bit 31)]
-__device__ __forceinline__ uint32_t pk_make(uint32_t dl, uint32_t seg) { return 0x80000000u | (seg << 15) | dl; }
-__device__ __forceinline__ bool pk_kept(uint32_t pk) { return (pk >> 31) != 0u; }
-__device__ __forceinline__ uint32_t pk_dl(uint32_t pk) { return pk & 0x7fffu; }
-__device__ __forceinline__ uint32_t pk_seg(uint32_t pk) { return (pk >> 15) & 0xffu; }
+template <bool WIDE>
+struct MaskOf {
+    typedef uint32_t type;
+};
+template <>
+struct MaskOf<true> {
+    typedef unsigned long long type;
+};
+__device__ __forceinline__ uint32_t mask_popc(uint32_t m) { return (uint32_t)__popc(m); }
+__device__ __forceinline__ uint32_t mask_popc(unsigned long long m) { return (uint32_t)__popcll(m); }
+__device__ __forceinline__ uint32_t mask_first(uint32_t m) { return (uint32_t)__ffs((int)m) - 1u; }
+__device__ __forceinline__ uint32_t mask_first(unsigned long long m) { return (uint32_t)__ffsll((long long)m) - 1u; }
 
-template <bool DF_ONLY>
-__global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
-    // region A: the range's document bitmap + the exclusive popcount prefix of its words; once every posting knows its
-    // document's rank both are dead and the region holds the cells of the multi-posting documents
-    __shared__ uint32_t region_a[2 * kBitWords];
-    uint32_t* const bitmap = region_a;
-    uint32_t* const word_rank = region_a + kBitWords;
-    float* const cellv = reinterpret_cast<float*>(region_a);
-    static_assert(sizeof(region_a) >= kRangeCap * sizeof(float), "cells alias the bitmap region");
-    __shared__ unsigned long long dmask[kRangeCap];        // per touched document (by rank): tokens present
-    __shared__ uint16_t cell_base[kRangeCap];              // per touched document: first cell | kInMap, kNoCell = singleton
-    __shared__ uint16_t owner[kRangeCap];                  // per cell: the posting slot that reports the document (first cell only)
-    __shared__ unsigned long long seg_pos[kRangeMaxRefs];  // first posting of each reference inside this range
-    __shared__ uint32_t seg_off[kRangeMaxRefs + 1];        // start of each reference's run among the gathered postings
-    __shared__ uint32_t seg_key[kRangeMaxRefs];            // token << 10 | rank
-    __shared__ float seg_boost[kRangeMaxRefs], seg_avg[kRangeMaxRefs];
-    __shared__ float idf[kMaxTokens];
-    __shared__ uint32_t df_lds[kMaxTokens];
-    __shared__ uint32_t wave_tot[kWaves];
-    __shared__ uint32_t red[4];                            // slot base, count, max key, ~min key
-    __shared__ unsigned long long multi_tok;               // tokens with more than one list
-    __shared__ uint32_t max_rank, cell_cursor;
+// LDS of one scoring workgroup.  WIDE: queries of more than 32 tokens (64-bit presence masks).
+template <bool WIDE>
+struct ScoreLds {
+    typedef typename MaskOf<WIDE>::type mask_t;
+    // region A, phases 1-3: the range's document bitmap + the exclusive popcount prefix of its words (u16: at most 2 048
+    // documents are touched); phases 5-6: the cells of the multi-posting documents + per first cell the slot and local
+    // document of the posting that lends the document its key slot
+    uint32_t region_a[2 * kRangeCap];
+    mask_t dmask[kRangeCap];                    // per touched document (by rank): tokens present
+    uint16_t cell_base[kRangeCap];              // per touched document: first cell, kNoCell = singleton
+    uint16_t multi_list[kRangeCap];             // the multi-posting documents (ranks), densely
+    unsigned long long seg_pos[kRangeMaxRefs];  // first posting of each reference inside this range
+    uint32_t seg_off[kRangeMaxRefs + 1];        // start of each reference's run among the gathered postings
+    uint32_t seg_key[kRangeMaxRefs];            // token << 10 | rank
+    float seg_boost[kRangeMaxRefs], seg_avg[kRangeMaxRefs];
+    uint16_t blk_run[kBlocks];                  // run that holds gathered posting 32 i
+    float idf[kMaxTokens];
+    uint32_t df_lds[kMaxTokens];
+    uint32_t wave_tot[kWaves];
+    uint32_t red[4];                            // slot base, count, max key, ~min key
+    unsigned long long multi_tok;               // tokens with more than one list
+    uint32_t max_rank, cell_cursor;             // cell_cursor: cells handed out | multi documents << 16
+    __device__ __forceinline__ uint32_t* bitmap() { return region_a; }
+    __device__ __forceinline__ uint16_t* word_rank() { return reinterpret_cast<uint16_t*>(region_a + kBitWords); }
+    __device__ __forceinline__ float* cellv() { return reinterpret_cast<float*>(region_a); }
+    __device__ __forceinline__ uint32_t* own() { return region_a + kRangeCap; }
+};
+static_assert(2 * kRangeCap * 4 >= kBitWords * 4 + kBitWords * 2, "bitmap + prefix fit the cell region");
 
-    // (query, range) of this workgroup: the batch's pairs laid end to end
-    uint32_t qi = 0;
-    {
-        uint32_t lo = 0, hi = b.n_queries;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (b.range_start[mid] <= blockIdx.x) lo = mid; else hi = mid;
-        }
-        qi = lo;
-    }
-    const RangeQuery q = b.queries[qi];
-    const uint32_t r = blockIdx.x - b.range_start[qi];
-    if (r >= q.n_ranges) return;
-    if (DF_ONLY && !q.want_df) return;
-    const uint32_t ns = q.seg_end - q.seg_begin;
-    const RangeSeg* segs = b.segs + q.seg_begin;
+// What phases 1-6 need to know about their workgroup (all workgroup-uniform).
+struct ScoreRange {
+    uint32_t qi, cap, slot_base, doc0, n_words;
+    bool count_each;
+};
+
+// Phases 1-6 for a workgroup whose lanes carry NITER postings each (NITER * 256 >= cap): compiled per NITER so that the
+// per-posting loops are straight-line code — a run-time round count inside one body made the compiler shuffle the whole
+// register arrays at every round's branch (a third of the vector instructions of the first form of this kernel).  Rounds
+// past the end (e >= cap) read the last posting again and are not `kept`.
+template <bool DF_ONLY, bool WIDE, int NITER>
+__device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery& q, const ScoreRange& rg, ScoreLds<WIDE>& L) {
+    typedef typename MaskOf<WIDE>::type mask_t;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t cap = rg.cap, qi = rg.qi, doc0 = rg.doc0, n_words = rg.n_words;
+    uint32_t* const bitmap = L.bitmap();
+    uint16_t* const word_rank = L.word_rank();
+    float* const cellv = L.cellv();
+    uint32_t* const own = L.own();
 
-    const bool count_each = DF_ONLY && q.want_df == 2u;  // every token has ONE list: a kept posting is its own (token, document) pair
-    const uint32_t n_words = (min(q.width, kRangeMaxWidth) + 31u) >> 5;
-    if (threadIdx.x < 4) red[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        multi_tok = 0ull;
-        max_rank = 0u;
-        cell_cursor = 0u;
-    }
-    if (!count_each) {  // (cleared two barriers before the gather's atomics)
-#pragma unroll
-        for (int n = 0; n < kWordsPerThread; ++n) {
-            const uint32_t w = threadIdx.x + n * kThreads;
-            if (w < n_words) bitmap[w] = 0u;
-        }
-    }
-    for (uint32_t t = threadIdx.x; t < kMaxTokens; t += kThreads) {
-        df_lds[t] = 0;
-        if (!DF_ONLY) idf[t] = t < q.n_tokens ? b.idf[(size_t)qi * kMaxTokens + t] : 0.0f;
-    }
-    __syncthreads();
-    // this range's run of every reference (the bounds of a range are contiguous over the references, and their
-    // address does not depend on the reference table: both loads are issued together);
-    // slot base = postings of the query in earlier ranges
-    uint32_t base_part = 0;
-    for (uint32_t i = threadIdx.x; i < ns; i += kThreads) {
-        const uint32_t* row = b.bounds + q.bounds_base + (uint64_t)r * ns;
-        const uint32_t b0 = row[i], b1 = row[ns + i];
-        const RangeSeg sg = segs[i];
-        seg_pos[i] = sg.post_begin + b0;
-        seg_off[i + 1] = b1 - b0;
-        seg_key[i] = sg.tok_rank;
-        seg_boost[i] = sg.boost;
-        seg_avg[i] = sg.avg_len;
-        base_part += b0;
-        const uint32_t rank = sg.tok_rank & 1023u;
-        if (rank) {
-            atomicOr(&multi_tok, 1ull << (sg.tok_rank >> 10));
-            atomicMax(&max_rank, rank);
-        }
-    }
-    base_part = wave_sum_u32(base_part);
-    if (lane == 0 && base_part) atomicAdd(&red[0], base_part);
-    __syncthreads();
-    if (threadIdx.x < 64) {  // inclusive scan of the run lengths by one wave, 64 references at a time
-        uint32_t carry = 0;
-        for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
-            const uint32_t i = i0 + threadIdx.x;
-            uint32_t x = i < ns ? seg_off[i + 1] : 0;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t y = __shfl_up(x, off, 64);
-                if ((int)threadIdx.x >= off) x += y;
-            }
-            if (i < ns) seg_off[i + 1] = carry + x;
-            carry += __shfl(x, 63, 64);
-        }
-        if (threadIdx.x == 0) seg_off[0] = 0;
-    }
-    __syncthreads();
-    const uint32_t cap = seg_off[ns];
-    if (cap == 0) return;
-    const uint32_t slot_base = red[0];
-    if (cap > kRangeCap) {
-        // the query is rerun with smaller ranges; its slots still reach the batch's top-k, so they must be empty
-        if (!DF_ONLY)
-            for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
-                b.keys[q.key_off + slot_base + e] = 0ull;
-                if (b.map_idx) b.map_idx[slot_base + e] = 0xffffffffu;
-            }
-        if (threadIdx.x == 0) b.results[qi].overflow = 1;
-        return;
-    }
-    const uint32_t doc0 = r * q.width;
-    if (!count_each) {
-#pragma unroll
-        for (int n = 0; n < kPerThread; ++n) {
-            const uint32_t e = threadIdx.x + n * kThreads;
-            if (e < cap) dmask[e] = 0ull;  // (touched documents <= postings)
-        }
-    }
-
-    // ---- 1. gather: element e belongs to the reference whose [seg_off[i], seg_off[i+1]) holds it
-    uint32_t pk[kPerThread];  // local document, run, kept
-    float pv[kPerThread];     // normalised tf (boost included)
+    // ---- 1. gather: posting e belongs to the run whose [seg_off[i], seg_off[i+1]) holds it
+    uint32_t pk[NITER];  // [kept:1 | token:6 | run:8 | pad:1 | local document:16]
+    float pv[NITER];     // normalised tf (boost included)
     {
-        unsigned long long pos[kPerThread];
-        uint32_t run[kPerThread];
+        unsigned long long pos[NITER];
+        uint32_t run[NITER];
 #pragma unroll
-        for (int n = 0; n < kPerThread; ++n) {
-            const uint32_t e = threadIdx.x + n * kThreads;
-            pos[n] = 0ull;
-            run[n] = 0u;
-            if (e < cap) {
-                uint32_t lo = 0, hi = ns;
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (seg_off[mid] <= e) lo = mid; else hi = mid;
-                }
-                run[n] = lo;
-                pos[n] = seg_pos[lo] + (e - seg_off[lo]);
-            }
+        for (int n = 0; n < NITER; ++n) {
+            if (!rg.count_each) L.dmask[threadIdx.x + n * kThreads] = (mask_t)0;  // (touched documents <= postings; first used in phase 3)
+            const uint32_t e = min(threadIdx.x + n * kThreads, cap - 1u);
+            uint32_t lo = L.blk_run[e >> kBlkShift];
+            while (L.seg_off[lo + 1] <= e) ++lo;  // (runs are ~100 postings: almost always zero steps)
+            run[n] = lo;
+            pos[n] = L.seg_pos[lo] + (e - L.seg_off[lo]);
         }
-        uint32_t doc[kPerThread], val[kPerThread];
+        uint32_t doc[NITER], val[NITER];
 #pragma unroll
-        for (int n = 0; n < kPerThread; ++n) {
-            const uint32_t e = threadIdx.x + n * kThreads;
-            doc[n] = 0u;
+        for (int n = 0; n < NITER; ++n) {
+            doc[n] = b.post_doc[pos[n]];
             val[n] = 0u;
-            if (e < cap) {
-                doc[n] = b.post_doc[pos[n]];
-                if (!DF_ONLY) val[n] = b.post_ntf ? __builtin_bit_cast(uint32_t, b.post_ntf[pos[n]]) : b.post_val[pos[n]];
-            }
+            if (!DF_ONLY) val[n] = b.post_ntf ? __builtin_bit_cast(uint32_t, b.post_ntf[pos[n]]) : b.post_val[pos[n]];
         }
         const float one_minus_b = 1.0f - b.b;
 #pragma unroll
-        for (int n = 0; n < kPerThread; ++n) {
-            const uint32_t e = threadIdx.x + n * kThreads;
-            pk[n] = 0u;
+        for (int n = 0; n < NITER; ++n) {
+            bool kept = threadIdx.x + n * kThreads < cap;
+            if (b.allow) {  // collect_contributions_with_filter: filtered docs never reach the scorer
+                const uint64_t id = b.docs ? b.docs[doc[n]] : b.dense_base + doc[n];  // dense ids: no table lookup
+                kept = kept && id < b.allow_bits && ((b.allow[id >> 6] >> (id & 63)) & 1ull);
+            }
+            const uint32_t dl = doc[n] - doc0;
+            const uint32_t key = L.seg_key[run[n]];
+            pk[n] = kept ? (0x80000000u | ((key >> 10) << 25) | (run[n] << 17) | dl) : 0u;
             pv[n] = 0.0f;
-            if (e < cap) {
-                bool kept = true;
-                if (b.allow) {  // collect_contributions_with_filter: filtered docs never reach the scorer
-                    const uint64_t id = b.docs ? b.docs[doc[n]] : b.dense_base + doc[n];  // dense ids: no table lookup
-                    kept = id < b.allow_bits && ((b.allow[id >> 6] >> (id & 63)) & 1ull);
-                }
-                if (kept) {
-                    const uint32_t dl = doc[n] - doc0;
-                    pk[n] = pk_make(dl, run[n]);
-                    if (count_each) {
-                        atomicAdd(&df_lds[seg_key[run[n]] >> 10], 1u);
-                    } else {
-                        atomicOr(&bitmap[dl >> 5], 1u << (dl & 31u));
-                        if (!DF_ONLY) {
-                            const float pre = b.post_ntf ? __builtin_bit_cast(float, val[n])
-                                                         : ntf_pre_of(val[n], one_minus_b, b.b, seg_avg[run[n]]);
-                            pv[n] = seg_boost[run[n]] * pre;
-                        }
-                    }
+            if (rg.count_each) {
+                if (kept) atomicAdd(&L.df_lds[key >> 10], 1u);
+            } else {
+                if (kept) atomicOr(&bitmap[dl >> 5], 1u << (dl & 31u));
+                if (!DF_ONLY) {
+                    const float pre = b.post_ntf ? __builtin_bit_cast(float, val[n]) : ntf_pre_of(val[n], one_minus_b, b.b, L.seg_avg[run[n]]);
+                    pv[n] = L.seg_boost[run[n]] * pre;
                 }
             }
         }
     }
     __syncthreads();
-    if (count_each) {
-        for (uint32_t t = threadIdx.x; t < q.n_tokens; t += kThreads)
-            if (df_lds[t]) atomicAdd(&b.results[qi].df[t], df_lds[t]);
+    if (rg.count_each) {
+        if (threadIdx.x < q.n_tokens && L.df_lds[threadIdx.x]) atomicAdd(&b.results[qi].df[threadIdx.x], L.df_lds[threadIdx.x]);
         return;
     }
 
@@ -306,66 +235,91 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
             const uint32_t y = __shfl_up(incl, off, 64);
             if ((int)lane >= off) incl += y;
         }
-        if (lane == 63) wave_tot[wave] = incl;
+        if (lane == 63) L.wave_tot[wave] = incl;
         __syncthreads();
         uint32_t excl = incl - sum;
-        for (uint32_t w = 0; w < wave; ++w) excl += wave_tot[w];
+#pragma unroll
+        for (int w = 0; w < kWaves - 1; ++w) excl += (uint32_t)w < wave ? L.wave_tot[w] : 0u;
 #pragma unroll
         for (int n = 0; n < kWordsPerThread; ++n) {
             const uint32_t w = threadIdx.x * kWordsPerThread + n;
-            if (w < n_words) word_rank[w] = excl;
+            if (w < n_words) word_rank[w] = (uint16_t)excl;
             excl += cnt[n];
         }
     }
     __syncthreads();
     uint32_t n_touched = 0;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) n_touched += wave_tot[w];
+    for (int w = 0; w < kWaves; ++w) n_touched += L.wave_tot[w];
 
     // ---- 3. every kept posting: rank of its document, its token into the document's presence mask
-    uint32_t prank[kPerThread];
+    uint32_t prank[NITER];
 #pragma unroll
-    for (int n = 0; n < kPerThread; ++n) {
-        prank[n] = 0u;
-        if (pk_kept(pk[n])) {
-            const uint32_t dl = pk_dl(pk[n]);
-            const uint32_t rank = word_rank[dl >> 5] + (uint32_t)__popc(bitmap[dl >> 5] & ((1u << (dl & 31u)) - 1u));
-            prank[n] = rank;
-            const uint32_t tok = seg_key[pk_seg(pk[n])] >> 10;
+    for (int n = 0; n < NITER; ++n) {
+        const uint32_t dl = pk[n] & 0xffffu;
+        const uint32_t rank = (uint32_t)word_rank[dl >> 5] + (uint32_t)__popc(bitmap[dl >> 5] & ((1u << (dl & 31u)) - 1u));
+        prank[n] = rank;
+        if (pk[n] >> 31) {
+            const uint32_t tok = (pk[n] >> 25) & 63u;
+            const mask_t bit = (mask_t)1 << tok;
             if (DF_ONLY) {
                 // corpus_docs.len(): distinct (token, document) pairs among the kept postings (token_score.rs:262-275)
-                const unsigned long long old = atomicOr(&dmask[rank], 1ull << tok);
-                if (!((old >> tok) & 1ull)) atomicAdd(&df_lds[tok], 1u);
+                const mask_t old = atomicOr(&L.dmask[rank], bit);
+                if (!(old & bit)) atomicAdd(&L.df_lds[tok], 1u);
             } else {
-                atomicOr(&dmask[rank], 1ull << tok);
+                atomicOr(&L.dmask[rank], bit);
             }
         }
     }
     __syncthreads();
     if (DF_ONLY) {
-        for (uint32_t t = threadIdx.x; t < q.n_tokens; t += kThreads)
-            if (df_lds[t]) atomicAdd(&b.results[qi].df[t], df_lds[t]);
+        if (threadIdx.x < q.n_tokens && L.df_lds[threadIdx.x]) atomicAdd(&b.results[qi].df[threadIdx.x], L.df_lds[threadIdx.x]);
         return;
     }
 
-    // ---- 4. cells for the documents that are not singletons: popcount(mask) cells each, handed out by an LDS cursor
-    const unsigned long long multi = multi_tok;
-    const uint32_t ranks = max_rank;  // a token has at most ranks + 1 lists
-    for (uint32_t d = threadIdx.x; d < n_touched; d += kThreads) {
-        const unsigned long long m = dmask[d];
-        uint32_t cb = kNoCell;
-        if ((m & (m - 1ull)) != 0ull || (m & multi) != 0ull) cb = atomicAdd(&cell_cursor, (uint32_t)__popcll(m));
-        cell_base[d] = (uint16_t)cb;
+    // ---- 4. cells for the documents that are not singletons (more than one token, or a token with several lists):
+    // popcount(mask) cells each and a place in the dense list of such documents, both handed out by ONE returning LDS
+    // atomic (cells in the low half, list position in the high half).  One-list queries: the posting of the document's
+    // FIRST token — there is exactly one — asks, and lends the document its key slot (`own`; that half of region A is
+    // not in use yet).  Multi-list queries: one lane per touched document asks.
+    const mask_t multi = (mask_t)L.multi_tok;
+    const uint32_t ranks = L.max_rank;  // a token has at most ranks + 1 lists
+    mask_t pm[NITER];      // the document's presence mask (0: dropped posting)
+    uint32_t pcb[NITER];   // one-list queries: the first cell this posting was handed (kNoCell: it did not ask)
+#pragma unroll
+    for (int n = 0; n < NITER; ++n) {
+        pm[n] = (pk[n] >> 31) ? L.dmask[prank[n]] : (mask_t)0;
+        pcb[n] = kNoCell;
+        if (ranks == 0u) {
+            const mask_t below = pm[n] & (((mask_t)1 << ((pk[n] >> 25) & 63u)) - 1);
+            if ((pm[n] & (pm[n] - 1)) != 0 && below == 0) {
+                const uint32_t got = atomicAdd(&L.cell_cursor, mask_popc(pm[n]) | (1u << 16));
+                pcb[n] = got & 0xffffu;
+                L.cell_base[prank[n]] = (uint16_t)(got & 0xffffu);
+                L.multi_list[got >> 16] = (uint16_t)prank[n];
+                own[got & 0xffffu] = (threadIdx.x + n * kThreads) | ((pk[n] & 0xffffu) << 16);
+            }
+        }
+    }
+    if (ranks != 0u) {
+        for (uint32_t d = threadIdx.x; d < n_touched; d += kThreads) {
+            const mask_t m = L.dmask[d];
+            if ((m & (m - 1)) != 0 || (m & multi) != 0) {
+                const uint32_t got = atomicAdd(&L.cell_cursor, mask_popc(m) | (1u << 16));
+                L.cell_base[d] = (uint16_t)(got & 0xffffu);
+                L.multi_list[got >> 16] = (uint16_t)d;
+            }
+        }
     }
     __syncthreads();  // (the bitmap and its prefix are dead from here on: region A holds the cells)
-    const uint32_t n_cells = cell_cursor;
+    const uint32_t n_cells = L.cell_cursor & 0xffffu, n_multi = L.cell_cursor >> 16;
     if (ranks != 0u && n_cells != 0u) {  // cells that several lists add into start from 0.0 (Iterator::sum)
         for (uint32_t c = threadIdx.x; c < n_cells; c += kThreads) cellv[c] = 0.0f;
         __syncthreads();
     }
 
     const float k1 = q.k + 1.0f;
-    unsigned long long* out = b.keys + q.key_off + slot_base;
+    unsigned long long* out = b.keys + q.key_off + rg.slot_base;
     uint32_t my_count = 0, my_max = 0u, my_min_inv = 0u;
     // the document of slot e is final: its key (0 = not in the map or NaN), its map entry in score-map mode
     auto report = [&](uint32_t e, uint32_t dl, float score, bool in_map) {
@@ -390,7 +344,7 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
         if (b.map_idx) {
             // score-map mode (a batch of ONE query): slot = position of the entry in the map's candidate list, the
             // per-document table points back at it (ScoreMapDev, facets.hip) — NaN scores included, they count
-            const uint32_t pos = slot_base + e;
+            const uint32_t pos = rg.slot_base + e;
             b.map_idx[pos] = map_doc;
             if (map_doc != 0xffffffffu) {
                 b.map_score[pos] = map_score;
@@ -399,97 +353,206 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
         }
     };
 
-    // ---- 5. singletons are scored by their posting's thread; the others park their normalised tf in their token's cell
-    uint32_t pcell[kPerThread];  // the document's first cell (kNoCell: reported already / dropped)
+    // ---- 5. a singleton is scored and reported by its posting's lane; a posting of any other document parks its normalised
+    // tf in its token's cell and leaves its own slot empty (the document's key goes to the lent slot in phase 6)
+    uint32_t pcell[NITER];  // multi-list queries only: the posting's cell (kNoCell: none)
 #pragma unroll
-    for (int n = 0; n < kPerThread; ++n) {
+    for (int n = 0; n < NITER; ++n) {
         const uint32_t e = threadIdx.x + n * kThreads;
+        const uint32_t dl = pk[n] & 0xffffu;
+        const uint32_t tok = (pk[n] >> 25) & 63u;
+        const mask_t m = pm[n];
+        const bool is_multi = (m & (m - 1)) != 0 || (m & multi) != 0;
         pcell[n] = kNoCell;
-        if (e >= cap) continue;
-        if (!pk_kept(pk[n])) {
-            report(e, 0u, 0.0f, false);
-            continue;
-        }
-        const uint32_t cb = cell_base[prank[n]];
-        const uint32_t key = seg_key[pk_seg(pk[n])];
-        const uint32_t tok = key >> 10;
-        if (cb == kNoCell) {
-            DocFold f;
-            f.add(tok, pv[n], idf, q.k, k1);
-            const bool in_map = f.finish(idf, q.k, k1, q.use_threshold, q.threshold);
-            report(e, pk_dl(pk[n]), f.score, in_map);
-            continue;
-        }
-        pcell[n] = cb;
-        const unsigned long long m = dmask[prank[n]];
-        const uint32_t c = cb + (uint32_t)__popcll(m & ((1ull << tok) - 1ull));
-        if (c == cb) owner[cb] = (uint16_t)e;  // any posting of the document's first token reports it
-        if (ranks == 0u) cellv[c] = 0.0f + 1.0f * pv[n];  // the token's only list
-    }
-    if (ranks != 0u && n_cells != 0u) {
-        // lists of one token add in reference order (a document is at most once in a list: no two postings of a pass share a cell)
-        for (uint32_t p = 0; p <= ranks; ++p) {
-#pragma unroll
-            for (int n = 0; n < kPerThread; ++n) {
-                if (pcell[n] == kNoCell) continue;
-                const uint32_t key = seg_key[pk_seg(pk[n])];
-                if ((key & 1023u) != p) continue;
-                const uint32_t tok = key >> 10;
-                const unsigned long long m = dmask[prank[n]];
-                const uint32_t c = pcell[n] + (uint32_t)__popcll(m & ((1ull << tok) - 1ull));
-                cellv[c] = cellv[c] + 1.0f * pv[n];
+        float score = 0.0f;
+        bool in_map = false, lends = false;
+        if (!is_multi) {
+            if (m != 0) {  // (a dropped posting reports an empty slot)
+                DocFold f;
+                f.add(tok, pv[n], L.idf, q.k, k1);
+                in_map = f.finish(L.idf, q.k, k1, q.use_threshold, q.threshold);
+                score = f.score;
             }
-            __syncthreads();
+        } else {
+            const uint32_t below = mask_popc((mask_t)(m & (((mask_t)1 << tok) - 1)));
+            if (ranks == 0u) {
+                lends = pcb[n] != kNoCell;  // THE lender: phase 6 writes its slot, nobody else does
+                const uint32_t cb = lends ? pcb[n] : (uint32_t)L.cell_base[prank[n]];
+                cellv[cb + below] = 0.0f + 1.0f * pv[n];  // the token's only list
+            } else {
+                const uint32_t cb = L.cell_base[prank[n]];
+                if (below == 0) own[cb] = e | (dl << 16);  // any posting of the document's first token lends its slot ...
+                pcell[n] = cb + below;                     // ... and all of them write their slot empty now
+            }
         }
+        if (e < cap && !lends) report(e, dl, score, in_map);
     }
     if (n_cells != 0u) {  // (workgroup-uniform)
-        __syncthreads();
-        // ---- 6. one thread per multi-posting document folds its cells, tokens ascending
-        for (uint32_t d = threadIdx.x; d < n_touched; d += kThreads) {
-            const uint32_t cb = cell_base[d];
-            if (cb == kNoCell) continue;
-            unsigned long long m = dmask[d];
-            DocFold f;
-            for (uint32_t i = 0; m != 0ull; ++i) {
-                const uint32_t tok = (uint32_t)__ffsll((long long)m) - 1u;
-                m &= m - 1ull;
-                f.add_summed(tok, cellv[cb + i], idf, q.k, k1);
+        if (ranks != 0u) {
+            // lists of one token add in reference order (a document is at most once in a list: no two postings of a pass
+            // share a cell); one pass per rank, a barrier between them
+            for (uint32_t p = 0; p <= ranks; ++p) {
+                __syncthreads();
+#pragma unroll
+                for (int n = 0; n < NITER; ++n) {
+                    if (pcell[n] == kNoCell) continue;
+                    if ((L.seg_key[(pk[n] >> 17) & 0xffu] & 1023u) != p) continue;
+                    cellv[pcell[n]] = cellv[pcell[n]] + 1.0f * pv[n];
+                }
             }
-            const bool in_map = f.finish(idf, q.k, k1, q.use_threshold, q.threshold);
-            cellv[cb] = f.score;
-            if (in_map) cell_base[d] = (uint16_t)(cb | kInMap);
+            // multi-list queries wrote the lent slot empty in phase 5 and write the document's entry there now: the first
+            // store must have reached L2 before the second is issued (one-list queries never write a slot twice)
+            __threadfence();
         }
         __syncthreads();
-        // ---- 7. the posting that owns the document's first cell reports it, its other postings leave their slots empty
-#pragma unroll
-        for (int n = 0; n < kPerThread; ++n) {
-            if (pcell[n] == kNoCell) continue;
-            const uint32_t e = threadIdx.x + n * kThreads;
-            const uint32_t cb = pcell[n];
-            if (owner[cb] == (uint16_t)e) report(e, pk_dl(pk[n]), cellv[cb], (cell_base[prank[n]] & kInMap) != 0u);
-            else report(e, 0u, 0.0f, false);
+        // ---- 6. one lane per multi-posting document: fold its cells with tokens ascending, report it in the slot lent to it
+        for (uint32_t i = threadIdx.x; i < n_multi; i += kThreads) {
+            const uint32_t d = L.multi_list[i];
+            const uint32_t cb = L.cell_base[d];
+            mask_t m = L.dmask[d];
+            DocFold f;
+            for (uint32_t c = cb; m != 0; ++c) {
+                const uint32_t tok = mask_first(m);
+                m &= m - 1;
+                f.add_summed(tok, cellv[c], L.idf, q.k, k1);
+            }
+            const bool in_map = f.finish(L.idf, q.k, k1, q.use_threshold, q.threshold);
+            const uint32_t o = own[cb];
+            report(o & 0xffffu, o >> 16, f.score, in_map);
         }
     }
 
-    my_count = wave_sum_u32(my_count);
-    if (lane == 0 && my_count) atomicAdd(&red[1], my_count);
+    if (my_count) atomicAdd(&L.red[1], my_count);
     if (q.track_minmax) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, off, 64));
-            my_min_inv = max(my_min_inv, (uint32_t)__shfl_xor((int)my_min_inv, off, 64));
-        }
-        if (lane == 0) {
-            if (my_max) atomicMax(&red[2], my_max);
-            if (my_min_inv) atomicMax(&red[3], my_min_inv);
-        }
+        if (my_max) atomicMax(&L.red[2], my_max);
+        if (my_min_inv) atomicMax(&L.red[3], my_min_inv);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (red[1]) atomicAdd(&b.results[qi].count, red[1]);
-        if (red[2]) atomicMax(&b.results[qi].max_key, red[2]);
-        if (red[3]) atomicMax(&b.results[qi].min_inv, red[3]);
+        if (L.red[1]) atomicAdd(&b.results[qi].count, L.red[1]);
+        if (L.red[2]) atomicMax(&b.results[qi].max_key, L.red[2]);
+        if (L.red[3]) atomicMax(&b.results[qi].min_inv, L.red[3]);
     }
+}
+
+// DF_ONLY: the counting pass (corpus_docs.len() per token under a filter / with several lists per token).
+template <bool DF_ONLY, bool WIDE>
+__global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
+    __shared__ ScoreLds<WIDE> L;
+
+    // (query, range) of this workgroup: the batch's pairs laid end to end
+    uint32_t qi = 0;
+    {
+        uint32_t lo = 0, hi = b.n_queries;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (b.range_start[mid] <= blockIdx.x) lo = mid; else hi = mid;
+        }
+        qi = lo;
+    }
+    const RangeQuery q = b.queries[qi];
+    const uint32_t r = blockIdx.x - b.range_start[qi];
+    if (r >= q.n_ranges) return;
+    if (DF_ONLY && !q.want_df) return;
+    const uint32_t ns = q.seg_end - q.seg_begin;
+    const RangeSeg* segs = b.segs + q.seg_begin;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    ScoreRange rg;
+    rg.qi = qi;
+    rg.count_each = DF_ONLY && q.want_df == 2u;  // every token has ONE list: a kept posting is its own (token, document) pair
+    rg.n_words = (min(q.width, kRangeMaxWidth) + 31u) >> 5;
+    rg.doc0 = r * q.width;
+
+    // ---- 0. wave 0: the range's run of every reference, their offsets among the gathered postings, the block table;
+    //         the other waves: clear the bitmap
+    if (wave == 0) {
+        if (lane < 4) L.red[lane] = 0;
+        if (lane == 0) {
+            L.multi_tok = 0ull;
+            L.max_rank = 0u;
+            L.cell_cursor = 0u;
+            L.seg_off[0] = 0;
+        }
+        L.df_lds[lane] = 0;
+        static_assert(kMaxTokens == 64, "one lane per token");
+        if (!DF_ONLY) L.idf[lane] = lane < q.n_tokens ? b.idf[(size_t)qi * kMaxTokens + lane] : 0.0f;
+        // (the bounds of a range are contiguous over the references, and their address does not depend on the reference
+        // table: both loads are issued together); slot base = postings of the query in earlier ranges
+        uint32_t carry = 0, base_part = 0;
+        unsigned long long multi = 0ull;
+        uint32_t mrank = 0;
+        const uint32_t* row = b.bounds + q.bounds_base + (uint64_t)r * ns;
+        for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            uint32_t x = 0;
+            if (i < ns) {
+                const uint32_t b0 = row[i], b1 = row[ns + i];
+                const RangeSeg sg = segs[i];
+                L.seg_pos[i] = sg.post_begin + b0;
+                L.seg_key[i] = sg.tok_rank;
+                L.seg_boost[i] = sg.boost;
+                L.seg_avg[i] = sg.avg_len;
+                base_part += b0;
+                x = b1 - b0;
+                const uint32_t rank = sg.tok_rank & 1023u;
+                if (rank) {
+                    multi |= 1ull << (sg.tok_rank >> 10);
+                    mrank = max(mrank, rank);
+                }
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {  // inclusive scan of the run lengths, 64 references at a time
+                const uint32_t y = __shfl_up(x, off, 64);
+                if ((int)lane >= off) x += y;
+            }
+            if (i < ns) L.seg_off[i + 1] = carry + x;
+            carry += __shfl(x, 63, 64);
+        }
+        if (base_part) atomicAdd(&L.red[0], base_part);
+        if (mrank) {
+            atomicOr(&L.multi_tok, multi);
+            atomicMax(&L.max_rank, mrank);
+        }
+        // block table: the run that holds gathered posting 32 * lane (the wave's own LDS writes above are visible to it:
+        // LDS operations of one wave complete in order)
+        if (carry <= kRangeCap && (lane << kBlkShift) < carry) {
+            const uint32_t e = lane << kBlkShift;
+            uint32_t lo = 0, hi = ns;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (L.seg_off[mid] <= e) lo = mid; else hi = mid;
+            }
+            L.blk_run[lane] = (uint16_t)lo;
+        }
+    } else if (!rg.count_each) {
+        for (uint32_t w = threadIdx.x - 64u; w < rg.n_words; w += kThreads - 64u) L.bitmap()[w] = 0u;
+    }
+    __syncthreads();
+    const uint32_t cap = L.seg_off[ns];
+    if (cap == 0) return;
+    rg.cap = cap;
+    rg.slot_base = L.red[0];
+    if (cap > kRangeCap) {
+        // the query is rerun with smaller ranges; its slots still reach the batch's top-k, so they must be empty
+        if (!DF_ONLY)
+            for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
+                b.keys[q.key_off + rg.slot_base + e] = 0ull;
+                if (b.map_idx) b.map_idx[rg.slot_base + e] = 0xffffffffu;
+            }
+        if (threadIdx.x == 0) b.results[qi].overflow = 1;
+        return;
+    }
+    // rounds of the per-posting phases (workgroup-uniform): the bodies that exist are 2, 4, 5, 6 and 8 rounds — a range of
+    // the targeted ~1 280 postings takes 5 or 6
+    const uint32_t n_iter = (cap + kThreads - 1) / kThreads;
+    if (DF_ONLY) {
+        if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4>(b, q, rg, L);
+        else score_body<DF_ONLY, WIDE, 8>(b, q, rg, L);
+    } else if (n_iter <= 2) score_body<DF_ONLY, WIDE, 2>(b, q, rg, L);
+    else if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4>(b, q, rg, L);
+    else if (n_iter == 5) score_body<DF_ONLY, WIDE, 5>(b, q, rg, L);
+    else if (n_iter == 6) score_body<DF_ONLY, WIDE, 6>(b, q, rg, L);
+    else score_body<DF_ONLY, WIDE, 8>(b, q, rg, L);
 }
 
 // Hybrid path: the full-text score of given documents.  One WAVE per document: lane i looks the document up in the
@@ -599,8 +662,13 @@ int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStr
     ProfScope prof(&ctx->prof, df_only ? "bm25_range_df" : "bm25_range_score", stream);
     const uint32_t grid = b.range_start[b.n_queries];
     ORAMA_REQUIRE(grid >= b.max_ranges, "internal: range_start table not filled");
-    if (df_only) hipLaunchKernelGGL(range_score_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, b);
-    else hipLaunchKernelGGL(range_score_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, b);
+    if (b.wide_masks) {
+        if (df_only) hipLaunchKernelGGL((range_score_kernel<true, true>), dim3(grid), dim3(kThreads), 0, stream, b);
+        else hipLaunchKernelGGL((range_score_kernel<false, true>), dim3(grid), dim3(kThreads), 0, stream, b);
+    } else {
+        if (df_only) hipLaunchKernelGGL((range_score_kernel<true, false>), dim3(grid), dim3(kThreads), 0, stream, b);
+        else hipLaunchKernelGGL((range_score_kernel<false, false>), dim3(grid), dim3(kThreads), 0, stream, b);
+    }
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -10,6 +10,7 @@ import pytest
 import oramacore_amd as oa
 import util
 from oracle import oracle as orc
+from oramacore_amd import _native as N
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -145,9 +146,17 @@ def test_wide_batches_equal_solo_queries(ctx, d):
     queries = util.gaussian_rows(256, d, seed=60 + d)
     picks = (0, 31, 32, 63, 64, 69, 96, 100, 127, 128, 160, 199, 224, 255)
     solos = {id(allow): {i: st.storage_search(queries[i], 30, allow) for i in picks} for allow in (None, bm)}
-    # every wide form: 4 = K2q (queries stationary in registers, the default), 5 = K2h (K loop split over a wave pair),
-    # 2 / 3 = K2d geometries, 1 = K2c
+    # every wide form: 4 = K2q (queries stationary in registers, the default), 2 / 3 = K2d geometries; 5 = K2h (K loop split
+    # over a wave pair) and 1 = K2c exist in comparison builds only (ORAMA_COMPARISON_KERNELS=1) — the product library
+    # refuses them with ORAMA_ERR_UNSUPPORTED
+    from oramacore_amd import _build
+
     for mode in (4, 5, 2, 3, 1):
+        if mode in (1, 5) and not _build.comparison_build():
+            with pytest.raises(oa.OramaError) as ei:
+                ctx.set_f16_wide(mode)
+            assert ei.value.status == N.ORAMA_ERR_UNSUPPORTED
+            continue
         ctx.set_f16_wide(mode)
         # repeated: the pipelines are asynchronous (LDS DMA rings) — catch races
         for allow in ((None, bm, None, None) if mode == 4 else (None, bm)):
