@@ -102,7 +102,9 @@ static_assert(kRangeCap / kThreads == 8, "a lane carries at most 8 postings thro
 constexpr uint32_t kBitWords = kRangeMaxWidth / 32;        // bitmap words of the widest range
 constexpr int kWordsPerThread = kBitWords / kThreads;
 constexpr uint32_t kBlkShift = 5, kBlocks = kRangeCap >> kBlkShift;  // run lookup table: one entry per 32 gathered postings
-constexpr uint32_t kNoCell = 0xffffu;                      // cell_base of a singleton document
+constexpr uint32_t kNoCell = 0xffffu;                      // "this posting was handed no cells"
+constexpr uint32_t kCells = 1024;                          // cells of the multi-posting documents of one range ...
+constexpr uint32_t kMultiMax = 512;                        // ... and how many such documents: more raise `overflow` (narrower ranges)
 static_assert(kRangeCap % kThreads == 0 && kBitWords % kThreads == 0, "phase loops are unrolled over whole threads");
 static_assert(kRangeCap <= 0x8000u && kRangeMaxWidth <= 0x10000u, "posting slot and local document share one 32-bit word");
 static_assert(kBlocks <= 64, "the block table is built by one wave");
@@ -120,21 +122,25 @@ __device__ __forceinline__ uint32_t mask_popc(unsigned long long m) { return (ui
 __device__ __forceinline__ uint32_t mask_first(uint32_t m) { return (uint32_t)__ffs((int)m) - 1u; }
 __device__ __forceinline__ uint32_t mask_first(unsigned long long m) { return (uint32_t)__ffsll((long long)m) - 1u; }
 
-// LDS of one scoring workgroup.  WIDE: queries of more than 32 tokens (64-bit presence masks).
-template <bool WIDE>
+// LDS of one scoring workgroup.  WIDE: queries of more than 32 tokens (64-bit presence masks); NS_CAP: references (non-empty
+// posting lists) the tables hold — 32 for ordinary queries, kRangeMaxRefs for queries expanded to many lists.  Kept under
+// 20 KB for the common instantiation: the kernel's waves spend most of their cycles waiting (dependent LDS and global
+// loads, barriers), so the workgroups resident per CU set its speed (profiles/r04_k3r_sq_counters_v2.md: at 39.6 KB —
+// 16 waves per CU — the launch took as long as with twice the vector instructions).
+template <bool WIDE, int NS_CAP>
 struct ScoreLds {
     typedef typename MaskOf<WIDE>::type mask_t;
-    // region A, phases 1-3: the range's document bitmap + the exclusive popcount prefix of its words (u16: at most 2 048
-    // documents are touched); phases 5-6: the cells of the multi-posting documents + per first cell the slot and local
-    // document of the posting that lends the document its key slot
-    uint32_t region_a[2 * kRangeCap];
-    mask_t dmask[kRangeCap];                    // per touched document (by rank): tokens present
-    uint16_t cell_base[kRangeCap];              // per touched document: first cell, kNoCell = singleton
-    uint16_t multi_list[kRangeCap];             // the multi-posting documents (ranks), densely
-    unsigned long long seg_pos[kRangeMaxRefs];  // first posting of each reference inside this range
-    uint32_t seg_off[kRangeMaxRefs + 1];        // start of each reference's run among the gathered postings
-    uint32_t seg_key[kRangeMaxRefs];            // token << 10 | rank
-    float seg_boost[kRangeMaxRefs], seg_avg[kRangeMaxRefs];
+    // region A, phases 1-3: the range's document bitmap (one bit per document) + the exclusive popcount prefix of its
+    // words (u16: at most 2 048 documents are touched).
+    // Phases 4-6: the multi-posting documents — their cells (one f32 per (document, token present)) and per document
+    // its first cell, its presence mask and the (slot, local document) of the posting that lends it its key slot.
+    static constexpr uint32_t kRegionWords = kCells + kMultiMax * 2 + kMultiMax / 2 + (WIDE ? kMultiMax : 0);
+    uint32_t region_a[kRegionWords];
+    mask_t dmask[kRangeCap];                    // per touched document (by rank): tokens present; after phase 4: first cell | list position << 16
+    unsigned long long seg_pos[NS_CAP];         // first posting of each reference inside this range
+    uint32_t seg_off[NS_CAP + 1];               // start of each reference's run among the gathered postings
+    uint32_t seg_key[NS_CAP];                   // token << 10 | rank
+    float seg_boost[NS_CAP], seg_avg[NS_CAP];
     uint16_t blk_run[kBlocks];                  // run that holds gathered posting 32 i
     float idf[kMaxTokens];
     uint32_t df_lds[kMaxTokens];
@@ -145,9 +151,11 @@ struct ScoreLds {
     __device__ __forceinline__ uint32_t* bitmap() { return region_a; }
     __device__ __forceinline__ uint16_t* word_rank() { return reinterpret_cast<uint16_t*>(region_a + kBitWords); }
     __device__ __forceinline__ float* cellv() { return reinterpret_cast<float*>(region_a); }
-    __device__ __forceinline__ uint32_t* own() { return region_a + kRangeCap; }
+    __device__ __forceinline__ uint32_t* md_own() { return region_a + kCells; }
+    __device__ __forceinline__ mask_t* md_mask() { return reinterpret_cast<mask_t*>(region_a + kCells + kMultiMax); }
+    __device__ __forceinline__ uint16_t* md_cb() { return reinterpret_cast<uint16_t*>(region_a + kCells + kMultiMax + kMultiMax * (WIDE ? 2 : 1)); }
 };
-static_assert(2 * kRangeCap * 4 >= kBitWords * 4 + kBitWords * 2, "bitmap + prefix fit the cell region");
+static_assert((kCells + kMultiMax * 2 + kMultiMax / 2) * 4 >= kBitWords * 4 + kBitWords * 2, "bitmap + prefix fit region A");
 
 // What phases 1-6 need to know about their workgroup (all workgroup-uniform).
 struct ScoreRange {
@@ -159,15 +167,17 @@ struct ScoreRange {
 // per-posting loops are straight-line code — a run-time round count inside one body made the compiler shuffle the whole
 // register arrays at every round's branch (a third of the vector instructions of the first form of this kernel).  Rounds
 // past the end (e >= cap) read the last posting again and are not `kept`.
-template <bool DF_ONLY, bool WIDE, int NITER>
-__device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery& q, const ScoreRange& rg, ScoreLds<WIDE>& L) {
+template <bool DF_ONLY, bool WIDE, int NS_CAP, int NITER>
+__device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery& q, const ScoreRange& rg, ScoreLds<WIDE, NS_CAP>& L) {
     typedef typename MaskOf<WIDE>::type mask_t;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t cap = rg.cap, qi = rg.qi, doc0 = rg.doc0, n_words = rg.n_words;
     uint32_t* const bitmap = L.bitmap();
     uint16_t* const word_rank = L.word_rank();
     float* const cellv = L.cellv();
-    uint32_t* const own = L.own();
+    uint32_t* const md_own = L.md_own();
+    mask_t* const md_mask = L.md_mask();
+    uint16_t* const md_cb = L.md_cb();
 
     // ---- 1. gather: posting e belongs to the run whose [seg_off[i], seg_off[i+1]) holds it
     uint32_t pk[NITER];  // [kept:1 | token:6 | run:8 | pad:1 | local document:16]
@@ -280,39 +290,57 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
     // ---- 4. cells for the documents that are not singletons (more than one token, or a token with several lists):
     // popcount(mask) cells each and a place in the dense list of such documents, both handed out by ONE returning LDS
     // atomic (cells in the low half, list position in the high half).  One-list queries: the posting of the document's
-    // FIRST token — there is exactly one — asks, and lends the document its key slot (`own`; that half of region A is
-    // not in use yet).  Multi-list queries: one lane per touched document asks.
+    // FIRST token — there is exactly one — asks, and lends the document its key slot.  Multi-list queries: one lane per
+    // touched document asks.  Every posting has read its document's mask before (barrier): the mask's slot then takes
+    // what the document's other postings need, first cell | list position << 16.
     const mask_t multi = (mask_t)L.multi_tok;
     const uint32_t ranks = L.max_rank;  // a token has at most ranks + 1 lists
     mask_t pm[NITER];      // the document's presence mask (0: dropped posting)
+#pragma unroll
+    for (int n = 0; n < NITER; ++n) pm[n] = (pk[n] >> 31) ? L.dmask[prank[n]] : (mask_t)0;
+    __syncthreads();  // (the bitmap and its prefix are dead from here on: region A holds the multi-document tables)
     uint32_t pcb[NITER];   // one-list queries: the first cell this posting was handed (kNoCell: it did not ask)
+    auto hand_out = [&](mask_t m, uint32_t rank) -> uint32_t {
+        const uint32_t cells = mask_popc(m);
+        const uint32_t got = atomicAdd(&L.cell_cursor, cells | (1u << 16));
+        const uint32_t cb = got & 0xffffu, mi = got >> 16;
+        if (cb + cells <= kCells && mi < kMultiMax) {  // (beyond: the range overflows, nothing of it is used)
+            L.dmask[rank] = (mask_t)(cb | (mi << 16));
+            md_mask[mi] = m;
+            md_cb[mi] = (uint16_t)cb;
+        }
+        return got;
+    };
 #pragma unroll
     for (int n = 0; n < NITER; ++n) {
-        pm[n] = (pk[n] >> 31) ? L.dmask[prank[n]] : (mask_t)0;
         pcb[n] = kNoCell;
         if (ranks == 0u) {
             const mask_t below = pm[n] & (((mask_t)1 << ((pk[n] >> 25) & 63u)) - 1);
             if ((pm[n] & (pm[n] - 1)) != 0 && below == 0) {
-                const uint32_t got = atomicAdd(&L.cell_cursor, mask_popc(pm[n]) | (1u << 16));
+                const uint32_t got = hand_out(pm[n], prank[n]);
                 pcb[n] = got & 0xffffu;
-                L.cell_base[prank[n]] = (uint16_t)(got & 0xffffu);
-                L.multi_list[got >> 16] = (uint16_t)prank[n];
-                own[got & 0xffffu] = (threadIdx.x + n * kThreads) | ((pk[n] & 0xffffu) << 16);
+                if ((got >> 16) < kMultiMax) md_own[got >> 16] = (threadIdx.x + n * kThreads) | ((pk[n] & 0xffffu) << 16);
             }
         }
     }
     if (ranks != 0u) {
         for (uint32_t d = threadIdx.x; d < n_touched; d += kThreads) {
             const mask_t m = L.dmask[d];
-            if ((m & (m - 1)) != 0 || (m & multi) != 0) {
-                const uint32_t got = atomicAdd(&L.cell_cursor, mask_popc(m) | (1u << 16));
-                L.cell_base[d] = (uint16_t)(got & 0xffffu);
-                L.multi_list[got >> 16] = (uint16_t)d;
-            }
+            if ((m & (m - 1)) != 0 || (m & multi) != 0) hand_out(m, d);
         }
     }
-    __syncthreads();  // (the bitmap and its prefix are dead from here on: region A holds the cells)
+    __syncthreads();
     const uint32_t n_cells = L.cell_cursor & 0xffffu, n_multi = L.cell_cursor >> 16;
+    if (n_cells > kCells || n_multi > kMultiMax) {
+        // more multi-posting documents than the tables hold (terms that occur together in most of their documents): like a
+        // range of too many postings, the query is rerun with narrower ranges; its slots must be empty meanwhile
+        for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
+            b.keys[q.key_off + rg.slot_base + e] = 0ull;
+            if (b.map_idx) b.map_idx[rg.slot_base + e] = 0xffffffffu;
+        }
+        if (threadIdx.x == 0) b.results[qi].overflow = 1;
+        return;
+    }
     if (ranks != 0u && n_cells != 0u) {  // cells that several lists add into start from 0.0 (Iterator::sum)
         for (uint32_t c = threadIdx.x; c < n_cells; c += kThreads) cellv[c] = 0.0f;
         __syncthreads();
@@ -377,12 +405,12 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
             const uint32_t below = mask_popc((mask_t)(m & (((mask_t)1 << tok) - 1)));
             if (ranks == 0u) {
                 lends = pcb[n] != kNoCell;  // THE lender: phase 6 writes its slot, nobody else does
-                const uint32_t cb = lends ? pcb[n] : (uint32_t)L.cell_base[prank[n]];
+                const uint32_t cb = lends ? pcb[n] : ((uint32_t)L.dmask[prank[n]] & 0xffffu);
                 cellv[cb + below] = 0.0f + 1.0f * pv[n];  // the token's only list
             } else {
-                const uint32_t cb = L.cell_base[prank[n]];
-                if (below == 0) own[cb] = e | (dl << 16);  // any posting of the document's first token lends its slot ...
-                pcell[n] = cb + below;                     // ... and all of them write their slot empty now
+                const uint32_t slot = (uint32_t)L.dmask[prank[n]];
+                if (below == 0) md_own[slot >> 16] = e | (dl << 16);  // any posting of the document's first token lends its slot ...
+                pcell[n] = (slot & 0xffffu) + below;                  // ... and all of them write their slot empty now
             }
         }
         if (e < cap && !lends) report(e, dl, score, in_map);
@@ -407,9 +435,8 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
         __syncthreads();
         // ---- 6. one lane per multi-posting document: fold its cells with tokens ascending, report it in the slot lent to it
         for (uint32_t i = threadIdx.x; i < n_multi; i += kThreads) {
-            const uint32_t d = L.multi_list[i];
-            const uint32_t cb = L.cell_base[d];
-            mask_t m = L.dmask[d];
+            const uint32_t cb = md_cb[i];
+            mask_t m = md_mask[i];
             DocFold f;
             for (uint32_t c = cb; m != 0; ++c) {
                 const uint32_t tok = mask_first(m);
@@ -417,7 +444,7 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
                 f.add_summed(tok, cellv[c], L.idf, q.k, k1);
             }
             const bool in_map = f.finish(L.idf, q.k, k1, q.use_threshold, q.threshold);
-            const uint32_t o = own[cb];
+            const uint32_t o = md_own[i];
             report(o & 0xffffu, o >> 16, f.score, in_map);
         }
     }
@@ -436,9 +463,9 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
 }
 
 // DF_ONLY: the counting pass (corpus_docs.len() per token under a filter / with several lists per token).
-template <bool DF_ONLY, bool WIDE>
+template <bool DF_ONLY, bool WIDE, int NS_CAP>
 __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
-    __shared__ ScoreLds<WIDE> L;
+    __shared__ ScoreLds<WIDE, NS_CAP> L;
 
     // (query, range) of this workgroup: the batch's pairs laid end to end
     uint32_t qi = 0;
@@ -546,13 +573,13 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     // the targeted ~1 280 postings takes 5 or 6
     const uint32_t n_iter = (cap + kThreads - 1) / kThreads;
     if (DF_ONLY) {
-        if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4>(b, q, rg, L);
-        else score_body<DF_ONLY, WIDE, 8>(b, q, rg, L);
-    } else if (n_iter <= 2) score_body<DF_ONLY, WIDE, 2>(b, q, rg, L);
-    else if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4>(b, q, rg, L);
-    else if (n_iter == 5) score_body<DF_ONLY, WIDE, 5>(b, q, rg, L);
-    else if (n_iter == 6) score_body<DF_ONLY, WIDE, 6>(b, q, rg, L);
-    else score_body<DF_ONLY, WIDE, 8>(b, q, rg, L);
+        if (n_iter <= 4) score_body<DF_ONLY, WIDE, NS_CAP, 4>(b, q, rg, L);
+        else score_body<DF_ONLY, WIDE, NS_CAP, 8>(b, q, rg, L);
+    } else if (n_iter <= 2) score_body<DF_ONLY, WIDE, NS_CAP, 2>(b, q, rg, L);
+    else if (n_iter <= 4) score_body<DF_ONLY, WIDE, NS_CAP, 4>(b, q, rg, L);
+    else if (n_iter == 5) score_body<DF_ONLY, WIDE, NS_CAP, 5>(b, q, rg, L);
+    else if (n_iter == 6) score_body<DF_ONLY, WIDE, NS_CAP, 6>(b, q, rg, L);
+    else score_body<DF_ONLY, WIDE, NS_CAP, 8>(b, q, rg, L);
 }
 
 // Hybrid path: the full-text score of given documents.  One WAVE per document: lane i looks the document up in the
@@ -662,13 +689,17 @@ int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStr
     ProfScope prof(&ctx->prof, df_only ? "bm25_range_df" : "bm25_range_score", stream);
     const uint32_t grid = b.range_start[b.n_queries];
     ORAMA_REQUIRE(grid >= b.max_ranges, "internal: range_start table not filled");
-    if (b.wide_masks) {
-        if (df_only) hipLaunchKernelGGL((range_score_kernel<true, true>), dim3(grid), dim3(kThreads), 0, stream, b);
-        else hipLaunchKernelGGL((range_score_kernel<false, true>), dim3(grid), dim3(kThreads), 0, stream, b);
+    // instantiation by the batch's widest query: 64-bit token masks beyond 32 tokens, big reference tables beyond 32 lists
+    const bool wide = b.wide_masks != 0, many = b.max_refs > 32;
+#define ORAMA_SCORE_LAUNCH(DF, W, NS) hipLaunchKernelGGL((range_score_kernel<DF, W, NS>), dim3(grid), dim3(kThreads), 0, stream, b)
+    if (df_only) {
+        if (wide) { if (many) ORAMA_SCORE_LAUNCH(true, true, (int)kRangeMaxRefs); else ORAMA_SCORE_LAUNCH(true, true, 32); }
+        else { if (many) ORAMA_SCORE_LAUNCH(true, false, (int)kRangeMaxRefs); else ORAMA_SCORE_LAUNCH(true, false, 32); }
     } else {
-        if (df_only) hipLaunchKernelGGL((range_score_kernel<true, false>), dim3(grid), dim3(kThreads), 0, stream, b);
-        else hipLaunchKernelGGL((range_score_kernel<false, false>), dim3(grid), dim3(kThreads), 0, stream, b);
+        if (wide) { if (many) ORAMA_SCORE_LAUNCH(false, true, (int)kRangeMaxRefs); else ORAMA_SCORE_LAUNCH(false, true, 32); }
+        else { if (many) ORAMA_SCORE_LAUNCH(false, false, (int)kRangeMaxRefs); else ORAMA_SCORE_LAUNCH(false, false, 32); }
     }
+#undef ORAMA_SCORE_LAUNCH
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -58,6 +58,7 @@ struct RangeBatch {
     uint64_t total_postings = 0;         // referenced by the whole batch
     uint32_t max_ranges = 0;             // most ranges of a query of the batch
     uint32_t wide_masks = 0;             // a query of the batch has more than 32 tokens: 64-bit token masks in the scoring launch
+    uint32_t max_refs = 0;               // most references (non-empty lists) of a query of the batch: sizes the launch's LDS tables
     // the scoring launch is a 1-D grid over the (query, range) pairs that exist: workgroup w scores range
     // w - range_start[q] of the query q with range_start[q] <= w < range_start[q + 1]
     uint32_t range_start[kRangeBatchMax + 1] = {0};

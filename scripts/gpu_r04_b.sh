@@ -12,13 +12,13 @@ timeout 900 python -m pytest tests/test_bm25_ranges_gpu.py tests/test_fulltext_g
 echo "== k3r A/B (comparison library)"
 timeout 600 python scripts/k3r_ab.py 2>&1 | tail -30 | tee $O/k3r_ab.log
 echo "== postings per range sweep"
-for T in 1024 1280 1536 1792; do echo "target $T"; ORAMA_K3R_TARGET=$T timeout 200 python scripts/k3r_chunk_probe.py 2>&1 | tail -1; done | tee $O/k3r_target_sweep.log
+for T in 1280 1536 1792 2000; do echo "target $T"; ORAMA_K3R_TARGET=$T timeout 200 python scripts/k3r_chunk_probe.py 2>&1 | tail -1; done | tee $O/k3r_target_sweep.log
 echo "== SQ counters"
 bash scripts/k3r_sq_pmc.sh > $O/k3r_sq.txt 2>&1; tail -32 $O/k3r_sq.txt | sort -u
 echo "== pytest -m gpu (all)"
 timeout 2400 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -12 | tee $O/pytest_gpu.log
 echo "== bench (driver command)"
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_all.json 2> $O/bench_all.err; tail -c 300 $O/bench_all.json; echo; tail -5 $O/bench_all.err
-echo "== fp16 slots 3"
+echo "== skip"; exit 0
 timeout 300 python bench.py --workload c5 --rows 10000000 --steps 20 --warmup 3 --no-cpu-baseline --configs none --no-pmc --f16-slots 3 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('c5 shard slots=3', round(d['value']), 'QPS', round(d['ms_per_step'],3), 'ms/step')"
 du -sh $O

@@ -161,6 +161,27 @@ def test_clustered_documents_shrink_the_ranges(ctx):
     corpus.store.close()
 
 
+def test_terms_that_occur_together_overflow_the_cell_tables(ctx):
+    """Round 4's scoring launch keeps the documents with more than one posting of a range in bounded LDS tables (1 024 cells,
+    512 documents).  Terms that occur in the SAME documents — every document of a range is then a multi-posting document —
+    overflow them at the first choice of range width: the query must rerun with narrower ranges and still return the
+    oracle's bits.  Also: three terms over the same documents with a threshold, two fields of one token (several lists per
+    token: the cells are summed in reference order), and a mix of both with a filter."""
+    rng = np.random.default_rng(15)
+    n_docs = 400_000
+    together = np.sort(rng.choice(n_docs, size=90_000, replace=False))
+    half = together[::2]
+    other = np.sort(rng.choice(n_docs, size=60_000, replace=False))
+    corpus = Corpus(ctx, n_docs, [(0, together), (0, together), (0, together), (1, together), (0, half), (1, other)], [30.0, 9.0], seed=16)
+    check(ctx, corpus, [(0, 0, 1.0), (1, 1, 1.0)], 2, 100, tag="two terms, same documents")
+    check(ctx, corpus, [(0, 0, 1.0), (1, 1, 2.0), (2, 2, 0.5)], 3, 250, 3, tag="three terms, same documents, threshold")
+    check(ctx, corpus, [(0, 0, 1.0), (0, 3, 1.5), (1, 4, 1.0)], 2, 100, tag="two fields of one token + a subset term")
+    mask = (np.arange(n_docs) % 5) != 2
+    check(ctx, corpus, [(0, 0, 1.0), (0, 3, 1.5), (1, 1, 1.0), (1, 5, 1.0), (2, 4, 1.0)], 3, 64, 2, allow=oa.AllowBitmap.from_mask(mask),
+          allow_mask=mask, tag="mixed, filtered")
+    corpus.store.close()
+
+
 def test_batch_with_mixed_queries(ctx):
     """orama_post_search_batch: queries with different token counts, thresholds and top_k (0 = count only), an empty
     query, a query whose 1 100 references do not fit the sort key (falls back to K3), all under one filter."""
