@@ -102,7 +102,6 @@ static_assert(kRangeCap / kThreads == 8, "a lane carries at most 8 postings thro
 constexpr uint32_t kBitWords = kRangeMaxWidth / 32;        // bitmap words of the widest range
 constexpr int kWordsPerThread = kBitWords / kThreads;
 constexpr uint32_t kBlkShift = 5, kBlocks = kRangeCap >> kBlkShift;  // run lookup table: one entry per 32 gathered postings
-constexpr uint32_t kNoCell = 0xffffu;                      // "this posting was handed no cells"
 constexpr uint32_t kCells = 1024;                          // cells of the multi-posting documents of one range ...
 constexpr uint32_t kMultiMax = 512;                        // ... and how many such documents: more raise `overflow` (narrower ranges)
 static_assert(kRangeCap % kThreads == 0 && kBitWords % kThreads == 0, "phase loops are unrolled over whole threads");
@@ -122,32 +121,30 @@ __device__ __forceinline__ uint32_t mask_popc(unsigned long long m) { return (ui
 __device__ __forceinline__ uint32_t mask_first(uint32_t m) { return (uint32_t)__ffs((int)m) - 1u; }
 __device__ __forceinline__ uint32_t mask_first(unsigned long long m) { return (uint32_t)__ffsll((long long)m) - 1u; }
 
-// LDS of one scoring workgroup.  WIDE: queries of more than 32 tokens (64-bit presence masks); NS_CAP: references (non-empty
-// posting lists) the tables hold — 32 for ordinary queries, kRangeMaxRefs for queries expanded to many lists.  Kept under
-// 20 KB for the common instantiation: the kernel's waves spend most of their cycles waiting (dependent LDS and global
-// loads, barriers), so the workgroups resident per CU set its speed (profiles/r04_k3r_sq_counters_v2.md: at 39.6 KB —
-// 16 waves per CU — the launch took as long as with twice the vector instructions).
-template <bool WIDE, int NS_CAP>
+// LDS of one scoring workgroup.  WIDE: queries of more than 32 references (64-bit presence masks).  Kept under 20 KB for the
+// common instantiation: the kernel's waves spend most of their cycles waiting (dependent LDS and global loads, barriers),
+// so the workgroups resident per CU set its speed (profiles/r04_k3r_sq_counters_v2.md: at 39.6 KB — 16 waves per CU — the
+// launch took as long as with twice the vector instructions).
+template <bool WIDE>
 struct ScoreLds {
     typedef typename MaskOf<WIDE>::type mask_t;
     // region A, phases 1-3: the range's document bitmap (one bit per document) + the exclusive popcount prefix of its
     // words (u16: at most 2 048 documents are touched).
-    // Phases 4-6: the multi-posting documents — their cells (one f32 per (document, token present)) and per document
-    // its first cell, its presence mask and the (slot, local document) of the posting that lends it its key slot.
+    // Phases 4-6: the multi-posting documents — their cells (one f32 per posting) and per document its first cell, its
+    // presence mask and the (slot, local document) of the posting that lends it its key slot.
     static constexpr uint32_t kRegionWords = kCells + kMultiMax * 2 + kMultiMax / 2 + (WIDE ? kMultiMax : 0);
     uint32_t region_a[kRegionWords];
-    mask_t dmask[kRangeCap];                    // per touched document (by rank): tokens present; after phase 4: first cell | list position << 16
-    unsigned long long seg_pos[NS_CAP];         // first posting of each reference inside this range
-    uint32_t seg_off[NS_CAP + 1];               // start of each reference's run among the gathered postings
-    uint32_t seg_key[NS_CAP];                   // token << 10 | rank
-    float seg_boost[NS_CAP], seg_avg[NS_CAP];
+    mask_t dmask[kRangeCap];                    // per touched document (by rank): REFERENCES (lists) that hold it; after phase 4: first cell
+    unsigned long long seg_pos[kRangeMaxRefs];  // first posting of each reference inside this range
+    uint32_t seg_off[kRangeMaxRefs + 1];        // start of each reference's run among the gathered postings
+    uint32_t seg_key[kRangeMaxRefs];            // token << 10 | rank
+    float seg_boost[kRangeMaxRefs], seg_avg[kRangeMaxRefs];
     uint16_t blk_run[kBlocks];                  // run that holds gathered posting 32 i
     float idf[kMaxTokens];
     uint32_t df_lds[kMaxTokens];
     uint32_t wave_tot[kWaves];
     uint32_t red[4];                            // slot base, count, max key, ~min key
-    unsigned long long multi_tok;               // tokens with more than one list
-    uint32_t max_rank, cell_cursor;             // cell_cursor: cells handed out | multi documents << 16
+    uint32_t cell_cursor;                       // cells handed out | multi documents << 16
     __device__ __forceinline__ uint32_t* bitmap() { return region_a; }
     __device__ __forceinline__ uint16_t* word_rank() { return reinterpret_cast<uint16_t*>(region_a + kBitWords); }
     __device__ __forceinline__ float* cellv() { return reinterpret_cast<float*>(region_a); }
@@ -156,6 +153,7 @@ struct ScoreLds {
     __device__ __forceinline__ uint16_t* md_cb() { return reinterpret_cast<uint16_t*>(region_a + kCells + kMultiMax + kMultiMax * (WIDE ? 2 : 1)); }
 };
 static_assert((kCells + kMultiMax * 2 + kMultiMax / 2) * 4 >= kBitWords * 4 + kBitWords * 2, "bitmap + prefix fit region A");
+static_assert(kRangeMaxRefs <= 64, "one bit per reference in the presence masks");
 
 // What phases 1-6 need to know about their workgroup (all workgroup-uniform).
 struct ScoreRange {
@@ -167,8 +165,8 @@ struct ScoreRange {
 // per-posting loops are straight-line code — a run-time round count inside one body made the compiler shuffle the whole
 // register arrays at every round's branch (a third of the vector instructions of the first form of this kernel).  Rounds
 // past the end (e >= cap) read the last posting again and are not `kept`.
-template <bool DF_ONLY, bool WIDE, int NS_CAP, int NITER>
-__device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery& q, const ScoreRange& rg, ScoreLds<WIDE, NS_CAP>& L) {
+template <bool DF_ONLY, bool WIDE, int NITER>
+__device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery& q, const ScoreRange& rg, ScoreLds<WIDE>& L) {
     typedef typename MaskOf<WIDE>::type mask_t;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t cap = rg.cap, qi = rg.qi, doc0 = rg.doc0, n_words = rg.n_words;
@@ -182,44 +180,53 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
     // ---- 1. gather: posting e belongs to the run whose [seg_off[i], seg_off[i+1]) holds it
     uint32_t pk[NITER];  // [kept:1 | token:6 | run:8 | pad:1 | local document:16]
     float pv[NITER];     // normalised tf (boost included)
-    {
-        unsigned long long pos[NITER];
-        uint32_t run[NITER];
+    const float one_minus_b = 1.0f - b.b;
+    // (rounds in groups of four: eight rounds of addresses, documents and values alive at once cost the registers of a
+    // resident wave per SIMD)
 #pragma unroll
-        for (int n = 0; n < NITER; ++n) {
+    for (int g = 0; g < NITER; g += 4) {
+        constexpr int G = 4;
+        unsigned long long pos[G];
+        uint32_t run[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int n = g + j;
+            if (n >= NITER) break;
             if (!rg.count_each) L.dmask[threadIdx.x + n * kThreads] = (mask_t)0;  // (touched documents <= postings; first used in phase 3)
             const uint32_t e = min(threadIdx.x + n * kThreads, cap - 1u);
             uint32_t lo = L.blk_run[e >> kBlkShift];
             while (L.seg_off[lo + 1] <= e) ++lo;  // (runs are ~100 postings: almost always zero steps)
-            run[n] = lo;
-            pos[n] = L.seg_pos[lo] + (e - L.seg_off[lo]);
+            run[j] = lo;
+            pos[j] = L.seg_pos[lo] + (e - L.seg_off[lo]);
         }
-        uint32_t doc[NITER], val[NITER];
+        uint32_t doc[G], val[G];
 #pragma unroll
-        for (int n = 0; n < NITER; ++n) {
-            doc[n] = b.post_doc[pos[n]];
-            val[n] = 0u;
-            if (!DF_ONLY) val[n] = b.post_ntf ? __builtin_bit_cast(uint32_t, b.post_ntf[pos[n]]) : b.post_val[pos[n]];
+        for (int j = 0; j < G; ++j) {
+            if (g + j >= NITER) break;
+            doc[j] = b.post_doc[pos[j]];
+            val[j] = 0u;
+            if (!DF_ONLY) val[j] = b.post_ntf ? __builtin_bit_cast(uint32_t, b.post_ntf[pos[j]]) : b.post_val[pos[j]];
         }
-        const float one_minus_b = 1.0f - b.b;
 #pragma unroll
-        for (int n = 0; n < NITER; ++n) {
+        for (int j = 0; j < G; ++j) {
+            const int n = g + j;
+            if (n >= NITER) break;
             bool kept = threadIdx.x + n * kThreads < cap;
             if (b.allow) {  // collect_contributions_with_filter: filtered docs never reach the scorer
-                const uint64_t id = b.docs ? b.docs[doc[n]] : b.dense_base + doc[n];  // dense ids: no table lookup
+                const uint64_t id = b.docs ? b.docs[doc[j]] : b.dense_base + doc[j];  // dense ids: no table lookup
                 kept = kept && id < b.allow_bits && ((b.allow[id >> 6] >> (id & 63)) & 1ull);
             }
-            const uint32_t dl = doc[n] - doc0;
-            const uint32_t key = L.seg_key[run[n]];
-            pk[n] = kept ? (0x80000000u | ((key >> 10) << 25) | (run[n] << 17) | dl) : 0u;
+            const uint32_t dl = doc[j] - doc0;
+            const uint32_t key = L.seg_key[run[j]];
+            pk[n] = kept ? (0x80000000u | ((key >> 10) << 25) | (run[j] << 17) | dl) : 0u;
             pv[n] = 0.0f;
             if (rg.count_each) {
                 if (kept) atomicAdd(&L.df_lds[key >> 10], 1u);
             } else {
                 if (kept) atomicOr(&bitmap[dl >> 5], 1u << (dl & 31u));
                 if (!DF_ONLY) {
-                    const float pre = b.post_ntf ? __builtin_bit_cast(float, val[n]) : ntf_pre_of(val[n], one_minus_b, b.b, L.seg_avg[run[n]]);
-                    pv[n] = L.seg_boost[run[n]] * pre;
+                    const float pre = b.post_ntf ? __builtin_bit_cast(float, val[j]) : ntf_pre_of(val[j], one_minus_b, b.b, L.seg_avg[run[j]]);
+                    pv[n] = L.seg_boost[run[j]] * pre;
                 }
             }
         }
@@ -262,71 +269,57 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) n_touched += L.wave_tot[w];
 
-    // ---- 3. every kept posting: rank of its document, its token into the document's presence mask
-    uint32_t prank[NITER];
+    // ---- 3. every kept posting: rank of its document, its REFERENCE (list) into the document's presence mask.  One bit per
+    // list, not per token: a document is then at most once behind each bit, every posting owns its cell, and the cells of a
+    // document in bit order are its contributions in (token, reference) order — queries with several lists per token
+    // (several fields, prefix / typo expansions) need no special path.
+    uint32_t prk[(NITER + 1) / 2] = {0};  // the ranks, two per register (a rank is < 2 048)
+#define PRANK(n) ((prk[(n) >> 1] >> (16 * ((n) & 1))) & 0xffffu)
 #pragma unroll
     for (int n = 0; n < NITER; ++n) {
         const uint32_t dl = pk[n] & 0xffffu;
         const uint32_t rank = (uint32_t)word_rank[dl >> 5] + (uint32_t)__popc(bitmap[dl >> 5] & ((1u << (dl & 31u)) - 1u));
-        prank[n] = rank;
-        if (pk[n] >> 31) {
-            const uint32_t tok = (pk[n] >> 25) & 63u;
-            const mask_t bit = (mask_t)1 << tok;
-            if (DF_ONLY) {
-                // corpus_docs.len(): distinct (token, document) pairs among the kept postings (token_score.rs:262-275)
-                const mask_t old = atomicOr(&L.dmask[rank], bit);
-                if (!(old & bit)) atomicAdd(&L.df_lds[tok], 1u);
-            } else {
-                atomicOr(&L.dmask[rank], bit);
-            }
-        }
+        prk[n >> 1] |= rank << (16 * (n & 1));
+        if (pk[n] >> 31) atomicOr(&L.dmask[rank], (mask_t)1 << ((pk[n] >> 17) & 63u));
     }
     __syncthreads();
+    mask_t pm[NITER];  // the document's presence mask (0: dropped posting)
+#pragma unroll
+    for (int n = 0; n < NITER; ++n) pm[n] = (pk[n] >> 31) ? L.dmask[PRANK(n)] : (mask_t)0;
     if (DF_ONLY) {
+        // corpus_docs.len(): distinct (token, document) pairs among the kept postings (token_score.rs:262-275): a posting
+        // counts when no EARLIER list of its token holds the document (the lists of a token are consecutive references)
+#pragma unroll
+        for (int n = 0; n < NITER; ++n) {
+            if (!(pk[n] >> 31)) continue;
+            const uint32_t run = (pk[n] >> 17) & 63u, first = run - (L.seg_key[run] & 1023u);
+            const mask_t earlier = (((mask_t)1 << run) - 1) & ~(((mask_t)1 << first) - 1);
+            if ((pm[n] & earlier) == 0) atomicAdd(&L.df_lds[(pk[n] >> 25) & 63u], 1u);
+        }
+        __syncthreads();
         if (threadIdx.x < q.n_tokens && L.df_lds[threadIdx.x]) atomicAdd(&b.results[qi].df[threadIdx.x], L.df_lds[threadIdx.x]);
         return;
     }
 
-    // ---- 4. cells for the documents that are not singletons (more than one token, or a token with several lists):
-    // popcount(mask) cells each and a place in the dense list of such documents, both handed out by ONE returning LDS
-    // atomic (cells in the low half, list position in the high half).  One-list queries: the posting of the document's
-    // FIRST token — there is exactly one — asks, and lends the document its key slot.  Multi-list queries: one lane per
-    // touched document asks.  Every posting has read its document's mask before (barrier): the mask's slot then takes
-    // what the document's other postings need, first cell | list position << 16.
-    const mask_t multi = (mask_t)L.multi_tok;
-    const uint32_t ranks = L.max_rank;  // a token has at most ranks + 1 lists
-    mask_t pm[NITER];      // the document's presence mask (0: dropped posting)
-#pragma unroll
-    for (int n = 0; n < NITER; ++n) pm[n] = (pk[n] >> 31) ? L.dmask[prank[n]] : (mask_t)0;
+    // ---- 4. cells for the documents with more than one posting: one cell per posting and a place in the dense list of such
+    // documents, both handed out by ONE returning LDS atomic (cells in the low half, list position in the high half) to the
+    // posting of the document's FIRST reference — there is exactly one — which also lends the document its key slot.
+    // Every posting has read its document's mask (above); the mask's slot then takes the first cell for the others.
     __syncthreads();  // (the bitmap and its prefix are dead from here on: region A holds the multi-document tables)
-    uint32_t pcb[NITER];   // one-list queries: the first cell this posting was handed (kNoCell: it did not ask)
-    auto hand_out = [&](mask_t m, uint32_t rank) -> uint32_t {
-        const uint32_t cells = mask_popc(m);
-        const uint32_t got = atomicAdd(&L.cell_cursor, cells | (1u << 16));
-        const uint32_t cb = got & 0xffffu, mi = got >> 16;
-        if (cb + cells <= kCells && mi < kMultiMax) {  // (beyond: the range overflows, nothing of it is used)
-            L.dmask[rank] = (mask_t)(cb | (mi << 16));
-            md_mask[mi] = m;
-            md_cb[mi] = (uint16_t)cb;
-        }
-        return got;
-    };
 #pragma unroll
     for (int n = 0; n < NITER; ++n) {
-        pcb[n] = kNoCell;
-        if (ranks == 0u) {
-            const mask_t below = pm[n] & (((mask_t)1 << ((pk[n] >> 25) & 63u)) - 1);
-            if ((pm[n] & (pm[n] - 1)) != 0 && below == 0) {
-                const uint32_t got = hand_out(pm[n], prank[n]);
-                pcb[n] = got & 0xffffu;
-                if ((got >> 16) < kMultiMax) md_own[got >> 16] = (threadIdx.x + n * kThreads) | ((pk[n] & 0xffffu) << 16);
+        const mask_t m = pm[n];
+        const mask_t below = m & (((mask_t)1 << ((pk[n] >> 17) & 63u)) - 1);
+        if ((m & (m - 1)) != 0 && below == 0) {
+            const uint32_t cells = mask_popc(m);
+            const uint32_t got = atomicAdd(&L.cell_cursor, cells | (1u << 16));
+            const uint32_t cb = got & 0xffffu, mi = got >> 16;
+            if (cb + cells <= kCells && mi < kMultiMax) {  // (beyond: the range overflows, nothing of it is used)
+                L.dmask[PRANK(n)] = (mask_t)cb;
+                md_mask[mi] = m;
+                md_cb[mi] = (uint16_t)cb;
+                md_own[mi] = (threadIdx.x + n * kThreads) | ((pk[n] & 0xffffu) << 16);
             }
-        }
-    }
-    if (ranks != 0u) {
-        for (uint32_t d = threadIdx.x; d < n_touched; d += kThreads) {
-            const mask_t m = L.dmask[d];
-            if ((m & (m - 1)) != 0 || (m & multi) != 0) hand_out(m, d);
         }
     }
     __syncthreads();
@@ -340,10 +333,6 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
         }
         if (threadIdx.x == 0) b.results[qi].overflow = 1;
         return;
-    }
-    if (ranks != 0u && n_cells != 0u) {  // cells that several lists add into start from 0.0 (Iterator::sum)
-        for (uint32_t c = threadIdx.x; c < n_cells; c += kThreads) cellv[c] = 0.0f;
-        __syncthreads();
     }
 
     const float k1 = q.k + 1.0f;
@@ -382,66 +371,39 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
     };
 
     // ---- 5. a singleton is scored and reported by its posting's lane; a posting of any other document parks its normalised
-    // tf in its token's cell and leaves its own slot empty (the document's key goes to the lent slot in phase 6)
-    uint32_t pcell[NITER];  // multi-list queries only: the posting's cell (kNoCell: none)
+    // tf in its own cell and leaves its slot empty — except the lender's, which phase 6 writes
 #pragma unroll
     for (int n = 0; n < NITER; ++n) {
         const uint32_t e = threadIdx.x + n * kThreads;
         const uint32_t dl = pk[n] & 0xffffu;
-        const uint32_t tok = (pk[n] >> 25) & 63u;
         const mask_t m = pm[n];
-        const bool is_multi = (m & (m - 1)) != 0 || (m & multi) != 0;
-        pcell[n] = kNoCell;
         float score = 0.0f;
         bool in_map = false, lends = false;
-        if (!is_multi) {
+        if ((m & (m - 1)) == 0) {
             if (m != 0) {  // (a dropped posting reports an empty slot)
                 DocFold f;
-                f.add(tok, pv[n], L.idf, q.k, k1);
+                f.add((pk[n] >> 25) & 63u, pv[n], L.idf, q.k, k1);
                 in_map = f.finish(L.idf, q.k, k1, q.use_threshold, q.threshold);
                 score = f.score;
             }
         } else {
-            const uint32_t below = mask_popc((mask_t)(m & (((mask_t)1 << tok) - 1)));
-            if (ranks == 0u) {
-                lends = pcb[n] != kNoCell;  // THE lender: phase 6 writes its slot, nobody else does
-                const uint32_t cb = lends ? pcb[n] : ((uint32_t)L.dmask[prank[n]] & 0xffffu);
-                cellv[cb + below] = 0.0f + 1.0f * pv[n];  // the token's only list
-            } else {
-                const uint32_t slot = (uint32_t)L.dmask[prank[n]];
-                if (below == 0) md_own[slot >> 16] = e | (dl << 16);  // any posting of the document's first token lends its slot ...
-                pcell[n] = (slot & 0xffffu) + below;                  // ... and all of them write their slot empty now
-            }
+            const uint32_t below = mask_popc((mask_t)(m & (((mask_t)1 << ((pk[n] >> 17) & 63u)) - 1)));
+            lends = below == 0;  // the posting of the document's first reference: it asked for the cells in phase 4
+            cellv[(uint32_t)L.dmask[PRANK(n)] + below] = pv[n];
         }
         if (e < cap && !lends) report(e, dl, score, in_map);
     }
     if (n_cells != 0u) {  // (workgroup-uniform)
-        if (ranks != 0u) {
-            // lists of one token add in reference order (a document is at most once in a list: no two postings of a pass
-            // share a cell); one pass per rank, a barrier between them
-            for (uint32_t p = 0; p <= ranks; ++p) {
-                __syncthreads();
-#pragma unroll
-                for (int n = 0; n < NITER; ++n) {
-                    if (pcell[n] == kNoCell) continue;
-                    if ((L.seg_key[(pk[n] >> 17) & 0xffu] & 1023u) != p) continue;
-                    cellv[pcell[n]] = cellv[pcell[n]] + 1.0f * pv[n];
-                }
-            }
-            // multi-list queries wrote the lent slot empty in phase 5 and write the document's entry there now: the first
-            // store must have reached L2 before the second is issued (one-list queries never write a slot twice)
-            __threadfence();
-        }
         __syncthreads();
-        // ---- 6. one lane per multi-posting document: fold its cells with tokens ascending, report it in the slot lent to it
+        // ---- 6. one lane per multi-posting document: its cells in bit order are its contributions in (token, reference)
+        // order — folded exactly as BM25Scorer::add / get_scores would, reported in the slot lent to it
         for (uint32_t i = threadIdx.x; i < n_multi; i += kThreads) {
-            const uint32_t cb = md_cb[i];
             mask_t m = md_mask[i];
             DocFold f;
-            for (uint32_t c = cb; m != 0; ++c) {
-                const uint32_t tok = mask_first(m);
+            for (uint32_t c = md_cb[i]; m != 0; ++c) {
+                const uint32_t ref = mask_first(m);
                 m &= m - 1;
-                f.add_summed(tok, cellv[c], L.idf, q.k, k1);
+                f.add(L.seg_key[ref] >> 10, cellv[c], L.idf, q.k, k1);
             }
             const bool in_map = f.finish(L.idf, q.k, k1, q.use_threshold, q.threshold);
             const uint32_t o = md_own[i];
@@ -460,12 +422,13 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
         if (L.red[2]) atomicMax(&b.results[qi].max_key, L.red[2]);
         if (L.red[3]) atomicMax(&b.results[qi].min_inv, L.red[3]);
     }
+#undef PRANK
 }
 
 // DF_ONLY: the counting pass (corpus_docs.len() per token under a filter / with several lists per token).
-template <bool DF_ONLY, bool WIDE, int NS_CAP>
+template <bool DF_ONLY, bool WIDE>
 __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
-    __shared__ ScoreLds<WIDE, NS_CAP> L;
+    __shared__ ScoreLds<WIDE> L;
 
     // (query, range) of this workgroup: the batch's pairs laid end to end
     uint32_t qi = 0;
@@ -495,8 +458,6 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     if (wave == 0) {
         if (lane < 4) L.red[lane] = 0;
         if (lane == 0) {
-            L.multi_tok = 0ull;
-            L.max_rank = 0u;
             L.cell_cursor = 0u;
             L.seg_off[0] = 0;
         }
@@ -506,8 +467,6 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
         // (the bounds of a range are contiguous over the references, and their address does not depend on the reference
         // table: both loads are issued together); slot base = postings of the query in earlier ranges
         uint32_t carry = 0, base_part = 0;
-        unsigned long long multi = 0ull;
-        uint32_t mrank = 0;
         const uint32_t* row = b.bounds + q.bounds_base + (uint64_t)r * ns;
         for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
             const uint32_t i = i0 + lane;
@@ -521,11 +480,6 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
                 L.seg_avg[i] = sg.avg_len;
                 base_part += b0;
                 x = b1 - b0;
-                const uint32_t rank = sg.tok_rank & 1023u;
-                if (rank) {
-                    multi |= 1ull << (sg.tok_rank >> 10);
-                    mrank = max(mrank, rank);
-                }
             }
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {  // inclusive scan of the run lengths, 64 references at a time
@@ -536,10 +490,6 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
             carry += __shfl(x, 63, 64);
         }
         if (base_part) atomicAdd(&L.red[0], base_part);
-        if (mrank) {
-            atomicOr(&L.multi_tok, multi);
-            atomicMax(&L.max_rank, mrank);
-        }
         // block table: the run that holds gathered posting 32 * lane (the wave's own LDS writes above are visible to it:
         // LDS operations of one wave complete in order)
         if (carry <= kRangeCap && (lane << kBlkShift) < carry) {
@@ -573,13 +523,13 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     // the targeted ~1 280 postings takes 5 or 6
     const uint32_t n_iter = (cap + kThreads - 1) / kThreads;
     if (DF_ONLY) {
-        if (n_iter <= 4) score_body<DF_ONLY, WIDE, NS_CAP, 4>(b, q, rg, L);
-        else score_body<DF_ONLY, WIDE, NS_CAP, 8>(b, q, rg, L);
-    } else if (n_iter <= 2) score_body<DF_ONLY, WIDE, NS_CAP, 2>(b, q, rg, L);
-    else if (n_iter <= 4) score_body<DF_ONLY, WIDE, NS_CAP, 4>(b, q, rg, L);
-    else if (n_iter == 5) score_body<DF_ONLY, WIDE, NS_CAP, 5>(b, q, rg, L);
-    else if (n_iter == 6) score_body<DF_ONLY, WIDE, NS_CAP, 6>(b, q, rg, L);
-    else score_body<DF_ONLY, WIDE, NS_CAP, 8>(b, q, rg, L);
+        if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4>(b, q, rg, L);
+        else score_body<DF_ONLY, WIDE, 8>(b, q, rg, L);
+    } else if (n_iter <= 2) score_body<DF_ONLY, WIDE, 2>(b, q, rg, L);
+    else if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4>(b, q, rg, L);
+    else if (n_iter == 5) score_body<DF_ONLY, WIDE, 5>(b, q, rg, L);
+    else if (n_iter == 6) score_body<DF_ONLY, WIDE, 6>(b, q, rg, L);
+    else score_body<DF_ONLY, WIDE, 8>(b, q, rg, L);
 }
 
 // Hybrid path: the full-text score of given documents.  One WAVE per document: lane i looks the document up in the
@@ -689,17 +639,15 @@ int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStr
     ProfScope prof(&ctx->prof, df_only ? "bm25_range_df" : "bm25_range_score", stream);
     const uint32_t grid = b.range_start[b.n_queries];
     ORAMA_REQUIRE(grid >= b.max_ranges, "internal: range_start table not filled");
-    // instantiation by the batch's widest query: 64-bit token masks beyond 32 tokens, big reference tables beyond 32 lists
-    const bool wide = b.wide_masks != 0, many = b.max_refs > 32;
-#define ORAMA_SCORE_LAUNCH(DF, W, NS) hipLaunchKernelGGL((range_score_kernel<DF, W, NS>), dim3(grid), dim3(kThreads), 0, stream, b)
+    // 64-bit presence masks when a query of the batch has more than 32 references
+    const bool wide = b.max_refs > 32;
     if (df_only) {
-        if (wide) { if (many) ORAMA_SCORE_LAUNCH(true, true, (int)kRangeMaxRefs); else ORAMA_SCORE_LAUNCH(true, true, 32); }
-        else { if (many) ORAMA_SCORE_LAUNCH(true, false, (int)kRangeMaxRefs); else ORAMA_SCORE_LAUNCH(true, false, 32); }
+        if (wide) hipLaunchKernelGGL((range_score_kernel<true, true>), dim3(grid), dim3(kThreads), 0, stream, b);
+        else hipLaunchKernelGGL((range_score_kernel<true, false>), dim3(grid), dim3(kThreads), 0, stream, b);
     } else {
-        if (wide) { if (many) ORAMA_SCORE_LAUNCH(false, true, (int)kRangeMaxRefs); else ORAMA_SCORE_LAUNCH(false, true, 32); }
-        else { if (many) ORAMA_SCORE_LAUNCH(false, false, (int)kRangeMaxRefs); else ORAMA_SCORE_LAUNCH(false, false, 32); }
+        if (wide) hipLaunchKernelGGL((range_score_kernel<false, true>), dim3(grid), dim3(kThreads), 0, stream, b);
+        else hipLaunchKernelGGL((range_score_kernel<false, false>), dim3(grid), dim3(kThreads), 0, stream, b);
     }
-#undef ORAMA_SCORE_LAUNCH
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -9,7 +9,7 @@ namespace orama {
 
 constexpr uint32_t kRangeCap = 2048;     // postings one workgroup scores in LDS
 constexpr uint32_t kRangeMaxWidth = 32768;  // documents per range (one bit each in the workgroup's LDS bitmap)
-constexpr uint32_t kRangeMaxRefs = 256;  // non-empty posting lists per query (per-reference tables live in LDS)
+constexpr uint32_t kRangeMaxRefs = 64;   // non-empty posting lists per query: one bit each in the scoring launch's presence masks
 constexpr uint32_t kRangeBatchMax = 32;  // queries scored by one set of launches
 
 // One (token, posting list) reference of one query of the batch.
@@ -57,8 +57,7 @@ struct RangeBatch {
     uint32_t n_segs = 0, n_queries = 0;
     uint64_t total_postings = 0;         // referenced by the whole batch
     uint32_t max_ranges = 0;             // most ranges of a query of the batch
-    uint32_t wide_masks = 0;             // a query of the batch has more than 32 tokens: 64-bit token masks in the scoring launch
-    uint32_t max_refs = 0;               // most references (non-empty lists) of a query of the batch: sizes the launch's LDS tables
+    uint32_t max_refs = 0;               // most references (non-empty lists) of a query of the batch: > 32 takes 64-bit presence masks
     // the scoring launch is a 1-D grid over the (query, range) pairs that exist: workgroup w scores range
     // w - range_start[q] of the query q with range_start[q] <= w < range_start[q + 1]
     uint32_t range_start[kRangeBatchMax + 1] = {0};

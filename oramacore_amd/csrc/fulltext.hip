@@ -483,16 +483,18 @@ bool ranges_eligible(const orama_post* p, const orama_term_ref* refs, uint32_t n
     return nonempty <= kRangeMaxRefs && total < 0x7fffffffull;
 }
 
-// Documents per range: `target` postings per range on average (ORAMA_K3R_TARGET; a workgroup merges at most kRangeCap = 2 048,
-// and the cost per posting falls with the postings per workgroup — the diagonal searches of the merge are amortised over
-// more outputs: 9.5 us per C4-shaped query at 512-1 024 postings per range, 8.3 at 700-1 400, 7.6 at 900-1 800), any width —
-// a power of two would leave the average anywhere between target / 2 and target — `shrink` times 8x smaller after an
-// overflow (documents of a term clustered in id space).
+// Documents per range: `target` postings per range on average (ORAMA_K3R_TARGET; a workgroup holds at most kRangeCap = 2 048).
+// The cost per posting falls with the postings per workgroup — per-workgroup work (tables, scans, barriers) is amortised over
+// more of them: round 4's sort-free kernel takes 5.03 us per C4-shaped query at 1 280, 4.78 at 1 536, 4.57 at 1 792 and 4.36 at
+// 2 000 (profiles/r04_k3r_target_sweep_v3.log) — but a range that exceeds the 2 048 reruns its whole query with 8x narrower
+// ranges, so the default keeps 25 % of headroom: 1 536 (a Poisson count of that mean is 13 standard deviations below the
+// cap; documents of a term clustered in id space overflow at any target).  Any width — a power of two would leave the average
+// anywhere between target / 2 and target — `shrink` times 8x smaller after an overflow.
 uint32_t choose_width(uint64_t n_docs, uint64_t total_postings, uint32_t shrink) {
     static const uint64_t target = [] {
         const char* e = std::getenv("ORAMA_K3R_TARGET");
         const long v = e ? std::atol(e) : 0;
-        return (uint64_t)(v >= 16 && v <= (long)kRangeCap ? v : 1280);
+        return (uint64_t)(v >= 16 && v <= (long)kRangeCap ? v : 1536);
     }();
     uint64_t w = total_postings ? n_docs * target / total_postings : n_docs;
     for (uint32_t i = 0; i < shrink; ++i) w /= 8;
@@ -698,7 +700,8 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             pending.pop_front();
         }
         const uint32_t nq = c.nq = (uint32_t)c.members.size();
-        const uint64_t max_total = c.max_total;
+        // stride of the key lists: even, so that every list starts 16-byte aligned (the top-k streams them with 16-byte loads)
+        const uint64_t max_total = c.max_total = (c.max_total + 1) & ~1ull;
         std::vector<RangeSeg>& segs = c.segs;
         std::vector<RangeQuery>& queries = c.queries;
         segs.clear();
@@ -803,7 +806,6 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             pairs += queries[ci].n_ranges;
             ORAMA_SUPPORT(pairs < 0x7fffffffull, "query batch needs too many document ranges");
             rb.range_start[ci + 1] = (uint32_t)pairs;
-            if (queries[ci].n_tokens > 32) rb.wide_masks = 1;
             rb.max_refs = std::max(rb.max_refs, queries[ci].seg_end - queries[ci].seg_begin);
         }
         rb.max_bound_entries = max_bound_entries;
@@ -840,7 +842,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             m->cand_idx = rb.map_idx;
             m->emit = rb.map_emit;
             m->epoch = rb.map_epoch;
-            *jobs[0].map_list_len = (uint32_t)max_total;
+            *jobs[0].map_list_len = (uint32_t)c.members[0].total;  // (the stride may be one slot longer: that slot is never written)
         }
         if (const char* e = std::getenv("ORAMA_K3R_DBG")) rb.debug = (uint32_t)std::atoi(e);
         ORAMA_TRY(launch_range_bounds(p->ctx, rb, s));

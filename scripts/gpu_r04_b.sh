@@ -12,7 +12,7 @@ timeout 900 python -m pytest tests/test_bm25_ranges_gpu.py tests/test_fulltext_g
 echo "== k3r A/B (comparison library)"
 timeout 600 python scripts/k3r_ab.py 2>&1 | tail -30 | tee $O/k3r_ab.log
 echo "== postings per range sweep"
-for T in 1280 1536 1792 2000; do echo "target $T"; ORAMA_K3R_TARGET=$T timeout 200 python scripts/k3r_chunk_probe.py 2>&1 | tail -1; done | tee $O/k3r_target_sweep.log
+for T in 1280 1536 1792; do echo "target $T"; ORAMA_K3R_TARGET=$T timeout 200 python scripts/k3r_chunk_probe.py 2>&1 | tail -1; done | tee $O/k3r_target_sweep.log
 echo "== SQ counters"
 bash scripts/k3r_sq_pmc.sh > $O/k3r_sq.txt 2>&1; tail -32 $O/k3r_sq.txt | sort -u
 echo "== pytest -m gpu (all)"
