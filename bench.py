@@ -466,6 +466,29 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
     ctx.prof_enable(False)
     scan_ms, scan_n = ctx.prof_get("vec_scan_f32")
     k3_launches = ctx.prof_get("bm25_accumulate")[1]  # 0 = every query took the range scorer + candidate tail
+    # The same queries from TWO callers (the reference serves search(&self) from many tokio workers at once,
+    # read/collection.rs:846-884): the scans still run one after the other, but one caller's tail — top-k of the scan, the
+    # per-document full-text scores, the host merge — overlaps the other's scan.  Reported beside `value`, never as it.
+    import threading
+
+    def caller(lo_i, hi_i, out):
+        for i in range(lo_i, hi_i):
+            out.append((i, hybrid(i)))
+
+    two_out = [[], []]
+    mid = warmup + (total - warmup) // 2
+    ths = [threading.Thread(target=caller, args=(warmup, mid, two_out[0])), threading.Thread(target=caller, args=(mid, total, two_out[1]))]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    ctx.synchronize()
+    el_two = time.perf_counter() - t0
+    for i, r in two_out[0] + two_out[1]:
+        a = plain_results[i - warmup]
+        assert a[2] == r[2] and np.array_equal(a[0], r[0]) and np.array_equal(a[1].view(np.uint32), r[1].view(np.uint32)), \
+            "hybrid answers of concurrent callers differ from the single caller's"
     shadow_out = None
     if shadow is not None:
         for i in range(warmup):
@@ -589,6 +612,9 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
                      "note": "a hybrid query = the fp32 scan (dominant) + the full-text leg on a second stream"},
         "full_text_leg": ("range scorer (K3r) beside the scan + candidate tail after it" if k3_launches == 0 else
                           f"per-record scorer (K3) used by {k3_launches} launches"),
+        "two_callers": {"value": steps / el_two, "unit": "queries/s", "ms_per_query": el_two / steps * 1e3,
+                        "note": "the same queries issued by two threads (one orama_hybrid_search each at a time): identical answers; "
+                                "one caller's tail overlaps the other's scan"},
         "shadow_store": shadow_out,
         "bm25_only": {"value": len(batch_q) / el_bb, "unit": "queries/s",
                       "note": "one orama_post_search_batch call over %d queries, descriptors built beforehand: K3r scores 32 queries "
@@ -607,7 +633,9 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
                                                            "range_df": kd_ms * 1e3 / n_dev_q,
                                                            "range_score": ks_ms * 1e3 / n_dev_q,
                                                            "topk_select": kt_ms * 1e3 / n_dev_q},
-                                   "note": "the scoring launch is bound by VALU issue (~550 lane instructions per posting: IEEE divisions for bit-exact ntf, four merge levels, the fold), not by HBM: profiles/r03_k3r_sq_counters.md, DESIGN K3r"},
+                                   "note": "round 4's sort-free scoring launch: 2.8 VALU wave instructions per posting (round 3's merge tree: 8.6), "
+                                           "VALU issue slots 82 % busy — still bound by vector issue, not by HBM (the chain streams 24 B per posting "
+                                           "at ~1 TB/s): profiles/r04_k3r_sq_counters_v4.md, DESIGN K3r"},
                       "cpu_baseline": cpu_bm25},
         "postings_fill_seconds": t_fill,
         "parity_check": "bit-exact vs oracle (last query): BM25 ids/scores/count, hybrid ids/scores/count",

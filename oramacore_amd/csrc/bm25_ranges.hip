@@ -52,10 +52,13 @@ namespace {
 
 constexpr int kBoundsThreads = 256;
 
-// bounds[query][range][reference]: one thread per entry does a lower-bound search of the range's first document in
-// the reference's (document-sorted) list.  (The first form of this kernel walked every referenced posting — one
-// thread per posting, 19 M threads per 32-query batch — to find the crossings: 3.9 us per query; the searches touch
-// 17 list elements per entry instead of all of them, and the upper levels of every search stay in cache: 0.7 us.)
+// bounds[query][range][reference] = lower bound of the range's first document in the reference's (document-sorted) list.
+// SIXTEEN lanes per entry search together: every round they probe 16 evenly spaced elements of the window at once and keep
+// the sixteenth that holds the answer — 4 dependent loads for a list of 50 K postings where a binary search makes 17.  The
+// launch is a chain of dependent loads and nothing else, and it sits at the head of every query: 14 us alone, 44 us beside the
+// 4.3 ms vector scan of a hybrid query (profiles/r03_hybrid_tail_timeline_after.log), with one thread per entry.
+// (The very first form walked every referenced posting — one thread per posting, 19 M threads per 32-query batch.)
+constexpr uint32_t kBoundsLanes = 16;
 __global__ __launch_bounds__(kBoundsThreads) void range_bounds_kernel(RangeBatch b) {
     const uint32_t qi = blockIdx.y;
     // the query's result words start at zero: cleared here, by the first launch of the set, instead of by a fill command
@@ -65,23 +68,35 @@ __global__ __launch_bounds__(kBoundsThreads) void range_bounds_kernel(RangeBatch
     const RangeQuery q = b.queries[qi];
     const uint32_t ns = q.seg_end - q.seg_begin;
     const uint64_t entries = (uint64_t)ns * (q.n_ranges + 1u);
-    const uint64_t e = (uint64_t)blockIdx.x * kBoundsThreads + threadIdx.x;
-    if (e >= entries) return;
-    const uint32_t r = (uint32_t)(e / ns), i = (uint32_t)(e - (uint64_t)r * ns);
+    const uint32_t sub = threadIdx.x & (kBoundsLanes - 1u);
+    const uint32_t group_shift = (threadIdx.x & 63u) & ~(kBoundsLanes - 1u);  // first lane of this group inside its wave
+    const uint64_t e = (uint64_t)blockIdx.x * (kBoundsThreads / kBoundsLanes) + threadIdx.x / kBoundsLanes;
+    const bool live = e < entries;  // (whole groups: the ballots below are executed by every lane of the wave)
+    const uint32_t r = live ? (uint32_t)(e / ns) : 0u, i = live ? (uint32_t)(e - (uint64_t)r * ns) : 0u;
     const RangeSeg* sg = b.segs + q.seg_begin + i;
-    const uint32_t len = sg->len;
+    const uint32_t len = live ? sg->len : 0u;
     uint32_t lo = 0, hi = len;
-    if (r >= q.n_ranges) {
-        lo = len;
-    } else if (r > 0) {
-        const uint32_t target = r * q.width;  // first document of range r (n_docs < 2^32)
-        const uint32_t* pd = b.post_doc + sg->post_begin;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (pd[mid] < target) lo = mid + 1; else hi = mid;
+    if (r >= q.n_ranges) lo = len, hi = len;
+    if (r == 0) hi = 0;
+    const uint32_t target = r * q.width;  // first document of range r (n_docs < 2^32)
+    const uint32_t* pd = b.post_doc + (live ? sg->post_begin : 0ull);
+    // the answer lies in [lo, hi]; every round cuts the window into 16 pieces (wave-uniform loop: groups that are done idle)
+    for (;;) {
+        const uint32_t span = hi - lo;
+        if (__ballot(span > 0) == 0ull) break;
+        const uint32_t step = (span + kBoundsLanes - 1u) / kBoundsLanes;  // >= 1 while span > 0
+        const uint32_t idx = lo + (sub + 1u) * step - 1u;                 // the last element of this lane's piece
+        const bool below = span > 0 && idx < hi && pd[idx] < target;      // ... lies before the boundary: so does the whole piece
+        const uint32_t m = (uint32_t)(__ballot(below) >> group_shift) & ((1u << kBoundsLanes) - 1u);
+        const uint32_t c = (uint32_t)__popc(m);  // pieces entirely below (the probes are monotone: a prefix of the lanes)
+        if (span > 0) {
+            const uint32_t nlo = lo + c * step;
+            // the boundary lies in piece c: [nlo, nlo + step - 1] — its last element is not below, so the answer is <= that index
+            hi = c == kBoundsLanes ? hi : min(hi, nlo + step - 1u);
+            lo = min(nlo, hi);
         }
     }
-    b.bounds[q.bounds_base + e] = lo;
+    if (live && sub == 0) b.bounds[q.bounds_base + e] = lo;
 }
 
 // ---------------------------------------------------------------------------------------------- the scoring launch
@@ -623,7 +638,8 @@ int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream)
     }
     ORAMA_REQUIRE(b.n_queries <= kRangeBatchMax, "bm25 ranges: batch too large");
     ProfScope prof(&ctx->prof, "bm25_range_bounds", stream);
-    const uint64_t blocks = (b.max_bound_entries + kBoundsThreads - 1) / kBoundsThreads;
+    const uint64_t per_block = kBoundsThreads / kBoundsLanes;  // entries a workgroup searches, 16 lanes each
+    const uint64_t blocks = (b.max_bound_entries + per_block - 1) / per_block;
     ORAMA_SUPPORT(blocks < 0x7fffffffull, "bm25 ranges: batch references too many postings");
     hipLaunchKernelGGL(range_bounds_kernel, dim3((uint32_t)blocks, b.n_queries), dim3(kBoundsThreads), 0, stream, b);
     ORAMA_HIP_TRY(hipGetLastError());

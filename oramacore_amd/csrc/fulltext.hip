@@ -19,6 +19,7 @@
 
 #include "bm25_kernels.hpp"
 #include "bm25_ranges.hpp"
+#include "shard_exchange.hpp"
 #include "common.hpp"
 #include "select.hpp"
 #include "vec_internal.hpp"
@@ -462,6 +463,9 @@ struct RangeJob {
     // sharded batches (orama_shard_post_search_batch): the index-wide document frequency of every token (kMaxTokens words) —
     // idf comes from it instead of from this shard's list lengths (corpus_docs.len() over the whole index, token_score.rs:262-275)
     const uint32_t* df_global = nullptr;
+    // df pass of a sharded batch (post_search_ranges(..., df_pass = true)): this shard's document frequency of every token
+    // (kMaxTokens words) — list lengths where that is exact, else counted by the counting launch — and nothing else
+    uint32_t* df_out = nullptr;
     // score-map mode (a batch of one, not hybrid): leave the whole map behind in the scratch set — see RangeBatch::map_idx
     QueryBuffers* map = nullptr;
     uint32_t* map_list_len = nullptr;
@@ -601,7 +605,7 @@ int hybrid_from_candidates(const RangeJob& jb, const RangeResult& res, const uin
 // host builds and uploads the tables of the next one on the other set's stream (the host side of a chunk — reference
 // tables, idf by libm, the upload — costs about as much wall time as its launches take on the device).
 int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_t n_jobs, float b,
-                       const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc, Scratch* sc2 = nullptr) {
+                       const uint64_t* allow_bitmap, uint64_t bitmap_bits, int apply_omc, Scratch* sc2 = nullptr, bool df_pass = false) {
     struct Pending {
         uint32_t job;
         uint32_t shrink;
@@ -635,7 +639,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         const RangeJob& jb = jobs[j];
         *jb.out_n = 0;
         if (jb.out_count) *jb.out_count = 0;
-        ORAMA_REQUIRE(jb.params->top_k == 0 || (jb.out_ids && jb.out_scores), "null output");
+        ORAMA_REQUIRE(df_pass || jb.params->top_k == 0 || (jb.out_ids && jb.out_scores), "null output");
         ORAMA_REQUIRE(jb.n_refs == 0 || jb.refs, "null refs");
         uint64_t total = 0;
         for (uint32_t i = 0; i < jb.n_refs; ++i) {
@@ -647,6 +651,20 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         if (!total && jb.hybrid) {  // no full-text side at all: the per-record path combines the vector map alone
             *jb.fallback = true;
             return ORAMA_OK;
+        }
+        if (df_pass) {
+            // df is the list length when no filter drops postings and every token has one list; otherwise it is counted
+            ORAMA_REQUIRE(jb.df_out, "internal: df pass without an output");
+            uint32_t lists_of[kMaxTokens] = {0};
+            bool counted = allow_bitmap != nullptr;
+            for (uint32_t t = 0; t < kMaxTokens; ++t) jb.df_out[t] = 0;
+            for (uint32_t i = 0; i < jb.n_refs; ++i) {
+                const uint32_t len = (uint32_t)(p->list_off[jb.refs[i].list + 1] - p->list_off[jb.refs[i].list]);
+                if (!len) continue;
+                if (++lists_of[jb.refs[i].token] > 1) counted = true;
+                jb.df_out[jb.refs[i].token] += len;
+            }
+            if (!counted || !total) continue;
         }
         if (total) pending.push_back({j, 0u, total});
     }
@@ -757,9 +775,9 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             const uint32_t ns = q.seg_end - q.seg_begin;
             bounds_entries += ((uint64_t)q.n_ranges + 1) * ns;
             max_bound_entries = std::max<uint64_t>(max_bound_entries, ((uint64_t)q.n_ranges + 1) * ns);
-            if (jb.df_global) {
-                ORAMA_REQUIRE(df_known, "internal: an index-wide df was given for a query whose df must be counted");
+            if (jb.df_global) {  // the index-wide df of a sharded index: nothing left to count here
                 for (uint32_t t = 0; t < kMaxTokens; ++t) df[t] = jb.df_global[t];
+                df_known = true;
             }
             q.want_df = df_known ? 0u : (multi_list ? 1u : 2u);
             any_df |= !df_known;
@@ -790,7 +808,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         const size_t res_bytes = c.res_bytes = (size_t)nq * sizeof(RangeResult);
         const size_t out_bytes = res_bytes + (size_t)nq * kk * 12 + (size_t)nq * 4;
         ORAMA_TRY(sc->misc2.reserve(out_bytes));
-        ORAMA_TRY(sc->misc3.reserve((size_t)nq * max_total * 8));
+        if (!df_pass) ORAMA_TRY(sc->misc3.reserve((size_t)nq * max_total * 8));
         char* d = sc->misc0.as<char>();
         float* d_idf = reinterpret_cast<float*>(d + seg_bytes + q_bytes);
         RangeBatch& rb = c.rb;
@@ -848,6 +866,11 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         ORAMA_TRY(launch_range_bounds(p->ctx, rb, s));
         ORAMA_TRY(sc->h_out.reserve(out_bytes + 64));
         RangeResult* h_res = c.h_res = sc->h_out.as<RangeResult>();
+        if (df_pass) {  // count, read the result words back, nothing else (complete() hands the df out)
+            ORAMA_TRY(launch_range_score(p->ctx, rb, true, s));
+            ORAMA_HIP_TRY(hipMemcpyAsync(h_res, sc->misc2.p, res_bytes, hipMemcpyDeviceToHost, s));
+            return ORAMA_OK;
+        }
         if (any_df) {
             // df counted on the device (filter, or tokens with several lists): one read-back, then idf by the host libm
             ORAMA_TRY(launch_range_score(p->ctx, rb, true, s));
@@ -917,6 +940,10 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                 ORAMA_REQUIRE(c.queries[ci].width > 1, "internal: a one-document range overflowed");
                 ++pd.shrink;
                 pending.push_back(pd);
+                continue;
+            }
+            if (df_pass) {
+                memcpy(jb.df_out, h_res[ci].df, sizeof(uint32_t) * kMaxTokens);
                 continue;
             }
             if (jb.hybrid) {
@@ -2471,15 +2498,21 @@ int orama_hybrid_rrf(orama_ctx* ctx, const uint64_t* vec_doc, const float* vec_s
 
 
 // ------------------------------------------------------------------ full-text batches over a shard group
-// orama_post_search_batch for an index sharded by document range when EVERY shard lives in this process (a
-// co-located group, or one process driving several GPUs).  The reference reads one index-wide quantity before it scores —
-// df per token = corpus_docs.len() (token_score.rs:262-275); with one posting list per token and no filter that is the sum
-// of the shards' list lengths, known on the host: no collective.  Every shard then scores the whole batch with the range
-// scorer (K3r, idf from the index-wide df; shards run side by side on their own threads, streams and scratch sets), and the
-// host merges the shards' top-k lists by (score desc, DocumentId asc) and sums their counts (sort.rs:260-279,
-// search.rs:482).  Queries outside that envelope (a filter, several lists per token, a reference the range scorer does
-// not take, a group with ranks in other processes) are answered one by one by orama_shard_post_search.  Same answers as
-// orama_post_search_batch over the union of the shards, bit for bit.
+// orama_post_search_batch for an index sharded by document range, for EVERY shape of group: all shards in this
+// process (co-located, or one process driving several GPUs) or one process per rank.  The reference reads one index-wide
+// quantity before it scores — df per token = corpus_docs.len() (token_score.rs:262-275) — and merges what the indexes return
+// (sort.rs:260-279, search.rs:482).  Per block of <= 512 queries, three phases on every shard and TWO collectives however many
+// queries the block holds (round 3 had no rank form: such groups answered a batch one staged query at a time, 1.5 K/s):
+//   A  this shard's df of every token of every query — the list length where that is exact; under a filter or with several
+//      lists per token, the counting launch of the range scorer (K3r) — summed over the shards: ONE all-reduce of
+//      n_queries x (64 + 2) words (the two extra words: "a shard cannot take this query on the range scorer" and "a
+//      shard failed", so that every rank takes the same decision without a second exchange);
+//   B  every shard scores the block with the range scorer, idf from the index-wide df: its own top-k lists and counts;
+//   C  ONE all-gather of the shards' blocks [ids | scores | n | count]; every rank merges them by (score desc,
+//      DocumentId asc) and sums the counts.
+// Queries the range scorer does not take (more than 64 non-empty lists, ...) are answered afterwards, one by one, by
+// orama_shard_post_search — in the same order on every rank.  Same answers as orama_post_search_batch over the union of the
+// shards, bit for bit.  Every rank of the group must make the same call (same queries, same order).
 int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shards, const orama_post_query_desc* queries,
                                   uint32_t n_queries, float b, const uint64_t* const* allow_bitmaps, uint64_t bitmap_bits,
                                   int apply_omc, uint32_t stride_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
@@ -2488,21 +2521,25 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
     if (n_queries == 0) return ORAMA_OK;
     ORAMA_REQUIRE(stride_k >= 1 && out_ids && out_scores, "null output");
     uint32_t world = 0, nl = 0;
-    ORAMA_TRY(orama_shard_group_info(g, &world, &nl, nullptr, nullptr));
+    shard_group_shape(g, &world, &nl, nullptr);
     for (uint32_t i = 0; i < nl; ++i) ORAMA_REQUIRE(shards[i], "null shard %u", i);
+    ShardCall call(g);  // one lane of the group from the first collective to the last
+    ORAMA_TRY(call.init());
     std::vector<int> status(n_queries, ORAMA_OK);
     std::vector<std::string> errors(n_queries);
     for (uint32_t j = 0; j < n_queries; ++j) {
         out_n[j] = 0;
         if (out_count) out_count[j] = 0;
     }
-    std::vector<uint32_t> fast, slow;
-    std::vector<uint32_t> df_global;  // [fast index][kMaxTokens]
-    {
-        // every shard stays read-locked from the eligibility test to its last launch
-        std::vector<std::shared_lock<std::shared_mutex>> locks;
-        for (uint32_t i = 0; i < nl; ++i) locks.emplace_back(shards[i]->mu);
-        for (uint32_t j = 0; j < n_queries; ++j) {
+    std::vector<uint32_t> slow;
+    constexpr uint32_t kBlockQueries = 512;  // queries per exchange (a block of 512 x top-100 lists is 620 KB per shard)
+    constexpr uint32_t kWordsPerQuery = kMaxTokens + 2;
+    int call_status = ORAMA_OK;  // a systemic failure (a shard's scratch pool, the device): the same on every rank, ends the call
+    for (uint32_t q0 = 0; q0 < n_queries && call_status == ORAMA_OK; q0 += kBlockQueries) {
+        const uint32_t nq = std::min(kBlockQueries, n_queries - q0);
+        // ---- which queries of the block can take the three phases at all (rank-independent tests first)
+        std::vector<uint32_t> cand;  // indices into `queries`
+        for (uint32_t j = q0; j < q0 + nq; ++j) {
             const orama_post_query_desc& qd = queries[j];
             if (qd.params.top_k > stride_k || qd.params.top_k == 0) {
                 set_error("query %u: top_k %u outside [1, stride %u]", j, qd.params.top_k, stride_k);
@@ -2510,97 +2547,176 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
                 errors[j] = orama_last_error();
                 continue;
             }
-            bool ok = world == nl && !allow_bitmaps && check_params(&qd.params) == ORAMA_OK;
-            uint32_t lists_of_token[kMaxTokens] = {0};
-            uint32_t df[kMaxTokens] = {0};
-            for (uint32_t i = 0; i < nl && ok; ++i) ok = ranges_eligible(shards[i], qd.refs, qd.n_refs, &qd.params);
-            for (uint32_t r = 0; r < qd.n_refs && ok; ++r) {
-                const orama_term_ref& ref = qd.refs[r];
-                if (ref.token >= qd.params.n_tokens) {
-                    ok = false;  // (the one-by-one path reports it)
-                    break;
-                }
-                uint64_t len = 0;
-                for (uint32_t i = 0; i < nl; ++i) len += shards[i]->list_off[ref.list + 1] - shards[i]->list_off[ref.list];
-                if (len == 0) continue;
-                if (++lists_of_token[ref.token] > 1 || len > 0xffffffffull) ok = false;
-                df[ref.token] = (uint32_t)len;
-            }
-            if (ok) {
-                fast.push_back(j);
-                df_global.insert(df_global.end(), df, df + kMaxTokens);
-            } else {
-                slow.push_back(j);
-            }
+            bool ok = check_params(&qd.params) == ORAMA_OK && qd.n_refs <= kRangeMaxRefs && (qd.n_refs == 0 || qd.refs);
+            for (uint32_t r = 0; r < qd.n_refs && ok; ++r) ok = qd.refs[r].token < qd.params.n_tokens;
+            if (ok) cand.push_back(j);
+            else slow.push_back(j);  // (the one-by-one path reports what is wrong with it)
         }
-        if (!fast.empty()) {
-            const size_t nf = fast.size();
-            std::vector<uint64_t> s_ids((size_t)nl * nf * stride_k);
-            std::vector<float> s_sc((size_t)nl * nf * stride_k);
-            std::vector<uint32_t> s_n((size_t)nl * nf, 0);
-            std::vector<uint64_t> s_cnt((size_t)nl * nf, 0);
-            std::vector<int> shard_status(nl, ORAMA_OK);
-            std::vector<std::string> shard_error(nl);
-            auto run_shard = [&](uint32_t i) {
-                orama_post* p = shards[i];
-                auto body = [&]() -> int {
-                    ORAMA_ON_DEVICE(p->ctx->device);
-                    std::vector<RangeJob> jobs;
-                    jobs.reserve(nf);
-                    for (size_t f = 0; f < nf; ++f) {
-                        const orama_post_query_desc& qd = queries[fast[f]];
-                        const size_t o = ((size_t)i * nf + f);
-                        RangeJob job{qd.refs, qd.n_refs, &qd.params, &s_ids[o * stride_k], &s_sc[o * stride_k], &s_n[o], &s_cnt[o]};
-                        job.df_global = &df_global[f * kMaxTokens];
-                        jobs.push_back(job);
-                    }
-                    ScratchLease sc(p->ctx), sc2(p->ctx);
-                    const bool two = jobs.size() > kRangeBatchMax;
-                    if (two) ORAMA_TRY(ScratchLease::init_pair(sc, sc2));
-                    else ORAMA_TRY(sc.init());
-                    return post_search_ranges(p, sc.s.get(), jobs.data(), (uint32_t)jobs.size(), b, nullptr, 0, apply_omc,
-                                              two ? sc2.s.get() : nullptr);
-                };
-                shard_status[i] = body();
+        const uint32_t nc = (uint32_t)cand.size();
+        if (nc == 0) continue;
+        // every shard stays read-locked from its eligibility test to its last launch
+        std::vector<std::shared_lock<std::shared_mutex>> locks;
+        for (uint32_t i = 0; i < nl; ++i) locks.emplace_back(shards[i]->mu);
+        std::vector<uint32_t> words((size_t)nc * kWordsPerQuery, 0);  // [df x 64 | cannot | failed] per query, summed over the shards
+        auto df_of_query = [&](size_t c) { return &words[c * kWordsPerQuery]; };
+        std::vector<std::vector<uint32_t>> shard_df(nl, std::vector<uint32_t>((size_t)nc * kMaxTokens, 0));
+        std::vector<int> shard_status(nl, ORAMA_OK);
+        std::vector<std::string> shard_error(nl);
+        std::vector<char> can((size_t)nl * nc, 1);
+        auto on_shards = [&](const std::function<int(uint32_t)>& body) {
+            auto run = [&](uint32_t i) {
+                shard_status[i] = body(i);
                 if (shard_status[i] != ORAMA_OK) shard_error[i] = orama_last_error();  // this thread's slot
             };
             std::vector<std::thread> pool;
-            for (uint32_t i = 1; i < nl; ++i) pool.emplace_back(run_shard, i);
-            run_shard(0);
+            for (uint32_t i = 1; i < nl; ++i) pool.emplace_back(run, i);
+            run(0);
             for (auto& t : pool) t.join();
-            bool all_ok = true;
-            for (uint32_t i = 0; i < nl; ++i) all_ok = all_ok && shard_status[i] == ORAMA_OK;
-            if (!all_ok) {
-                // a set of launches failed as a whole on some shard: every query of it is answered (or refused) on its own
-                slow.insert(slow.end(), fast.begin(), fast.end());
-            } else {
-                struct Hit {
-                    float score;
-                    uint64_t id;
-                };
-                std::vector<Hit> hits;
-                for (size_t f = 0; f < nf; ++f) {
-                    const uint32_t j = fast[f], k = queries[j].params.top_k;
-                    hits.clear();
-                    uint64_t count = 0;
-                    for (uint32_t i = 0; i < nl; ++i) {
-                        const size_t o = (size_t)i * nf + f;
-                        count += s_cnt[o];
-                        for (uint32_t e = 0; e < s_n[o]; ++e) hits.push_back(Hit{s_sc[o * stride_k + e], s_ids[o * stride_k + e]});
-                    }
-                    std::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& c) { return a.score > c.score || (a.score == c.score && a.id < c.id); });
-                    const uint32_t n = (uint32_t)std::min<size_t>(hits.size(), k);
-                    for (uint32_t e = 0; e < n; ++e) {
-                        out_ids[(size_t)j * stride_k + e] = hits[e].id;
-                        out_scores[(size_t)j * stride_k + e] = hits[e].score;
-                    }
-                    out_n[j] = n;
-                    if (out_count) out_count[j] = count;
+        };
+        // ---- phase A: this process's df of every token (+ the two flags)
+        on_shards([&](uint32_t i) -> int {
+            orama_post* p = shards[i];
+            ORAMA_ON_DEVICE(p->ctx->device);
+            std::vector<RangeJob> jobs;
+            std::vector<uint32_t> dummy_n(nc, 0);
+            for (uint32_t c = 0; c < nc; ++c) {
+                const orama_post_query_desc& qd = queries[cand[c]];
+                if (!ranges_eligible(p, qd.refs, qd.n_refs, &qd.params)) {
+                    can[(size_t)i * nc + c] = 0;
+                    continue;
                 }
+                RangeJob job{qd.refs, qd.n_refs, &qd.params, nullptr, nullptr, &dummy_n[c], nullptr};
+                job.df_out = &shard_df[i][(size_t)c * kMaxTokens];
+                jobs.push_back(job);
             }
+            if (jobs.empty()) return ORAMA_OK;
+            ScratchLease sc(p->ctx), sc2(p->ctx);
+            const bool two = jobs.size() > kRangeBatchMax;
+            if (two) ORAMA_TRY(ScratchLease::init_pair(sc, sc2));
+            else ORAMA_TRY(sc.init());
+            return post_search_ranges(p, sc.s.get(), jobs.data(), (uint32_t)jobs.size(), b, allow_bitmaps ? allow_bitmaps[i] : nullptr,
+                                      allow_bitmaps ? bitmap_bits : 0, apply_omc, two ? sc2.s.get() : nullptr, /*df_pass=*/true);
+        });
+        for (uint32_t i = 0; i < nl; ++i)
+            for (uint32_t c = 0; c < nc; ++c) {
+                uint32_t* w = df_of_query(c);
+                for (uint32_t t = 0; t < kMaxTokens; ++t) w[t] += shard_df[i][(size_t)c * kMaxTokens + t];
+                if (!can[(size_t)i * nc + c]) w[kMaxTokens] += 1;
+                if (shard_status[i] != ORAMA_OK) w[kMaxTokens + 1] += 1;
+            }
+        int local_fail = ORAMA_OK;
+        std::string local_error;
+        for (uint32_t i = 0; i < nl && local_fail == ORAMA_OK; ++i)
+            if (shard_status[i] != ORAMA_OK) local_fail = shard_status[i], local_error = shard_error[i];
+        // ---- exchange 1: index-wide df and flags
+        {
+            const int st = shard_sum_u32(g, words.data(), words.size());
+            if (st != ORAMA_OK) return st;  // the transport itself failed: nothing more can be agreed on
+        }
+        bool any_failed = false;
+        for (uint32_t c = 0; c < nc; ++c) any_failed = any_failed || df_of_query(c)[kMaxTokens + 1] != 0;
+        if (any_failed) {  // (seen by every rank: all of them stop here)
+            call_status = local_fail != ORAMA_OK ? local_fail : ORAMA_ERR_HIP;
+            if (local_fail != ORAMA_OK) set_error("sharded batch: %s", local_error.c_str());
+            else set_error("sharded batch: the df pass failed on another rank");
+            break;
+        }
+        std::vector<uint32_t> fast;  // positions in `cand`
+        for (uint32_t c = 0; c < nc; ++c) {
+            if (df_of_query(c)[kMaxTokens] == 0) fast.push_back(c);
+            else slow.push_back(cand[c]);
+        }
+        const uint32_t nf = (uint32_t)fast.size();
+        if (nf == 0) continue;
+        // ---- phase B: every local shard scores the fast queries with the index-wide df -> its block
+        // block of one shard: [nf x stride_k ids u64][nf x stride_k scores f32][nf n u32][nf count u64][failed u32, pad]
+        const size_t ids_bytes = (size_t)nf * stride_k * 8, sc_bytes = (size_t)nf * stride_k * 4, n_bytes = (((size_t)nf * 4) + 7) & ~(size_t)7;
+        const size_t cnt_bytes = (size_t)nf * 8, block_bytes = ids_bytes + ((sc_bytes + 7) & ~(size_t)7) + n_bytes + cnt_bytes + 8;
+        const size_t off_sc = ids_bytes, off_n = off_sc + ((sc_bytes + 7) & ~(size_t)7), off_cnt = off_n + n_bytes, off_fail = off_cnt + cnt_bytes;
+        std::vector<char> local_blocks(block_bytes * nl, 0);
+        std::vector<uint32_t> df_fast((size_t)nf * kMaxTokens);
+        for (uint32_t x = 0; x < nf; ++x) memcpy(&df_fast[(size_t)x * kMaxTokens], df_of_query(fast[x]), sizeof(uint32_t) * kMaxTokens);
+        on_shards([&](uint32_t i) -> int {
+            orama_post* p = shards[i];
+            ORAMA_ON_DEVICE(p->ctx->device);
+            char* blk = local_blocks.data() + (size_t)i * block_bytes;
+            std::vector<RangeJob> jobs;
+            jobs.reserve(nf);
+            for (uint32_t x = 0; x < nf; ++x) {
+                const orama_post_query_desc& qd = queries[cand[fast[x]]];
+                RangeJob job{qd.refs, qd.n_refs, &qd.params, reinterpret_cast<uint64_t*>(blk) + (size_t)x * stride_k,
+                             reinterpret_cast<float*>(blk + off_sc) + (size_t)x * stride_k, reinterpret_cast<uint32_t*>(blk + off_n) + x,
+                             reinterpret_cast<uint64_t*>(blk + off_cnt) + x};
+                job.df_global = &df_fast[(size_t)x * kMaxTokens];
+                jobs.push_back(job);
+            }
+            ScratchLease sc(p->ctx), sc2(p->ctx);
+            const bool two = jobs.size() > kRangeBatchMax;
+            if (two) ORAMA_TRY(ScratchLease::init_pair(sc, sc2));
+            else ORAMA_TRY(sc.init());
+            return post_search_ranges(p, sc.s.get(), jobs.data(), (uint32_t)jobs.size(), b, allow_bitmaps ? allow_bitmaps[i] : nullptr,
+                                      allow_bitmaps ? bitmap_bits : 0, apply_omc, two ? sc2.s.get() : nullptr);
+        });
+        local_fail = ORAMA_OK;
+        for (uint32_t i = 0; i < nl; ++i)
+            if (shard_status[i] != ORAMA_OK) {
+                *reinterpret_cast<uint32_t*>(local_blocks.data() + (size_t)i * block_bytes + off_fail) = 1u;
+                if (local_fail == ORAMA_OK) local_fail = shard_status[i], local_error = shard_error[i];
+            }
+        locks.clear();
+        // ---- exchange 2: every shard's block
+        std::vector<char> all_blocks(block_bytes * world);
+        {
+            const int st = shard_gather_blocks(g, local_blocks.data(), block_bytes, all_blocks.data());
+            if (st != ORAMA_OK) return st;
+        }
+        for (uint32_t r = 0; r < world; ++r) any_failed = any_failed || *reinterpret_cast<const uint32_t*>(all_blocks.data() + (size_t)r * block_bytes + off_fail) != 0;
+        if (any_failed) {
+            call_status = local_fail != ORAMA_OK ? local_fail : ORAMA_ERR_HIP;
+            if (local_fail != ORAMA_OK) set_error("sharded batch: %s", local_error.c_str());
+            else set_error("sharded batch: the scoring pass failed on another rank");
+            break;
+        }
+        // ---- phase C: merge by (score desc, DocumentId asc), sum the counts
+        struct Hit {
+            float score;
+            uint64_t id;
+        };
+        std::vector<Hit> hits;
+        for (uint32_t x = 0; x < nf; ++x) {
+            const uint32_t j = cand[fast[x]], k = queries[j].params.top_k;
+            hits.clear();
+            uint64_t count = 0;
+            for (uint32_t r = 0; r < world; ++r) {
+                const char* blk = all_blocks.data() + (size_t)r * block_bytes;
+                const uint32_t n = reinterpret_cast<const uint32_t*>(blk + off_n)[x];
+                count += reinterpret_cast<const uint64_t*>(blk + off_cnt)[x];
+                const uint64_t* ids = reinterpret_cast<const uint64_t*>(blk) + (size_t)x * stride_k;
+                const float* sc = reinterpret_cast<const float*>(blk + off_sc) + (size_t)x * stride_k;
+                for (uint32_t e = 0; e < n && e < stride_k; ++e) hits.push_back(Hit{sc[e], ids[e]});
+            }
+            std::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& c) { return a.score > c.score || (a.score == c.score && a.id < c.id); });
+            const uint32_t n = (uint32_t)std::min<size_t>(hits.size(), k);
+            for (uint32_t e = 0; e < n; ++e) {
+                out_ids[(size_t)j * stride_k + e] = hits[e].id;
+                out_scores[(size_t)j * stride_k + e] = hits[e].score;
+            }
+            out_n[j] = n;
+            if (out_count) out_count[j] = count;
         }
     }
-    // (the shard locks are released: the staged query below takes them itself)
+    if (call_status != ORAMA_OK) {  // systemic: every query of the call carries it (nothing is retried one by one)
+        const std::string err = orama_last_error();
+        for (uint32_t j = 0; j < n_queries; ++j) {
+            out_n[j] = 0;
+            if (out_count) out_count[j] = 0;
+            if (out_status) out_status[j] = call_status;
+        }
+        set_error("%s", err.c_str());
+        return call_status;
+    }
+    // (the shard locks are released: the staged query below takes them itself; `slow` is the same list on every rank)
+    std::sort(slow.begin(), slow.end());
     for (uint32_t j : slow) {
         const orama_post_query_desc& qd = queries[j];
         uint64_t cnt = 0;

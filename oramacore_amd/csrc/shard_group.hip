@@ -34,6 +34,7 @@
 #include "bm25_kernels.hpp"
 #include "common.hpp"
 #include "select.hpp"
+#include "shard_exchange.hpp"
 #include "vec_internal.hpp"
 
 using namespace orama;
@@ -854,6 +855,96 @@ int orama_shard_hybrid_search(orama_shard_group* g, orama_vec* const* vec_shards
 }
 
 }  // extern "C"
+
+// ====================================================================== host-level exchanges of multi-phase calls
+namespace orama {
+
+int ShardCall::init() {
+    LaneLease* l = new (std::nothrow) LaneLease(g_);
+    if (!l) {
+        set_error("out of host memory");
+        return ORAMA_ERR_OOM;
+    }
+    const int st = l->init();
+    if (st != ORAMA_OK) {
+        delete l;
+        return st;
+    }
+    lease_ = l;
+    return ORAMA_OK;
+}
+ShardCall::~ShardCall() { delete static_cast<LaneLease*>(lease_); }
+
+void shard_group_shape(orama_shard_group* g, uint32_t* world, uint32_t* nl, uint32_t* rank0) {
+    if (world) *world = (uint32_t)g->world;
+    if (nl) *nl = n_local(g);
+    if (rank0) *rank0 = (uint32_t)g->rank0;
+}
+
+int shard_sum_u32(orama_shard_group* g, uint32_t* inout, size_t count) {
+    if (count == 0 || g->colocated || g->world == (int)n_local(g)) return ORAMA_OK;  // every shard is here: already summed
+    DeviceScope caller_device__;
+    ORAMA_LEASE_LANE(g);
+    const uint32_t nl = n_local(g);
+    // local shard 0 carries the process's contribution, the other local ranks add zeros (every rank of the communicator
+    // takes part in the collective)
+    for (uint32_t i = 0; i < nl; ++i) {
+        ShardLocal& s = L(g, i);
+        ORAMA_HIP_TRY(hipSetDevice(s.device));
+        ORAMA_TRY(s.df.reserve(std::max<size_t>(count * 4, kDfWords * 4)));
+        if (i == 0) ORAMA_HIP_TRY(hipMemcpyAsync(s.df.p, inout, count * 4, hipMemcpyHostToDevice, s.stream));
+        else ORAMA_HIP_TRY(hipMemsetAsync(s.df.p, 0, count * 4, s.stream));
+    }
+    {
+        Rccl* r = g->rccl;
+        std::lock_guard<std::mutex> issue(g->issue_mu);
+        if (nl > 1) ORAMA_NCCL_TRY(r, r->GroupStart());
+        for (uint32_t i = 0; i < nl; ++i) {
+            ShardLocal& s = L(g, i);
+            ORAMA_HIP_TRY(hipSetDevice(s.device));
+            ORAMA_NCCL_TRY(r, r->AllReduce(s.df.p, s.df.p, count, kNcclInt32, kNcclSum, s.comm, s.stream));
+        }
+        if (nl > 1) ORAMA_NCCL_TRY(r, r->GroupEnd());
+    }
+    ShardLocal& s0 = L(g, 0);
+    ORAMA_HIP_TRY(hipSetDevice(s0.device));
+    ORAMA_HIP_TRY(hipMemcpyAsync(inout, s0.df.p, count * 4, hipMemcpyDeviceToHost, s0.stream));
+    for (uint32_t i = 0; i < nl; ++i) {
+        ORAMA_HIP_TRY(hipSetDevice(L(g, i).device));
+        ORAMA_HIP_TRY(hipStreamSynchronize(L(g, i).stream));
+    }
+    return ORAMA_OK;
+}
+
+int shard_gather_blocks(orama_shard_group* g, const void* local_blocks, size_t block_bytes, void* out) {
+    const uint32_t nl = n_local(g);
+    if (block_bytes == 0) return ORAMA_OK;
+    if (g->colocated || g->world == (int)nl) {
+        memcpy(out, local_blocks, block_bytes * nl);
+        return ORAMA_OK;
+    }
+    DeviceScope caller_device__;
+    ORAMA_LEASE_LANE(g);
+    ORAMA_TRY(reserve_gathered(g, block_bytes));
+    for (uint32_t i = 0; i < nl; ++i) {
+        ShardLocal& s = L(g, i);
+        ORAMA_HIP_TRY(hipSetDevice(s.device));
+        ORAMA_HIP_TRY(hipMemcpyAsync(s.gathered.as<char>() + (size_t)slot_of(g, i) * block_bytes,
+                                     static_cast<const char*>(local_blocks) + (size_t)i * block_bytes, block_bytes, hipMemcpyHostToDevice,
+                                     s.stream));
+    }
+    ORAMA_TRY(exchange_all_gather(g, block_bytes));
+    ShardLocal& s0 = L(g, 0);
+    ORAMA_HIP_TRY(hipSetDevice(s0.device));
+    ORAMA_HIP_TRY(hipMemcpyAsync(out, s0.gathered.p, block_bytes * (size_t)g->world, hipMemcpyDeviceToHost, s0.stream));
+    for (uint32_t i = 0; i < nl; ++i) {
+        ORAMA_HIP_TRY(hipSetDevice(L(g, i).device));
+        ORAMA_HIP_TRY(hipStreamSynchronize(L(g, i).stream));
+    }
+    return ORAMA_OK;
+}
+
+}  // namespace orama
 
 // ====================================================================== pipelined session (bench / serving loop)
 // Queries resident in HBM on every local device, steps enqueued back to back without host synchronisation: ONE scan

@@ -174,11 +174,15 @@ def run_job(group: ShardGroup, shard_ids: list[int], world: int) -> dict:
         ids, sc, count = group.post_search(posts, refs, n_tok, total, 30, threshold=case["threshold"], vector=vec,
                                            apply_omc=False)
         out[f"hyb{ci}_ids"], out[f"hyb{ci}_sc"], out[f"hyb{ci}_count"] = ids, sc, np.uint64(count)
-    # ---- the batch entry: one process per rank -> every query through the staged sharded query (collectives in batch order);
-    # one process holding every shard -> the range scorer on every shard, df summed on the host, no collective
+    # ---- the batch entry: the range scorer on every shard in three phases — df (list lengths or the counting launch), ONE
+    # all-reduce of the df words, scoring with the index-wide idf, ONE all-gather of the shards' top-k blocks — whatever the
+    # shape of the group (round 3: one process per rank fell back to one staged query at a time)
     batch = [(refs_of(meta, list_id, meta["cases"][ci]), len(meta["cases"][ci]["terms"]), meta["cases"][ci]["threshold"]) for ci in TEXT_CASES]
     for bi, (ids, sc, count) in enumerate(group.post_search_batch(posts, batch, float(meta["n_docs"]), 40)):
         out[f"batch{bi}_ids"], out[f"batch{bi}_sc"], out[f"batch{bi}_count"] = ids, sc, np.uint64(count)
+    # ... and under the NOT-deleted filter: every shard counts its df (filter + several lists per token), ONE all-reduce sums them
+    for bi, (ids, sc, count) in enumerate(group.post_search_batch(posts, batch, float(meta["n_docs"]), 40, allow=res)):
+        out[f"batchf{bi}_ids"], out[f"batchf{bi}_sc"], out[f"batchf{bi}_count"] = ids, sc, np.uint64(count)
     # request batchers form their batches from whatever arrived: refused when ranks live in other processes
     try:
         group.post_batcher(posts).close()

@@ -74,6 +74,8 @@ def expected(ctx):
     batch = [(W.refs_of(meta, list_id, meta["cases"][ci]), len(meta["cases"][ci]["terms"]), meta["cases"][ci]["threshold"]) for ci in W.TEXT_CASES]
     for bi, r in enumerate(post.search_batch(batch, total, 40)):
         e[f"batch{bi}"] = r
+    for bi, r in enumerate(post.search_batch(batch, total, 40, allow=bm)):
+        e[f"batchf{bi}"] = r
     post.set_omc({int(doc_ids[3]): 2.0, int(doc_ids[-2]): 4.0, int(doc_ids[1000]): 0.5})
     case = meta["cases"][12]
     e["omc"] = post.search(W.refs_of(meta, list_id, case), len(case["terms"]), total, 100)
@@ -113,7 +115,7 @@ def check_rank(got, e, world, form, rank):
     assert same(got["wide_cnt"], cnt) and same(got["wide_ids"], ids) and same(got["wide_dist"], dist), (what, "wide")
     assert int(got["batcher_refused"]) == (1 if form == "rank" else 0), what
     for key in ([f"text{ci}" for ci in W.TEXT_CASES] + [f"hyb{ci}" for ci in W.TEXT_CASES] + ["omc", "onecall_a", "onecall_b"] +
-                [f"batch{bi}" for bi in range(len(W.TEXT_CASES))]):
+                [f"batch{bi}" for bi in range(len(W.TEXT_CASES))] + [f"batchf{bi}" for bi in range(len(W.TEXT_CASES))]):
         ids, sc, count = e[key]
         assert int(got[key + "_count"]) == count, (what, key)
         assert got[key + "_ids"].tolist() == ids.tolist(), (what, key)
