@@ -86,10 +86,10 @@ def parse_args():
     ap.add_argument("--dump-result", default="",
                     help="every rank writes the last step's queries and answer (ids, distances, counts) to "
                          "<path>.rank<r>.npz after the timed region (multi-rank parity tests compare the ranks)")
-    ap.add_argument("--f16-slots", type=int, default=1,
+    ap.add_argument("--f16-slots", type=int, default=2,
                     help="fp16 workloads: steps in flight (each slot is one stream carrying its scans AND selections; the scans of two "
                          "slots cannot overlap — every scan kernel fills all CUs — but the launch-bound selections of one slot run beside "
-                         "the other slot's work; measured in profiles/, default 1)")
+                         "the other slot's work: +2.4 % at 256 queries per step, +4.1 % at 64, profiles/r04_f16_slots_experiment.log)")
     ap.add_argument("--no-preflight", action="store_true", help="self-launched N > 1: skip the pre-launch check of devices and RCCL")
     return ap.parse_args()
 
@@ -342,8 +342,11 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
     # concurrently, so each keeps the whole HBM bandwidth) + `--streams` high-priority tail streams used round-robin
     # for top-k / all-gather / merge, which are launch-bound and overlap the next step's scan.
     # fp16 workloads: the scan and its threshold-filter selections depend on each other step by step and all run on the
-    # tail stream, so a second slot would only make two corpus scans share the HBM bandwidth (and inflate the per-launch
-    # durations the roofline is computed from) — one slot.
+    # slot's one stream.  Two slots (two steps in flight, round 4): the scans of the two cannot overlap — every scan kernel
+    # fills all CUs, the second one's workgroups wait for the first's to leave — but one slot's launch-bound selection chain
+    # and query preparation run while the other slot scans: +2.4 % at 256 queries per step, +4.1 % at 64
+    # (profiles/r04_f16_slots_experiment.log; three slots add nothing).  The kernels' own durations are measured on a
+    # separate short pass with one step in flight (below).
     n_streams = max(1, f16_slots) if f16 else max(1, streams)
     sess = group.session([store], queries_h, qb, k, n_slots=n_streams, force_exchange=force_exchange)
 
@@ -372,11 +375,29 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
                  lo=lo, hi=hi, world=world)
 
     kern = "vec_scan_f16" if f16 else "vec_scan_f32"
+    prof_steps, prof_note = steps, "HIP events on the launching stream over the timed region"
+    if f16 and n_streams > 1:
+        # Two steps in flight: a launch of one slot queues behind the other slot's scan (every scan kernel fills all CUs), and an
+        # event pair on a stream then brackets that wait as well — the kernel's own duration (what rocprofv3 reports, what the
+        # roofline is about) is measured on a short pass with ONE step in flight instead.
+        sess.close()
+        sess = group.session([store], queries_h, qb, k, n_slots=1, force_exchange=force_exchange)
+        prof_steps = min(steps, 8)
+        sess.step(0)
+        sess.sync()
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        for i in range(1, 1 + prof_steps):
+            sess.step(i)
+        sess.sync()
+        ctx.prof_enable(False)
+        prof_note = (f"HIP events over {prof_steps} extra steps with ONE step in flight (the timed region runs {n_streams}: a launch "
+                     "then waits for the other slot's scan inside its event pair)")
     scan_ms, scan_n = ctx.prof_get(kern)
     sel_ms, _ = ctx.prof_get("topk_select")
     kpad = (dim + 127) // 128 * 128
     bytes_per_step = n_local * (kpad * 2 if f16 else dim * 4)  # one corpus pass per step
-    launches_per_step = max(scan_n, 1) / steps
+    launches_per_step = max(scan_n, 1) / prof_steps
     alg_bytes = bytes_per_step / launches_per_step
     avg_scan_s = scan_ms / max(scan_n, 1) / 1e3
     achieved = alg_bytes / avg_scan_s / 1e9 if scan_n else 0.0
@@ -404,14 +425,15 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
                      "alg_bytes_per_launch": alg_bytes,
                      "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_n,
                      "scan_launches_per_step": launches_per_step,
-                     "topk_select_ms_per_step": sel_ms / steps,
+                     "topk_select_ms_per_step": sel_ms / prof_steps,
+                     "kernel_durations_from": prof_note,
                      "clocks_during_timed_region": clocks.summary()},
         "parity_check": "last step vs oracle: distances recomputed from the rows (<= 1e-4), no better row among 20 000 "
                         "sampled rows of the shard",
         "fill_seconds": t_fill,
     }
     if f16:
-        flops = 2.0 * qb * n_local * kpad * steps
+        flops = 2.0 * qb * n_local * kpad * prof_steps
         out["roofline"]["mfma_tflops"] = flops / (scan_ms / 1e3) / 1e12 if scan_ms else 0.0
         out["roofline"]["mfma_peak_tflops_dense_f16"] = MFMA_F16_PEAK_TFLOPS
         out["roofline"]["mfma_frac"] = out["roofline"]["mfma_tflops"] / MFMA_F16_PEAK_TFLOPS
@@ -801,13 +823,13 @@ def main():
                 st.close()
             st16 = None
             if "c3" in want:
-                configs["c3"], st16, qh = vector_leg(oa, group, "c3", WORKLOADS["c3"][0], 30, 3, 1)
+                configs["c3"], st16, qh = vector_leg(oa, group, "c3", WORKLOADS["c3"][0], 30, 3, 1, f16_slots=args.f16_slots)
                 configs["c3"].update(host_api_latency(st16, qh, 64, k, n=10))
             if "c5_shard" in want:
                 # the per-GPU shard of BASELINE configs[4]: 10 M of the 80 M x 768 fp16 rows, all 256 queries of a batch
                 # (the rows are the ones C3 scans: the same store serves both legs)
                 configs["c5_shard"], st16, _ = vector_leg(
-                    oa, group, "c5", 10_000_000, 20, 3, 1, store=st16,
+                    oa, group, "c5", 10_000_000, 20, 3, 1, store=st16, f16_slots=args.f16_slots,
                     desc="per-GPU shard (10M rows) of: " + WORKLOADS["c5"][5])
                 configs["c5_shard"]["config"]["note"] = ("one of the eight 10 M-row shards of configs[4] on one GPU; the 8-GPU "
                                                          "job adds one 307 KB all-gather + merge per batch")

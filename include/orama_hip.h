@@ -51,7 +51,11 @@
 extern "C" {
 #endif
 
-#define ORAMA_ABI_VERSION 1
+/* 2 (round 4): every search / insert entry point may return ORAMA_ERR_BUSY (5) — acquire times out where version 1 blocked —;
+ * orama_ctx_set_f16_wide refuses the comparison kernels (modes 1, 5) in the product library; co-located groups are limited to 16
+ * shards; a postings store keeps 4 more bytes per posting (the pre-divided normalised tf).  A shim built against version 1
+ * must map status 5 before it is relinked. */
+#define ORAMA_ABI_VERSION 2
 
 /* status codes */
 #define ORAMA_OK 0

@@ -112,7 +112,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         raise RuntimeError(f"{path} not found — run `python __graft_entry__.py` (build) first; no CPU fallback exists")
     lib = C.CDLL(str(path))
     _declare(lib)
-    if lib.orama_abi_version() != 1:
+    if lib.orama_abi_version() != 2:
         raise RuntimeError("liborama_hip ABI version mismatch")
     _lib = lib
     return lib

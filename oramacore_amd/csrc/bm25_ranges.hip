@@ -58,7 +58,10 @@ constexpr int kBoundsThreads = 256;
 // launch is a chain of dependent loads and nothing else, and it sits at the head of every query: 14 us alone, 44 us beside the
 // 4.3 ms vector scan of a hybrid query (profiles/r03_hybrid_tail_timeline_after.log), with one thread per entry.
 // (The very first form walked every referenced posting — one thread per posting, 19 M threads per 32-query batch.)
-constexpr uint32_t kBoundsLanes = 16;
+// kBoundsLanes = 16 for small batches (the launch is latency: one query, or the few of a hybrid search); big batches hide the
+// latency behind their own parallelism and pay for the 16 probes per round instead (1.22 against 0.55 us per query at 32
+// queries per launch, profiles/r04_bounds_lanes.log): they search with ONE lane per entry, a plain binary search.
+template <uint32_t kBoundsLanes>
 __global__ __launch_bounds__(kBoundsThreads) void range_bounds_kernel(RangeBatch b) {
     const uint32_t qi = blockIdx.y;
     // the query's result words start at zero: cleared here, by the first launch of the set, instead of by a fill command
@@ -80,6 +83,14 @@ __global__ __launch_bounds__(kBoundsThreads) void range_bounds_kernel(RangeBatch
     if (r == 0) hi = 0;
     const uint32_t target = r * q.width;  // first document of range r (n_docs < 2^32)
     const uint32_t* pd = b.post_doc + (live ? sg->post_begin : 0ull);
+    if constexpr (kBoundsLanes == 1) {  // one lane per entry: binary search
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pd[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        if (live) b.bounds[q.bounds_base + e] = lo;
+        return;
+    }
     // the answer lies in [lo, hi]; every round cuts the window into 16 pieces (wave-uniform loop: groups that are done idle)
     for (;;) {
         const uint32_t span = hi - lo;
@@ -638,10 +649,12 @@ int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream)
     }
     ORAMA_REQUIRE(b.n_queries <= kRangeBatchMax, "bm25 ranges: batch too large");
     ProfScope prof(&ctx->prof, "bm25_range_bounds", stream);
-    const uint64_t per_block = kBoundsThreads / kBoundsLanes;  // entries a workgroup searches, 16 lanes each
+    const uint32_t lanes = b.n_queries <= 4 ? 16u : 1u;     // lanes that search one entry together
+    const uint64_t per_block = kBoundsThreads / lanes;      // entries a workgroup searches
     const uint64_t blocks = (b.max_bound_entries + per_block - 1) / per_block;
     ORAMA_SUPPORT(blocks < 0x7fffffffull, "bm25 ranges: batch references too many postings");
-    hipLaunchKernelGGL(range_bounds_kernel, dim3((uint32_t)blocks, b.n_queries), dim3(kBoundsThreads), 0, stream, b);
+    if (lanes == 16u) hipLaunchKernelGGL(range_bounds_kernel<16>, dim3((uint32_t)blocks, b.n_queries), dim3(kBoundsThreads), 0, stream, b);
+    else hipLaunchKernelGGL(range_bounds_kernel<1>, dim3((uint32_t)blocks, b.n_queries), dim3(kBoundsThreads), 0, stream, b);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

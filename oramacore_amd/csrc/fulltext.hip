@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <functional>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <deque>
 #include <shared_mutex>
@@ -2525,6 +2526,9 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
     for (uint32_t i = 0; i < nl; ++i) ORAMA_REQUIRE(shards[i], "null shard %u", i);
     ShardCall call(g);  // one lane of the group from the first collective to the last
     ORAMA_TRY(call.init());
+    static const bool trace = std::getenv("ORAMA_SHARD_BATCH_TRACE") != nullptr;  // phase times of every block on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     std::vector<int> status(n_queries, ORAMA_OK);
     std::vector<std::string> errors(n_queries);
     for (uint32_t j = 0; j < n_queries; ++j) {
@@ -2574,6 +2578,7 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
             for (auto& t : pool) t.join();
         };
         // ---- phase A: this process's df of every token (+ the two flags)
+        const auto t_block = now();
         on_shards([&](uint32_t i) -> int {
             orama_post* p = shards[i];
             ORAMA_ON_DEVICE(p->ctx->device);
@@ -2608,6 +2613,7 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
         std::string local_error;
         for (uint32_t i = 0; i < nl && local_fail == ORAMA_OK; ++i)
             if (shard_status[i] != ORAMA_OK) local_fail = shard_status[i], local_error = shard_error[i];
+        const double ms_a = ms_since(t_block);
         // ---- exchange 1: index-wide df and flags
         {
             const int st = shard_sum_u32(g, words.data(), words.size());
@@ -2628,6 +2634,8 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
         }
         const uint32_t nf = (uint32_t)fast.size();
         if (nf == 0) continue;
+        const double ms_x1 = ms_since(t_block) - ms_a;
+        const auto t_b = now();
         // ---- phase B: every local shard scores the fast queries with the index-wide df -> its block
         // block of one shard: [nf x stride_k ids u64][nf x stride_k scores f32][nf n u32][nf count u64][failed u32, pad]
         const size_t ids_bytes = (size_t)nf * stride_k * 8, sc_bytes = (size_t)nf * stride_k * 4, n_bytes = (((size_t)nf * 4) + 7) & ~(size_t)7;
@@ -2664,6 +2672,8 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
                 if (local_fail == ORAMA_OK) local_fail = shard_status[i], local_error = shard_error[i];
             }
         locks.clear();
+        const double ms_b = ms_since(t_b);
+        const auto t_x2 = now();
         // ---- exchange 2: every shard's block
         std::vector<char> all_blocks(block_bytes * world);
         {
@@ -2677,33 +2687,43 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
             else set_error("sharded batch: the scoring pass failed on another rank");
             break;
         }
+        const double ms_x2 = ms_since(t_x2);
+        const auto t_c = now();
         // ---- phase C: merge by (score desc, DocumentId asc), sum the counts
-        struct Hit {
-            float score;
-            uint64_t id;
-        };
-        std::vector<Hit> hits;
+        // (every shard's list is already in that order: a k-way merge of `world` sorted lists — a full sort of world x k hits per
+        // query was 7 us per query on the host, a third of the call)
+        std::vector<uint32_t> head(world);
         for (uint32_t x = 0; x < nf; ++x) {
             const uint32_t j = cand[fast[x]], k = queries[j].params.top_k;
-            hits.clear();
             uint64_t count = 0;
             for (uint32_t r = 0; r < world; ++r) {
-                const char* blk = all_blocks.data() + (size_t)r * block_bytes;
-                const uint32_t n = reinterpret_cast<const uint32_t*>(blk + off_n)[x];
-                count += reinterpret_cast<const uint64_t*>(blk + off_cnt)[x];
-                const uint64_t* ids = reinterpret_cast<const uint64_t*>(blk) + (size_t)x * stride_k;
-                const float* sc = reinterpret_cast<const float*>(blk + off_sc) + (size_t)x * stride_k;
-                for (uint32_t e = 0; e < n && e < stride_k; ++e) hits.push_back(Hit{sc[e], ids[e]});
+                head[r] = 0;
+                count += reinterpret_cast<const uint64_t*>(all_blocks.data() + (size_t)r * block_bytes + off_cnt)[x];
             }
-            std::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& c) { return a.score > c.score || (a.score == c.score && a.id < c.id); });
-            const uint32_t n = (uint32_t)std::min<size_t>(hits.size(), k);
-            for (uint32_t e = 0; e < n; ++e) {
-                out_ids[(size_t)j * stride_k + e] = hits[e].id;
-                out_scores[(size_t)j * stride_k + e] = hits[e].score;
+            uint32_t n = 0;
+            for (; n < k; ++n) {
+                int best = -1;
+                float best_sc = 0.0f;
+                uint64_t best_id = 0;
+                for (uint32_t r = 0; r < world; ++r) {
+                    const char* blk = all_blocks.data() + (size_t)r * block_bytes;
+                    const uint32_t len = std::min(reinterpret_cast<const uint32_t*>(blk + off_n)[x], stride_k);
+                    if (head[r] >= len) continue;
+                    const float sc = (reinterpret_cast<const float*>(blk + off_sc) + (size_t)x * stride_k)[head[r]];
+                    const uint64_t id = (reinterpret_cast<const uint64_t*>(blk) + (size_t)x * stride_k)[head[r]];
+                    if (best < 0 || sc > best_sc || (sc == best_sc && id < best_id)) best = (int)r, best_sc = sc, best_id = id;
+                }
+                if (best < 0) break;
+                ++head[best];
+                out_ids[(size_t)j * stride_k + n] = best_id;
+                out_scores[(size_t)j * stride_k + n] = best_sc;
             }
             out_n[j] = n;
             if (out_count) out_count[j] = count;
         }
+        if (trace)
+            fprintf(stderr, "[shard batch] %u queries, %u local shards of %u: df pass %.3f ms | exchange %.3f | scoring %.3f | gather %.3f | merge %.3f\n",
+                    nf, nl, world, ms_a, ms_x1, ms_b, ms_x2, ms_since(t_c));
     }
     if (call_status != ORAMA_OK) {  // systemic: every query of the call carries it (nothing is retried one by one)
         const std::string err = orama_last_error();

@@ -724,12 +724,14 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
     const int lane = threadIdx.x & 63;
     const unsigned long long* in = keys + (uint64_t)qi * in_stride;
     if (n_per_list) n_keys = min(n_keys, n_per_list[qi]);
-    if (n_keys > 2 * next_pow2(k)) {
-        // Many more candidates than answers (32 chunks x 100 survivors of a scan's wave lists: 3 200 keys for 100 results):
+    if (n_keys > k) {
+        // More candidates than answers (e.g. 32 chunks x 100 survivors of a scan's wave lists: 3 200 keys for 100 results):
         // ordering all of them is a 4 096-element bitonic sort with a 64-bit id gather per element, 80 us of a 4.4 ms query.
         // The k best BY KEY are cut out first — the radix threshold of the reduction levels, so that the cut among equal
         // values keeps the lowest indices exactly as every level before this one does (DESIGN.md §3 rule 4) — and only
-        // those are ordered by (value, id, index).
+        // those are ordered by (value, id, index).  For EVERY list longer than k (round 3 sorted lists of up to
+        // 2 x pow2(k) keys whole and let the lowest DocumentIds win the cut there: which tied rows came back depended on the
+        // list's length wherever DocumentIds are not monotonic in the row index — ADVICE r03).
         // (the key buffer aliases the whole record array: 8 192 keys — two reduction chunks' worth, see keys_final_capacity)
         unsigned long long* kb = reinterpret_cast<unsigned long long*>(&s);
         for (uint32_t i = threadIdx.x; i < n_keys; i += blockDim.x) kb[i] = in[i];

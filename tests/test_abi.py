@@ -10,7 +10,7 @@ from oramacore_amd import _build, _native as N
 
 def test_library_builds_and_loads():
     lib = N.load()
-    assert lib.orama_abi_version() == 1
+    assert lib.orama_abi_version() == 2
     assert _build.lib_path().exists()
 
 

@@ -409,3 +409,29 @@ def test_searches_are_not_blocked_by_a_large_ingest(ctx):
     assert st.info()["pending_ops"] == 0 and st.info()["num_rows"] == n0 + n_add - 1
     assert np.array_equal(before[0], after[0]) and np.allclose(before[1], after[1], atol=1e-6)
     st.close()
+
+
+def test_ties_at_the_cut_are_decided_by_row_index_whatever_the_list_length(ctx):
+    """DESIGN §3 rule 4 (the oracle's orc_vector_search): among rows at the SAME distance the k-th boundary keeps the lowest
+    ROW indices; the survivors are then ordered by (distance, DocumentId, row).  With DocumentIds that are not monotonic in
+    the row index the two orders differ — and round 3's final selection cut short lists (<= 2 x pow2(k) candidates) by
+    DocumentId and longer ones by row index.  Exact duplicates of one row make the ties; three store sizes put
+    the final selection on its short, its medium and its reduced (multi-chunk) path."""
+    d, k = 64, 100
+    rng = np.random.default_rng(77)
+    base = rng.standard_normal(d).astype(np.float32)
+    q = base + 0.01 * rng.standard_normal(d).astype(np.float32)
+    for n in (180, 1000, 40_000):
+        rows = rng.standard_normal((n, d)).astype(np.float32)
+        dup = np.sort(rng.choice(n, size=150, replace=False))  # 150 rows at the same (smallest) distance, k = 100 of them survive
+        rows[dup] = base
+        doc_ids = (np.uint64(10 * n) - np.arange(n, dtype=np.uint64) * np.uint64(7)).astype(np.uint64)  # descending: lowest rows = highest ids
+        st = oa.EmbeddingFieldStorage(ctx, dimensions=d)
+        st.insert_rows(doc_ids, rows)
+        ids, dist, cnt = st.storage_search(q, k)
+        o_ids, o_dist, o_rows = orc.vector_search(rows, doc_ids, q, k)
+        assert cnt[0] == k
+        assert set(o_rows.tolist()) == set(dup[:k].tolist())  # the oracle's rule: the lowest row indices among the ties
+        assert ids[0].tolist() == o_ids.tolist(), n
+        assert np.max(np.abs(dist[0] - o_dist)) <= 1e-6
+        st.close()
