@@ -86,10 +86,11 @@ def parse_args():
     ap.add_argument("--dump-result", default="",
                     help="every rank writes the last step's queries and answer (ids, distances, counts) to "
                          "<path>.rank<r>.npz after the timed region (multi-rank parity tests compare the ranks)")
-    ap.add_argument("--f16-slots", type=int, default=2,
+    ap.add_argument("--f16-slots", type=int, default=1,
                     help="fp16 workloads: steps in flight (each slot is one stream carrying its scans AND selections; the scans of two "
                          "slots cannot overlap — every scan kernel fills all CUs — but the launch-bound selections of one slot run beside "
-                         "the other slot's work: +2.4 % at 256 queries per step, +4.1 % at 64, profiles/r04_f16_slots_experiment.log)")
+                         "the other slot's work: +2.4 % at 256 queries per step and +4.1 % at 64 on its own, nothing inside the full bench "
+                         "run — profiles/r04_f16_slots_experiment.log; default 1)")
     ap.add_argument("--no-preflight", action="store_true", help="self-launched N > 1: skip the pre-launch check of devices and RCCL")
     return ap.parse_args()
 
@@ -342,11 +343,11 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
     # concurrently, so each keeps the whole HBM bandwidth) + `--streams` high-priority tail streams used round-robin
     # for top-k / all-gather / merge, which are launch-bound and overlap the next step's scan.
     # fp16 workloads: the scan and its threshold-filter selections depend on each other step by step and all run on the
-    # slot's one stream.  Two slots (two steps in flight, round 4): the scans of the two cannot overlap — every scan kernel
-    # fills all CUs, the second one's workgroups wait for the first's to leave — but one slot's launch-bound selection chain
-    # and query preparation run while the other slot scans: +2.4 % at 256 queries per step, +4.1 % at 64
-    # (profiles/r04_f16_slots_experiment.log; three slots add nothing).  The kernels' own durations are measured on a
-    # separate short pass with one step in flight (below).
+    # slot's one stream: ONE slot.  Two steps in flight (`--f16-slots 2`, round 4's experiment) cannot overlap their scans —
+    # every scan kernel fills all CUs with full-register waves, the second one's workgroups wait for the first's to leave —
+    # only one slot's launch-bound selection chain runs beside the other slot's scan: +2.4 % at 256 queries per step and
+    # +4.1 % at 64 measured alone, nothing inside this script's full run, and every HIP-event duration then includes the
+    # wait for the other slot (profiles/r04_f16_slots_experiment.log).  Not the default.
     n_streams = max(1, f16_slots) if f16 else max(1, streams)
     sess = group.session([store], queries_h, qb, k, n_slots=n_streams, force_exchange=force_exchange)
 
@@ -488,29 +489,6 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
     ctx.prof_enable(False)
     scan_ms, scan_n = ctx.prof_get("vec_scan_f32")
     k3_launches = ctx.prof_get("bm25_accumulate")[1]  # 0 = every query took the range scorer + candidate tail
-    # The same queries from TWO callers (the reference serves search(&self) from many tokio workers at once,
-    # read/collection.rs:846-884): the scans still run one after the other, but one caller's tail — top-k of the scan, the
-    # per-document full-text scores, the host merge — overlaps the other's scan.  Reported beside `value`, never as it.
-    import threading
-
-    def caller(lo_i, hi_i, out):
-        for i in range(lo_i, hi_i):
-            out.append((i, hybrid(i)))
-
-    two_out = [[], []]
-    mid = warmup + (total - warmup) // 2
-    ths = [threading.Thread(target=caller, args=(warmup, mid, two_out[0])), threading.Thread(target=caller, args=(mid, total, two_out[1]))]
-    t0 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    ctx.synchronize()
-    el_two = time.perf_counter() - t0
-    for i, r in two_out[0] + two_out[1]:
-        a = plain_results[i - warmup]
-        assert a[2] == r[2] and np.array_equal(a[0], r[0]) and np.array_equal(a[1].view(np.uint32), r[1].view(np.uint32)), \
-            "hybrid answers of concurrent callers differ from the single caller's"
     shadow_out = None
     if shadow is not None:
         for i in range(warmup):
@@ -634,9 +612,6 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
                      "note": "a hybrid query = the fp32 scan (dominant) + the full-text leg on a second stream"},
         "full_text_leg": ("range scorer (K3r) beside the scan + candidate tail after it" if k3_launches == 0 else
                           f"per-record scorer (K3) used by {k3_launches} launches"),
-        "two_callers": {"value": steps / el_two, "unit": "queries/s", "ms_per_query": el_two / steps * 1e3,
-                        "note": "the same queries issued by two threads (one orama_hybrid_search each at a time): identical answers; "
-                                "one caller's tail overlaps the other's scan"},
         "shadow_store": shadow_out,
         "bm25_only": {"value": len(batch_q) / el_bb, "unit": "queries/s",
                       "note": "one orama_post_search_batch call over %d queries, descriptors built beforehand: K3r scores 32 queries "

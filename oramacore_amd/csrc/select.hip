@@ -209,6 +209,8 @@ __device__ __forceinline__ bool rec_before(uint32_t ha, uint64_t ia, uint32_t xa
     return xa < xb;
 }
 
+// USE_ID = false orders by (value, index) only — the order in which the k-th boundary is cut (DESIGN §3 rule 4)
+template <bool USE_ID = true>
 __device__ void lds_bitonic_sort(SortLds& s, uint32_t p2) {
     for (uint32_t size = 2; size <= p2; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
@@ -219,7 +221,7 @@ __device__ void lds_bitonic_sort(SortLds& s, uint32_t p2) {
                 uint32_t ha = s.hi[lo], hb = s.hi[hi];
                 uint64_t ia = s.id[lo], ib = s.id[hi];
                 uint32_t xa = s.idx[lo], xb = s.idx[hi];
-                bool b_first = rec_before(hb, ib, xb, ha, ia, xa);
+                bool b_first = USE_ID ? rec_before(hb, ib, xb, ha, ia, xa) : rec_before(hb, 0, xb, ha, 0, xa);
                 if (b_first == up) {
                     s.hi[lo] = hb; s.hi[hi] = ha;
                     s.id[lo] = ib; s.id[hi] = ia;
@@ -316,8 +318,24 @@ __global__ __launch_bounds__(kSortThreads) void select_small_kernel(
     }
     if (my_valid) atomicAdd(&valid_s, my_valid);
     __syncthreads();
-    lds_bitonic_sort(s, p2);
     const uint32_t count = min(valid_s, k);
+    if (id_map && valid_s > k) {
+        // more candidates than answers and ids of their own: the k-th boundary is cut by (value, INDEX) — as the radix
+        // selection of the longer lists, the reduction levels of the key lists and the oracle cut it — and only the survivors
+        // are ordered by (value, id, index).  (One sort by (value, id, index) let the lowest ids win the cut: with ids that do
+        // not grow with the index, which tied entries came back depended on the list's length — ADVICE r03.)
+        lds_bitonic_sort<false>(s, p2);
+        const uint32_t pk = next_pow2(max(count, 1u));
+        for (uint32_t i = count + threadIdx.x; i < pk; i += blockDim.x) {
+            s.hi[i] = 0;
+            s.idx[i] = 0xffffffffu;
+            s.id[i] = ~0ull;
+        }
+        __syncthreads();
+        lds_bitonic_sort(s, pk);
+    } else {
+        lds_bitonic_sort(s, p2);
+    }
     write_sorted(s, count, k, descending, out_idx ? out_idx + (uint64_t)qi * k : nullptr,
                  out_ids ? out_ids + (uint64_t)qi * k : nullptr, out_val + (uint64_t)qi * k,
                  out_n ? out_n + qi : nullptr);
