@@ -598,11 +598,16 @@ int orama_shard_hybrid_search(orama_shard_group* g, orama_vec* const* vec_shards
  * carrying the same array share a pass).  Every shard of the group must live in this process (ORAMA_ERR_UNSUPPORTED
  * otherwise: processes would form different batches).  The group and the stores must outlive the batcher. */
 /* orama_post_search_batch_status over the document shards of one index (`shards`: the group's local shards in rank order,
- * built as for orama_shard_post_search).  When every shard of the group lives in this process, queries with one posting
- * list per token and no filter are scored by the range scorer on all shards side by side — the index-wide df is the sum of
- * the shards' list lengths, known on the host, so no collective runs — and merged on the host; every other query is
- * answered by orama_shard_post_search, one at a time.  allow_bitmaps: NULL or one resident token per local shard.
- * Results per query as orama_post_search over the union of the shards, bit for bit; out_status may be NULL. */
+ * built as for orama_shard_post_search) — for every shape of group: all shards in this process or one process per rank
+ * (every rank then makes the same call: same queries, same order).  Per block of <= 512 queries: every shard's df of every
+ * token (list lengths where exact; under a filter or with several lists per token the range scorer's counting launch), ONE
+ * all-reduce sums them over the index (corpus_docs.len(), token_score.rs:262-275); every shard scores the block with the range
+ * scorer and the index-wide idf; ONE all-gather moves the shards' top-k blocks and every rank merges them by (score desc,
+ * DocumentId asc) and sums the counts (sort.rs:260-279, search.rs:482).  Queries the range scorer does not take (more than 64
+ * non-empty lists) are answered afterwards by orama_shard_post_search, one at a time.  A systemic failure on any shard
+ * (ORAMA_ERR_BUSY, _HIP, _OOM) ends the call with that status for every query on every rank.  allow_bitmaps: NULL or one
+ * resident token per local shard.  Results per query as orama_post_search over the union of the shards, bit for bit;
+ * out_status may be NULL. */
 int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shards, const orama_post_query_desc* queries,
                                   uint32_t n_queries, float b, const uint64_t* const* allow_bitmaps, uint64_t bitmap_bits,
                                   int apply_omc, uint32_t stride_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
