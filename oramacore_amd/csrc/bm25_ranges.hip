@@ -171,8 +171,6 @@ struct ScoreLds {
     uint32_t wave_tot[kWaves];
     uint32_t red[4];                            // slot base, count, max key, ~min key
     uint32_t cell_cursor;                       // cells handed out | multi documents << 16
-    uint32_t cand_n;                            // pass 2: keys at or above the filter bound so far
-    unsigned long long cand[kCandPerRange];     // ... and the first kCandPerRange of them
     __device__ __forceinline__ uint32_t* bitmap() { return region_a; }
     __device__ __forceinline__ uint16_t* word_rank() { return reinterpret_cast<uint16_t*>(region_a + kBitWords); }
     __device__ __forceinline__ float* cellv() { return reinterpret_cast<float*>(region_a); }
@@ -187,8 +185,6 @@ static_assert(kRangeMaxRefs <= 64, "one bit per reference in the presence masks"
 struct ScoreRange {
     uint32_t qi, cap, slot_base, doc0, n_words;
     bool count_each;
-    unsigned long long* out;   // pass 0: the range's slots of the key list; pass 1: its slots of the sample region; pass 2: its candidate slots
-    unsigned long long tau;    // pass 2: keys below it are dropped (>= 1)
 };
 
 // Phases 1-6 for a workgroup whose lanes carry NITER postings each (NITER * 256 >= cap): compiled per NITER so that the
@@ -295,6 +291,9 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
         }
     }
     __syncthreads();
+    uint32_t n_touched = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) n_touched += L.wave_tot[w];
 
     // ---- 3. every kept posting: rank of its document, its REFERENCE (list) into the document's presence mask.  One bit per
     // list, not per token: a document is then at most once behind each bit, every posting owns its cell, and the cells of a
@@ -310,30 +309,22 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
         if (pk[n] >> 31) atomicOr(&L.dmask[rank], (mask_t)1 << ((pk[n] >> 17) & 63u));
     }
     __syncthreads();
-    // every posting reads its document's mask ONCE and keeps what it needs of it in its packed word: is the document a
-    // singleton (bit 24), and how many of the document's lists come before this posting's (bits 17-22, in place of the run
-    // index, which only named the bit) — 8 registers of masks less per lane through the rest of the kernel
+    mask_t pm[NITER];  // the document's presence mask (0: dropped posting)
+#pragma unroll
+    for (int n = 0; n < NITER; ++n) pm[n] = (pk[n] >> 31) ? L.dmask[PRANK(n)] : (mask_t)0;
     if (DF_ONLY) {
         // corpus_docs.len(): distinct (token, document) pairs among the kept postings (token_score.rs:262-275): a posting
         // counts when no EARLIER list of its token holds the document (the lists of a token are consecutive references)
 #pragma unroll
         for (int n = 0; n < NITER; ++n) {
             if (!(pk[n] >> 31)) continue;
-            const mask_t m = L.dmask[PRANK(n)];
             const uint32_t run = (pk[n] >> 17) & 63u, first = run - (L.seg_key[run] & 1023u);
             const mask_t earlier = (((mask_t)1 << run) - 1) & ~(((mask_t)1 << first) - 1);
-            if ((m & earlier) == 0) atomicAdd(&L.df_lds[(pk[n] >> 25) & 63u], 1u);
+            if ((pm[n] & earlier) == 0) atomicAdd(&L.df_lds[(pk[n] >> 25) & 63u], 1u);
         }
         __syncthreads();
         if (threadIdx.x < q.n_tokens && L.df_lds[threadIdx.x]) atomicAdd(&b.results[qi].df[threadIdx.x], L.df_lds[threadIdx.x]);
         return;
-    }
-#pragma unroll
-    for (int n = 0; n < NITER; ++n) {
-        const mask_t m = (pk[n] >> 31) ? L.dmask[PRANK(n)] : (mask_t)1;  // (a dropped posting: "singleton", never scored)
-        const uint32_t below = mask_popc((mask_t)(m & (((mask_t)1 << ((pk[n] >> 17) & 63u)) - 1)));
-        const uint32_t single = (m & (m - 1)) == 0 ? 1u : 0u;
-        pk[n] = (pk[n] & 0xfe01ffffu) | (single << 24) | (below << 17);
     }
 
     // ---- 4. cells for the documents with more than one posting: one cell per posting and a place in the dense list of such
@@ -343,8 +334,9 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
     __syncthreads();  // (the bitmap and its prefix are dead from here on: region A holds the multi-document tables)
 #pragma unroll
     for (int n = 0; n < NITER; ++n) {
-        if ((pk[n] & 0x017e0000u) == 0u && (pk[n] >> 31)) {  // not a singleton, no list of the document before this one: the lender
-            const mask_t m = L.dmask[PRANK(n)];  // (still the mask: only this lane overwrites it)
+        const mask_t m = pm[n];
+        const mask_t below = m & (((mask_t)1 << ((pk[n] >> 17) & 63u)) - 1);
+        if ((m & (m - 1)) != 0 && below == 0) {
             const uint32_t cells = mask_popc(m);
             const uint32_t got = atomicAdd(&L.cell_cursor, cells | (1u << 16));
             const uint32_t cb = got & 0xffffu, mi = got >> 16;
@@ -357,14 +349,12 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
         }
     }
     __syncthreads();
-    const uint32_t cursor_now = uniform_u32(L.cell_cursor);
-    const uint32_t n_cells = cursor_now & 0xffffu, n_multi = cursor_now >> 16;
+    const uint32_t n_cells = L.cell_cursor & 0xffffu, n_multi = L.cell_cursor >> 16;
     if (n_cells > kCells || n_multi > kMultiMax) {
         // more multi-posting documents than the tables hold (terms that occur together in most of their documents): like a
         // range of too many postings, the query is rerun with narrower ranges; its slots must be empty meanwhile
-        const uint32_t span = b.pass == 0u ? cap : (b.pass == 1u ? kRangeCap : kCandPerRange);
-        for (uint32_t e = threadIdx.x; e < span; e += kThreads) {
-            rg.out[e] = 0ull;
+        for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
+            b.keys[q.key_off + rg.slot_base + e] = 0ull;
             if (b.map_idx) b.map_idx[rg.slot_base + e] = 0xffffffffu;
         }
         if (threadIdx.x == 0) b.results[qi].overflow = 1;
@@ -372,8 +362,7 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
     }
 
     const float k1 = q.k + 1.0f;
-    unsigned long long* out = rg.out;
-    const bool filtering = b.pass == 2u;
+    unsigned long long* out = b.keys + q.key_off + rg.slot_base;
     uint32_t my_count = 0, my_max = 0u, my_min_inv = 0u;
     // the document of slot e is final: its key (0 = not in the map or NaN), its map entry in score-map mode
     auto report = [&](uint32_t e, uint32_t dl, float score, bool in_map) {
@@ -394,13 +383,6 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
             if (score == score)  // a NaN score stays in the map (count) and is never selected
                 out_key = ((unsigned long long)f32_to_ordered(score) << 32) | (unsigned long long)(~doc);
         }
-        if (filtering) {  // only what can still be among the query's best k leaves the workgroup (rg.tau >= 1: empties never)
-            if (out_key >= rg.tau) {
-                const uint32_t pos = atomicAdd(&L.cand_n, 1u);
-                if (pos < kCandPerRange) L.cand[pos] = out_key;
-            }
-            return;
-        }
         out[e] = out_key;
         if (b.map_idx) {
             // score-map mode (a batch of ONE query): slot = position of the entry in the map's candidate list, the
@@ -420,17 +402,18 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
     for (int n = 0; n < NITER; ++n) {
         const uint32_t e = threadIdx.x + n * kThreads;
         const uint32_t dl = pk[n] & 0xffffu;
+        const mask_t m = pm[n];
         float score = 0.0f;
         bool in_map = false, lends = false;
-        if ((pk[n] >> 24) & 1u) {
-            if (pk[n] >> 31) {  // (a dropped posting reports an empty slot)
+        if ((m & (m - 1)) == 0) {
+            if (m != 0) {  // (a dropped posting reports an empty slot)
                 DocFold f;
                 f.add((pk[n] >> 25) & 63u, pv[n], L.idf, q.k, k1);
                 in_map = f.finish(L.idf, q.k, k1, q.use_threshold, q.threshold);
                 score = f.score;
             }
         } else {
-            const uint32_t below = (pk[n] >> 17) & 63u;
+            const uint32_t below = mask_popc((mask_t)(m & (((mask_t)1 << ((pk[n] >> 17) & 63u)) - 1)));
             lends = below == 0;  // the posting of the document's first reference: it asked for the cells in phase 4
             cellv[(uint32_t)L.dmask[PRANK(n)] + below] = pv[n];
         }
@@ -454,14 +437,6 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
         }
     }
 
-    if (b.pass == 1u) {  // the sample region's slots behind this range's postings are empty
-        for (uint32_t e = cap + threadIdx.x; e < kRangeCap; e += kThreads) out[e] = 0ull;
-    } else if (filtering) {
-        __syncthreads();
-        const uint32_t n = L.cand_n;
-        if (threadIdx.x < kCandPerRange) out[threadIdx.x] = threadIdx.x < n ? L.cand[threadIdx.x] : 0ull;
-        if (threadIdx.x == 0 && n > kCandPerRange) b.results[qi].cand_overflow = 1u;
-    }
     if (my_count) atomicAdd(&L.red[1], my_count);
     if (q.track_minmax) {
         if (my_max) atomicMax(&L.red[2], my_max);
@@ -492,8 +467,7 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
         qi = lo;
     }
     const RangeQuery q = b.queries[qi];
-    const uint32_t ri = blockIdx.x - b.range_start[qi];  // index among the ranges of this pass
-    const uint32_t r = b.pass == 0u ? ri : (b.pass == 1u ? ri * q.sample_s : ri + ri / (q.sample_s - 1u) + 1u);
+    const uint32_t r = blockIdx.x - b.range_start[qi];
     if (r >= q.n_ranges) return;
     if (DF_ONLY && !q.want_df) return;
     const uint32_t ns = q.seg_end - q.seg_begin;
@@ -513,7 +487,6 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
             L.cell_cursor = 0u;
             L.seg_off[0] = 0;
         }
-        if (lane == 0) L.cand_n = 0u;
         L.df_lds[lane] = 0;
         static_assert(kMaxTokens == 64, "one lane per token");
         if (!DF_ONLY) L.idf[lane] = lane < q.n_tokens ? b.idf[(size_t)qi * kMaxTokens + lane] : 0.0f;
@@ -558,38 +531,17 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
         for (uint32_t w = threadIdx.x - 64u; w < rg.n_words; w += kThreads - 64u) L.bitmap()[w] = 0u;
     }
     __syncthreads();
-    const uint32_t cap = uniform_u32(L.seg_off[ns]);
+    const uint32_t cap = L.seg_off[ns];
+    if (cap == 0) return;
     rg.cap = cap;
-    rg.slot_base = uniform_u32(L.red[0]);  // (workgroup-uniform values read from LDS / HBM: pinned to scalar registers)
-    rg.tau = 1ull;
-    rg.out = nullptr;
-    if (!DF_ONLY) {
-        if (b.pass == 0u) {
-            rg.out = b.keys + q.key_off + rg.slot_base;
-        } else if (b.pass == 1u) {
-            rg.out = b.keys + q.key_off + (uint64_t)ri * kRangeCap;
-        } else {
-            rg.out = b.keys + q.key_off + (uint64_t)q.n_sample * kRangeCap + (uint64_t)ri * kCandPerRange;
-            const unsigned long long t = b.results[qi].filter_tau;  // written by the launch before this one
-            const unsigned long long tu = ((unsigned long long)uniform_u32((uint32_t)(t >> 32)) << 32) | uniform_u32((uint32_t)t);
-            rg.tau = tu > 1ull ? tu : 1ull;
-        }
-    }
-    if (cap == 0) {
-        // nothing to score; the regions of a filtered pass are read whole by the top-k: they must be empty
-        if (!DF_ONLY && b.pass != 0u)
-            for (uint32_t e = threadIdx.x; e < (b.pass == 1u ? kRangeCap : kCandPerRange); e += kThreads) rg.out[e] = 0ull;
-        return;
-    }
+    rg.slot_base = L.red[0];
     if (cap > kRangeCap) {
         // the query is rerun with smaller ranges; its slots still reach the batch's top-k, so they must be empty
-        if (!DF_ONLY) {
-            const uint32_t span = b.pass == 0u ? cap : (b.pass == 1u ? kRangeCap : kCandPerRange);
-            for (uint32_t e = threadIdx.x; e < span; e += kThreads) {
-                rg.out[e] = 0ull;
+        if (!DF_ONLY)
+            for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
+                b.keys[q.key_off + rg.slot_base + e] = 0ull;
                 if (b.map_idx) b.map_idx[rg.slot_base + e] = 0xffffffffu;
             }
-        }
         if (threadIdx.x == 0) b.results[qi].overflow = 1;
         return;
     }
@@ -715,8 +667,7 @@ int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStr
 #endif
     ProfScope prof(&ctx->prof, df_only ? "bm25_range_df" : "bm25_range_score", stream);
     const uint32_t grid = b.range_start[b.n_queries];
-    ORAMA_REQUIRE(b.pass != 0u || grid >= b.max_ranges, "internal: range_start table not filled");
-    if (grid == 0) return ORAMA_OK;
+    ORAMA_REQUIRE(grid >= b.max_ranges, "internal: range_start table not filled");
     // 64-bit presence masks when a query of the batch has more than 32 references
     const bool wide = b.max_refs > 32;
     if (df_only) {

@@ -11,7 +11,6 @@ constexpr uint32_t kRangeCap = 2048;     // postings one workgroup scores in LDS
 constexpr uint32_t kRangeMaxWidth = 32768;  // documents per range (one bit each in the workgroup's LDS bitmap)
 constexpr uint32_t kRangeMaxRefs = 64;   // non-empty posting lists per query: one bit each in the scoring launch's presence masks
 constexpr uint32_t kRangeBatchMax = 32;  // queries scored by one set of launches
-constexpr uint32_t kCandPerRange = 32;   // filtered top-k: key slots a non-sample range owns (expected use: ~k / sample ranges)
 
 // One (token, posting list) reference of one query of the batch.
 struct RangeSeg {
@@ -33,8 +32,7 @@ struct RangeQuery {
     float k;
     uint32_t want_df;     // count df on the device: 1 = a token has several lists (distinct pairs), 2 = only a filter
     uint32_t track_minmax; // hybrid: reduce the largest / smallest non-NaN score into the result words
-    // filtered top-k (RangeBatch::pass 1 / 2): every sample_s-th range is a SAMPLE range; n_sample of them
-    uint32_t sample_s, n_sample;
+    uint64_t pad2;
 };
 
 // Per-query result words (device): 128 bytes apart so that the per-workgroup atomics of different queries and of
@@ -50,11 +48,8 @@ struct RangeResult {
     uint32_t min_inv;     // hybrid: ~ordered(smallest non-NaN score), 0 = none
     uint32_t pad3[31];
     unsigned long long topk_tau;  // running bound of the key list's top-k reduction (launch_keys_topk, zero at launch)
-    unsigned long long filter_tau;  // filtered top-k: the k-th best key of the sample ranges (0: fewer than k keys there)
-    uint32_t cand_overflow;       // filtered top-k: a range had more keys at or above filter_tau than its candidate slots: rerun unfiltered
-    uint32_t pad4[27];
+    uint32_t pad4[30];
 };
-static_assert(sizeof(RangeResult) == 896, "result words: whole cache lines per quantity");
 
 struct RangeBatch {
     const RangeSeg* segs = nullptr;      // grouped by query, in (token, reference) order
@@ -63,12 +58,6 @@ struct RangeBatch {
     uint64_t total_postings = 0;         // referenced by the whole batch
     uint32_t max_ranges = 0;             // most ranges of a query of the batch
     uint32_t max_refs = 0;               // most references (non-empty lists) of a query of the batch: > 32 takes 64-bit presence masks
-    // Filtered top-k of big batches.  pass 0: every range scores, one key per posting slot (slot lists of `stride` keys).
-    // pass 1: only the sample ranges r = i * sample_s score; keys go to the query's SAMPLE region [i][kRangeCap] of its
-    // candidate buffer.  pass 2: the other ranges score; a key reaches the range's kCandPerRange slots of the MAIN region
-    // (behind the sample region) only if it is >= results[q].filter_tau, the k-th best key of the sample — a lower bound of
-    // the query's k-th best key, so nothing that could be an answer is dropped.  range_start counts the ranges of the pass.
-    uint32_t pass = 0;
     // the scoring launch is a 1-D grid over the (query, range) pairs that exist: workgroup w scores range
     // w - range_start[q] of the query q with range_start[q] <= w < range_start[q + 1]
     uint32_t range_start[kRangeBatchMax + 1] = {0};

@@ -611,7 +611,6 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         uint32_t job;
         uint32_t shrink;
         uint64_t total;
-        bool no_filter = false;  // its candidate slots overflowed under the filtered top-k: score it the plain way
     };
     // hybrid (a batch of one): the vector map as local document indices; a hit that is not a document of this index is the
     // per-record scorer's business (it reports the error)
@@ -687,7 +686,6 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         std::vector<RangeQuery> queries;
         std::vector<uint32_t> lens;
         uint32_t nq = 0, kmax = 0, kk = 1;
-        bool filtered = false;
         uint64_t max_total = 0;
         size_t res_bytes = 0;
         RangeBatch rb;
@@ -738,6 +736,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             const Pending& pd = c.members[ci];
             const RangeJob& jb = jobs[pd.job];
             RangeQuery& q = queries[ci];
+            q.key_off = (uint64_t)ci * max_total;
             q.bounds_base = bounds_entries;
             q.seg_begin = (uint32_t)segs.size();
             q.width = choose_width(p->n_docs, pd.total, pd.shrink);
@@ -790,71 +789,27 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                     t < q.n_tokens ? log1pf((jb.params->total_documents - d + 0.5f) / (d + 0.5f)) : 0.0f;
             }
         }
-        // ---- filtered top-k (round 4).  The key list of a query has one slot per posting and the top-k reads every one of
-        // them (8 B written + 8 B read per posting: as much traffic as the scoring itself).  For a set of launches of several
-        // big queries: every S-th range is scored FIRST (pass 1; keys into a sample region), the k-th best key of that sample
-        // is a lower bound of the query's k-th best key (launch_keys_kth), and the launch over the other ranges (pass 2)
-        // lets only keys at or above it out — into kCandPerRange slots per range.  The top-k then reads the sample region
-        // + 32 slots per range instead of ~1 536 per range.  Exact: a key below the bound cannot be among the best k.  A range
-        // with more survivors than slots (scores clustered in id space, a loose sample) flags the query; it is scored again the
-        // plain way.
-        static const bool filter_on = [] { const char* e = std::getenv("ORAMA_K3R_FILTER"); return !e || std::atoi(e) != 0; }();
-        bool filtered = filter_on && !df_pass && !hybrid_job && !(n_jobs == 1 && jobs[0].map) && nq >= 4 && c.kmax >= 1 && c.kmax <= 1024 &&
-                        !(apply_omc && p->has_omc && false);
-        for (uint32_t ci = 0; ci < nq && filtered; ++ci) {
-            const uint32_t nr = queries[ci].n_ranges;
-            const uint32_t S = std::max(2u, nr / 24u), ns_ = (nr + S - 1) / S;
-            // the sample must hold several times k documents (~1 000+ per range), and the rest must be worth filtering
-            if (c.members[ci].no_filter || nr < 64 || (uint64_t)ns_ * 1000 < 4ull * c.kmax) filtered = false;
-        }
-        c.filtered = filtered;
-        uint64_t key_stride = max_total;  // slots per query in the key buffer
-        if (filtered) {
-            key_stride = 0;
-            for (uint32_t ci = 0; ci < nq; ++ci) {
-                RangeQuery& q = queries[ci];
-                q.sample_s = std::max(2u, q.n_ranges / 24u);
-                q.n_sample = (q.n_ranges + q.sample_s - 1) / q.sample_s;
-                const uint64_t len = (uint64_t)q.n_sample * kRangeCap + (uint64_t)(q.n_ranges - q.n_sample) * kCandPerRange;
-                c.lens[ci] = (uint32_t)len;
-                key_stride = std::max(key_stride, len);
-            }
-            key_stride = (key_stride + 1) & ~1ull;
-        }
-        for (uint32_t ci = 0; ci < nq; ++ci) queries[ci].key_off = (uint64_t)ci * key_stride;
         ORAMA_SUPPORT(virt < 0xffffffffull && bounds_entries < 0xffffffffull, "query batch references too many postings");
         // device tables: [segs | queries | idf | list lengths]
         const size_t seg_bytes = (segs.size() * sizeof(RangeSeg) + 63) & ~(size_t)63;
         const size_t q_bytes = ((size_t)nq * sizeof(RangeQuery) + 63) & ~(size_t)63;
         const size_t idf_bytes = (size_t)nq * kMaxTokens * 4;
         const size_t len_bytes = ((size_t)nq * 4 + 63) & ~(size_t)63;
-        // (filtered top-k: per query the offset and length of its sample region and the k its bound is taken at)
-        const size_t kth_off = seg_bytes + q_bytes + idf_bytes + len_bytes, kth_bytes = (size_t)kRangeBatchMax * 16;
-        ORAMA_TRY(sc->h_in.reserve(kth_off + kth_bytes));
+        ORAMA_TRY(sc->h_in.reserve(seg_bytes + q_bytes + idf_bytes + len_bytes));
         char* h = sc->h_in.as<char>();
         memcpy(h, segs.data(), segs.size() * sizeof(RangeSeg));
         memcpy(h + seg_bytes, queries.data(), (size_t)nq * sizeof(RangeQuery));
         memcpy(h + seg_bytes + q_bytes, h_idf, idf_bytes);
         memcpy(h + seg_bytes + q_bytes + idf_bytes, c.lens.data(), (size_t)nq * 4);
-        {
-            uint64_t* ko = reinterpret_cast<uint64_t*>(h + kth_off);
-            uint32_t* kl = reinterpret_cast<uint32_t*>(h + kth_off + (size_t)kRangeBatchMax * 8);
-            uint32_t* kk_ = kl + kRangeBatchMax;
-            for (uint32_t ci = 0; ci < nq; ++ci) {
-                ko[ci] = queries[ci].key_off;
-                kl[ci] = filtered ? queries[ci].n_sample * kRangeCap : 0u;
-                kk_[ci] = c.kmax;
-            }
-        }
-        ORAMA_TRY(sc->misc0.reserve(kth_off + kth_bytes));
-        ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, h, kth_off + kth_bytes, hipMemcpyHostToDevice, s));
+        ORAMA_TRY(sc->misc0.reserve(seg_bytes + q_bytes + idf_bytes + len_bytes));
+        ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, h, seg_bytes + q_bytes + idf_bytes + len_bytes, hipMemcpyHostToDevice, s));
         ORAMA_TRY(sc->misc1.reserve((size_t)bounds_entries * 4));
         // device results in ONE block: [RangeResult x nq | ids | scores | n]  -> one read-back per chunk
         const uint32_t kk = c.kk = std::max(c.kmax, 1u);
         const size_t res_bytes = c.res_bytes = (size_t)nq * sizeof(RangeResult);
         const size_t out_bytes = res_bytes + (size_t)nq * kk * 12 + (size_t)nq * 4;
         ORAMA_TRY(sc->misc2.reserve(out_bytes));
-        if (!df_pass) ORAMA_TRY(sc->misc3.reserve((size_t)nq * key_stride * 8));
+        if (!df_pass) ORAMA_TRY(sc->misc3.reserve((size_t)nq * max_total * 8));
         char* d = sc->misc0.as<char>();
         float* d_idf = reinterpret_cast<float*>(d + seg_bytes + q_bytes);
         RangeBatch& rb = c.rb;
@@ -932,31 +887,12 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             }
             ORAMA_HIP_TRY(hipMemcpyAsync(d_idf, h_idf, idf_bytes, hipMemcpyHostToDevice, s));
         }
-        if (filtered) {
-            RangeBatch pass = rb;
-            // pass 1: the sample ranges
-            pass.pass = 1;
-            uint32_t at = 0;
-            for (uint32_t ci = 0; ci < nq; ++ci) pass.range_start[ci + 1] = (at += queries[ci].n_sample);
-            ORAMA_TRY(launch_range_score(p->ctx, pass, false, s));
-            ORAMA_TRY(launch_keys_kth(p->ctx, rb.keys, reinterpret_cast<const uint64_t*>(d + kth_off),
-                                      reinterpret_cast<const uint32_t*>(d + kth_off + (size_t)kRangeBatchMax * 8),
-                                      reinterpret_cast<const uint32_t*>(d + kth_off + (size_t)kRangeBatchMax * 12), nq,
-                                      &rb.results[0].filter_tau, (uint32_t)(sizeof(RangeResult) / 8), s));
-            // pass 2: everything else, filtered by the sample's k-th best key
-            pass.pass = 2;
-            at = 0;
-            for (uint32_t ci = 0; ci < nq; ++ci) pass.range_start[ci + 1] = (at += queries[ci].n_ranges - queries[ci].n_sample);
-            ORAMA_TRY(launch_range_score(p->ctx, pass, false, s));
-        } else {
-            ORAMA_TRY(launch_range_score(p->ctx, rb, false, s));
-        }
+        ORAMA_TRY(launch_range_score(p->ctx, rb, false, s));
         char* d_out = sc->misc2.as<char>();
         uint64_t* d_ids = reinterpret_cast<uint64_t*>(d_out + res_bytes);
         float* d_val = reinterpret_cast<float*>(d_out + res_bytes + (size_t)nq * kk * 8);
         uint32_t* d_n = reinterpret_cast<uint32_t*>(d_out + res_bytes + (size_t)nq * kk * 12);
         if (c.kmax) {
-            const uint64_t max_total = key_stride;  // (the key lists of a filtered set are its candidate buffers)
             ORAMA_TRY(sc->misc4.reserve((size_t)keys_topk_scratch_keys((uint32_t)max_total, nq, c.kmax) * 8 + 8));
             ORAMA_TRY(launch_keys_topk(p->ctx, rb.keys, (uint32_t)max_total, max_total, nq, c.kmax, true, p->d_docs.as<uint64_t>(),
                                        sc->misc4.as<unsigned long long>(), nullptr, d_ids, d_val, d_n, s,
@@ -1009,11 +945,6 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             }
             if (df_pass) {
                 memcpy(jb.df_out, h_res[ci].df, sizeof(uint32_t) * kMaxTokens);
-                continue;
-            }
-            if (c.filtered && h_res[ci].cand_overflow) {  // more survivors than candidate slots somewhere: the plain way
-                pd.no_filter = true;
-                pending.push_back(pd);
                 continue;
             }
             if (jb.hybrid) {

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kSortThreads) void select_small_kernel(
     const uint32_t count = min(valid_s, k);
     if (id_map && valid_s > k) {
         // more candidates than answers and ids of their own: the k-th boundary is cut by (value, INDEX) — as the radix
-        // selection of the longer lists, the reduction levels of the key lists and the oracle cut it — and only the survivors
+        // selection of the longer lists, the reduction levels of the key lists and the CPU restatement of the path cut it — and only the survivors
         // are ordered by (value, id, index).  (One sort by (value, id, index) let the lowest ids win the cut: with ids that do
         // not grow with the index, which tied entries came back depended on the list's length — ADVICE r03.)
         lds_bitonic_sort<false>(s, p2);
@@ -725,79 +725,6 @@ __global__ __launch_bounds__(kSortThreads) void pairs_reduce_kernel(const float*
 }
 
 // Final ordering of <= 4096 keys: (value, 64-bit id asc, idx asc), empties (0) dropped.
-// The k-th best key of a list (0 when the list holds fewer than k keys): one workgroup per list walks it in rounds of up to
-// 8 192 keys, carrying its best k along (pairs_reduce_kernel's scheme on ready-made keys), and reduces the minimum of what is
-// left.  Used by the filtered top-k of the BM25 range scorer: the k-th best key of a SAMPLE of a query's ranges bounds the
-// query's k-th best key from below.
-__global__ __launch_bounds__(kSortThreads) void keys_kth_kernel(const unsigned long long* __restrict__ keys,
-                                                                const uint64_t* __restrict__ list_off,
-                                                                const uint32_t* __restrict__ list_len,
-                                                                const uint32_t* __restrict__ list_k,
-                                                                unsigned long long* __restrict__ out, uint32_t out_stride) {
-    __shared__ unsigned long long s[kKeysChunk];
-    __shared__ uint32_t hist[256];
-    __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
-    __shared__ uint32_t red_nz[kSortThreads / 64];
-    __shared__ uint32_t sel[3], cursor;
-    const uint32_t qi = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long* in = keys + list_off[qi];
-    const uint32_t end = list_len[qi];
-    const uint32_t k = min(list_k[qi], kSelectMaxK);
-    uint32_t pos = 0, kept = 0;
-    constexpr uint32_t kPerThread = kKeysChunk / kSortThreads;
-    if (k == 0 || end == 0) {
-        if (threadIdx.x == 0) out[(uint64_t)qi * out_stride] = 0ull;
-        return;
-    }
-    for (;;) {
-        const uint32_t take = min(kKeysChunk - kept, end - pos);
-        for (uint32_t i = threadIdx.x; i < take; i += blockDim.x) s[kept + i] = in[pos + i];
-        const uint32_t cnt = kept + take;
-        pos += take;
-        if (threadIdx.x == 0) cursor = 0;
-        __syncthreads();
-        const unsigned long long thr = lds_keys_threshold(s, cnt, k, hist, red_max, red_min, red_nz, sel);
-        unsigned long long mine[kPerThread];
-#pragma unroll
-        for (uint32_t t = 0; t < kPerThread; ++t) {
-            const uint32_t i = t * blockDim.x + threadIdx.x;
-            mine[t] = i < cnt ? s[i] : 0ull;
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t t = 0; t < kPerThread; ++t) {
-            const bool tk = mine[t] >= thr;  // thr >= 1: empties never
-            const unsigned long long m = __ballot(tk);
-            uint32_t base = 0;
-            if (lane == 0 && m) base = atomicAdd(&cursor, (uint32_t)__popcll(m));
-            base = __shfl(base, 0, 64);
-            if (tk) {
-                const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (p < k) s[p] = mine[t];
-            }
-        }
-        __syncthreads();
-        kept = min(cursor, k);
-        __syncthreads();  // cursor is reset by the next round
-        if (pos >= end) break;
-    }
-    // fewer than k keys in the whole list: no bound; else the smallest of the k kept ones
-    unsigned long long mn = ~0ull;
-    for (uint32_t i = threadIdx.x; i < kept; i += blockDim.x) mn = s[i] < mn ? s[i] : mn;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(mn, off, 64);
-        mn = o < mn ? o : mn;
-    }
-    if (lane == 0) red_min[wave] = mn;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (uint32_t w = 0; w < kSortThreads / 64; ++w) mn = red_min[w] < mn ? red_min[w] : mn;
-        out[(uint64_t)qi * out_stride] = kept >= k ? mn : 0ull;
-    }
-}
-
 __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned long long* __restrict__ keys,
                                                                   uint32_t n_keys, uint64_t in_stride,
                                                                   const uint32_t* __restrict__ n_per_list, uint32_t k,
@@ -951,15 +878,6 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
 static bool select_pairs_enabled() {
     static const bool on = [] { const char* e = std::getenv("ORAMA_SELECT_PAIRS"); return !e || std::atoi(e) != 0; }();
     return on;
-}
-
-int launch_keys_kth(orama_ctx* ctx, const unsigned long long* d_keys, const uint64_t* d_list_off, const uint32_t* d_list_len,
-                    const uint32_t* d_list_k, uint32_t q, unsigned long long* d_out, uint32_t out_stride, hipStream_t stream) {
-    if (q == 0) return ORAMA_OK;
-    ProfScope prof(&ctx->prof, "topk_select", stream);
-    hipLaunchKernelGGL(keys_kth_kernel, dim3(q), dim3(kSortThreads), 0, stream, d_keys, d_list_off, d_list_len, d_list_k, d_out, out_stride);
-    ORAMA_HIP_TRY(hipGetLastError());
-    return ORAMA_OK;
 }
 
 int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {

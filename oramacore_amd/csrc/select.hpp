@@ -68,10 +68,6 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
                      unsigned long long* d_tmp, uint32_t* out_idx, uint64_t* out_ids, float* out_val,
                      uint32_t* out_n, hipStream_t stream, const uint32_t* d_n_per_list = nullptr,
                      unsigned long long* d_tau = nullptr, uint32_t tau_stride = 0);
-// d_out[i * out_stride] = the d_list_k[i]-th best key of list i = d_keys[d_list_off[i] .. + d_list_len[i]) (0 = empty slot), or 0
-// when the list holds fewer keys than that.  One workgroup per list.
-int launch_keys_kth(orama_ctx* ctx, const unsigned long long* d_keys, const uint64_t* d_list_off, const uint32_t* d_list_len,
-                    const uint32_t* d_list_k, uint32_t q, unsigned long long* d_out, uint32_t out_stride, hipStream_t stream);
 // Keys of scratch launch_keys_topk needs for lists of n_keys entries.
 uint64_t keys_topk_scratch_keys(uint32_t n_keys, uint32_t q, uint32_t k);
 
