@@ -164,6 +164,7 @@ struct ScoreLds {
     unsigned long long seg_pos[kRangeMaxRefs];  // first posting of each reference inside this range
     uint32_t seg_off[kRangeMaxRefs + 1];        // start of each reference's run among the gathered postings
     uint32_t seg_key[kRangeMaxRefs];            // token << 10 | rank
+    uint32_t seg_pkb[kRangeMaxRefs];            // the constant part of a kept posting's packed word: kept | token << 25 | reference << 17
     float seg_boost[kRangeMaxRefs], seg_avg[kRangeMaxRefs];
     uint16_t blk_run[kBlocks];                  // run that holds gathered posting 32 i
     float idf[kMaxTokens];
@@ -243,11 +244,10 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
                 kept = kept && id < b.allow_bits && ((b.allow[id >> 6] >> (id & 63)) & 1ull);
             }
             const uint32_t dl = doc[j] - doc0;
-            const uint32_t key = L.seg_key[run[j]];
-            pk[n] = kept ? (0x80000000u | ((key >> 10) << 25) | (run[j] << 17) | dl) : 0u;
+            pk[n] = kept ? (L.seg_pkb[run[j]] | dl) : 0u;
             pv[n] = 0.0f;
             if (rg.count_each) {
-                if (kept) atomicAdd(&L.df_lds[key >> 10], 1u);
+                if (kept) atomicAdd(&L.df_lds[(pk[n] >> 25) & 63u], 1u);
             } else {
                 if (kept) atomicOr(&bitmap[dl >> 5], 1u << (dl & 31u));
                 if (!DF_ONLY) {
@@ -502,6 +502,7 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
                 const RangeSeg sg = segs[i];
                 L.seg_pos[i] = sg.post_begin + b0;
                 L.seg_key[i] = sg.tok_rank;
+                L.seg_pkb[i] = 0x80000000u | ((sg.tok_rank >> 10) << 25) | (i << 17);
                 L.seg_boost[i] = sg.boost;
                 L.seg_avg[i] = sg.avg_len;
                 base_part += b0;
@@ -545,8 +546,9 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
         if (threadIdx.x == 0) b.results[qi].overflow = 1;
         return;
     }
-    // rounds of the per-posting phases (workgroup-uniform): the bodies that exist are 2, 4, 5, 6 and 8 rounds — a range of
-    // the targeted ~1 280 postings takes 5 or 6
+    // rounds of the per-posting phases (workgroup-uniform): the bodies that exist are 2, 4, 5, 6, 7 and 8 rounds — a range of
+    // the targeted ~1 536 postings takes 6 or 7 (a round count without a body of its own runs the next one: whole rounds of
+    // clamped, unkept postings)
     const uint32_t n_iter = (cap + kThreads - 1) / kThreads;
     if (DF_ONLY) {
         if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4>(b, q, rg, L);
@@ -555,6 +557,7 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     else if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4>(b, q, rg, L);
     else if (n_iter == 5) score_body<DF_ONLY, WIDE, 5>(b, q, rg, L);
     else if (n_iter == 6) score_body<DF_ONLY, WIDE, 6>(b, q, rg, L);
+    else if (n_iter == 7) score_body<DF_ONLY, WIDE, 7>(b, q, rg, L);
     else score_body<DF_ONLY, WIDE, 8>(b, q, rg, L);
 }
 
