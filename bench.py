@@ -745,6 +745,10 @@ def main():
         device = local_rank
         group = ShardGroup([local_rank], flags=FORCE_RCCL if args.force_exchange else 0)
     ctx = group.ctx(0)
+    # RCCL writes its version banner through C stdio (fully buffered when stdout is a pipe) when the communicator is made:
+    # every rank pushes it out NOW, so that nothing of it can land behind rank 0's JSON line when the ranks exit
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
     # who is in the job, as the communicator itself reports it: one all-reduce(max) per rank slot carries that rank's device
     # ordinal and pid to everybody (a rank that is missing, or two ranks that believe they are the same one, show up here
     # — and in `n_gpus` — instead of as a plausible-looking number)
