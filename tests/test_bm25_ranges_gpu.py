@@ -137,6 +137,12 @@ def test_many_tokens_wrap_the_threshold_mask(ctx):
     refs = [(t, t, 1.0) for t in range(64)]
     for thr in (None, 5, 20, 33):
         check(ctx, corpus, refs, 64, 200, thr, tag=("64 tokens", thr))
+    # 33 .. 64 lists take the range scorer's 64-bit presence masks (one bit per list); more than 64 lists fall to the
+    # per-record scorer — same answers either way
+    refs = [(t, (3 * t + j) % 64, 1.0 + 0.5 * j) for t in range(20) for j in range(2)]   # 40 lists, two per token
+    check(ctx, corpus, refs, 20, 150, 3, tag="40 lists over 20 tokens")
+    refs = [(t, (5 * t + j) % 64, 1.0) for t in range(24) for j in range(3)]             # 72 lists: beyond the masks
+    check(ctx, corpus, refs, 24, 150, None, tag="72 lists over 24 tokens")
     corpus.store.close()
 
 
