@@ -601,6 +601,33 @@ int hybrid_from_candidates(const RangeJob& jb, const RangeResult& res, const uin
     return ORAMA_OK;
 }
 
+// ORAMA_POST_CALL_TRACE=1: where the HOST spends a range-scorer call (mean microseconds per phase over every 2 000 chunks,
+// on stderr) — table building, each enqueue, the wait, the hand-out.  Single-threaded use only (plain statics).
+struct CallTrace {
+    static constexpr int kMarks = 8;
+    static bool on() {
+        static const bool v = std::getenv("ORAMA_POST_CALL_TRACE") != nullptr;
+        return v;
+    }
+    std::chrono::steady_clock::time_point t[kMarks];
+    void mark(int i) {
+        if (on()) t[i] = std::chrono::steady_clock::now();
+    }
+    void done() {
+        if (!on()) return;
+        static double sum[kMarks] = {0};
+        static uint32_t n = 0;
+        for (int i = 1; i < kMarks; ++i) sum[i] += std::chrono::duration<double, std::micro>(t[i] - t[i - 1]).count();
+        if (++n == 2000) {
+            fprintf(stderr, "post call trace (us, mean of %u): tables %.1f | upload enqueue %.1f | bounds launch %.1f | score launch %.1f | "
+                    "top-k launches %.1f | read-back enqueue %.1f | wait %.1f\n", n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n,
+                    sum[5] / n, sum[6] / n, sum[7] / n);
+            for (double& x : sum) x = 0;
+            n = 0;
+        }
+    }
+};
+
 // Score `n_jobs` eligible queries (each validated by check_params and ranges_eligible) on sc->stream; synchronises.
 // With a second set (`sc2`) the sets of launches are double-buffered: while the device scores one chunk of 32 queries, the
 // host builds and uploads the tables of the next one on the other set's stream (the host side of a chunk — reference
@@ -685,6 +712,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         std::vector<RangeSeg> segs;
         std::vector<RangeQuery> queries;
         std::vector<uint32_t> lens;
+        CallTrace trace;
         uint32_t nq = 0, kmax = 0, kk = 1;
         uint64_t max_total = 0;
         size_t res_bytes = 0;
@@ -700,6 +728,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
     auto enqueue = [&](Chunk& c) -> int {
         Scratch* sc = c.sc;
         hipStream_t s = sc->stream;
+        c.trace.mark(0);
         if (!c.allow_resolved) {
             ORAMA_TRY(resolve_allow(p->ctx, sc, allow_bitmap, bitmap_bits, s, &c.d_allow));
             c.allow_resolved = true;
@@ -802,7 +831,9 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         memcpy(h + seg_bytes + q_bytes, h_idf, idf_bytes);
         memcpy(h + seg_bytes + q_bytes + idf_bytes, c.lens.data(), (size_t)nq * 4);
         ORAMA_TRY(sc->misc0.reserve(seg_bytes + q_bytes + idf_bytes + len_bytes));
+        c.trace.mark(1);
         ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, h, seg_bytes + q_bytes + idf_bytes + len_bytes, hipMemcpyHostToDevice, s));
+        c.trace.mark(2);
         ORAMA_TRY(sc->misc1.reserve((size_t)bounds_entries * 4));
         // device results in ONE block: [RangeResult x nq | ids | scores | n]  -> one read-back per chunk
         const uint32_t kk = c.kk = std::max(c.kmax, 1u);
@@ -865,6 +896,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         }
         if (const char* e = std::getenv("ORAMA_K3R_DBG")) rb.debug = (uint32_t)std::atoi(e);
         ORAMA_TRY(launch_range_bounds(p->ctx, rb, s));
+        c.trace.mark(3);
         ORAMA_TRY(sc->h_out.reserve(out_bytes + 64));
         RangeResult* h_res = c.h_res = sc->h_out.as<RangeResult>();
         if (df_pass) {  // count, read the result words back, nothing else (complete() hands the df out)
@@ -888,6 +920,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             ORAMA_HIP_TRY(hipMemcpyAsync(d_idf, h_idf, idf_bytes, hipMemcpyHostToDevice, s));
         }
         ORAMA_TRY(launch_range_score(p->ctx, rb, false, s));
+        c.trace.mark(4);
         char* d_out = sc->misc2.as<char>();
         uint64_t* d_ids = reinterpret_cast<uint64_t*>(d_out + res_bytes);
         float* d_val = reinterpret_cast<float*>(d_out + res_bytes + (size_t)nq * kk * 8);
@@ -899,7 +932,9 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                                        reinterpret_cast<const uint32_t*>(d + seg_bytes + q_bytes + idf_bytes), &rb.results[0].topk_tau,
                                        (uint32_t)(sizeof(RangeResult) / 8)));
         }
+        c.trace.mark(5);
         ORAMA_HIP_TRY(hipMemcpyAsync(h_res, d_out, c.kmax ? out_bytes : res_bytes, hipMemcpyDeviceToHost, s));
+        c.trace.mark(6);
         return ORAMA_OK;
     };
 
@@ -934,6 +969,10 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             ORAMA_TRY(launch_range_score_docs(p->ctx, c.rb, 0, reinterpret_cast<const uint32_t*>(hv), nv, h_vft, h_vpresent, s));
         }
         ORAMA_HIP_TRY(hipStreamSynchronize(s));
+        if (!df_pass && !hybrid_job) {
+            c.trace.mark(7);
+            c.trace.done();
+        }
         for (uint32_t ci = 0; ci < nq; ++ci) {
             Pending pd = c.members[ci];
             const RangeJob& jb = jobs[pd.job];

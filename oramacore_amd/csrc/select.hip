@@ -28,6 +28,11 @@ __constant__ const uint32_t kBits[6] = {11, 11, 10, 11, 11, 10};
 constexpr int kHistThreads = 256;
 constexpr int kSortThreads = 1024;
 
+// phase stamps of the key-list kernels: defined by scripts/micro/keys_reduce_probe.hip (which includes this file), nothing here
+#ifndef ORAMA_KEYS_STAMP
+#define ORAMA_KEYS_STAMP(i) ((void)0)
+#endif
+
 __device__ __forceinline__ unsigned long long make_key(float v, uint32_t idx, bool descending) {
     uint32_t o = f32_to_ordered(v);
     uint32_t hi = descending ? o : ~o;
@@ -385,6 +390,159 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(
                  out_n ? out_n + qi : nullptr);
 }
 
+// ---------------------------------------------------------------- exact cuts without histogram rounds
+// The radix selection below costs up to seven barrier-separated rounds of LDS atomics that pile onto a few bins (the
+// scores of one query share their leading bits): 12-15 us for the 8 192 keys of a chunk that starts without a bound — all
+// chunks of a lone query (profiles/r04_k3r_single_query_timeline.log) and the first wave of workgroups of a batch.  With
+// 16 waves on a CU every VALU instruction of a workgroup costs 16 issue cycles, so the replacements count instructions:
+//   wave_kth_largest_hi   a LOWER BOUND of the workgroup's k-th best key from registers alone: every lane gives the best of
+//                         its keys, every wave the j-th best of its 64 lane bests (j = ceil(k / waves)) by a 32-step binary
+//                         search on the value word — one compare per step, the counting is scalar (ballot + s_bcnt1) —
+//                         and the smallest of the waves' answers has waves * j >= k keys at or above it.  About 2k of
+//                         8 192 keys survive it.  (First form: every lane counted the lane bests above its own, 64 x
+//                         (2 v_readlane + v_cmp_u64 + add): 2.45 us of a 6.4 us workgroup, scripts/micro/keys_reduce_probe.)
+//   compact_to_lds        one LDS atomic per WAVE for all eight keys of its lanes (eight dependent atomics before: 1.6 us).
+//   rank_by_counting      the exact rank of each of a few hundred keys: T lanes per key count the keys above it (broadcast
+//                         LDS reads, no atomics, no barrier).  Keys are unique, so ranks are a permutation: rank r < k IS
+//                         the output position, in key order — the final kernel's records need no sort.  Work grows with
+//                         the square of the count: up to 320 keys (k = 100 leaves ~200).
+//   wave_exact_kth        the exact k-th best of 321..512 survivors (k ~ 256) by ONE wave: binary search on the value word,
+//                         then on the index word among the keys that tie with it — the other waves wait at the barrier.
+constexpr uint32_t kWaveBoundMaxK = 256;   // j <= 16 of 64 lane bests per wave
+constexpr uint32_t kRankCountMax = 512;
+constexpr uint32_t kRankCountSmall = 320;  // up to here counting ranks beats one wave's search (1.8 against 3.0 us at 200 keys)
+
+// the j-th largest of the wave's 64 values (0 when fewer than j of them are non-zero)
+__device__ __forceinline__ uint32_t wave_kth_largest_hi(uint32_t v, uint32_t j) {
+    uint32_t p = 0;
+#pragma unroll
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t t = p | (1u << b);
+        p = (uint32_t)__popcll(__ballot(v >= t)) >= j ? t : p;  // (uniform: the compare is the only vector instruction)
+    }
+    return p;
+}
+
+// Workgroup-wide lower bound of the k-th best of the keys the lanes hold (`lane_best` = the best key of this lane), or 1
+// ("every non-empty key") when a wave cannot vouch for its share.  `red` holds one entry per wave; the caller's next
+// barrier-separated use of it must come after a barrier of its own.  Contains one barrier.
+__device__ __forceinline__ unsigned long long workgroup_kth_lower_bound(unsigned long long lane_best, uint32_t k,
+                                                                        unsigned long long* red) {
+    constexpr uint32_t kWaves = kSortThreads / 64;
+    const uint32_t wb = wave_kth_largest_hi((uint32_t)(lane_best >> 32), (k + kWaves - 1u) / kWaves);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wb;
+    __syncthreads();
+    unsigned long long b = ~0ull;
+#pragma unroll
+    for (uint32_t w = 0; w < kWaves; ++w) b = red[w] < b ? red[w] : b;
+    return b ? b << 32 : 1ull;  // every key whose value word reaches the bound: at least j per wave
+}
+
+// The lanes' keys at or above `floor_key` (>= 1: empties never) go to s[cursor ...]: one LDS atomic per wave.
+template <int N>
+__device__ __forceinline__ void compact_to_lds(const unsigned long long (&kr)[N], unsigned long long floor_key,
+                                               unsigned long long* s, uint32_t* cursor) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long m[N];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        m[j] = __ballot(kr[j] >= floor_key);
+        tot += (uint32_t)__popcll(m[j]);
+    }
+    uint32_t base = 0;
+    if (lane == 0 && tot) base = atomicAdd(cursor, tot);
+    base = __shfl(base, 0, 64);
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        if (kr[j] >= floor_key) s[base + (uint32_t)__popcll(m[j] & below)] = kr[j];
+        base += (uint32_t)__popcll(m[j]);
+    }
+}
+
+// Called by ONE wave (all 64 lanes): s[0 .. cnt) are unique non-empty keys, k <= cnt <= 64 * NT.  Returns the k-th largest:
+// exactly k keys are >= it.  Straight-line code, NT compares per step (a guard per register made every step a chain of
+// taken scalar branches: 5.6 us for 200 keys; registers past cnt hold 0 and never count, every threshold is >= 1).
+template <int NT>
+__device__ __forceinline__ unsigned long long wave_exact_kth_n(const unsigned long long* s, uint32_t cnt, uint32_t k) {
+    const int lane = threadIdx.x & 63;
+    uint32_t hi[NT], lo[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const uint32_t i = (uint32_t)t * 64u + (uint32_t)lane;
+        const unsigned long long key = i < cnt ? s[i] : 0ull;
+        hi[t] = (uint32_t)(key >> 32);
+        lo[t] = (uint32_t)key;
+    }
+    // the k-th largest value word: the largest p with at least k value words >= p
+    uint32_t p = 0;
+#pragma unroll
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t t = p | (1u << b);
+        uint32_t c = 0;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) c += (uint32_t)__popcll(__ballot(hi[u] >= t));
+        p = c >= k ? t : p;
+    }
+    // keys above it are in; of the keys that carry exactly it, the `need` with the largest index words are
+    uint32_t above = 0, ties = 0;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        above += (uint32_t)__popcll(__ballot(hi[u] > p));
+        const bool tie = hi[u] == p && (hi[u] | lo[u]) != 0u;
+        ties += (uint32_t)__popcll(__ballot(tie));
+        lo[u] = tie ? lo[u] : 0u;  // (the index word of a real key is never 0: ~index, and index 2^32 - 1 is the padding index)
+    }
+    const uint32_t need = k - above;  // 1 <= need <= ties
+    uint32_t q;
+    if (need == ties) {  // (uniform, the usual case) every tying key is taken: the smallest of their index words closes the key
+        q = ~0u;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) q = (lo[u] != 0u && lo[u] < q) ? lo[u] : q;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_xor(q, off, 64);
+            q = o < q ? o : q;
+        }
+    } else {
+        q = 0;
+#pragma unroll
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t t = q | (1u << b);
+            uint32_t c = 0;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) c += (uint32_t)__popcll(__ballot(lo[u] >= t));
+            q = c >= need ? t : q;
+        }
+    }
+    return ((unsigned long long)p << 32) | q;
+}
+
+__device__ __forceinline__ unsigned long long wave_exact_kth(const unsigned long long* s, uint32_t cnt, uint32_t k) {
+    static_assert(kRankCountMax == 512, "register counts below");
+    if (cnt <= 128u) return wave_exact_kth_n<2>(s, cnt, k);
+    if (cnt <= 256u) return wave_exact_kth_n<4>(s, cnt, k);
+    return wave_exact_kth_n<8>(s, cnt, k);
+}
+
+// s[0 .. cnt): unique non-empty keys, cnt <= kRankCountMax.  Returns the number of keys above the key this thread answers
+// for, s[threadIdx.x / T] (T = lanes per key: 8 up to 128 keys, 4 up to 256, 2 above); `key` receives that key, 0 when the
+// thread has none.
+__device__ __forceinline__ uint32_t rank_by_counting(const unsigned long long* s, uint32_t cnt, unsigned long long* key) {
+    const uint32_t T = cnt <= kSortThreads / 8 ? 8u : cnt <= kSortThreads / 4 ? 4u : 2u;
+    const uint32_t i = threadIdx.x / T, part = threadIdx.x & (T - 1u);
+    const unsigned long long mine = i < cnt ? s[i] : ~0ull;
+    uint32_t above = 0;
+#pragma unroll 4
+    for (uint32_t j = part; j < cnt; j += T) above += s[j] > mine ? 1u : 0u;
+    above += __shfl_xor(above, 1, 64);
+    if (T >= 4u) above += __shfl_xor(above, 2, 64);
+    if (T >= 8u) above += __shfl_xor(above, 4, 64);
+    *key = (i < cnt && part == 0u) ? mine : 0ull;
+    return above;
+}
+
 // ---------------------------------------------------------------- key lists (fused per-wave top-k of K1, K3r)
 // One workgroup per (chunk, list): the best k of up to 8192 u64 keys, as a SET (the final kernel orders the survivors).
 // MSB-first radix select in LDS instead of a sort: the bits above the first one in which the chunk's largest and
@@ -421,6 +579,7 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
     }
     const uint32_t n_in = min(kKeysChunk, n_keys - begin);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ORAMA_KEYS_STAMP(0);
     // Stream the chunk through REGISTERS: every lane issues all of its loads first (16 bytes each where the chunk is
     // 16-byte aligned: the whole 64 KB chunk is in flight at once), drops what lies below the running bound, and only the
     // survivors — about k of 8 192 once a bound exists — are compacted into LDS (one LDS atomic per wave and round).  The
@@ -447,20 +606,56 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
             kr[j] = i < n_in ? src[i] : 0ull;
         }
     }
-    if (threadIdx.x == 0) cursor = 0;
-    __syncthreads();
-    const unsigned long long floor_key = tau0 > 1ull ? tau0 : 1ull;  // below the bound: cannot be among the list's best k; 0: empty
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const bool take = kr[j] >= floor_key;
-        const unsigned long long m = __ballot(take);
-        uint32_t base = 0;
-        if (lane == 0 && m) base = atomicAdd(&cursor, (uint32_t)__popcll(m));
-        base = __shfl(base, 0, 64);
-        if (take) s[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = kr[j];
+    ORAMA_KEYS_STAMP(1);
+    if (threadIdx.x == 0) {
+        cursor = 0;
+        sel_cnt = 0;
     }
+    unsigned long long floor_key = tau0 > 1ull ? tau0 : 1ull;  // below the bound: cannot be among the list's best k; 0: empty
+    if (tau0 <= 1ull && k <= kWaveBoundMaxK) {  // (workgroup-uniform) no bound yet: one from the lanes' best keys
+        unsigned long long best = kr[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) best = kr[j] > best ? kr[j] : best;
+        floor_key = workgroup_kth_lower_bound(best, k, red_min);
+    } else {
+        __syncthreads();
+    }
+    ORAMA_KEYS_STAMP(2);
+    compact_to_lds(kr, floor_key, s, &cursor);
     __syncthreads();
     const uint32_t cnt = cursor;  // non-empty keys at or above the bound, s[0 .. cnt)
+    ORAMA_KEYS_STAMP(3);
+    if (cnt > k && cnt <= kRankCountSmall) {  // (workgroup-uniform) a couple of hundred left: their exact ranks
+        unsigned long long key;
+        const uint32_t r = rank_by_counting(s, cnt, &key);
+        if (key && r < k) {
+            o[r] = key;  // cnt > k unique keys: every position below k is written
+            if (tau && r == k - 1u) atomicMax(tau + (uint64_t)qi * tau_stride, key);
+        }
+        ORAMA_KEYS_STAMP(4);
+        return;
+    }
+    if (cnt > k && cnt <= kRankCountMax) {  // a few hundred: counting grows with the square, one wave's search does not
+        if (wave == 0) {  // the exact k-th best of them, by one wave
+            const unsigned long long t = wave_exact_kth(s, cnt, k);
+            if (lane == 0) {
+                red_max[0] = t;
+                if (tau) atomicMax(tau + (uint64_t)qi * tau_stride, t);
+            }
+        }
+        __syncthreads();
+        const unsigned long long t = red_max[0];
+        if (threadIdx.x < ((cnt + 63u) & ~63u)) {  // (whole waves) exactly k of the cnt keys reach it: every position is written
+            const unsigned long long key = threadIdx.x < cnt ? s[threadIdx.x] : 0ull;
+            const unsigned long long m = __ballot(key >= t);
+            uint32_t base = 0;
+            if (lane == 0 && m) base = atomicAdd(&sel_cnt, (uint32_t)__popcll(m));
+            base = __shfl(base, 0, 64);
+            if (key >= t) o[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+        }
+        ORAMA_KEYS_STAMP(4);
+        return;
+    }
     __syncthreads();              // (everybody has read it: the final compaction counts with it again)
     if (threadIdx.x == 0) cursor = 0;
     uint32_t nz = cnt;
@@ -561,6 +756,7 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
     __syncthreads();
     const uint32_t taken = min(cursor, k);
     for (uint32_t i = taken + threadIdx.x; i < k; i += blockDim.x) o[i] = 0ull;
+    ORAMA_KEYS_STAMP(5);
 }
 
 // ---------------------------------------------------------------- (value, index) lists in two launches
@@ -752,48 +948,100 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
         // list's length wherever DocumentIds are not monotonic in the row index — ADVICE r03).
         // (the key buffer aliases the whole record array: 8 192 keys — two reduction chunks' worth, see keys_final_capacity)
         unsigned long long* kb = reinterpret_cast<unsigned long long*>(&s);
-        for (uint32_t i = threadIdx.x; i < n_keys; i += blockDim.x) kb[i] = in[i];
-        if (threadIdx.x == 0) cursor = 0;
-        __syncthreads();
-        const unsigned long long thr = lds_keys_threshold(kb, n_keys, k, hist, red_max, red_min, red_nz, sel);
         constexpr uint32_t kPerThread = kKeysChunk / kSortThreads;
         static_assert(sizeof(SortLds) >= kKeysChunk * 8, "the key buffer must fit the record array");
+        // The candidates pass through REGISTERS first (all loads of a lane in flight at once); a lower bound of the k-th best
+        // from the lanes' best keys (workgroup_kth_lower_bound) leaves about 2k of them for LDS, whose exact ranks are counted
+        // (rank_by_counting) — round 3 parked all of them in LDS and ran the histogram rounds over them, 17-22 us for the
+        // 7 200 candidates of a lone BM25 query.  Lists the bound cannot thin (large k, mostly empty lanes) take that path still.
         unsigned long long mine[kPerThread];
+        unsigned long long best = 0ull;
+        ORAMA_KEYS_STAMP(0);
 #pragma unroll
         for (uint32_t t = 0; t < kPerThread; ++t) {
             const uint32_t i = t * blockDim.x + threadIdx.x;
-            mine[t] = i < n_keys ? kb[i] : 0ull;
+            mine[t] = i < n_keys ? in[i] : 0ull;
+            best = mine[t] > best ? mine[t] : best;
         }
-        __syncthreads();  // every key is in a register: the records may be written
+        ORAMA_KEYS_STAMP(1);
+        if (threadIdx.x == 0) cursor = 0;
+        unsigned long long floor_key = 1ull;
+        if (k <= kWaveBoundMaxK) floor_key = workgroup_kth_lower_bound(best, k, red_min);
+        else __syncthreads();
+        ORAMA_KEYS_STAMP(2);
+        compact_to_lds(mine, floor_key, kb, &cursor);
+        __syncthreads();
+        const uint32_t cnt = cursor;  // candidates at or above the bound, kb[0 .. cnt): at least min(k, non-empty keys)
+        uint32_t count;
+        bool in_key_order = false;
+        ORAMA_KEYS_STAMP(3);
+        if (cnt > k && cnt <= kRankCountMax) {  // (workgroup-uniform)
+            unsigned long long key;
+            const uint32_t r = rank_by_counting(kb, cnt, &key);
+            __syncthreads();  // every key is in a register: the records may be written
+            if (key && r < k) {
+                const uint32_t ix = ~(uint32_t)key;
+                s.hi[r] = (uint32_t)(key >> 32);
+                s.idx[r] = ix;
+                s.id[r] = id_map ? id_map[ix] : (uint64_t)ix;
+            }
+            count = k;
+            in_key_order = true;  // records sit in (value, index) order
+        } else {
+            __syncthreads();  // (everybody has read the cursor: the second compaction counts with it again)
+            if (threadIdx.x == 0) cursor = 0;
+            __syncthreads();
+            const unsigned long long thr = lds_keys_threshold(kb, cnt, k, hist, red_max, red_min, red_nz, sel);
 #pragma unroll
-        for (uint32_t t = 0; t < kPerThread; ++t) {
-            const bool tk = mine[t] >= thr;  // thr >= 1: empties never
-            const unsigned long long m = __ballot(tk);
-            uint32_t base = 0;
-            if (lane == 0 && m) base = atomicAdd(&cursor, (uint32_t)__popcll(m));
-            base = __shfl(base, 0, 64);
-            if (tk) {
-                const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (p < k) {
-                    const uint32_t ix = ~(uint32_t)mine[t];
-                    s.hi[p] = (uint32_t)(mine[t] >> 32);
-                    s.idx[p] = ix;
-                    s.id[p] = id_map ? id_map[ix] : (uint64_t)ix;
+            for (uint32_t t = 0; t < kPerThread; ++t) {
+                const uint32_t i = t * blockDim.x + threadIdx.x;
+                mine[t] = i < cnt ? kb[i] : 0ull;
+            }
+            __syncthreads();  // every key is in a register: the records may be written
+#pragma unroll
+            for (uint32_t t = 0; t < kPerThread; ++t) {
+                const bool tk = mine[t] >= thr;  // thr >= 1: empties never
+                const unsigned long long m = __ballot(tk);
+                uint32_t base = 0;
+                if (lane == 0 && m) base = atomicAdd(&cursor, (uint32_t)__popcll(m));
+                base = __shfl(base, 0, 64);
+                if (tk) {
+                    const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (p < k) {
+                        const uint32_t ix = ~(uint32_t)mine[t];
+                        s.hi[p] = (uint32_t)(mine[t] >> 32);
+                        s.idx[p] = ix;
+                        s.id[p] = id_map ? id_map[ix] : (uint64_t)ix;
+                    }
                 }
             }
+            __syncthreads();
+            count = min(cursor, k);
         }
-        __syncthreads();
-        const uint32_t count = min(cursor, k);
+        ORAMA_KEYS_STAMP(4);
         const uint32_t p2 = next_pow2(max(count, 1u));
         for (uint32_t i = count + threadIdx.x; i < p2; i += blockDim.x) {
             s.hi[i] = 0;
             s.idx[i] = 0xffffffffu;
             s.id[i] = ~0ull;
         }
-        __syncthreads();
-        lds_bitonic_sort(s, p2);
+        // Records in (value, index) order are in FINAL order unless two neighbours of equal value carry their ids the other
+        // way round (ids need not grow with the index): only then are they sorted — 28 barrier-separated passes for 128.
+        bool unordered = !in_key_order;
+        if (in_key_order) {
+            __syncthreads();
+            bool swapped = false;
+            for (uint32_t i = threadIdx.x; i + 1 < count; i += blockDim.x)
+                swapped |= s.hi[i] == s.hi[i + 1] && s.id[i] > s.id[i + 1];
+            unordered = __syncthreads_or(swapped) != 0;
+        } else {
+            __syncthreads();
+        }
+        if (unordered) lds_bitonic_sort(s, p2);
+        ORAMA_KEYS_STAMP(5);
         write_sorted(s, count, k, descending, out_idx ? out_idx + (uint64_t)qi * k : nullptr,
                      out_ids ? out_ids + (uint64_t)qi * k : nullptr, out_val + (uint64_t)qi * k, out_n ? out_n + qi : nullptr);
+        ORAMA_KEYS_STAMP(6);
         return;
     }
     const uint32_t p2 = next_pow2(max(n_keys, 1u));
