@@ -255,10 +255,39 @@ def shadow_store(oa, ctx, dim, n_local, lo, rank):
     return st
 
 
-def two_stage_leg(oa, ctx, plain, st, dim, k, qb, queries_h) -> dict:
+def two_stage_session(group, plain, st, k, qb, queries_h, steps=40, warmup=5) -> dict:
+    """The shadow store through the SAME pipelined session as `value` (queries resident in HBM, results stay there, no host
+    between the stages): the device form of the plan — the fallback for queries that are not proven is decided and run on
+    the device.  Checked against the plain store's session, step by step, on the last two steps."""
+    total = warmup + steps
+    nq = (queries_h.shape[0] // qb)
+    out = {}
+    last = {}
+    for name, store in (("shadow", st), ("plain", plain)):
+        sess = group.session([store], queries_h, qb, k, n_slots=2)
+        for i in range(warmup):
+            sess.step(i)
+        sess.sync()
+        t0 = time.perf_counter()
+        for i in range(warmup, total):
+            sess.step(i)
+        sess.sync()
+        out[name] = steps * qb / (time.perf_counter() - t0)
+        last[name] = [sess.result((total - 1 - j) % 2) for j in range(2)]
+        sess.close()
+    same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2], b[2])
+               for a, b in zip(last["shadow"], last["plain"]))
+    assert same, "two-stage session answers differ from the fp32 session's"
+    assert nq >= 1
+    return {"value": out["shadow"], "unit": "queries/s", "plain_fp32_session": out["plain"], "queries_per_step": qb,
+            "identical_to_fp32_session": same, "steps": steps}
+
+
+def two_stage_leg(oa, ctx, plain, st, dim, k, qb, queries_h, group=None) -> dict:
     """Host-buffer API, one call per query batch: plain fp32 store vs fp32 rows + fp16 shadow (`st`, closed here)."""
     nq = min(40, queries_h.shape[0] // qb)
     identical = True
+    session = two_stage_session(group, plain, st, k, qb, queries_h) if group is not None else None
     for i in range(3):
         a = plain.storage_search(queries_h[i * qb:(i + 1) * qb], k)
         b = st.storage_search(queries_h[i * qb:(i + 1) * qb], k)
@@ -284,7 +313,7 @@ def two_stage_leg(oa, ctx, plain, st, dim, k, qb, queries_h) -> dict:
     return {"value": nq * qb / el, "unit": "queries/s", "plain_fp32_same_api": nq * qb / el_plain,
             "batch64_queries_per_s": 5 * 64 / el64, "identical_to_fp32_scan": identical,
             "fallbacks": int(info["two_stage_fallbacks"]), "queries": int(info["two_stage_queries"]),
-            "hbm_bytes": int(info["hbm_bytes"]),
+            "hbm_bytes": int(info["hbm_bytes"]), "session": session,
             "note": "fp32 rows + fp16 shadow (ORAMA_DTYPE_F32_SHADOW16): the fp16 scan proposes max(2k, k+256) candidates, "
                     "K1's arithmetic on the fp32 rows decides; a query whose candidate list cannot be proven complete "
                     "falls back to the fp32 scan; results bit-identical to the plain store (DESIGN.md K1s)"}
@@ -793,7 +822,7 @@ def main():
                 configs["c4"] = hybrid_leg(oa, ctx, store, n_total, dim, k, steps=max(10, min(args.steps, 40)), warmup=3,
                                            shadow=shadow)
         if shadow is not None:
-            out["two_stage_exact"] = two_stage_leg(oa, ctx, store, shadow, dim, k, qb, queries_h)
+            out["two_stage_exact"] = two_stage_leg(oa, ctx, store, shadow, dim, k, qb, queries_h, group=group)
         store.close()
         store = None
         if args.workload == "ns" and not args.rows:

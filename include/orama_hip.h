@@ -79,9 +79,12 @@ extern "C" {
  * candidates, the fp32 rows give their exact distances and the final order.  The answer is the fp32 scan's, bit for bit:
  * a query whose candidate list cannot be PROVEN to contain the exact top-k (error bound of the fp16 image, see
  * DESIGN §4 K1s) is answered by the plain fp32 scan instead.  Cosine metric, dimensions % 4 == 0 and <= 1024, k <= 2048;
- * outside that, and for the *_device entry points and the pipelined shard session (which never return to the host between
- * their launches), the store behaves as ORAMA_DTYPE_F32.  orama_hybrid_search and orama_shard_vec_search /
- * orama_shard_hybrid_search take the two stages too (shards begin together and are joined one by one). */
+ * outside that the store behaves as ORAMA_DTYPE_F32.  orama_hybrid_search and orama_shard_vec_search /
+ * orama_shard_hybrid_search take the two stages too (shards begin together and are joined one by one).  The *_device entry
+ * points and the pipelined shard session — which never return to the host between their launches — take them for k <= 128
+ * with the fallback decided and run ON THE DEVICE: the queries that are not proven (or that the fp16 image cannot serve: a
+ * zero vector, components >= 6e4, NaN) are re-answered behind the selection by the fp32 scan's own kernel over a
+ * device-made list of queries; with nothing to re-answer those launches end at once. */
 #define ORAMA_DTYPE_F32_SHADOW16 2
 
 typedef struct orama_ctx orama_ctx;   /* one per GPU: device ordinal, stream + scratch pools */

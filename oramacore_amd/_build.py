@@ -79,7 +79,7 @@ def _sources() -> list[Path]:
 
 def _fingerprint() -> str:
     h = hashlib.sha256()
-    for p in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + list(INCLUDE.glob("*.h"))):
+    for p in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) + list(INCLUDE.glob("*.h"))):
         h.update(p.name.encode())
         h.update(p.read_bytes())
     # flags without the checkout-specific include paths: the tree is shipped to the GPU box under another root, and a

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
                                                                    const uint32_t* __restrict__ n_per_list,
                                                                    uint32_t k, unsigned long long* __restrict__ out,
                                                                    uint64_t out_stride, unsigned long long* tau = nullptr,
-                                                                   uint32_t tau_stride = 0) {
+                                                                   uint32_t tau_stride = 0, const uint32_t* __restrict__ n_active = nullptr) {
     __shared__ unsigned long long s[kKeysChunk];
     __shared__ uint32_t hist[256];
     __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
@@ -563,6 +563,7 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
     // holds the first chunks of EVERY list and the later chunks of each list find a bound (chunk-fastest, a list's chunks
     // would all start together and none would)
     const uint32_t qi = tau ? blockIdx.x : blockIdx.y, chunk = tau ? blockIdx.y : blockIdx.x;
+    if (n_active && qi >= *n_active) return;  // (uniform) only the first *n_active lists exist: nothing of the others is read or written
     // A list's chunks share a running bound (tau, zero at launch): every workgroup that had to select publishes the k-th best
     // key of its chunk — a lower bound of the list's k-th best — and a chunk treats what lies below the bound it finds as
     // empty: about k of its 8 192 keys are left, the histogram rounds (LDS atomics that pile onto a few bins, since the
@@ -927,10 +928,11 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
                                                                   bool descending,
                                                                   const uint64_t* __restrict__ id_map,
                                                                   uint32_t* out_idx, uint64_t* out_ids, float* out_val,
-                                                                  uint32_t* out_n) {
+                                                                  uint32_t* out_n, const uint32_t* __restrict__ n_active = nullptr) {
     __shared__ SortLds s;
     __shared__ uint32_t valid_s;
     __shared__ uint32_t hist[256];
+    if (n_active && blockIdx.x >= *n_active) return;  // (uniform) see keys_reduce_kernel
     __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
     __shared__ uint32_t red_nz[kSortThreads / 64];
     __shared__ uint32_t sel[3], cursor;
@@ -1096,7 +1098,7 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
                      uint32_t q, uint32_t k, bool descending, const uint64_t* id_map,
                      unsigned long long* d_tmp, uint32_t* out_idx, uint64_t* out_ids, float* out_val,
                      uint32_t* out_n, hipStream_t stream, const uint32_t* d_n_per_list, unsigned long long* d_tau,
-                     uint32_t tau_stride) {
+                     uint32_t tau_stride, const uint32_t* d_n_active) {
     ORAMA_REQUIRE(k >= 1 && k <= kSelectMaxK && q >= 1 && d_keys && out_val, "keys top-k: bad arguments");
     ProfScope prof(&ctx->prof, "topk_select", stream);
     const unsigned long long* cur = d_keys;
@@ -1109,7 +1111,7 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
         const uint32_t chunks = (n + kKeysChunk - 1) / kKeysChunk;
         const uint64_t out_stride = (uint64_t)chunks * k;
         hipLaunchKernelGGL(keys_reduce_kernel, d_tau ? dim3(q, chunks) : dim3(chunks, q), dim3(kSortThreads), 0, stream, cur, n,
-                           cur_stride, n_per_list, k, tmp, out_stride, d_tau, tau_stride);
+                           cur_stride, n_per_list, k, tmp, out_stride, d_tau, tau_stride, d_n_active);
         d_tau = nullptr;  // (a bound belongs to the caller's lists: the next level starts without one)
         cur = tmp;
         cur_stride = out_stride;
@@ -1118,7 +1120,7 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
         tmp = tmp + (uint64_t)q * out_stride;  // next level (if any) writes behind this one
     }
     hipLaunchKernelGGL(keys_final_kernel, dim3(q), dim3(kSortThreads), 0, stream, cur, n, cur_stride, n_per_list, k,
-                       descending, id_map, out_idx, out_ids, out_val, out_n);
+                       descending, id_map, out_idx, out_ids, out_val, out_n, d_n_active);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -61,13 +61,14 @@ int launch_merge_candidates(orama_ctx* ctx, const uint64_t* d_ids, const float* 
 // final order (value, 64-bit id asc, idx asc).  d_tmp must hold keys_topk_scratch_keys() keys.  d_n_per_list (optional,
 // device): list i holds only min(n_keys, d_n_per_list[i]) keys — what lies behind them is never read.  d_tau (optional):
 // one ZEROED 64-bit word per list, tau_stride words apart — the running bound the chunks of a list share in the first
-// reduction level (a chunk with at most k keys at or above the bound skips its selection).
+// reduction level (a chunk with at most k keys at or above the bound skips its selection).  d_n_active (optional, device):
+// only lists 0 .. *d_n_active - 1 exist — the workgroups of the others end at once and their outputs are left untouched.
 constexpr uint32_t kKeysChunk = 8192;
 int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t n_keys, uint64_t stride,
                      uint32_t q, uint32_t k, bool descending, const uint64_t* id_map,
                      unsigned long long* d_tmp, uint32_t* out_idx, uint64_t* out_ids, float* out_val,
                      uint32_t* out_n, hipStream_t stream, const uint32_t* d_n_per_list = nullptr,
-                     unsigned long long* d_tau = nullptr, uint32_t tau_stride = 0);
+                     unsigned long long* d_tau = nullptr, uint32_t tau_stride = 0, const uint32_t* d_n_active = nullptr);
 // Keys of scratch launch_keys_topk needs for lists of n_keys entries.
 uint64_t keys_topk_scratch_keys(uint32_t n_keys, uint32_t q, uint32_t k);
 

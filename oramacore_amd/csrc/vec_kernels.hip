@@ -59,125 +59,26 @@ __device__ __forceinline__ bool row_excluded(uint64_t row, const uint32_t* dead,
 // NCHUNK = ceil(dim/4 / 64) 16-byte pieces per lane per row; EXACT: dim/4 == 64*NCHUNK.
 template <int NCHUNK, bool EXACT, int ROWS, bool NT, int METRIC, bool FUSED>
 __global__ __launch_bounds__(kScanThreads) void vec_scan_f32_kernel(ScanArgs a) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const uint32_t wave = uniform_u32(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
-    const uint32_t d4 = a.dim >> 2;
-    const f32x4* __restrict__ base = reinterpret_cast<const f32x4*>(a.corpus);
+#include "vec_scan_f32_body.inc"
+}
 
-    // query → registers; |q| from the same registers (no extra launch)
-    f32x4 qv[NCHUNK];
-    float qq = 0.0f;
-#pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) {
-        const uint32_t f = c * kWave + lane;
-        if (EXACT || f < d4) {
-            qv[c] = reinterpret_cast<const f32x4*>(a.query)[f];
-        } else {
-            qv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+// The same pass for a set of queries chosen ON THE DEVICE (the two-stage plan's fallback on the device path, vec_store.hip):
+// queries pick[0 .. *n_pick) of a.query, one after the other, each with its own wave lists; *n_pick == 0 — the usual case —
+// ends the launch at once.  Same arithmetic per row as the kernel above (the body is the same text), cosine and fused mode only.
+template <int NCHUNK, bool EXACT, int ROWS>
+__global__ __launch_bounds__(kScanThreads) void vec_scan_f32_picked_kernel(ScanArgs a, const uint32_t* __restrict__ pick,
+                                                                            const uint32_t* __restrict__ n_pick, uint64_t list_stride) {
+    const uint32_t np = uniform_u32(*n_pick);
+    const float* queries = a.query;
+    unsigned long long* lists = a.wave_lists;
+    constexpr bool NT = false, FUSED = true;
+    constexpr int METRIC = ORAMA_METRIC_COSINE;
+    for (uint32_t f = 0; f < np; ++f) {
+        a.query = queries + (size_t)uniform_u32(pick[f]) * a.dim;
+        a.wave_lists = lists + (uint64_t)f * list_stride;
+        {
+#include "vec_scan_f32_body.inc"
         }
-        qq = fmaf(qv[c].x, qv[c].x, qq);
-        qq = fmaf(qv[c].y, qv[c].y, qq);
-        qq = fmaf(qv[c].z, qv[c].z, qq);
-        qq = fmaf(qv[c].w, qv[c].w, qq);
-    }
-    float qscale = 0.0f;
-    if (METRIC == ORAMA_METRIC_COSINE) {
-        qq = wave_sum(qq);
-        qscale = qq > 0.0f ? 1.0f / sqrtf(qq) : 0.0f;  // zero-norm query: similarity 0
-    }
-    const bool filtered = (a.dead != nullptr) || (a.allow != nullptr);
-    constexpr bool fused = FUSED;  // compile-time: the dense kernel carries none of the list state
-    WaveTopK best;
-
-    for (uint64_t r0 = (uint64_t)wave * ROWS; r0 < a.n; r0 += (uint64_t)nwaves * ROWS) {
-        f32x4 x[ROWS][NCHUNK];
-        bool live[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const uint64_t row = r0 + r;
-            live[r] = row < a.n;
-            if (filtered && live[r])
-                live[r] = !row_excluded(row, a.dead, a.row_doc, a.allow, a.allow_bits);
-            const f32x4* p = base + row * d4 + lane;
-#pragma unroll
-            for (int c = 0; c < NCHUNK; ++c) {
-                const bool ok = live[r] && (EXACT || (uint32_t)(c * kWave + lane) < d4);
-                x[r][c] = ok ? load16<NT>(p + c * kWave) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        // per-lane partial dot products of the ROWS rows
-        float acc[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            acc[r] = 0.0f;
-#pragma unroll
-            for (int c = 0; c < NCHUNK; ++c) {
-                if (METRIC == ORAMA_METRIC_COSINE) {
-                    acc[r] = fmaf(x[r][c].x, qv[c].x, acc[r]);
-                    acc[r] = fmaf(x[r][c].y, qv[c].y, acc[r]);
-                    acc[r] = fmaf(x[r][c].z, qv[c].z, acc[r]);
-                    acc[r] = fmaf(x[r][c].w, qv[c].w, acc[r]);
-                } else {
-                    float t0 = x[r][c].x - qv[c].x, t1 = x[r][c].y - qv[c].y;
-                    float t2 = x[r][c].z - qv[c].z, t3 = x[r][c].w - qv[c].w;
-                    acc[r] = fmaf(t0, t0, acc[r]);
-                    acc[r] = fmaf(t1, t1, acc[r]);
-                    acc[r] = fmaf(t2, t2, acc[r]);
-                    acc[r] = fmaf(t3, t3, acc[r]);
-                }
-            }
-        }
-        if constexpr (!fused && ROWS >= 2) {
-            // ONE transposed reduction for the ROWS rows (same summation tree as wave_sum, see device_utils.hpp):
-            // lane l ends up with the total of row r0 + lane_query<ROWS>(l); lanes 0..ROWS-1 finish their row
-            const float tot = wave_sum_scatter<ROWS>(acc, lane);
-            const int my_r = lane_query<ROWS>(lane);
-            bool my_live = false;
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r)
-                if (my_r == r) my_live = live[r];
-            if (lane < ROWS) {
-                float dist;
-                if (METRIC == ORAMA_METRIC_COSINE) {
-                    const float inv = my_live ? a.inv_norm[r0 + my_r] : 0.0f;
-                    dist = 1.0f - tot * (inv * qscale);
-                } else {
-                    dist = tot;
-                }
-                if (!my_live) dist = __builtin_nanf("");
-                if (r0 + my_r < a.n) a.out_dist[r0 + my_r] = dist;
-            }
-        } else {
-            float mine = 0.0f;
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const float tot = wave_sum(acc[r]);
-                float dist;
-                if (METRIC == ORAMA_METRIC_COSINE) {
-                    const float inv = live[r] ? a.inv_norm[r0 + r] : 0.0f;
-                    dist = 1.0f - tot * (inv * qscale);
-                } else {
-                    dist = tot;
-                }
-                if (!live[r]) dist = __builtin_nanf("");
-                if (fused) {
-                    if (live[r] && dist == dist) {  // smaller distance wins, then lower row: key = ~ordered(d) << 32 | ~row
-                        const unsigned long long key =
-                            ((unsigned long long)(~f32_to_ordered(dist)) << 32) | (unsigned long long)(uint32_t)(~(uint32_t)(r0 + r));
-                        if (best.count < a.topk || key > best.thr) best.insert(key, a.topk, lane);
-                    }
-                } else if (lane == r) {
-                    mine = dist;
-                }
-            }
-            if (!fused && lane < ROWS && r0 + lane < a.n) a.out_dist[r0 + lane] = mine;
-        }
-    }
-    if (fused) {
-        unsigned long long* out = a.wave_lists + (uint64_t)wave * kWaveListKeys;
-        out[lane] = best.s0;
-        out[lane + 64] = best.s1;
     }
 }
 
@@ -537,6 +438,50 @@ int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a_in, hipStream_t stream
             hipLaunchKernelGGL((vec_scan_f32_generic_kernel<ORAMA_METRIC_COSINE>), grid, dim3(kScanThreads), 0, stream, a);
         else
             hipLaunchKernelGGL((vec_scan_f32_generic_kernel<ORAMA_METRIC_L2SQ>), grid, dim3(kScanThreads), 0, stream, a);
+    }
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+namespace {
+// picked scans: 4 rows in flight per wave whatever the tuning says (the fallback's speed matters little, its instantiations
+// do; 4 rows x 4 chunks x 4 registers is the widest the register budget of K1 takes)
+constexpr int kPickedRows = 4;
+template <int NCHUNK, bool EXACT>
+void launch_picked(const ScanArgs& a, dim3 grid, const uint32_t* pick, const uint32_t* n_pick, uint64_t stride, hipStream_t s) {
+    static_assert(kPickedRows * NCHUNK <= 16, "register budget of the scan body");
+    hipLaunchKernelGGL((vec_scan_f32_picked_kernel<NCHUNK, EXACT, kPickedRows>), grid, dim3(kScanThreads), 0, s, a, pick, n_pick, stride);
+}
+}  // namespace
+
+bool vec_scan_f32_picked_supported(const ScanArgs& a) {
+    const uint32_t d4 = a.dim >> 2;
+    return (a.dim & 3) == 0 && d4 <= 4 * kWave && a.metric == ORAMA_METRIC_COSINE;
+}
+
+uint32_t vec_scan_f32_picked_waves(orama_ctx* ctx, const ScanArgs& a) {
+    if (!a.n) return 0;
+    const uint32_t cap = (uint32_t)ctx->compute_units * (uint32_t)ctx->scan_tuning.blocks_per_cu;
+    return grid_for_rows((a.n + kPickedRows - 1) / kPickedRows, cap) * kWavesPerBlock;
+}
+
+int launch_vec_scan_f32_picked(orama_ctx* ctx, const ScanArgs& a, const uint32_t* d_pick, const uint32_t* d_n_pick,
+                               uint64_t list_stride, hipStream_t stream) {
+    ORAMA_REQUIRE(a.corpus && a.query && a.inv_norm && a.wave_lists && d_pick && d_n_pick && a.topk >= 1 && a.topk <= kWaveListKeys,
+                  "picked scan: bad arguments");
+    ORAMA_REQUIRE(vec_scan_f32_picked_supported(a), "picked scan: cosine over dimensions that are a multiple of 4 up to 1024");
+    ORAMA_REQUIRE(!a.allow || a.row_doc, "vec_scan: filter needs row_doc");
+    ORAMA_REQUIRE(a.n < 0xffffffffull, "vec_scan: too many rows");
+    if (a.n == 0) return ORAMA_OK;
+    const uint32_t d4 = a.dim >> 2;
+    const int nchunk = (int)((d4 + kWave - 1) / kWave);
+    const bool exact = d4 == (uint32_t)nchunk * kWave;
+    const dim3 grid(vec_scan_f32_picked_waves(ctx, a) / kWavesPerBlock);
+    switch (nchunk) {
+        case 1: exact ? launch_picked<1, true>(a, grid, d_pick, d_n_pick, list_stride, stream) : launch_picked<1, false>(a, grid, d_pick, d_n_pick, list_stride, stream); break;
+        case 2: exact ? launch_picked<2, true>(a, grid, d_pick, d_n_pick, list_stride, stream) : launch_picked<2, false>(a, grid, d_pick, d_n_pick, list_stride, stream); break;
+        case 3: exact ? launch_picked<3, true>(a, grid, d_pick, d_n_pick, list_stride, stream) : launch_picked<3, false>(a, grid, d_pick, d_n_pick, list_stride, stream); break;
+        default: exact ? launch_picked<4, true>(a, grid, d_pick, d_n_pick, list_stride, stream) : launch_picked<4, false>(a, grid, d_pick, d_n_pick, list_stride, stream); break;
     }
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;

@@ -36,6 +36,14 @@ int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a, hipStream_t stream);
 uint32_t vec_scan_f32_waves(orama_ctx* ctx, const ScanArgs& a);
 constexpr uint32_t kWaveListKeys = 128;
 
+// K1 for queries chosen on the device: queries d_pick[0 .. *d_n_pick) of a.query (an array of queries), one corpus pass each,
+// wave lists of the f-th at a.wave_lists + f * list_stride (vec_scan_f32_picked_waves() lists of 128 keys); fused mode,
+// cosine, dimensions on the vectorised path.  *d_n_pick == 0 ends the launch at once.  Distances bit-identical to K1's.
+bool vec_scan_f32_picked_supported(const ScanArgs& a);
+uint32_t vec_scan_f32_picked_waves(orama_ctx* ctx, const ScanArgs& a);
+int launch_vec_scan_f32_picked(orama_ctx* ctx, const ScanArgs& a, const uint32_t* d_pick, const uint32_t* d_n_pick,
+                               uint64_t list_stride, hipStream_t stream);
+
 // K1b: one corpus pass, nq in [2, 8] queries (a.query = nq contiguous queries); distances of query j go to
 // a.out_dist[j * out_stride + row].  Bit-identical per (row, query) to launch_vec_scan_f32.  Dense mode only.
 constexpr uint32_t kScanMultiMaxQ = 8;

@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "device_utils.hpp"
 #include "select.hpp"
 #include "vec_f16.hpp"
 #include "vec_internal.hpp"
@@ -251,6 +252,7 @@ struct orama_vec {
     // scratch for the device-pointer entry point, one per caller stream
     std::mutex dev_mu;
     std::map<hipStream_t, std::unique_ptr<Scratch>> dev_scratch;
+    std::map<hipStream_t, std::unique_ptr<Scratch>> dev_scratch2;  // shadow stores: the candidate stage's set (two_stage_search)
 
     bool f16() const { return dtype == ORAMA_DTYPE_F16; }
     size_t row_bytes() const { return (size_t)dim * sizeof(float); }  // f32 row (host side / f32 store)
@@ -342,6 +344,58 @@ __global__ void gather_u64_kernel(const uint64_t* __restrict__ src, const uint64
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         out[i] = src[idx[i]];
 }
+// ---- the two-stage plan's fallback without the host (device path: orama_vec_search_*device*, sessions)
+// A query the fp16 shadow cannot serve (the test its rows pass at insert: |q|^2 >= 1e-4, every |q_i| < 6e4 — NaN fails both)
+// flags itself "not proven"; one wave per query.
+__global__ void query_shadow_unsafe_kernel(const float* __restrict__ queries, uint32_t q, uint32_t dim, uint32_t* __restrict__ flag) {
+    const uint32_t j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (j >= q) return;
+    const int lane = threadIdx.x & 63;
+    const float* x = queries + (size_t)j * dim;
+    float n2 = 0.0f, mx = 0.0f;
+    bool nan = false;
+    for (uint32_t i = lane; i < dim; i += 64) {
+        const float v = x[i];
+        n2 = fmaf(v, v, n2);
+        mx = fmaxf(mx, fabsf(v));
+        nan |= v != v;
+    }
+    n2 = wave_sum(n2);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const bool any_nan = __ballot(nan) != 0ull;
+    if (lane == 0 && (any_nan || !(n2 >= 1e-4f && mx < 6.0e4f))) flag[j] = 1u;
+}
+// pick[0 .. *n_pick) = the flagged queries in ascending order (one workgroup of 256 threads)
+__global__ void pick_flagged_kernel(const uint32_t* __restrict__ flag, uint32_t q, uint32_t* __restrict__ pick,
+                                    uint32_t* __restrict__ n_pick) {
+    __shared__ uint32_t cnt[256];
+    const uint32_t per = (q + 255u) / 256u;
+    const uint32_t lo = min(q, threadIdx.x * per), hi = min(q, lo + per);
+    uint32_t c = 0;
+    for (uint32_t j = lo; j < hi; ++j) c += flag[j] != 0u;
+    cnt[threadIdx.x] = c;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t t = 0; t < threadIdx.x; ++t) base += cnt[t];
+    for (uint32_t j = lo; j < hi; ++j)
+        if (flag[j] != 0u) pick[base++] = j;
+    if (threadIdx.x == 255) *n_pick = base;
+}
+// the answers of the picked queries go to their own slots (workgroup f = the f-th picked query)
+__global__ void scatter_picked_kernel(const uint32_t* __restrict__ pick, const uint32_t* __restrict__ n_pick, uint32_t k,
+                                      const uint64_t* __restrict__ ids, const float* __restrict__ dist, const uint32_t* __restrict__ n,
+                                      uint64_t* __restrict__ out_ids, float* __restrict__ out_dist, uint32_t* __restrict__ out_n) {
+    const uint32_t f = blockIdx.x;
+    if (f >= *n_pick) return;
+    const uint32_t j = pick[f];
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        out_ids[(size_t)j * k + i] = ids[(size_t)f * k + i];
+        out_dist[(size_t)j * k + i] = dist[(size_t)f * k + i];
+    }
+    if (threadIdx.x == 0) out_n[j] = n[f];
+}
+
 uint32_t blocks_for_rows(uint64_t n) { return (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1, (n + 255) / 256)); }
 
 bool row_valid(const float* x, uint32_t d) {  // EmbeddingIndexer::index_vec_vec -> None (assumption)
@@ -731,13 +785,21 @@ int search_enqueue(orama_vec* v, Scratch* sc, const float* d_queries, uint32_t q
 // same tie rule as the one-stage path.  The answer equals the fp32 scan's bit for bit.
 constexpr float kShadowEps = 2.5e-3f;
 
-int two_stage_search(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k,
+// `flags_pending` == nullptr selects the DEVICE form (orama_vec_search_*device*, sessions — no host between the stages and the
+// consumer of the answers): the queries that are not proven are re-answered on the device, behind the selection, by K1's own
+// kernel run over a list of queries that is made on the device (pick_flagged_kernel -> launch_vec_scan_f32_picked -> the key
+// lists' top-k restricted to the picked lists -> scatter_picked_kernel).  With nothing flagged — 99.9 % of the queries — these
+// launches end at once (~40 us per call); every flagged query costs one fp32 pass, as on the host form.  A query the shadow
+// cannot serve at all (query_shadow_unsafe_kernel: the test vec_two_stage_usable applies on the host) is flagged like an
+// unproven one.
+int two_stage_search(orama_vec* v, Scratch* sc, Scratch* sc2, const float* d_queries, uint32_t q, uint32_t k,
                      const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n,
                      hipStream_t s, bool* flags_pending) {
     // (the caller holds the shadow's mu shared — and v->mu shared, which also excludes a compaction of the pair — until
-    // the launches below have completed)
+    // the launches below have completed; on the device form: until they are enqueued, like every *_device call)
     orama_vec* sh = v->shadow.get();
-    *flags_pending = false;
+    const bool device_form = flags_pending == nullptr;
+    if (flags_pending) *flags_pending = false;
     const View w = snapshot(v);
     View ws = snapshot(sh);
     ws.n_rows = std::min(ws.n_rows, w.n_rows);  // the shadow is written first: it may already hold unpublished rows
@@ -762,7 +824,38 @@ int two_stage_search(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const fl
     uint32_t* d_n1 = sc2->out_n.as<uint32_t>();
     uint32_t* d_flag = d_n1 + q;
     uint32_t* d_inexact = d_n1 + 2 * (size_t)q;  // stage 1 itself could not prove its list (K1h's 64 rows per wave)
-    ORAMA_TRY(search_enqueue_f16(sh, ws, sc2.s.get(), d_queries, q, k1, d_allow, allow_bits, sc2->out_ids.as<uint64_t>(),
+    // the device form's buffers first: nothing is (re)allocated behind launches that are already enqueued
+    ScanArgs fa;  // the fallback's scan (K1, fused mode)
+    uint32_t fb_keys = 0;
+    uint32_t *d_pick = nullptr, *d_n_pick = nullptr, *fb_n = nullptr;
+    uint64_t* fb_ids = nullptr;
+    float* fb_dist = nullptr;
+    if (device_form) {
+        fa.corpus = static_cast<const float*>(w.rows);
+        fa.inv_norm = w.inv_norm;
+        fa.query = d_queries;
+        fa.n = w.n_rows;
+        fa.dim = v->dim;
+        fa.metric = v->metric;
+        fa.row_doc = w.row_doc;
+        fa.dead = w.dead;
+        fa.allow = d_allow;
+        fa.allow_bits = allow_bits;
+        fa.topk = k;
+        ORAMA_REQUIRE(k <= kWaveListKeys && vec_scan_f32_picked_supported(fa), "internal: two-stage device form outside its envelope");
+        fb_keys = vec_scan_f32_picked_waves(v->ctx, fa) * kWaveListKeys;
+        ORAMA_TRY(sc->misc3.reserve((size_t)q * fb_keys * 8));
+        ORAMA_TRY(sc->misc4.reserve((size_t)keys_topk_scratch_keys(fb_keys, q, k) * 8 + 8));
+        const size_t nk = (size_t)q * k;
+        ORAMA_TRY(sc->misc5.reserve(nk * 12 + (size_t)q * 8 + 64));
+        fb_ids = sc->misc5.as<uint64_t>();
+        fb_dist = reinterpret_cast<float*>(fb_ids + nk);
+        fb_n = reinterpret_cast<uint32_t*>(fb_dist + nk);
+        d_pick = fb_n + q;
+        d_n_pick = d_pick + q;
+        fa.wave_lists = sc->misc3.as<unsigned long long>();
+    }
+    ORAMA_TRY(search_enqueue_f16(sh, ws, sc2, d_queries, q, k1, d_allow, allow_bits, sc2->out_ids.as<uint64_t>(),
                                  sc2->out_val.as<float>(), d_n1, s, sc2->out_idx.as<uint32_t>(), d_inexact));
     ORAMA_TRY(launch_shadow_band(sc2->out_val.as<float>(), d_n1, q, k, k1, 2.0f * kShadowEps, d_flag, s, d_inexact));
     // stage 2: exact distances of the candidates, then the final order
@@ -787,10 +880,35 @@ int two_stage_search(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const fl
     p.out_val = d_out_dist;
     p.out_n = d_out_n;
     ORAMA_TRY(launch_select(v->ctx, p, s));
+    if (device_form) {
+        hipLaunchKernelGGL(query_shadow_unsafe_kernel, dim3((q + 3) / 4), dim3(256), 0, s, d_queries, q, v->dim, d_flag);
+        hipLaunchKernelGGL(pick_flagged_kernel, dim3(1), dim3(256), 0, s, d_flag, q, d_pick, d_n_pick);
+        ORAMA_HIP_TRY(hipGetLastError());
+        ORAMA_TRY(launch_vec_scan_f32_picked(v->ctx, fa, d_pick, d_n_pick, fb_keys, s));
+        ORAMA_TRY(launch_keys_topk(v->ctx, fa.wave_lists, fb_keys, fb_keys, q, k, false, w.row_doc, sc->misc4.as<unsigned long long>(),
+                                   nullptr, fb_ids, fb_dist, fb_n, s, nullptr, nullptr, 0, d_n_pick));
+        hipLaunchKernelGGL(scatter_picked_kernel, dim3(q), dim3(128), 0, s, d_pick, d_n_pick, k, fb_ids, fb_dist, fb_n, d_out_ids,
+                           d_out_dist, d_out_n);
+        ORAMA_HIP_TRY(hipGetLastError());
+        v->two_stage_queries.fetch_add(q, std::memory_order_relaxed);
+        return ORAMA_OK;
+    }
     ORAMA_TRY(sc2->h_out.reserve((size_t)q * 4));
     ORAMA_HIP_TRY(hipMemcpyAsync(sc2->h_out.p, d_flag, (size_t)q * 4, hipMemcpyDeviceToHost, s));
     *flags_pending = true;  // sc2->h_out holds one word per query once `s` has drained: non-zero = not proven
     return ORAMA_OK;
+}
+
+// The device entry points take the two-stage plan when the store keeps a shadow and the call lies inside the plan's envelope
+// (the host form's conditions without the look at the queries — they are on the device: query_shadow_unsafe_kernel).
+bool two_stage_device_usable(orama_vec* v, uint32_t q, uint32_t k) {
+    if (!(v->shadow && v->ctx->two_stage && v->shadow_ok.load(std::memory_order_acquire) && k >= 1 && k <= kWaveListKeys &&
+          v->metric == ORAMA_METRIC_COSINE && (v->dim & 3) == 0 && v->dim <= 1024))
+        return false;
+    const uint64_t rows = v->n_rows.load(std::memory_order_relaxed);
+    if (v->ctx->two_stage != 2 && q <= 8 && rows * v->row_bytes() < (4ull << 30)) return false;  // (as vec_two_stage_usable)
+    // wave lists of the fallback: one set per query of the call (4 MB each at the default grid)
+    return (uint64_t)q * (uint64_t)v->ctx->compute_units * (uint64_t)v->ctx->scan_tuning.blocks_per_cu * 4ull * kWaveListKeys * 8ull <= (4ull << 30);
 }
 
 }  // namespace
@@ -843,7 +961,7 @@ int VecTwoStage::begin(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const 
     d_out_ids_ = d_out_ids, d_out_dist_ = d_out_dist, d_out_n_ = d_out_n;
     v->shadow->mu.lock_shared();
     locked_ = &v->shadow->mu;
-    return two_stage_search(v, sc, sc2, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, sc->stream, &flags_pending_);
+    return two_stage_search(v, sc.s.get(), sc2.s.get(), d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, sc->stream, &flags_pending_);
 }
 int VecTwoStage::finish() {
     ORAMA_REQUIRE(locked_, "internal: two-stage search not begun");
@@ -1262,6 +1380,32 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     return ORAMA_OK;
 }
 
+// Device-resident search on the caller's stream(s); v->mu is held shared by the caller.  A store with an fp16 shadow takes the
+// two-stage plan in its device form (two_stage_search) — everything on the tail stream `s`: the fp16 pipeline interleaves
+// scans and selections with dependencies in both directions.
+static int device_search_enqueue(orama_vec* v, const float* d_queries, uint32_t q, uint32_t k, const uint64_t* d_allow,
+                                 uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n, hipStream_t s,
+                                 hipStream_t s_scan, bool two_streams) {
+    const bool two_stage = two_stage_device_usable(v, q, k);
+    Scratch *sc = nullptr, *sc2 = nullptr;
+    {
+        std::lock_guard<std::mutex> g(v->dev_mu);
+        auto& slot = v->dev_scratch[s];
+        if (!slot) slot.reset(new Scratch());
+        sc = slot.get();
+        if (two_stage) {
+            auto& slot2 = v->dev_scratch2[s];
+            if (!slot2) slot2.reset(new Scratch());
+            sc2 = slot2.get();
+        }
+    }
+    if (two_stage) {
+        std::shared_lock<std::shared_mutex> sl(v->shadow->mu);
+        return two_stage_search(v, sc, sc2, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, s, nullptr);
+    }
+    return search_enqueue(v, sc, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, s, s_scan, two_streams);
+}
+
 int orama_vec_search_device(orama_vec* v, const float* d_queries, uint32_t q, uint32_t k,
                             const uint64_t* d_allow_bitmap, uint64_t bitmap_bits,
                             uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n,
@@ -1273,14 +1417,7 @@ int orama_vec_search_device(orama_vec* v, const float* d_queries, uint32_t q, ui
     ORAMA_ON_DEVICE(v->ctx->device);
     hipStream_t s = (hipStream_t)hip_stream;
     std::shared_lock<std::shared_mutex> lk(v->mu);
-    Scratch* sc = nullptr;
-    {
-        std::lock_guard<std::mutex> g(v->dev_mu);
-        auto& slot = v->dev_scratch[s];
-        if (!slot) slot.reset(new Scratch());
-        sc = slot.get();
-    }
-    return search_enqueue(v, sc, d_queries, q, k, d_allow_bitmap, bitmap_bits, d_out_ids, d_out_dist, d_out_n, s);
+    return device_search_enqueue(v, d_queries, q, k, d_allow_bitmap, bitmap_bits, d_out_ids, d_out_dist, d_out_n, s, nullptr, false);
 }
 
 int orama_vec_search_packed_device2(orama_vec* v, const float* d_queries, uint32_t q, uint32_t k,
@@ -1293,16 +1430,9 @@ int orama_vec_search_packed_device2(orama_vec* v, const float* d_queries, uint32
     ORAMA_ON_DEVICE(v->ctx->device);
     hipStream_t s = (hipStream_t)tail_stream, ss = (hipStream_t)scan_stream;
     std::shared_lock<std::shared_mutex> lk(v->mu);
-    Scratch* sc = nullptr;
-    {
-        std::lock_guard<std::mutex> g(v->dev_mu);
-        auto& slot = v->dev_scratch[s];
-        if (!slot) slot.reset(new Scratch());
-        sc = slot.get();
-    }
     char* base = reinterpret_cast<char*>(d_packed_block);
-    return search_enqueue(v, sc, d_queries, q, k, d_allow_bitmap, bitmap_bits, reinterpret_cast<uint64_t*>(base),
-                          reinterpret_cast<float*>(base + (uint64_t)q * k * 8), d_out_n, s, ss, true);
+    return device_search_enqueue(v, d_queries, q, k, d_allow_bitmap, bitmap_bits, reinterpret_cast<uint64_t*>(base),
+                                 reinterpret_cast<float*>(base + (uint64_t)q * k * 8), d_out_n, s, ss, true);
 }
 
 int orama_merge_candidates_device(orama_ctx* ctx, const uint64_t* d_ids, const float* d_dist,

@@ -275,3 +275,95 @@ def test_the_plan_is_chosen_only_where_it_pays(ctx):
         ctx.set_two_stage(True, always=True)
     plain.close()
     shadow.close()
+
+
+def test_the_device_path_decides_the_fallback_on_the_device(ctx):
+    """orama_vec_search_device / _packed_device and the pipelined session on a shadow store: the two-stage plan
+    with NO host between its stages and the consumer of the answers.  Queries that are not proven — a query in the middle of
+    6 000 near-duplicates — and queries the fp16 shadow cannot serve at all (a zero vector, components beyond the fp16
+    range, a NaN) are re-answered on the device by K1's own kernel over a device-made list of queries: every answer equals
+    the plain fp32 store's bit for bit, under a filter too; k beyond the fused scan's 128 keeps the fp32 scan."""
+    from oramacore_amd import _native as N
+    from oramacore_amd.shard_group import ShardGroup
+
+    lib = N.load()
+    rng = np.random.default_rng(17)
+    dim, n, k = 256, 40_000, 100
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    centre = rng.standard_normal(dim).astype(np.float32)
+    rows[:6000] = centre + (rng.standard_normal((6000, dim)) * 1e-4).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64) * np.uint64(5) + np.uint64(3)
+    plain, shadow = pair(ctx, dim)
+    plain.insert_rows(ids, rows)
+    shadow.insert_rows(ids, rows)
+    qs = rng.standard_normal((16, dim)).astype(np.float32)
+    qs[1] = centre + (rng.standard_normal(dim) * 1e-3).astype(np.float32)  # not proven: the band holds thousands of rows
+    qs[4] = 0.0                                                             # |q| = 0
+    qs[7] *= np.float32(1e5)                                                # beyond the fp16 range
+    qs[9, 3] = np.nan
+    qs[12] = centre
+    Q = qs.shape[0]
+    e_ids, e_dist, e_cnt = plain.storage_search(qs, k)
+
+    def device_search(store, q, kk, allow=None):
+        d_q = oa.DeviceBuffer(ctx, q.nbytes).upload(q)
+        d_i, d_d, d_n = oa.DeviceBuffer(ctx, len(q) * kk * 8), oa.DeviceBuffer(ctx, len(q) * kk * 4), oa.DeviceBuffer(ctx, len(q) * 4)
+        tok, nbits = allow.ffi_args() if allow is not None else (None, 0)
+        N.check(lib.orama_vec_search_device(store.handle, d_q.ptr, len(q), kk, tok, nbits, d_i.ptr, d_d.ptr, d_n.ptr, None))
+        ctx.synchronize()
+        out = (d_i.download(np.uint64, len(q) * kk).reshape(len(q), kk), d_d.download(np.float32, len(q) * kk).reshape(len(q), kk),
+               d_n.download(np.uint32, len(q)))
+        for b in (d_q, d_i, d_d, d_n):
+            b.free()
+        return out
+
+    def equal(got, exp, tag):
+        gi, gd, gn = got
+        xi, xd, xn = exp
+        assert gn.tolist() == xn.tolist(), tag
+        for j in range(len(gn)):
+            m = int(gn[j])
+            assert gi[j, :m].tolist() == xi[j, :m].tolist(), (tag, j)
+            assert np.array_equal(bits(gd[j, :m]), bits(xd[j, :m])), (tag, j)
+
+    before = shadow.info()["two_stage_queries"]
+    equal(device_search(shadow, qs, k), (e_ids, e_dist, e_cnt), "batch of 16")
+    assert shadow.info()["two_stage_queries"] == before + Q  # the plan ran (the device form counts its queries)
+    for j in (0, 1, 4, 7, 9):
+        equal(device_search(shadow, qs[j:j + 1], k), (e_ids[j:j + 1], e_dist[j:j + 1], e_cnt[j:j + 1]), ("solo", j))
+    # a batch in which EVERY query is flagged
+    allbad = np.zeros((5, dim), dtype=np.float32)
+    equal(device_search(shadow, allbad, k), plain.storage_search(allbad, k), "all flagged")
+    # under a filter (resident bitmap)
+    mask_ids = ids[rng.random(n) < 0.4]
+    bm = oa.AllowBitmap(int(ids.max()) + 1, mask_ids).to_device(ctx)
+    host_bm = oa.AllowBitmap(int(ids.max()) + 1, mask_ids)
+    equal(device_search(shadow, qs, 50, bm), plain.storage_search(qs, 50, host_bm), "filtered")
+    bm.close()
+    # k beyond the fused scan's lists: the fp32 scan answers, the plan's counter stands still
+    before = shadow.info()["two_stage_queries"]
+    equal(device_search(shadow, qs[:3], 200), plain.storage_search(qs[:3], 200), "k = 200")
+    assert shadow.info()["two_stage_queries"] == before
+    # the pipelined session (bench.py's loop): 4 queries per step, two slots in flight
+    group = ShardGroup([0])  # (its own context: the stores of a session belong to the group's)
+    group.ctx(0).set_two_stage(True, always=True)
+    gp, gs = pair(group.ctx(0), dim)
+    gp.insert_rows(ids, rows)
+    gs.insert_rows(ids, rows)
+    for force in (False, True):
+        sess = group.session([gs], qs, 4, k, n_slots=2, force_exchange=force)
+        for step in range(Q // 4):
+            sess.step(step)
+            if step % 2 == 1:  # both slots hold a finished step
+                sess.sync()
+                for slot, st in ((0, step - 1), (1, step)):
+                    s_ids, s_dist, s_cnt = sess.result(slot)
+                    equal((s_ids, s_dist, s_cnt), (e_ids[4 * st:4 * st + 4], e_dist[4 * st:4 * st + 4], e_cnt[4 * st:4 * st + 4]),
+                          ("session", force, st))
+        sess.close()
+    assert gs.info()["two_stage_queries"] >= 2 * Q
+    gp.close()
+    gs.close()
+    group.close()
+    plain.close()
+    shadow.close()
