@@ -478,6 +478,14 @@ class PostingsStore(Owner):
                                               C.byref(out_n), C.byref(out_count)))
         return out_ids[: out_n.value], out_sc[: out_n.value], out_count.value
 
+    def prepare_hybrid(self, vec_store, query, limit: int, similarity: float, refs, n_tokens: int, total_documents: float,
+                       top_k: int, threshold=None, allow: AllowBitmap | None = None, apply_omc: bool = True,
+                       rescale_e5: bool = False, b: float = B_DEFAULT, k: float = K1_DEFAULT) -> "PreparedHybrid":
+        """The arguments of `hybrid_search` marshalled once (what a native caller holds anyway): `.run()` is the bare
+        orama_hybrid_search call and returns what `hybrid_search` returns."""
+        return PreparedHybrid(self, vec_store, query, limit, similarity, refs, n_tokens, total_documents, top_k, threshold, allow,
+                              apply_omc, rescale_e5, b, k)
+
     def info(self) -> dict:
         nd, nl, npst, avg = C.c_uint64(), C.c_uint32(), C.c_uint64(), C.c_float()
         N.check(self._lib.orama_post_info(self._h, C.byref(nd), C.byref(nl), C.byref(npst), C.byref(avg)))
@@ -590,6 +598,30 @@ class PostingsStore(Owner):
         sq = StagedQuery(self._lib, h, top_k)
         self._adopt(sq)
         return sq
+
+
+class PreparedHybrid:
+    """One orama_hybrid_search call with its arguments already in C form (PostingsStore.prepare_hybrid)."""
+
+    def __init__(self, post, vec_store, query, limit, similarity, refs, n_tokens, total_documents, top_k, threshold, allow,
+                 apply_omc, rescale_e5, b, k):
+        self._post, self._vec, self._allow = post, vec_store, allow  # (kept alive)
+        self._arr = post._refs(refs)
+        self._params = _params(total_documents, n_tokens, threshold, top_k, k)
+        self._qv = _f32(query)
+        self._out_ids = np.zeros(max(top_k, 1), dtype=np.uint64)
+        self._out_sc = np.zeros(max(top_k, 1), dtype=np.float32)
+        self._out_n, self._out_count = C.c_uint32(), C.c_uint64()
+        bm_ptr, bm_bits = allow.ffi_args() if allow is not None else (None, 0)
+        self._args = (vec_store.handle, post._h, self._qv.ctypes.data, int(limit), float(similarity), 1 if rescale_e5 else 0,
+                      self._arr, len(refs), b, C.byref(self._params), bm_ptr, bm_bits, 1 if apply_omc else 0,
+                      self._out_ids.ctypes.data, self._out_sc.ctypes.data, C.byref(self._out_n), C.byref(self._out_count))
+        self._call = post._lib.orama_hybrid_search
+
+    def run(self):
+        N.check(self._call(*self._args))
+        n = self._out_n.value
+        return self._out_ids[:n].copy(), self._out_sc[:n].copy(), self._out_count.value
 
 
 def post_block_bytes(top_k: int) -> int:
