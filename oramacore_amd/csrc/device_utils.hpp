@@ -42,6 +42,9 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    return ((unsigned long long)uniform_u32((uint32_t)(v >> 32)) << 32) | uniform_u32((uint32_t)v);
+}
 
 // Order-preserving map f32 -> u32 (larger float <=> larger key). -0.0 is canonicalised to +0.0 so
 // that keys compare equal exactly when the floats do. NaN must be filtered by the caller.

@@ -31,6 +31,7 @@ constexpr int kSortThreads = 1024;
 // phase stamps of the key-list kernels: defined by scripts/micro/keys_reduce_probe.hip (which includes this file), nothing here
 #ifndef ORAMA_KEYS_STAMP
 #define ORAMA_KEYS_STAMP(i) ((void)0)
+#define ORAMA_KEYS_NOTE(i, v) ((void)0)
 #endif
 
 __device__ __forceinline__ unsigned long long make_key(float v, uint32_t idx, bool descending) {
@@ -390,6 +391,24 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(
                  out_n ? out_n + qi : nullptr);
 }
 
+// The per-wave extremes of a workgroup's 16 waves -> the workgroup's, in every lane: lanes 0..15 read one entry each and the
+// wave reduces by shuffles (a loop over the 16 entries had the compiler fetch all of them at once: 64 registers that cost
+// pairs_reduce_kernel its second resident workgroup per CU).
+__device__ __forceinline__ void workgroup_extremes(const unsigned long long* red_max, const unsigned long long* red_min,
+                                                   unsigned long long* mx, unsigned long long* mn) {
+    static_assert(kSortThreads / 64 == 16, "one entry per lane of the first 16");
+    const int lane = threadIdx.x & 63;
+    unsigned long long a = lane < 16 ? red_max[lane] : 0ull, b = lane < 16 ? red_min[lane] : ~0ull;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        const unsigned long long x = __shfl_xor(a, off, 64), y = __shfl_xor(b, off, 64);
+        a = x > a ? x : a;
+        b = y < b ? y : b;
+    }
+    *mx = uniform_u64(a);  // (lane 0 holds the result; scalar registers from here on)
+    *mn = uniform_u64(b);
+}
+
 // ---------------------------------------------------------------- exact cuts without histogram rounds
 // The radix selection below costs up to seven barrier-separated rounds of LDS atomics that pile onto a few bins (the
 // scores of one query share their leading bits): 12-15 us for the 8 192 keys of a chunk that starts without a bound — all
@@ -406,11 +425,12 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(
 //                         LDS reads, no atomics, no barrier).  Keys are unique, so ranks are a permutation: rank r < k IS
 //                         the output position, in key order — the final kernel's records need no sort.  Work grows with
 //                         the square of the count: up to 320 keys (k = 100 leaves ~200).
-//   wave_exact_kth        the exact k-th best of 321..512 survivors (k ~ 256) by ONE wave: binary search on the value word,
-//                         then on the index word among the keys that tie with it — the other waves wait at the barrier.
+//                         (One wave's binary search for the exact k-th key — value word, then index word among its ties —
+//                         was tried in its place: 3.0 us against 1.8 at 200 keys, and its registers cost the reduction
+//                         kernels their second resident workgroup per CU; profiles/r04_keys_topk_phases.log.)
 constexpr uint32_t kWaveBoundMaxK = 256;   // j <= 16 of 64 lane bests per wave
 constexpr uint32_t kRankCountMax = 512;
-constexpr uint32_t kRankCountSmall = 320;  // up to here counting ranks beats one wave's search (1.8 against 3.0 us at 200 keys)
+constexpr uint32_t kRankCountSmall = 320;  // the reduction kernels count ranks up to here (k = 100 leaves ~200), the final kernel up to 512
 
 // the j-th largest of the wave's 64 values (0 when fewer than j of them are non-zero)
 __device__ __forceinline__ uint32_t wave_kth_largest_hi(uint32_t v, uint32_t j) {
@@ -426,16 +446,30 @@ __device__ __forceinline__ uint32_t wave_kth_largest_hi(uint32_t v, uint32_t j) 
 // Workgroup-wide lower bound of the k-th best of the keys the lanes hold (`lane_best` = the best key of this lane), or 1
 // ("every non-empty key") when a wave cannot vouch for its share.  `red` holds one entry per wave; the caller's next
 // barrier-separated use of it must come after a barrier of its own.  Contains one barrier.
+// `n_keys` = how many of the workgroup's threads hold at least one key, or any larger number (keys laid out key i -> thread
+// i % 1024: the key count will do): with fewer than 1 024 only the first n_keys / 64 waves are full — they alone vouch, each
+// for a larger share (a list of 800 keys left the last waves empty and the bound at 0: all 800 went through the histogram
+// rounds).
 __device__ __forceinline__ unsigned long long workgroup_kth_lower_bound(unsigned long long lane_best, uint32_t k,
-                                                                        unsigned long long* red) {
+                                                                        unsigned long long* red, uint32_t n_keys = kKeysChunk) {
     constexpr uint32_t kWaves = kSortThreads / 64;
-    const uint32_t wb = wave_kth_largest_hi((uint32_t)(lane_best >> 32), (k + kWaves - 1u) / kWaves);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wb;
+    const uint32_t vouching = min(kWaves, n_keys / 64u);                   // (uniform)
+    const uint32_t j = vouching ? (k + vouching - 1u) / vouching : 65u;    // each vouching wave's share
+    const uint32_t wave = uniform_u32(threadIdx.x >> 6);  // (scalar: the LDS address below is not kept in a vector register)
+    uint32_t wb = ~0u;                                    // a wave that does not vouch does not lower the bound either
+    if (wave < vouching) wb = j <= 64u ? wave_kth_largest_hi((uint32_t)(lane_best >> 32), j) : 0u;
+    if (!vouching) wb = 0u;
+    if ((threadIdx.x & 63) == 0) red[wave] = wb;
     __syncthreads();
-    unsigned long long b = ~0ull;
+    const int lane = threadIdx.x & 63;
+    uint32_t b = lane < (int)kWaves ? (uint32_t)red[lane] : ~0u;
 #pragma unroll
-    for (uint32_t w = 0; w < kWaves; ++w) b = red[w] < b ? red[w] : b;
-    return b ? b << 32 : 1ull;  // every key whose value word reaches the bound: at least j per wave
+    for (int off = (int)kWaves / 2; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(b, off, 64);
+        b = o < b ? o : b;
+    }
+    b = uniform_u32(b);
+    return b ? (unsigned long long)b << 32 : 1ull;  // every key whose value word reaches the bound: at least j per wave
 }
 
 // The lanes' keys at or above `floor_key` (>= 1: empties never) go to s[cursor ...]: one LDS atomic per wave.
@@ -459,71 +493,6 @@ __device__ __forceinline__ void compact_to_lds(const unsigned long long (&kr)[N]
         if (kr[j] >= floor_key) s[base + (uint32_t)__popcll(m[j] & below)] = kr[j];
         base += (uint32_t)__popcll(m[j]);
     }
-}
-
-// Called by ONE wave (all 64 lanes): s[0 .. cnt) are unique non-empty keys, k <= cnt <= 64 * NT.  Returns the k-th largest:
-// exactly k keys are >= it.  Straight-line code, NT compares per step (a guard per register made every step a chain of
-// taken scalar branches: 5.6 us for 200 keys; registers past cnt hold 0 and never count, every threshold is >= 1).
-template <int NT>
-__device__ __forceinline__ unsigned long long wave_exact_kth_n(const unsigned long long* s, uint32_t cnt, uint32_t k) {
-    const int lane = threadIdx.x & 63;
-    uint32_t hi[NT], lo[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const uint32_t i = (uint32_t)t * 64u + (uint32_t)lane;
-        const unsigned long long key = i < cnt ? s[i] : 0ull;
-        hi[t] = (uint32_t)(key >> 32);
-        lo[t] = (uint32_t)key;
-    }
-    // the k-th largest value word: the largest p with at least k value words >= p
-    uint32_t p = 0;
-#pragma unroll
-    for (int b = 31; b >= 0; --b) {
-        const uint32_t t = p | (1u << b);
-        uint32_t c = 0;
-#pragma unroll
-        for (int u = 0; u < NT; ++u) c += (uint32_t)__popcll(__ballot(hi[u] >= t));
-        p = c >= k ? t : p;
-    }
-    // keys above it are in; of the keys that carry exactly it, the `need` with the largest index words are
-    uint32_t above = 0, ties = 0;
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        above += (uint32_t)__popcll(__ballot(hi[u] > p));
-        const bool tie = hi[u] == p && (hi[u] | lo[u]) != 0u;
-        ties += (uint32_t)__popcll(__ballot(tie));
-        lo[u] = tie ? lo[u] : 0u;  // (the index word of a real key is never 0: ~index, and index 2^32 - 1 is the padding index)
-    }
-    const uint32_t need = k - above;  // 1 <= need <= ties
-    uint32_t q;
-    if (need == ties) {  // (uniform, the usual case) every tying key is taken: the smallest of their index words closes the key
-        q = ~0u;
-#pragma unroll
-        for (int u = 0; u < NT; ++u) q = (lo[u] != 0u && lo[u] < q) ? lo[u] : q;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const uint32_t o = __shfl_xor(q, off, 64);
-            q = o < q ? o : q;
-        }
-    } else {
-        q = 0;
-#pragma unroll
-        for (int b = 31; b >= 0; --b) {
-            const uint32_t t = q | (1u << b);
-            uint32_t c = 0;
-#pragma unroll
-            for (int u = 0; u < NT; ++u) c += (uint32_t)__popcll(__ballot(lo[u] >= t));
-            q = c >= need ? t : q;
-        }
-    }
-    return ((unsigned long long)p << 32) | q;
-}
-
-__device__ __forceinline__ unsigned long long wave_exact_kth(const unsigned long long* s, uint32_t cnt, uint32_t k) {
-    static_assert(kRankCountMax == 512, "register counts below");
-    if (cnt <= 128u) return wave_exact_kth_n<2>(s, cnt, k);
-    if (cnt <= 256u) return wave_exact_kth_n<4>(s, cnt, k);
-    return wave_exact_kth_n<8>(s, cnt, k);
 }
 
 // s[0 .. cnt): unique non-empty keys, cnt <= kRankCountMax.  Returns the number of keys above the key this thread answers
@@ -579,7 +548,7 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
         return;
     }
     const uint32_t n_in = min(kKeysChunk, n_keys - begin);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (int)uniform_u32(threadIdx.x >> 6);
     ORAMA_KEYS_STAMP(0);
     // Stream the chunk through REGISTERS: every lane issues all of its loads first (16 bytes each where the chunk is
     // 16-byte aligned: the whole 64 KB chunk is in flight at once), drops what lies below the running bound, and only the
@@ -617,7 +586,7 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
         unsigned long long best = kr[0];
 #pragma unroll
         for (int j = 1; j < 8; ++j) best = kr[j] > best ? kr[j] : best;
-        floor_key = workgroup_kth_lower_bound(best, k, red_min);
+        floor_key = workgroup_kth_lower_bound(best, k, red_min);  // (a short last chunk leaves waves empty: no bound, the histogram rounds)
     } else {
         __syncthreads();
     }
@@ -632,27 +601,6 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
         if (key && r < k) {
             o[r] = key;  // cnt > k unique keys: every position below k is written
             if (tau && r == k - 1u) atomicMax(tau + (uint64_t)qi * tau_stride, key);
-        }
-        ORAMA_KEYS_STAMP(4);
-        return;
-    }
-    if (cnt > k && cnt <= kRankCountMax) {  // a few hundred: counting grows with the square, one wave's search does not
-        if (wave == 0) {  // the exact k-th best of them, by one wave
-            const unsigned long long t = wave_exact_kth(s, cnt, k);
-            if (lane == 0) {
-                red_max[0] = t;
-                if (tau) atomicMax(tau + (uint64_t)qi * tau_stride, t);
-            }
-        }
-        __syncthreads();
-        const unsigned long long t = red_max[0];
-        if (threadIdx.x < ((cnt + 63u) & ~63u)) {  // (whole waves) exactly k of the cnt keys reach it: every position is written
-            const unsigned long long key = threadIdx.x < cnt ? s[threadIdx.x] : 0ull;
-            const unsigned long long m = __ballot(key >= t);
-            uint32_t base = 0;
-            if (lane == 0 && m) base = atomicAdd(&sel_cnt, (uint32_t)__popcll(m));
-            base = __shfl(base, 0, 64);
-            if (key >= t) o[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
         }
         ORAMA_KEYS_STAMP(4);
         return;
@@ -678,11 +626,7 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
             red_min[wave] = mn;
         }
         __syncthreads();
-        mx = 0ull, mn = ~0ull;
-        for (uint32_t w = 0; w < kSortThreads / 64; ++w) {
-            mx = red_max[w] > mx ? red_max[w] : mx;
-            mn = red_min[w] < mn ? red_min[w] : mn;
-        }
+        workgroup_extremes(red_max, red_min, &mx, &mn);
     }
     __syncthreads();
     unsigned long long thr = 1ull;  // take every non-empty key
@@ -730,10 +674,10 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
                 }
             }
             __syncthreads();
-            prefix |= (unsigned long long)sel_bin << shift;
-            need -= sel_above;
+            prefix |= (unsigned long long)uniform_u32(sel_bin) << shift;
+            need -= uniform_u32(sel_above);
             low = shift;
-            const bool whole = sel_cnt == need;
+            const bool whole = uniform_u32(sel_cnt) == need;
             __syncthreads();  // sel_* are rewritten by the next round
             if (whole || low == 0) break;
         }
@@ -763,17 +707,18 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
 // ---------------------------------------------------------------- (value, index) lists in two launches
 // The candidate lists of the fp16 scans (a few thousand entries per query, length known on the device only) went
 // through the general selection: memset + 6 x (histogram + scan) + collect + sort = 15 launches of 2-15 us with a
-// 6-11 us gap before each (~0.2 ms), 5-8 times per wide batch; this form takes 36 + 39 us.  (Not used for dense lists:
-// 131 072 values x 256 queries take 227 + 82 us here against ~150 us of histogram passes.)  This kernel is
-// keys_reduce_kernel's LDS radix select applied to keys built on the fly from (value, index) pairs: list `qi` is split
-// into gridDim.x contiguous ranges, a workgroup walks its range in rounds of up to 8192 keys, carrying its best k along
-// (the keys of a round sit in registers while the survivors are compacted to the front of the LDS array), and writes
-// its best k; keys_final_kernel then orders gridDim.x * k <= 4096 survivors.  Exact for any list length (a list of
-// millions of entries just takes more rounds).  NaN values become empty keys.
+// 6-11 us gap before each (~0.2 ms), 5-8 times per wide batch; this form took 36 + 39 us in round 2.  This kernel is
+// keys_reduce_kernel's selection applied to keys built on the fly from (value, index) pairs: list `qi` is split
+// into gridDim.x contiguous ranges, a workgroup walks its range in rounds of up to 8192 keys, carrying its best k along,
+// and writes its best k; keys_final_kernel then orders gridDim.x * k <= 4096 survivors.  Exact for any list length (a list
+// of millions of entries just takes more rounds).  NaN values become empty keys.  Round 4: the keys of a round stay in
+// registers, only what reaches the floor (the k-th best so far, or the bound of workgroup_kth_lower_bound) goes to LDS, and
+// the cut is made by counting ranks — which is also what lets the dense heads of the fp16 scans (131 072 values per query:
+// one round for each of 16 workgroups) take this form instead of six histogram passes.
 __device__ unsigned long long lds_keys_threshold(unsigned long long* s, uint32_t cnt, uint32_t k, uint32_t* hist,
                                                  unsigned long long* red_max, unsigned long long* red_min,
                                                  uint32_t* red_nz, uint32_t* sel /* bin, above, cnt */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (int)uniform_u32(threadIdx.x >> 6);
     unsigned long long mx = 0ull, mn = ~0ull;
     uint32_t nz = 0;
     for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
@@ -798,12 +743,11 @@ __device__ unsigned long long lds_keys_threshold(unsigned long long* s, uint32_t
         red_nz[wave] = nz;
     }
     __syncthreads();
-    mx = 0ull, mn = ~0ull, nz = 0;
-    for (uint32_t w = 0; w < kSortThreads / 64; ++w) {
-        mx = red_max[w] > mx ? red_max[w] : mx;
-        mn = red_min[w] < mn ? red_min[w] : mn;
-        nz += red_nz[w];
-    }
+    workgroup_extremes(red_max, red_min, &mx, &mn);
+    nz = lane < 16 ? red_nz[lane] : 0u;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) nz += __shfl_xor(nz, off, 64);
+    nz = uniform_u32(nz);
     if (nz <= k) return 1ull;  // take every non-empty key
     uint32_t low = 64u - (uint32_t)__builtin_clzll(mx ^ mn);  // mx != mn: nz > k >= 1 unique keys
     unsigned long long prefix = low >= 64u ? 0ull : (mx >> low) << low;
@@ -847,78 +791,194 @@ __device__ unsigned long long lds_keys_threshold(unsigned long long* s, uint32_t
             }
         }
         __syncthreads();
-        prefix |= (unsigned long long)sel[0] << shift;
-        need -= sel[1];
+        prefix |= (unsigned long long)uniform_u32(sel[0]) << shift;
+        need -= uniform_u32(sel[1]);
         low = shift;
-        const bool whole = sel[2] == need;
+        const bool whole = uniform_u32(sel[2]) == need;
         __syncthreads();  // sel is rewritten by the next round
         if (whole || low == 0) break;
     }
     return prefix;  // keys >= prefix: exactly k of them (unique keys)
 }
 
-__global__ __launch_bounds__(kSortThreads) void pairs_reduce_kernel(const float* __restrict__ vals,
+// Where a list of ONE round — the workgroup that reduces it has seen all of it — gets its final order right away (ids,
+// (value, id, index) order, padding, count: what keys_final_kernel does), and the word that tells keys_final_kernel so.
+struct PairsFinal {
+    const uint64_t* id_map = nullptr;
+    uint32_t* out_idx = nullptr;
+    uint64_t* out_ids = nullptr;
+    float* out_val = nullptr;
+    uint32_t* out_n = nullptr;
+    uint32_t* done = nullptr;  // one word per list: 1 = the outputs are written (nullptr: never finish here)
+};
+
+// The final order of a list whose best `kept` (<= 1 024: one per thread) keys sit at s[0 .. kept): ids, (value, id, index) order,
+// padding, count — what keys_final_kernel does, in the workgroup that reduced the list.
+__device__ __forceinline__ void finish_whole_list(unsigned long long* s, uint32_t kept, bool in_key_order, uint32_t k, bool descending,
+                                               uint32_t qi, const PairsFinal& fin) {
+    // the final order here, without a second launch: the records alias the key buffer (both 64 KB)
+    static_assert(sizeof(SortLds) <= kKeysChunk * 8, "the records alias the key buffer");
+    const uint32_t i = threadIdx.x;
+    const unsigned long long mine = i < kept ? s[i] : 0ull;
+    __syncthreads();  // every key is in a register: the records may be written
+    SortLds& rec = *reinterpret_cast<SortLds*>(s);
+    const uint32_t p2 = next_pow2(max(kept, 1u));
+    if (i < kept) {
+        const uint32_t ri = ~(uint32_t)mine;
+        rec.hi[i] = (uint32_t)(mine >> 32);
+        rec.idx[i] = ri;
+        rec.id[i] = fin.id_map ? fin.id_map[ri] : (uint64_t)ri;
+    } else if (i < p2) {
+        rec.hi[i] = 0;
+        rec.idx[i] = 0xffffffffu;
+        rec.id[i] = ~0ull;
+    }
+    bool unordered = !in_key_order;
+    if (in_key_order) {  // final order unless two neighbours of equal value carry their ids the other way round
+        __syncthreads();
+        bool swapped = false;
+        for (uint32_t i = threadIdx.x; i + 1 < kept; i += blockDim.x)
+            swapped |= rec.hi[i] == rec.hi[i + 1] && rec.id[i] > rec.id[i + 1];
+        unordered = __syncthreads_or(swapped) != 0;
+    } else {
+        __syncthreads();
+    }
+    if (unordered) lds_bitonic_sort(rec, p2);
+    write_sorted(rec, kept, k, descending, fin.out_idx ? fin.out_idx + (uint64_t)qi * k : nullptr,
+                 fin.out_ids ? fin.out_ids + (uint64_t)qi * k : nullptr, fin.out_val + (uint64_t)qi * k,
+                 fin.out_n ? fin.out_n + qi : nullptr);
+}
+
+template <bool HAS_IDX>
+__global__ __launch_bounds__(kSortThreads, 8) void pairs_reduce_kernel(const float* __restrict__ vals,
                                                                     const uint32_t* __restrict__ idx, uint64_t stride,
                                                                     const uint32_t* __restrict__ n_dev, uint32_t n_max,
                                                                     bool descending, uint32_t k,
-                                                                    unsigned long long* __restrict__ out) {
+                                                                    unsigned long long* __restrict__ out, PairsFinal fin) {
     __shared__ unsigned long long s[kKeysChunk];
     __shared__ uint32_t hist[256];
     __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
     __shared__ uint32_t red_nz[kSortThreads / 64];
-    __shared__ uint32_t sel[3], cursor;
+    __shared__ uint32_t sel[3], cursor, cursor2;  // appended keys of a round / keys kept by its cut
+    __shared__ unsigned long long kth_s;
     const uint32_t qi = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const uint32_t n = n_dev ? min(n_max, n_dev[qi]) : n_max;
-    const uint64_t per = ((uint64_t)n + gridDim.x - 1) / gridDim.x;  // (64-bit: n may be close to 2^32)
-    uint32_t pos = (uint32_t)min((uint64_t)n, blockIdx.x * per);
-    const uint32_t end = (uint32_t)min((uint64_t)n, (uint64_t)pos + per);
-    const float* v = vals + (uint64_t)qi * stride;
-    const uint32_t* ix = idx ? idx + (uint64_t)qi * stride : nullptr;
+    const uint32_t n = uniform_u32(n_dev ? min(n_max, n_dev[qi]) : n_max);  // (scalar registers for everything derived from it)
     unsigned long long* o = out + ((uint64_t)qi * gridDim.x + blockIdx.x) * k;
-    uint32_t kept = 0;
+    uint32_t pos, end;
+    if (n <= kKeysChunk) {
+        // a list of one round (the candidate lists of the fp16 scans hold a few hundred entries; the grid was sized for the
+        // worst case): ONE workgroup takes all of it, the others only write their k empty outputs
+        if (blockIdx.x != 0) {
+            if (!(fin.done && k <= kSortThreads))  // (finished by workgroup 0: the final kernel will not look)
+                for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = 0ull;
+            return;
+        }
+        pos = 0;
+        end = n;
+    } else {
+        const uint64_t per = ((uint64_t)n + gridDim.x - 1) / gridDim.x;  // (64-bit: n may be close to 2^32)
+        pos = (uint32_t)min((uint64_t)n, blockIdx.x * per);
+        end = (uint32_t)min((uint64_t)n, (uint64_t)pos + per);
+    }
+    const float* v = vals + (uint64_t)qi * stride;
+    const uint32_t* ix = HAS_IDX ? idx + (uint64_t)qi * stride : nullptr;
     constexpr uint32_t kPerThread = kKeysChunk / kSortThreads;
+    // Rounds of up to 8 192 values.  The best k so far sit at s[0 .. kept); once a round had to cut, the k-th best key is known
+    // (`kth`) and is the floor of every later round: a value below it never reaches LDS.  A round that starts without a floor
+    // takes a lower bound from the lanes' best keys (workgroup_kth_lower_bound); what survives — a couple of hundred keys — is
+    // cut by counting ranks, as in keys_reduce_kernel; the histogram rounds remain for the rest (k beyond ~150, lists of equal
+    // values).  (One wave's search for 321..512 survivors is left out here: its registers cost this kernel its second
+    // resident workgroup per CU.)
+    uint32_t kept = 0;
+    unsigned long long kth = 0ull;  // (uniform) 0: not known
+    bool in_key_order = true;       // (uniform) s[0 .. kept) is in key order
     for (;;) {
         const uint32_t take = min(kKeysChunk - kept, end - pos);
-        for (uint32_t i = threadIdx.x; i < take; i += blockDim.x) {
-            const float x = v[pos + i];
-            s[kept + i] = x == x ? make_key(x, ix ? ix[pos + i] : pos + i, descending) : 0ull;
-        }
-        const uint32_t cnt = kept + take;
-        pos += take;
-        if (threadIdx.x == 0) cursor = 0;
-        __syncthreads();
-        const unsigned long long thr = lds_keys_threshold(s, cnt, k, hist, red_max, red_min, red_nz, sel);
-        const bool last = pos >= end;
-        // survivors: to the output (last round) or to the front of `s` (the round's keys wait in registers meanwhile)
-        unsigned long long mine[kPerThread];
+        ORAMA_KEYS_STAMP(0);
+        unsigned long long kr[kPerThread];
+        unsigned long long best = 0ull;
 #pragma unroll
         for (uint32_t t = 0; t < kPerThread; ++t) {
             const uint32_t i = t * blockDim.x + threadIdx.x;
-            mine[t] = i < cnt ? s[i] : 0ull;
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t t = 0; t < kPerThread; ++t) {
-            const bool tk = mine[t] >= thr;  // thr >= 1: empties never
-            const unsigned long long m = __ballot(tk);
-            uint32_t base = 0;
-            if (lane == 0 && m) base = atomicAdd(&cursor, (uint32_t)__popcll(m));
-            base = __shfl(base, 0, 64);
-            if (tk) {
-                const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (p < k) {
-                    if (last) o[p] = mine[t];
-                    else s[p] = mine[t];
-                }
+            unsigned long long key = 0ull;
+            if (i < take) {
+                const float x = v[pos + i];
+                if (x == x) key = make_key(x, HAS_IDX ? ix[pos + i] : pos + i, descending);
             }
+            kr[t] = key;
+            best = key > best ? key : best;
         }
+        pos += take;
+        ORAMA_KEYS_STAMP(1);
+        if (threadIdx.x == 0) {
+            cursor = kept;
+            cursor2 = 0;
+        }
+        unsigned long long floor_key = kth > 1ull ? kth : 1ull;
+        if (kth == 0ull && k <= kWaveBoundMaxK && kept + take > kRankCountSmall) floor_key = workgroup_kth_lower_bound(best, k, red_min, take);
+        else __syncthreads();
+        ORAMA_KEYS_STAMP(2);
+        compact_to_lds(kr, floor_key, s, &cursor);  // behind the kept keys
         __syncthreads();
-        kept = min(cursor, k);
-        __syncthreads();  // cursor is reset by the next round
-        if (last) break;
+        const uint32_t cnt = uniform_u32(cursor);
+        ORAMA_KEYS_STAMP(3);
+        if (cnt <= k) {
+            in_key_order = in_key_order && cnt == kept;
+            kept = cnt;  // nothing to cut (the k-th best stays unknown until a round cuts)
+            __syncthreads();  // (the cursor is rewritten by the next round)
+        } else if (cnt <= kRankCountSmall) {
+            unsigned long long key;
+            const uint32_t r = rank_by_counting(s, cnt, &key);
+            __syncthreads();  // every key is in a register
+            if (key && r < k) {
+                s[r] = key;  // in key order
+                if (r == k - 1u) kth_s = key;
+            }
+            __syncthreads();
+            kept = k;
+            kth = uniform_u64(kth_s);
+            in_key_order = true;
+        } else {
+            const unsigned long long thr = lds_keys_threshold(s, cnt, k, hist, red_max, red_min, red_nz, sel);  // (barriers inside)
+            // keep the keys at or above it, in place: the first 1 024 are read before anything is written (what is kept lands
+            // below k <= 4 096... at most `cnt` positions, all of them already read by then); exactly k keys reach thr
+            const int lane = threadIdx.x & 63;
+            unsigned long long key = threadIdx.x < cnt ? s[threadIdx.x] : 0ull;
+            __syncthreads();
+            for (uint32_t i0 = 0; i0 < cnt; i0 += blockDim.x) {
+                if (i0) {
+                    __syncthreads();  // (writes of the previous pass land below the positions read now only if k <= i0: make it so)
+                    key = i0 + threadIdx.x < cnt ? s[i0 + threadIdx.x] : 0ull;
+                    __syncthreads();
+                }
+                const bool tk = key >= thr;  // thr >= 1: empties never
+                const unsigned long long m = __ballot(tk);
+                uint32_t base = 0;
+                if (lane == 0 && m) base = atomicAdd(&cursor2, (uint32_t)__popcll(m));
+                base = __shfl(base, 0, 64);
+                if (tk) s[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+            }
+            __syncthreads();
+            kept = min(uniform_u32(cursor2), k);
+            kth = uniform_u64(thr);
+            in_key_order = false;
+            __syncthreads();
+        }
+        if (pos >= end) break;
     }
-    for (uint32_t i = kept + threadIdx.x; i < k; i += blockDim.x) o[i] = 0ull;
+    ORAMA_KEYS_STAMP(4);
+    if (fin.done && blockIdx.x == 0) {
+        // (uniform) this workgroup has seen the whole list, and its best k are one key per thread
+        const bool whole = n <= kKeysChunk && k <= kSortThreads;
+        if (threadIdx.x == 0) fin.done[qi] = whole ? 1u : 0u;
+        if (whole) {
+            finish_whole_list(s, kept, in_key_order, k, descending, qi, fin);
+            ORAMA_KEYS_STAMP(5);
+            if (threadIdx.x == 0) ORAMA_KEYS_NOTE(6, ((unsigned long long)in_key_order << 32) | kept);
+            return;
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = i < kept ? s[i] : 0ull;
 }
 
 // Final ordering of <= 4096 keys: (value, 64-bit id asc, idx asc), empties (0) dropped.
@@ -928,11 +988,13 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
                                                                   bool descending,
                                                                   const uint64_t* __restrict__ id_map,
                                                                   uint32_t* out_idx, uint64_t* out_ids, float* out_val,
-                                                                  uint32_t* out_n, const uint32_t* __restrict__ n_active = nullptr) {
+                                                                  uint32_t* out_n, const uint32_t* __restrict__ n_active = nullptr,
+                                                                  const uint32_t* __restrict__ done = nullptr) {
     __shared__ SortLds s;
     __shared__ uint32_t valid_s;
     __shared__ uint32_t hist[256];
     if (n_active && blockIdx.x >= *n_active) return;  // (uniform) see keys_reduce_kernel
+    if (done && done[blockIdx.x]) return;              // (uniform) pairs_reduce_kernel has finished this list itself
     __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
     __shared__ uint32_t red_nz[kSortThreads / 64];
     __shared__ uint32_t sel[3], cursor;
@@ -968,7 +1030,7 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
         ORAMA_KEYS_STAMP(1);
         if (threadIdx.x == 0) cursor = 0;
         unsigned long long floor_key = 1ull;
-        if (k <= kWaveBoundMaxK) floor_key = workgroup_kth_lower_bound(best, k, red_min);
+        if (k <= kWaveBoundMaxK) floor_key = workgroup_kth_lower_bound(best, k, red_min, n_keys);
         else __syncthreads();
         ORAMA_KEYS_STAMP(2);
         compact_to_lds(mine, floor_key, kb, &cursor);
@@ -1147,17 +1209,38 @@ int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
     }
     ORAMA_REQUIRE(p.state && p.keys, "top-k: scratch missing");
     const uint64_t expect = p.n_hint ? p.n_hint : p.n;
-    if (p.n_dev && p.keys_capacity >= (uint64_t)p.q * kSelectMaxK && expect <= 16ull * kKeysChunk && select_pairs_enabled()) {
+    if (p.keys_capacity >= (uint64_t)p.q * kSelectMaxK && expect <= 16ull * kKeysChunk && select_pairs_enabled()) {
         // (value, index) lists in two launches: `parts` workgroups per list keep their best k, one orders parts * k keys
-        // (lists expected to be longer than 16 chunks keep the histogram passes, which spread one list over the chip)
+        // (lists expected to be longer than 16 chunks keep the histogram passes, which spread one list over the chip).
+        // Lists of a length known here (the dense heads of the fp16 scans: 131 072 distances per query) take it too since
+        // round 4: 16 workgroups per list, one round each.
         uint32_t parts = kSelectMaxK / p.k;
         parts = std::min<uint32_t>(parts, (uint32_t)std::max<uint64_t>(1, (expect + kKeysChunk - 1) / kKeysChunk));
         parts = std::min<uint32_t>(parts, 16u);
-        hipLaunchKernelGGL(pairs_reduce_kernel, dim3(parts, p.q), dim3(kSortThreads), 0, stream, p.vals, p.idx, p.stride,
-                           p.n_dev, p.n, p.descending, p.k, p.keys);
+        // lists of a known length (dense heads): two resident waves of workgroups (2 per CU) are enough — a workgroup's first
+        // round costs ~10 us (bound, ~2k survivors, their ranks), every later one runs under the floor of the k-th best so
+        // far and costs a third of that: 256 lists x 16 parts of one round each took 108 us, x 4 parts of four rounds take less
+        if (!p.n_dev) parts = std::min<uint32_t>(parts, std::max<uint32_t>(1u, (4u * (uint32_t)ctx->compute_units) / p.q));
+        // a list of one round is finished by the workgroup that reduces it (the candidate lists of the fp16 scans: a few
+        // hundred entries); the final kernel then finds its word set and ends at once.  The words sit in the histogram
+        // state this form does not use.
+        PairsFinal fin;
+        fin.id_map = p.id_map;
+        fin.out_idx = p.out_idx;
+        fin.out_ids = p.out_ids;
+        fin.out_val = p.out_val;
+        fin.out_n = p.out_n;
+        fin.done = reinterpret_cast<uint32_t*>(p.state);
+        static_assert(sizeof(SelectState) >= sizeof(uint32_t), "one word per list");
+        if (p.idx)
+            hipLaunchKernelGGL(pairs_reduce_kernel<true>, dim3(parts, p.q), dim3(kSortThreads), 0, stream, p.vals, p.idx, p.stride,
+                               p.n_dev, p.n, p.descending, p.k, p.keys, fin);
+        else
+            hipLaunchKernelGGL(pairs_reduce_kernel<false>, dim3(parts, p.q), dim3(kSortThreads), 0, stream, p.vals, p.idx, p.stride,
+                               p.n_dev, p.n, p.descending, p.k, p.keys, fin);
         hipLaunchKernelGGL(keys_final_kernel, dim3(p.q), dim3(kSortThreads), 0, stream, p.keys, parts * p.k,
                            (uint64_t)parts * p.k, nullptr, p.k, p.descending, p.id_map, p.out_idx, p.out_ids, p.out_val,
-                           p.out_n);
+                           p.out_n, nullptr, fin.done);
         ORAMA_HIP_TRY(hipGetLastError());
         return ORAMA_OK;
     }

@@ -699,16 +699,22 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
         // select launches.  That paid while a passing row drained its wave's prefetch ring (64 queries with 228
         // candidates each: 5.4 -> 3.2 ms of scan).  Since K2 and K2d stage passing rows in LDS and append them in bulk it
         // costs more than it saves at every batch size measured (two-stage: 100 queries 4.87 -> 3.88 ms without growth,
-        // 128: 4.41 -> 3.94, 200: 6.10 -> 5.67, 64: 3.35 -> 2.97) and is OFF by default.
+        // 128: 4.41 -> 3.94, 200: 6.10 -> 5.67, 64: 3.35 -> 2.97) and was OFF by default through round 3.
         static const int grow_env = [] {
             const char* e = std::getenv("ORAMA_F16_CHUNK_GROW");
             return e ? std::atoi(e) : -1;
         }();
-        static const uint64_t grow_factor = [] {
+        static const uint64_t grow_factor_env = [] {
             const char* e = std::getenv("ORAMA_F16_GROW_FACTOR");
             return e ? (uint64_t)std::max(2, std::atoi(e)) : 2ull;
         }();
-        const bool grow = grow_env > 0;
+        // Round 4: ON for the wide passes (more than 64 queries: K2q / K2d) with factor 8 — there the candidate budget cuts the rest
+        // into ~3 M-row super-chunks anyway, and ONE extra small chunk behind the head (7 x 131 072 rows) hands the first big
+        // one a threshold from 1 M rows instead of 131 072: 2 400 -> ~1 000 candidates per query, C5 shard 4.80 -> 4.69 ms per
+        // step now that a selection costs 45 instead of 75 us.  64 queries (one super-chunk covers the whole rest) lose 5 %
+        // with it (2.51 -> 2.64 ms): off there.
+        const bool grow = grow_env >= 0 ? grow_env > 0 : wide;
+        const uint64_t grow_factor = grow_env > 0 ? grow_factor_env : 8ull;
         uint64_t this_chunk =
             grow ? std::min<uint64_t>(chunk_rows, (grow_factor - 1) * std::max<uint64_t>(s1 & ~255ull, 1u << 17)) : chunk_rows;
         for (uint64_t r0 = s1; r0 < n;) {
@@ -730,7 +736,11 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
             c.stride = cand_stride;
             c.n_dev = cand_count;
             c.n = (uint32_t)cand_stride;
-            c.n_hint = 1u << 16;  // lists hold ~k·ln(N/S1) entries on unordered data; the grid-stride loops cover more
+            // lists hold k + ~k x (rows of the super-chunk / rows before it) entries on unordered data — a few hundred to a
+            // thousand; longer ones (sorted data) just take more rounds.  The hint sizes the grid: two workgroups per list (it
+            // was eight: launching 2 048 workgroups of 16 waves, 7 of 8 with nothing to do, took 60 us by itself —
+            // scripts/micro/keys_reduce_probe.hip)
+            c.n_hint = 2u * kKeysChunk;
             c.q = gq;
             c.k = k;
             c.descending = false;

@@ -11,8 +11,10 @@ __device__ unsigned long long g_stamps[8192 * 8];
         __builtin_amdgcn_s_waitcnt(0);                                                                               \
         if (threadIdx.x == 0) g_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64();           \
     } while (0)
+#define ORAMA_KEYS_NOTE(i, v) (g_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = (v))
 #include "select.hip"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -126,6 +128,79 @@ int main() {
         memcpy(&f, &u, 4);
         printf("   best score of list 0: device %.7g host %.7g\n", val[0], f);
         for (void* b : {(void*)d_keys, (void*)d_tmp, (void*)d_tau, (void*)d_val, (void*)d_ids, (void*)d_n}) (void)hipFree(b);
+    }
+
+    // ---- (value, index) candidate lists as the fp16 filter scans leave them: 100 seeds (the best so far, sorted) + ~700 rows
+    // that beat the worst seed; 256 lists, 8 parts, finished by the reducing workgroup
+    {
+        const uint32_t q = 256, n = 800, stride = 3000000, k = 100;
+        std::mt19937_64 rng(11);
+        std::vector<float> hv((size_t)q * n);
+        std::vector<uint32_t> hi((size_t)q * n), hn(q, n);
+        for (uint32_t l = 0; l < q; ++l) {
+            std::vector<float> seeds(k);
+            for (auto& x : seeds) x = 0.80f + 0.05f * (float)((rng() >> 11) * (1.0 / 9007199254740992.0));
+            std::sort(seeds.begin(), seeds.end());
+            for (uint32_t i = 0; i < n; ++i) {
+                hv[(size_t)l * n + i] = i < k ? seeds[i] : 0.78f + 0.07f * (float)((rng() >> 11) * (1.0 / 9007199254740992.0));
+                hi[(size_t)l * n + i] = (uint32_t)(rng() % 10000000u);
+            }
+        }
+        float* d_v;
+        uint32_t *d_i, *d_n, *d_on, *d_state;
+        unsigned long long* d_keys;
+        uint64_t* d_ids;
+        float* d_val;
+        CK(hipMalloc(&d_v, (size_t)q * stride * 4));
+        CK(hipMalloc(&d_i, (size_t)q * stride * 4));
+        for (uint32_t l = 0; l < q; ++l) {
+            CK(hipMemcpy(d_v + (size_t)l * stride, &hv[(size_t)l * n], n * 4, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_i + (size_t)l * stride, &hi[(size_t)l * n], n * 4, hipMemcpyHostToDevice));
+        }
+        CK(hipMalloc(&d_n, q * 4));
+        CK(hipMemcpy(d_n, hn.data(), q * 4, hipMemcpyHostToDevice));
+        CK(hipMalloc(&d_keys, (size_t)q * 4096 * 8));
+        CK(hipMalloc(&d_ids, q * k * 8));
+        CK(hipMalloc(&d_val, q * k * 4));
+        CK(hipMalloc(&d_on, q * 4));
+        CK(hipMalloc(&d_state, q * 4));
+        PairsFinal fin;
+        fin.out_ids = d_ids;
+        fin.out_val = d_val;
+        fin.out_n = d_on;
+        fin.done = d_state;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        std::vector<unsigned long long> st(8192 * 8), zero(8192 * 8, 0ull);
+        for (uint32_t parts : {8u, 2u})
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero.data(), zero.size() * 8));
+            CK(hipDeviceSynchronize());
+            (void)hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(pairs_reduce_kernel<true>, dim3(parts, q), dim3(kSortThreads), 0, 0, d_v, d_i, (uint64_t)stride, d_n, stride, false, k,
+                               d_keys, fin);
+            (void)hipEventRecord(e1, 0);
+            CK(hipDeviceSynchronize());
+            float ms;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8));
+            if (rep == 2) {
+                double sum[5] = {0};
+                uint32_t ordered = 0;
+                unsigned long long t_first = ~0ull, t_last = 0;
+                for (uint32_t l = 0; l < q; ++l) {
+                    const unsigned long long* s = &st[(size_t)(l * parts) * 8];
+                    for (int i = 0; i < 5; ++i) sum[i] += (double)(s[i + 1] - s[i]);
+                    ordered += (uint32_t)(s[6] >> 32);
+                    t_first = s[0] < t_first ? s[0] : t_first;
+                    t_last = s[5] > t_last ? s[5] : t_last;
+                }
+                printf("pairs_reduce q=%u lists of %u (%u workgroups per list, one of them working; fused final): launch %.1f us by events, first to last stamp of the working groups %.1f us\n"
+                       "   per working workgroup: loads %.2f us, bound %.2f, compaction %.2f, cut %.2f, final order %.2f; %u of %u lists left the cut in key order\n",
+                       q, n, parts, ms * 1e3, (double)(t_last - t_first) * 0.01, sum[0] / q * 0.01, sum[1] / q * 0.01, sum[2] / q * 0.01, sum[3] / q * 0.01,
+                       sum[4] / q * 0.01, ordered, q);
+            }
+        }
     }
     return 0;
 }

@@ -134,6 +134,33 @@ def run_job(group: ShardGroup, shard_ids: list[int], world: int) -> dict:
                 s_ids, s_dist, s_cnt = sess.result(slot)
                 out[f"sess_slot{slot}_ids"], out[f"sess_slot{slot}_dist"], out[f"sess_slot{slot}_cnt"] = s_ids, s_dist, s_cnt
             sess.close()
+            # the same session over stores that also keep an fp16 copy of their rows: every shard takes the two-stage plan in
+            # its device form (candidates from the shadow, decision by the fp32 rows, the fallback decided on the device) and
+            # the exchange sees the same blocks; query 4 is one the shadow cannot serve (a zero vector)
+            sq = np.concatenate([qs[:4], np.zeros((1, VEC_D), dtype=np.float32)])
+            for li in range(nl):
+                group.ctx(li).set_two_stage(True, always=True)
+            shadows = []
+            for li, g in enumerate(shard_ids):
+                st = oa.EmbeddingFieldStorage(group.ctx(li), dimensions=VEC_D, dtype=N.DTYPE_F32_SHADOW16)
+                st.insert_rows(doc_ids[cuts[g]:cuts[g + 1]], rows[cuts[g]:cuts[g + 1]])
+                shadows.append(st)
+            got = {}
+            for tag, ss in (("plain", stores), ("shadow", shadows)):
+                sess = group.session(ss, sq, 1, 20, n_slots=2)
+                for i in range(5):
+                    sess.step(i)
+                    sess.sync()
+                    got[(tag, i)] = sess.result(i % 2)
+                sess.close()
+            for i in range(5):
+                a, b2 = got[("plain", i)], got[("shadow", i)]
+                assert np.array_equal(a[0], b2[0]) and np.array_equal(a[1].view(np.uint32), b2[1].view(np.uint32)) and \
+                    np.array_equal(a[2], b2[2]), ("shadow session differs from the plain one", i)
+                out[f"sess_shadow_q{i}_ids"], out[f"sess_shadow_q{i}_dist"] = b2[0], b2[1]
+            assert all(st.info()["two_stage_queries"] >= 5 for st in shadows)
+            for st in shadows:
+                st.close()
         for r in res:
             r.close()
         for st in stores:
