@@ -861,14 +861,16 @@ __global__ __launch_bounds__(kSortThreads, 8) void pairs_reduce_kernel(const flo
     __shared__ uint32_t red_nz[kSortThreads / 64];
     __shared__ uint32_t sel[3], cursor, cursor2;  // appended keys of a round / keys kept by its cut
     __shared__ unsigned long long kth_s;
-    const uint32_t qi = blockIdx.y;
+    // grid (lists, parts), LIST-fastest: consecutive workgroups go to the 8 XCDs in turn, and of a short list only part 0 works —
+    // part-fastest, with 8 parts, EVERY working workgroup landed on XCD 0 (256 of them on 32 CUs: 66 us instead of 12)
+    const uint32_t qi = blockIdx.x, part = blockIdx.y, parts = gridDim.y;
     const uint32_t n = uniform_u32(n_dev ? min(n_max, n_dev[qi]) : n_max);  // (scalar registers for everything derived from it)
-    unsigned long long* o = out + ((uint64_t)qi * gridDim.x + blockIdx.x) * k;
+    unsigned long long* o = out + ((uint64_t)qi * parts + part) * k;
     uint32_t pos, end;
     if (n <= kKeysChunk) {
         // a list of one round (the candidate lists of the fp16 scans hold a few hundred entries; the grid was sized for the
         // worst case): ONE workgroup takes all of it, the others only write their k empty outputs
-        if (blockIdx.x != 0) {
+        if (part != 0) {
             if (!(fin.done && k <= kSortThreads))  // (finished by workgroup 0: the final kernel will not look)
                 for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = 0ull;
             return;
@@ -876,8 +878,8 @@ __global__ __launch_bounds__(kSortThreads, 8) void pairs_reduce_kernel(const flo
         pos = 0;
         end = n;
     } else {
-        const uint64_t per = ((uint64_t)n + gridDim.x - 1) / gridDim.x;  // (64-bit: n may be close to 2^32)
-        pos = (uint32_t)min((uint64_t)n, blockIdx.x * per);
+        const uint64_t per = ((uint64_t)n + parts - 1) / parts;  // (64-bit: n may be close to 2^32)
+        pos = (uint32_t)min((uint64_t)n, part * per);
         end = (uint32_t)min((uint64_t)n, (uint64_t)pos + per);
     }
     const float* v = vals + (uint64_t)qi * stride;
@@ -967,7 +969,7 @@ __global__ __launch_bounds__(kSortThreads, 8) void pairs_reduce_kernel(const flo
         if (pos >= end) break;
     }
     ORAMA_KEYS_STAMP(4);
-    if (fin.done && blockIdx.x == 0) {
+    if (fin.done && part == 0) {
         // (uniform) this workgroup has seen the whole list, and its best k are one key per thread
         const bool whole = n <= kKeysChunk && k <= kSortThreads;
         if (threadIdx.x == 0) fin.done[qi] = whole ? 1u : 0u;
@@ -1217,9 +1219,9 @@ int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
         uint32_t parts = kSelectMaxK / p.k;
         parts = std::min<uint32_t>(parts, (uint32_t)std::max<uint64_t>(1, (expect + kKeysChunk - 1) / kKeysChunk));
         parts = std::min<uint32_t>(parts, 16u);
-        // lists of a known length (dense heads): two resident waves of workgroups (2 per CU) are enough — a workgroup's first
-        // round costs ~10 us (bound, ~2k survivors, their ranks), every later one runs under the floor of the k-th best so
-        // far and costs a third of that: 256 lists x 16 parts of one round each took 108 us, x 4 parts of four rounds take less
+        // lists of a known length (dense heads): two resident waves of workgroups (2 per CU) — a workgroup's first round costs
+        // ~10 us (bound, ~2k survivors, their ranks), every later one runs under the floor of the k-th best so far: 256 lists
+        // x 16 parts of one round each took 108 us, x 4 parts of four rounds 88-97
         if (!p.n_dev) parts = std::min<uint32_t>(parts, std::max<uint32_t>(1u, (4u * (uint32_t)ctx->compute_units) / p.q));
         // a list of one round is finished by the workgroup that reduces it (the candidate lists of the fp16 scans: a few
         // hundred entries); the final kernel then finds its word set and ends at once.  The words sit in the histogram
@@ -1233,10 +1235,10 @@ int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
         fin.done = reinterpret_cast<uint32_t*>(p.state);
         static_assert(sizeof(SelectState) >= sizeof(uint32_t), "one word per list");
         if (p.idx)
-            hipLaunchKernelGGL(pairs_reduce_kernel<true>, dim3(parts, p.q), dim3(kSortThreads), 0, stream, p.vals, p.idx, p.stride,
+            hipLaunchKernelGGL(pairs_reduce_kernel<true>, dim3(p.q, parts), dim3(kSortThreads), 0, stream, p.vals, p.idx, p.stride,
                                p.n_dev, p.n, p.descending, p.k, p.keys, fin);
         else
-            hipLaunchKernelGGL(pairs_reduce_kernel<false>, dim3(parts, p.q), dim3(kSortThreads), 0, stream, p.vals, p.idx, p.stride,
+            hipLaunchKernelGGL(pairs_reduce_kernel<false>, dim3(p.q, parts), dim3(kSortThreads), 0, stream, p.vals, p.idx, p.stride,
                                p.n_dev, p.n, p.descending, p.k, p.keys, fin);
         hipLaunchKernelGGL(keys_final_kernel, dim3(p.q), dim3(kSortThreads), 0, stream, p.keys, parts * p.k,
                            (uint64_t)parts * p.k, nullptr, p.k, p.descending, p.id_map, p.out_idx, p.out_ids, p.out_val,

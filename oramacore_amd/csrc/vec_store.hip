@@ -737,9 +737,8 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
             c.n_dev = cand_count;
             c.n = (uint32_t)cand_stride;
             // lists hold k + ~k x (rows of the super-chunk / rows before it) entries on unordered data — a few hundred to a
-            // thousand; longer ones (sorted data) just take more rounds.  The hint sizes the grid: two workgroups per list (it
-            // was eight: launching 2 048 workgroups of 16 waves, 7 of 8 with nothing to do, took 60 us by itself —
-            // scripts/micro/keys_reduce_probe.hip)
+            // thousand: ONE workgroup reduces and finishes such a list; longer ones (sorted data) are split over the two the
+            // hint asks for and take more rounds
             c.n_hint = 2u * kKeysChunk;
             c.q = gq;
             c.k = k;

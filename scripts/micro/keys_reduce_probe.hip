@@ -177,7 +177,7 @@ int main() {
             CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero.data(), zero.size() * 8));
             CK(hipDeviceSynchronize());
             (void)hipEventRecord(e0, 0);
-            hipLaunchKernelGGL(pairs_reduce_kernel<true>, dim3(parts, q), dim3(kSortThreads), 0, 0, d_v, d_i, (uint64_t)stride, d_n, stride, false, k,
+            hipLaunchKernelGGL(pairs_reduce_kernel<true>, dim3(q, parts), dim3(kSortThreads), 0, 0, d_v, d_i, (uint64_t)stride, d_n, stride, false, k,
                                d_keys, fin);
             (void)hipEventRecord(e1, 0);
             CK(hipDeviceSynchronize());
@@ -189,7 +189,7 @@ int main() {
                 uint32_t ordered = 0;
                 unsigned long long t_first = ~0ull, t_last = 0;
                 for (uint32_t l = 0; l < q; ++l) {
-                    const unsigned long long* s = &st[(size_t)(l * parts) * 8];
+                    const unsigned long long* s = &st[(size_t)l * 8];  // (grid (lists, parts): workgroup (l, 0))
                     for (int i = 0; i < 5; ++i) sum[i] += (double)(s[i + 1] - s[i]);
                     ordered += (uint32_t)(s[6] >> 32);
                     t_first = s[0] < t_first ? s[0] : t_first;
