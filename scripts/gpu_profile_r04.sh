@@ -7,7 +7,7 @@ R=$PWD
 O=$R/gpurun_out/r04final
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
-echo "== pytest -m gpu"; timeout 2400 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -6 | tee $O/pytest_gpu.log
+echo "== pytest -m gpu"; timeout 2400 python -m pytest tests -q -m gpu -p no:cacheprovider > $O/pytest_gpu_full.log 2>&1; grep -E "passed|failed|error" $O/pytest_gpu_full.log | tail -3 | tee $O/pytest_gpu.log
 echo "== bench (driver command)"; timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_all.json 2> $O/bench_all.err; tail -c 300 $O/bench_all.json; echo
 echo "== bench --force-exchange (the N-rank code path on one rank)"; timeout 300 python bench.py --gpus 1 --force-exchange --steps 20 --warmup 5 --no-cpu-baseline --no-two-stage --configs none --no-pmc > $O/bench_force_exchange.json 2>$O/bench_force_exchange.err; tail -c 200 $O/bench_force_exchange.json; echo
 cd /tmp
