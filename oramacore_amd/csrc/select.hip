@@ -11,6 +11,14 @@
 // Roofline: HBM — each pass streams the value array once (4 B/element); the final sort is
 // LDS-resident.  For the dense single-query vector path this is 4 x N x 4 B on top of the
 // N x D x 4 B corpus pass (0.5 % at D = 768).
+//
+// That multi-pass form serves long dense lists (millions of values).  The lists the hot paths produce take one or two
+// launches of the forms further down, all built on one cut: the candidates of a round stay in registers, a floor (the k-th
+// best so far, a list's shared running bound, or a bound from the lanes' best keys) decides what reaches LDS, and a
+// couple of hundred survivors are cut by counting ranks —
+//   keys_reduce_kernel + keys_final_kernel    lists of 64-bit keys (K1's per-wave lists, K3r's one slot per posting),
+//   pairs_reduce_kernel (+ keys_final_kernel)  (value, index) lists: the candidate lists and the dense heads of the fp16
+//                                              scans; a list of one round is finished by the workgroup that reduces it.
 #include "select.hpp"
 
 #include <algorithm>
@@ -514,10 +522,14 @@ __device__ __forceinline__ uint32_t rank_by_counting(const unsigned long long* s
 
 // ---------------------------------------------------------------- key lists (fused per-wave top-k of K1, K3r)
 // One workgroup per (chunk, list): the best k of up to 8192 u64 keys, as a SET (the final kernel orders the survivors).
-// MSB-first radix select in LDS instead of a sort: the bits above the first one in which the chunk's largest and
-// smallest key differ are skipped (BM25 scores of one query share sign, exponent and often leading mantissa bits),
-// then 8-bit digits: per-digit histogram with LDS atomics, one wave finds the bin that holds the k-th key, everything
-// above it is taken; stops as soon as a bin is taken whole.  Keys are unique (the low word is ~index), 0 = empty.
+// Keys are unique (the low word is ~index), 0 = empty.  The chunk passes through registers; what reaches the floor (the
+// list's running bound, or the bound from the lanes' best keys) goes to LDS; up to 320 survivors are cut by counting ranks
+// (see above).  Beyond that — large k, lists of equal values — an MSB-first radix select in LDS: the bits above the first
+// one in which the survivors' largest and smallest key differ are skipped (BM25 scores of one query share sign, exponent
+// and often leading mantissa bits), then 8-bit digits: per-digit histogram with LDS atomics, one wave finds the bin that
+// holds the k-th key, everything above it is taken; stops as soon as a bin is taken whole.
+// (Walking several chunks per workgroup, carrying the best k from round to round, was measured and dropped: 172 -> 168 K
+// BM25 queries/s — profiles/r04_keys_topk_phases.log (d).)
 __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigned long long* __restrict__ keys,
                                                                    uint32_t n_keys, uint64_t in_stride,
                                                                    const uint32_t* __restrict__ n_per_list,
