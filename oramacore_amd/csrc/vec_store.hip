@@ -620,7 +620,12 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
             if (fw >= 4 && vec_scan_f16_qs_supports(args.dim, args.q)) return launch_vec_scan_f16_qs(v->ctx, args, sc->f16_bfrag.p, s);
             return launch_vec_scan_f16_pc(v->ctx, args, sc->f16_bfrag.p, s, fw == 3 ? 2 : 1);
         };
-        const uint64_t s1 = std::min<uint64_t>(n, kS1);
+        static const uint64_t head_rows = [] {  // ORAMA_F16_HEAD_ROWS: the dense head (sweeps; a multiple of 256)
+            const char* e = std::getenv("ORAMA_F16_HEAD_ROWS");
+            const uint64_t v = e ? std::strtoull(e, nullptr, 10) : 0;
+            return v >= 4096 && v % 256 == 0 ? v : kS1;
+        }();
+        const uint64_t s1 = std::min<uint64_t>(n, head_rows);
         // super-chunk size: gq * (rows + k) * 8 B <= budget
         static const uint64_t budget = [] {
             const char* e = std::getenv("ORAMA_F16_CAND_MIB");
@@ -716,7 +721,7 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
         const bool grow = grow_env >= 0 ? grow_env > 0 : wide;
         const uint64_t grow_factor = grow_env > 0 ? grow_factor_env : 8ull;
         uint64_t this_chunk =
-            grow ? std::min<uint64_t>(chunk_rows, (grow_factor - 1) * std::max<uint64_t>(s1 & ~255ull, 1u << 17)) : chunk_rows;
+            grow ? std::min<uint64_t>(chunk_rows, (grow_factor - 1) * std::max<uint64_t>(s1 & ~255ull, 1u << 12)) : chunk_rows;
         for (uint64_t r0 = s1; r0 < n;) {
             const uint64_t r1 = std::min<uint64_t>(n, r0 + this_chunk);
             ORAMA_TRY(launch_f16_seed_candidates(best_dist, best_row, out_n, gq, k, tau, cand_dist, cand_row,
