@@ -11,6 +11,7 @@
 #include <functional>
 #include <atomic>
 #include <chrono>
+#include <unordered_map>
 #include <cmath>
 #include <deque>
 #include <shared_mutex>
@@ -199,12 +200,30 @@ struct orama_post {
     bool ntf_valid = false;
     bool has_omc = false;
     uint64_t generation = 0;  // bumped by every rebuild of the doc table: facet fields resolved against an older one are stale
+    // corpus_docs.len() of a token that has SEVERAL lists (one per field, prefix / typo expansions) = the number of distinct
+    // documents in the union of those lists (token_score.rs:262-275): a property of the INDEX, not of the query.  The first
+    // query that brings a set of lists has it counted on the device (a second scoring-sized launch and a host round trip in
+    // front of the real one); the count is remembered under the sorted list ids until the postings change.  Unfiltered
+    // searches only (under a filter the count depends on the filter).
+    std::mutex df_union_mu;
+    std::unordered_map<std::string, uint32_t> df_union;
+    static constexpr size_t kDfUnionMax = 1u << 20;  // entries; the map is emptied when it gets there
+    static std::string df_union_key(const uint32_t* lists, uint32_t n) {
+        uint32_t sorted[kRangeMaxRefs];
+        std::copy(lists, lists + n, sorted);
+        std::sort(sorted, sorted + n);
+        return std::string(reinterpret_cast<const char*>(sorted), (size_t)n * 4);
+    }
 };
 
 namespace {
 
 // (Re)compute p->d_post_ntf for the store's current postings and average lengths.  Caller holds p->mu exclusively.
 int refresh_post_ntf(orama_post* p) {
+    {  // (every change of the postings comes through here: what was counted over the old lists is forgotten)
+        std::lock_guard<std::mutex> g(p->df_union_mu);
+        p->df_union.clear();
+    }
     p->ntf_valid = false;
     if (p->n_postings == 0 || p->n_lists == 0) return ORAMA_OK;
     const size_t need = (size_t)p->n_postings * 4;
@@ -778,14 +797,17 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             c.lens[ci] = (uint32_t)pd.total;
             max_ranges = std::max(max_ranges, q.n_ranges);
             uint32_t per_token[kMaxTokens] = {0}, df[kMaxTokens] = {0};
+            uint32_t tok_lists[kRangeMaxRefs], tok_first[kMaxTokens + 1] = {0}, n_tok_lists = 0;  // the lists of every token, in order
             bool df_known = d_allow == nullptr, multi_list = false;
             // references in (token, reference order): the rank of a list among its token's lists is its position
             for (uint32_t t = 0; t < q.n_tokens; ++t) {
+                tok_first[t] = n_tok_lists;
                 for (uint32_t i = 0; i < jb.n_refs; ++i) {
                     if (jb.refs[i].token != t) continue;
                     const uint32_t l = jb.refs[i].list;
                     const uint32_t len = (uint32_t)(p->list_off[l + 1] - p->list_off[l]);
                     if (len == 0) continue;
+                    if (n_tok_lists < kRangeMaxRefs) tok_lists[n_tok_lists++] = l;  // (ranges_eligible: at most kRangeMaxRefs non-empty lists)
                     RangeSeg g{};
                     g.post_begin = p->list_off[l];
                     g.len = len;
@@ -800,6 +822,19 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                     }
                     df[t] += len;
                 }
+            }
+            tok_first[q.n_tokens] = n_tok_lists;
+            if (multi_list && d_allow == nullptr && !jb.df_global && !df_pass) {
+                // tokens with several lists: the size of the union, if an earlier query had it counted
+                std::lock_guard<std::mutex> g(p->df_union_mu);
+                bool all = true;
+                for (uint32_t t = 0; t < q.n_tokens && all; ++t) {
+                    if (per_token[t] < 2) continue;
+                    auto it = p->df_union.find(orama_post::df_union_key(tok_lists + tok_first[t], tok_first[t + 1] - tok_first[t]));
+                    if (it == p->df_union.end()) all = false;
+                    else df[t] = it->second;
+                }
+                df_known = all;
             }
             q.seg_end = (uint32_t)segs.size();
             const uint32_t ns = q.seg_end - q.seg_begin;
@@ -911,10 +946,25 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             ORAMA_HIP_TRY(hipStreamSynchronize(s));
             for (uint32_t ci = 0; ci < nq; ++ci) {
                 if (!queries[ci].want_df) continue;
-                const orama_bm25_params* pr = jobs[c.members[ci].job].params;
+                const RangeJob& jb = jobs[c.members[ci].job];
+                const orama_bm25_params* pr = jb.params;
                 for (uint32_t t = 0; t < queries[ci].n_tokens; ++t) {
                     const float dd = (float)(h_res[ci].df[t] < 1 ? 1u : h_res[ci].df[t]);
                     h_idf[(size_t)ci * kMaxTokens + t] = log1pf((pr->total_documents - dd + 0.5f) / (dd + 0.5f));
+                }
+                if (queries[ci].want_df == 1u && d_allow == nullptr && !h_res[ci].overflow) {
+                    // the unions this query had counted, for the queries to come (orama_post::df_union)
+                    std::lock_guard<std::mutex> g(p->df_union_mu);
+                    if (p->df_union.size() >= orama_post::kDfUnionMax) p->df_union.clear();
+                    for (uint32_t t = 0; t < queries[ci].n_tokens; ++t) {
+                        uint32_t lists[kRangeMaxRefs], nl = 0;
+                        for (uint32_t i = 0; i < jb.n_refs; ++i) {
+                            if (jb.refs[i].token != t) continue;
+                            const uint32_t l = jb.refs[i].list;
+                            if (p->list_off[l + 1] != p->list_off[l] && nl < kRangeMaxRefs) lists[nl++] = l;
+                        }
+                        if (nl >= 2) p->df_union[orama_post::df_union_key(lists, nl)] = h_res[ci].df[t];
+                    }
                 }
             }
             ORAMA_HIP_TRY(hipMemcpyAsync(d_idf, h_idf, idf_bytes, hipMemcpyHostToDevice, s));

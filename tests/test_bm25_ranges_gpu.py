@@ -238,6 +238,65 @@ def test_appended_lists_and_dense_ids(ctx):
     corpus.store.close()
 
 
+def test_unions_of_a_tokens_lists_are_counted_once_per_index(ctx):
+    """A token with several lists (one per field, expansions) needs |union of the lists| as its document frequency: counted on
+    the device by the first query that brings the set (a second scoring-sized launch), remembered under the list ids until
+    the postings change.  Same answers — the oracle's — with and without the remembered counts; a filtered query never uses
+    them (its count depends on the filter); an append forgets them."""
+    rng = np.random.default_rng(77)
+    n0 = 30_000
+    corpus = Corpus(ctx, n0, random_lists(rng, n0, 8, 2, 2000, 9000), [55.0, 9.0], seed=78)
+    refs = [(0, 0, 1.0), (0, 1, 2.0), (1, 2, 1.0), (2, 3, 1.0), (2, 4, 1.5), (2, 5, 1.0)]
+    refs_same_sets = [(0, 1, 1.0), (0, 0, 1.0), (1, 6, 1.0), (2, 5, 1.0), (2, 3, 2.0), (2, 4, 1.0)]  # other order, other boosts
+
+    def df_launches(fn):
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        fn()
+        ctx.prof_enable(False)
+        return ctx.prof_get("bm25_range_df")[1]
+
+    ctx.set_bm25_ranges(True)
+    od, os_, ocount = corpus.oracle(refs, 3, 40)
+    for attempt in range(3):
+        got = {}
+        n_df = df_launches(lambda: got.update(r=corpus.store.search(refs, 3, float(n0), 40)))
+        ids, sc, count = got["r"]
+        assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_)), attempt
+        assert (n_df > 0) == (attempt == 0), (attempt, n_df)  # counted by the first query only
+    od2, os2, oc2 = corpus.oracle(refs_same_sets, 3, 40)
+    got = {}
+    assert df_launches(lambda: got.update(r=corpus.store.search(refs_same_sets, 3, float(n0), 40))) == 0  # the same sets of lists
+    assert got["r"][2] == oc2 and got["r"][0].tolist() == od2.tolist() and np.array_equal(bits(got["r"][1]), bits(os2))
+    # a batch: queries with remembered sets beside one with a new set
+    new_set = [(0, 0, 1.0), (0, 7, 1.0), (1, 2, 1.0)]
+    res = corpus.store.search_batch([(refs, 3, None, 40), (new_set, 2, None, 25), (refs_same_sets, 3, None, 40)], float(n0), 64)
+    for (ids, sc, count), (r, nt, k) in zip(res, ((refs, 3, 40), (new_set, 2, 25), (refs_same_sets, 3, 40))):
+        xd, xs, xc = corpus.oracle(r, nt, k)
+        assert count == xc and ids.tolist() == xd.tolist() and np.array_equal(bits(sc), bits(xs))
+    # under a filter the count is the filter's
+    mask = rng.random(n0) < 0.5
+    bm = oa.AllowBitmap(n0, np.nonzero(mask)[0].astype(np.uint64))
+    fd, fs, fc = corpus.oracle(refs, 3, 40, None, mask)
+    got = {}
+    assert df_launches(lambda: got.update(r=corpus.store.search(refs, 3, float(n0), 40, allow=bm))) > 0
+    assert got["r"][2] == fc and got["r"][0].tolist() == fd.tolist() and np.array_equal(bits(got["r"][1]), bits(fs))
+    # an append changes the lists' neighbours and the averages: nothing remembered survives it
+    n1 = 500
+    new_docs = np.arange(n0, n0 + n1, dtype=np.uint64)
+    local = np.sort(rng.choice(n1, size=300, replace=False)) + n0
+    tf, ln = rng.integers(1, 6, size=len(local)), rng.integers(1, 400, size=len(local))
+    corpus.lists.append((0, local, tf, ln))
+    corpus.doc_ids = np.arange(n0 + n1, dtype=np.uint64)
+    corpus.n_docs = n0 + n1
+    corpus.store.append(new_docs, corpus.avg, [ft.PostingList(field=0, docs=local.astype(np.uint64), tf=tf, field_len=ln)])
+    od3, os3, oc3 = corpus.oracle(refs, 3, 40)
+    got = {}
+    assert df_launches(lambda: got.update(r=corpus.store.search(refs, 3, float(n0 + n1), 40))) > 0
+    assert got["r"][2] == oc3 and got["r"][0].tolist() == od3.tolist() and np.array_equal(bits(got["r"][1]), bits(os3))
+    corpus.store.close()
+
+
 def test_request_batcher_equals_direct_searches(ctx):
     """orama_post_batcher_*: 16 threads of single-query requests (two filters, different k, thresholds) are coalesced
     into batches; every answer equals the direct orama_post_search of the same request and the oracle's."""
