@@ -243,7 +243,11 @@ int orama_vec_get_rows(orama_vec* v, const uint64_t* row_idx, uint64_t n, float*
  * words (uploaded for that call) or the token of a resident bitmap (used in place, no PCIe traffic;
  * `bitmap_bits` must not exceed the bitmap's size).  The shim caches handles per filter hash and flips single bits
  * with orama_allow_set when a document is deleted / re-admitted (under the index's write lock, like the delete
- * itself: a search in flight may see either state).  Destroy only after searches using the token returned. */
+ * itself: a search in flight may see either state).  Destroy only after searches using the token returned.
+ * A postings store remembers the document frequencies it had to COUNT under a resident bitmap (corpus_docs.len() of
+ * collect_contributions_with_filter, token_score.rs:262-275) per set of lists and content of the bitmap: the next query with
+ * the same lists under the same bitmap is scored in one launch, like an unfiltered one (orama_allow_set starts a new
+ * content; host words are never remembered). */
 typedef struct orama_allow orama_allow;
 int orama_allow_create(orama_ctx* ctx, const uint64_t* words, uint64_t bitmap_bits, orama_allow** out);
 void orama_allow_destroy(orama_allow* a);

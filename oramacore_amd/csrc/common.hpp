@@ -269,6 +269,11 @@ struct orama_ctx {
     // of these pointers uses it in place instead of uploading host words
     std::mutex allow_mu;
     std::unordered_map<const void*, uint64_t> allow_reg;
+    // ... and the version of its CONTENT: a number no other content of any resident bitmap of this context ever had (a new one
+    // at creation and after every orama_allow_set).  What was counted under a filter can be remembered under it
+    // (orama_post::df_union).
+    std::unordered_map<const void*, uint64_t> allow_version;
+    uint64_t allow_next_version = 1;
 
     // Borrow a scratch set (creates one when the pool is empty); blocks while max_inflight sets are out.
     int acquire(std::unique_ptr<orama::Scratch>* out, int kind = orama::kScratchGeneral);
@@ -314,8 +319,9 @@ struct ScratchLease {
 
 // The device bitmap a search reads: `allow_bitmap` itself when it is the token of a resident bitmap
 // (orama_allow_token), else a per-call upload of the host words into sc->bitmap on `s`.  nullptr stays nullptr.
+// `*version` (optional): the content version of a resident bitmap, 0 for host words (nobody knows what they hold).
 int resolve_allow(orama_ctx* ctx, Scratch* sc, const uint64_t* allow_bitmap, uint64_t bitmap_bits, hipStream_t s,
-                  const uint64_t** d_allow);
+                  const uint64_t** d_allow, uint64_t* version = nullptr);
 
 inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 }  // namespace orama

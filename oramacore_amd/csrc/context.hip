@@ -219,8 +219,9 @@ void orama_ctx::release(std::unique_ptr<orama::Scratch> s, bool detached) {
 
 namespace orama {
 int resolve_allow(orama_ctx* ctx, Scratch* sc, const uint64_t* allow_bitmap, uint64_t bitmap_bits, hipStream_t s,
-                  const uint64_t** d_allow) {
+                  const uint64_t** d_allow, uint64_t* version) {
     *d_allow = nullptr;
+    if (version) *version = 0;
     if (!allow_bitmap) return ORAMA_OK;
     {
         std::lock_guard<std::mutex> g(ctx->allow_mu);
@@ -229,6 +230,10 @@ int resolve_allow(orama_ctx* ctx, Scratch* sc, const uint64_t* allow_bitmap, uin
             ORAMA_REQUIRE(bitmap_bits <= it->second, "resident bitmap holds %llu bits, %llu requested",
                           (unsigned long long)it->second, (unsigned long long)bitmap_bits);
             *d_allow = allow_bitmap;
+            if (version) {
+                auto v = ctx->allow_version.find(allow_bitmap);
+                *version = v != ctx->allow_version.end() ? v->second : 0;
+            }
             return ORAMA_OK;
         }
     }
@@ -278,6 +283,7 @@ int orama_allow_create(orama_ctx* ctx, const uint64_t* words, uint64_t bitmap_bi
     {
         std::lock_guard<std::mutex> g(ctx->allow_mu);
         ctx->allow_reg[a->words.p] = bitmap_bits;
+        ctx->allow_version[a->words.p] = ctx->allow_next_version++;
     }
     *out = a.release();
     return ORAMA_OK;
@@ -290,6 +296,7 @@ void orama_allow_destroy(orama_allow* a) {
     {
         std::lock_guard<std::mutex> g(a->ctx->allow_mu);
         a->ctx->allow_reg.erase(a->words.p);
+        a->ctx->allow_version.erase(a->words.p);
     }
     delete a;
 }
@@ -318,7 +325,17 @@ int orama_allow_set(orama_allow* a, const uint64_t* doc_ids, uint64_t n, int all
     hipLaunchKernelGGL(allow_set_kernel, dim3(blocks), dim3(256), 0, s, a->words.as<unsigned long long>(),
                        sc->misc0.as<uint64_t>(), n, allowed != 0);
     ORAMA_HIP_TRY(hipGetLastError());
-    ORAMA_HIP_TRY(hipStreamSynchronize(s));
+    {  // a new content: nothing counted under the old one applies (before the bits move AND after: a search that resolved the
+       // bitmap in between remembers its counts under a version nobody will ask for again)
+        std::lock_guard<std::mutex> g(a->ctx->allow_mu);
+        a->ctx->allow_version[a->words.p] = a->ctx->allow_next_version++;
+    }
+    const hipError_t e = hipStreamSynchronize(s);
+    {
+        std::lock_guard<std::mutex> g(a->ctx->allow_mu);
+        a->ctx->allow_version[a->words.p] = a->ctx->allow_next_version++;
+    }
+    ORAMA_HIP_TRY(e);
     return ORAMA_OK;
 }
 

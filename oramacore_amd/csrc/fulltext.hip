@@ -203,16 +203,20 @@ struct orama_post {
     // corpus_docs.len() of a token that has SEVERAL lists (one per field, prefix / typo expansions) = the number of distinct
     // documents in the union of those lists (token_score.rs:262-275): a property of the INDEX, not of the query.  The first
     // query that brings a set of lists has it counted on the device (a second scoring-sized launch and a host round trip in
-    // front of the real one); the count is remembered under the sorted list ids until the postings change.  Unfiltered
-    // searches only (under a filter the count depends on the filter).
+    // front of the real one); the count is remembered under the sorted list ids until the postings change.  Under a filter
+    // the count — of one list or of several — depends on the filter: remembered as well when the filter is a RESIDENT bitmap
+    // (orama_allow_*: the NOT-deleted bitmap every query of an index with pending deletes carries), under the version of its
+    // content (0 = no filter); host words are anybody's guess and nothing is remembered for them.
     std::mutex df_union_mu;
     std::unordered_map<std::string, uint32_t> df_union;
     static constexpr size_t kDfUnionMax = 1u << 20;  // entries; the map is emptied when it gets there
-    static std::string df_union_key(const uint32_t* lists, uint32_t n) {
+    static std::string df_union_key(const uint32_t* lists, uint32_t n, uint64_t filter_version) {
         uint32_t sorted[kRangeMaxRefs];
         std::copy(lists, lists + n, sorted);
         std::sort(sorted, sorted + n);
-        return std::string(reinterpret_cast<const char*>(sorted), (size_t)n * 4);
+        std::string key(reinterpret_cast<const char*>(sorted), (size_t)n * 4);
+        key.append(reinterpret_cast<const char*>(&filter_version), 8);
+        return key;
     }
 };
 
@@ -726,6 +730,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
     struct Chunk {
         Scratch* sc = nullptr;
         const uint64_t* d_allow = nullptr;
+        uint64_t allow_version = 0;  // content version of a resident filter bitmap (0: none, or host words)
         bool allow_resolved = false;
         std::vector<Pending> members;
         std::vector<RangeSeg> segs;
@@ -749,7 +754,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         hipStream_t s = sc->stream;
         c.trace.mark(0);
         if (!c.allow_resolved) {
-            ORAMA_TRY(resolve_allow(p->ctx, sc, allow_bitmap, bitmap_bits, s, &c.d_allow));
+            ORAMA_TRY(resolve_allow(p->ctx, sc, allow_bitmap, bitmap_bits, s, &c.d_allow, &c.allow_version));
             c.allow_resolved = true;
         }
         const uint64_t* d_allow = c.d_allow;
@@ -824,13 +829,15 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                 }
             }
             tok_first[q.n_tokens] = n_tok_lists;
-            if (multi_list && d_allow == nullptr && !jb.df_global && !df_pass) {
-                // tokens with several lists: the size of the union, if an earlier query had it counted
+            const bool filter_known = d_allow != nullptr && c.allow_version != 0;  // a resident bitmap
+            if (((multi_list && d_allow == nullptr) || filter_known) && !jb.df_global && !df_pass) {
+                // what an earlier query had counted: the union of a token's several lists; under a resident filter, every count
                 std::lock_guard<std::mutex> g(p->df_union_mu);
                 bool all = true;
                 for (uint32_t t = 0; t < q.n_tokens && all; ++t) {
-                    if (per_token[t] < 2) continue;
-                    auto it = p->df_union.find(orama_post::df_union_key(tok_lists + tok_first[t], tok_first[t + 1] - tok_first[t]));
+                    if (per_token[t] < (filter_known ? 1u : 2u)) continue;
+                    auto it = p->df_union.find(orama_post::df_union_key(tok_lists + tok_first[t], tok_first[t + 1] - tok_first[t],
+                                                                        filter_known ? c.allow_version : 0));
                     if (it == p->df_union.end()) all = false;
                     else df[t] = it->second;
                 }
@@ -952,8 +959,9 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                     const float dd = (float)(h_res[ci].df[t] < 1 ? 1u : h_res[ci].df[t]);
                     h_idf[(size_t)ci * kMaxTokens + t] = log1pf((pr->total_documents - dd + 0.5f) / (dd + 0.5f));
                 }
-                if (queries[ci].want_df == 1u && d_allow == nullptr && !h_res[ci].overflow) {
-                    // the unions this query had counted, for the queries to come (orama_post::df_union)
+                const bool filter_known = d_allow != nullptr && c.allow_version != 0;
+                if ((d_allow == nullptr || filter_known) && !h_res[ci].overflow) {
+                    // what this query had counted, for the queries to come (orama_post::df_union)
                     std::lock_guard<std::mutex> g(p->df_union_mu);
                     if (p->df_union.size() >= orama_post::kDfUnionMax) p->df_union.clear();
                     for (uint32_t t = 0; t < queries[ci].n_tokens; ++t) {
@@ -963,7 +971,8 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                             const uint32_t l = jb.refs[i].list;
                             if (p->list_off[l + 1] != p->list_off[l] && nl < kRangeMaxRefs) lists[nl++] = l;
                         }
-                        if (nl >= 2) p->df_union[orama_post::df_union_key(lists, nl)] = h_res[ci].df[t];
+                        if (nl >= (filter_known ? 1u : 2u))
+                            p->df_union[orama_post::df_union_key(lists, nl, filter_known ? c.allow_version : 0)] = h_res[ci].df[t];
                     }
                 }
             }

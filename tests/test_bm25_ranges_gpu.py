@@ -281,6 +281,26 @@ def test_unions_of_a_tokens_lists_are_counted_once_per_index(ctx):
     got = {}
     assert df_launches(lambda: got.update(r=corpus.store.search(refs, 3, float(n0), 40, allow=bm))) > 0
     assert got["r"][2] == fc and got["r"][0].tolist() == fd.tolist() and np.array_equal(bits(got["r"][1]), bits(fs))
+    # ... unless the filter is a RESIDENT bitmap (the NOT-deleted bitmap of an index with pending deletes): remembered under
+    # the version of its content — until somebody sets a bit
+    res_bm = bm.to_device(ctx)
+    single = [(0, 0, 1.0), (1, 2, 1.0), (2, 4, 1.0)]  # one list per token: under a filter their counts are the filter's too
+    for r, nt in ((refs, 3), (single, 3)):
+        xd, xs, xc = corpus.oracle(r, nt, 40, None, mask)
+        for attempt in range(2):
+            got = {}
+            n_df = df_launches(lambda: got.update(r=corpus.store.search(r, nt, float(n0), 40, allow=res_bm)))
+            assert got["r"][2] == xc and got["r"][0].tolist() == xd.tolist() and np.array_equal(bits(got["r"][1]), bits(xs)), attempt
+            assert (n_df > 0) == (attempt == 0), (attempt, n_df)
+    gone = np.nonzero(mask)[0][:700].astype(np.uint64)
+    res_bm.set(gone, False)
+    mask2 = mask.copy()
+    mask2[gone.astype(np.int64)] = False
+    xd, xs, xc = corpus.oracle(refs, 3, 40, None, mask2)
+    got = {}
+    assert df_launches(lambda: got.update(r=corpus.store.search(refs, 3, float(n0), 40, allow=res_bm))) > 0  # new content: counted again
+    assert got["r"][2] == xc and got["r"][0].tolist() == xd.tolist() and np.array_equal(bits(got["r"][1]), bits(xs))
+    res_bm.close()
     # an append changes the lists' neighbours and the averages: nothing remembered survives it
     n1 = 500
     new_docs = np.arange(n0, n0 + n1, dtype=np.uint64)
