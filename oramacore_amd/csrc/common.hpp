@@ -319,6 +319,8 @@ struct ScratchLease {
 
 // The device bitmap a search reads: `allow_bitmap` itself when it is the token of a resident bitmap
 // (orama_allow_token), else a per-call upload of the host words into sc->bitmap on `s`.  nullptr stays nullptr.
+// The content version of a resident bitmap (orama_ctx::allow_version); 0 for host words and for nullptr.
+uint64_t allow_content_version(orama_ctx* ctx, const uint64_t* allow_bitmap);
 // `*version` (optional): the content version of a resident bitmap, 0 for host words (nobody knows what they hold).
 int resolve_allow(orama_ctx* ctx, Scratch* sc, const uint64_t* allow_bitmap, uint64_t bitmap_bits, hipStream_t s,
                   const uint64_t** d_allow, uint64_t* version = nullptr);

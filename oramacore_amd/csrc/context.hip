@@ -218,6 +218,13 @@ void orama_ctx::release(std::unique_ptr<orama::Scratch> s, bool detached) {
 }
 
 namespace orama {
+uint64_t allow_content_version(orama_ctx* ctx, const uint64_t* allow_bitmap) {
+    if (!allow_bitmap) return 0;
+    std::lock_guard<std::mutex> g(ctx->allow_mu);
+    auto v = ctx->allow_version.find(allow_bitmap);
+    return v != ctx->allow_version.end() ? v->second : 0;
+}
+
 int resolve_allow(orama_ctx* ctx, Scratch* sc, const uint64_t* allow_bitmap, uint64_t bitmap_bits, hipStream_t s,
                   const uint64_t** d_allow, uint64_t* version) {
     *d_allow = nullptr;

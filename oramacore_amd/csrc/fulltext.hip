@@ -222,6 +222,47 @@ struct orama_post {
 
 namespace {
 
+// orama_post::df_union.  `filtered` with filter_version == 0 (host words): nothing is known, nothing is kept.
+// recall: true when every token of the query that needs a COUNT — several lists, or any list under a filter — has one
+// remembered; df[t] is set for those tokens (the others keep the caller's value: the list length).
+bool df_recall(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, uint32_t n_tokens, bool filtered, uint64_t filter_version,
+               uint32_t* df) {
+    if (filtered && !filter_version) return false;
+    const uint32_t need = filtered ? 1u : 2u;
+    std::lock_guard<std::mutex> g(p->df_union_mu);
+    for (uint32_t t = 0; t < n_tokens; ++t) {
+        uint32_t lists[kRangeMaxRefs], nl = 0;
+        for (uint32_t i = 0; i < n_refs; ++i) {
+            if (refs[i].token != t) continue;
+            const uint32_t l = refs[i].list;
+            if (p->list_off[l + 1] == p->list_off[l]) continue;
+            if (nl == kRangeMaxRefs) return false;
+            lists[nl++] = l;
+        }
+        if (nl < need) continue;
+        auto it = p->df_union.find(orama_post::df_union_key(lists, nl, filtered ? filter_version : 0));
+        if (it == p->df_union.end()) return false;
+        df[t] = it->second;
+    }
+    return true;
+}
+void df_remember(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, uint32_t n_tokens, bool filtered, uint64_t filter_version,
+                 const uint32_t* df) {
+    if (filtered && !filter_version) return;
+    const uint32_t need = filtered ? 1u : 2u;
+    std::lock_guard<std::mutex> g(p->df_union_mu);
+    if (p->df_union.size() >= orama_post::kDfUnionMax) p->df_union.clear();
+    for (uint32_t t = 0; t < n_tokens; ++t) {
+        uint32_t lists[kRangeMaxRefs], nl = 0;
+        for (uint32_t i = 0; i < n_refs; ++i) {
+            if (refs[i].token != t) continue;
+            const uint32_t l = refs[i].list;
+            if (p->list_off[l + 1] != p->list_off[l] && nl < kRangeMaxRefs) lists[nl++] = l;
+        }
+        if (nl >= need) p->df_union[orama_post::df_union_key(lists, nl, filtered ? filter_version : 0)] = df[t];
+    }
+}
+
 // (Re)compute p->d_post_ntf for the store's current postings and average lengths.  Caller holds p->mu exclusively.
 int refresh_post_ntf(orama_post* p) {
     {  // (every change of the postings comes through here: what was counted over the old lists is forgotten)
@@ -716,6 +757,10 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                 jb.df_out[jb.refs[i].token] += len;
             }
             if (!counted || !total) continue;
+            // (counted before, under this filter / for these sets of lists?  then the host has the answer)
+            if (df_recall(p, jb.refs, jb.n_refs, jb.params->n_tokens, allow_bitmap != nullptr, allow_content_version(p->ctx, allow_bitmap),
+                          jb.df_out))
+                continue;
         }
         if (total) pending.push_back({j, 0u, total});
     }
@@ -802,17 +847,14 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             c.lens[ci] = (uint32_t)pd.total;
             max_ranges = std::max(max_ranges, q.n_ranges);
             uint32_t per_token[kMaxTokens] = {0}, df[kMaxTokens] = {0};
-            uint32_t tok_lists[kRangeMaxRefs], tok_first[kMaxTokens + 1] = {0}, n_tok_lists = 0;  // the lists of every token, in order
             bool df_known = d_allow == nullptr, multi_list = false;
             // references in (token, reference order): the rank of a list among its token's lists is its position
             for (uint32_t t = 0; t < q.n_tokens; ++t) {
-                tok_first[t] = n_tok_lists;
                 for (uint32_t i = 0; i < jb.n_refs; ++i) {
                     if (jb.refs[i].token != t) continue;
                     const uint32_t l = jb.refs[i].list;
                     const uint32_t len = (uint32_t)(p->list_off[l + 1] - p->list_off[l]);
                     if (len == 0) continue;
-                    if (n_tok_lists < kRangeMaxRefs) tok_lists[n_tok_lists++] = l;  // (ranges_eligible: at most kRangeMaxRefs non-empty lists)
                     RangeSeg g{};
                     g.post_begin = p->list_off[l];
                     g.len = len;
@@ -828,21 +870,8 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                     df[t] += len;
                 }
             }
-            tok_first[q.n_tokens] = n_tok_lists;
-            const bool filter_known = d_allow != nullptr && c.allow_version != 0;  // a resident bitmap
-            if (((multi_list && d_allow == nullptr) || filter_known) && !jb.df_global && !df_pass) {
-                // what an earlier query had counted: the union of a token's several lists; under a resident filter, every count
-                std::lock_guard<std::mutex> g(p->df_union_mu);
-                bool all = true;
-                for (uint32_t t = 0; t < q.n_tokens && all; ++t) {
-                    if (per_token[t] < (filter_known ? 1u : 2u)) continue;
-                    auto it = p->df_union.find(orama_post::df_union_key(tok_lists + tok_first[t], tok_first[t + 1] - tok_first[t],
-                                                                        filter_known ? c.allow_version : 0));
-                    if (it == p->df_union.end()) all = false;
-                    else df[t] = it->second;
-                }
-                df_known = all;
-            }
+            if ((multi_list || d_allow != nullptr) && !jb.df_global && !df_pass)  // what an earlier query had counted
+                df_known = df_recall(p, jb.refs, jb.n_refs, q.n_tokens, d_allow != nullptr, c.allow_version, df);
             q.seg_end = (uint32_t)segs.size();
             const uint32_t ns = q.seg_end - q.seg_begin;
             bounds_entries += ((uint64_t)q.n_ranges + 1) * ns;
@@ -959,22 +988,8 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                     const float dd = (float)(h_res[ci].df[t] < 1 ? 1u : h_res[ci].df[t]);
                     h_idf[(size_t)ci * kMaxTokens + t] = log1pf((pr->total_documents - dd + 0.5f) / (dd + 0.5f));
                 }
-                const bool filter_known = d_allow != nullptr && c.allow_version != 0;
-                if ((d_allow == nullptr || filter_known) && !h_res[ci].overflow) {
-                    // what this query had counted, for the queries to come (orama_post::df_union)
-                    std::lock_guard<std::mutex> g(p->df_union_mu);
-                    if (p->df_union.size() >= orama_post::kDfUnionMax) p->df_union.clear();
-                    for (uint32_t t = 0; t < queries[ci].n_tokens; ++t) {
-                        uint32_t lists[kRangeMaxRefs], nl = 0;
-                        for (uint32_t i = 0; i < jb.n_refs; ++i) {
-                            if (jb.refs[i].token != t) continue;
-                            const uint32_t l = jb.refs[i].list;
-                            if (p->list_off[l + 1] != p->list_off[l] && nl < kRangeMaxRefs) lists[nl++] = l;
-                        }
-                        if (nl >= (filter_known ? 1u : 2u))
-                            p->df_union[orama_post::df_union_key(lists, nl, filter_known ? c.allow_version : 0)] = h_res[ci].df[t];
-                    }
-                }
+                if (!h_res[ci].overflow)  // what this query had counted, for the queries to come
+                    df_remember(p, jb.refs, jb.n_refs, queries[ci].n_tokens, d_allow != nullptr, c.allow_version, h_res[ci].df);
             }
             ORAMA_HIP_TRY(hipMemcpyAsync(d_idf, h_idf, idf_bytes, hipMemcpyHostToDevice, s));
         }
@@ -1043,6 +1058,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             }
             if (df_pass) {
                 memcpy(jb.df_out, h_res[ci].df, sizeof(uint32_t) * kMaxTokens);
+                df_remember(p, jb.refs, jb.n_refs, jb.params->n_tokens, c.d_allow != nullptr, c.allow_version, h_res[ci].df);
                 continue;
             }
             if (jb.hybrid) {

@@ -32,7 +32,7 @@ def rank_main(rank: int, world: int, uid_hex: str):
     p = ft.PostingsStore(g.ctx(0))
     p.fill_synthetic(per, ranks, seed=0xB25 + rank, first_doc_id=rank * per)
     bm = oa.AllowBitmap.from_mask((np.arange(n) % 7) != 3).to_device(g.ctx(0))
-    for tag, allow in (("unfiltered", None), ("NOT-deleted filter (df counted on every shard)", [bm])):
+    for tag, allow in (("unfiltered", None), ("NOT-deleted filter, resident (df counted on every shard by the warm-up call, remembered since)", [bm])):
         g.post_search_batch([p], qs, float(n), k, allow=allow)
         g.barrier()
         t0 = time.perf_counter()
