@@ -2535,7 +2535,7 @@ int orama_top_n(orama_ctx* ctx, const uint64_t* doc, const float* score, uint64_
     ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, hd, (size_t)n * 8, hipMemcpyHostToDevice, s));
     ORAMA_HIP_TRY(hipMemcpyAsync(sc->dist.p, hs, (size_t)n * 4, hipMemcpyHostToDevice, s));
     ORAMA_TRY(sc->sel_state.reserve(sizeof(SelectState)));
-    ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * top_k));
+    ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * kSelectMaxK));  // (lists of up to 16 chunks: the two-launch form)
     ORAMA_TRY(sc->out_ids.reserve((size_t)top_k * 8));
     ORAMA_TRY(sc->out_val.reserve((size_t)top_k * 4));
     ORAMA_TRY(sc->out_n.reserve(4));
@@ -2545,6 +2545,7 @@ int orama_top_n(orama_ctx* ctx, const uint64_t* doc, const float* score, uint64_
     p.n = (uint32_t)n;
     p.q = 1;
     p.k = top_k;
+    p.keys_capacity = kSelectMaxK;
     p.descending = true;
     p.id_map = sc->misc0.as<uint64_t>();
     p.state = sc->sel_state.as<SelectState>();

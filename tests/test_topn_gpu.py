@@ -23,8 +23,8 @@ def gpu_top_n(ctx, doc, score, k):
     return out_ids[:n.value], out_sc[:n.value]
 
 
-@pytest.mark.parametrize("n", [1, 2, 100, 4096, 4097, 50_000, 1_000_003])
-@pytest.mark.parametrize("k", [1, 10, 100, 1000])
+@pytest.mark.parametrize("n", [1, 2, 100, 4096, 4097, 8192, 8193, 50_000, 131_072, 131_073, 1_000_003])
+@pytest.mark.parametrize("k", [1, 10, 100, 257, 1000, 4096])
 def test_top_n_matches_oracle_bit_exact(ctx, n, k):
     rng = np.random.default_rng(n * 31 + k)
     doc = rng.permutation(n * 3)[:n].astype(np.uint64)
