@@ -192,7 +192,9 @@ struct ScoreRange {
 // per-posting loops are straight-line code — a run-time round count inside one body made the compiler shuffle the whole
 // register arrays at every round's branch (a third of the vector instructions of the first form of this kernel).  Rounds
 // past the end (e >= cap) read the last posting again and are not `kept`.
-template <bool DF_ONLY, bool WIDE, int NITER>
+// PLAIN: a batch without score maps, OMC multipliers and min / max tracking whose store holds the pre-divided tf (every plain
+// top-k search at the default b, filtered or not): those branches — per posting, per round — are not compiled in.
+template <bool DF_ONLY, bool WIDE, int NITER, bool PLAIN = false>
 __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery& q, const ScoreRange& rg, ScoreLds<WIDE>& L) {
     typedef typename MaskOf<WIDE>::type mask_t;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -232,7 +234,7 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
             if (g + j >= NITER) break;
             doc[j] = b.post_doc[pos[j]];
             val[j] = 0u;
-            if (!DF_ONLY) val[j] = b.post_ntf ? __builtin_bit_cast(uint32_t, b.post_ntf[pos[j]]) : b.post_val[pos[j]];
+            if (!DF_ONLY) val[j] = (PLAIN || b.post_ntf) ? __builtin_bit_cast(uint32_t, b.post_ntf[pos[j]]) : b.post_val[pos[j]];
         }
 #pragma unroll
         for (int j = 0; j < G; ++j) {
@@ -251,7 +253,7 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
             } else {
                 if (kept) atomicOr(&bitmap[dl >> 5], 1u << (dl & 31u));
                 if (!DF_ONLY) {
-                    const float pre = b.post_ntf ? __builtin_bit_cast(float, val[j]) : ntf_pre_of(val[j], one_minus_b, b.b, L.seg_avg[run[j]]);
+                    const float pre = (PLAIN || b.post_ntf) ? __builtin_bit_cast(float, val[j]) : ntf_pre_of(val[j], one_minus_b, b.b, L.seg_avg[run[j]]);
                     pv[n] = L.seg_boost[run[j]] * pre;
                 }
             }
@@ -371,12 +373,14 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
         float map_score = 0.0f;
         if (in_map) {
             const uint32_t doc = doc0 + dl;
-            if (q.track_minmax && score == score) {  // hybrid: min / max of the full-text scores (before any OMC)
-                const uint32_t ord = f32_to_ordered(score);
-                my_max = max(my_max, ord);
-                my_min_inv = max(my_min_inv, ~ord);
+            if constexpr (!PLAIN) {
+                if (q.track_minmax && score == score) {  // hybrid: min / max of the full-text scores (before any OMC)
+                    const uint32_t ord = f32_to_ordered(score);
+                    my_max = max(my_max, ord);
+                    my_min_inv = max(my_min_inv, ~ord);
+                }
+                if (b.omc_dense) score = score * b.omc_dense[doc];
             }
-            if (b.omc_dense) score = score * b.omc_dense[doc];
             ++my_count;
             map_doc = doc;
             map_score = score;
@@ -384,7 +388,10 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
                 out_key = ((unsigned long long)f32_to_ordered(score) << 32) | (unsigned long long)(~doc);
         }
         out[e] = out_key;
-        if (b.map_idx) {
+        if constexpr (PLAIN) {
+            (void)map_doc;
+            (void)map_score;
+        } else if (b.map_idx) {
             // score-map mode (a batch of ONE query): slot = position of the entry in the map's candidate list, the
             // per-document table points back at it (ScoreMapDev, facets.hip) — NaN scores included, they count
             const uint32_t pos = rg.slot_base + e;
@@ -398,6 +405,34 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
 
     // ---- 5. a singleton is scored and reported by its posting's lane; a posting of any other document parks its normalised
     // tf in its own cell and leaves its slot empty — except the lender's, which phase 6 writes
+    if constexpr (PLAIN) {
+        // Straight-line form of the loop below for the plain search: every lane evaluates the singleton's fold (the additions
+        // DocFold::add + finish perform for ONE contribution, in their order) and selects; only the rare posting of a document
+        // with several postings branches.  The general loop nests four divergent branches per posting: the scalar unit — exec
+        // masks, branches — was as busy as the vector units (profiles/r04_k3r_sq_counters_v5.md).
+#pragma unroll
+        for (int n = 0; n < NITER; ++n) {
+            const uint32_t e = threadIdx.x + n * kThreads;
+            const uint32_t dl = pk[n] & 0xffffu;
+            const mask_t m = pm[n];
+            const bool single = m != 0 && (m & (m - 1)) == 0;
+            const float sum = 0.0f + 1.0f * pv[n];                                      // Iterator::sum() from 0.0, weight 1.0
+            const float term = L.idf[(pk[n] >> 25) & 63u] * k1 * sum / (q.k + sum);      // bm25f_score, bm25.rs:124-126
+            const bool applied = f32_is_normal(sum) && term == term;
+            const float score = 0.0f + term * 1.0f;                                     // entry(key).or_insert(0.0) += term * boost 1.0
+            const bool in_map = single && applied && !(q.use_threshold && 1u < q.threshold);  // (one token: popcount(mask) = 1)
+            bool lends = false;
+            if (m != 0 && !single) {
+                const uint32_t below = mask_popc((mask_t)(m & (((mask_t)1 << ((pk[n] >> 17) & 63u)) - 1)));
+                lends = below == 0;  // the posting of the document's first reference: it asked for the cells in phase 4
+                cellv[(uint32_t)L.dmask[PRANK(n)] + below] = pv[n];
+            }
+            const uint32_t doc = doc0 + dl;
+            const unsigned long long key = in_map ? ((unsigned long long)f32_to_ordered(score) << 32) | (unsigned long long)(~doc) : 0ull;
+            my_count += in_map ? 1u : 0u;
+            if (e < cap && !lends) out[e] = key;
+        }
+    } else {
 #pragma unroll
     for (int n = 0; n < NITER; ++n) {
         const uint32_t e = threadIdx.x + n * kThreads;
@@ -419,6 +454,7 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
         }
         if (e < cap && !lends) report(e, dl, score, in_map);
     }
+    }
     if (n_cells != 0u) {  // (workgroup-uniform)
         __syncthreads();
         // ---- 6. one lane per multi-posting document: its cells in bit order are its contributions in (token, reference)
@@ -438,9 +474,11 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
     }
 
     if (my_count) atomicAdd(&L.red[1], my_count);
-    if (q.track_minmax) {
-        if (my_max) atomicMax(&L.red[2], my_max);
-        if (my_min_inv) atomicMax(&L.red[3], my_min_inv);
+    if constexpr (!PLAIN) {
+        if (q.track_minmax) {
+            if (my_max) atomicMax(&L.red[2], my_max);
+            if (my_min_inv) atomicMax(&L.red[3], my_min_inv);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -452,7 +490,7 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
 }
 
 // DF_ONLY: the counting pass (corpus_docs.len() per token under a filter / with several lists per token).
-template <bool DF_ONLY, bool WIDE>
+template <bool DF_ONLY, bool WIDE, bool PLAIN = false>
 __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     __shared__ ScoreLds<WIDE> L;
 
@@ -551,14 +589,14 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     // clamped, unkept postings)
     const uint32_t n_iter = (cap + kThreads - 1) / kThreads;
     if (DF_ONLY) {
-        if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4>(b, q, rg, L);
-        else score_body<DF_ONLY, WIDE, 8>(b, q, rg, L);
-    } else if (n_iter <= 2) score_body<DF_ONLY, WIDE, 2>(b, q, rg, L);
-    else if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4>(b, q, rg, L);
-    else if (n_iter == 5) score_body<DF_ONLY, WIDE, 5>(b, q, rg, L);
-    else if (n_iter == 6) score_body<DF_ONLY, WIDE, 6>(b, q, rg, L);
-    else if (n_iter == 7) score_body<DF_ONLY, WIDE, 7>(b, q, rg, L);
-    else score_body<DF_ONLY, WIDE, 8>(b, q, rg, L);
+        if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4, PLAIN>(b, q, rg, L);
+        else score_body<DF_ONLY, WIDE, 8, PLAIN>(b, q, rg, L);
+    } else if (n_iter <= 2) score_body<DF_ONLY, WIDE, 2, PLAIN>(b, q, rg, L);
+    else if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4, PLAIN>(b, q, rg, L);
+    else if (n_iter == 5) score_body<DF_ONLY, WIDE, 5, PLAIN>(b, q, rg, L);
+    else if (n_iter == 6) score_body<DF_ONLY, WIDE, 6, PLAIN>(b, q, rg, L);
+    else if (n_iter == 7) score_body<DF_ONLY, WIDE, 7, PLAIN>(b, q, rg, L);
+    else score_body<DF_ONLY, WIDE, 8, PLAIN>(b, q, rg, L);
 }
 
 // Hybrid path: the full-text score of given documents.  One WAVE per document: lane i looks the document up in the
@@ -677,7 +715,10 @@ int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStr
         if (wide) hipLaunchKernelGGL((range_score_kernel<true, true>), dim3(grid), dim3(kThreads), 0, stream, b);
         else hipLaunchKernelGGL((range_score_kernel<true, false>), dim3(grid), dim3(kThreads), 0, stream, b);
     } else {
+        // (plain: the pre-divided tf at hand, nothing of the batch asks for a score map, OMC multipliers or min / max)
+        const bool plain = !b.map_idx && !b.omc_dense && !b.any_minmax && b.post_ntf;
         if (wide) hipLaunchKernelGGL((range_score_kernel<false, true>), dim3(grid), dim3(kThreads), 0, stream, b);
+        else if (plain) hipLaunchKernelGGL((range_score_kernel<false, false, true>), dim3(grid), dim3(kThreads), 0, stream, b);
         else hipLaunchKernelGGL((range_score_kernel<false, false>), dim3(grid), dim3(kThreads), 0, stream, b);
     }
     ORAMA_HIP_TRY(hipGetLastError());

@@ -84,6 +84,7 @@ struct RangeBatch {
     float* map_score = nullptr;
     unsigned long long* map_emit = nullptr;
     uint32_t map_epoch = 0;
+    uint32_t any_minmax = 0;  // a query of the batch tracks the min / max of its scores (hybrid)
     uint32_t debug = 0;  // comparison build only (ORAMA_K3R_DBG): 1 skip the merge, 2 skip the fold, 4 stop after the bounds loads
 };
 

@@ -928,6 +928,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             ORAMA_SUPPORT(pairs < 0x7fffffffull, "query batch needs too many document ranges");
             rb.range_start[ci + 1] = (uint32_t)pairs;
             rb.max_refs = std::max(rb.max_refs, queries[ci].seg_end - queries[ci].seg_begin);
+            rb.any_minmax |= queries[ci].track_minmax;
         }
         rb.max_bound_entries = max_bound_entries;
         rb.post_doc = p->d_post_doc.as<uint32_t>();
