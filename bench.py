@@ -666,9 +666,9 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
                                                            "range_df": kd_ms * 1e3 / n_dev_q,
                                                            "range_score": ks_ms * 1e3 / n_dev_q,
                                                            "topk_select": kt_ms * 1e3 / n_dev_q},
-                                   "note": "round 4's sort-free scoring launch: 2.8 VALU wave instructions per posting (round 3's merge tree: 8.6), "
-                                           "VALU issue slots 82 % busy — still bound by vector issue, not by HBM (the chain streams 24 B per posting "
-                                           "at ~1 TB/s): profiles/r04_k3r_sq_counters_v4.md, DESIGN K3r"},
+                                   "note": "round 4's sort-free scoring launch: 2.5 VALU + 2.4 scalar wave instructions per posting (round 3's merge "
+                                           "tree: 8.6 VALU), 32 waves per CU — bound by instruction issue, vector and scalar, not by HBM (the chain "
+                                           "streams 24 B per posting at ~1 TB/s): profiles/r04_k3r_sq_counters_v6.md, DESIGN K3r"},
                       "cpu_baseline": cpu_bm25},
         "postings_fill_seconds": t_fill,
         "parity_check": "bit-exact vs oracle (last query): BM25 ids/scores/count, hybrid ids/scores/count",
