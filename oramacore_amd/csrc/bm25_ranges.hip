@@ -31,6 +31,11 @@
 // sorted here: a posting costs one run lookup, two LDS atomics without return, one rank computation and — for the 97 % —
 // one IEEE division.  The normalised tf's query-independent part tf / (1 - b + b len / avglen) is stored per posting by the
 // store (same operations, same bits; recomputed when the average lengths move), which removes two more divisions.
+// The plain top-k search — no score map, OMC multipliers or min / max in the batch — runs an instantiation of its own
+// (PLAIN): none of those branches compiled in, and the singleton's score evaluated by every lane and SELECTED instead of
+// branched to; the general form nests four divergent branches per posting, and the scalar unit (exec masks, branches) was as
+// busy as the vector units.  2.50 vector + 2.41 scalar wave-instructions per posting, 62 registers: eight workgroups per CU,
+// 3.5 us per C4-shaped query (profiles/r04_k3r_sq_counters_v6.md).
 //
 // HBM traffic: 8 B per posting read by the score kernel + 8 B per posting written and read once by the top-k (the
 // bounds searches touch ~17 elements per list and range).
