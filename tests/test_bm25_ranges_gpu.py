@@ -238,6 +238,33 @@ def test_appended_lists_and_dense_ids(ctx):
     corpus.store.close()
 
 
+def test_the_plain_instantiation_equals_the_general_one(ctx):
+    """The scoring launch has an instantiation of its own for batches without score map, OMC multipliers and min / max (singleton
+    scores evaluated by every lane and selected, not branched to).  The same queries through the general form — forced by an OMC
+    table whose only multiplier is 1.0 — must give the same bits: plain, threshold, several lists per token, filtered, k = 1..300."""
+    rng = np.random.default_rng(123)
+    n_docs = 80_000
+    corpus = Corpus(ctx, n_docs, random_lists(rng, n_docs, 10, 2, 3000, 30000), [40.0, 12.0], seed=124)
+    mask = rng.random(n_docs) < 0.7
+    bm = oa.AllowBitmap(n_docs, np.nonzero(mask)[0].astype(np.uint64))
+    ctx.set_bm25_ranges(True)
+    cases = [([(0, 0, 1.0), (1, 1, 1.0), (2, 2, 1.5)], 3, 100, None, None),
+             ([(0, 3, 1.0), (1, 4, 1.0), (2, 5, 1.0), (3, 6, 2.0)], 4, 10, 2, None),
+             ([(0, 0, 1.0), (0, 1, 2.0), (1, 7, 1.0), (1, 8, 1.0), (1, 9, 0.5)], 2, 300, None, None),
+             ([(0, 2, 1.0), (1, 3, 1.0)], 2, 1, None, bm),
+             ([(0, 5, 1.0), (1, 6, 1.0), (2, 7, 1.0)], 3, 64, 3, bm)]
+    plain = [corpus.store.search(r, nt, float(n_docs), k, thr, allow=al, apply_omc=False) for r, nt, k, thr, al in cases]
+    corpus.store.set_omc({int(n_docs - 1): 1.0})  # a multiplier table exists: the general form runs
+    general = [corpus.store.search(r, nt, float(n_docs), k, thr, allow=al, apply_omc=True) for r, nt, k, thr, al in cases]
+    corpus.store.set_omc({})
+    for i, ((pi, ps, pc), (gi, gs, gc)) in enumerate(zip(plain, general)):
+        assert pc == gc and pi.tolist() == gi.tolist() and np.array_equal(bits(ps), bits(gs)), i
+        r, nt, k, thr, al = cases[i]
+        od, os_, ocount = corpus.oracle(r, nt, k, thr, mask if al is not None else None)
+        assert pc == ocount and pi.tolist() == od.tolist() and np.array_equal(bits(ps), bits(os_)), i
+    corpus.store.close()
+
+
 def test_unions_of_a_tokens_lists_are_counted_once_per_index(ctx):
     """A token with several lists (one per field, expansions) needs |union of the lists| as its document frequency: counted on
     the device by the first query that brings the set (a second scoring-sized launch), remembered under the list ids until
