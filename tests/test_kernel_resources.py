@@ -67,3 +67,24 @@ def test_wide_scan_kernels_keep_their_occupancy_plan():
         for k in per_unit.get(unit, []) if unit in COMPARISON_UNITS else per_unit[unit]:
             if "_kernel" in k["name"] and "prep" not in k["name"]:
                 assert k["occupancy_waves_per_simd"] >= floor, (unit, k)
+
+
+def test_register_budgets_that_buy_a_resident_workgroup():
+    """Three kernels owe a resident workgroup per CU to a register count (DESIGN §4 K3r form v6, §4 K4): the plain instantiation of
+    K3r's scoring launch (62 VGPRs: the eighth workgroup of 256 threads beside 19.9 KB of LDS) and the two reduction kernels of the
+    selections (1 024 threads: two workgroups per CU need <= 64).  A change that costs them is a performance regression the
+    parity tests cannot see."""
+    _build.build_native()
+    per_unit = _build.kernel_resources()
+    by_name = {k["name"]: k for unit in ("bm25_ranges", "select") for k in per_unit[unit]}
+
+    def the(fragment):
+        hits = [k for name, k in by_name.items() if fragment in name]
+        assert hits, fragment
+        return hits
+
+    for k in the("range_score_kernelILb0ELb0ELb1E"):
+        assert k["vgprs"] <= 64 and k["lds_bytes_per_block"] * 8 <= 160 * 1024, k
+    for fragment in ("pairs_reduce_kernel", "keys_reduce_kernel", "keys_final_kernel"):
+        for k in the(fragment):
+            assert k["vgprs"] <= 64 and k["lds_bytes_per_block"] * 2 <= 160 * 1024, k
