@@ -29,6 +29,7 @@ from __future__ import annotations
 
 import argparse
 import csv
+import ctypes
 import glob
 import json
 import os
@@ -171,54 +172,96 @@ def cpu_baseline(store, dim: int, n_total: int, k: int, sample_rows: int) -> dic
     }
 
 
-class ClockSampler:
-    """Shader clock and package power of GPU `device` while a leg runs, read straight from sysfs by a side thread (no
-    rocm-smi process: a sample costs microseconds, so even the 90 ms north-star region gets dozens).  Everything is optional:
-    on a box without the files the record says so instead of failing the bench.  VERDICT r03 #7: rocprofv3 sets of the same
-    kernel differed by 5 % between runs — the clock the chip sustained under its power cap is the missing column."""
+class GsSummary(ctypes.Structure):
+    _C = ctypes
+    _fields_ = [("available", _C.c_int), ("samples", _C.c_uint32), ("seconds", _C.c_double),
+                ("gfxclk_mhz_median", _C.c_double), ("gfxclk_mhz_min", _C.c_double), ("gfxclk_mhz_max", _C.c_double),
+                ("xcd_spread_mhz_max", _C.c_double), ("socket_power_w_mean", _C.c_double), ("socket_power_w_max", _C.c_double),
+                ("energy_j", _C.c_double), ("energy_power_w", _C.c_double), ("ppt_residency_pct", _C.c_double),
+                ("thm_residency_pct", _C.c_double), ("gfx_activity_pct_median", _C.c_double), ("xcds_reporting", _C.c_uint32),
+                ("rsmi_index", _C.c_uint32), ("bdfid", _C.c_uint64)]
 
-    def __init__(self, device: int = 0, period_s: float = 0.002):
+
+_SAMPLER_LIB = None
+
+
+def sampler_lib():
+    """scripts/native/libgpu_sampler.so (gpu_sampler.c: a native thread over librocm_smi64's decoded gpu_metrics table), built on
+    first use with gcc when __graft_entry__.build() has not; None when it cannot be had — the record then says so."""
+    global _SAMPLER_LIB
+    if _SAMPLER_LIB is not None:
+        return _SAMPLER_LIB or None
+    src = ROOT / "scripts" / "native" / "gpu_sampler.c"
+    lib = src.with_name("libgpu_sampler.so")
+    try:
+        if not lib.exists() or lib.stat().st_mtime < src.stat().st_mtime:
+            subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-I/opt/rocm/include", str(src), "-o", str(lib), "-L/opt/rocm/lib",
+                            "-lrocm_smi64", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"], check=True, capture_output=True, timeout=120)
+        l = ctypes.CDLL(str(lib))
+        l.gs_last_error.restype = ctypes.c_char_p
+        l.gs_open.argtypes = [ctypes.c_char_p]
+        l.gs_start.argtypes = [ctypes.c_double]
+        l.gs_stop.argtypes = [ctypes.POINTER(GsSummary)]
+        _SAMPLER_LIB = l
+    except (OSError, subprocess.SubprocessError):
+        _SAMPLER_LIB = False
+    return _SAMPLER_LIB or None
+
+
+class ClockSampler:
+    """Shader clock, socket power and throttle residency of the GPU at PCI address `bdf` (orama_ctx_pci_bus_id of the device the
+    leg runs on) while a leg runs.  VERDICT r04 weak #4: round 4 indexed /sys/class/drm/card* by HIP ordinal and read hwmon's
+    slow power1_average from a Python thread — on the driver's box that was another card (97 MHz during a saturated scan).  Now:
+    the device is found by its PCI address, the firmware's gpu_metrics table (per-XCD gfxclk, current socket power, energy and
+    PPT / thermal residency accumulators) is sampled every 2 ms by a native thread (no GIL), and a record whose clock reads
+    under 500 MHz while the GPU was busy is marked unavailable instead of being quoted.  Fallback when librocm_smi64 cannot be
+    used: hwmon under /sys/bus/pci/devices/<bdf>/ (labelled).  Everything is optional: a box without either says so."""
+
+    BUSY_MIN_MHZ = 500.0
+
+    def __init__(self, bdf: str | None, period_s: float = 0.002):
         import threading
 
+        self.bdf = (bdf or "").lower()
         self.period = period_s
-        self.power_file = self.sclk_file = self.freq_file = None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/power1_*"))]
-        if device < len(cards):
-            base = cards[device]
-            for name in ("power1_average", "power1_input"):
+        self.lib = sampler_lib() if self.bdf else None
+        self.native = False
+        self.note = None
+        if self.lib is not None:
+            if self.lib.gs_open(self.bdf.encode()) >= 0:
+                self.native = True
+            else:
+                self.note = "rocm_smi: " + self.lib.gs_last_error().decode()
+        self.power_file = self.freq_file = None
+        if not self.native and self.bdf:
+            base = f"/sys/bus/pci/devices/{self.bdf}"
+            for name in ("power1_input", "power1_average"):
                 hits = glob.glob(os.path.join(base, "hwmon/hwmon*/" + name))
                 if hits:
                     self.power_file = hits[0]
                     break
             hits = glob.glob(os.path.join(base, "hwmon/hwmon*/freq1_input"))
             self.freq_file = hits[0] if hits else None
-            f = os.path.join(base, "pp_dpm_sclk")
-            self.sclk_file = f if os.path.exists(f) else None
         self.samples_w, self.samples_mhz = [], []
         self._stop = threading.Event()
         self._thread = None
+        self._summary = None
 
     def _read(self):
         try:
             if self.power_file:
                 self.samples_w.append(int(open(self.power_file).read().strip()) / 1e6)
-        except (OSError, ValueError):
-            pass
-        try:
             if self.freq_file:
                 self.samples_mhz.append(int(open(self.freq_file).read().strip()) / 1e6)
-            elif self.sclk_file:
-                for line in open(self.sclk_file).read().splitlines():
-                    if line.rstrip().endswith("*"):
-                        self.samples_mhz.append(float(line.split(":")[1].strip().split("M")[0]))
-        except (OSError, ValueError, IndexError):
+        except (OSError, ValueError):
             pass
 
     def __enter__(self):
         import threading
 
-        if self.power_file or self.freq_file or self.sclk_file:
+        if self.native:
+            self.native = self.lib.gs_start(self.period) == 0
+        elif self.power_file or self.freq_file:
             def loop():
                 while not self._stop.is_set():
                     self._read()
@@ -228,20 +271,50 @@ class ClockSampler:
         return self
 
     def __exit__(self, *exc):
+        if self.native:
+            g = GsSummary()
+            self.lib.gs_stop(g)
+            self._summary = g
         self._stop.set()
         if self._thread:
             self._thread.join(timeout=1.0)
 
     def summary(self) -> dict:
+        base = {"pci_bus_id": self.bdf or None}
+        if self.note:
+            base["note"] = self.note
+        g = self._summary
+        if g is not None and g.available:
+            out = dict(base, available=True, samples=int(g.samples), seconds=g.seconds,
+                       source="gpu_metrics table via librocm_smi64, device matched by PCI address, native sampling thread",
+                       sclk_mhz_median=g.gfxclk_mhz_median, sclk_mhz_min=g.gfxclk_mhz_min, sclk_mhz_max=g.gfxclk_mhz_max,
+                       xcds_reporting=int(g.xcds_reporting), xcd_spread_mhz_max=g.xcd_spread_mhz_max,
+                       power_w_mean=g.socket_power_w_mean, power_w_max=g.socket_power_w_max,
+                       energy_j=g.energy_j or None, power_w_from_energy_counter=g.energy_power_w or None,
+                       ppt_throttle_residency_pct=None if g.ppt_residency_pct < 0 else g.ppt_residency_pct,
+                       thermal_throttle_residency_pct=None if g.thm_residency_pct < 0 else g.thm_residency_pct,
+                       gfx_activity_pct_median=None if g.gfx_activity_pct_median < 0 else g.gfx_activity_pct_median)
+            if g.gfxclk_mhz_median < self.BUSY_MIN_MHZ:
+                out.update(available=False, reason=f"median clock {g.gfxclk_mhz_median:.0f} MHz during a busy region: not this GPU's "
+                                                   "clock domain (or the table is stale) — record kept for inspection, not evidence")
+            return out
         if not self.samples_w and not self.samples_mhz:
-            return {"available": False}
-        out = {"available": True, "samples": max(len(self.samples_w), len(self.samples_mhz)), "source": "sysfs hwmon / pp_dpm_sclk"}
+            return dict(base, available=False)
+        out = dict(base, available=True, samples=max(len(self.samples_w), len(self.samples_mhz)),
+                   source=f"hwmon under /sys/bus/pci/devices/{self.bdf}/ ({os.path.basename(self.power_file or '')}, Python thread)")
         if self.samples_mhz:
             out.update(sclk_mhz_median=float(np.median(self.samples_mhz)), sclk_mhz_min=float(np.min(self.samples_mhz)),
                        sclk_mhz_max=float(np.max(self.samples_mhz)))
+            if out["sclk_mhz_median"] < self.BUSY_MIN_MHZ:
+                out.update(available=False, reason="clock under 500 MHz during a busy region")
         if self.samples_w:
             out.update(power_w_mean=float(np.mean(self.samples_w)), power_w_max=float(np.max(self.samples_w)))
         return out
+
+
+def pctl(lat_ms) -> dict:
+    a = np.asarray(lat_ms, dtype=np.float64)
+    return {"latency_ms_p50": float(np.percentile(a, 50)), "latency_ms_p95": float(np.percentile(a, 95)), "latency_samples": int(a.size)}
 
 
 def vec_two_stage_ok(dim: int, k: int) -> bool:
@@ -349,8 +422,20 @@ def check_vector_result(store, ids_all, dst_all, cnt, queries_last, k, qb, lo, h
         assert not missed, f"bench parity check failed: rows {missed[:5]} beat the reported k-th distance"
 
 
+MEDIAN_MIN_LAUNCHES = 50  # the roofline is quoted on the median of >= 50 launches
+
+
+def scan_step_samples(ctx, kern: str, launches_per_step: int) -> np.ndarray:
+    """Scan time per STEP (ms) from the per-launch HIP-event samples: a step of the wide fp16 paths is several launches of
+    different sizes (a dense head + super-chunks), so launches are summed step by step before any statistic is taken."""
+    smp = ctx.prof_samples(kern).astype(np.float64)
+    lps = max(1, launches_per_step)
+    n = (smp.size // lps) * lps
+    return smp[:n].reshape(-1, lps).sum(axis=1) if n else smp[:0]
+
+
 def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=False, rank=0, world=1, lo=0, hi=None,
-               store=None, valid=True, desc=None, dump="", f16_slots=1, device=0):
+               store=None, valid=True, desc=None, dump="", f16_slots=1, bdf=None, latency_steps=50):
     """One vector workload through the pipelined shard session: returns (bench-line dict, store, host queries)."""
     _, dim, k, qb, dtype, wdesc = WORKLOADS[name]
     desc = desc or wdesc
@@ -389,7 +474,7 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
     barrier()
     ctx.prof_reset()
     ctx.prof_enable(True)
-    with ClockSampler(device) as clocks:
+    with ClockSampler(bdf) as clocks:
         t0 = time.perf_counter()
         for i in range(warmup, total_b):
             sess.step(i)
@@ -425,12 +510,56 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
                      "then waits for the other slot's scan inside its event pair)")
     scan_ms, scan_n = ctx.prof_get(kern)
     sel_ms, _ = ctx.prof_get("topk_select")
+    ag_ms, ag_n = ctx.prof_get("shard_all_gather")
+    mg_ms, mg_n = ctx.prof_get("shard_merge")
     kpad = (dim + 127) // 128 * 128
     bytes_per_step = n_local * (kpad * 2 if f16 else dim * 4)  # one corpus pass per step
     launches_per_step = max(scan_n, 1) / prof_steps
     alg_bytes = bytes_per_step / launches_per_step
     avg_scan_s = scan_ms / max(scan_n, 1) / 1e3
-    achieved = alg_bytes / avg_scan_s / 1e9 if scan_n else 0.0
+    achieved_avg = alg_bytes / avg_scan_s / 1e9 if scan_n else 0.0
+
+    # ---- the figure the roofline is quoted on: MEDIAN scan time per step over >= 50 steps.  The driver's run times
+    # 20 steps: the timed region's samples are kept and the same pipelined session simply keeps stepping (profiler on, clocks
+    # sampled again) until there are enough.  These steps are not part of `value`.
+    lps_int = int(round(launches_per_step))
+    uniform = scan_n > 0 and abs(launches_per_step - lps_int) < 1e-9
+    extra = 0
+    clocks_median = None
+    if uniform:
+        have = scan_step_samples(ctx, kern, lps_int).size
+        extra = max(0, MEDIAN_MIN_LAUNCHES - have)
+        if extra:
+            ctx.prof_enable(True)
+            with ClockSampler(bdf) as clocks2:
+                for i in range(extra):
+                    sess.step(i % total_b)
+                sess.sync()
+            ctx.prof_enable(False)
+            clocks_median = clocks2.summary()
+        per_step = scan_step_samples(ctx, kern, lps_int)
+        med_step_ms = float(np.median(per_step))
+        achieved = bytes_per_step / (med_step_ms / 1e3) / 1e9
+        median_rec = {"median_scan_ms_per_step": med_step_ms, "median_launch_ms": med_step_ms / lps_int,
+                      "steps_in_median": int(per_step.size), "of_which_behind_the_timed_region": int(extra),
+                      "p05_scan_ms_per_step": float(np.percentile(per_step, 5)), "p95_scan_ms_per_step": float(np.percentile(per_step, 95)),
+                      "min_scan_ms_per_step": float(per_step.min())}
+    else:
+        achieved, median_rec = achieved_avg, {"median_scan_ms_per_step": None, "note": "launch count per step not constant: average used"}
+
+    # ---- per-step latency (BASELINE.json's metric names p50): ONE step in flight, queries resident in HBM, the clock stops when
+    # the step's answer (after all-gather + K6 for N > 1) is complete on this rank; the slowest rank's time per step, then
+    # percentiles.  The host-buffer API (adds PCIe both ways) is `latency_ms_p50_host_api`, N = 1 only.
+    group.barrier()
+    lat = []
+    for i in range(max(5, latency_steps)):
+        t1 = time.perf_counter()
+        sess.step(i % total_b)
+        sess.sync()
+        dt = (time.perf_counter() - t1) * 1e3
+        lat.append(group.allreduce_max(dt) if world > 1 else dt)
+    lat = lat[min(3, len(lat) - 1):]  # the first steps re-warm a drained pipeline
+
     out = {
         "metric": f"queries/sec, cosine top-{k} scan ({n_total // 1_000_000}M x {dim} {dtype}) — HBM GB/s vs peak in "
                   "`roofline`",
@@ -440,6 +569,9 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
         "steps": steps,
         "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3,
+        **pctl(lat),
+        "latency_definition": "one step in flight through the session (queries resident in HBM, answer complete on the rank incl. "
+                              "all-gather + merge for N > 1), slowest rank per step; p50 / p95 over the samples",
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -452,12 +584,24 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": (("vec_scan_f16_qs_kernel" if qb > 128 and dim <= 768 else "vec_scan_f16_pc_kernel") if f16 and qb > 64 else kern + "_kernel"),
-                     "alg_bytes_per_launch": alg_bytes,
+                     "achieved_from": f"median scan time per step over {median_rec.get('steps_in_median')} steps (HIP events on the "
+                                      "launching stream)" if uniform else "average launch",
+                     "alg_bytes_per_launch": alg_bytes, "alg_bytes_per_step": bytes_per_step,
+                     **median_rec,
                      "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_n,
+                     "achieved_from_avg_of_timed_region": achieved_avg, "frac_from_avg_of_timed_region": achieved_avg / HBM_PEAK_GBS,
                      "scan_launches_per_step": launches_per_step,
                      "topk_select_ms_per_step": sel_ms / prof_steps,
                      "kernel_durations_from": prof_note,
-                     "clocks_during_timed_region": clocks.summary()},
+                     "clocks_during_timed_region": clocks.summary(),
+                     "clocks_during_median_steps": clocks_median},
+        "step_breakdown_us": {"scan": scan_ms / prof_steps * 1e3, "select": sel_ms / prof_steps * 1e3,
+                              "all_gather": (ag_ms / ag_n * 1e3) if ag_n else None,
+                              "merge_k6": (mg_ms / mg_n * 1e3) if mg_n else None,
+                              "step_wall": elapsed / steps * 1e3,
+                              "note": "HIP-event spans on this rank over the timed region; the select and exchange spans run on "
+                                      "tail streams beside the next step's scan, so they do not add up to step_wall; all_gather "
+                                      "includes the wait for the slowest peer's block"},
         "parity_check": "last step vs oracle: distances recomputed from the rows (<= 1e-4), no better row among 20 000 "
                         "sampled rows of the shard",
         "fill_seconds": t_fill,
@@ -481,7 +625,7 @@ def host_api_latency(store, queries_h, qb, k, n=50) -> dict:
 
 
 # ---------------------------------------------------------------------------------------------- C4: hybrid
-def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, shadow=None) -> dict:
+def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, shadow=None, bdf=None) -> dict:
     """BASELINE configs[3]: 10 M-doc BM25F (12-token queries) + the 10 M x 768 fp32 scan, min-max merge, top-100.
     `vec` is the north-star store (same rows), `shadow` the same rows with an fp16 copy (the vector leg takes the
     two-stage plan there; answers must be identical).  Synthetic postings per SURVEY §8d, generated in HBM."""
@@ -509,12 +653,15 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
     for i in range(warmup):
         calls[i].run()
     ctx.synchronize()
-    plain_results = []
-    t0 = time.perf_counter()
-    for i in range(warmup, total):
-        plain_results.append(calls[i].run())
-    ctx.synchronize()
-    el_h = time.perf_counter() - t0
+    plain_results, lat_h = [], []
+    with ClockSampler(bdf) as clocks:
+        t0 = time.perf_counter()
+        for i in range(warmup, total):
+            t1 = time.perf_counter()
+            plain_results.append(calls[i].run())  # one blocking call per query: its duration IS the request's latency
+            lat_h.append((time.perf_counter() - t1) * 1e3)
+        ctx.synchronize()
+        el_h = time.perf_counter() - t0
     h_ids, h_sc, h_count = plain_results[-1]  # (checked against the oracle below)
     ctx.prof_reset()
     ctx.prof_enable(True)
@@ -531,13 +678,17 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
             s_calls[i].run()
         ctx.synchronize()
         t0 = time.perf_counter()
-        s_results = [s_calls[i].run() for i in range(warmup, total)]
+        s_results, lat_s = [], []
+        for i in range(warmup, total):
+            t1 = time.perf_counter()
+            s_results.append(s_calls[i].run())
+            lat_s.append((time.perf_counter() - t1) * 1e3)
         ctx.synchronize()
         el_s = time.perf_counter() - t0
         same = all(a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
                    for a, b in zip(plain_results, s_results))
         assert same, "hybrid answers on the shadow store differ from the plain store's"
-        shadow_out = {"value": steps / el_s, "unit": "queries/s", "ms_per_step": el_s / steps * 1e3,
+        shadow_out = {"value": steps / el_s, "unit": "queries/s", "ms_per_step": el_s / steps * 1e3, **pctl(lat_s),
                       "identical_to_plain_store": same,
                       "note": "same call on the store with an fp16 shadow: the vector leg is the two-stage plan"}
 
@@ -639,6 +790,9 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
     return {
         "metric": "queries/sec, hybrid search: 10M-doc BM25F (12 tokens) + 10M x 768 fp32 cosine scan, min-max merge, top-100",
         "value": steps / el_h, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": el_h / steps * 1e3,
+        **pctl(lat_h),
+        "latency_definition": "wall time of one blocking orama_hybrid_search call (query upload, both legs, merge, result in host "
+                              "memory)",
         "dtype": "f32",
         "config": {"workload": "Hybrid: 10M docs BM25 (12 terms/query) + 10M x 768 vector, min-max merge (BASELINE configs[3])",
                    "docs": n, "dim": dim, "k": k, "tokens_per_query": T, "posting_lists": int(len(ranks)),
@@ -647,6 +801,7 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "vec_scan_f32_kernel",
                      "alg_bytes_per_launch": alg_vec, "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_n,
+                     "clocks_during_timed_region": clocks.summary(),
                      "note": "a hybrid query = the fp32 scan (dominant) + the full-text leg on a second stream"},
         "full_text_leg": ("range scorer (K3r) beside the scan + candidate tail after it" if k3_launches == 0 else
                           f"per-record scorer (K3) used by {k3_launches} launches"),
@@ -711,8 +866,9 @@ def measure_traffic(args, kernel_substr: str, alg_bytes: float) -> dict | None:
     if args.no_pmc or being_profiled() or not exe:
         return None
     med = {}
+    clock = None
     with tempfile.TemporaryDirectory(prefix="orama_pmc_") as tmp:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE"):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, str(Path(__file__).resolve()), "--pmc-child", "--workload", args.workload]
@@ -722,12 +878,26 @@ def measure_traffic(args, kernel_substr: str, alg_bytes: float) -> dict | None:
                 r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), capture_output=True, text=True, timeout=300)
             except subprocess.TimeoutExpired:
                 return None
-            vals = []
+            vals, per_ns = [], []
             for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(path, newline="") as f:
                     for row in csv.DictReader(f):
                         if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
                             vals.append(float(row["Counter_Value"]))
+                            try:
+                                ns = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+                                if ns > 0:
+                                    per_ns.append(float(row["Counter_Value"]) / ns)
+                            except (KeyError, ValueError):
+                                pass
+            if counter == "GRBM_GUI_ACTIVE":  # optional: the traffic stands without it
+                if r.returncode == 0 and per_ns:
+                    # the counter is summed over the 8 XCDs; busy cycles / wall = the clock the kernel ran at (MI355X_MICROARCH.md,
+                    # "DVFS give-back") — of the PROFILED pass, which runs 2-4 % slower than the un-profiled timed region
+                    clock = {"effective_gfxclk_mhz": statistics.median(per_ns) / 8 * 1e3, "launches": len(per_ns),
+                             "source": "rocprofv3 --pmc GRBM_GUI_ACTIVE pass of `bench.py --pmc-child`: counter / 8 XCDs / kernel wall "
+                                       "time, median over the launches (a profiled pass)"}
+                continue
             if r.returncode != 0 or not vals:
                 return None
             med[counter] = statistics.median(vals)
@@ -735,7 +905,8 @@ def measure_traffic(args, kernel_substr: str, alg_bytes: float) -> dict | None:
     return {"traffic": read_b + write_b, "traffic_unit": "bytes/launch",
             "traffic_source": "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate, kernel "
                               "trace only) of `bench.py --pmc-child`; KiB units, FETCH_SIZE x2 per MI355X_MICROARCH.md",
-            "traffic_over_algorithmic": (read_b + write_b) / alg_bytes}
+            "traffic_over_algorithmic": (read_b + write_b) / alg_bytes,
+            "effective_clock_profiled_pass": clock}
 
 
 def committed_traffic(workload: str) -> dict | None:
@@ -798,6 +969,10 @@ def main():
     if group.world != world or any(e["device"] < 0 for e in ranks_seen):
         raise SystemExit(f"bench.py: communicator reports world {group.world}, ranks {ranks_seen} — expected {world} ranks")
 
+    try:
+        bdf = ctx.pci_bus_id()
+    except Exception:  # noqa: BLE001 — the sampler is optional
+        bdf = None
     n_total, dim, k, qb, dtype, desc = WORKLOADS[args.workload]
     if args.rows:
         n_total = args.rows
@@ -805,7 +980,7 @@ def main():
     f16 = dtype == "f16"
     out, store, queries_h = vector_leg(oa, group, args.workload, n_total, args.steps, args.warmup, args.streams,
                                        force_exchange=args.force_exchange, rank=rank, world=world, lo=lo, hi=hi,
-                                       valid=not bool(args.rows), dump=args.dump_result, f16_slots=args.f16_slots, device=device)
+                                       valid=not bool(args.rows), dump=args.dump_result, f16_slots=args.f16_slots, bdf=bdf)
     out["config"]["ranks_seen"] = ranks_seen
     out["config"]["comm_world"] = group.world
     out["config"]["exchange"] = ("rccl" + (" (ORAMA_RCCL_LIB loopback: " + os.path.basename(os.environ["ORAMA_RCCL_LIB"]) + ")"
@@ -829,24 +1004,26 @@ def main():
         if args.workload == "ns" and not args.rows:
             if "c4" in want:  # shares the north-star rows
                 configs["c4"] = hybrid_leg(oa, ctx, store, n_total, dim, k, steps=max(10, min(args.steps, 40)), warmup=3,
-                                           shadow=shadow)
+                                           shadow=shadow, bdf=bdf)
         if shadow is not None:
             out["two_stage_exact"] = two_stage_leg(oa, ctx, store, shadow, dim, k, qb, queries_h, group=group)
         store.close()
         store = None
         if args.workload == "ns" and not args.rows:
             if "c2" in want:
-                configs["c2"], st, _ = vector_leg(oa, group, "c2", WORKLOADS["c2"][0], 200, 10, args.streams)
+                configs["c2"], st, qh2 = vector_leg(oa, group, "c2", WORKLOADS["c2"][0], 200, 10, args.streams, bdf=bdf)
+                configs["c2"].update(host_api_latency(st, qh2, 1, k))
                 st.close()
             st16 = None
             if "c3" in want:
-                configs["c3"], st16, qh = vector_leg(oa, group, "c3", WORKLOADS["c3"][0], 30, 3, 1, f16_slots=args.f16_slots)
+                configs["c3"], st16, qh = vector_leg(oa, group, "c3", WORKLOADS["c3"][0], 30, 3, 1, f16_slots=args.f16_slots, bdf=bdf,
+                                                         latency_steps=30)
                 configs["c3"].update(host_api_latency(st16, qh, 64, k, n=10))
             if "c5_shard" in want:
                 # the per-GPU shard of BASELINE configs[4]: 10 M of the 80 M x 768 fp16 rows, all 256 queries of a batch
                 # (the rows are the ones C3 scans: the same store serves both legs)
                 configs["c5_shard"], st16, _ = vector_leg(
-                    oa, group, "c5", 10_000_000, 20, 3, 1, store=st16, f16_slots=args.f16_slots,
+                    oa, group, "c5", 10_000_000, 20, 3, 1, store=st16, f16_slots=args.f16_slots, bdf=bdf, latency_steps=30,
                     desc="per-GPU shard (10M rows) of: " + WORKLOADS["c5"][5])
                 configs["c5_shard"]["config"]["note"] = ("one of the eight 10 M-row shards of configs[4] on one GPU; the 8-GPU "
                                                          "job adds one 307 KB all-gather + merge per batch")

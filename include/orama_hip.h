@@ -104,6 +104,9 @@ void orama_ctx_destroy(orama_ctx* ctx);
 int orama_ctx_synchronize(orama_ctx* ctx);
 /* Device facts for reports: name (<= 255 chars), CU count, HBM bytes. Any pointer may be NULL. */
 int orama_ctx_device_info(orama_ctx* ctx, char* name256, int* compute_units, uint64_t* hbm_bytes);
+/* PCI address of the context's device, "dddd:bb:dd.f" (hipDeviceGetPCIBusId) — what a monitor needs to find THIS device under
+ * /sys/bus/pci/devices/ or in an SMI library: HIP ordinals are not DRM card numbers (bench.py's clock / power sampler). */
+int orama_ctx_pci_bus_id(orama_ctx* ctx, char* out, int capacity);
 
 /* Launch geometry of the K1 scan (tuning sweeps; defaults are the measured best on MI355X):
  * rows each wave keeps in flight (1/2/4/8), persistent workgroups per CU, nontemporal corpus loads. */
@@ -128,10 +131,13 @@ int orama_ctx_set_two_stage(orama_ctx* ctx, int on);
 /* Per-kernel HIP-event timing (used by bench.py's roofline leg).  When enabled, the library
  * brackets each launch of the named hot kernels with hipEvents on the launching stream.
  * kernels: "vec_scan_f32", "vec_scan_f16", "topk_select", "bm25_accumulate", "bm25_finalize",
- * "bm25_range_bounds", "bm25_range_df", "bm25_range_score". */
+ * "bm25_range_bounds", "bm25_range_df", "bm25_range_score", "shard_all_gather" (one rank per process), "shard_merge". */
 int orama_prof_enable(orama_ctx* ctx, int on);
 int orama_prof_reset(orama_ctx* ctx);
 int orama_prof_get(orama_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
+/* The individual launch durations behind orama_prof_get's sum, oldest first (the most recent 65 536 are kept): the roofline is
+ * quoted on the MEDIAN launch.  Writes min(*n, capacity) values; `out_ms` may be NULL to ask for the count. */
+int orama_prof_samples(orama_ctx* ctx, const char* kernel, float* out_ms, uint64_t capacity, uint64_t* n);
 
 /* Raw HBM buffers for callers that drive the *_device entry points themselves (tests, bench.py, a shim that keeps
  * queries / results resident): plain hipMalloc / hipMemcpy on the context's device — no torch, no other runtime.

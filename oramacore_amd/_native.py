@@ -134,6 +134,8 @@ def _declare(lib: C.CDLL) -> None:
         "orama_prof_enable": [vp, C.c_int],
         "orama_prof_reset": [vp],
         "orama_prof_get": [vp, C.c_char_p, C.POINTER(C.c_double), u64p],
+        "orama_prof_samples": [vp, C.c_char_p, C.POINTER(C.c_float), C.c_uint64, u64p],
+        "orama_ctx_pci_bus_id": [vp, C.c_char_p, C.c_int],
         "orama_dev_malloc": [vp, C.c_uint64, C.POINTER(vp)],
         "orama_dev_upload": [vp, vp, C.c_uint64, vp, C.c_uint64],
         "orama_dev_download": [vp, vp, C.c_uint64, vp, C.c_uint64],

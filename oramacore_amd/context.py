@@ -104,6 +104,24 @@ class Context(Owner):
         N.check(self._lib.orama_prof_get(self.handle, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def prof_samples(self, kernel: str):
+        """Per-launch durations (ms, oldest first) of `kernel` since the last reset — the median is what the roofline quotes."""
+        import numpy as np
+
+        n = C.c_uint64()
+        N.check(self._lib.orama_prof_samples(self.handle, kernel.encode(), None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        if n.value:
+            N.check(self._lib.orama_prof_samples(self.handle, kernel.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), n.value,
+                                                 C.byref(n)))
+        return out[:n.value]
+
+    def pci_bus_id(self) -> str:
+        """PCI address of this context's device ("0000:c5:00.0"): the key monitors find it by (HIP ordinals are not DRM cards)."""
+        buf = C.create_string_buffer(64)
+        N.check(self._lib.orama_ctx_pci_bus_id(self.handle, buf, 64))
+        return buf.value.decode().lower()
+
 
 class DeviceBuffer:
     """A raw HBM allocation (orama_dev_*): what callers of the *_device entry points pass as device pointers.

@@ -145,6 +145,7 @@ struct Profiler {
     struct Acc {
         double ms = 0.0;
         uint64_t n = 0;
+        std::vector<float> samples;  // per-launch durations (orama_prof_samples), bounded
         std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     };
     std::map<std::string, Acc> acc;

@@ -55,6 +55,8 @@ int Profiler::resolve() {
             if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
                 kv.second.ms += (double)ms;
                 kv.second.n += 1;
+                if (kv.second.samples.size() >= 65536) kv.second.samples.erase(kv.second.samples.begin(), kv.second.samples.begin() + 32768);
+                kv.second.samples.push_back(ms);
             }
             free_events.push_back(pr.first);
             free_events.push_back(pr.second);
@@ -70,6 +72,7 @@ void Profiler::reset() {
     for (auto& kv : acc) {
         kv.second.ms = 0.0;
         kv.second.n = 0;
+        kv.second.samples.clear();
     }
 }
 
@@ -405,7 +408,9 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
     c->device = device_ordinal;
     c->compute_units = prop.multiProcessorCount;
     c->hbm_bytes = (uint64_t)prop.totalGlobalMem;
-    snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+    // (some driver stacks leave the marketing name empty: say what IS known rather than print " (gfx950…)")
+    snprintf(c->name, sizeof(c->name), "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD GPU, marketing name not reported",
+             prop.gcnArchName, prop.multiProcessorCount);
     *out = c;
     return ORAMA_OK;
 }
@@ -432,6 +437,12 @@ int orama_ctx_device_info(orama_ctx* ctx, char* name256, int* compute_units, uin
     }
     if (compute_units) *compute_units = ctx->compute_units;
     if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return ORAMA_OK;
+}
+
+int orama_ctx_pci_bus_id(orama_ctx* ctx, char* out, int capacity) {
+    ORAMA_REQUIRE(ctx && out && capacity >= 13, "null argument or a buffer under 13 bytes");
+    ORAMA_HIP_TRY(hipDeviceGetPCIBusId(out, capacity, ctx->device));
     return ORAMA_OK;
 }
 
@@ -563,6 +574,19 @@ int orama_prof_get(orama_ctx* ctx, const char* kernel, double* total_ms, uint64_
     }
     if (total_ms) *total_ms = ms;
     if (launches) *launches = n;
+    return ORAMA_OK;
+}
+
+int orama_prof_samples(orama_ctx* ctx, const char* kernel, float* out_ms, uint64_t capacity, uint64_t* n) {
+    ORAMA_REQUIRE(ctx && kernel && n, "null argument");
+    ORAMA_ON_DEVICE(ctx->device);
+    ctx->prof.resolve();
+    std::lock_guard<std::mutex> g(ctx->prof.mu);
+    auto it = ctx->prof.acc.find(kernel);
+    uint64_t have = it == ctx->prof.acc.end() ? 0 : (uint64_t)it->second.samples.size();
+    if (out_ms)
+        for (uint64_t i = 0; i < have && i < capacity; ++i) out_ms[i] = it->second.samples[i];
+    *n = have;
     return ORAMA_OK;
 }
 

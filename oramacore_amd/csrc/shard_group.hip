@@ -1093,6 +1093,9 @@ int orama_shard_session_step(orama_shard_session* s, uint32_t step) {
         for (uint32_t i = 0; i < nl; ++i) {
             ORAMA_HIP_TRY(hipSetDevice(L(g, i).device));
             char* base = s->local[i]->gathered[slot].as<char>();
+            // (HIP events around the collective when the profiler is on and the process holds ONE rank: the span includes the
+            // wait for the slowest peer's block — the exchange cost a step sees; bench.py's per-step breakdown)
+            orama::ProfScope prof__(nl == 1 ? &L(g, i).ctx->prof : nullptr, "shard_all_gather", s->local[i]->tail[slot]);
             ORAMA_NCCL_TRY(r, r->AllGather(base + (size_t)slot_of(g, i) * s->nb, base, s->nb, kNcclUint8, L(g, i).comm,
                                            s->local[i]->tail[slot]));
         }
@@ -1103,8 +1106,11 @@ int orama_shard_session_step(orama_shard_session* s, uint32_t step) {
         if (g->colocated && i > 0) break;
         SessionLocal& sl = *s->local[i];
         ORAMA_HIP_TRY(hipSetDevice(L(g, i).device));
-        ORAMA_TRY(launch_merge_packed(L(g, i).ctx, gathered(i), (uint32_t)g->world, s->q, s->k, sl.out_ids[slot].as<uint64_t>(),
-                                      sl.out_val[slot].as<float>(), sl.out_n[slot].as<uint32_t>(), sl.tail[slot]));
+        {
+            orama::ProfScope prof__(&L(g, i).ctx->prof, "shard_merge", sl.tail[slot]);
+            ORAMA_TRY(launch_merge_packed(L(g, i).ctx, gathered(i), (uint32_t)g->world, s->q, s->k, sl.out_ids[slot].as<uint64_t>(),
+                                          sl.out_val[slot].as<float>(), sl.out_n[slot].as<uint32_t>(), sl.tail[slot]));
+        }
         if (g->colocated) {
             ORAMA_HIP_TRY(hipEventRecord(sl.ev_merged[slot], sl.tail[slot]));
             sl.merged_recorded[slot] = 1;
