@@ -199,7 +199,7 @@ struct ScoreRange {
 // past the end (e >= cap) read the last posting again and are not `kept`.
 // PLAIN: a batch without score maps, OMC multipliers and min / max tracking whose store holds the pre-divided tf (every plain
 // top-k search at the default b, filtered or not): those branches — per posting, per round — are not compiled in.
-template <bool DF_ONLY, bool WIDE, int NITER, bool PLAIN = false>
+template <bool DF_ONLY, bool WIDE, int NITER, bool PLAIN = false, bool COMPACT = false>
 __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery& q, const ScoreRange& rg, ScoreLds<WIDE>& L) {
     typedef typename MaskOf<WIDE>::type mask_t;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -360,10 +360,11 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
     if (n_cells > kCells || n_multi > kMultiMax) {
         // more multi-posting documents than the tables hold (terms that occur together in most of their documents): like a
         // range of too many postings, the query is rerun with narrower ranges; its slots must be empty meanwhile
-        for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
-            b.keys[q.key_off + rg.slot_base + e] = 0ull;
-            if (b.map_idx) b.map_idx[rg.slot_base + e] = 0xffffffffu;
-        }
+        if (!COMPACT)  // (a compact list has no slots to clear: nothing of this range is appended)
+            for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
+                b.keys[q.key_off + rg.slot_base + e] = 0ull;
+                if (b.map_idx) b.map_idx[rg.slot_base + e] = 0xffffffffu;
+            }
         if (threadIdx.x == 0) b.results[qi].overflow = 1;
         return;
     }
@@ -410,6 +411,117 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
 
     // ---- 5. a singleton is scored and reported by its posting's lane; a posting of any other document parks its normalised
     // tf in its own cell and leaves its slot empty — except the lender's, which phase 6 writes
+    if constexpr (PLAIN && COMPACT) {
+        // COMPACT key list (round 5).  Round 4 wrote one 8-byte slot per posting — empty or not — and the top-k read them all
+        // back: 2.2 x the algorithmic bytes over the chain (profiles/r04_pmc_k3r_*.json), the top-k bound by READING slots.  Here
+        // a lane keeps the score words of its postings in registers (the normalised tf's registers: dead by now), the workgroup
+        // derives a FLOOR — the j-th best of each wave's 64 lane bests, j = ceil(topk / 4): at least topk of this range's
+        // documents reach the smallest of the four, so the query's topk-th best does too — raises it to what earlier
+        // workgroups of the query published, appends the keys at or above it behind ONE bump of the query's cursor, and
+        // publishes its own.  A floor never cuts the answer (>= topk documents are at or above it; ties on the score word
+        // pass), `count` comes from the presence masks as before: same answers, bit for bit.
+        uint32_t ko[NITER];
+#pragma unroll
+        for (int n = 0; n < NITER; ++n) {
+            const uint32_t e = threadIdx.x + n * kThreads;
+            const mask_t m = pm[n];
+            const bool single = m != 0 && (m & (m - 1)) == 0;
+            const float sum = 0.0f + 1.0f * pv[n];                                      // Iterator::sum() from 0.0, weight 1.0
+            const float term = L.idf[(pk[n] >> 25) & 63u] * k1 * sum / (q.k + sum);      // bm25f_score, bm25.rs:124-126
+            const bool applied = f32_is_normal(sum) && term == term;
+            const float score = 0.0f + term * 1.0f;                                     // entry(key).or_insert(0.0) += term * boost 1.0
+            const bool in_map = single && applied && !(q.use_threshold && 1u < q.threshold);
+            if (m != 0 && !single) {
+                const uint32_t below = mask_popc((mask_t)(m & (((mask_t)1 << ((pk[n] >> 17) & 63u)) - 1)));
+                cellv[(uint32_t)L.dmask[PRANK(n)] + below] = pv[n];
+            }
+            my_count += in_map ? 1u : 0u;
+            ko[n] = (in_map && e < cap) ? f32_to_ordered(score) : 0u;
+        }
+        // the floor other workgroups of this query have published so far (loaded here, where few registers are live; its
+        // latency passes behind the bound below and the barrier)
+        const uint32_t tau0 = __hip_atomic_load(&b.results[qi].score_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t best = ko[0];
+#pragma unroll
+        for (int n = 1; n < NITER; ++n) best = max(best, ko[n]);
+        const uint32_t kq = q.topk, jshare = (kq + kWaves - 1u) / kWaves;
+        uint32_t wb = 0u;
+        if (kq != 0u && jshare <= 64u) {  // the jshare-th largest of the wave's lane bests (0: fewer lanes hold a key)
+#pragma unroll
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t t = wb | (1u << bit);
+                wb = (uint32_t)__popcll(__ballot(best >= t)) >= jshare ? t : wb;
+            }
+        }
+        if (lane == 0) L.wave_tot[wave] = wb;  // (the prefix sums of phase 2 are consumed)
+        if (n_cells != 0u) {  // (workgroup-uniform) ---- 6. the multi-posting documents: folded as below, their score word parked in LDS
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n_multi; i += kThreads) {
+                mask_t m = md_mask[i];
+                DocFold f;
+                for (uint32_t c = md_cb[i]; m != 0; ++c) {
+                    const uint32_t ref = mask_first(m);
+                    m &= m - 1;
+                    f.add(L.seg_key[ref] >> 10, cellv[c], L.idf, q.k, k1);
+                }
+                const bool in_map = f.finish(L.idf, q.k, k1, q.use_threshold, q.threshold);
+                my_count += in_map ? 1u : 0u;
+                md_mask[i] = (mask_t)((in_map && f.score == f.score) ? f32_to_ordered(f.score) : 0u);
+            }
+        }
+        if (my_count) atomicAdd(&L.red[1], my_count);
+        __syncthreads();
+        uint32_t lb = L.wave_tot[0];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) lb = min(lb, L.wave_tot[w]);
+        const uint32_t floor_w = kq == 0u ? 0xffffffffu : max(max(lb, tau0), 1u);
+        constexpr int kMultiRounds = kMultiMax / kThreads;
+        // (the multi-posting documents' score words are read from LDS where they are used — counted here, written below —
+        // instead of being carried in registers across the barriers: the kernel's 64-register budget, eight workgroups per CU)
+        unsigned long long sm[NITER + kMultiRounds];
+        uint32_t tot = 0u;
+#pragma unroll
+        for (int n = 0; n < NITER; ++n) {
+            sm[n] = __ballot(ko[n] >= floor_w);
+            tot += (uint32_t)__popcll(sm[n]);
+        }
+#pragma unroll
+        for (int t = 0; t < kMultiRounds; ++t) {
+            const uint32_t i = threadIdx.x + t * kThreads;
+            sm[NITER + t] = (uint32_t)t * kThreads < n_multi ? __ballot(i < n_multi && (uint32_t)md_mask[i] >= floor_w) : 0ull;
+            tot += (uint32_t)__popcll(sm[NITER + t]);
+        }
+        uint32_t woff = 0u;
+        if (lane == 0 && tot) woff = atomicAdd(&L.red[2], tot);
+        woff = __shfl(woff, 0, 64);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t total = L.red[2];
+            L.red[3] = total ? atomicAdd(&b.key_count[qi], total) : 0u;
+            if (lb > tau0) atomicMax(&b.results[qi].score_floor, lb);
+            if (L.red[1]) atomicAdd(&b.results[qi].count, L.red[1]);
+        }
+        __syncthreads();
+        unsigned long long* const lst = b.keys + q.key_off;
+        uint32_t at = L.red[3] + woff;
+        const unsigned long long below_me = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int n = 0; n < NITER; ++n) {
+            if (ko[n] >= floor_w)
+                lst[at + (uint32_t)__popcll(sm[n] & below_me)] = ((unsigned long long)ko[n] << 32) | (unsigned long long)(~(doc0 + (pk[n] & 0xffffu)));
+            at += (uint32_t)__popcll(sm[n]);
+        }
+#pragma unroll
+        for (int t = 0; t < kMultiRounds; ++t) {
+            if ((sm[NITER + t] >> lane) & 1ull) {
+                const uint32_t i = threadIdx.x + t * kThreads;
+                lst[at + (uint32_t)__popcll(sm[NITER + t] & below_me)] =
+                    ((unsigned long long)(uint32_t)md_mask[i] << 32) | (unsigned long long)(~(doc0 + (md_own[i] >> 16)));
+            }
+            at += (uint32_t)__popcll(sm[NITER + t]);
+        }
+        return;
+    }
     if constexpr (PLAIN) {
         // Straight-line form of the loop below for the plain search: every lane evaluates the singleton's fold (the additions
         // DocFold::add + finish perform for ONE contribution, in their order) and selects; only the rare posting of a document
@@ -495,8 +607,8 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
 }
 
 // DF_ONLY: the counting pass (corpus_docs.len() per token under a filter / with several lists per token).
-template <bool DF_ONLY, bool WIDE, bool PLAIN = false>
-__global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
+template <bool DF_ONLY, bool WIDE, bool PLAIN = false, bool COMPACT = false>
+__device__ __forceinline__ void range_score_main(const RangeBatch& b) {
     __shared__ ScoreLds<WIDE> L;
 
     // (query, range) of this workgroup: the batch's pairs laid end to end
@@ -581,7 +693,7 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     rg.slot_base = L.red[0];
     if (cap > kRangeCap) {
         // the query is rerun with smaller ranges; its slots still reach the batch's top-k, so they must be empty
-        if (!DF_ONLY)
+        if (!DF_ONLY && !COMPACT)
             for (uint32_t e = threadIdx.x; e < cap; e += kThreads) {
                 b.keys[q.key_off + rg.slot_base + e] = 0ull;
                 if (b.map_idx) b.map_idx[rg.slot_base + e] = 0xffffffffu;
@@ -594,14 +706,24 @@ __global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
     // clamped, unkept postings)
     const uint32_t n_iter = (cap + kThreads - 1) / kThreads;
     if (DF_ONLY) {
-        if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4, PLAIN>(b, q, rg, L);
-        else score_body<DF_ONLY, WIDE, 8, PLAIN>(b, q, rg, L);
-    } else if (n_iter <= 2) score_body<DF_ONLY, WIDE, 2, PLAIN>(b, q, rg, L);
-    else if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4, PLAIN>(b, q, rg, L);
-    else if (n_iter == 5) score_body<DF_ONLY, WIDE, 5, PLAIN>(b, q, rg, L);
-    else if (n_iter == 6) score_body<DF_ONLY, WIDE, 6, PLAIN>(b, q, rg, L);
-    else if (n_iter == 7) score_body<DF_ONLY, WIDE, 7, PLAIN>(b, q, rg, L);
-    else score_body<DF_ONLY, WIDE, 8, PLAIN>(b, q, rg, L);
+        if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4, PLAIN, COMPACT>(b, q, rg, L);
+        else score_body<DF_ONLY, WIDE, 8, PLAIN, COMPACT>(b, q, rg, L);
+    } else if (n_iter <= 2) score_body<DF_ONLY, WIDE, 2, PLAIN, COMPACT>(b, q, rg, L);
+    else if (n_iter <= 4) score_body<DF_ONLY, WIDE, 4, PLAIN, COMPACT>(b, q, rg, L);
+    else if (n_iter == 5) score_body<DF_ONLY, WIDE, 5, PLAIN, COMPACT>(b, q, rg, L);
+    else if (n_iter == 6) score_body<DF_ONLY, WIDE, 6, PLAIN, COMPACT>(b, q, rg, L);
+    else if (n_iter == 7) score_body<DF_ONLY, WIDE, 7, PLAIN, COMPACT>(b, q, rg, L);
+    else score_body<DF_ONLY, WIDE, 8, PLAIN, COMPACT>(b, q, rg, L);
+}
+
+template <bool DF_ONLY, bool WIDE, bool PLAIN = false>
+__global__ __launch_bounds__(kThreads) void range_score_kernel(RangeBatch b) {
+    range_score_main<DF_ONLY, WIDE, PLAIN, false>(b);
+}
+// The plain search with compact key lists.  Eight workgroups per CU are what makes this launch fast (it waits — dependent LDS
+// and global loads, barriers — most of its cycles): the register allocator is held to the 64 VGPRs that buys.
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void range_score_compact_kernel(RangeBatch b) {
+    range_score_main<false, false, true, true>(b);
 }
 
 // Hybrid path: the full-text score of given documents.  One WAVE per document: lane i looks the document up in the
@@ -722,7 +844,9 @@ int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStr
     } else {
         // (plain: the pre-divided tf at hand, nothing of the batch asks for a score map, OMC multipliers or min / max)
         const bool plain = !b.map_idx && !b.omc_dense && !b.any_minmax && b.post_ntf;
+        ORAMA_REQUIRE(!b.key_count || (plain && !wide), "internal: compact key lists need the plain scoring launch");
         if (wide) hipLaunchKernelGGL((range_score_kernel<false, true>), dim3(grid), dim3(kThreads), 0, stream, b);
+        else if (plain && b.key_count) hipLaunchKernelGGL(range_score_compact_kernel, dim3(grid), dim3(kThreads), 0, stream, b);
         else if (plain) hipLaunchKernelGGL((range_score_kernel<false, false, true>), dim3(grid), dim3(kThreads), 0, stream, b);
         else hipLaunchKernelGGL((range_score_kernel<false, false>), dim3(grid), dim3(kThreads), 0, stream, b);
     }

@@ -32,7 +32,8 @@ struct RangeQuery {
     float k;
     uint32_t want_df;     // count df on the device: 1 = a token has several lists (distinct pairs), 2 = only a filter
     uint32_t track_minmax; // hybrid: reduce the largest / smallest non-NaN score into the result words
-    uint64_t pad2;
+    uint32_t topk;        // keys the caller will take from this query's list (compact key lists: the scoring launch's floor)
+    uint32_t pad2;
 };
 
 // Per-query result words (device): 128 bytes apart so that the per-workgroup atomics of different queries and of
@@ -49,6 +50,8 @@ struct RangeResult {
     uint32_t pad3[31];
     unsigned long long topk_tau;  // running bound of the key list's top-k reduction (launch_keys_topk, zero at launch)
     uint32_t pad4[30];
+    uint32_t score_floor; // compact key lists: ordered(score) that at least `topk` documents scored so far reach (monotone)
+    uint32_t pad5[31];
 };
 
 struct RangeBatch {
@@ -76,6 +79,11 @@ struct RangeBatch {
     const float* idf = nullptr;          // [n_queries][kMaxTokens]
     const float* omc_dense = nullptr;
     unsigned long long* keys = nullptr;  // ordered(score) << 32 | ~local doc; 0 = empty
+    // Compact key lists (round 5; plain top-k batches): key_count[query] starts at zero and the scoring launch APPENDS — a
+    // workgroup writes only the keys that reach its floor (a score at least `topk` documents are known to reach), behind one
+    // cursor bump per workgroup; the top-k reads key_count[query] keys instead of one slot per posting.  nullptr: one slot
+    // per posting (score maps, OMC, hybrid min / max, wide masks).
+    uint32_t* key_count = nullptr;
     RangeResult* results = nullptr;
     // score-map mode (n_queries == 1): besides its key, every slot gets the map entry it stands for — map_idx[slot] = local
     // document (0xffffffff: none), map_score[slot] = its score (after OMC; NaN stays), map_emit[document] = epoch << 32 | slot:

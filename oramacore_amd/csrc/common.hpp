@@ -236,6 +236,9 @@ struct orama_ctx {
     // 0 = always the per-document-record scorer K3 (ORAMA_BM25_RANGES, orama_ctx_set_bm25_ranges)
     int bm25_ranges = 1;
     int bm25_ranges_hybrid = 1;  // orama_post_search_hybrid on the range scorer where it applies (ORAMA_BM25_RANGES_HYBRID=0: K3)
+    // K3r's plain top-k batches append only the keys that can still reach the answer (round 5, bm25_ranges.hip "COMPACT");
+    // false = one key slot per posting as in round 4 (ORAMA_K3R_COMPACT=0, orama_ctx_set_bm25_ranges(ctx, 3): A/B runs)
+    bool bm25_compact_keys = true;
     int k3r_merge = 0;  // comparison builds only (ORAMA_COMPARISON_KERNELS=1): ORAMA_K3R_MERGE=1 scores ranges with the round-3 merge tree
     // stores created as ORAMA_DTYPE_F32_SHADOW16 answer orama_vec_search in two stages (fp16 candidates, fp32 decision);
     // 0 = always the plain fp32 scan, 2 = two stages also where the plain scan is expected to be faster (small stores

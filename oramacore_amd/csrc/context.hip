@@ -395,6 +395,7 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
     if (c->f16_wide == 1 || c->f16_wide == 5) c->f16_wide = 4;  // K2c / K2h are not in this build
 #endif
     if (const char* e = std::getenv("ORAMA_BM25_RANGES")) c->bm25_ranges = std::atoi(e) != 0;
+    if (const char* e = std::getenv("ORAMA_K3R_COMPACT")) c->bm25_compact_keys = std::atoi(e) != 0;
     if (const char* e = std::getenv("ORAMA_BM25_RANGES_HYBRID")) c->bm25_ranges_hybrid = std::atoi(e) != 0;
 #if ORAMA_COMPARISON_KERNELS
     if (const char* e = std::getenv("ORAMA_K3R_MERGE")) c->k3r_merge = std::atoi(e) != 0;
@@ -531,9 +532,10 @@ int orama_ctx_set_two_stage(orama_ctx* ctx, int on) {
 
 int orama_ctx_set_bm25_ranges(orama_ctx* ctx, int on) {
     ORAMA_REQUIRE(ctx, "null context");
-    ORAMA_REQUIRE(on >= 0 && on <= 2, "bm25 ranges mode %d outside [0, 2]", on);
+    ORAMA_REQUIRE(on >= 0 && on <= 3, "bm25 ranges mode %d outside [0, 3]", on);
     ctx->bm25_ranges = on != 0;
-    ctx->bm25_ranges_hybrid = on == 1;
+    ctx->bm25_ranges_hybrid = on == 1 || on == 3;
+    ctx->bm25_compact_keys = on != 3;
     return ORAMA_OK;
 }
 

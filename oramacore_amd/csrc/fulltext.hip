@@ -209,15 +209,23 @@ struct orama_post {
     // content (0 = no filter); host words are anybody's guess and nothing is remembered for them.
     std::mutex df_union_mu;
     std::unordered_map<std::string, uint32_t> df_union;
-    static constexpr size_t kDfUnionMax = 1u << 20;  // entries; the map is emptied when it gets there
-    static std::string df_union_key(const uint32_t* lists, uint32_t n, uint64_t filter_version) {
+    // entries; the map is emptied when it gets there (keys are at most 272 bytes: under 32 MB of host memory with the nodes)
+    static constexpr size_t kDfUnionMax = 1u << 16;
+    // (the count under a filter also depends on how many of the bitmap's bits the call declares valid — a posting is kept
+    // only when id < bitmap_bits: the key carries both)
+    static std::string df_union_key(const uint32_t* lists, uint32_t n, uint64_t filter_version, uint64_t filter_bits = 0) {
         uint32_t sorted[kRangeMaxRefs];
         std::copy(lists, lists + n, sorted);
         std::sort(sorted, sorted + n);
         std::string key(reinterpret_cast<const char*>(sorted), (size_t)n * 4);
         key.append(reinterpret_cast<const char*>(&filter_version), 8);
+        if (filter_version) key.append(reinterpret_cast<const char*>(&filter_bits), 8);
         return key;
     }
+    // Range width that worked for a set of lists: a query whose lists overlap heavily — the same term in
+    // several fields, terms that occur together — overflows the scoring launch's cell tables at the default width, is scored
+    // once for nothing and rerun with 8x narrower ranges; the NEXT query over the same lists starts at the width that held.
+    std::unordered_map<std::string, uint32_t> shrink_hint;
 };
 
 namespace {
@@ -226,7 +234,7 @@ namespace {
 // recall: true when every token of the query that needs a COUNT — several lists, or any list under a filter — has one
 // remembered; df[t] is set for those tokens (the others keep the caller's value: the list length).
 bool df_recall(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, uint32_t n_tokens, bool filtered, uint64_t filter_version,
-               uint32_t* df) {
+               uint64_t filter_bits, uint32_t* df) {
     if (filtered && !filter_version) return false;
     const uint32_t need = filtered ? 1u : 2u;
     std::lock_guard<std::mutex> g(p->df_union_mu);
@@ -240,14 +248,14 @@ bool df_recall(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, uint3
             lists[nl++] = l;
         }
         if (nl < need) continue;
-        auto it = p->df_union.find(orama_post::df_union_key(lists, nl, filtered ? filter_version : 0));
+        auto it = p->df_union.find(orama_post::df_union_key(lists, nl, filtered ? filter_version : 0, filter_bits));
         if (it == p->df_union.end()) return false;
         df[t] = it->second;
     }
     return true;
 }
 void df_remember(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, uint32_t n_tokens, bool filtered, uint64_t filter_version,
-                 const uint32_t* df) {
+                 uint64_t filter_bits, const uint32_t* df) {
     if (filtered && !filter_version) return;
     const uint32_t need = filtered ? 1u : 2u;
     std::lock_guard<std::mutex> g(p->df_union_mu);
@@ -259,8 +267,27 @@ void df_remember(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, uin
             const uint32_t l = refs[i].list;
             if (p->list_off[l + 1] != p->list_off[l] && nl < kRangeMaxRefs) lists[nl++] = l;
         }
-        if (nl >= need) p->df_union[orama_post::df_union_key(lists, nl, filtered ? filter_version : 0)] = df[t];
+        if (nl >= need) p->df_union[orama_post::df_union_key(lists, nl, filtered ? filter_version : 0, filter_bits)] = df[t];
     }
+}
+
+// orama_post::shrink_hint: the non-empty lists of the whole query, sorted
+std::string shrink_key(const orama_post* p, const orama_term_ref* refs, uint32_t n_refs) {
+    uint32_t lists[kRangeMaxRefs], nl = 0;
+    for (uint32_t i = 0; i < n_refs && nl < kRangeMaxRefs; ++i)
+        if (p->list_off[refs[i].list + 1] != p->list_off[refs[i].list]) lists[nl++] = refs[i].list;
+    return orama_post::df_union_key(lists, nl, 0);
+}
+uint32_t shrink_recall(orama_post* p, const orama_term_ref* refs, uint32_t n_refs) {
+    std::lock_guard<std::mutex> g(p->df_union_mu);
+    if (p->shrink_hint.empty()) return 0u;
+    auto it = p->shrink_hint.find(shrink_key(p, refs, n_refs));
+    return it == p->shrink_hint.end() ? 0u : it->second;
+}
+void shrink_remember(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, uint32_t shrink) {
+    std::lock_guard<std::mutex> g(p->df_union_mu);
+    if (p->shrink_hint.size() >= orama_post::kDfUnionMax) p->shrink_hint.clear();
+    p->shrink_hint[shrink_key(p, refs, n_refs)] = shrink;
 }
 
 // (Re)compute p->d_post_ntf for the store's current postings and average lengths.  Caller holds p->mu exclusively.
@@ -268,6 +295,7 @@ int refresh_post_ntf(orama_post* p) {
     {  // (every change of the postings comes through here: what was counted over the old lists is forgotten)
         std::lock_guard<std::mutex> g(p->df_union_mu);
         p->df_union.clear();
+        p->shrink_hint.clear();
     }
     p->ntf_valid = false;
     if (p->n_postings == 0 || p->n_lists == 0) return ORAMA_OK;
@@ -566,7 +594,9 @@ uint32_t choose_width(uint64_t n_docs, uint64_t total_postings, uint32_t shrink)
         return (uint64_t)(v >= 16 && v <= (long)kRangeCap ? v : 1536);
     }();
     uint64_t w = total_postings ? n_docs * target / total_postings : n_docs;
-    for (uint32_t i = 0; i < shrink; ++i) w /= 8;
+    // (the first step is 4x: a cell-table overflow — lists that overlap — needs little, and the width that held is remembered
+    // for the next query over the same lists, orama_post::shrink_hint; clustered documents take the 8x steps behind it)
+    for (uint32_t i = 0; i < shrink; ++i) w /= i == 0 ? 4 : 8;
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(w, 1), kRangeMaxWidth);
 }
 
@@ -759,10 +789,10 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             if (!counted || !total) continue;
             // (counted before, under this filter / for these sets of lists?  then the host has the answer)
             if (df_recall(p, jb.refs, jb.n_refs, jb.params->n_tokens, allow_bitmap != nullptr, allow_content_version(p->ctx, allow_bitmap),
-                          jb.df_out))
+                          bitmap_bits, jb.df_out))
                 continue;
         }
-        if (total) pending.push_back({j, 0u, total});
+        if (total) pending.push_back({j, shrink_recall(p, jb.refs, jb.n_refs), total});
     }
     ORAMA_REQUIRE(p->n_docs > 0 || pending.empty(), "postings store is empty (orama_post_build not called)");
     // Queries of similar length share a set of launches: the launches of a chunk are sized by its longest query (grid of the
@@ -844,6 +874,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             q.threshold = jb.params->threshold;
             q.k = jb.params->k;
             q.track_minmax = jb.hybrid ? 1u : 0u;
+            q.topk = jb.params->top_k;
             c.lens[ci] = (uint32_t)pd.total;
             max_ranges = std::max(max_ranges, q.n_ranges);
             uint32_t per_token[kMaxTokens] = {0}, df[kMaxTokens] = {0};
@@ -871,7 +902,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                 }
             }
             if ((multi_list || d_allow != nullptr) && !jb.df_global && !df_pass)  // what an earlier query had counted
-                df_known = df_recall(p, jb.refs, jb.n_refs, q.n_tokens, d_allow != nullptr, c.allow_version, df);
+                df_known = df_recall(p, jb.refs, jb.n_refs, q.n_tokens, d_allow != nullptr, c.allow_version, bitmap_bits, df);
             q.seg_end = (uint32_t)segs.size();
             const uint32_t ns = q.seg_end - q.seg_begin;
             bounds_entries += ((uint64_t)q.n_ranges + 1) * ns;
@@ -890,6 +921,14 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             }
         }
         ORAMA_SUPPORT(virt < 0xffffffffull && bounds_entries < 0xffffffffull, "query batch references too many postings");
+        // Compact key lists (round 5): a plain top-k batch — no score map, OMC, hybrid min / max, 64-bit masks, and the store's
+        // pre-divided tf at hand (the conditions of the PLAIN scoring launch) — appends only the keys that can still reach the
+        // answer; the per-list lengths the top-k reads then START AT ZERO and are counted up by the scoring launch.
+        bool compact = !df_pass && c.kmax != 0 && p->ctx->bm25_compact_keys && !(n_jobs == 1 && jobs[0].map) && !(apply_omc && p->has_omc) &&
+                       p->ntf_valid && b == p->ntf_b;
+        for (uint32_t ci = 0; ci < nq && compact; ++ci)
+            compact = !queries[ci].track_minmax && queries[ci].seg_end - queries[ci].seg_begin <= 32u;
+        if (compact) c.lens.assign(nq, 0u);
         // device tables: [segs | queries | idf | list lengths]
         const size_t seg_bytes = (segs.size() * sizeof(RangeSeg) + 63) & ~(size_t)63;
         const size_t q_bytes = ((size_t)nq * sizeof(RangeQuery) + 63) & ~(size_t)63;
@@ -944,6 +983,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         rb.omc_dense = (apply_omc && p->has_omc) ? p->d_omc.as<float>() : nullptr;
         rb.keys = sc->misc3.as<unsigned long long>();
         rb.results = sc->misc2.as<RangeResult>();
+        if (compact) rb.key_count = reinterpret_cast<uint32_t*>(d + seg_bytes + q_bytes + idf_bytes);
         if (n_jobs == 1 && jobs[0].map) {
             // the per-document table is the set's epoch-stamped one (shared with the per-record scorer's use of the set)
             ORAMA_TRY(reserve_zeroed(sc->bm25_emit, (size_t)p->n_docs * 8, s));
@@ -990,7 +1030,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                     h_idf[(size_t)ci * kMaxTokens + t] = log1pf((pr->total_documents - dd + 0.5f) / (dd + 0.5f));
                 }
                 if (!h_res[ci].overflow)  // what this query had counted, for the queries to come
-                    df_remember(p, jb.refs, jb.n_refs, queries[ci].n_tokens, d_allow != nullptr, c.allow_version, h_res[ci].df);
+                    df_remember(p, jb.refs, jb.n_refs, queries[ci].n_tokens, d_allow != nullptr, c.allow_version, bitmap_bits, h_res[ci].df);
             }
             ORAMA_HIP_TRY(hipMemcpyAsync(d_idf, h_idf, idf_bytes, hipMemcpyHostToDevice, s));
         }
@@ -1005,7 +1045,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             ORAMA_TRY(launch_keys_topk(p->ctx, rb.keys, (uint32_t)max_total, max_total, nq, c.kmax, true, p->d_docs.as<uint64_t>(),
                                        sc->misc4.as<unsigned long long>(), nullptr, d_ids, d_val, d_n, s,
                                        reinterpret_cast<const uint32_t*>(d + seg_bytes + q_bytes + idf_bytes), &rb.results[0].topk_tau,
-                                       (uint32_t)(sizeof(RangeResult) / 8)));
+                                       (uint32_t)(sizeof(RangeResult) / 8), nullptr, compact));
         }
         c.trace.mark(5);
         ORAMA_HIP_TRY(hipMemcpyAsync(h_res, d_out, c.kmax ? out_bytes : res_bytes, hipMemcpyDeviceToHost, s));
@@ -1057,9 +1097,10 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                 pending.push_back(pd);
                 continue;
             }
+            if (pd.shrink && !df_pass) shrink_remember(p, jb.refs, jb.n_refs, pd.shrink);  // (the width the next query over these lists starts at)
             if (df_pass) {
                 memcpy(jb.df_out, h_res[ci].df, sizeof(uint32_t) * kMaxTokens);
-                df_remember(p, jb.refs, jb.n_refs, jb.params->n_tokens, c.d_allow != nullptr, c.allow_version, h_res[ci].df);
+                df_remember(p, jb.refs, jb.n_refs, jb.params->n_tokens, c.d_allow != nullptr, c.allow_version, bitmap_bits, h_res[ci].df);
                 continue;
             }
             if (jb.hybrid) {

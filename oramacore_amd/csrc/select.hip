@@ -535,7 +535,8 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
                                                                    const uint32_t* __restrict__ n_per_list,
                                                                    uint32_t k, unsigned long long* __restrict__ out,
                                                                    uint64_t out_stride, unsigned long long* tau = nullptr,
-                                                                   uint32_t tau_stride = 0, const uint32_t* __restrict__ n_active = nullptr) {
+                                                                   uint32_t tau_stride = 0, const uint32_t* __restrict__ n_active = nullptr,
+                                                                   uint32_t direct_cap = 0) {
     __shared__ unsigned long long s[kKeysChunk];
     __shared__ uint32_t hist[256];
     __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
@@ -555,6 +556,10 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
     const uint32_t begin = chunk * kKeysChunk;
     if (n_per_list) n_keys = min(n_keys, n_per_list[qi]);  // lists shorter than the stride: the tail is not read
     unsigned long long* o = out + (uint64_t)qi * out_stride + (uint64_t)chunk * k;
+    // counted lists (direct_cap != 0: the length was produced on the device — K3r's compact key lists): a list the final kernel
+    // can take whole is not reduced at all, and a chunk past the end writes nothing — the final kernel reads
+    // ceil(length / chunk) * k survivors, not the grid's worth
+    if (direct_cap && (n_keys <= direct_cap || begin >= n_keys)) return;
     if (begin >= n_keys) {
         for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = 0ull;
         return;
@@ -1003,7 +1008,9 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
                                                                   const uint64_t* __restrict__ id_map,
                                                                   uint32_t* out_idx, uint64_t* out_ids, float* out_val,
                                                                   uint32_t* out_n, const uint32_t* __restrict__ n_active = nullptr,
-                                                                  const uint32_t* __restrict__ done = nullptr) {
+                                                                  const uint32_t* __restrict__ done = nullptr,
+                                                                  const unsigned long long* __restrict__ direct_keys = nullptr,
+                                                                  uint64_t direct_stride = 0, uint32_t direct_cap = 0) {
     __shared__ SortLds s;
     __shared__ uint32_t valid_s;
     __shared__ uint32_t hist[256];
@@ -1015,7 +1022,18 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
     const uint32_t qi = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned long long* in = keys + (uint64_t)qi * in_stride;
-    if (n_per_list) n_keys = min(n_keys, n_per_list[qi]);
+    if (direct_cap) {
+        // counted lists (see keys_reduce_kernel): n_per_list is the length of the CALLER's list; `keys` is the reduced level
+        const uint32_t len = n_per_list[qi];
+        if (len <= direct_cap) {  // (uniform) nothing was reduced: the list itself
+            in = direct_keys + (uint64_t)qi * direct_stride;
+            n_keys = len;
+        } else {
+            n_keys = min(n_keys, ((len + kKeysChunk - 1u) / kKeysChunk) * k);
+        }
+    } else if (n_per_list) {
+        n_keys = min(n_keys, n_per_list[qi]);
+    }
     if (n_keys > k) {
         // More candidates than answers (e.g. 32 chunks x 100 survivors of a scan's wave lists: 3 200 keys for 100 results):
         // ordering all of them is a 4 096-element bitonic sort with a 64-bit id gather per element, 80 us of a 4.4 ms query.
@@ -1174,9 +1192,29 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
                      uint32_t q, uint32_t k, bool descending, const uint64_t* id_map,
                      unsigned long long* d_tmp, uint32_t* out_idx, uint64_t* out_ids, float* out_val,
                      uint32_t* out_n, hipStream_t stream, const uint32_t* d_n_per_list, unsigned long long* d_tau,
-                     uint32_t tau_stride, const uint32_t* d_n_active) {
+                     uint32_t tau_stride, const uint32_t* d_n_active, bool counted) {
     ORAMA_REQUIRE(k >= 1 && k <= kSelectMaxK && q >= 1 && d_keys && out_val, "keys top-k: bad arguments");
     ProfScope prof(&ctx->prof, "topk_select", stream);
+    if (counted && d_n_per_list) {
+        // Lists whose lengths were produced on the device and are expected to be MUCH shorter than n_keys (K3r's compact key
+        // lists: a few percent of one slot per posting).  One reduction level sized for the worst case, of which only the
+        // chunks that exist do anything, and none at all for a list the final kernel can take whole.
+        const uint32_t cap = keys_final_capacity(k);
+        const uint32_t chunks = (n_keys + kKeysChunk - 1) / kKeysChunk;
+        if ((uint64_t)chunks * k <= cap) {
+            if (n_keys > cap) {
+                ORAMA_REQUIRE(d_tmp, "keys top-k: scratch missing");
+                hipLaunchKernelGGL(keys_reduce_kernel, d_tau ? dim3(q, chunks) : dim3(chunks, q), dim3(kSortThreads), 0, stream, d_keys,
+                                   n_keys, stride, d_n_per_list, k, d_tmp, (uint64_t)chunks * k, d_tau, tau_stride, d_n_active, cap);
+            }
+            hipLaunchKernelGGL(keys_final_kernel, dim3(q), dim3(kSortThreads), 0, stream, d_tmp ? d_tmp : d_keys, chunks * k,
+                               (uint64_t)chunks * k, d_n_per_list, k, descending, id_map, out_idx, out_ids, out_val, out_n, d_n_active,
+                               (const uint32_t*)nullptr, d_keys, stride, cap);
+            ORAMA_HIP_TRY(hipGetLastError());
+            return ORAMA_OK;
+        }
+        // (longer lists: the general levels below, reading the counted lengths at the first one)
+    }
     const unsigned long long* cur = d_keys;
     uint64_t cur_stride = stride;
     uint32_t n = n_keys;

@@ -658,3 +658,75 @@ def test_large_lists_and_multi_chunk_batches(ctx):
     ids, sc, count = flat.store.search([(0, 0, 1.0)], 1, float(n_flat), 25)
     assert count == n_flat and ids.tolist() == list(range(25)) and len(set(bits(sc).tolist())) == 1
     flat.store.close()
+
+
+def test_compact_key_lists_equal_one_slot_per_posting(ctx):
+    """Round 5: a plain top-k batch APPENDS only the keys at or above a floor (bm25_ranges.hip, COMPACT) instead of writing one
+    slot per posting.  A floor is a score at least `top_k` documents are known to reach, so it cannot cut the answer: the same
+    ids, score bits and counts as round 4's lists (orama_ctx_set_bm25_ranges(ctx, 3)) and as the oracle — for k from 1 to past
+    the 256 the floor supports, for lists full of EQUAL scores (every key ties at the floor), for count-only queries, under a
+    filter and a threshold, single calls and batches."""
+    rng = np.random.default_rng(55)
+    n_docs = 600_000
+    lists = random_lists(rng, n_docs, 10, 2, 20_000, 90_000)
+    corpus = Corpus(ctx, n_docs, lists, [64.0, 9.5], seed=56)
+    # two lists whose postings all carry the same tf and length: thousands of equal scores, ties decided by document id
+    same = np.sort(rng.choice(n_docs, size=50_000, replace=False))
+    flat = Corpus(ctx, n_docs, [(0, same), (0, same[::2])], [10.0], seed=57)
+    flat.store.close()  # (the same lists again with constant tf and length)
+    flat.lists = [(f, loc, np.full(len(loc), 2), np.full(len(loc), 10)) for f, loc, _, _ in flat.lists]
+    flat.store = ft.PostingsStore(ctx)
+    flat.store.build(flat.doc_ids, flat.avg, [ft.PostingList(field=f, docs=flat.doc_ids[loc], tf=tf, field_len=ln)
+                                              for f, loc, tf, ln in flat.lists])
+    allow_mask = rng.random(n_docs) < 0.5
+    bm = oa.AllowBitmap(n_docs, np.arange(n_docs, dtype=np.uint64)[allow_mask])
+    cases = []
+    for k in (1, 7, 100, 256, 257, 300, 1000):
+        refs = [(t, int(l), 1.0) for t, l in enumerate(rng.choice(10, size=6, replace=False))]
+        cases.append((corpus, refs, 6, k, None, None, None))
+    cases.append((corpus, [(0, 1, 1.0), (1, 2, 2.0), (2, 3, 1.0)], 3, 50, 2, None, None))       # threshold
+    cases.append((corpus, [(0, 4, 1.0), (1, 5, 1.0)], 2, 100, None, bm, allow_mask))           # filter
+    cases.append((flat, [(0, 0, 1.0)], 1, 100, None, None, None))                                # all scores equal
+    cases.append((flat, [(0, 0, 1.0), (1, 1, 1.0)], 2, 100, None, None, None))                   # two score levels, many ties
+    cases.append((corpus, [(0, 0, 1.0), (1, 9, 1.0)], 2, 0, None, None, None))                   # count only
+    answers = {}
+    for compact in (True, False):
+        ctx.set_bm25_ranges(True, compact_keys=compact)
+        got = []
+        for c, refs, nt, k, thr, allow, mask in cases:
+            ids, sc, count = c.store.search(refs, nt, float(n_docs), k, thr, allow=allow)
+            if k:
+                od, os_, ocount = c.oracle(refs, nt, k, thr, mask)
+                assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_)), (compact, refs, k)
+            got.append((ids, sc, count))
+        # the same queries of the big corpus as ONE batch (queries of different k share a set of launches: k = the largest)
+        batch = [(refs, nt, thr) for c, refs, nt, k, thr, allow, mask in cases if c is corpus and allow is None]
+        got.append(corpus.store.search_batch(batch, float(n_docs), 100))
+        answers[compact] = got
+    ctx.set_bm25_ranges(True)
+    for a, b_ in zip(answers[True][:-1], answers[False][:-1]):
+        assert a[2] == b_[2] and a[0].tolist() == b_[0].tolist() and np.array_equal(bits(a[1]), bits(b_[1]))
+    for a, b_ in zip(answers[True][-1], answers[False][-1]):
+        assert a[2] == b_[2] and a[0].tolist() == b_[0].tolist() and np.array_equal(bits(a[1]), bits(b_[1]))
+    corpus.store.close()
+    flat.store.close()
+
+
+def test_the_range_width_that_held_is_remembered(ctx):
+    """lists that overlap heavily (the same term in two fields) overflow the scoring launch's cell tables at the
+    default range width; the query is rerun with narrower ranges — and the width that held is remembered for the lists, so
+    the next query over them is scored once.  Same answers before and after, equal to the oracle's."""
+    rng = np.random.default_rng(77)
+    n_docs = 200_000
+    base = np.sort(rng.choice(n_docs, size=120_000, replace=False))
+    lists = [(0, base), (1, base), (0, np.sort(rng.choice(n_docs, size=30_000, replace=False)))]
+    corpus = Corpus(ctx, n_docs, lists, [40.0, 6.0], seed=78)
+    refs = [(0, 0, 1.0), (0, 1, 2.0), (1, 2, 1.0)]  # token 0 in both fields: every document of `base` has two postings
+    od, os_, ocount = corpus.oracle(refs, 2, 100)
+    for _ in range(3):  # first call: overflow + rerun; later calls start at the remembered width
+        ids, sc, count = corpus.store.search(refs, 2, float(n_docs), 100)
+        assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
+    res = corpus.store.search_batch([(refs, 2, None)] * 40, float(n_docs), 100)
+    for ids, sc, count in res:
+        assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
+    corpus.store.close()

@@ -83,8 +83,8 @@ def test_register_budgets_that_buy_a_resident_workgroup():
         assert hits, fragment
         return hits
 
-    for k in the("range_score_kernelILb0ELb0ELb1E"):
-        assert k["vgprs"] <= 64 and k["lds_bytes_per_block"] * 8 <= 160 * 1024, k
+    for k in the("range_score_kernelILb0ELb0ELb1E") + the("range_score_compact_kernel"):  # (round 5: the compact-list form too)
+        assert k["vgprs"] <= 64 and k["lds_bytes_per_block"] * 8 <= 160 * 1024 and k["scratch_bytes_per_lane"] == 0, k
     for fragment in ("pairs_reduce_kernel", "keys_reduce_kernel", "keys_final_kernel"):
         for k in the(fragment):
             assert k["vgprs"] <= 64 and k["lds_bytes_per_block"] * 2 <= 160 * 1024, k
