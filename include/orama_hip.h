@@ -122,7 +122,8 @@ int orama_ctx_set_f16_wide(orama_ctx* ctx, int mode);
  * whole query batches per launch (bm25_ranges.hip) — for the plain top-k search and, where no OMC applies, for
  * orama_post_search_hybrid; 2 = K3r for the plain search only; 0 = K3, per-document records in HBM (bm25_kernels.hip),
  * which the score-map / precomputed-ntf / fused-hybrid entry points always use; 3 = as 1 with round 4's key lists (one key
- * slot per posting; the default appends only the keys that can still reach the answer — A/B runs).  Same results bit for bit. */
+ * slot per posting; the default appends only the keys that can still reach the answer, for batches of 8 queries or more —
+ * A/B runs), 4 = as 1 with the compact lists for every batch size (parity tests).  Same results bit for bit. */
 int orama_ctx_set_bm25_ranges(orama_ctx* ctx, int on);
 /* ORAMA_DTYPE_F32_SHADOW16 stores: 1 (default) = two-stage search where it pays (batches of more than 8 queries, or at
  * least 4 GB of fp32 rows: below that the plain scan is faster than the second stage's launches), 2 = always two stages,

@@ -82,10 +82,12 @@ class Context(Owner):
         scan; always=True takes the two stages for small stores too."""
         N.check(self._lib.orama_ctx_set_two_stage(self.handle, (2 if always else 1) if on else 0))
 
-    def set_bm25_ranges(self, on: bool, hybrid: bool = True, compact_keys: bool = True) -> None:
+    def set_bm25_ranges(self, on: bool, hybrid: bool = True, compact_keys: bool | str = True) -> None:
         """BM25 searches: True = K3r range-partitioned batch scorer (default; hybrid=False keeps it to the plain top-k
-        search; compact_keys=False = round 4's key lists, one slot per posting), False = K3 per-document records."""
-        N.check(self._lib.orama_ctx_set_bm25_ranges(self.handle, (3 if not compact_keys else 1 if hybrid else 2) if on else 0))
+        search; compact_keys=False = round 4's key lists, one slot per posting; "always" = compact lists for every batch
+        size, not only for 8 queries and more), False = K3 per-document records."""
+        mode = 4 if compact_keys == "always" else 3 if not compact_keys else 1 if hybrid else 2
+        N.check(self._lib.orama_ctx_set_bm25_ranges(self.handle, mode if on else 0))
 
     def set_f16_wide(self, mode: int) -> None:
         """0 = K2 passes of 64, 1 = K2c, 2 / 3 = K2d geometry 1 / 2, 4 = K2q (default), 5 = K2h (orama_ctx_set_f16_wide)."""

@@ -71,8 +71,10 @@ __global__ __launch_bounds__(kBoundsThreads) void range_bounds_kernel(RangeBatch
     const uint32_t qi = blockIdx.y;
     // the query's result words start at zero: cleared here, by the first launch of the set, instead of by a fill command
     // of their own in front of it
-    if (blockIdx.x == 0)
+    if (blockIdx.x == 0) {
         for (uint32_t i = threadIdx.x; i < sizeof(RangeResult) / 4; i += kBoundsThreads) reinterpret_cast<uint32_t*>(&b.results[qi])[i] = 0u;
+        if (b.score_pub && threadIdx.x < kScorePubRanges) b.score_pub[(size_t)qi * kScorePubRanges + threadIdx.x] = 0u;
+    }
     const RangeQuery q = b.queries[qi];
     const uint32_t ns = q.seg_end - q.seg_begin;
     const uint64_t entries = (uint64_t)ns * (q.n_ranges + 1u);
@@ -177,6 +179,7 @@ struct ScoreLds {
     uint32_t wave_tot[kWaves];
     uint32_t red[4];                            // slot base, count, max key, ~min key
     uint32_t cell_cursor;                       // cells handed out | multi documents << 16
+    uint32_t pub_floor;                         // compact key lists: the floor the query's published scores gave when the workgroup started
     __device__ __forceinline__ uint32_t* bitmap() { return region_a; }
     __device__ __forceinline__ uint16_t* word_rank() { return reinterpret_cast<uint16_t*>(region_a + kBitWords); }
     __device__ __forceinline__ float* cellv() { return reinterpret_cast<float*>(region_a); }
@@ -191,6 +194,8 @@ static_assert(kRangeMaxRefs <= 64, "one bit per reference in the presence masks"
 struct ScoreRange {
     uint32_t qi, cap, slot_base, doc0, n_words;
     bool count_each;
+    bool publish = false;   // compact key lists: this range publishes its score word (ScoreRange::pub_slot) for the query's other ranges
+    uint32_t pub_slot = 0;
 };
 
 // Phases 1-6 for a workgroup whose lanes carry NITER postings each (NITER * 256 >= cap): compiled per NITER so that the
@@ -438,22 +443,38 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
             my_count += in_map ? 1u : 0u;
             ko[n] = (in_map && e < cap) ? f32_to_ordered(score) : 0u;
         }
-        // the floor other workgroups of this query have published so far (loaded here, where few registers are live; its
-        // latency passes behind the bound below and the barrier)
-        const uint32_t tau0 = __hip_atomic_load(&b.results[qi].score_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t best = ko[0];
 #pragma unroll
         for (int n = 1; n < NITER; ++n) best = max(best, ko[n]);
         const uint32_t kq = q.topk, jshare = (kq + kWaves - 1u) / kWaves;
         uint32_t wb = 0u;
-        if (kq != 0u && jshare <= 64u) {  // the jshare-th largest of the wave's lane bests (0: fewer lanes hold a key)
+        if (kq != 0u && jshare <= 64u) {
+            // the jshare-th largest of the wave's lane bests, to its leading 24 bits (15 mantissa bits: a LOWER bound of it, 0.003 %
+            // below at most) in 24 dependent ballot steps — one compare each, the counting is scalar: the launch is bound by
+            // latency, and this chain sits on every workgroup's critical path (0: fewer than jshare lanes hold a key).
+            // Tried and dropped (profiles/r05_k3r_compact_ab_v*.log): whole keys — score word, then document — as floors (ties
+            // are not what lets keys through: same survivors, +0.7 us per query); a second chain for the 2 jshare-th largest, two
+            // waves vouching for all topk (the waves of a range see different lists: 9 -> 6 % survivors, +0.2 us per query, the
+            // top-k no faster).
 #pragma unroll
-            for (int bit = 31; bit >= 0; --bit) {
+            for (int bit = 31; bit >= 8; --bit) {
                 const uint32_t t = wb | (1u << bit);
                 wb = (uint32_t)__popcll(__ballot(best >= t)) >= jshare ? t : wb;
             }
         }
         if (lane == 0) L.wave_tot[wave] = wb;  // (the prefix sums of phase 2 are consumed)
+        if (rg.publish) {
+            // (workgroup-uniform: one of the query's first ranges) what this range publishes for the others' floor: the 4th
+            // largest lane best of its best wave — 4 documents at or above it (the smallest of the four wave MAXIMA was
+            // published first: the wave that saw no rare term drags it under the local floors, profiles/r05_k3r_compact_ab_v8.log)
+            uint32_t w4 = 0u;
+#pragma unroll
+            for (int bit = 31; bit >= 8; --bit) {
+                const uint32_t t = w4 | (1u << bit);
+                w4 = (uint32_t)__popcll(__ballot(best >= t)) >= 4u ? t : w4;
+            }
+            if (lane == 0) L.df_lds[wave] = w4;  // (df_lds: the counting modes' table, unused here)
+        }
         if (n_cells != 0u) {  // (workgroup-uniform) ---- 6. the multi-posting documents: folded as below, their score word parked in LDS
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < n_multi; i += kThreads) {
@@ -474,7 +495,8 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
         uint32_t lb = L.wave_tot[0];
 #pragma unroll
         for (int w = 1; w < kWaves; ++w) lb = min(lb, L.wave_tot[w]);
-        const uint32_t floor_w = kq == 0u ? 0xffffffffu : max(max(lb, tau0), 1u);
+        // (L.pub_floor: what the query's published scores gave when this workgroup started — range_score_main, wave 1)
+        const uint32_t floor_w = kq == 0u ? 0xffffffffu : max(max(lb, L.pub_floor), 1u);
         constexpr int kMultiRounds = kMultiMax / kThreads;
         // (the multi-posting documents' score words are read from LDS where they are used — counted here, written below —
         // instead of being carried in registers across the barriers: the kernel's 64-register budget, eight workgroups per CU)
@@ -491,19 +513,29 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
             sm[NITER + t] = (uint32_t)t * kThreads < n_multi ? __ballot(i < n_multi && (uint32_t)md_mask[i] >= floor_w) : 0ull;
             tot += (uint32_t)__popcll(sm[NITER + t]);
         }
-        uint32_t woff = 0u;
-        if (lane == 0 && tot) woff = atomicAdd(&L.red[2], tot);
-        woff = __shfl(woff, 0, 64);
-        __syncthreads();
+        // one cursor bump per WAVE, no barrier behind the floor's: a workgroup-wide bump (LDS offsets, barrier, one global atomic,
+        // barrier) put two barriers and a returning global atomic in a row on every workgroup's critical path — 3.5 -> 4.3 us per
+        // query (profiles/r05_k3r_compact_ab_v2.log); the cursors of different queries live 1 KB apart, ~1 500 bumps each
+        uint32_t at = 0u;
+        if (lane == 0 && tot) at = atomicAdd(&b.results[qi].n_keys, tot);
+        at = __shfl(at, 0, 64);
         if (threadIdx.x == 0) {
-            const uint32_t total = L.red[2];
-            L.red[3] = total ? atomicAdd(&b.key_count[qi], total) : 0u;
-            if (lb > tau0) atomicMax(&b.results[qi].score_floor, lb);
             if (L.red[1]) atomicAdd(&b.results[qi].count, L.red[1]);
+            if (b.debug & 16u) {  // ORAMA_K3R_DBG=16 (with ORAMA_K3R_STATS=1): how many workgroups found a published floor, the largest one, the largest local one
+                if (L.pub_floor) atomicAdd(&b.results[qi].pad0[0], 1u);
+                if (L.pub_floor > lb) atomicAdd(&b.results[qi].pad0[1], 1u);
+                atomicMax(&b.results[qi].score_floor, L.pub_floor);
+                atomicMax(&b.results[qi].pad0[2], lb);
+            }
+            if (rg.publish) {
+                uint32_t v = L.df_lds[0];
+#pragma unroll
+                for (int w = 1; w < kWaves; ++w) v = max(v, L.df_lds[w]);
+                // (one atomic per publisher and address, performed at the memory side: visible to the other XCDs' agent-scope loads)
+                if (v) atomicMax(&b.score_pub[(size_t)qi * kScorePubRanges + rg.pub_slot], v);
+            }
         }
-        __syncthreads();
         unsigned long long* const lst = b.keys + q.key_off;
-        uint32_t at = L.red[3] + woff;
         const unsigned long long below_me = (1ull << lane) - 1ull;
 #pragma unroll
         for (int n = 0; n < NITER; ++n) {
@@ -612,17 +644,32 @@ __device__ __forceinline__ void range_score_main(const RangeBatch& b) {
     __shared__ ScoreLds<WIDE> L;
 
     // (query, range) of this workgroup: the batch's pairs laid end to end
-    uint32_t qi = 0;
-    {
+    uint32_t qi = 0, r = 0;
+    if constexpr (COMPACT) {
+        // compact key lists: the batch is scored in kRangeStripes passes over its queries (RangeBatch::stripe_start), so that a
+        // query's ranges are scored THROUGHOUT the launch: its first ranges have published their scores by the time most of
+        // the others start.  (Query after query, the ~400 workgroups of a query are dispatched together and none finds a
+        // floor; range-major — workgroup w = range w / n of query w % n — ties the launch to the LARGEST query of the batch:
+        // 3.5 -> 6.7 us per query on unsorted batches, profiles/r05_k3r_compact_ab_v5.log.)
+        uint32_t lo = 0, hi = kRangeStripes * kRangeBatchMax;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (b.stripe_start[mid] <= blockIdx.x) lo = mid; else hi = mid;
+        }
+        // (entries of equal value = empty (stripe, query) cells: the LAST of them is the one that holds the workgroup)
+        qi = lo % kRangeBatchMax;
+        const uint32_t stripe = lo / kRangeBatchMax;
+        r = (uint32_t)((uint64_t)stripe * b.queries[qi].n_ranges / kRangeStripes) + (blockIdx.x - b.stripe_start[lo]);
+    } else {
         uint32_t lo = 0, hi = b.n_queries;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
             if (b.range_start[mid] <= blockIdx.x) lo = mid; else hi = mid;
         }
         qi = lo;
+        r = blockIdx.x - b.range_start[qi];
     }
     const RangeQuery q = b.queries[qi];
-    const uint32_t r = blockIdx.x - b.range_start[qi];
     if (r >= q.n_ranges) return;
     if (DF_ONLY && !q.want_df) return;
     const uint32_t ns = q.seg_end - q.seg_begin;
@@ -633,6 +680,11 @@ __device__ __forceinline__ void range_score_main(const RangeBatch& b) {
     rg.count_each = DF_ONLY && q.want_df == 2u;  // every token has ONE list: a kept posting is its own (token, document) pair
     rg.n_words = (min(q.width, kRangeMaxWidth) + 31u) >> 5;
     rg.doc0 = r * q.width;
+    if constexpr (COMPACT) {
+        // the publishers: the query's first kScorePubRanges ranges — the ones the range-major grid scores first
+        rg.publish = r < kScorePubRanges;
+        rg.pub_slot = r;
+    }
 
     // ---- 0. wave 0: the range's run of every reference, their offsets among the gathered postings, the block table;
     //         the other waves: clear the bitmap
@@ -685,6 +737,23 @@ __device__ __forceinline__ void range_score_main(const RangeBatch& b) {
         }
     } else if (!rg.count_each) {
         for (uint32_t w = threadIdx.x - 64u; w < rg.n_words; w += kThreads - 64u) L.bitmap()[w] = 0u;
+        if constexpr (COMPACT) {
+            if (wave == 1) {
+                // the floor the query's first ranges have published so far: the ceil(topk / 4)-th largest of their words (each
+                // vouches for 4 documents at or above its word; unpublished = 0), to its leading 24 bits; 0: not enough yet
+                const uint32_t v = __hip_atomic_load(&b.score_pub[(size_t)qi * kScorePubRanges + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t need = (q.topk + 3u) / 4u;
+                uint32_t fl = 0u;
+                if (q.topk != 0u && need <= kScorePubRanges) {
+#pragma unroll
+                    for (int bit = 31; bit >= 8; --bit) {
+                        const uint32_t t = fl | (1u << bit);
+                        fl = (uint32_t)__popcll(__ballot(v >= t)) >= need ? t : fl;
+                    }
+                }
+                if (lane == 0) L.pub_floor = fl;
+            }
+        }
     }
     __syncthreads();
     const uint32_t cap = L.seg_off[ns];
@@ -844,9 +913,13 @@ int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStr
     } else {
         // (plain: the pre-divided tf at hand, nothing of the batch asks for a score map, OMC multipliers or min / max)
         const bool plain = !b.map_idx && !b.omc_dense && !b.any_minmax && b.post_ntf;
-        ORAMA_REQUIRE(!b.key_count || (plain && !wide), "internal: compact key lists need the plain scoring launch");
+        ORAMA_REQUIRE(!b.compact_keys || (plain && !wide), "internal: compact key lists need the plain scoring launch");
         if (wide) hipLaunchKernelGGL((range_score_kernel<false, true>), dim3(grid), dim3(kThreads), 0, stream, b);
-        else if (plain && b.key_count) hipLaunchKernelGGL(range_score_compact_kernel, dim3(grid), dim3(kThreads), 0, stream, b);
+        else if (plain && b.compact_keys) {
+            ORAMA_REQUIRE(b.score_pub, "internal: compact key lists without their published-score table");
+            ORAMA_REQUIRE(b.stripe_start[kRangeStripes * kRangeBatchMax] == grid, "internal: stripe table not filled");
+            hipLaunchKernelGGL(range_score_compact_kernel, dim3(grid), dim3(kThreads), 0, stream, b);
+        }
         else if (plain) hipLaunchKernelGGL((range_score_kernel<false, false, true>), dim3(grid), dim3(kThreads), 0, stream, b);
         else hipLaunchKernelGGL((range_score_kernel<false, false>), dim3(grid), dim3(kThreads), 0, stream, b);
     }

@@ -11,6 +11,8 @@ constexpr uint32_t kRangeCap = 2048;     // postings one workgroup scores in LDS
 constexpr uint32_t kRangeMaxWidth = 32768;  // documents per range (one bit each in the workgroup's LDS bitmap)
 constexpr uint32_t kRangeMaxRefs = 64;   // non-empty posting lists per query: one bit each in the scoring launch's presence masks
 constexpr uint32_t kRangeBatchMax = 32;  // queries scored by one set of launches
+constexpr uint32_t kRangeStripes = 8;     // compact key lists: the scoring launch walks the batch in this many passes over its queries
+constexpr uint32_t kScorePubRanges = 64;  // compact key lists: ranges of a query that publish a score for the others' floor (one per lane)
 
 // One (token, posting list) reference of one query of the batch.
 struct RangeSeg {
@@ -52,6 +54,8 @@ struct RangeResult {
     uint32_t pad4[30];
     uint32_t score_floor; // compact key lists: ordered(score) that at least `topk` documents scored so far reach (monotone)
     uint32_t pad5[31];
+    uint32_t n_keys;      // compact key lists: keys appended so far (the cursor; the top-k reads it as the list's length)
+    uint32_t pad6[31];
 };
 
 struct RangeBatch {
@@ -64,6 +68,11 @@ struct RangeBatch {
     // the scoring launch is a 1-D grid over the (query, range) pairs that exist: workgroup w scores range
     // w - range_start[q] of the query q with range_start[q] <= w < range_start[q + 1]
     uint32_t range_start[kRangeBatchMax + 1] = {0};
+    // compact key lists: the launch scores the batch in kRangeStripes passes — stripe s holds ranges [s n / S, (s + 1) n / S) of
+    // every query (n = its ranges), queries in order inside a stripe — so that every query's ranges are scored THROUGHOUT
+    // the launch whatever the queries' sizes: stripe_start[s * kRangeBatchMax + q] = first workgroup of (stripe s, query q),
+    // unused queries repeat the next entry; stripe_start[S * kRangeBatchMax] = all pairs
+    uint32_t stripe_start[kRangeStripes * kRangeBatchMax + 1] = {0};
     uint64_t max_bound_entries = 0;      // largest references x (ranges + 1) of a query: grid.x of the bounds launch
     const uint32_t* post_doc = nullptr;
     const uint32_t* post_val = nullptr;
@@ -79,11 +88,19 @@ struct RangeBatch {
     const float* idf = nullptr;          // [n_queries][kMaxTokens]
     const float* omc_dense = nullptr;
     unsigned long long* keys = nullptr;  // ordered(score) << 32 | ~local doc; 0 = empty
-    // Compact key lists (round 5; plain top-k batches): key_count[query] starts at zero and the scoring launch APPENDS — a
-    // workgroup writes only the keys that reach its floor (a score at least `topk` documents are known to reach), behind one
-    // cursor bump per workgroup; the top-k reads key_count[query] keys instead of one slot per posting.  nullptr: one slot
-    // per posting (score maps, OMC, hybrid min / max, wide masks).
-    uint32_t* key_count = nullptr;
+    // Compact key lists (round 5; plain top-k batches): results[query].n_keys starts at zero (the bounds launch clears the
+    // result words) and the scoring launch APPENDS — a workgroup writes only the keys that reach its floor (a score at least
+    // `topk` documents are known to reach), behind one cursor bump per workgroup; the top-k reads n_keys keys instead of one
+    // slot per posting.  (The cursors of a batch live 1 KB apart, like every other per-query word: 12 K returning atomics
+    // on ONE cache line took the scoring launch from 3.5 to 5.7 us per query — profiles/r05_k3r_compact_ab_v1.log.)
+    // 0: one slot per posting (score maps, OMC, hybrid min / max, wide masks).
+    uint32_t compact_keys = 0;
+    // Compact key lists: what the FIRST kScorePubRanges ranges of each query publish — one word each, the smallest of the
+    // workgroup's four wave maxima: at least 4 of the range's documents score that or more — [n_queries][kScorePubRanges] u32,
+    // zeroed by the bounds launch.  The ceil(topk / 4)-th largest published word is a floor for every later range of the query
+    // (that many ranges hold 4 documents each at or above it).  Plain stores and loads: same-address global atomics (a
+    // cursor per query, a histogram of the scores) cost ~50 ns EACH on this chip — profiles/r05_k3r_compact_ab_v*.log.
+    uint32_t* score_pub = nullptr;
     RangeResult* results = nullptr;
     // score-map mode (n_queries == 1): besides its key, every slot gets the map entry it stands for — map_idx[slot] = local
     // document (0xffffffff: none), map_score[slot] = its score (after OMC; NaN stays), map_emit[document] = epoch << 32 | slot:

@@ -239,6 +239,10 @@ struct orama_ctx {
     // K3r's plain top-k batches append only the keys that can still reach the answer (round 5, bm25_ranges.hip "COMPACT");
     // false = one key slot per posting as in round 4 (ORAMA_K3R_COMPACT=0, orama_ctx_set_bm25_ranges(ctx, 3): A/B runs)
     bool bm25_compact_keys = true;
+    // ... for batches of at least this many queries: the lists' cursors are bumped by returning global atomics (~50 ns each on
+    // one address) and a lone query's 400 workgroups run together — 14.7 -> 11.7 K single calls per second with compact lists
+    // (orama_ctx_set_bm25_ranges(ctx, 4): every batch size, for the parity tests)
+    uint32_t bm25_compact_min = 8;
     int k3r_merge = 0;  // comparison builds only (ORAMA_COMPARISON_KERNELS=1): ORAMA_K3R_MERGE=1 scores ranges with the round-3 merge tree
     // stores created as ORAMA_DTYPE_F32_SHADOW16 answer orama_vec_search in two stages (fp16 candidates, fp32 decision);
     // 0 = always the plain fp32 scan, 2 = two stages also where the plain scan is expected to be faster (small stores

@@ -532,10 +532,11 @@ int orama_ctx_set_two_stage(orama_ctx* ctx, int on) {
 
 int orama_ctx_set_bm25_ranges(orama_ctx* ctx, int on) {
     ORAMA_REQUIRE(ctx, "null context");
-    ORAMA_REQUIRE(on >= 0 && on <= 3, "bm25 ranges mode %d outside [0, 3]", on);
+    ORAMA_REQUIRE(on >= 0 && on <= 4, "bm25 ranges mode %d outside [0, 4]", on);
     ctx->bm25_ranges = on != 0;
-    ctx->bm25_ranges_hybrid = on == 1 || on == 3;
+    ctx->bm25_ranges_hybrid = on == 1 || on >= 3;
     ctx->bm25_compact_keys = on != 3;
+    ctx->bm25_compact_min = on == 4 ? 1u : 8u;
     return ORAMA_OK;
 }
 

@@ -722,6 +722,14 @@ struct CallTrace {
     }
 };
 
+// ORAMA_K3R_STATS=1: one stderr line per query scored with compact key lists (keys appended against postings).
+static bool k3r_stats_enabled() {
+    static const bool on = [] { const char* e = std::getenv("ORAMA_K3R_STATS"); return e && std::atoi(e) != 0; }();
+    return on;
+}
+
+static std::atomic<uint32_t> k3r_stats_lines{0};  // (the first 24 queries of the process)
+
 // Score `n_jobs` eligible queries (each validated by check_params and ranges_eligible) on sc->stream; synchronises.
 // With a second set (`sc2`) the sets of launches are double-buffered: while the device scores one chunk of 32 queries, the
 // host builds and uploads the tables of the next one on the other set's stream (the host side of a chunk — reference
@@ -923,12 +931,12 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         ORAMA_SUPPORT(virt < 0xffffffffull && bounds_entries < 0xffffffffull, "query batch references too many postings");
         // Compact key lists (round 5): a plain top-k batch — no score map, OMC, hybrid min / max, 64-bit masks, and the store's
         // pre-divided tf at hand (the conditions of the PLAIN scoring launch) — appends only the keys that can still reach the
-        // answer; the per-list lengths the top-k reads then START AT ZERO and are counted up by the scoring launch.
-        bool compact = !df_pass && c.kmax != 0 && p->ctx->bm25_compact_keys && !(n_jobs == 1 && jobs[0].map) && !(apply_omc && p->has_omc) &&
+        // answer; the list lengths the top-k reads are then the cursors the scoring launch counted up (RangeResult::n_keys).
+        // (not for small batches: orama_ctx::bm25_compact_min)
+        bool compact = !df_pass && c.kmax != 0 && p->ctx->bm25_compact_keys && nq >= p->ctx->bm25_compact_min && !(n_jobs == 1 && jobs[0].map) && !(apply_omc && p->has_omc) &&
                        p->ntf_valid && b == p->ntf_b;
         for (uint32_t ci = 0; ci < nq && compact; ++ci)
             compact = !queries[ci].track_minmax && queries[ci].seg_end - queries[ci].seg_begin <= 32u;
-        if (compact) c.lens.assign(nq, 0u);
         // device tables: [segs | queries | idf | list lengths]
         const size_t seg_bytes = (segs.size() * sizeof(RangeSeg) + 63) & ~(size_t)63;
         const size_t q_bytes = ((size_t)nq * sizeof(RangeQuery) + 63) & ~(size_t)63;
@@ -949,7 +957,8 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         const uint32_t kk = c.kk = std::max(c.kmax, 1u);
         const size_t res_bytes = c.res_bytes = (size_t)nq * sizeof(RangeResult);
         const size_t out_bytes = res_bytes + (size_t)nq * kk * 12 + (size_t)nq * 4;
-        ORAMA_TRY(sc->misc2.reserve(out_bytes));
+        const size_t pub_off = (out_bytes + 255) & ~(size_t)255;  // (behind what is read back: the published scores of compact lists)
+        ORAMA_TRY(sc->misc2.reserve(pub_off + (compact ? (size_t)nq * kScorePubRanges * 4 : 0)));
         if (!df_pass) ORAMA_TRY(sc->misc3.reserve((size_t)nq * max_total * 8));
         char* d = sc->misc0.as<char>();
         float* d_idf = reinterpret_cast<float*>(d + seg_bytes + q_bytes);
@@ -969,6 +978,18 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             rb.max_refs = std::max(rb.max_refs, queries[ci].seg_end - queries[ci].seg_begin);
             rb.any_minmax |= queries[ci].track_minmax;
         }
+        if (compact) {  // the scoring launch's walk over the batch: kRangeStripes passes over the queries (RangeBatch::stripe_start)
+            uint32_t w = 0;
+            for (uint32_t st = 0; st < kRangeStripes; ++st)
+                for (uint32_t ci = 0; ci < kRangeBatchMax; ++ci) {
+                    rb.stripe_start[st * kRangeBatchMax + ci] = w;
+                    if (ci < nq) {
+                        const uint64_t n = queries[ci].n_ranges;
+                        w += (uint32_t)((st + 1) * n / kRangeStripes - st * n / kRangeStripes);
+                    }
+                }
+            rb.stripe_start[kRangeStripes * kRangeBatchMax] = w;
+        }
         rb.max_bound_entries = max_bound_entries;
         rb.post_doc = p->d_post_doc.as<uint32_t>();
         rb.post_val = p->d_post_val.as<uint32_t>();
@@ -983,7 +1004,8 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         rb.omc_dense = (apply_omc && p->has_omc) ? p->d_omc.as<float>() : nullptr;
         rb.keys = sc->misc3.as<unsigned long long>();
         rb.results = sc->misc2.as<RangeResult>();
-        if (compact) rb.key_count = reinterpret_cast<uint32_t*>(d + seg_bytes + q_bytes + idf_bytes);
+        rb.compact_keys = compact ? 1u : 0u;
+        if (compact) rb.score_pub = reinterpret_cast<uint32_t*>(sc->misc2.as<char>() + pub_off);
         if (n_jobs == 1 && jobs[0].map) {
             // the per-document table is the set's epoch-stamped one (shared with the per-record scorer's use of the set)
             ORAMA_TRY(reserve_zeroed(sc->bm25_emit, (size_t)p->n_docs * 8, s));
@@ -1044,8 +1066,9 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             ORAMA_TRY(sc->misc4.reserve((size_t)keys_topk_scratch_keys((uint32_t)max_total, nq, c.kmax) * 8 + 8));
             ORAMA_TRY(launch_keys_topk(p->ctx, rb.keys, (uint32_t)max_total, max_total, nq, c.kmax, true, p->d_docs.as<uint64_t>(),
                                        sc->misc4.as<unsigned long long>(), nullptr, d_ids, d_val, d_n, s,
-                                       reinterpret_cast<const uint32_t*>(d + seg_bytes + q_bytes + idf_bytes), &rb.results[0].topk_tau,
-                                       (uint32_t)(sizeof(RangeResult) / 8), nullptr, compact));
+                                       compact ? &rb.results[0].n_keys : reinterpret_cast<const uint32_t*>(d + seg_bytes + q_bytes + idf_bytes),
+                                       &rb.results[0].topk_tau, (uint32_t)(sizeof(RangeResult) / 8), nullptr, compact,
+                                       compact ? (uint32_t)(sizeof(RangeResult) / 4) : 1u));
         }
         c.trace.mark(5);
         ORAMA_HIP_TRY(hipMemcpyAsync(h_res, d_out, c.kmax ? out_bytes : res_bytes, hipMemcpyDeviceToHost, s));
@@ -1109,6 +1132,11 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                 continue;
             }
             if (jb.out_count) *jb.out_count = h_res[ci].count;
+            if (c.rb.compact_keys && k3r_stats_enabled() && k3r_stats_lines.fetch_add(1) < 24)
+                fprintf(stderr, "[k3r] query of %llu postings, %u ranges: %u keys appended (%.2f %%), top_k %u | dbg16: %u workgroups found a "
+                        "published floor, %u above their own; largest published %08x, largest local %08x\n",
+                        (unsigned long long)pd.total, c.queries[ci].n_ranges, h_res[ci].n_keys, 100.0 * h_res[ci].n_keys / (double)pd.total,
+                        jb.params->top_k, h_res[ci].pad0[0], h_res[ci].pad0[1], h_res[ci].score_floor, h_res[ci].pad0[2]);
             if (jb.params->top_k) {
                 const uint32_t n = std::min(reinterpret_cast<const uint32_t*>(h_n)[ci], jb.params->top_k);
                 memcpy(jb.out_ids, h_ids + (size_t)ci * kk * 8, (size_t)n * 8);

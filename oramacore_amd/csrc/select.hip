@@ -536,7 +536,7 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
                                                                    uint32_t k, unsigned long long* __restrict__ out,
                                                                    uint64_t out_stride, unsigned long long* tau = nullptr,
                                                                    uint32_t tau_stride = 0, const uint32_t* __restrict__ n_active = nullptr,
-                                                                   uint32_t direct_cap = 0) {
+                                                                   uint32_t direct_cap = 0, uint32_t n_stride = 1) {
     __shared__ unsigned long long s[kKeysChunk];
     __shared__ uint32_t hist[256];
     __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
     const unsigned long long tau0 = tau ? __hip_atomic_load(tau + (uint64_t)qi * tau_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     const unsigned long long* in = keys + (uint64_t)qi * in_stride;
     const uint32_t begin = chunk * kKeysChunk;
-    if (n_per_list) n_keys = min(n_keys, n_per_list[qi]);  // lists shorter than the stride: the tail is not read
+    if (n_per_list) n_keys = min(n_keys, n_per_list[(uint64_t)qi * n_stride]);  // lists shorter than the stride: the tail is not read
     unsigned long long* o = out + (uint64_t)qi * out_stride + (uint64_t)chunk * k;
     // counted lists (direct_cap != 0: the length was produced on the device — K3r's compact key lists): a list the final kernel
     // can take whole is not reduced at all, and a chunk past the end writes nothing — the final kernel reads
@@ -1010,7 +1010,8 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
                                                                   uint32_t* out_n, const uint32_t* __restrict__ n_active = nullptr,
                                                                   const uint32_t* __restrict__ done = nullptr,
                                                                   const unsigned long long* __restrict__ direct_keys = nullptr,
-                                                                  uint64_t direct_stride = 0, uint32_t direct_cap = 0) {
+                                                                  uint64_t direct_stride = 0, uint32_t direct_cap = 0,
+                                                                  uint32_t n_stride = 1) {
     __shared__ SortLds s;
     __shared__ uint32_t valid_s;
     __shared__ uint32_t hist[256];
@@ -1024,7 +1025,7 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
     const unsigned long long* in = keys + (uint64_t)qi * in_stride;
     if (direct_cap) {
         // counted lists (see keys_reduce_kernel): n_per_list is the length of the CALLER's list; `keys` is the reduced level
-        const uint32_t len = n_per_list[qi];
+        const uint32_t len = min(n_per_list[(uint64_t)qi * n_stride], (uint32_t)direct_stride);
         if (len <= direct_cap) {  // (uniform) nothing was reduced: the list itself
             in = direct_keys + (uint64_t)qi * direct_stride;
             n_keys = len;
@@ -1032,7 +1033,7 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
             n_keys = min(n_keys, ((len + kKeysChunk - 1u) / kKeysChunk) * k);
         }
     } else if (n_per_list) {
-        n_keys = min(n_keys, n_per_list[qi]);
+        n_keys = min(n_keys, n_per_list[(uint64_t)qi * n_stride]);
     }
     if (n_keys > k) {
         // More candidates than answers (e.g. 32 chunks x 100 survivors of a scan's wave lists: 3 200 keys for 100 results):
@@ -1192,7 +1193,7 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
                      uint32_t q, uint32_t k, bool descending, const uint64_t* id_map,
                      unsigned long long* d_tmp, uint32_t* out_idx, uint64_t* out_ids, float* out_val,
                      uint32_t* out_n, hipStream_t stream, const uint32_t* d_n_per_list, unsigned long long* d_tau,
-                     uint32_t tau_stride, const uint32_t* d_n_active, bool counted) {
+                     uint32_t tau_stride, const uint32_t* d_n_active, bool counted, uint32_t n_per_list_stride) {
     ORAMA_REQUIRE(k >= 1 && k <= kSelectMaxK && q >= 1 && d_keys && out_val, "keys top-k: bad arguments");
     ProfScope prof(&ctx->prof, "topk_select", stream);
     if (counted && d_n_per_list) {
@@ -1205,36 +1206,41 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
             if (n_keys > cap) {
                 ORAMA_REQUIRE(d_tmp, "keys top-k: scratch missing");
                 hipLaunchKernelGGL(keys_reduce_kernel, d_tau ? dim3(q, chunks) : dim3(chunks, q), dim3(kSortThreads), 0, stream, d_keys,
-                                   n_keys, stride, d_n_per_list, k, d_tmp, (uint64_t)chunks * k, d_tau, tau_stride, d_n_active, cap);
+                                   n_keys, stride, d_n_per_list, k, d_tmp, (uint64_t)chunks * k, d_tau, tau_stride, d_n_active, cap,
+                                   n_per_list_stride);
             }
             hipLaunchKernelGGL(keys_final_kernel, dim3(q), dim3(kSortThreads), 0, stream, d_tmp ? d_tmp : d_keys, chunks * k,
                                (uint64_t)chunks * k, d_n_per_list, k, descending, id_map, out_idx, out_ids, out_val, out_n, d_n_active,
-                               (const uint32_t*)nullptr, d_keys, stride, cap);
+                               (const uint32_t*)nullptr, d_keys, stride, cap, n_per_list_stride);
             ORAMA_HIP_TRY(hipGetLastError());
             return ORAMA_OK;
         }
         // (longer lists: the general levels below, reading the counted lengths at the first one)
     }
+
     const unsigned long long* cur = d_keys;
     uint64_t cur_stride = stride;
     uint32_t n = n_keys;
     unsigned long long* tmp = d_tmp;
     const uint32_t* n_per_list = d_n_per_list;  // applies to the caller's lists only; reduced levels are full
+    uint32_t n_stride = n_per_list_stride;
     while (n > keys_final_capacity(k)) {
         ORAMA_REQUIRE(tmp, "keys top-k: scratch missing");
         const uint32_t chunks = (n + kKeysChunk - 1) / kKeysChunk;
         const uint64_t out_stride = (uint64_t)chunks * k;
         hipLaunchKernelGGL(keys_reduce_kernel, d_tau ? dim3(q, chunks) : dim3(chunks, q), dim3(kSortThreads), 0, stream, cur, n,
-                           cur_stride, n_per_list, k, tmp, out_stride, d_tau, tau_stride, d_n_active);
+                           cur_stride, n_per_list, k, tmp, out_stride, d_tau, tau_stride, d_n_active, 0u, n_stride);
         d_tau = nullptr;  // (a bound belongs to the caller's lists: the next level starts without one)
         cur = tmp;
         cur_stride = out_stride;
         n = chunks * k;
         n_per_list = nullptr;
+        n_stride = 1;
         tmp = tmp + (uint64_t)q * out_stride;  // next level (if any) writes behind this one
     }
     hipLaunchKernelGGL(keys_final_kernel, dim3(q), dim3(kSortThreads), 0, stream, cur, n, cur_stride, n_per_list, k,
-                       descending, id_map, out_idx, out_ids, out_val, out_n, d_n_active);
+                       descending, id_map, out_idx, out_ids, out_val, out_n, d_n_active, (const uint32_t*)nullptr,
+                       (const unsigned long long*)nullptr, (uint64_t)0, 0u, n_stride);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -69,7 +69,7 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
                      unsigned long long* d_tmp, uint32_t* out_idx, uint64_t* out_ids, float* out_val,
                      uint32_t* out_n, hipStream_t stream, const uint32_t* d_n_per_list = nullptr,
                      unsigned long long* d_tau = nullptr, uint32_t tau_stride = 0, const uint32_t* d_n_active = nullptr,
-                     bool counted = false);
+                     bool counted = false, uint32_t n_per_list_stride = 1);
 // Keys of scratch launch_keys_topk needs for lists of n_keys entries.
 uint64_t keys_topk_scratch_keys(uint32_t n_keys, uint32_t q, uint32_t k);
 

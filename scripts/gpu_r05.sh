@@ -51,7 +51,7 @@ for STEP in "$@"; do
       python scripts/pmc_summary.py $O/pmc_k3r keys_ 151000000 mean > $O/pmc_k3r_keys.json 2>>$O/pmc_k3r.err
       for W in ns c2 c3 c5 c4 k3r; do echo "-- $W"; head -8 $O/${W}_kernel_stats.md | cut -c1-180; tail -2 $O/${W}_kernel_stats.md | cut -c1-400; done ;;
     py:*) A=${STEP#py:}; S=${A%%:*}; ARGS=""; [ "$A" != "$S" ] && ARGS=$(echo "${A#*:}" | tr ',' ' '); B=$(basename $S .py)
-      echo "== python $S $ARGS"; timeout 1200 python $S $ARGS > $O/$B.log 2>&1; echo rc=$?; tail -40 $O/$B.log ;;
+      echo "== python $S $ARGS"; ORAMA_K3R_STATS=1 ORAMA_K3R_DBG=${K3R_DBG:-0} timeout 1200 python $S $ARGS > $O/$B.log 2>&1; echo rc=$?; tail -60 $O/$B.log ;;
   esac
 done
 find $O -name "*.csv" -size +2M -delete; find $O -name "*.db" -delete

@@ -20,6 +20,7 @@ rng = np.random.default_rng(0xB26)
 ranks = np.unique(np.exp(rng.uniform(np.log(100), np.log(100000), size=2048)).astype(np.uint32))
 ctx_new, ctx_old = oa.Context(0), oa.Context(0)
 ctx_old.set_bm25_ranges(True, compact_keys=False)
+ctx_new.set_bm25_ranges(True, compact_keys=True)  # (compact for batches of 8 queries and more; single calls keep round 4's lists)
 posts = {}
 for name, ctx in (("compact (r05)", ctx_new), ("slot per posting (r04)", ctx_old)):
     p = ft.PostingsStore(ctx)
