@@ -1267,14 +1267,21 @@ int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
     }
     ORAMA_REQUIRE(p.state && p.keys, "top-k: scratch missing");
     const uint64_t expect = p.n_hint ? p.n_hint : p.n;
-    if (p.keys_capacity >= (uint64_t)p.q * kSelectMaxK && expect <= 16ull * kKeysChunk && select_pairs_enabled()) {
+    const uint64_t list_chunks = std::max<uint64_t>(1, (expect + kKeysChunk - 1) / kKeysChunk);
+    // A FEW long lists (a lone query's dense distance array: 1 M values = 122 chunks) take the two launches as well, with as
+    // many parts as the final kernel can order (kSelectMaxK / k: 40 at k = 100) walking at most 8 rounds each — the
+    // histogram form is 16 launches with a gap before each: 98 us behind a 240 us scan of 1 M x 384 rows
+    // (profiles/r04_c2_kernel_stats.md), the two launches ~30.
+    const uint32_t parts_cap = p.q <= 4 ? std::max<uint32_t>(16u, kSelectMaxK / p.k) : 16u;
+    const bool few_long = p.q <= 4 && list_chunks <= 8ull * std::min<uint32_t>(parts_cap, std::max<uint32_t>(1u, kSelectMaxK / p.k));
+    if (p.keys_capacity >= (uint64_t)p.q * kSelectMaxK && (list_chunks <= 16 || few_long) && select_pairs_enabled()) {
         // (value, index) lists in two launches: `parts` workgroups per list keep their best k, one orders parts * k keys
         // (lists expected to be longer than 16 chunks keep the histogram passes, which spread one list over the chip).
         // Lists of a length known here (the dense heads of the fp16 scans: 131 072 distances per query) take it too since
         // round 4: 16 workgroups per list, one round each.
         uint32_t parts = kSelectMaxK / p.k;
-        parts = std::min<uint32_t>(parts, (uint32_t)std::max<uint64_t>(1, (expect + kKeysChunk - 1) / kKeysChunk));
-        parts = std::min<uint32_t>(parts, 16u);
+        parts = std::min<uint32_t>(parts, (uint32_t)list_chunks);
+        parts = std::min<uint32_t>(parts, parts_cap);
         // lists of a known length (dense heads): two resident waves of workgroups (2 per CU) — a workgroup's first round costs
         // ~10 us (bound, ~2k survivors, their ranks), every later one runs under the floor of the k-th best so far: 256 lists
         // x 16 parts of one round each took 108 us, x 4 parts of four rounds 88-97

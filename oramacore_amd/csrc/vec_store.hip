@@ -496,7 +496,8 @@ int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_
     }
     ORAMA_TRY(sc->dist.reserve((size_t)group * (size_t)(n ? n : 1) * sizeof(float)));
     ORAMA_TRY(sc->sel_state.reserve(sizeof(SelectState) * (size_t)group));
-    ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * (size_t)group * k));
+    // (kSelectMaxK keys per list: what the two-launch (value, index) selection wants — a lone query over 1 M rows takes it)
+    ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * (size_t)group * std::max<uint32_t>(k, kSelectMaxK)));
     for (uint32_t q0 = 0; q0 < q; q0 += group) {
         const uint32_t gq = (q - q0) < group ? (q - q0) : group;
         ORAMA_TRY(scan_begin(sc, s_scan, s));
@@ -534,6 +535,7 @@ int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_
         p.id_map = w.row_doc;
         p.state = sc->sel_state.as<SelectState>();
         p.keys = sc->sel_keys.as<unsigned long long>();
+        p.keys_capacity = (uint64_t)group * std::max<uint32_t>(k, kSelectMaxK);
         p.out_ids = d_out_ids + (size_t)q0 * k;
         p.out_val = d_out_dist + (size_t)q0 * k;
         p.out_n = d_out_n + q0;

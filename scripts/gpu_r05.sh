@@ -50,6 +50,12 @@ for STEP in "$@"; do
       python scripts/pmc_summary.py $O/pmc_k3r range_score_kernel 151000000 mean > $O/pmc_k3r_range_score.json 2>$O/pmc_k3r.err
       python scripts/pmc_summary.py $O/pmc_k3r keys_ 151000000 mean > $O/pmc_k3r_keys.json 2>>$O/pmc_k3r.err
       for W in ns c2 c3 c5 c4 k3r; do echo "-- $W"; head -8 $O/${W}_kernel_stats.md | cut -c1-180; tail -2 $O/${W}_kernel_stats.md | cut -c1-400; done ;;
+    c2) echo "== bench c2"; timeout 600 python bench.py --workload c2 --steps 200 --warmup 10 --no-cpu-baseline --no-two-stage --configs none --no-pmc > $O/bench_c2.json 2> $O/bench_c2.err; python - $O/bench_c2.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print({k: d[k] for k in ("value", "ms_per_step", "latency_ms_p50", "latency_ms_p95", "latency_ms_p50_host_api")}, d["roofline"]["frac"], d["step_breakdown_us"])
+PY
+      ;;
     py:*) A=${STEP#py:}; S=${A%%:*}; ARGS=""; [ "$A" != "$S" ] && ARGS=$(echo "${A#*:}" | tr ',' ' '); B=$(basename $S .py)
       echo "== python $S $ARGS"; ORAMA_K3R_STATS=1 ORAMA_K3R_DBG=${K3R_DBG:-0} timeout 1200 python $S $ARGS > $O/$B.log 2>&1; echo rc=$?; tail -60 $O/$B.log ;;
   esac
