@@ -291,7 +291,11 @@ void shrink_remember(orama_post* p, const orama_term_ref* refs, uint32_t n_refs,
 }
 
 // (Re)compute p->d_post_ntf for the store's current postings and average lengths.  Caller holds p->mu exclusively.
-int refresh_post_ntf(orama_post* p) {
+// The table is an OPTIMISATION (two IEEE divisions less per posting and query): the postings, documents and averages are
+// committed before this runs, so a failure here — out of memory for the +4 B per posting, a HIP error — must not fail the
+// build / append that called it (a caller that retried the append would append twice: ADVICE r04).  It leaves ntf_valid
+// false — the kernels then divide themselves, same operations, same bits — and reports OK.
+int refresh_post_ntf_try(orama_post* p) {
     {  // (every change of the postings comes through here: what was counted over the old lists is forgotten)
         std::lock_guard<std::mutex> g(p->df_union_mu);
         p->df_union.clear();
@@ -314,6 +318,14 @@ int refresh_post_ntf(orama_post* p) {
                                     nullptr));
     ORAMA_HIP_TRY(hipDeviceSynchronize());
     p->ntf_valid = true;
+    return ORAMA_OK;
+}
+int refresh_post_ntf(orama_post* p) {
+    if (refresh_post_ntf_try(p) != ORAMA_OK) {
+        p->ntf_valid = false;
+        (void)hipGetLastError();  // (a failed allocation leaves a sticky-looking error code behind: the store itself is intact)
+        clear_error();
+    }
     return ORAMA_OK;
 }
 
