@@ -530,13 +530,14 @@ __device__ __forceinline__ uint32_t rank_by_counting(const unsigned long long* s
 // holds the k-th key, everything above it is taken; stops as soon as a bin is taken whole.
 // (Walking several chunks per workgroup, carrying the best k from round to round, was measured and dropped: 172 -> 168 K
 // BM25 queries/s — profiles/r04_keys_topk_phases.log (d).)
-__global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigned long long* __restrict__ keys,
+__global__ __launch_bounds__(kSortThreads, 8) void keys_reduce_kernel(const unsigned long long* __restrict__ keys,
                                                                    uint32_t n_keys, uint64_t in_stride,
                                                                    const uint32_t* __restrict__ n_per_list,
                                                                    uint32_t k, unsigned long long* __restrict__ out,
                                                                    uint64_t out_stride, unsigned long long* tau = nullptr,
                                                                    uint32_t tau_stride = 0, const uint32_t* __restrict__ n_active = nullptr,
-                                                                   uint32_t direct_cap = 0, uint32_t n_stride = 1) {
+                                                                   uint32_t direct_cap = 0, uint32_t n_stride = 1,
+                                                                   uint32_t chunk_step = 0) {
     __shared__ unsigned long long s[kKeysChunk];
     __shared__ uint32_t hist[256];
     __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
@@ -544,8 +545,14 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
     // with a bound the grid is (lists, chunks): workgroups are dispatched list-fastest, so the first wave of workgroups
     // holds the first chunks of EVERY list and the later chunks of each list find a bound (chunk-fastest, a list's chunks
     // would all start together and none would)
-    const uint32_t qi = tau ? blockIdx.x : blockIdx.y, chunk = tau ? blockIdx.y : blockIdx.x;
+    const uint32_t qi = tau ? blockIdx.x : blockIdx.y, chunk0 = tau ? blockIdx.y : blockIdx.x;
     if (n_active && qi >= *n_active) return;  // (uniform) only the first *n_active lists exist: nothing of the others is read or written
+    if (n_per_list) n_keys = min(n_keys, n_per_list[(uint64_t)qi * n_stride]);  // lists shorter than the stride: the tail is not read
+    const int lane = threadIdx.x & 63, wave = (int)uniform_u32(threadIdx.x >> 6);
+    // chunk_step != 0 (counted lists: the grid holds a few workgroups per list, not one per chunk of the worst case): the
+    // workgroup walks chunks chunk0, chunk0 + chunk_step, ... of its list — each one the same procedure, under the list's
+    // running bound as the earlier ones left it
+    auto process = [&](const uint32_t chunk) {
     // A list's chunks share a running bound (tau, zero at launch): every workgroup that had to select publishes the k-th best
     // key of its chunk — a lower bound of the list's k-th best — and a chunk treats what lies below the bound it finds as
     // empty: about k of its 8 192 keys are left, the histogram rounds (LDS atomics that pile onto a few bins, since the
@@ -554,7 +561,6 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
     const unsigned long long tau0 = tau ? __hip_atomic_load(tau + (uint64_t)qi * tau_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     const unsigned long long* in = keys + (uint64_t)qi * in_stride;
     const uint32_t begin = chunk * kKeysChunk;
-    if (n_per_list) n_keys = min(n_keys, n_per_list[(uint64_t)qi * n_stride]);  // lists shorter than the stride: the tail is not read
     unsigned long long* o = out + (uint64_t)qi * out_stride + (uint64_t)chunk * k;
     // counted lists (direct_cap != 0: the length was produced on the device — K3r's compact key lists): a list the final kernel
     // can take whole is not reduced at all, and a chunk past the end writes nothing — the final kernel reads
@@ -565,7 +571,6 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
         return;
     }
     const uint32_t n_in = min(kKeysChunk, n_keys - begin);
-    const int lane = threadIdx.x & 63, wave = (int)uniform_u32(threadIdx.x >> 6);
     ORAMA_KEYS_STAMP(0);
     // Stream the chunk through REGISTERS: every lane issues all of its loads first (16 bytes each where the chunk is
     // 16-byte aligned: the whole 64 KB chunk is in flight at once), drops what lies below the running bound, and only the
@@ -719,6 +724,15 @@ __global__ __launch_bounds__(kSortThreads) void keys_reduce_kernel(const unsigne
     const uint32_t taken = min(cursor, k);
     for (uint32_t i = taken + threadIdx.x; i < k; i += blockDim.x) o[i] = 0ull;
     ORAMA_KEYS_STAMP(5);
+    };
+    if (!chunk_step) {
+        process(chunk0);
+        return;
+    }
+    for (uint32_t c = chunk0; (uint64_t)c * kKeysChunk < n_keys; c += chunk_step) {
+        process(c);
+        __syncthreads();  // (the next chunk reuses the key buffer, the cursors and the selection words)
+    }
 }
 
 // ---------------------------------------------------------------- (value, index) lists in two launches
@@ -1205,9 +1219,12 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
         if ((uint64_t)chunks * k <= cap) {
             if (n_keys > cap) {
                 ORAMA_REQUIRE(d_tmp, "keys top-k: scratch missing");
-                hipLaunchKernelGGL(keys_reduce_kernel, d_tau ? dim3(q, chunks) : dim3(chunks, q), dim3(kSortThreads), 0, stream, d_keys,
+                // (a few workgroups per list, each walking every walkers-th chunk that exists: the worst case is one slot per
+                // posting — 72 to 200 chunks per list of which 3 to 8 exist, thousands of workgroups that end at once)
+                const uint32_t walkers = std::min<uint32_t>(chunks, 8u);
+                hipLaunchKernelGGL(keys_reduce_kernel, d_tau ? dim3(q, walkers) : dim3(walkers, q), dim3(kSortThreads), 0, stream, d_keys,
                                    n_keys, stride, d_n_per_list, k, d_tmp, (uint64_t)chunks * k, d_tau, tau_stride, d_n_active, cap,
-                                   n_per_list_stride);
+                                   n_per_list_stride, walkers);
             }
             hipLaunchKernelGGL(keys_final_kernel, dim3(q), dim3(kSortThreads), 0, stream, d_tmp ? d_tmp : d_keys, chunks * k,
                                (uint64_t)chunks * k, d_n_per_list, k, descending, id_map, out_idx, out_ids, out_val, out_n, d_n_active,

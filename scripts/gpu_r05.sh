@@ -24,9 +24,12 @@ for line in open(sys.argv[1]):
     if line.startswith("{") and '"roofline"' in line:
         d = json.loads(line)
         rf = d["roofline"]
-        print(f"\nthe same (profiled) run's own record: ms_per_step {d['ms_per_step']:.4f}; HIP events: median scan per step "
-              f"{rf.get('median_scan_ms_per_step')} ms over {rf.get('steps_in_median')} steps, average launch {rf['avg_launch_ms']:.4f} ms; "
-              f"clocks during the timed region: {json.dumps(rf.get('clocks_during_timed_region', {}))}")
+        c = rf.get("clocks_during_timed_region", {})
+        c = {k: c.get(k) for k in ("available", "samples", "sclk_mhz_median", "power_w_mean", "power_w_from_energy_counter",
+                                   "ppt_throttle_residency_pct", "pci_bus_id")}
+        print(f"\nclocks during the timed region of this (profiled) run: {json.dumps(c)}; ms_per_step {d['ms_per_step']:.4f}, "
+              f"HIP events: median scan per step {rf.get('median_scan_ms_per_step')} ms over {rf.get('steps_in_median')} steps, "
+              f"average launch {rf['avg_launch_ms']:.4f} ms")
 PY
 }
 for STEP in "$@"; do
@@ -47,8 +50,9 @@ for STEP in "$@"; do
       for C in FETCH_SIZE WRITE_SIZE; do
         echo "== pmc k3r $C"; (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_k3r/$C -o p -- python $R/scripts/k3r_chunk_probe.py > $O/pmc_k3r_$C.log 2>&1)
       done
-      python scripts/pmc_summary.py $O/pmc_k3r range_score_kernel 151000000 mean > $O/pmc_k3r_range_score.json 2>$O/pmc_k3r.err
-      python scripts/pmc_summary.py $O/pmc_k3r keys_ 151000000 mean > $O/pmc_k3r_keys.json 2>>$O/pmc_k3r.err
+      python scripts/pmc_summary.py $O/pmc_k3r range_score_ 151000000 mean > $O/pmc_k3r_range_score.json 2>$O/pmc_k3r.err
+      python scripts/pmc_summary.py $O/pmc_k3r keys_reduce_kernel 151000000 mean > $O/pmc_k3r_keys_reduce.json 2>>$O/pmc_k3r.err
+      python scripts/pmc_summary.py $O/pmc_k3r keys_final_kernel 151000000 mean > $O/pmc_k3r_keys_final.json 2>>$O/pmc_k3r.err
       for W in ns c2 c3 c5 c4 k3r; do echo "-- $W"; head -8 $O/${W}_kernel_stats.md | cut -c1-180; tail -2 $O/${W}_kernel_stats.md | cut -c1-400; done ;;
     c2) echo "== bench c2"; timeout 600 python bench.py --workload c2 --steps 200 --warmup 10 --no-cpu-baseline --no-two-stage --configs none --no-pmc > $O/bench_c2.json 2> $O/bench_c2.err; python - $O/bench_c2.json <<'PY'
 import json, sys
