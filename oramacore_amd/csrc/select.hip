@@ -537,7 +537,7 @@ __global__ __launch_bounds__(kSortThreads, 8) void keys_reduce_kernel(const unsi
                                                                    uint64_t out_stride, unsigned long long* tau = nullptr,
                                                                    uint32_t tau_stride = 0, const uint32_t* __restrict__ n_active = nullptr,
                                                                    uint32_t direct_cap = 0, uint32_t n_stride = 1,
-                                                                   uint32_t chunk_step = 0) {
+                                                                   uint32_t chunk_step = 0, uint32_t derive_k = 0) {
     __shared__ unsigned long long s[kKeysChunk];
     __shared__ uint32_t hist[256];
     __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
@@ -547,7 +547,16 @@ __global__ __launch_bounds__(kSortThreads, 8) void keys_reduce_kernel(const unsi
     // would all start together and none would)
     const uint32_t qi = tau ? blockIdx.x : blockIdx.y, chunk0 = tau ? blockIdx.y : blockIdx.x;
     if (n_active && qi >= *n_active) return;  // (uniform) only the first *n_active lists exist: nothing of the others is read or written
-    if (n_per_list) n_keys = min(n_keys, n_per_list[(uint64_t)qi * n_stride]);  // lists shorter than the stride: the tail is not read
+    if (n_per_list) {
+        const uint32_t len = n_per_list[(uint64_t)qi * n_stride];
+        // (derive_k != 0: this is the SECOND level over a counted list — its input holds derive_k survivors of every chunk of
+        // the caller's list that exists; a list whose first level the final kernel can take whole is not reduced again)
+        n_keys = min(n_keys, derive_k ? ((len + kKeysChunk - 1u) / kKeysChunk) * derive_k : len);  // lists shorter than the stride: the tail is not read
+        if (derive_k && len <= direct_cap) return;
+    }
+    // counted lists: a chunk past the end writes nothing, and (first level) a list the final kernel takes whole is not reduced
+    const bool sparse = direct_cap != 0;
+    const uint32_t whole_cap = derive_k ? 0u : direct_cap;
     const int lane = threadIdx.x & 63, wave = (int)uniform_u32(threadIdx.x >> 6);
     // chunk_step != 0 (counted lists: the grid holds a few workgroups per list, not one per chunk of the worst case): the
     // workgroup walks chunks chunk0, chunk0 + chunk_step, ... of its list — each one the same procedure, under the list's
@@ -565,7 +574,7 @@ __global__ __launch_bounds__(kSortThreads, 8) void keys_reduce_kernel(const unsi
     // counted lists (direct_cap != 0: the length was produced on the device — K3r's compact key lists): a list the final kernel
     // can take whole is not reduced at all, and a chunk past the end writes nothing — the final kernel reads
     // ceil(length / chunk) * k survivors, not the grid's worth
-    if (direct_cap && (n_keys <= direct_cap || begin >= n_keys)) return;
+    if (sparse && (n_keys <= whole_cap || begin >= n_keys)) return;
     if (begin >= n_keys) {
         for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = 0ull;
         return;
@@ -1025,7 +1034,9 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
                                                                   const uint32_t* __restrict__ done = nullptr,
                                                                   const unsigned long long* __restrict__ direct_keys = nullptr,
                                                                   uint64_t direct_stride = 0, uint32_t direct_cap = 0,
-                                                                  uint32_t n_stride = 1) {
+                                                                  uint32_t n_stride = 1,
+                                                                  const unsigned long long* __restrict__ l2_keys = nullptr,
+                                                                  uint64_t l2_stride = 0) {
     __shared__ SortLds s;
     __shared__ uint32_t valid_s;
     __shared__ uint32_t hist[256];
@@ -1044,7 +1055,13 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
             in = direct_keys + (uint64_t)qi * direct_stride;
             n_keys = len;
         } else {
-            n_keys = min(n_keys, ((len + kKeysChunk - 1u) / kKeysChunk) * k);
+            const uint32_t n1 = ((len + kKeysChunk - 1u) / kKeysChunk) * k;  // what the first level left of the list
+            if (n1 <= direct_cap || !l2_keys) {
+                n_keys = min(n_keys, n1);
+            } else {  // (uniform) more than this kernel takes: the second level's output
+                in = l2_keys + (uint64_t)qi * l2_stride;
+                n_keys = ((n1 + kKeysChunk - 1u) / kKeysChunk) * k;
+            }
         }
     } else if (n_per_list) {
         n_keys = min(n_keys, n_per_list[(uint64_t)qi * n_stride]);
@@ -1216,19 +1233,31 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
         // chunks that exist do anything, and none at all for a list the final kernel can take whole.
         const uint32_t cap = keys_final_capacity(k);
         const uint32_t chunks = (n_keys + kKeysChunk - 1) / kKeysChunk;
-        if ((uint64_t)chunks * k <= cap) {
+        const uint64_t n1 = (uint64_t)chunks * k;                              // first-level survivors of a list in the worst case
+        const uint32_t chunks2 = (uint32_t)((n1 + kKeysChunk - 1) / kKeysChunk);
+        if ((uint64_t)chunks2 * k <= cap) {
+            unsigned long long* l2 = nullptr;
             if (n_keys > cap) {
                 ORAMA_REQUIRE(d_tmp, "keys top-k: scratch missing");
                 // (a few workgroups per list, each walking every walkers-th chunk that exists: the worst case is one slot per
                 // posting — 72 to 200 chunks per list of which 3 to 8 exist, thousands of workgroups that end at once)
                 const uint32_t walkers = std::min<uint32_t>(chunks, 8u);
                 hipLaunchKernelGGL(keys_reduce_kernel, d_tau ? dim3(q, walkers) : dim3(walkers, q), dim3(kSortThreads), 0, stream, d_keys,
-                                   n_keys, stride, d_n_per_list, k, d_tmp, (uint64_t)chunks * k, d_tau, tau_stride, d_n_active, cap,
+                                   n_keys, stride, d_n_per_list, k, d_tmp, n1, d_tau, tau_stride, d_n_active, cap,
                                    n_per_list_stride, walkers);
+                if (n1 > cap) {
+                    // the worst case leaves more first-level survivors than the final kernel takes (lists of more than
+                    // cap / k chunks: 660 K keys at k = 100): a second level for the lists that really are that long — its
+                    // workgroups end at once for every other list, and the final kernel reads the level that applies
+                    l2 = d_tmp + (uint64_t)q * n1;
+                    hipLaunchKernelGGL(keys_reduce_kernel, dim3(chunks2, q), dim3(kSortThreads), 0, stream, d_tmp, (uint32_t)n1, n1,
+                                       d_n_per_list, k, l2, (uint64_t)chunks2 * k, (unsigned long long*)nullptr, 0u, d_n_active,
+                                       (uint32_t)(((uint64_t)cap / k) * kKeysChunk), n_per_list_stride, 0u, k);
+                }
             }
-            hipLaunchKernelGGL(keys_final_kernel, dim3(q), dim3(kSortThreads), 0, stream, d_tmp ? d_tmp : d_keys, chunks * k,
-                               (uint64_t)chunks * k, d_n_per_list, k, descending, id_map, out_idx, out_ids, out_val, out_n, d_n_active,
-                               (const uint32_t*)nullptr, d_keys, stride, cap, n_per_list_stride);
+            hipLaunchKernelGGL(keys_final_kernel, dim3(q), dim3(kSortThreads), 0, stream, d_tmp ? d_tmp : d_keys, (uint32_t)n1, n1,
+                               d_n_per_list, k, descending, id_map, out_idx, out_ids, out_val, out_n, d_n_active,
+                               (const uint32_t*)nullptr, d_keys, stride, cap, n_per_list_stride, l2, (uint64_t)chunks2 * k);
             ORAMA_HIP_TRY(hipGetLastError());
             return ORAMA_OK;
         }

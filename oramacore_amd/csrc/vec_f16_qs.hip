@@ -84,7 +84,9 @@ struct QsCfg {
     static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 };
 
-// DBG bits (timing ablations, ORAMA_K2C_DBG): 1 no MFMA, 2 no DMA, 8 no LDS fragment reads, 32 no epilogue, 16 = block 0 records
+// DBG bits (timing ablations, ORAMA_K2C_DBG): 1 no MFMA, 2 no DMA, 8 no LDS fragment reads, 32 no epilogue, 64 = the fast reject
+// of a UNIT-NORM store (no norm reads from LDS, no multiplies: 16 maxima against the column's bound; right answers on rows of
+// norm 1 only — the ceiling experiment of VERDICT r04 next #5b, scripts/k2q_unit_norm_probe.py), 16 = block 0 records
 // s_memtime stamps per step (waves 0 and 4: arrival at the barrier, release, DMA issued, stage multiplied, epilogue done —
 // scripts/k2q_trace.py)
 template <class C, int DBG, bool DENSE, bool L2>
@@ -293,7 +295,10 @@ __global__ __launch_bounds__(C::kThreads) void vec_scan_f16_qs_kernel(F16ScanArg
             const uint32_t dead_word = a.dead ? dead_lds[mb * 64 + tl] : 0u;
             f4 nv[4];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) nv[g4] = *reinterpret_cast<const f4*>(nrm + 8 * g4);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                if constexpr ((DBG & 64) != 0 && !DENSE) nv[g4] = f4{1.0f, 1.0f, 1.0f, 1.0f};  // (the slow path reads nrm[] itself)
+                else nv[g4] = *reinterpret_cast<const f4*>(nrm + 8 * g4);
+            }
             const bool full = (uint64_t)tile * 32 + 32 <= a.row_end;
             if constexpr (DENSE) {
                 if (!live) continue;
@@ -569,6 +574,7 @@ int qs_dispatch(orama_ctx* ctx, const F16ScanArgs& a, const char* bfrag, const f
                 case 34: return qs_launch<QsWide<KSTEPS>, 34>(ctx, a, bfrag, qinv, stream);  // LDS reads + MFMA + barriers, no epilogue
                 case 40: return qs_launch<QsWide<KSTEPS>, 40>(ctx, a, bfrag, qinv, stream);  // DMA + MFMA, no LDS reads, no epilogue
                 case 42: return qs_launch<QsWide<KSTEPS>, 42>(ctx, a, bfrag, qinv, stream);  // MFMA + barriers only
+                case 64: return qs_launch<QsWide<KSTEPS>, 64>(ctx, a, bfrag, qinv, stream);  // unit-norm fast reject (rows of norm 1)
                 default: break;
             }
         }

@@ -207,7 +207,7 @@ __device__ __forceinline__ float u01(uint32_t bits) {  // (0, 1]
 
 __global__ __launch_bounds__(kScanThreads) void synth_fill_kernel(float* __restrict__ corpus,
                                                                   uint64_t first, uint64_t n,
-                                                                  uint32_t dim, uint64_t seed) {
+                                                                  uint32_t dim, uint64_t seed, bool unit_norm) {
     const int lane = threadIdx.x & (kWave - 1);
     const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
@@ -227,7 +227,9 @@ __global__ __launch_bounds__(kScanThreads) void synth_fill_kernel(float* __restr
         }
         ss = wave_sum(ss);
         uint64_t hs = splitmix64(seed ^ 0xA5A5A5A55A5A5A5Aull ^ (row * 0x2545F4914F6CDD1Dull));
-        const float u = 0.5f + 1.5f * u01((uint32_t)hs);
+        // (ORAMA_SYNTH_UNIT_NORM=1: rows of norm 1 — the corpus of the unit-norm store experiment, scripts/k2q_unit_norm_probe.py;
+        // SURVEY §8d's workloads re-scale every row by u ~ U(0.5, 2) so that the norms matter)
+        const float u = unit_norm ? 1.0f : 0.5f + 1.5f * u01((uint32_t)hs);
         const float scale = ss > 0.0f ? u / sqrtf(ss) : 0.0f;
         for (uint32_t c = lane * 2; c < dim; c += 2 * kWave) {
             uint64_t h = splitmix64(seed ^ (row * 0xD1342543DE82EF95ull + (uint64_t)(c >> 1)));
@@ -499,8 +501,9 @@ int launch_row_inv_norm_f32(const float* corpus, uint64_t first, uint64_t n, uin
 int launch_synth_fill_f32(float* corpus, uint64_t first, uint64_t n, uint32_t dim, uint64_t seed,
                           hipStream_t stream) {
     if (n == 0) return ORAMA_OK;
+    static const bool unit_norm = [] { const char* e = std::getenv("ORAMA_SYNTH_UNIT_NORM"); return e && std::atoi(e) != 0; }();
     hipLaunchKernelGGL(synth_fill_kernel, dim3(grid_for_rows(n, 8192)), dim3(kScanThreads), 0, stream,
-                       corpus, first, n, dim, seed);
+                       corpus, first, n, dim, seed, unit_norm);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }
