@@ -804,7 +804,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))
 constexpr int kDocsThreads = 256;
 __global__ __launch_bounds__(kDocsThreads) void range_score_docs_kernel(RangeBatch b, uint32_t qi, const uint32_t* __restrict__ docs,
                                                                         uint32_t n, float* __restrict__ out_score,
-                                                                        uint32_t* __restrict__ out_present) {
+                                                                        uint32_t* __restrict__ out_present,
+                                                                        const uint32_t* __restrict__ n_dev) {
     constexpr uint32_t kDocWaves = kDocsThreads / 64;
     __shared__ float idf[kMaxTokens];
     __shared__ float found_ntf[kDocWaves][kRangeMaxRefs];
@@ -814,6 +815,7 @@ __global__ __launch_bounds__(kDocsThreads) void range_score_docs_kernel(RangeBat
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const uint32_t j = blockIdx.x * kDocWaves + w;
+    if (n_dev) n = min(n, *n_dev);  // (the device tail: the grid was sized for `limit`, the vector map holds *n_dev documents)
     if (j >= n) return;  // (wave-uniform; no block-wide barrier below)
     const uint32_t doc = docs[j];
     bool allowed = true;
@@ -928,11 +930,11 @@ int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStr
 }
 
 int launch_range_score_docs(orama_ctx* ctx, const RangeBatch& b, uint32_t qi, const uint32_t* d_doc, uint32_t n, float* d_out_score,
-                            uint32_t* d_out_present, hipStream_t stream) {
+                            uint32_t* d_out_present, hipStream_t stream, const uint32_t* d_n) {
     (void)ctx;
     if (n == 0) return ORAMA_OK;
     hipLaunchKernelGGL(range_score_docs_kernel, dim3((n + kDocsThreads / 64 - 1) / (kDocsThreads / 64)), dim3(kDocsThreads), 0, stream, b, qi,
-                       d_doc, n, d_out_score, d_out_present);
+                       d_doc, n, d_out_score, d_out_present, d_n);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

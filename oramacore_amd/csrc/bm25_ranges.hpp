@@ -127,7 +127,8 @@ int launch_ntf_precompute(const uint32_t* post_val, float* post_ntf, const uint6
                           uint32_t n_lists, uint64_t n_postings, float b, hipStream_t stream);
 // Hybrid: the full-text score of `n` given documents (local indices) of query `qi`, by the same fold as the range kernel
 // (lists of a token in reference order, tokens ascending): out_score[j] / out_present[j] (in the score map or not).
+// (d_n, optional, device: only the first min(n, *d_n) documents exist — the device tail of the one-call hybrid search)
 int launch_range_score_docs(orama_ctx* ctx, const RangeBatch& b, uint32_t qi, const uint32_t* d_doc, uint32_t n, float* d_out_score,
-                            uint32_t* d_out_present, hipStream_t stream);
+                            uint32_t* d_out_present, hipStream_t stream, const uint32_t* d_n = nullptr);
 
 }  // namespace orama

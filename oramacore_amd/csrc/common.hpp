@@ -200,10 +200,14 @@ struct Scratch {
     // two-stream search (scan on one stream, top-k tail on another): scan → tail and tail → next-scan ordering
     hipEvent_t ev_scan = nullptr, ev_tail = nullptr;
     bool tail_recorded = false;
+    // "everything enqueued on this set's stream so far is done", for ANOTHER set's stream to wait on (the one-call hybrid
+    // search: the range scorer's stream runs the tail behind the vector leg's top-k); created on first use
+    hipEvent_t ev_done = nullptr;
     ~Scratch() {
         if (stream) (void)hipStreamDestroy(stream);
         if (ev_scan) (void)hipEventDestroy(ev_scan);
         if (ev_tail) (void)hipEventDestroy(ev_tail);
+        if (ev_done) (void)hipEventDestroy(ev_done);
     }
 };
 
@@ -238,6 +242,11 @@ struct orama_ctx {
     int bm25_ranges_hybrid = 1;  // orama_post_search_hybrid on the range scorer where it applies (ORAMA_BM25_RANGES_HYBRID=0: K3)
     // K3r's plain top-k batches append only the keys that can still reach the answer (round 5, bm25_ranges.hip "COMPACT");
     // false = one key slot per posting as in round 4 (ORAMA_K3R_COMPACT=0, orama_ctx_set_bm25_ranges(ctx, 3): A/B runs)
+    // orama_hybrid_search on the range scorer can finish on the device (hybrid_tail.hip: one read-back, one host wake-up) —
+    // built in round 5, measured, NOT the default: four small dependent launches behind the scan's top-k cost more than the
+    // wake-up they save (C4 p50 4.454 against 4.403 ms, shadow store 2.447 against 2.360: profiles/r05_hybrid_device_tail_ab.log).
+    // ORAMA_HYBRID_DEVICE_TAIL=1 enables it (the parity test runs both forms).
+    bool hybrid_device_tail = false;
     bool bm25_compact_keys = true;
     // ... for batches of at least this many queries: the lists' cursors are bumped by returning global atomics (~50 ns each on
     // one address) and a lone query's 400 workgroups run together — 14.7 -> 11.7 K single calls per second with compact lists

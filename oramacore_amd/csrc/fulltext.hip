@@ -21,6 +21,7 @@
 
 #include "bm25_kernels.hpp"
 #include "bm25_ranges.hpp"
+#include "hybrid_tail.hpp"
 #include "shard_exchange.hpp"
 #include "common.hpp"
 #include "select.hpp"
@@ -565,6 +566,18 @@ struct RangeJob {
     // per-document launch and a merge of <= top_k + 2 n_vec_max + 1 entries on the host (DESIGN.md K5 "hybrid tail").
     std::function<int(const uint64_t** doc, const float** score, uint32_t* n)> vec_provider;
     uint32_t n_vec_max = 0;
+    // ... and, round 5, the DEVICE form of that tail (hybrid_tail.hip): the vector leg's answer [ids | distances | n] stays on the
+    // device; behind `vec_ready` (recorded on the vector leg's stream) the range scorer's own stream runs the a2 epilogue, the
+    // per-document scoring of the hits, normalize_and_combine and K4 — one read-back, one host wake-up.  The provider is
+    // only asked when the device says the candidates cannot prove the answer (the K3 fallback wants the map on the host).
+    bool device_tail = false;
+    const uint64_t* d_vec_ids = nullptr;
+    const float* d_vec_dist = nullptr;
+    const uint32_t* d_vec_n = nullptr;
+    hipEvent_t vec_ready = nullptr;
+    uint32_t vec_limit = 0;
+    float min_similarity = 0.0f;
+    int rescale_e5 = 0;
     // sharded batches (orama_shard_post_search_batch): the index-wide document frequency of every token (kMaxTokens words) —
     // idf comes from it instead of from this shard's list lengths (corpus_docs.len() over the whole index, token_score.rs:262-275)
     const uint32_t* df_global = nullptr;
@@ -769,6 +782,10 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         return ORAMA_OK;
     };
     const bool hybrid_job = n_jobs == 1 && jobs[0].hybrid;
+    // the device form of the hybrid tail: hits and merged entries that fit its kernels (else the host form below)
+    const bool device_tail = hybrid_job && jobs[0].device_tail && jobs[0].vec_provider && jobs[0].vec_limit >= 1 &&
+                             jobs[0].vec_limit <= kHybridTailMaxVec &&
+                             (uint64_t)jobs[0].params->top_k + 2ull * jobs[0].vec_limit + 1 <= kSelectMaxK;
     if (hybrid_job) {
         *jobs[0].fallback = false;
         if (!jobs[0].vec_provider) {
@@ -837,6 +854,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         size_t res_bytes = 0;
         RangeBatch rb;
         RangeResult* h_res = nullptr;
+        const char* h_tail = nullptr;  // device tail: [flag u32 | n u32 | count u64 | ids top_k x u64 | scores top_k x f32] once the stream drained
     };
     Chunk slots[2];
     slots[0].sc = sc;
@@ -878,7 +896,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         uint32_t max_ranges = 0;
         bool any_df = false;
         // (+ the hybrid job's vector hits: sized now so that nothing is re-allocated behind the scan)
-        ORAMA_TRY(sc->h_misc.reserve((size_t)nq * kMaxTokens * 4 + 4096 + (size_t)(c.kmax + 1) * 12));
+        ORAMA_TRY(sc->h_misc.reserve((size_t)nq * kMaxTokens * 4 + 4096 + (size_t)(c.kmax + 1) * 12 + 64));
         float* h_idf = sc->h_misc.as<float>();
         for (uint32_t ci = 0; ci < nq; ++ci) {
             const Pending& pd = c.members[ci];
@@ -1083,6 +1101,71 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                                        compact ? (uint32_t)(sizeof(RangeResult) / 4) : 1u));
         }
         c.trace.mark(5);
+        c.h_tail = nullptr;
+        if (device_tail) {
+            // ---- the hybrid tail on this stream (hybrid_tail.hip): waits for the vector leg's top-k, then four small launches
+            const RangeJob& jb = jobs[0];
+            const uint32_t L = jb.vec_limit, top_k = jb.params->top_k, cap = c.kmax + L;  // entries: <= k_asked + vector hits
+            const size_t o_vdoc = 0, o_edoc = o_vdoc + (size_t)L * 8, o_vsc = o_edoc + (size_t)cap * 8, o_vloc = o_vsc + (size_t)L * 4,
+                         o_vft = o_vloc + (size_t)L * 4, o_vpr = o_vft + (size_t)L * 4, o_esc = o_vpr + (size_t)L * 4,
+                         o_state = o_esc + (size_t)cap * 4, o_out = (o_state + 16 + 15) & ~(size_t)15;
+            const size_t out_tail = 16 + (size_t)top_k * 12;
+            ORAMA_TRY(sc->misc5.reserve(o_out + out_tail + 16));
+            char* t = sc->misc5.as<char>();
+            HybridTailArgs ta;
+            ta.v_ids = jb.d_vec_ids;
+            ta.v_dist = jb.d_vec_dist;
+            ta.v_n = jb.d_vec_n;
+            ta.limit = L;
+            ta.min_similarity = jb.min_similarity;
+            ta.rescale_e5 = jb.rescale_e5;
+            ta.docs = p->d_docs.as<uint64_t>();
+            ta.n_docs = p->n_docs;
+            ta.dense_base = p->dense_base;
+            ta.dense = p->dense ? 1 : 0;
+            ta.vdoc = reinterpret_cast<uint64_t*>(t + o_vdoc);
+            ta.e_doc = reinterpret_cast<uint64_t*>(t + o_edoc);
+            ta.vsc = reinterpret_cast<float*>(t + o_vsc);
+            ta.vlocal = reinterpret_cast<uint32_t*>(t + o_vloc);
+            ta.vft = reinterpret_cast<float*>(t + o_vft);
+            ta.vpresent = reinterpret_cast<uint32_t*>(t + o_vpr);
+            ta.e_score = reinterpret_cast<float*>(t + o_esc);
+            ta.state = reinterpret_cast<uint32_t*>(t + o_state);
+            ta.cand_id = d_ids;
+            ta.cand_score = d_val;
+            ta.cand_n = d_n;
+            ta.k_asked = c.kmax;
+            ta.top_k = top_k;
+            ta.res_count = &rb.results[0].count;
+            ta.res_max_key = &rb.results[0].max_key;
+            ta.res_min_inv = &rb.results[0].min_inv;
+            ta.res_overflow = &rb.results[0].overflow;
+            char* d_tail = t + o_out;
+            ta.out_flag = reinterpret_cast<uint32_t*>(d_tail);
+            ta.out_count = reinterpret_cast<unsigned long long*>(d_tail + 8);
+            ORAMA_HIP_TRY(hipStreamWaitEvent(s, jb.vec_ready, 0));
+            ORAMA_TRY(launch_hybrid_vec_epilogue(ta, s));
+            ORAMA_TRY(launch_range_score_docs(p->ctx, rb, 0, ta.vlocal, L, ta.vft, ta.vpresent, s, ta.state));
+            ORAMA_TRY(launch_hybrid_merge(ta, s));
+            if (top_k) {
+                SelectPlan sp;  // top_n: score desc, DocumentId asc, NaN already left out (sort.rs:260-279)
+                sp.vals = ta.e_score;
+                sp.stride = cap;
+                sp.n = cap;
+                sp.n_dev = ta.state + 2;
+                sp.q = 1;
+                sp.k = top_k;
+                sp.descending = true;
+                sp.id_map = ta.e_doc;
+                sp.out_ids = reinterpret_cast<uint64_t*>(d_tail + 16);
+                sp.out_val = reinterpret_cast<float*>(d_tail + 16 + (size_t)top_k * 8);
+                sp.out_n = reinterpret_cast<uint32_t*>(d_tail + 4);
+                ORAMA_TRY(launch_select(p->ctx, sp, s));
+            }
+            char* h_tail = sc->h_misc.as<char>() + (size_t)nq * kMaxTokens * 4 + 4096;  // (behind the idf staging: reserved above)
+            ORAMA_HIP_TRY(hipMemcpyAsync(h_tail, d_tail, out_tail, hipMemcpyDeviceToHost, s));
+            c.h_tail = h_tail;
+        }
         ORAMA_HIP_TRY(hipMemcpyAsync(h_res, d_out, c.kmax ? out_bytes : res_bytes, hipMemcpyDeviceToHost, s));
         c.trace.mark(6);
         return ORAMA_OK;
@@ -1100,7 +1183,26 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         uint32_t nv = 0;
         float* h_vft = nullptr;          // full-text score of every vector hit ...
         uint32_t* h_vpresent = nullptr;  // ... and whether it is in the full-text map at all
-        if (hybrid_job) {  // (one-call form: this is where the vector leg is joined — everything above ran beside it)
+        if (device_tail) {
+            // one wake-up: the answer, or the word that says why not
+            ORAMA_HIP_TRY(hipStreamSynchronize(s));
+            const uint32_t flag = *reinterpret_cast<const uint32_t*>(c.h_tail);
+            if (!(flag & 4u)) {  // (overflow: the loop below reruns the full-text leg with narrower ranges, tail included)
+                const RangeJob& jb = jobs[0];
+                if (flag & 3u) {  // the candidates cannot prove the answer / a hit outside the index: K3, with the map on the host
+                    ORAMA_TRY(take_map());
+                    *hj.fallback = true;
+                    return ORAMA_OK;
+                }
+                const uint32_t top_k = jb.params->top_k;
+                const uint32_t n = top_k ? std::min(*reinterpret_cast<const uint32_t*>(c.h_tail + 4), top_k) : 0u;
+                memcpy(jb.out_ids, c.h_tail + 16, (size_t)n * 8);
+                memcpy(jb.out_scores, c.h_tail + 16 + (size_t)top_k * 8, (size_t)n * 4);
+                *jb.out_n = n;
+                if (jb.out_count) *jb.out_count = *reinterpret_cast<const unsigned long long*>(c.h_tail + 8);
+                return ORAMA_OK;
+            }
+        } else if (hybrid_job) {  // (one-call form: this is where the vector leg is joined — everything above ran beside it)
             ORAMA_TRY(take_map());
             if (*hj.fallback) {
                 ORAMA_HIP_TRY(hipStreamSynchronize(s));
@@ -2124,6 +2226,7 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
     const uint32_t dim = vec_dim(v);
     const bool have_rows = vec_rows(v) > 0 && limit > 0;
     const uint32_t kk = limit ? limit : 1;
+    bool two_stage_device = false;  // the vector leg of a shadow store in the plan's device form (set with the device tail below)
     // ---- leg A: vector scan + top-`limit` rows on a's stream; the read-back lands in a->h_out
     auto vector_leg = [&](ScratchLease& a, ScratchLease& a2, VecTwoStage& ts) -> int {
         if (!have_rows) return ORAMA_OK;
@@ -2140,6 +2243,8 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
         float* d_dist = reinterpret_cast<float*>(d_ids + kk);
         uint32_t* d_n = reinterpret_cast<uint32_t*>(d_dist + kk);
         ORAMA_TRY(a->h_out.reserve((size_t)kk * 12 + 8));
+        if (two_stage && two_stage_device)  // (the device tail: nothing of the plan is left for the host to decide)
+            return ts.begin_device(v, a, a2, a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n);
         if (two_stage) return ts.begin(v, a, a2, a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n);
         ORAMA_TRY(vec_search_enqueue(v, a.s.get(), a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n, sa));
         ORAMA_HIP_TRY(hipMemcpyAsync(a->h_out.p, d_ids, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, sa));
@@ -2194,11 +2299,29 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
             if (two_stage) ORAMA_TRY(ScratchLease::init_three(a, a2, g));
             else ORAMA_TRY(ScratchLease::init_pair(a, g));
             VecTwoStage ts;
+            // the tail on the device (hybrid_tail.hip) where its kernels take the call: hits and merged entries within their
+            // envelopes, and a vector leg that needs no host decision (a shadow store: the plan's device form)
+            const bool dev_tail = ctx->hybrid_device_tail && have_rows && limit <= kHybridTailMaxVec &&
+                                  (uint64_t)params->top_k + 2ull * limit + 1 <= kSelectMaxK &&
+                                  (!two_stage || vec_two_stage_device_usable(v, 1, limit));
+            two_stage_device = dev_tail && two_stage;
             ORAMA_TRY(vector_leg(a, a2, ts));
             RangeJob job{refs, n_refs, params, out_ids, out_scores, out_n, out_count};
             job.hybrid = true;
             job.fallback = &fallback;
             job.n_vec_max = have_rows ? limit : 0;
+            if (dev_tail) {
+                if (!a->ev_done) ORAMA_HIP_TRY(hipEventCreateWithFlags(&a->ev_done, hipEventDisableTiming));
+                ORAMA_HIP_TRY(hipEventRecord(a->ev_done, a->stream));
+                job.device_tail = true;
+                job.d_vec_ids = a->out_ids.as<uint64_t>();
+                job.d_vec_dist = reinterpret_cast<const float*>(job.d_vec_ids + kk);
+                job.d_vec_n = reinterpret_cast<const uint32_t*>(job.d_vec_dist + kk);
+                job.vec_ready = a->ev_done;
+                job.vec_limit = limit;
+                job.min_similarity = min_similarity;
+                job.rescale_e5 = rescale_e5;
+            }
             job.vec_provider = [&](const uint64_t** doc, const float** score, uint32_t* n) -> int {
                 if (!joined) {
                     ORAMA_TRY(join_vector_leg(a, ts));
@@ -2214,7 +2337,12 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
                 if (!joined && have_rows) (void)hipStreamSynchronize(a->stream);  // nothing of the call stays in flight
                 return rc;
             }
-            if (!fallback) return ORAMA_OK;
+            if (!fallback) {
+                // (the device tail never joined the vector leg on the host: its stream has drained — the tail waited for it —
+                // and a shadow store's read lock goes back here)
+                if (two_stage && !joined) ORAMA_TRY(ts.finish());
+                return ORAMA_OK;
+            }
             if (!joined) {  // (no full-text side at all: the scorer never asked for the map)
                 const uint64_t* d_;
                 const float* s_;

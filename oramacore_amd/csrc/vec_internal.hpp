@@ -29,6 +29,8 @@ int vec_search_enqueue(orama_vec* v, Scratch* sc, const float* d_queries, uint32
 
 // Two-stage exact search of a store with an fp16 shadow (vec_store.hip): usable for these host queries?
 bool vec_two_stage_usable(orama_vec* v, const float* queries, uint32_t q, uint32_t k);
+// ... and in its device form (the query test runs on the device)?
+bool vec_two_stage_device_usable(orama_vec* v, uint32_t q, uint32_t k);
 // Runs it on sc's stream with sc2 as the shadow stage's scratch; BLOCKS until the answers are in the device outputs.
 // Queries whose candidate list could not be proven complete are re-answered by the plain scan (also blocking).
 int vec_two_stage_search(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k,
@@ -46,6 +48,10 @@ class VecTwoStage {
     VecTwoStage& operator=(const VecTwoStage&) = delete;
     int begin(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k, const uint64_t* d_allow,
               uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n);
+    // The plan's DEVICE form (vec_two_stage_device_usable must hold): the unproven queries are re-answered on the device, behind
+    // everything else on the stream — nothing for the host to decide; finish() then only drains the stream and unlocks.
+    int begin_device(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k,
+                     const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n);
     int finish();
 
    private:
@@ -60,7 +66,7 @@ class VecTwoStage {
     uint64_t* d_out_ids_ = nullptr;
     float* d_out_dist_ = nullptr;
     uint32_t* d_out_n_ = nullptr;
-    bool flags_pending_ = false;
+    bool flags_pending_ = false, device_form_ = false;
 };
 
 }  // namespace orama

@@ -979,12 +979,26 @@ int VecTwoStage::begin(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const 
     locked_ = &v->shadow->mu;
     return two_stage_search(v, sc.s.get(), sc2.s.get(), d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, sc->stream, &flags_pending_);
 }
+bool vec_two_stage_device_usable(orama_vec* v, uint32_t q, uint32_t k) { return two_stage_device_usable(v, q, k); }
+int VecTwoStage::begin_device(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k,
+                              const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n) {
+    ORAMA_REQUIRE(!locked_, "internal: two-stage search begun twice");
+    ORAMA_REQUIRE(two_stage_device_usable(v, q, k), "internal: two-stage device form outside its envelope");
+    v_ = v, sc_ = sc.s.get(), sc2_ = sc2.s.get(), d_queries_ = d_queries, q_ = q, k_ = k, d_allow_ = d_allow, allow_bits_ = allow_bits;
+    d_out_ids_ = d_out_ids, d_out_dist_ = d_out_dist, d_out_n_ = d_out_n;
+    v->shadow->mu.lock_shared();
+    locked_ = &v->shadow->mu;
+    flags_pending_ = false;
+    device_form_ = true;
+    return two_stage_search(v, sc.s.get(), sc2.s.get(), d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, sc->stream, nullptr);
+}
 int VecTwoStage::finish() {
     ORAMA_REQUIRE(locked_, "internal: two-stage search not begun");
     hipStream_t s = sc_->stream;
     const hipError_t e = hipStreamSynchronize(s);
     unlock();
     ORAMA_HIP_TRY(e);
+    if (device_form_) return ORAMA_OK;  // (the device form counts its queries itself, two_stage_search)
     v_->two_stage_queries.fetch_add(q_, std::memory_order_relaxed);
     if (!flags_pending_) return ORAMA_OK;
     const uint32_t* hf = sc2_->h_out.as<uint32_t>();

@@ -60,6 +60,14 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print({k: d[k] for k in ("value", "ms_per_step", "latency_ms_p50", "latency_ms_p95", "latency_ms_p50_host_api")}, d["roofline"]["frac"], d["step_breakdown_us"])
 PY
       ;;
+    c4) for T in 1 0; do echo "== bench c4, ORAMA_HYBRID_DEVICE_TAIL=$T"; ORAMA_HYBRID_DEVICE_TAIL=$T timeout 600 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --configs c4 --no-pmc > $O/bench_c4_tail$T.json 2> $O/bench_c4_tail$T.err; python - $O/bench_c4_tail$T.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+c = d["configs"]["c4"]
+print("ns", round(d["value"], 2), "| c4", round(c["value"], 2), "QPS, p50", round(c["latency_ms_p50"], 4), "ms | shadow", round(c["shadow_store"]["value"], 2),
+      "QPS, p50", round(c["shadow_store"]["latency_ms_p50"], 4), "| two-stage host API", round(d["two_stage_exact"]["value"], 1), "session", round(d["two_stage_exact"]["session"]["value"], 1))
+PY
+      done ;;
     py:*) A=${STEP#py:}; S=${A%%:*}; ARGS=""; [ "$A" != "$S" ] && ARGS=$(echo "${A#*:}" | tr ',' ' '); B=$(basename $S .py)
       echo "== python $S $ARGS"; ORAMA_K3R_STATS=1 ORAMA_K3R_DBG=${K3R_DBG:-0} timeout 1200 python $S $ARGS > $O/$B.log 2>&1; echo rc=$?; tail -60 $O/$B.log ;;
   esac

@@ -730,3 +730,57 @@ def test_the_range_width_that_held_is_remembered(ctx):
     for ids, sc, count in res:
         assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
     corpus.store.close()
+
+
+def test_hybrid_tail_on_the_device_equals_the_host_tail():
+    """Round 5: orama_hybrid_search finishes ON THE DEVICE (hybrid_tail.hip: a2 epilogue, per-document scoring of the hits,
+    normalize_and_combine, K4 — one read-back, one host wake-up).  Same corpus on two contexts, one of them created with
+    ORAMA_HYBRID_DEVICE_TAIL=0 (round 3's host tail): identical ids, score bits and counts — plain and shadow stores, E5
+    rescale, cut-off, filter, several rows per document, thresholds, k / limit from 1 to 300 (beyond 512 hits the device form
+    steps aside by itself)."""
+    import os
+
+    import util
+
+    rng = np.random.default_rng(177)
+    n_docs, dim = 20_000, 64
+    lists = random_lists(rng, n_docs, 12, 2, 200, 5000)
+    doc_ids = np.arange(n_docs, dtype=np.uint64) * 2 + 9
+    rows = util.gaussian_rows(n_docs + 3000, dim, seed=179)
+    row_doc = np.concatenate([doc_ids, doc_ids[rng.choice(n_docs, size=3000, replace=False)]])
+    allow_mask = rng.random(n_docs) < 0.6
+    cases = []
+    for case in range(8):
+        n_tok = int(rng.integers(1, 5))
+        refs = [(t, int(l), float(F(rng.choice([1.0, 1.5])))) for t in range(n_tok) for l in rng.choice(12, size=int(rng.integers(1, 3)), replace=False)]
+        q = (rows[int(rng.integers(len(rows)))] + F(0.4) * rows[int(rng.integers(len(rows)))]).astype(F)
+        k, limit = [(10, 10), (1, 300), (100, 100), (300, 1), (25, 40), (100, 7), (5, 64), (50, 200)][case]
+        sim, e5, filt = [(0.0, False, False), (0.0, False, True), (0.5, False, False), (0.0, True, False)][case % 4]
+        cases.append((refs, n_tok, q, k, limit, sim, e5, filt, 1 if case == 5 else None))
+    answers = {}
+    for form in ("device", "host"):
+        old = os.environ.get("ORAMA_HYBRID_DEVICE_TAIL")
+        os.environ["ORAMA_HYBRID_DEVICE_TAIL"] = "1" if form == "device" else "0"
+        try:
+            c = oa.Context(0)
+        finally:
+            if old is None:
+                os.environ.pop("ORAMA_HYBRID_DEVICE_TAIL", None)
+            else:
+                os.environ["ORAMA_HYBRID_DEVICE_TAIL"] = old
+        corpus = Corpus(c, n_docs, lists, [80.0, 12.0], doc_ids=doc_ids, seed=178)
+        bm = oa.AllowBitmap(int(doc_ids.max()) + 1, doc_ids[allow_mask])
+        stores = {"plain": oa.EmbeddingFieldStorage(c, dimensions=dim), "shadow": oa.EmbeddingFieldStorage(c, dimensions=dim, dtype=oa._native.DTYPE_F32_SHADOW16)}
+        c.set_two_stage(True, always=True)  # (a 20 K-row store would take the plain scan otherwise)
+        got = []
+        for st in stores.values():
+            st.insert_rows(row_doc, rows)
+            for refs, n_tok, q, k, limit, sim, e5, filt, thr in cases:
+                got.append(corpus.store.hybrid_search(st, q, limit, sim, refs, n_tok, float(n_docs), k, thr, allow=bm if filt else None, rescale_e5=e5))
+        answers[form] = got
+        for st in stores.values():
+            st.close()
+        corpus.store.close()
+        c.close()
+    for i, (a, b_) in enumerate(zip(answers["device"], answers["host"])):
+        assert a[2] == b_[2] and a[0].tolist() == b_[0].tolist() and np.array_equal(bits(a[1]), bits(b_[1])), i
