@@ -192,6 +192,8 @@ struct Scratch {
     DevBuf out_idx, out_val, out_n, out_ids;
     DevBuf bitmap;     // uploaded allow bitmap
     DevBuf f16_bfrag;  // K2c: fp16 query fragments + 1/|q| of the current wide batch
+    DevBuf f16_tau_cap;  // ORAMA_F16_TAU_ORACLE=1 (experiment): the previous call's final k-th distances
+    uint32_t f16_tau_cap_q = 0, f16_tau_cap_k = 0;
     DevBuf misc0, misc1, misc2, misc3, misc4, misc5;
     PinnedBuf h_in, h_out, h_misc;
     // BM25 accumulators: epoch-stamped, zeroed only when (re)allocated (see bm25_kernels.hip)

@@ -876,7 +876,7 @@ __global__ void f16_seed_candidates_kernel(const float* __restrict__ best_dist,
                                            const uint32_t* __restrict__ best_row,
                                            const uint32_t* __restrict__ best_n, uint32_t k, float* tau,
                                            float* cand_dist, uint32_t* cand_row, uint32_t* cand_count,
-                                           uint64_t cand_stride) {
+                                           uint64_t cand_stride, const float* __restrict__ tau_cap) {
     const uint32_t j = blockIdx.x;
     const uint32_t n = best_n[j];
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -887,8 +887,21 @@ __global__ void f16_seed_candidates_kernel(const float* __restrict__ best_dist,
         cand_count[j] = n;
         // strict '<' against the k-th best: a later row with an equal distance has a higher row index
         // and can never displace it (tie rule: distance asc, row asc)
-        tau[j] = (n == k) ? best_dist[(uint64_t)j * k + (k - 1)] : __builtin_huge_valf();
+        float t = (n == k) ? best_dist[(uint64_t)j * k + (k - 1)] : __builtin_huge_valf();
+        // (tau_cap: a bound from OUTSIDE this store's own rows so far — another shard's head, or the ceiling experiment's
+        // oracle: rows AT the bound may still belong to the answer there, so the cap is passed one ulp up by its producer)
+        if (tau_cap) t = fminf(t, tau_cap[j]);
+        tau[j] = t;
     }
+}
+
+// ORAMA_F16_TAU_ORACLE=1 (scripts/f16_tau_ceiling_probe.py): remember each query's final k-th distance, one ulp up — the
+// tightest threshold ANY exchange between shards could hand the next identical batch.
+__global__ void f16_remember_kth_kernel(const float* __restrict__ out_dist, const uint32_t* __restrict__ out_n, uint32_t k, uint32_t q,
+                                        float* __restrict__ cap) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= q) return;
+    cap[j] = out_n[j] == k ? nextafterf(out_dist[(uint64_t)j * k + (k - 1)], __builtin_huge_valf()) : __builtin_huge_valf();
 }
 
 }  // namespace
@@ -1053,9 +1066,15 @@ int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a_in, hipStream_t str
 
 int launch_f16_seed_candidates(const float* best_dist, const uint32_t* best_row, const uint32_t* best_n,
                                uint32_t q, uint32_t k, float* tau, float* cand_dist, uint32_t* cand_row,
-                               uint32_t* cand_count, uint64_t cand_stride, hipStream_t stream) {
+                               uint32_t* cand_count, uint64_t cand_stride, hipStream_t stream, const float* tau_cap) {
     hipLaunchKernelGGL(f16_seed_candidates_kernel, dim3(q), dim3(256), 0, stream, best_dist, best_row, best_n,
-                       k, tau, cand_dist, cand_row, cand_count, cand_stride);
+                       k, tau, cand_dist, cand_row, cand_count, cand_stride, tau_cap);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_f16_remember_kth(const float* out_dist, const uint32_t* out_n, uint32_t k, uint32_t q, float* cap, hipStream_t stream) {
+    hipLaunchKernelGGL(f16_remember_kth_kernel, dim3((q + 255) / 256), dim3(256), 0, stream, out_dist, out_n, k, q, cap);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -132,6 +132,8 @@ int launch_vec_scan_f16_kh(orama_ctx* ctx, const F16ScanArgs& a, void* d_query_f
 // with the current best entries: cand[j][0..n_j) = (dist, row), cand_count[j] = n_j.
 int launch_f16_seed_candidates(const float* best_dist, const uint32_t* best_row, const uint32_t* best_n,
                                uint32_t q, uint32_t k, float* tau, float* cand_dist, uint32_t* cand_row,
-                               uint32_t* cand_count, uint64_t cand_stride, hipStream_t stream);
+                               uint32_t* cand_count, uint64_t cand_stride, hipStream_t stream, const float* tau_cap = nullptr);
+// the ceiling experiment of a threshold shared between shards (ORAMA_F16_TAU_ORACLE=1): cap[j] = query j's final k-th distance, one ulp up
+int launch_f16_remember_kth(const float* out_dist, const uint32_t* out_n, uint32_t k, uint32_t q, float* cap, hipStream_t stream);
 
 }  // namespace orama

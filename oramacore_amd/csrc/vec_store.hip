@@ -668,6 +668,16 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
         a.allow = d_allow;
         a.allow_bits = allow_bits;
         a.solo = d_out_rows != nullptr && v->ctx->f16_solo;  // the shadow stage of the two-stage plan
+        // ORAMA_F16_TAU_ORACLE=1, the CEILING of any threshold exchange between shards (scripts/
+        // f16_tau_ceiling_probe.py): the filter passes run under the final k-th distances the PREVIOUS call of this scratch set
+        // left behind (one ulp up) — exact only when that call asked the same queries, which the probe does
+        static const bool tau_oracle = [] { const char* e = std::getenv("ORAMA_F16_TAU_ORACLE"); return e && std::atoi(e) != 0; }();
+        const float* tau_cap = nullptr;
+        if (tau_oracle && q0 == 0 && gq == q) {
+            const bool have = sc->f16_tau_cap_q == gq && sc->f16_tau_cap_k == k;
+            ORAMA_TRY(sc->f16_tau_cap.reserve((size_t)gq * 4));
+            if (have) tau_cap = sc->f16_tau_cap.as<float>();
+        }
         // 1. dense head
         a.row_begin = 0;
         a.row_end = s1;
@@ -727,7 +737,7 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
         for (uint64_t r0 = s1; r0 < n;) {
             const uint64_t r1 = std::min<uint64_t>(n, r0 + this_chunk);
             ORAMA_TRY(launch_f16_seed_candidates(best_dist, best_row, out_n, gq, k, tau, cand_dist, cand_row,
-                                                 cand_count, cand_stride, s));
+                                                 cand_count, cand_stride, s, tau_cap));
             a.row_begin = r0;
             a.row_end = r1;
             a.out_dense = nullptr;
@@ -766,6 +776,11 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
             ORAMA_TRY(launch_select(v->ctx, c, s));
             r0 = r1;
             if (grow) this_chunk = std::min<uint64_t>(chunk_rows, (grow_factor - 1) * (r1 & ~255ull));
+        }
+        if (tau_oracle && q0 == 0 && gq == q) {
+            ORAMA_TRY(launch_f16_remember_kth(out_dist, out_n, k, gq, sc->f16_tau_cap.as<float>(), s));
+            sc->f16_tau_cap_q = gq;
+            sc->f16_tau_cap_k = k;
         }
         q0 += gq;
     }
