@@ -823,9 +823,10 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
                                                            "range_df": kd_ms * 1e3 / n_dev_q,
                                                            "range_score": ks_ms * 1e3 / n_dev_q,
                                                            "topk_select": kt_ms * 1e3 / n_dev_q},
-                                   "note": "round 4's sort-free scoring launch: 2.5 VALU + 2.4 scalar wave instructions per posting (round 3's merge "
-                                           "tree: 8.6 VALU), 32 waves per CU — bound by instruction issue, vector and scalar, not by HBM (the chain "
-                                           "streams 24 B per posting at ~1 TB/s): profiles/r04_k3r_sq_counters_v6.md, DESIGN K3r"},
+                                   "note": "round 5: compact key lists — the scoring launch (2.5 VALU wave instructions per posting, bound by "
+                                           "instruction issue and latency, not by HBM) appends only the keys at or above a floor, the top-k "
+                                           "reads survivors only: chain traffic 0.92 x the algorithmic bytes (round 4: 2.2 x) — DESIGN K3r, "
+                                           "profiles/r05_k3r_compact_ab_final.log, r05_pmc_k3r_*.json"},
                       "cpu_baseline": cpu_bm25},
         "postings_fill_seconds": t_fill,
         "parity_check": "bit-exact vs oracle (last query): BM25 ids/scores/count, hybrid ids/scores/count",
@@ -1037,13 +1038,20 @@ def main():
     group.barrier()
     group.close()
     if solo:
-        # HBM traffic of the dominant kernel from the PMC counters — measured now (two short profiler passes of this
+        # HBM traffic of the dominant kernel from the PMC counters — measured now (three short profiler passes of this
         # script's --pmc-child mode, after this process has released the GPU), else the committed record, labelled
         kern = "vec_scan_f16" if f16 else "vec_scan_f32"
         t = measure_traffic(args, kern, out["roofline"]["alg_bytes_per_launch"]) or (
             None if args.rows else committed_traffic(args.workload))
         if t:
             out["roofline"].update(t)
+    elif rank == 0 and not args.rows:
+        # N > 1: nothing is profiled inside a multi-rank job; the committed single-GPU record of the same kernel, labelled as such
+        # (per launch of the FULL corpus: a rank's launch moves rows_per_gpu / rows_total of it)
+        t = committed_traffic(args.workload)
+        if t:
+            t["traffic_source"] += " — a launch over the whole single-GPU corpus; this job's ranks scan 1/N of it each"
+            out["roofline"]["traffic_reference"] = t
     if rank == 0:
         out["device"] = device_name
         # RCCL writes its version banner through C stdio (fully buffered when stdout is a pipe): push it out first

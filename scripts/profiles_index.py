@@ -23,7 +23,7 @@ def kernel_stats_line(path: Path) -> str:
             rows.append((m.group(1), int(m.group(2)), float(m.group(3)), float(m.group(4))))
         if line.startswith("clocks during the timed region"):
             c = re.search(r'"sclk_mhz_median": ([0-9.]+)', line)
-            w = re.search(r'"power_w_mean": ([0-9.]+)', line)
+            w = re.search(r'"power_w_from_energy_counter": ([0-9.]+)', line) or re.search(r'"power_w_mean": ([0-9.]+)', line)
             if c:
                 clocks = f"; sclk {float(c.group(1)):.0f} MHz" + (f", {float(w.group(1)):.0f} W" if w else "") + " during the timed region"
     if not rows:
@@ -48,7 +48,11 @@ def bench_line(path: Path) -> str:
         d = json.loads(txt)
     except Exception:  # noqa: BLE001
         return "(not a JSON line)"
+    if "value" not in d:
+        return "(not a bench line: see the notes below)"
     out = f"value {d.get('value', 0):.1f} {d.get('unit', '')}, ms_per_step {d.get('ms_per_step', 0):.3f}, n_gpus {d.get('n_gpus')}"
+    if d.get("latency_ms_p50") is not None:
+        out += f", p50 {d['latency_ms_p50']:.3f} ms"
     r = d.get("roofline") or {}
     if r:
         out += f", roofline.frac {r.get('frac', 0):.3f} ({r.get('kernel', '')})"
@@ -61,10 +65,10 @@ def bench_line(path: Path) -> str:
 
 
 def main() -> None:
-    print("# profiles/ — measurement evidence (one MI355X, ROCm 7.x, `gpurun`); files are named per round: `r01_*` … `r04_*`\n")
+    print("# profiles/ — measurement evidence (one MI355X, ROCm 7.x, `gpurun`); files are named per round: `r01_*` … `r05_*`\n")
     print("The tables below are GENERATED from the files by `scripts/profiles_index.py` (figures are read out of each file, not "
           "typed); the notes on the other records follow them.\n")
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         files = sorted(P.glob(f"{rnd}_*"))
         if not files:
             continue
