@@ -527,13 +527,6 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
                 atomicMax(&b.results[qi].score_floor, L.pub_floor);
                 atomicMax(&b.results[qi].pad0[2], lb);
             }
-            if (rg.publish) {
-                uint32_t v = L.df_lds[0];
-#pragma unroll
-                for (int w = 1; w < kWaves; ++w) v = max(v, L.df_lds[w]);
-                // (one atomic per publisher and address, performed at the memory side: visible to the other XCDs' agent-scope loads)
-                if (v) atomicMax(&b.score_pub[(size_t)qi * kScorePubRanges + rg.pub_slot], v);
-            }
         }
         unsigned long long* const lst = b.keys + q.key_off;
         const unsigned long long below_me = (1ull << lane) - 1ull;
@@ -551,6 +544,28 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
                     ((unsigned long long)(uint32_t)md_mask[i] << 32) | (unsigned long long)(~(doc0 + (md_own[i] >> 16)));
             }
             at += (uint32_t)__popcll(sm[NITER + t]);
+        }
+        if (rg.publish && wave == 0) {
+            // what this range publishes for the floor of the query's later ranges: a score word 4 of its documents reach — the
+            // larger of (the 4th largest lane best of its best wave: single-term documents) and (the 4th largest score among its
+            // documents that hold SEVERAL of the query's terms, parked in LDS by phase 6: the query's k-th best lives among those,
+            // a floor made of single-term keys alone let 3-6 % of the postings through).  One atomicMax per publisher and address,
+            // performed at the memory side: visible to the other XCDs' agent-scope loads.
+            uint32_t v = L.df_lds[0];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) v = max(v, L.df_lds[w]);
+            if (n_multi >= 4u) {
+                uint32_t mbest = 0u;  // this lane's best of the multi-term scores lane, lane + 64, ...
+                for (uint32_t i = lane; i < n_multi; i += 64u) mbest = max(mbest, (uint32_t)md_mask[i]);
+                uint32_t m4 = 0u;
+#pragma unroll
+                for (int bit = 31; bit >= 8; --bit) {
+                    const uint32_t t = m4 | (1u << bit);
+                    m4 = (uint32_t)__popcll(__ballot(mbest >= t)) >= 4u ? t : m4;
+                }
+                v = max(v, m4);
+            }
+            if (lane == 0 && v) atomicMax(&b.score_pub[(size_t)qi * kScorePubRanges + rg.pub_slot], v);
         }
         return;
     }
