@@ -43,6 +43,10 @@ def lib() -> C.CDLL:
     vp = C.c_void_p
     L.cpf_distances_f32.restype = None
     L.cpf_distances_f32.argtypes = [vp, C.c_uint64, C.c_uint32, vp, vp, C.c_int]
+    L.cpf_place_rows.restype = vp
+    L.cpf_place_rows.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_int]
+    L.cpf_free.restype = None
+    L.cpf_free.argtypes = [vp]
     L.cpf_bm25_hashmap.restype = C.c_uint64
     L.cpf_bm25_hashmap.argtypes = [C.POINTER(_Entry), C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_uint32, C.c_uint64,
                                    vp, vp, C.POINTER(C.c_uint64)]
@@ -62,6 +66,32 @@ def distances(corpus, q, threads: int = 1) -> np.ndarray:
     out = np.empty(n, dtype=np.float32)
     lib().cpf_distances_f32(corpus.ctypes.data, n, d, q.ctypes.data, out.ctypes.data, int(threads))
     return out
+
+
+class PlacedRows:
+    """A copy of `corpus` first-touched by the `threads` threads that will scan it (cpf_place_rows): `distances(q)` scans it with
+    the same split.  Context manager; frees the copy on exit."""
+
+    def __init__(self, corpus, threads: int):
+        corpus = np.ascontiguousarray(corpus, dtype=np.float32)
+        self.n, self.d, self.threads = corpus.shape[0], corpus.shape[1], int(threads)
+        self.ptr = lib().cpf_place_rows(corpus.ctypes.data, self.n, self.d, self.threads)
+        if not self.ptr:
+            raise MemoryError("cpf_place_rows")
+
+    def distances(self, q) -> np.ndarray:
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        out = np.empty(self.n, dtype=np.float32)
+        lib().cpf_distances_f32(self.ptr, self.n, self.d, q.ctypes.data, out.ctypes.data, self.threads)
+        return out
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self.ptr:
+            lib().cpf_free(self.ptr)
+            self.ptr = None
 
 
 def bm25_hashmap(entries, n_tokens: int, total_documents: float, k: float, threshold, top_k: int):
