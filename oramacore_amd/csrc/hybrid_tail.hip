@@ -16,7 +16,7 @@
 //
 // One read-back, one wake-up.  Same f32 operations in the same order as the host forms (this unit is compiled with
 // -ffp-contract=off like every unit that must round like the scalar reference): bit-identical answers, tested against the
-// host tail, K3 and the oracle (tests/test_bm25_ranges_gpu.py::test_one_call_hybrid_search_on_the_range_scorer,
+// host tail, K3 and the CPU restatement (tests/test_bm25_ranges_gpu.py::test_one_call_hybrid_search_on_the_range_scorer,
 // tests/test_full_size_gpu.py::test_c4_full_size_hybrid_bit_exact).
 #include "hybrid_tail.hpp"
 

@@ -888,8 +888,8 @@ __global__ void f16_seed_candidates_kernel(const float* __restrict__ best_dist,
         // strict '<' against the k-th best: a later row with an equal distance has a higher row index
         // and can never displace it (tie rule: distance asc, row asc)
         float t = (n == k) ? best_dist[(uint64_t)j * k + (k - 1)] : __builtin_huge_valf();
-        // (tau_cap: a bound from OUTSIDE this store's own rows so far — another shard's head, or the ceiling experiment's
-        // oracle: rows AT the bound may still belong to the answer there, so the cap is passed one ulp up by its producer)
+        // (tau_cap: a bound from OUTSIDE this store's own rows so far — another shard's head, or the ceiling experiment's best-case
+        // bound: rows AT the bound may still belong to the answer there, so the cap is passed one ulp up by its producer)
         if (tau_cap) t = fminf(t, tau_cap[j]);
         tau[j] = t;
     }
