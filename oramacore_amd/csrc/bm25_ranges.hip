@@ -370,7 +370,11 @@ __device__ __forceinline__ void score_body(const RangeBatch& b, const RangeQuery
                 b.keys[q.key_off + rg.slot_base + e] = 0ull;
                 if (b.map_idx) b.map_idx[rg.slot_base + e] = 0xffffffffu;
             }
-        if (threadIdx.x == 0) b.results[qi].overflow = 1;
+        if (threadIdx.x == 0) {
+            b.results[qi].overflow = 1;
+            // how much too much, in 1/16: what the host narrows the ranges by (the tables take kMultiMax documents / kCells cells)
+            atomicMax(&b.results[qi].pad1[0], max((n_multi * 16u + kMultiMax - 1u) / kMultiMax, (n_cells * 16u + kCells - 1u) / kCells));
+        }
         return;
     }
 
@@ -782,7 +786,10 @@ __device__ __forceinline__ void range_score_main(const RangeBatch& b) {
                 b.keys[q.key_off + rg.slot_base + e] = 0ull;
                 if (b.map_idx) b.map_idx[rg.slot_base + e] = 0xffffffffu;
             }
-        if (threadIdx.x == 0) b.results[qi].overflow = 1;
+        if (threadIdx.x == 0) {
+            b.results[qi].overflow = 1;
+            atomicMax(&b.results[qi].pad1[0], (cap * 16u + kRangeCap - 1u) / kRangeCap);  // (postings against the 2 048 a range takes, in 1/16)
+        }
         return;
     }
     // rounds of the per-posting phases (workgroup-uniform): the bodies that exist are 2, 4, 5, 6, 7 and 8 rounds — a range of

@@ -44,7 +44,7 @@ struct RangeResult {
     uint32_t count;       // documents in the score map
     uint32_t pad0[31];
     uint32_t overflow;    // a range held more than kRangeCap postings: rerun with smaller ranges
-    uint32_t pad1[31];
+    uint32_t pad1[31];    // pad1[0]: by how much the worst range was too large, in 1/16 (postings / documents with several postings / cells against what a workgroup takes)
     uint32_t df[kMaxTokens];
     uint32_t max_key;     // hybrid: ordered(largest non-NaN score), 0 = none
     uint32_t pad2[31];

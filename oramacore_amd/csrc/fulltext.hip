@@ -612,17 +612,29 @@ bool ranges_eligible(const orama_post* p, const orama_term_ref* refs, uint32_t n
 // ranges, so the default keeps 25 % of headroom: 1 536 (a Poisson count of that mean is 13 standard deviations below the
 // cap; documents of a term clustered in id space overflow at any target).  Any width — a power of two would leave the average
 // anywhere between target / 2 and target — `shrink` times 8x smaller after an overflow.
-uint32_t choose_width(uint64_t n_docs, uint64_t total_postings, uint32_t shrink) {
+// `narrow16`: by how much the ranges are narrower than the target asks, in 1/16 (16 = not at all).  After an overflow the scoring
+// launch says by how much its worst range was too large (RangeResult::pad1[0]: postings, documents with several postings or
+// cells against what a workgroup takes) and the query is rerun that much narrower plus a quarter — 1.5 x at least; round 4
+// went 8 x narrower whatever the excess: lists over the same documents (a term in two fields) ran at a third of the rate of
+// independent lists ever after (scripts/bench_overlap_lists.py).  The factor that held is remembered per list set
+// (orama_post::shrink_hint).
+uint32_t choose_width(uint64_t n_docs, uint64_t total_postings, uint32_t narrow16) {
     static const uint64_t target = [] {
         const char* e = std::getenv("ORAMA_K3R_TARGET");
         const long v = e ? std::atol(e) : 0;
         return (uint64_t)(v >= 16 && v <= (long)kRangeCap ? v : 1536);
     }();
     uint64_t w = total_postings ? n_docs * target / total_postings : n_docs;
-    // (the first step is 4x: a cell-table overflow — lists that overlap — needs little, and the width that held is remembered
-    // for the next query over the same lists, orama_post::shrink_hint; clustered documents take the 8x steps behind it)
-    for (uint32_t i = 0; i < shrink; ++i) w /= i == 0 ? 4 : 8;
+    if (narrow16 > 16u) w = w * 16u / narrow16;
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(w, 1), kRangeMaxWidth);
+}
+uint32_t narrower_after_overflow(uint32_t narrow16, uint32_t excess16) {
+    const uint64_t cur = std::max(narrow16, 16u);
+    // (the excess is measured at the current width: narrower by that factor again, a quarter on top for the ranges' spread)
+    uint64_t next = cur * std::max(excess16, 17u) / 16u;
+    next = next + next / 4;
+    next = std::max<uint64_t>(next, cur + cur / 2);
+    return (uint32_t)std::min<uint64_t>(next, 1u << 30);
 }
 
 // Hybrid answer from the range scorer's outputs (a batch of one, no OMC): normalize_and_combine + count + top_n
@@ -829,7 +841,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                           bitmap_bits, jb.df_out))
                 continue;
         }
-        if (total) pending.push_back({j, shrink_recall(p, jb.refs, jb.n_refs), total});
+        if (total) pending.push_back({j, shrink_recall(p, jb.refs, jb.n_refs), total});  // (shrink = narrow16: 0 / 16 = the target's width)
     }
     ORAMA_REQUIRE(p->n_docs > 0 || pending.empty(), "postings store is empty (orama_post_build not called)");
     // Queries of similar length share a set of launches: the launches of a chunk are sized by its longest query (grid of the
@@ -1230,11 +1242,11 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             const RangeJob& jb = jobs[pd.job];
             if (h_res[ci].overflow) {
                 ORAMA_REQUIRE(c.queries[ci].width > 1, "internal: a one-document range overflowed");
-                ++pd.shrink;
+                pd.shrink = narrower_after_overflow(pd.shrink, h_res[ci].pad1[0]);
                 pending.push_back(pd);
                 continue;
             }
-            if (pd.shrink && !df_pass) shrink_remember(p, jb.refs, jb.n_refs, pd.shrink);  // (the width the next query over these lists starts at)
+            if (pd.shrink > 16u && !df_pass) shrink_remember(p, jb.refs, jb.n_refs, pd.shrink);  // (the width the next query over these lists starts at)
             if (df_pass) {
                 memcpy(jb.df_out, h_res[ci].df, sizeof(uint32_t) * kMaxTokens);
                 df_remember(p, jb.refs, jb.n_refs, jb.params->n_tokens, c.d_allow != nullptr, c.allow_version, bitmap_bits, h_res[ci].df);
