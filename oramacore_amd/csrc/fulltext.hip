@@ -201,6 +201,9 @@ struct orama_post {
     bool ntf_valid = false;
     bool has_omc = false;
     uint64_t generation = 0;  // bumped by every rebuild of the doc table: facet fields resolved against an older one are stale
+    // bumped (under the exclusive lock) by everything a search's answer depends on — postings, average lengths, multipliers: a
+    // call that lets go of the shared lock between two phases (the sharded batch around its first exchange) compares it
+    uint64_t mutations = 0;
     // corpus_docs.len() of a token that has SEVERAL lists (one per field, prefix / typo expansions) = the number of distinct
     // documents in the union of those lists (token_score.rs:262-275): a property of the INDEX, not of the query.  The first
     // query that brings a set of lists has it counted on the device (a second scoring-sized launch and a host round trip in
@@ -297,6 +300,7 @@ void shrink_remember(orama_post* p, const orama_term_ref* refs, uint32_t n_refs,
 // build / append that called it (a caller that retried the append would append twice: ADVICE r04).  It leaves ntf_valid
 // false — the kernels then divide themselves, same operations, same bits — and reports OK.
 int refresh_post_ntf_try(orama_post* p) {
+    ++p->mutations;
     {  // (every change of the postings comes through here: what was counted over the old lists is forgotten)
         std::lock_guard<std::mutex> g(p->df_union_mu);
         p->df_union.clear();
@@ -1640,6 +1644,7 @@ int orama_post_set_omc(orama_post* p, const uint64_t* omc_doc, const float* omc_
     ORAMA_REQUIRE(n == 0 || (omc_doc && omc_mul), "null argument");
     ORAMA_ON_DEVICE(p->ctx->device);
     std::unique_lock<std::shared_mutex> lk(p->mu);
+    ++p->mutations;
     if (n == 0) {
         p->has_omc = false;
         return ORAMA_OK;
@@ -2895,9 +2900,16 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
         }
         const uint32_t nc = (uint32_t)cand.size();
         if (nc == 0) continue;
-        // every shard stays read-locked from its eligibility test to its last launch
+        // every shard is read-locked during its df pass and again during its scoring pass — NOT across the exchange between them
+        // (a writer on any rank waited for a network collective): a store that changed in between is noticed
+        // (`mutations`) and the block's queries go to the staged one-by-one form, which holds its locks from df to answer
         std::vector<std::shared_lock<std::shared_mutex>> locks;
         for (uint32_t i = 0; i < nl; ++i) locks.emplace_back(shards[i]->mu);
+        std::vector<uint64_t> mutations_a(nl);
+        for (uint32_t i = 0; i < nl; ++i) mutations_a[i] = shards[i]->mutations;
+        // a failure that belongs to a QUERY (INVALID / UNSUPPORTED out of a shard's pass) is not the call's: those queries take
+        // the one-by-one form, which reports per query; BUSY / HIP / OOM are the call's
+        auto query_specific = [](int st) { return st == ORAMA_ERR_INVALID || st == ORAMA_ERR_UNSUPPORTED; };
         std::vector<uint32_t> words((size_t)nc * kWordsPerQuery, 0);  // [df x 64 | cannot | failed] per query, summed over the shards
         auto df_of_query = [&](size_t c) { return &words[c * kWordsPerQuery]; };
         std::vector<std::vector<uint32_t>> shard_df(nl, std::vector<uint32_t>((size_t)nc * kMaxTokens, 0));
@@ -2943,13 +2955,14 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
             for (uint32_t c = 0; c < nc; ++c) {
                 uint32_t* w = df_of_query(c);
                 for (uint32_t t = 0; t < kMaxTokens; ++t) w[t] += shard_df[i][(size_t)c * kMaxTokens + t];
-                if (!can[(size_t)i * nc + c]) w[kMaxTokens] += 1;
-                if (shard_status[i] != ORAMA_OK) w[kMaxTokens + 1] += 1;
+                if (!can[(size_t)i * nc + c] || query_specific(shard_status[i])) w[kMaxTokens] += 1;
+                if (shard_status[i] != ORAMA_OK && !query_specific(shard_status[i])) w[kMaxTokens + 1] += 1;
             }
         int local_fail = ORAMA_OK;
         std::string local_error;
         for (uint32_t i = 0; i < nl && local_fail == ORAMA_OK; ++i)
-            if (shard_status[i] != ORAMA_OK) local_fail = shard_status[i], local_error = shard_error[i];
+            if (shard_status[i] != ORAMA_OK && !query_specific(shard_status[i])) local_fail = shard_status[i], local_error = shard_error[i];
+        locks.clear();
         const double ms_a = ms_since(t_block);
         // ---- exchange 1: index-wide df and flags
         {
@@ -2981,7 +2994,10 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
         std::vector<char> local_blocks(block_bytes * nl, 0);
         std::vector<uint32_t> df_fast((size_t)nf * kMaxTokens);
         for (uint32_t x = 0; x < nf; ++x) memcpy(&df_fast[(size_t)x * kMaxTokens], df_of_query(fast[x]), sizeof(uint32_t) * kMaxTokens);
-        on_shards([&](uint32_t i) -> int {
+        for (uint32_t i = 0; i < nl; ++i) locks.emplace_back(shards[i]->mu);
+        bool stale = false;  // a store of this process changed between the df pass and now: its df no longer describes it
+        for (uint32_t i = 0; i < nl; ++i) stale = stale || shards[i]->mutations != mutations_a[i];
+        if (!stale) on_shards([&](uint32_t i) -> int {
             orama_post* p = shards[i];
             ORAMA_ON_DEVICE(p->ctx->device);
             char* blk = local_blocks.data() + (size_t)i * block_bytes;
@@ -3003,11 +3019,15 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
                                       allow_bitmaps ? bitmap_bits : 0, apply_omc, two ? sc2.s.get() : nullptr);
         });
         local_fail = ORAMA_OK;
-        for (uint32_t i = 0; i < nl; ++i)
-            if (shard_status[i] != ORAMA_OK) {
-                *reinterpret_cast<uint32_t*>(local_blocks.data() + (size_t)i * block_bytes + off_fail) = 1u;
+        for (uint32_t i = 0; i < nl; ++i) {
+            uint32_t* word = reinterpret_cast<uint32_t*>(local_blocks.data() + (size_t)i * block_bytes + off_fail);
+            if (stale || query_specific(shard_status[i])) {
+                *word = 2u;  // not the call's failure: the block's queries are answered one by one
+            } else if (shard_status[i] != ORAMA_OK) {
+                *word = 1u;
                 if (local_fail == ORAMA_OK) local_fail = shard_status[i], local_error = shard_error[i];
             }
+        }
         locks.clear();
         const double ms_b = ms_since(t_b);
         const auto t_x2 = now();
@@ -3017,12 +3037,21 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
             const int st = shard_gather_blocks(g, local_blocks.data(), block_bytes, all_blocks.data());
             if (st != ORAMA_OK) return st;
         }
-        for (uint32_t r = 0; r < world; ++r) any_failed = any_failed || *reinterpret_cast<const uint32_t*>(all_blocks.data() + (size_t)r * block_bytes + off_fail) != 0;
+        bool any_one_by_one = false;
+        for (uint32_t r = 0; r < world; ++r) {
+            const uint32_t word = *reinterpret_cast<const uint32_t*>(all_blocks.data() + (size_t)r * block_bytes + off_fail);
+            any_failed = any_failed || word == 1u;
+            any_one_by_one = any_one_by_one || word == 2u;
+        }
         if (any_failed) {
             call_status = local_fail != ORAMA_OK ? local_fail : ORAMA_ERR_HIP;
             if (local_fail != ORAMA_OK) set_error("sharded batch: %s", local_error.c_str());
             else set_error("sharded batch: the scoring pass failed on another rank");
             break;
+        }
+        if (any_one_by_one) {  // (seen by every rank: the same queries join `slow` everywhere)
+            for (uint32_t x = 0; x < nf; ++x) slow.push_back(cand[fast[x]]);
+            continue;
         }
         const double ms_x2 = ms_since(t_x2);
         const auto t_c = now();
