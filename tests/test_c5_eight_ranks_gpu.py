@@ -51,6 +51,11 @@ def test_c5_eight_rank_job_over_the_loopback_transport(ctx, tmp_path):
     seen = line["config"]["ranks_seen"]
     assert [e["rank"] for e in seen] == list(range(G)) and len({e["pid"] for e in seen}) == G, seen
     assert line["value"] > 0 and line["config"]["queries_per_step"] == Q
+    # BASELINE.json's metric names p50 latency at every N: the 8-rank line carries it (slowest rank per step), with the HIP-event
+    # spans of the step's parts — all-gather and K6 among them
+    assert line["latency_ms_p50"] > 0 and line["latency_ms_p95"] >= line["latency_ms_p50"] and line["latency_samples"] >= 5
+    bd = line["step_breakdown_us"]
+    assert bd["scan"] > 0 and bd["all_gather"] is not None and bd["merge_k6"] is not None
 
     ranks = [np.load(f"{dump}.rank{g}.npz") for g in range(G)]
     ids, dist, cnt, qs = ranks[0]["ids"], ranks[0]["dist"], ranks[0]["cnt"], ranks[0]["queries"]
