@@ -1279,13 +1279,20 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
 
     uint32_t head = 0, inflight = 0;
     int rc = ORAMA_OK;
+    static const bool trace_flow = [] { const char* e = std::getenv("ORAMA_K3R_FLOW"); return e && std::atoi(e) != 0; }();
+    const auto t_flow = std::chrono::steady_clock::now();
+    auto us_flow = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_flow).count(); };
     while (rc == ORAMA_OK && (!pending.empty() || inflight)) {
         while (rc == ORAMA_OK && inflight < n_slots && !pending.empty()) {
+            const double t0 = us_flow();
             rc = enqueue(slots[(head + inflight) % n_slots]);
+            if (trace_flow && n_jobs > 64) fprintf(stderr, "[flow] %9.1f us: enqueued on slot %u in %.1f us (%u in flight before)\n", t0, (head + inflight) % n_slots, us_flow() - t0, inflight);
             ++inflight;  // (a chunk that failed half-way may still have launches on its stream: drained below)
         }
         if (rc != ORAMA_OK) break;
+        const double t1 = us_flow();
         rc = complete(slots[head]);
+        if (trace_flow && n_jobs > 64) fprintf(stderr, "[flow] %9.1f us: completed slot %u in %.1f us\n", t1, head, us_flow() - t1);
         head = (head + 1) % n_slots;
         --inflight;
     }
