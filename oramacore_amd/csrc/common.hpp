@@ -254,6 +254,10 @@ struct orama_ctx {
     // one address) and a lone query's 400 workgroups run together — 14.7 -> 11.7 K single calls per second with compact lists
     // (orama_ctx_set_bm25_ranges(ctx, 4): every batch size, for the parity tests)
     uint32_t bm25_compact_min = 8;
+    // small host<->device blocks (the range scorer's chunk tables and answers, a lone query and its hits) move by a kernel of
+    // the caller's stream instead of an SDMA copy (stage.hip); ORAMA_STAGE_COPY=dma puts the copy commands back
+    bool stage_by_kernel = true;
+    int select_wide = 1;  // K4: a few long dense lists take one round of 32 values per thread (select.hip, pairs_reduce_wide_kernel)
     int k3r_merge = 0;  // comparison builds only (ORAMA_COMPARISON_KERNELS=1): ORAMA_K3R_MERGE=1 scores ranges with the round-3 merge tree
     // stores created as ORAMA_DTYPE_F32_SHADOW16 answer orama_vec_search in two stages (fp16 candidates, fp32 decision);
     // 0 = always the plain fp32 scan, 2 = two stages also where the plain scan is expected to be faster (small stores

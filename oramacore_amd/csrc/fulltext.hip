@@ -25,6 +25,7 @@
 #include "shard_exchange.hpp"
 #include "common.hpp"
 #include "select.hpp"
+#include "stage.hpp"
 #include "vec_internal.hpp"
 
 using namespace orama;
@@ -996,7 +997,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         memcpy(h + seg_bytes + q_bytes + idf_bytes, c.lens.data(), (size_t)nq * 4);
         ORAMA_TRY(sc->misc0.reserve(seg_bytes + q_bytes + idf_bytes + len_bytes));
         c.trace.mark(1);
-        ORAMA_HIP_TRY(hipMemcpyAsync(sc->misc0.p, h, seg_bytes + q_bytes + idf_bytes + len_bytes, hipMemcpyHostToDevice, s));
+        ORAMA_TRY(stage_block(p->ctx, sc->misc0.p, h, seg_bytes + q_bytes + idf_bytes + len_bytes, hipMemcpyHostToDevice, s));
         c.trace.mark(2);
         ORAMA_TRY(sc->misc1.reserve((size_t)bounds_entries * 4));
         // device results in ONE block: [RangeResult x nq | ids | scores | n]  -> one read-back per chunk
@@ -1179,10 +1180,10 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                 ORAMA_TRY(launch_select(p->ctx, sp, s));
             }
             char* h_tail = sc->h_misc.as<char>() + (size_t)nq * kMaxTokens * 4 + 4096;  // (behind the idf staging: reserved above)
-            ORAMA_HIP_TRY(hipMemcpyAsync(h_tail, d_tail, out_tail, hipMemcpyDeviceToHost, s));
+            ORAMA_TRY(stage_block(p->ctx, h_tail, d_tail, out_tail, hipMemcpyDeviceToHost, s));
             c.h_tail = h_tail;
         }
-        ORAMA_HIP_TRY(hipMemcpyAsync(h_res, d_out, c.kmax ? out_bytes : res_bytes, hipMemcpyDeviceToHost, s));
+        ORAMA_TRY(stage_block(p->ctx, h_res, d_out, c.kmax ? out_bytes : res_bytes, hipMemcpyDeviceToHost, s));
         c.trace.mark(6);
         return ORAMA_OK;
     };
@@ -2258,7 +2259,7 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
         ORAMA_TRY(a->query.reserve((size_t)dim * 4));
         ORAMA_TRY(a->h_in.reserve((size_t)dim * 4));
         memcpy(a->h_in.p, query, (size_t)dim * 4);
-        ORAMA_HIP_TRY(hipMemcpyAsync(a->query.p, a->h_in.p, (size_t)dim * 4, hipMemcpyHostToDevice, sa));
+        ORAMA_TRY(stage_block(ctx, a->query.p, a->h_in.p, (size_t)dim * 4, hipMemcpyHostToDevice, sa));
         const uint64_t* d_allow = nullptr;
         ORAMA_TRY(resolve_allow(ctx, a.s.get(), allow_bitmap, bitmap_bits, sa, &d_allow));
         // results in one block [ids | distances | n]: one read-back
@@ -2271,7 +2272,7 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
             return ts.begin_device(v, a, a2, a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n);
         if (two_stage) return ts.begin(v, a, a2, a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n);
         ORAMA_TRY(vec_search_enqueue(v, a.s.get(), a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n, sa));
-        ORAMA_HIP_TRY(hipMemcpyAsync(a->h_out.p, d_ids, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, sa));
+        ORAMA_TRY(stage_block(ctx, a->h_out.p, d_ids, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, sa));
         return ORAMA_OK;
     };
     // ---- join A; in-tree epilogue on the host: similarity, rescale, cut-off, per-doc sum (hit order)
@@ -2281,7 +2282,7 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
         if (!have_rows) return ORAMA_OK;
         if (two_stage) {  // (an unproven candidate list is re-answered by the plain scan in here)
             ORAMA_TRY(ts.finish());
-            ORAMA_HIP_TRY(hipMemcpyAsync(a->h_out.p, a->out_ids.p, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, a->stream));
+            ORAMA_TRY(stage_block(ctx, a->h_out.p, a->out_ids.p, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, a->stream));
         }
         ORAMA_HIP_TRY(hipStreamSynchronize(a->stream));
         const char* ha = a->h_out.as<char>();

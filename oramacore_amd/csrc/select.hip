@@ -1023,6 +1023,158 @@ __global__ __launch_bounds__(kSortThreads, 8) void pairs_reduce_kernel(const flo
     for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = i < kept ? s[i] : 0ull;
 }
 
+// ---- a FEW LONG dense lists (a lone query's distance array: 1 M values), round 5 -------------------------------------------------
+// pairs_reduce_kernel walks such a list in rounds of 8 192 values: 40 parts of 1 M values take 3-4 rounds each, every round a
+// chain of load -> bound -> compact -> cut: 39 us behind a 230 us scan of 1 M x 384 rows (profiles/r05_c2_kernel_stats.md).
+// Here a part's <= 32 768 values are loaded ONCE, 32 per thread, all loads in flight together; the bound from the lanes' best
+// keys (workgroup_kth_lower_bound) leaves a few hundred of them for LDS and ONE cut finishes the part.  The bound is a
+// heuristic for the survivor count, not a guarantee (one wave of small values lowers it for everybody): when more than
+// 8 192 keys reach it, nothing has been lost — the values are still in registers — and the part is redone in rounds of 7 per
+// thread (7 168 + k <= 8 192) exactly as pairs_reduce_kernel would.  One workgroup per CU (the registers), which 40 parts do
+// not mind.
+constexpr int kWidePer = 32;
+
+struct WideState {
+    uint32_t kept;
+    unsigned long long kth;  // 0: not known
+};
+
+// One round over x[T0 .. T0 + TN) (value t of thread i is element t * 1024 + i of the part).  Returns false — and leaves
+// s[0 .. st.kept) and `st` as they were — when more keys reached the floor than LDS holds behind the kept ones.
+template <int T0, int TN>
+__device__ __forceinline__ bool wide_round(const float (&x)[kWidePer], uint32_t base_index, uint32_t cnt_in, bool descending,
+                                           uint32_t k, unsigned long long* s, uint32_t* hist, unsigned long long* red_max,
+                                           unsigned long long* red_min, uint32_t* red_nz, uint32_t* sel, uint32_t* cursor,
+                                           uint32_t* cursor2, unsigned long long* kth_s, WideState& st) {
+    if ((uint32_t)T0 * kSortThreads >= cnt_in) return true;  // (uniform) nothing of the part lies here
+    const uint32_t here = min((uint32_t)TN * kSortThreads, cnt_in - (uint32_t)T0 * kSortThreads);
+    const int lane = threadIdx.x & 63;
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const float v = x[T0 + j];
+        const unsigned long long key = v == v ? make_key(v, base_index + (uint32_t)(T0 + j) * kSortThreads + threadIdx.x, descending) : 0ull;
+        best = key > best ? key : best;
+    }
+    if (threadIdx.x == 0) {
+        *cursor = st.kept;
+        *cursor2 = 0;
+    }
+    unsigned long long floor_key = st.kth > 1ull ? st.kth : 1ull;
+    {
+        const unsigned long long lb = workgroup_kth_lower_bound(best, k, red_min, here);  // (one barrier inside)
+        floor_key = lb > floor_key ? lb : floor_key;
+    }
+    // the keys at or above the floor, behind the kept ones; one LDS atomic per wave and 8 values; nothing written past the end
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j0 = 0; j0 < TN; j0 += 8) {
+        unsigned long long kr[8], m[8];
+        uint32_t tot = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            kr[j] = 0ull;
+            if (j0 + j < TN) {
+                const float v = x[T0 + j0 + j];
+                if (v == v) kr[j] = make_key(v, base_index + (uint32_t)(T0 + j0 + j) * kSortThreads + threadIdx.x, descending);
+            }
+            m[j] = __ballot(kr[j] >= floor_key);
+            tot += (uint32_t)__popcll(m[j]);
+        }
+        uint32_t base = 0;
+        if (lane == 0 && tot) base = atomicAdd(cursor, tot);
+        base = __shfl(base, 0, 64);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t at = base + (uint32_t)__popcll(m[j] & below);
+            if (kr[j] >= floor_key && at < kKeysChunk) s[at] = kr[j];
+            base += (uint32_t)__popcll(m[j]);
+        }
+    }
+    __syncthreads();
+    const uint32_t cnt = uniform_u32(*cursor);
+    if (cnt > kKeysChunk) {  // (uniform) more than LDS holds: the caller takes smaller rounds
+        __syncthreads();     // (the cursor is rewritten by the next round)
+        return false;
+    }
+    if (cnt <= k) {
+        st.kept = cnt;
+        __syncthreads();
+    } else if (cnt <= kRankCountSmall) {
+        unsigned long long key;
+        const uint32_t r = rank_by_counting(s, cnt, &key);
+        __syncthreads();  // every key is in a register
+        if (key && r < k) {
+            s[r] = key;
+            if (r == k - 1u) *kth_s = key;
+        }
+        __syncthreads();
+        st.kept = k;
+        st.kth = uniform_u64(*kth_s);
+    } else {
+        const unsigned long long thr = lds_keys_threshold(s, cnt, k, hist, red_max, red_min, red_nz, sel);  // (barriers inside)
+        unsigned long long key = threadIdx.x < cnt ? s[threadIdx.x] : 0ull;
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < cnt; i0 += blockDim.x) {
+            if (i0) {
+                __syncthreads();
+                key = i0 + threadIdx.x < cnt ? s[i0 + threadIdx.x] : 0ull;
+                __syncthreads();
+            }
+            const bool tk = key >= thr;
+            const unsigned long long m = __ballot(tk);
+            uint32_t base = 0;
+            if (lane == 0 && m) base = atomicAdd(cursor2, (uint32_t)__popcll(m));
+            base = __shfl(base, 0, 64);
+            if (tk) s[base + (uint32_t)__popcll(m & below)] = key;
+        }
+        __syncthreads();
+        st.kept = min(uniform_u32(*cursor2), k);
+        st.kth = uniform_u64(thr);
+        __syncthreads();
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(kSortThreads) void pairs_reduce_wide_kernel(const float* __restrict__ vals, uint64_t stride,
+                                                                        const uint32_t* __restrict__ n_dev, uint32_t n_max,
+                                                                        bool descending, uint32_t k,
+                                                                        unsigned long long* __restrict__ out, bool force_narrow) {
+    __shared__ unsigned long long s[kKeysChunk];
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
+    __shared__ uint32_t red_nz[kSortThreads / 64];
+    __shared__ uint32_t sel[3], cursor, cursor2;
+    __shared__ unsigned long long kth_s;
+    const uint32_t qi = blockIdx.x, part = blockIdx.y, parts = gridDim.y;
+    const uint32_t n = uniform_u32(n_dev ? min(n_max, n_dev[qi]) : n_max);
+    const uint64_t per = ((uint64_t)n + parts - 1) / parts;  // <= kWidePer * 1024: the launcher's rule
+    const uint32_t pos = (uint32_t)min((uint64_t)n, part * per);
+    const uint32_t end = (uint32_t)min((uint64_t)n, (uint64_t)pos + per);
+    const uint32_t cnt_in = end - pos;
+    const float* v = vals + (uint64_t)qi * stride + pos;
+    float x[kWidePer];
+#pragma unroll
+    for (int t = 0; t < kWidePer; ++t) {
+        const uint32_t i = (uint32_t)t * kSortThreads + threadIdx.x;
+        x[t] = i < cnt_in ? v[i] : __builtin_nanf("");
+    }
+    WideState st{0u, 0ull};
+#define ORAMA_WIDE_ROUND(T0, TN) \
+    wide_round<T0, TN>(x, pos, cnt_in, descending, k, s, hist, red_max, red_min, red_nz, sel, &cursor, &cursor2, &kth_s, st)
+    if (force_narrow || !ORAMA_WIDE_ROUND(0, kWidePer)) {
+        // (uniform) rounds that always fit: 7 x 1 024 + kept <= 8 192 (k <= 256 here)
+        ORAMA_WIDE_ROUND(0, 7);
+        ORAMA_WIDE_ROUND(7, 7);
+        ORAMA_WIDE_ROUND(14, 7);
+        ORAMA_WIDE_ROUND(21, 7);
+        ORAMA_WIDE_ROUND(28, 4);
+    }
+#undef ORAMA_WIDE_ROUND
+    unsigned long long* o = out + ((uint64_t)qi * parts + part) * k;
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = i < st.kept ? s[i] : 0ull;
+}
+
 // Final ordering of <= 4096 keys: (value, 64-bit id asc, idx asc), empties (0) dropped.
 __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned long long* __restrict__ keys,
                                                                   uint32_t n_keys, uint64_t in_stride,
@@ -1343,7 +1495,15 @@ int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
         fin.out_n = p.out_n;
         fin.done = reinterpret_cast<uint32_t*>(p.state);
         static_assert(sizeof(SelectState) >= sizeof(uint32_t), "one word per list");
-        if (p.idx)
+        // a few long dense lists whose parts fit one round of 32 values per thread (1 M values in 40 parts at k = 100)
+        const int wide_mode = ctx->select_wide;  // ORAMA_SELECT_WIDE: 0 = rounds of 8 192 (round 4), 2 = the fallback rounds only (tests)
+        const bool wide = wide_mode != 0 && !p.idx && list_chunks > 16 && p.k <= kWaveBoundMaxK &&
+                          ((uint64_t)p.n + parts - 1) / parts <= (uint64_t)kWidePer * kSortThreads;
+        if (wide) {
+            hipLaunchKernelGGL(pairs_reduce_wide_kernel, dim3(p.q, parts), dim3(kSortThreads), 0, stream, p.vals, p.stride,
+                               p.n_dev, p.n, p.descending, p.k, p.keys, wide_mode == 2);
+            fin.done = nullptr;  // (never a whole list: the final kernel always orders)
+        } else if (p.idx)
             hipLaunchKernelGGL(pairs_reduce_kernel<true>, dim3(p.q, parts), dim3(kSortThreads), 0, stream, p.vals, p.idx, p.stride,
                                p.n_dev, p.n, p.descending, p.k, p.keys, fin);
         else

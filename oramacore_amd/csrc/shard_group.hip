@@ -33,6 +33,7 @@
 
 #include "bm25_kernels.hpp"
 #include "common.hpp"
+#include "stage.hpp"
 #include "select.hpp"
 #include "shard_exchange.hpp"
 #include "vec_internal.hpp"
@@ -644,7 +645,7 @@ int orama_shard_vec_search(orama_shard_group* g, orama_vec* const* shards, const
         ORAMA_TRY(s.d_n.reserve((size_t)q * 4));
         ORAMA_TRY(s.h_in.reserve(qbytes));
         memcpy(s.h_in.p, queries, qbytes);
-        ORAMA_HIP_TRY(hipMemcpyAsync(s.queries.p, s.h_in.p, qbytes, hipMemcpyHostToDevice, s.stream));
+        ORAMA_TRY(stage_block(s.ctx, s.queries.p, s.h_in.p, qbytes, hipMemcpyHostToDevice, s.stream));
         const uint64_t* allow = allow_bitmaps ? allow_bitmaps[i] : nullptr;
         ORAMA_REQUIRE(!allow || is_resident_allow(s.ctx, allow),
                       "sharded search takes RESIDENT allow bitmaps (orama_allow_token), one per local shard");
@@ -682,9 +683,8 @@ int orama_shard_vec_search(orama_shard_group* g, orama_vec* const* shards, const
                                   s0.out_val.as<float>(), s0.out_n.as<uint32_t>(), s0.stream));
     ORAMA_TRY(s0.h_out.reserve(nk * 12 + (size_t)q * 4));
     char* h = s0.h_out.as<char>();
-    ORAMA_HIP_TRY(hipMemcpyAsync(h, s0.out_ids.p, nk * 8, hipMemcpyDeviceToHost, s0.stream));
-    ORAMA_HIP_TRY(hipMemcpyAsync(h + nk * 8, s0.out_val.p, nk * 4, hipMemcpyDeviceToHost, s0.stream));
-    ORAMA_HIP_TRY(hipMemcpyAsync(h + nk * 12, s0.out_n.p, (size_t)q * 4, hipMemcpyDeviceToHost, s0.stream));
+    const StagePart back[3] = {{h, s0.out_ids.p, nk * 8}, {h + nk * 8, s0.out_val.p, nk * 4}, {h + nk * 12, s0.out_n.p, (size_t)q * 4}};
+    ORAMA_TRY(stage_blocks(s0.ctx, back, 3, hipMemcpyDeviceToHost, s0.stream));
     for (uint32_t i = n_local(g); i-- > 0;) {  // shard 0 last: its stream carries the merge + download
         ORAMA_HIP_TRY(hipSetDevice(L(g, i).device));
         ORAMA_HIP_TRY(hipStreamSynchronize(L(g, i).stream));

@@ -21,6 +21,7 @@
 #include "select.hpp"
 #include "vec_f16.hpp"
 #include "vec_internal.hpp"
+#include "stage.hpp"
 #include "vec_kernels.hpp"
 
 using namespace orama;
@@ -1399,7 +1400,7 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     ORAMA_TRY(sc->query.reserve(qbytes));
     ORAMA_TRY(sc->h_in.reserve(qbytes));
     memcpy(sc->h_in.p, queries, qbytes);
-    ORAMA_HIP_TRY(hipMemcpyAsync(sc->query.p, sc->h_in.p, qbytes, hipMemcpyHostToDevice, s));
+    ORAMA_TRY(stage_block(v->ctx, sc->query.p, sc->h_in.p, qbytes, hipMemcpyHostToDevice, s));
     const uint64_t* d_allow = nullptr;
     ORAMA_TRY(resolve_allow(v->ctx, sc.s.get(), allow_bitmap, bitmap_bits, s, &d_allow));
     const size_t nk = (size_t)q * k;
@@ -1415,9 +1416,8 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
     }
     ORAMA_TRY(sc->h_out.reserve(nk * 12 + (size_t)q * 4));
     char* h = sc->h_out.as<char>();
-    ORAMA_HIP_TRY(hipMemcpyAsync(h, sc->out_ids.p, nk * 8, hipMemcpyDeviceToHost, s));
-    ORAMA_HIP_TRY(hipMemcpyAsync(h + nk * 8, sc->out_val.p, nk * 4, hipMemcpyDeviceToHost, s));
-    ORAMA_HIP_TRY(hipMemcpyAsync(h + nk * 12, sc->out_n.p, (size_t)q * 4, hipMemcpyDeviceToHost, s));
+    const StagePart back[3] = {{h, sc->out_ids.p, nk * 8}, {h + nk * 8, sc->out_val.p, nk * 4}, {h + nk * 12, sc->out_n.p, (size_t)q * 4}};
+    ORAMA_TRY(stage_blocks(v->ctx, back, 3, hipMemcpyDeviceToHost, s));  // one launch, no copy engine (stage.hip)
     ORAMA_HIP_TRY(hipStreamSynchronize(s));
     memcpy(out_ids, h, nk * 8);
     memcpy(out_dist, h + nk * 8, nk * 4);

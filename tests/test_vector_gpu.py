@@ -435,3 +435,45 @@ def test_ties_at_the_cut_are_decided_by_row_index_whatever_the_list_length(ctx):
         assert ids[0].tolist() == o_ids.tolist(), n
         assert np.max(np.abs(dist[0] - o_dist)) <= 1e-6
         st.close()
+
+
+@pytest.mark.parametrize("mode", ["1", "2", "0"])
+def test_a_lone_query_over_a_long_dense_list_takes_one_round_per_part(monkeypatch, mode):
+    """Round 5: the distance array of a lone query (> 16 chunks of 8 192 values) is cut by
+    pairs_reduce_wide_kernel — a part's <= 32 768 values in registers, one bound, one cut.  ORAMA_SELECT_WIDE=2 forces the
+    rounds it falls back to when more keys reach the bound than LDS holds, 0 the rounds of round 4: three forms, one answer —
+    checked against a host selection over the distances the device reports for every row (limit = n is not offered: the
+    distances come from the rows read back), with exact ties across the cut and NaN-free inputs of three lengths."""
+    monkeypatch.setenv("ORAMA_SELECT_WIDE", mode)
+    c = oa.Context(0)
+    d = 16
+    rng = np.random.default_rng(5150)
+    for n, ks in ((140_000, (1, 100)), (300_000, (10, 100, 256)), (1_000_003, (100, 128))):
+        rows = rng.standard_normal((n, d)).astype(np.float32)
+        q = rng.standard_normal(d).astype(np.float32)
+        dup = np.sort(rng.choice(n, size=300, replace=False))
+        rows[dup] = q * np.float32(2.0)  # 300 rows at distance ~0: the cut falls among exact ties for every k here
+        st = make_store(c, rows)
+        o_d = orc.distances(rows, q)
+        for k in ks:
+            ids, dist, cnt = st.storage_search(q, k)
+            assert cnt[0] == k
+            assert ids[0].tolist() == dup[:k].tolist(), (n, k)  # ties: lowest rows, then DocumentId order (= row order here)
+            assert np.max(np.abs(dist[0] - o_d[ids[0].astype(np.int64)])) <= TOL
+        # without the ties: the k best of a plain gaussian corpus
+        rows[dup] = rng.standard_normal((300, d)).astype(np.float32)
+        st.close()
+        st = make_store(c, rows)
+        o_d = orc.distances(rows, q)
+        for k in ks:
+            ids, dist, cnt = st.storage_search(q, k)
+            order = np.lexsort((np.arange(n), o_d))[: k + 8]
+            assert cnt[0] == k and np.all(np.diff(dist[0]) >= 0)
+            assert np.max(np.abs(dist[0] - o_d[order[:k]])) <= TOL
+            # ids identical wherever the distances are separated by more than the fp32 summation-order noise
+            sep = np.abs(np.diff(o_d[order])) > 1e-5
+            for j in range(k):
+                if (j == 0 or sep[j - 1]) and sep[j]:
+                    assert ids[0, j] == order[j], (n, k, j)
+        st.close()
+    c.close()
