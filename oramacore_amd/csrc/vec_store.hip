@@ -926,7 +926,7 @@ int two_stage_search(orama_vec* v, Scratch* sc, Scratch* sc2, const float* d_que
         return ORAMA_OK;
     }
     ORAMA_TRY(sc2->h_out.reserve((size_t)q * 4));
-    ORAMA_HIP_TRY(hipMemcpyAsync(sc2->h_out.p, d_flag, (size_t)q * 4, hipMemcpyDeviceToHost, s));
+    ORAMA_TRY(stage_block(v->ctx, sc2->h_out.p, d_flag, (size_t)q * 4, hipMemcpyDeviceToHost, s));
     *flags_pending = true;  // sc2->h_out holds one word per query once `s` has drained: non-zero = not proven
     return ORAMA_OK;
 }
