@@ -128,7 +128,8 @@ struct PinnedBuf {
         p = nullptr;
         cap = 0;
         size_t want = bytes < 4096 ? 4096 : bytes;
-        ORAMA_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        // (portable + mapped: kernels of EVERY device of the process read and write it — the staging kernel, stage.hip)
+        ORAMA_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocPortable | hipHostMallocMapped));
         cap = want;
         return ORAMA_OK;
     }

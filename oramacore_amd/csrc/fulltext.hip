@@ -2270,7 +2270,10 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
         ORAMA_TRY(a->h_out.reserve((size_t)kk * 12 + 8));
         if (two_stage && two_stage_device)  // (the device tail: nothing of the plan is left for the host to decide)
             return ts.begin_device(v, a, a2, a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n);
-        if (two_stage) return ts.begin(v, a, a2, a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n);
+        if (two_stage) {  // (the read-back behind the plan, before the host looks at the proof word: one wake-up — join_vector_leg)
+            ORAMA_TRY(ts.begin(v, a, a2, a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n));
+            return stage_block(ctx, a->h_out.p, d_ids, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, sa);
+        }
         ORAMA_TRY(vec_search_enqueue(v, a.s.get(), a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n, sa));
         ORAMA_TRY(stage_block(ctx, a->h_out.p, d_ids, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, sa));
         return ORAMA_OK;
@@ -2281,8 +2284,10 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
     auto join_vector_leg = [&](ScratchLease& a, VecTwoStage& ts) -> int {
         if (!have_rows) return ORAMA_OK;
         if (two_stage) {  // (an unproven candidate list is re-answered by the plain scan in here)
-            ORAMA_TRY(ts.finish());
-            ORAMA_TRY(stage_block(ctx, a->h_out.p, a->out_ids.p, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, a->stream));
+            bool reran = false;
+            ORAMA_TRY(ts.finish(&reran));
+            if (reran || two_stage_device)
+                ORAMA_TRY(stage_block(ctx, a->h_out.p, a->out_ids.p, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, a->stream));
         }
         ORAMA_HIP_TRY(hipStreamSynchronize(a->stream));
         const char* ha = a->h_out.as<char>();

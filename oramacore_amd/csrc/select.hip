@@ -436,7 +436,7 @@ __device__ __forceinline__ void workgroup_extremes(const unsigned long long* red
 //                         (One wave's binary search for the exact k-th key — value word, then index word among its ties —
 //                         was tried in its place: 3.0 us against 1.8 at 200 keys, and its registers cost the reduction
 //                         kernels their second resident workgroup per CU; profiles/r04_keys_topk_phases.log.)
-constexpr uint32_t kWaveBoundMaxK = 256;   // j <= 16 of 64 lane bests per wave
+constexpr uint32_t kWaveBoundMaxK = 512;   // j <= 32 of 64 lane bests per wave (round 5: 256 -> 512 for the two-stage plan's k + 256 candidates)
 constexpr uint32_t kRankCountMax = 512;
 constexpr uint32_t kRankCountSmall = 320;  // the reduction kernels count ranks up to here (k = 100 leaves ~200), the final kernel up to 512
 
@@ -887,6 +887,45 @@ __device__ __forceinline__ void finish_whole_list(unsigned long long* s, uint32_
     write_sorted(rec, kept, k, descending, fin.out_idx ? fin.out_idx + (uint64_t)qi * k : nullptr,
                  fin.out_ids ? fin.out_ids + (uint64_t)qi * k : nullptr, fin.out_val + (uint64_t)qi * k,
                  fin.out_n ? fin.out_n + qi : nullptr);
+}
+
+// A list of <= 512 values (the reranked candidates of the two-stage plan: 356 for k = 100; the merged entries of a hybrid call)
+// in ONE workgroup without a sort (round 5): select_small_kernel's two bitonic sorts of 512 and 128 records are 73 barrier-
+// separated steps — 23-29 us behind a lone query (profiles/r05_lone_call_timelines.log).  The keys are unique, so the rank of a
+// key — counted, rank_by_counting — IS its position: the best k land in key order, which is the final order unless two
+// neighbours of equal value carry their DocumentIds the other way round (finish_whole_list sorts only then).  Same keys, same
+// cut (value, then index), same final order (value, id, index) as every other form.
+__global__ __launch_bounds__(kSortThreads) void select_tiny_kernel(const float* __restrict__ vals, const uint32_t* __restrict__ idx,
+                                                                  uint64_t stride, const uint32_t* __restrict__ n_dev, uint32_t n_max,
+                                                                  uint32_t k, bool descending, PairsFinal fin) {
+    __shared__ unsigned long long s[kKeysChunk];  // (finish_whole_list lays its records over the key buffer)
+    __shared__ uint32_t cursor;
+    const uint32_t qi = blockIdx.x;
+    const uint32_t n = uniform_u32(n_dev ? min(n_dev[qi], n_max) : n_max);  // <= kRankCountMax: the launcher's rule
+    const float* v = vals + (uint64_t)qi * stride;
+    const uint32_t* ix = idx ? idx + (uint64_t)qi * stride : nullptr;
+    if (threadIdx.x == 0) cursor = 0;
+    __syncthreads();
+    unsigned long long key = 0ull;
+    if (threadIdx.x < n) {
+        const float x = v[threadIdx.x];
+        if (x == x) key = make_key(x, ix ? ix[threadIdx.x] : threadIdx.x, descending);
+    }
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(key != 0ull);
+    uint32_t base = 0;
+    if (lane == 0 && m) base = atomicAdd(&cursor, (uint32_t)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (key) s[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+    __syncthreads();
+    const uint32_t valid = uniform_u32(cursor);
+    const uint32_t kept = min(valid, k);
+    unsigned long long mine;
+    const uint32_t r = rank_by_counting(s, valid, &mine);
+    __syncthreads();  // every key is in a register
+    if (mine && r < kept) s[r] = mine;
+    __syncthreads();
+    finish_whole_list(s, kept, true, k, descending, qi, fin);
 }
 
 template <bool HAS_IDX>
@@ -1456,6 +1495,18 @@ int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
     if (p.n <= kSelectMaxK) {
         if (p.n == 0) {
             // empty list: emit padding + zero counts through the small kernel with n = 0
+        }
+        if (p.n >= 1 && p.n <= kRankCountMax && p.k <= kSortThreads && ctx->select_wide != 0) {
+            PairsFinal fin;
+            fin.id_map = p.id_map;
+            fin.out_idx = p.out_idx;
+            fin.out_ids = p.out_ids;
+            fin.out_val = p.out_val;
+            fin.out_n = p.out_n;
+            hipLaunchKernelGGL(select_tiny_kernel, dim3(p.q), dim3(kSortThreads), 0, stream, p.vals, p.idx, p.stride, p.n_dev, p.n,
+                               p.k, p.descending, fin);
+            ORAMA_HIP_TRY(hipGetLastError());
+            return ORAMA_OK;
         }
         hipLaunchKernelGGL(select_small_kernel, dim3(p.q), dim3(kSortThreads), 0, stream, p.vals,
                            p.idx, p.stride, p.n_dev, p.n, p.k, p.descending, p.id_map, p.out_idx,

@@ -52,7 +52,7 @@ class VecTwoStage {
     // everything else on the stream — nothing for the host to decide; finish() then only drains the stream and unlocks.
     int begin_device(orama_vec* v, ScratchLease& sc, ScratchLease& sc2, const float* d_queries, uint32_t q, uint32_t k,
                      const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_n);
-    int finish();
+    int finish(bool* reran = nullptr);  // *reran: an unproven query was answered again by the plain scan (outputs rewritten after the caller's read-back was enqueued)
 
    private:
     void unlock();
