@@ -368,8 +368,10 @@ __global__ void query_shadow_unsafe_kernel(const float* __restrict__ queries, ui
     if (lane == 0 && (any_nan || !(n2 >= 1e-4f && mx < 6.0e4f))) flag[j] = 1u;
 }
 // pick[0 .. *n_pick) = the flagged queries in ascending order (one workgroup of 256 threads)
+// (`round_n[r]` = how many of the picked queries round r answers: the fallback keeps list sets for `sets` queries and is
+// enqueued ceil(q / sets) times — a round with nothing to do ends at once)
 __global__ void pick_flagged_kernel(const uint32_t* __restrict__ flag, uint32_t q, uint32_t* __restrict__ pick,
-                                    uint32_t* __restrict__ n_pick) {
+                                    uint32_t* __restrict__ n_pick, uint32_t sets, uint32_t rounds, uint32_t* __restrict__ round_n) {
     __shared__ uint32_t cnt[256];
     const uint32_t per = (q + 255u) / 256u;
     const uint32_t lo = min(q, threadIdx.x * per), hi = min(q, lo + per);
@@ -381,7 +383,10 @@ __global__ void pick_flagged_kernel(const uint32_t* __restrict__ flag, uint32_t 
     for (uint32_t t = 0; t < threadIdx.x; ++t) base += cnt[t];
     for (uint32_t j = lo; j < hi; ++j)
         if (flag[j] != 0u) pick[base++] = j;
-    if (threadIdx.x == 255) *n_pick = base;
+    if (threadIdx.x == 255) {
+        *n_pick = base;
+        for (uint32_t r = 0; r < rounds; ++r) round_n[r] = base > r * sets ? min(sets, base - r * sets) : 0u;
+    }
 }
 // the answers of the picked queries go to their own slots (workgroup f = the f-th picked query)
 __global__ void scatter_picked_kernel(const uint32_t* __restrict__ pick, const uint32_t* __restrict__ n_pick, uint32_t k,
@@ -396,6 +401,8 @@ __global__ void scatter_picked_kernel(const uint32_t* __restrict__ pick, const u
     }
     if (threadIdx.x == 0) out_n[j] = n[f];
 }
+
+constexpr uint32_t kTwoStageFallbackSets = 64;  // list sets of the device form's fp32 fallback (two_stage_search)
 
 uint32_t blocks_for_rows(uint64_t n) { return (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1, (n + 255) / 256)); }
 
@@ -859,7 +866,8 @@ int two_stage_search(orama_vec* v, Scratch* sc, Scratch* sc2, const float* d_que
     // the device form's buffers first: nothing is (re)allocated behind launches that are already enqueued
     ScanArgs fa;  // the fallback's scan (K1, fused mode)
     uint32_t fb_keys = 0;
-    uint32_t *d_pick = nullptr, *d_n_pick = nullptr, *fb_n = nullptr;
+    uint32_t fb_sets = 0, fb_rounds = 0;
+    uint32_t *d_pick = nullptr, *d_n_pick = nullptr, *d_round_n = nullptr, *fb_n = nullptr;
     uint64_t* fb_ids = nullptr;
     float* fb_dist = nullptr;
     if (device_form) {
@@ -876,15 +884,21 @@ int two_stage_search(orama_vec* v, Scratch* sc, Scratch* sc2, const float* d_que
         fa.topk = k;
         ORAMA_REQUIRE(k <= kWaveListKeys && vec_scan_f32_picked_supported(fa), "internal: two-stage device form outside its envelope");
         fb_keys = vec_scan_f32_picked_waves(v->ctx, fa) * kWaveListKeys;
-        ORAMA_TRY(sc->misc3.reserve((size_t)q * fb_keys * 8));
-        ORAMA_TRY(sc->misc4.reserve((size_t)keys_topk_scratch_keys(fb_keys, q, k) * 8 + 8));
-        const size_t nk = (size_t)q * k;
-        ORAMA_TRY(sc->misc5.reserve(nk * 12 + (size_t)q * 8 + 64));
+        // list sets for kTwoStageFallbackSets queries (4 MB each at the north-star shape), not for q: the path answers ~0.1 % of
+        // the queries, and a batch of 256 pinned 1 GB per tail stream and shard for it.  More flagged queries than
+        // sets take further rounds of the same three launches
+        fb_sets = std::min<uint32_t>(q, kTwoStageFallbackSets);
+        fb_rounds = (q + fb_sets - 1) / fb_sets;
+        ORAMA_TRY(sc->misc3.reserve((size_t)fb_sets * fb_keys * 8));
+        ORAMA_TRY(sc->misc4.reserve((size_t)keys_topk_scratch_keys(fb_keys, fb_sets, k) * 8 + 8));
+        const size_t nk = (size_t)fb_sets * k;
+        ORAMA_TRY(sc->misc5.reserve(nk * 12 + (size_t)fb_sets * 4 + (size_t)q * 4 + 4 + (size_t)fb_rounds * 4 + 64));
         fb_ids = sc->misc5.as<uint64_t>();
         fb_dist = reinterpret_cast<float*>(fb_ids + nk);
         fb_n = reinterpret_cast<uint32_t*>(fb_dist + nk);
-        d_pick = fb_n + q;
+        d_pick = fb_n + fb_sets;
         d_n_pick = d_pick + q;
+        d_round_n = d_n_pick + 1;
         fa.wave_lists = sc->misc3.as<unsigned long long>();
     }
     ORAMA_TRY(search_enqueue_f16(sh, ws, sc2, d_queries, q, k1, d_allow, allow_bits, sc2->out_ids.as<uint64_t>(),
@@ -914,14 +928,17 @@ int two_stage_search(orama_vec* v, Scratch* sc, Scratch* sc2, const float* d_que
     ORAMA_TRY(launch_select(v->ctx, p, s));
     if (device_form) {
         hipLaunchKernelGGL(query_shadow_unsafe_kernel, dim3((q + 3) / 4), dim3(256), 0, s, d_queries, q, v->dim, d_flag);
-        hipLaunchKernelGGL(pick_flagged_kernel, dim3(1), dim3(256), 0, s, d_flag, q, d_pick, d_n_pick);
+        hipLaunchKernelGGL(pick_flagged_kernel, dim3(1), dim3(256), 0, s, d_flag, q, d_pick, d_n_pick, fb_sets, fb_rounds, d_round_n);
         ORAMA_HIP_TRY(hipGetLastError());
-        ORAMA_TRY(launch_vec_scan_f32_picked(v->ctx, fa, d_pick, d_n_pick, fb_keys, s));
-        ORAMA_TRY(launch_keys_topk(v->ctx, fa.wave_lists, fb_keys, fb_keys, q, k, false, w.row_doc, sc->misc4.as<unsigned long long>(),
-                                   nullptr, fb_ids, fb_dist, fb_n, s, nullptr, nullptr, 0, d_n_pick));
-        hipLaunchKernelGGL(scatter_picked_kernel, dim3(q), dim3(128), 0, s, d_pick, d_n_pick, k, fb_ids, fb_dist, fb_n, d_out_ids,
-                           d_out_dist, d_out_n);
-        ORAMA_HIP_TRY(hipGetLastError());
+        for (uint32_t r = 0; r < fb_rounds; ++r) {
+            const uint32_t* picks = d_pick + (size_t)r * fb_sets;
+            ORAMA_TRY(launch_vec_scan_f32_picked(v->ctx, fa, picks, d_round_n + r, fb_keys, s));
+            ORAMA_TRY(launch_keys_topk(v->ctx, fa.wave_lists, fb_keys, fb_keys, fb_sets, k, false, w.row_doc, sc->misc4.as<unsigned long long>(),
+                                       nullptr, fb_ids, fb_dist, fb_n, s, nullptr, nullptr, 0, d_round_n + r));
+            hipLaunchKernelGGL(scatter_picked_kernel, dim3(fb_sets), dim3(128), 0, s, picks, d_round_n + r, k, fb_ids, fb_dist, fb_n, d_out_ids,
+                               d_out_dist, d_out_n);
+            ORAMA_HIP_TRY(hipGetLastError());
+        }
         v->two_stage_queries.fetch_add(q, std::memory_order_relaxed);
         return ORAMA_OK;
     }
@@ -939,8 +956,8 @@ bool two_stage_device_usable(orama_vec* v, uint32_t q, uint32_t k) {
         return false;
     const uint64_t rows = v->n_rows.load(std::memory_order_relaxed);
     if (v->ctx->two_stage != 2 && q <= 8 && rows * v->row_bytes() < (4ull << 30)) return false;  // (as vec_two_stage_usable)
-    // wave lists of the fallback: one set per query of the call (4 MB each at the default grid)
-    return (uint64_t)q * (uint64_t)v->ctx->compute_units * (uint64_t)v->ctx->scan_tuning.blocks_per_cu * 4ull * kWaveListKeys * 8ull <= (4ull << 30);
+    // (wave lists of the fallback: one set per query up to kTwoStageFallbackSets, 4 MB each at the default grid — two_stage_search)
+    return q <= 4096;
 }
 
 }  // namespace

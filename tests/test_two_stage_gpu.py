@@ -334,6 +334,13 @@ def test_the_device_path_decides_the_fallback_on_the_device(ctx):
     # a batch in which EVERY query is flagged
     allbad = np.zeros((5, dim), dtype=np.float32)
     equal(device_search(shadow, allbad, k), plain.storage_search(allbad, k), "all flagged")
+    # more flagged queries than the fallback keeps list sets for (64; round 5): 150 of 200 — three rounds of the same launches
+    many = rng.standard_normal((200, dim)).astype(np.float32)
+    bad = np.sort(rng.choice(200, size=150, replace=False))
+    many[bad[:50]] = 0.0
+    many[bad[50:100]] *= np.float32(1e5)
+    many[bad[100:]] = centre + (rng.standard_normal((50, dim)) * 1e-3).astype(np.float32)
+    equal(device_search(shadow, many, k), plain.storage_search(many, k), "150 of 200 flagged")
     # under a filter (resident bitmap)
     mask_ids = ids[rng.random(n) < 0.4]
     bm = oa.AllowBitmap(int(ids.max()) + 1, mask_ids).to_device(ctx)
