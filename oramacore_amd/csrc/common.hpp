@@ -155,6 +155,7 @@ struct Profiler {
     hipEvent_t get_event();
     void begin(const char* name, hipStream_t s, hipEvent_t* start);
     void end(const char* name, hipStream_t s, hipEvent_t start);
+    void pair(const char* name, hipEvent_t* start, hipEvent_t* stop);  // for ONE dispatch (hipExtLaunchKernelGGL): nothing is recorded here
     int resolve();
     void reset();
     ~Profiler();
@@ -170,6 +171,15 @@ struct ProfScope {
     }
     ~ProfScope() {
         if (start) prof->end(name, stream, start);
+    }
+};
+
+// The event pair of ONE kernel dispatch: handed to hipExtLaunchKernelGGL, which stamps them from the dispatch's own completion
+// signal — no event-record (barrier) packets before and after the kernel.  Both null when the profiler is off.
+struct ProfLaunch {
+    hipEvent_t start = nullptr, stop = nullptr;
+    ProfLaunch(Profiler* p, const char* name) {
+        if (p && p->on) p->pair(name, &start, &stop);
     }
 };
 

@@ -46,6 +46,19 @@ void Profiler::end(const char* name, hipStream_t s, hipEvent_t start) {
     acc[name].pending.emplace_back(start, e);
 }
 
+void Profiler::pair(const char* name, hipEvent_t* start, hipEvent_t* stop) {
+    std::lock_guard<std::mutex> g(mu);
+    hipEvent_t a = get_event(), b = get_event();
+    if (!a || !b) {
+        if (a) free_events.push_back(a);
+        if (b) free_events.push_back(b);
+        return;
+    }
+    *start = a;
+    *stop = b;
+    acc[name].pending.emplace_back(a, b);
+}
+
 int Profiler::resolve() {
     std::lock_guard<std::mutex> g(mu);
     for (auto& kv : acc) {

@@ -9,6 +9,8 @@
 // the matrix at any moment.  Per row: 4·NCHUNK FMAs/lane, a DPP wave reduction, one scalar
 // epilogue → VALU load is a few % of the HBM time; the kernel is bound by HBM bandwidth
 // (algorithmic bytes = n · dim · 4 per pass; distances written back are 4 B/row, < 0.2 %).
+#include <hip/hip_ext.h>
+
 #include "vec_kernels.hpp"
 
 #include <cstdlib>
@@ -131,48 +133,51 @@ __global__ __launch_bounds__(kScanThreads) void vec_scan_f32_generic_kernel(Scan
     }
 }
 
+// `ev`: the profiler's event pair for THIS dispatch (ProfLaunch; both null when the profiler is off).  The events ride on the
+// kernel's own dispatch packet (hipExtLaunchKernelGGL) instead of bracketing it with two recorded events: no barrier packets
+// between consecutive scans of a pipelined session — 13 us of a 4.33 ms step with the profiler on (scripts/ns_step_gap_probe.py).
 template <int NCHUNK, bool EXACT, int ROWS, bool NT>
-void launch_scan_metric(const ScanArgs& a, dim3 grid, hipStream_t s) {
+void launch_scan_metric(const ScanArgs& a, dim3 grid, hipStream_t s, const ProfLaunch& ev) {
     const bool fused = a.wave_lists != nullptr;
     if (a.metric == ORAMA_METRIC_COSINE) {
         if (fused)
-            hipLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_COSINE, true>), grid,
-                               dim3(kScanThreads), 0, s, a);
+            hipExtLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_COSINE, true>), grid,
+                                  dim3(kScanThreads), 0, s, ev.start, ev.stop, 0, a);
         else
-            hipLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_COSINE, false>), grid,
-                               dim3(kScanThreads), 0, s, a);
+            hipExtLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_COSINE, false>), grid,
+                                  dim3(kScanThreads), 0, s, ev.start, ev.stop, 0, a);
     } else {
         if (fused)
-            hipLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_L2SQ, true>), grid,
-                               dim3(kScanThreads), 0, s, a);
+            hipExtLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_L2SQ, true>), grid,
+                                  dim3(kScanThreads), 0, s, ev.start, ev.stop, 0, a);
         else
-            hipLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_L2SQ, false>), grid,
-                               dim3(kScanThreads), 0, s, a);
+            hipExtLaunchKernelGGL((vec_scan_f32_kernel<NCHUNK, EXACT, ROWS, NT, ORAMA_METRIC_L2SQ, false>), grid,
+                                  dim3(kScanThreads), 0, s, ev.start, ev.stop, 0, a);
     }
 }
 
 template <int NCHUNK, bool EXACT>
-void launch_scan_rows(const ScanArgs& a, const ScanTuning& t, dim3 grid, hipStream_t s) {
+void launch_scan_rows(const ScanArgs& a, const ScanTuning& t, dim3 grid, hipStream_t s, const ProfLaunch& ev) {
     const bool nt = t.nontemporal != 0;
     // register budget: ROWS * NCHUNK * 4 data VGPRs — cap ROWS for wide rows
     int rows = t.rows_per_wave;
     while (rows * NCHUNK > 16) rows >>= 1;
     switch (rows) {
         case 8:
-            nt ? launch_scan_metric<NCHUNK, EXACT, 8, true>(a, grid, s)
-               : launch_scan_metric<NCHUNK, EXACT, 8, false>(a, grid, s);
+            nt ? launch_scan_metric<NCHUNK, EXACT, 8, true>(a, grid, s, ev)
+               : launch_scan_metric<NCHUNK, EXACT, 8, false>(a, grid, s, ev);
             break;
         case 4:
-            nt ? launch_scan_metric<NCHUNK, EXACT, 4, true>(a, grid, s)
-               : launch_scan_metric<NCHUNK, EXACT, 4, false>(a, grid, s);
+            nt ? launch_scan_metric<NCHUNK, EXACT, 4, true>(a, grid, s, ev)
+               : launch_scan_metric<NCHUNK, EXACT, 4, false>(a, grid, s, ev);
             break;
         case 2:
-            nt ? launch_scan_metric<NCHUNK, EXACT, 2, true>(a, grid, s)
-               : launch_scan_metric<NCHUNK, EXACT, 2, false>(a, grid, s);
+            nt ? launch_scan_metric<NCHUNK, EXACT, 2, true>(a, grid, s, ev)
+               : launch_scan_metric<NCHUNK, EXACT, 2, false>(a, grid, s, ev);
             break;
         default:
-            nt ? launch_scan_metric<NCHUNK, EXACT, 1, true>(a, grid, s)
-               : launch_scan_metric<NCHUNK, EXACT, 1, false>(a, grid, s);
+            nt ? launch_scan_metric<NCHUNK, EXACT, 1, true>(a, grid, s, ev)
+               : launch_scan_metric<NCHUNK, EXACT, 1, false>(a, grid, s, ev);
             break;
     }
 }
@@ -413,26 +418,27 @@ int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a_in, hipStream_t stream
     ORAMA_REQUIRE(a.n < 0xffffffffull, "vec_scan: too many rows");
     if (a.n == 0) return ORAMA_OK;
     const ScanTuning& t = ctx->scan_tuning;
-    ProfScope prof(&ctx->prof, "vec_scan_f32", stream);
     const ScanGeom g = scan_geom(ctx, a);
     const dim3 grid(g.blocks);
+    ProfLaunch ev(g.vec4 ? &ctx->prof : nullptr, "vec_scan_f32");            // events on the dispatch itself
+    ProfScope prof(g.vec4 ? nullptr : &ctx->prof, "vec_scan_f32", stream);  // (the generic kernel: bracketed as before)
     if (g.vec4) {
         switch (g.nchunk) {
             case 1:
-                g.exact ? launch_scan_rows<1, true>(a, t, grid, stream)
-                        : launch_scan_rows<1, false>(a, t, grid, stream);
+                g.exact ? launch_scan_rows<1, true>(a, t, grid, stream, ev)
+                        : launch_scan_rows<1, false>(a, t, grid, stream, ev);
                 break;
             case 2:
-                g.exact ? launch_scan_rows<2, true>(a, t, grid, stream)
-                        : launch_scan_rows<2, false>(a, t, grid, stream);
+                g.exact ? launch_scan_rows<2, true>(a, t, grid, stream, ev)
+                        : launch_scan_rows<2, false>(a, t, grid, stream, ev);
                 break;
             case 3:
-                g.exact ? launch_scan_rows<3, true>(a, t, grid, stream)
-                        : launch_scan_rows<3, false>(a, t, grid, stream);
+                g.exact ? launch_scan_rows<3, true>(a, t, grid, stream, ev)
+                        : launch_scan_rows<3, false>(a, t, grid, stream, ev);
                 break;
             default:
-                g.exact ? launch_scan_rows<4, true>(a, t, grid, stream)
-                        : launch_scan_rows<4, false>(a, t, grid, stream);
+                g.exact ? launch_scan_rows<4, true>(a, t, grid, stream, ev)
+                        : launch_scan_rows<4, false>(a, t, grid, stream, ev);
                 break;
         }
     } else {
