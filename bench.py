@@ -930,10 +930,16 @@ def measure_traffic(args, kernel_substr: str, alg_bytes: float) -> dict | None:
 
 
 def committed_traffic(workload: str) -> dict | None:
-    pmc_files = sorted((ROOT / "profiles").glob(f"r*_pmc_{workload}_vec_scan.json"))
+    pmc_files = sorted(list((ROOT / "profiles").glob(f"r*_pmc_{workload}_vec_scan.json")) +
+                       list((ROOT / "profiles").glob(f"r*_pmc_{workload}_shard_vec_scan.json")), key=lambda f: f.name[:3])
     if not pmc_files:
         return None
     rec = json.loads(pmc_files[-1].read_text())
+    if "traffic_bytes_per_step" in rec:  # round 5's records: total over a fixed number of steps (scripts/pmc_total.py)
+        return {"traffic": rec["traffic_bytes_per_step"], "traffic_unit": "bytes/step (one corpus pass; the fp16 scans split it into several launches)",
+                "traffic_over_algorithmic": rec.get("traffic_over_algorithmic"),
+                "traffic_source": f"NOT measured in this run — profiles/{pmc_files[-1].name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                  "passes of scripts/pmc_scan_probe.py, total over 6 steps; FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
     return {"traffic": rec.get("traffic_bytes_per_launch"), "traffic_unit": "bytes/launch",
             "traffic_source": f"NOT measured in this run — profiles/{pmc_files[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                               "passes of this command; FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
@@ -1049,6 +1055,12 @@ def main():
                                                          "job adds one 307 KB all-gather + merge per batch")
             if st16 is not None:
                 st16.close()
+        for cname, wname in (("c2", "c2"), ("c3", "c3"), ("c5_shard", "c5_shard")):
+            # (only NS's traffic is measured inside this run; the other legs point at their committed PMC record)
+            if cname in configs and configs[cname]["roofline"].get("traffic") is None:
+                t = committed_traffic(wname)
+                if t:
+                    configs[cname]["roofline"]["traffic_reference"] = t
         if configs:
             out["configs"] = configs
     device_name = ctx.device_info()["name"]

@@ -5,6 +5,7 @@
 #   scale     scripts/scale_dry_run.py (bench.py --gpus 2/4/8 over the loopback transport + uncontended rank steps)
 #   tests     the whole GPU suite            tests:<expr>  pytest -k <expr>
 #   prof      rocprofv3 kernel traces of every bench leg + the K3r chunk probe + PMC passes of the K3r launches
+#   pmc       FETCH_SIZE / WRITE_SIZE passes over the scan kernels of C2 / C3 / C5 shard / NS (total traffic per step)
 #   py:<path> any script under scripts/ (arguments after a colon, comma separated)
 set +e
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -54,6 +55,15 @@ for STEP in "$@"; do
       python scripts/pmc_summary.py $O/pmc_k3r keys_reduce_kernel 151000000 mean > $O/pmc_k3r_keys_reduce.json 2>>$O/pmc_k3r.err
       python scripts/pmc_summary.py $O/pmc_k3r keys_final_kernel 151000000 mean > $O/pmc_k3r_keys_final.json 2>>$O/pmc_k3r.err
       for W in ns c2 c3 c5 c4 k3r; do echo "-- $W"; head -8 $O/${W}_kernel_stats.md | cut -c1-180; tail -2 $O/${W}_kernel_stats.md | cut -c1-400; done ;;
+    pmc)  # HBM traffic of the scan kernels of C2 / C3 / C5-shard / NS: total over a fixed number of steps (scripts/pmc_scan_probe.py)
+      for W in c2 c3 c5 ns; do
+        for C in FETCH_SIZE WRITE_SIZE; do
+          (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$W/$C -o p -- python $R/scripts/pmc_scan_probe.py $W 6 > $O/pmc_${W}_$C.log 2>&1)
+        done
+        A=$(grep -o '"alg_bytes_per_step": [0-9]*' $O/pmc_${W}_FETCH_SIZE.log | grep -o '[0-9]*$')
+        python scripts/pmc_total.py $O/pmc_$W vec_scan $A 6 > $O/pmc_${W}_vec_scan.json 2>> $O/pmc_scans.err
+        echo "-- $W"; grep -E "traffic_over|launches|FETCH|WRITE" $O/pmc_${W}_vec_scan.json | tr -d '\n'; echo
+      done ;;
     c2) echo "== bench c2"; timeout 600 python bench.py --workload c2 --steps 200 --warmup 10 --no-cpu-baseline --no-two-stage --configs none --no-pmc > $O/bench_c2.json 2> $O/bench_c2.err; python - $O/bench_c2.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
