@@ -268,6 +268,9 @@ struct orama_ctx {
     // small host<->device blocks (the range scorer's chunk tables and answers, a lone query and its hits) move by a kernel of
     // the caller's stream instead of an SDMA copy (stage.hip); ORAMA_STAGE_COPY=dma puts the copy commands back
     bool stage_by_kernel = true;
+    // two-stream searches: the scan's completion event rides on its dispatch instead of a record packet behind it (vec_store.hip
+    // scan_end; ORAMA_SCAN_DONE_EVENT=record restores the packet)
+    bool scan_done_on_dispatch = true;
     int select_wide = 1;  // K4: a few long dense lists take one round of 32 values per thread (select.hip, pairs_reduce_wide_kernel)
     int k3r_merge = 0;  // comparison builds only (ORAMA_COMPARISON_KERNELS=1): ORAMA_K3R_MERGE=1 scores ranges with the round-3 merge tree
     // stores created as ORAMA_DTYPE_F32_SHADOW16 answer orama_vec_search in two stages (fp16 candidates, fp32 decision);

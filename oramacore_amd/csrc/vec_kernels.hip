@@ -409,7 +409,11 @@ uint32_t vec_scan_f32_waves(orama_ctx* ctx, const ScanArgs& a) {
     return a.n ? scan_geom(ctx, a).blocks * kWavesPerBlock : 0;
 }
 
-int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a_in, hipStream_t stream) {
+// `done` / `attached`: the two-stream mode's "this scan has finished" event without a record packet behind the kernel —
+// `done` (or the profiler's stop event when the profiler is on) rides on the dispatch, and *attached tells the caller which
+// event to wait for (nullptr: none rode along — the generic kernel, or ORAMA_SCAN_DONE_EVENT=record — record one yourself).
+int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a_in, hipStream_t stream, hipEvent_t done, hipEvent_t* attached) {
+    if (attached) *attached = nullptr;
     const ScanArgs& a = a_in;
     ORAMA_REQUIRE(a.corpus && a.query && a.dim > 0, "vec_scan: bad arguments");
     ORAMA_REQUIRE(a.out_dist || (a.wave_lists && a.topk >= 1 && a.topk <= kWaveListKeys), "vec_scan: no output mode");
@@ -421,6 +425,10 @@ int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a_in, hipStream_t stream
     const ScanGeom g = scan_geom(ctx, a);
     const dim3 grid(g.blocks);
     ProfLaunch ev(g.vec4 ? &ctx->prof : nullptr, "vec_scan_f32");            // events on the dispatch itself
+    if (g.vec4 && attached && ctx->scan_done_on_dispatch) {
+        if (!ev.stop) ev.stop = done;
+        *attached = ev.stop;
+    }
     ProfScope prof(g.vec4 ? nullptr : &ctx->prof, "vec_scan_f32", stream);  // (the generic kernel: bracketed as before)
     if (g.vec4) {
         switch (g.nchunk) {

@@ -31,7 +31,7 @@ struct ScanArgs {
 };
 
 // K1: one corpus pass, one query.  Algorithmic HBM traffic: n * dim * 4 bytes.
-int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a, hipStream_t stream);
+int launch_vec_scan_f32(orama_ctx* ctx, const ScanArgs& a, hipStream_t stream, hipEvent_t done = nullptr, hipEvent_t* attached = nullptr);
 // Number of waves launch_vec_scan_f32 will use for `a` (= number of 128-key lists written in fused mode).
 uint32_t vec_scan_f32_waves(orama_ctx* ctx, const ScanArgs& a);
 constexpr uint32_t kWaveListKeys = 128;

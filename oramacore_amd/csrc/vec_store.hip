@@ -438,11 +438,19 @@ int scan_begin(Scratch* sc, hipStream_t s_scan, hipStream_t s) {
     if (s_scan == s) return ORAMA_OK;
     if (!sc->ev_scan) ORAMA_HIP_TRY(hipEventCreateWithFlags(&sc->ev_scan, hipEventDisableTiming));
     if (!sc->ev_tail) ORAMA_HIP_TRY(hipEventCreateWithFlags(&sc->ev_tail, hipEventDisableTiming));
-    if (sc->tail_recorded) ORAMA_HIP_TRY(hipStreamWaitEvent(s_scan, sc->ev_tail, 0));
+    // (a tail that has already finished needs no wait packet in front of the scan: a caller with one step in flight never has one)
+    if (sc->tail_recorded && hipEventQuery(sc->ev_tail) != hipSuccess) ORAMA_HIP_TRY(hipStreamWaitEvent(s_scan, sc->ev_tail, 0));
+    (void)hipGetLastError();  // (hipErrorNotReady of the query is not an error of this call)
     return ORAMA_OK;
 }
-int scan_end(Scratch* sc, hipStream_t s_scan, hipStream_t s) {
+// `attached`: an event that completes with the LAST scan launch (it rode on the dispatch: launch_vec_scan_f32) — then no record
+// packet goes behind the scan (round 5: every packet between two scans of a pipelined session costs microseconds of an idle chip)
+int scan_end(Scratch* sc, hipStream_t s_scan, hipStream_t s, hipEvent_t attached = nullptr) {
     if (s_scan == s) return ORAMA_OK;
+    if (attached) {
+        ORAMA_HIP_TRY(hipStreamWaitEvent(s, attached, 0));
+        return ORAMA_OK;
+    }
     ORAMA_HIP_TRY(hipEventRecord(sc->ev_scan, s_scan));
     ORAMA_HIP_TRY(hipStreamWaitEvent(s, sc->ev_scan, 0));
     return ORAMA_OK;
@@ -484,12 +492,14 @@ int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_
         ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * (size_t)q * n_keys));
         ORAMA_TRY(sc->dist.reserve(sizeof(unsigned long long) * (size_t)q * (size_t)(chunks + 1) * k * 2 + 64));
         ORAMA_TRY(scan_begin(sc, s_scan, s));
+        hipEvent_t rode = nullptr;
         for (uint32_t j = 0; j < q; ++j) {
             a.query = d_queries + (size_t)j * v->dim;
             a.wave_lists = sc->sel_keys.as<unsigned long long>() + (size_t)j * n_keys;
-            ORAMA_TRY(launch_vec_scan_f32(v->ctx, a, s_scan));
+            const bool last = j + 1 == q && s_scan != s;
+            ORAMA_TRY(launch_vec_scan_f32(v->ctx, a, s_scan, last ? sc->ev_scan : nullptr, last ? &rode : nullptr));
         }
-        ORAMA_TRY(scan_end(sc, s_scan, s));
+        ORAMA_TRY(scan_end(sc, s_scan, s, rode));
         ORAMA_TRY(launch_keys_topk(v->ctx, sc->sel_keys.as<unsigned long long>(), n_keys, n_keys, q, k, false,
                                 w.row_doc, sc->dist.as<unsigned long long>(), nullptr, d_out_ids,
                                 d_out_dist, d_out_n, s));
@@ -509,6 +519,7 @@ int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_
     for (uint32_t q0 = 0; q0 < q; q0 += group) {
         const uint32_t gq = (q - q0) < group ? (q - q0) : group;
         ORAMA_TRY(scan_begin(sc, s_scan, s));
+        hipEvent_t rode = nullptr;
         for (uint32_t j = 0; j < gq;) {
             ScanArgs a;
             a.corpus = static_cast<const float*>(w.rows);
@@ -528,11 +539,12 @@ int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_
                 ORAMA_TRY(launch_vec_scan_f32_multi(v->ctx, a, nq, n, s_scan));
                 j += nq;
             } else {
-                ORAMA_TRY(launch_vec_scan_f32(v->ctx, a, s_scan));
+                const bool last = j + 1 == gq && s_scan != s;
+                ORAMA_TRY(launch_vec_scan_f32(v->ctx, a, s_scan, last ? sc->ev_scan : nullptr, last ? &rode : nullptr));
                 j += 1;
             }
         }
-        ORAMA_TRY(scan_end(sc, s_scan, s));
+        ORAMA_TRY(scan_end(sc, s_scan, s, rode));
         SelectPlan p;
         p.vals = sc->dist.as<float>();
         p.stride = n;
