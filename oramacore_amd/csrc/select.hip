@@ -1548,8 +1548,17 @@ int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
         static_assert(sizeof(SelectState) >= sizeof(uint32_t), "one word per list");
         // a few long dense lists whose parts fit one round of 32 values per thread (1 M values in 40 parts at k = 100)
         const int wide_mode = ctx->select_wide;  // ORAMA_SELECT_WIDE: 0 = rounds of 8 192 (round 4), 2 = the fallback rounds only (tests)
-        const bool wide = wide_mode != 0 && !p.idx && list_chunks > 16 && p.k <= kWaveBoundMaxK &&
-                          ((uint64_t)p.n + parts - 1) / parts <= (uint64_t)kWidePer * kSortThreads;
+        bool wide = wide_mode != 0 && !p.idx && list_chunks > 16 && p.k <= kWaveBoundMaxK &&
+                    ((uint64_t)p.n + parts - 1) / parts <= (uint64_t)kWidePer * kSortThreads;
+        // many dense lists of a known length (the dense heads of the fp16 scans: 131 072 distances for each of 64 / 256 queries)
+        // as well: 4 parts of one round each per list instead of 16 parts of one round (C3) or 4 parts of four rounds (C5)
+        if (!wide && wide_mode != 0 && wide_mode != 3 && !p.idx && !p.n_dev && list_chunks >= 4 && list_chunks <= 16 && p.k <= kWaveBoundMaxK) {
+            const uint32_t pw = (uint32_t)(((uint64_t)p.n + (uint64_t)kWidePer * kSortThreads - 1) / ((uint64_t)kWidePer * kSortThreads));
+            if ((uint64_t)pw * p.k <= kSelectMaxK) {
+                parts = pw;
+                wide = true;
+            }
+        }
         if (wide) {
             hipLaunchKernelGGL(pairs_reduce_wide_kernel, dim3(p.q, parts), dim3(kSortThreads), 0, stream, p.vals, p.stride,
                                p.n_dev, p.n, p.descending, p.k, p.keys, wide_mode == 2);
