@@ -5,6 +5,7 @@
 #   scale     scripts/scale_dry_run.py (bench.py --gpus 2/4/8 over the loopback transport + uncontended rank steps)
 #   tests     the whole GPU suite            tests:<expr>  pytest -k <expr>
 #   prof      rocprofv3 kernel traces of every bench leg + the K3r chunk probe + PMC passes of the K3r launches
+#   profall   rocprofv3 --kernel-trace --stats of `python bench.py --steps 20 --warmup 5 --no-pmc` (every leg in one trace)
 #   pmc       FETCH_SIZE / WRITE_SIZE passes over the scan kernels of C2 / C3 / C5 shard / NS (total traffic per step)
 #   py:<path> any script under scripts/ (arguments after a colon, comma separated)
 set +e
@@ -55,6 +56,9 @@ for STEP in "$@"; do
       python scripts/pmc_summary.py $O/pmc_k3r keys_reduce_kernel 151000000 mean > $O/pmc_k3r_keys_reduce.json 2>>$O/pmc_k3r.err
       python scripts/pmc_summary.py $O/pmc_k3r keys_final_kernel 151000000 mean > $O/pmc_k3r_keys_final.json 2>>$O/pmc_k3r.err
       for W in ns c2 c3 c5 c4 k3r; do echo "-- $W"; head -8 $O/${W}_kernel_stats.md | cut -c1-180; tail -2 $O/${W}_kernel_stats.md | cut -c1-400; done ;;
+    profall)  # the DRIVER'S command itself under the kernel trace (its nested --pmc passes off: rocprofv3 does not nest)
+      prof driver_command --steps 20 --warmup 5 --no-pmc
+      head -14 $O/driver_command_kernel_stats.md | cut -c1-200; tail -2 $O/driver_command_kernel_stats.md | cut -c1-400 ;;
     pmc)  # HBM traffic of the scan kernels of C2 / C3 / C5-shard / NS: total over a fixed number of steps (scripts/pmc_scan_probe.py)
       for W in c2 c3 c5 ns; do
         for C in FETCH_SIZE WRITE_SIZE; do
