@@ -9,6 +9,12 @@
  * Parity status:
  *   - BM25F scorer arithmetic (orc_bm25f_*):      PINNED by the reference's own known-answer
  *     tests src/collection_manager/bm25.rs:533-563, 911-983, 985-1043 (tests/golden/bm25_kat.json).
+ *   - facet counts, score-ordered groups (orc_facet_count_*, orc_group_top): PINNED by the facet / group results the
+ *     reference's own integration tests assert — src/tests/facets.rs:9-576 (8 cases), src/tests/groupby.rs:9-174, 416-467,
+ *     580-754 (6 cases) — held as data in tests/golden/reference_facet_cases.json, reference_group_cases.json
+ *     (tests/test_reference_cases.py).
+ *   - ntf / field boost / exact-match factor / threshold / OMC: CONSTRAINED (inequalities, orders, ratios) by seven more of
+ *     its cases (tests/golden/reference_cases.json); the formulas themselves live in the un-vendored crates below.
  *   - cosine scan / top-k ties / hybrid combine:  PARITY UNPINNED — the arithmetic lives in the
  *     un-vendored crates oramacore_fields 0.2.0 / oramacore_lib 0.4.4 (Cargo.lock:5313-5335) and
  *     the reference holds no numeric test for it; this file restates the published semantics

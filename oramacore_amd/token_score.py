@@ -354,13 +354,17 @@ def facets_and_groups(tsc: "TokenScoreContext", params: TokenScoreParams, facets
                     docs = set.intersection(*[variants[i][val] for i, val in enumerate(combo)])  # group.rs:143-160
                     combos.append(combo)
                     buckets.append(sorted(docs))
-                fld = FacetField.buckets(idx._post, buckets)
-                try:
-                    g_ids, g_sc, g_n = sm.group_top(fld, max_results)  # sort.rs:203-213
-                finally:
-                    fld.close()
-                for combo, i_, s_, n_ in zip(combos, g_ids, g_sc, g_n):
-                    group_results[combo] = list(zip(i_[: int(n_)].tolist(), s_[: int(n_)].tolist()))
+                if max_results == 0:  # (src/tests/groupby.rs:624-663: the groups exist and are empty — nothing to select)
+                    for combo in combos:
+                        group_results[combo] = []
+                else:
+                    fld = FacetField.buckets(idx._post, buckets)
+                    try:
+                        g_ids, g_sc, g_n = sm.group_top(fld, max_results)  # sort.rs:203-213
+                    finally:
+                        fld.close()
+                    for combo, i_, s_, n_ in zip(combos, g_ids, g_sc, g_n):
+                        group_results[combo] = list(zip(i_[: int(n_)].tolist(), s_[: int(n_)].tolist()))
     finally:
         sm.close()
     return hits, count, facet_results, group_results

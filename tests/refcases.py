@@ -13,6 +13,7 @@ class HostIndex:
 
     def __init__(self):
         self.string_fields, self.omc, self.document_ids = {}, {}, set()
+        self.bool_fields, self.number_fields, self.string_filter_fields = {}, {}, {}
 
     @property
     def document_count(self):
@@ -126,3 +127,131 @@ def check_case(case, search):
     if alt:  # the declared default (1.0): same documents, same order by id, but the scores tie — the factor is what the reference pins
         hits, count, ids = search(alt, 1.0)
         check_expect(hits, count, ids, alt["expect"])
+
+
+# ---------------------------------------------------------------- facet cases (tests/golden/reference_facet_cases.json)
+def fill_filters(idx, case, ids):
+    """The case's filter-field values (`values[i]` = document i in insert order) into idx.bool_fields / number_fields /
+    string_filter_fields ({DocumentId: value}) — HostIndex or the mirror's Index (before its commit)."""
+    order = [ids[d["id"]] for d in documents_of(case)]
+    for name, spec in case.get("filter_fields", {}).items():
+        store = {"bool": idx.bool_fields, "number": idx.number_fields, "string": idx.string_filter_fields}[spec["kind"]]
+        assert len(spec["values"]) == len(order), name
+        store[name] = dict(zip(order, spec["values"]))
+
+
+def facet_definitions(case):
+    """JSON -> what token_score.facets_and_groups takes: "bool" | "string" | [(from, to), ...]."""
+    return {n: (d if isinstance(d, str) else [tuple(r) for r in d["ranges"]]) for n, d in case["facets"].items()}
+
+
+def where_docs(idx, where):
+    """Documents that satisfy the case's `where` (field == value on a string filter field), or None."""
+    if not where:
+        return None
+    keep = None
+    for name, value in where.items():
+        hit = {d for d, v in idx.string_filter_fields[name].items() if v == value}
+        keep = hit if keep is None else keep & hit
+    return keep
+
+
+def oracle_facets(idx, map_docs, definitions):
+    """facet.rs:150-206 over the score map `map_docs` through the oracle's counting functions: {name: {"count", "values"}};
+    a field this index does not hold is skipped (facet.rs:159-163)."""
+    out = {}
+    live = idx.document_ids
+    for name, definition in definitions.items():
+        if isinstance(definition, list):
+            if name not in idx.number_fields:
+                continue
+            docs = [d for d in idx.number_fields[name] if d in live]
+            nums = [float(idx.number_fields[name][d]) for d in docs]
+            counts = orc.facet_count_ranges(map_docs, docs, nums, definition)
+            values = {f"{a}-{b}": int(c) for (a, b), c in zip(definition, counts)}
+        else:
+            store = idx.bool_fields if definition == "bool" else idx.string_filter_fields
+            if name not in store:
+                continue
+            keys = [True, False] if definition == "bool" else sorted({v for d, v in store[name].items() if d in live})
+            buckets = [sorted(d for d, v in store[name].items() if (v is k if definition == "bool" else v == k) and d in live) for k in keys]
+            off = np.concatenate([[0], np.cumsum([len(b) for b in buckets])]).astype(np.uint64)
+            flat = np.concatenate([np.asarray(b, dtype=np.uint64) for b in buckets]) if sum(map(len, buckets)) else np.zeros(0, dtype=np.uint64)
+            counts = orc.facet_count_buckets(map_docs, off, flat)
+            labels = [("true" if k else "false") for k in keys] if definition == "bool" else keys
+            values = {str(l): int(c) for l, c in zip(labels, counts)}
+        out[name] = {"count": len(values), "values": values}
+    return out
+
+
+def add_facets(total, part):
+    """Facet results of one more index into the collection's (values added, `count` = distinct values: search.rs:398-420)."""
+    for name, r in part.items():
+        t = total.setdefault(name, {"count": 0, "values": {}})
+        for k, v in r["values"].items():
+            t["values"][k] = t["values"].get(k, 0) + v
+        t["count"] = len(t["values"])
+    return total
+
+
+def check_facets(case, got):
+    for name, exp in case["expect"].items():
+        assert name in got, (case["name"], name)
+        assert got[name]["values"] == exp["values"], (case["name"], name, got[name]["values"])
+        if "count" in exp:
+            assert got[name]["count"] == exp["count"], (case["name"], name)
+
+
+# ---------------------------------------------------------------- group cases (tests/golden/reference_group_cases.json)
+def group_variants(idx, name):
+    """calculate_group_for_field (group.rs:181-270): value -> documents, over whichever filter store holds the field."""
+    for store in (idx.bool_fields, idx.number_fields, idx.string_filter_fields):
+        if name in store:
+            out = {}
+            for d, v in store[name].items():
+                if d in idx.document_ids:
+                    out.setdefault(v, set()).add(d)
+            return out
+    return None
+
+
+def oracle_groups(idx, map_docs, map_scores, properties, max_results):
+    """group.rs:113-160 + sort.rs:203-213 through the oracle: {tuple(values): [(doc, score)]} — one group per combination of
+    the properties' values, its documents = the intersection of the values' document sets, the best `max_results` of them that
+    are in the score map by (score desc, DocumentId asc)."""
+    import itertools
+
+    variants = [group_variants(idx, p) for p in properties]
+    if any(v is None for v in variants):
+        return {}
+    combos, buckets = [], []
+    for combo in itertools.product(*[sorted(v, key=str) for v in variants]):
+        combos.append(combo)
+        buckets.append(sorted(set.intersection(*[variants[i][val] for i, val in enumerate(combo)])))
+    off = np.concatenate([[0], np.cumsum([len(b) for b in buckets])]).astype(np.uint64)
+    flat = np.concatenate([np.asarray(b, dtype=np.uint64) for b in buckets]) if sum(map(len, buckets)) else np.zeros(0, dtype=np.uint64)
+    if max_results == 0:
+        return {c: [] for c in combos}
+    g_ids, g_sc, g_n = orc.group_top(np.asarray(map_docs, dtype=np.uint64), np.asarray(map_scores, dtype=F), off, flat, max_results)
+    return {c: list(zip(i_[: int(n_)].tolist(), s_[: int(n_)].tolist())) for c, i_, s_, n_ in zip(combos, g_ids, g_sc, g_n)}
+
+
+def check_groups(spec, groups, ids, hits=None):
+    """`groups`: {tuple(values): [(doc, score)]}; the reference lists only groups... of every combination (empty ones included)."""
+    exp = spec["expect"]
+    back = {v: k for k, v in ids.items()}
+    norm = lambda v: tuple(float(x) if isinstance(x, (int, float)) and not isinstance(x, bool) else x for x in v)
+    if "group_values" in exp:
+        assert {norm(k) for k in groups} == {norm(v) for v in exp["group_values"]}, sorted(groups, key=str)
+    if "max_len" in exp:
+        assert all(len(g) <= exp["max_len"] for g in groups.values())
+    for name, want in exp.get("groups", {}).items():
+        assert [back[d] for d, _ in groups[(name,)]] == want, (name, groups[(name,)])
+    for name, n in exp.get("group_lens", {}).items():
+        assert len(groups[(name,)]) == n, (name, groups[(name,)])
+    if "group_lens" in exp:
+        assert len(groups) == len(exp["group_lens"])
+    if "hit_ids" in exp and hits is not None:
+        assert [back[h[0]] for h in hits] == exp["hit_ids"]
+    for g in groups.values():  # own: score-ordered, ties by DocumentId
+        assert all((a[1], -a[0]) >= (b[1], -b[0]) for a, b in zip(g, g[1:])), g

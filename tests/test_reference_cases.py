@@ -31,3 +31,60 @@ def test_oracle_satisfies_the_reference_case(case):
         return [(int(d), float(s)) for d, s in zip(td, ts)], len(docs), ids
 
     refcases.check_case(case, search)
+
+
+# ---------------------------------------------------------------- facets (src/tests/facets.rs as data)
+FACET_CASES = util.load_json("reference_facet_cases.json")["cases"]
+
+
+def test_every_facet_case_cites_the_reference():
+    assert len(FACET_CASES) >= 8
+    for c in FACET_CASES:
+        assert c["reference"].startswith("src/tests/facets.rs:") and c["constrains"] and c["facets"] and c["expect"], c["name"]
+        for spec in c["filter_fields"].values():
+            assert spec["kind"] in ("bool", "number", "string")
+
+
+@pytest.mark.parametrize("case", FACET_CASES, ids=lambda c: c["name"])
+def test_oracle_counts_the_facets_the_reference_asserts(case):
+    """The restatement of facet.rs (orc_facet_count_buckets / orc_facet_count_ranges over the restatement's score map) against
+    the facet results the reference's own tests assert — number ranges inclusive at both ends, bool / string values, facets of
+    the matched documents only, the `where` filter left out of the facet map, values added over the indexes of a collection."""
+    import numpy as np
+
+    total = {}
+    defs = refcases.facet_definitions(case)
+    for _ in range(case.get("indexes", 1)):
+        idx = refcases.HostIndex()
+        ids = refcases.fill(idx, case)
+        refcases.fill_filters(idx, case, ids)
+        docs, scores = refcases.oracle_search(idx, {"term": case["search"]["term"]}, case["fields"])
+        keep = refcases.where_docs(idx, case["search"].get("where"))
+        if "expect_hits_count" in case:  # the hits keep the filter ...
+            assert sum(1 for d in docs if keep is None or int(d) in keep) == case["expect_hits_count"]
+        # ... the facets do not (search.rs:347-396)
+        refcases.add_facets(total, refcases.oracle_facets(idx, np.asarray(docs, dtype=np.uint64), defs))
+    for _ in range(case.get("empty_indexes", 0)):
+        refcases.add_facets(total, refcases.oracle_facets(refcases.HostIndex(), np.zeros(0, dtype=np.uint64), defs))
+    refcases.check_facets(case, total)
+
+
+# ---------------------------------------------------------------- groups (src/tests/groupby.rs as data)
+GROUP_CASES = util.load_json("reference_group_cases.json")["cases"]
+
+
+@pytest.mark.parametrize("case", GROUP_CASES, ids=lambda c: c["name"])
+def test_oracle_forms_the_groups_the_reference_asserts(case):
+    """The restatement of group.rs / sort.rs's score-ordered groups (orc_group_top over the restatement's score map) against
+    what the reference's own tests assert about them."""
+    assert case["reference"].startswith("src/tests/groupby.rs:") and case["constrains"]
+    idx = refcases.HostIndex()
+    ids = refcases.fill(idx, case)
+    refcases.fill_filters(idx, case, ids)
+    for spec in case["searches"]:
+        docs, scores = refcases.oracle_search(idx, {"term": spec["term"]}, case["fields"])
+        g = spec["group_by"]
+        mr = 1 if g["max_results"] is None else g["max_results"]  # default_group_by_max_results, types.rs:1473-1475
+        groups = refcases.oracle_groups(idx, docs, scores, g["properties"], mr)
+        td, ts = orc.top_n(docs, scores, 10)
+        refcases.check_groups(spec, groups, ids, hits=list(zip(td.tolist(), ts.tolist())))
