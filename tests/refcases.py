@@ -51,6 +51,16 @@ def fill(idx, case):
     return ids
 
 
+def levenshtein(a: bytes, b: bytes) -> int:
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, start=1):
+        cur = [i]
+        for j, cb in enumerate(b, start=1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
 def oracle_search(idx, p, fields, exact_match_boost=1.0):
     """One search of a case through the CPU restatement: (docs, scores) of the whole map after OMC."""
     fmap = {name: fi for fi, name in enumerate(fields)}
@@ -58,12 +68,15 @@ def oracle_search(idx, p, fields, exact_match_boost=1.0):
     tokens = tokens_of(p["term"], exact)
     props = sorted(idx.string_fields) if "properties" not in p else sorted(fmap[n] for n in p["properties"])
     boost = {fmap[n]: float(v) for n, v in p.get("boost", {}).items()}
+    tol = int(p.get("tolerance") or 0)
     entries = []
     for ti, tok in enumerate(tokens):
         for fid in props:
             sf = idx.string_fields[fid]
             for term in sorted(sf.postings):
-                if not (term == tok if exact else term.startswith(tok)):
+                # the dictionary step: the term itself (exact), or every term the token prefixes plus, with `tolerance`, every
+                # term within that Levenshtein distance (bytes) — src/tests/fulltext_search.rs:603-753, 956-1018
+                if not (term == tok if exact else (term.startswith(tok) or (tol and levenshtein(term.encode(), tok.encode()) <= tol))):
                     continue
                 bo = F(boost.get(fid, 1.0))
                 if term == tok and exact_match_boost != 1.0:

@@ -12,7 +12,7 @@ CASES = util.load_json("reference_cases.json")["cases"]
 
 
 def test_every_case_cites_the_reference_and_names_what_it_constrains():
-    assert len(CASES) >= 7
+    assert len(CASES) >= 12
     for c in CASES:
         assert c["reference"].startswith("src/tests/") and ":" in c["reference"], c["name"]
         assert c["constrains"] and c["fields"] and c["searches"], c["name"]
@@ -27,8 +27,9 @@ def test_oracle_satisfies_the_reference_case(case):
     def search(spec, exact_match_boost):
         p = spec["params"]
         docs, scores = refcases.oracle_search(idx, p, case["fields"], exact_match_boost)
-        td, ts = orc.top_n(docs, scores, p.get("limit", 10))
-        return [(int(d), float(s)) for d, s in zip(td, ts)], len(docs), ids
+        off = p.get("offset", 0)
+        td, ts = orc.top_n(docs, scores, p.get("limit", 10) + off)  # search.rs:481-500: top (limit + offset), skip(offset)
+        return [(int(d), float(s)) for d, s in zip(td[off:], ts[off:])], len(docs), ids
 
     refcases.check_case(case, search)
 

@@ -29,13 +29,14 @@ def test_reference_case_through_the_hip_path(case):
         def search(spec, exact_match_boost):
             p = spec["params"]
             tsc = TokenScoreContext(idx, exact_match_boost=exact_match_boost)
-            mode = FulltextMode(p["term"], threshold=p.get("threshold"), exact=p.get("exact", False))
-            params = TokenScoreParams(mode=mode, limit=p.get("limit", 10),
+            mode = FulltextMode(p["term"], threshold=p.get("threshold"), exact=p.get("exact", False), tolerance=p.get("tolerance"))
+            params = TokenScoreParams(mode=mode, limit=p.get("limit", 10), offset=p.get("offset", 0),
                                       properties=None if "properties" not in p else [fields[n] for n in p["properties"]],
                                       boost={fields[n]: float(v) for n, v in p.get("boost", {}).items()})
             hits, count = tsc.execute(params)
             od, os_ = refcases.oracle_search(idx, p, case["fields"], exact_match_boost)
-            td, ts = orc.top_n(od, os_, params.limit)
+            td, ts = orc.top_n(od, os_, params.limit + params.offset)
+            td, ts = td[params.offset:], ts[params.offset:]
             assert count == len(od), (spec, count, len(od))
             assert [h[0] for h in hits] == td.tolist(), spec
             assert np.array_equal(np.array([h[1] for h in hits], dtype=F).view(np.uint32), ts.view(np.uint32)), spec
