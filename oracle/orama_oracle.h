@@ -13,7 +13,7 @@
  *     reference's own integration tests assert — src/tests/facets.rs:9-576 (8 cases), src/tests/groupby.rs:9-174, 416-467,
  *     580-754 (6 cases) — held as data in tests/golden/reference_facet_cases.json, reference_group_cases.json
  *     (tests/test_reference_cases.py).
- *   - ntf / field boost / exact-match factor / threshold / OMC: CONSTRAINED (inequalities, orders, ratios, hit counts) by twelve more of
+ *   - ntf / field boost / exact-match factor / threshold / OMC: CONSTRAINED (inequalities, orders, ratios, hit counts) by nineteen more of
  *     its cases (tests/golden/reference_cases.json); the formulas themselves live in the un-vendored crates below.
  *   - cosine scan / top-k ties / hybrid combine:  PARITY UNPINNED — the arithmetic lives in the
  *     un-vendored crates oramacore_fields 0.2.0 / oramacore_lib 0.4.4 (Cargo.lock:5313-5335) and

@@ -46,8 +46,18 @@ def fill(idx, case):
         for fi, name in enumerate(fields):
             if name in doc:
                 idx.string_fields[fi].insert(n, doc[name])
-        if "_omc" in doc:
-            idx.omc[n] = float(doc["_omc"])
+        v = doc.get("_omc")
+        # write/index/mod.rs:451-458: only a positive NUMBER is a multiplier (as_f64, > 0); anything else is ignored
+        if isinstance(v, (int, float)) and not isinstance(v, bool) and float(v) > 0.0:
+            idx.omc[n] = float(v)
+    for gone in case.get("delete_ids", []):  # delete_documents: out of the document set, the fields and the OMC map
+        n = ids.get(gone)
+        if n is None:
+            continue  # (an id the index never held: src/tests/delete_doc.rs:72-120)
+        idx.document_ids.discard(n)
+        for sf in idx.string_fields.values():
+            sf.delete(n)
+        idx.omc.pop(n, None)
     return ids
 
 
@@ -106,8 +116,14 @@ def check_expect(hits, count, ids, exp):
         assert got[: len(exp["ids_prefix"])] == exp["ids_prefix"]
     if "first_id" in exp:
         assert got[0] == exp["first_id"]
+    for a, b in exp.get("rank_before", []):
+        assert got.index(a) < got.index(b), (a, b, got)
+    for i in exp.get("contains_ids", []):
+        assert i in got, (i, got)
     for i in range(exp.get("strictly_decreasing_scores", 1) - 1):
         assert hits[i][1] > hits[i + 1][1], (i, hits[i], hits[i + 1])
+    if exp.get("positive_scores"):
+        assert all(h[1] > 0.0 for h in hits), hits
     if exp.get("scores_bit_equal"):
         assert len({np.float32(h[1]).view(np.uint32).item() for h in hits}) == 1, hits
 
@@ -122,6 +138,8 @@ def check_case(case, search):
         check_expect(hits, count, ids, spec["expect"])
         if "save_top_score_as" in spec:
             saved[spec["save_top_score_as"]] = float(hits[0][1])
+        for name, doc_id in spec.get("save_scores", {}).items():  # the score of ONE document among the hits
+            saved[name] = float(dict(hits)[ids[doc_id]])
         by_id = {k: dict(hits).get(v) for k, v in ids.items()}
         for r in spec.get("score_ratios", []):
             assert abs(by_id[r["a"]] - by_id[r["b"]] * r["ratio"]) <= r["abs_tol"], (r, by_id)
