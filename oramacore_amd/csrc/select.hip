@@ -1227,10 +1227,13 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
                                                                   uint64_t direct_stride = 0, uint32_t direct_cap = 0,
                                                                   uint32_t n_stride = 1,
                                                                   const unsigned long long* __restrict__ l2_keys = nullptr,
-                                                                  uint64_t l2_stride = 0) {
+                                                                  uint64_t l2_stride = 0, KeysMirror mirror = KeysMirror()) {
     __shared__ SortLds s;
     __shared__ uint32_t valid_s;
     __shared__ uint32_t hist[256];
+    if (mirror.src)  // (the words are final: everything that writes them was launched before this kernel)
+        for (uint32_t i = threadIdx.x; i < mirror.words; i += blockDim.x)
+            mirror.dst[(size_t)blockIdx.x * mirror.words + i] = mirror.src[(size_t)blockIdx.x * mirror.words + i];
     if (n_active && blockIdx.x >= *n_active) return;  // (uniform) see keys_reduce_kernel
     if (done && done[blockIdx.x]) return;              // (uniform) pairs_reduce_kernel has finished this list itself
     __shared__ unsigned long long red_max[kSortThreads / 64], red_min[kSortThreads / 64];
@@ -1415,8 +1418,10 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
                      uint32_t q, uint32_t k, bool descending, const uint64_t* id_map,
                      unsigned long long* d_tmp, uint32_t* out_idx, uint64_t* out_ids, float* out_val,
                      uint32_t* out_n, hipStream_t stream, const uint32_t* d_n_per_list, unsigned long long* d_tau,
-                     uint32_t tau_stride, const uint32_t* d_n_active, bool counted, uint32_t n_per_list_stride) {
+                     uint32_t tau_stride, const uint32_t* d_n_active, bool counted, uint32_t n_per_list_stride,
+                     const KeysMirror* mirror) {
     ORAMA_REQUIRE(k >= 1 && k <= kSelectMaxK && q >= 1 && d_keys && out_val, "keys top-k: bad arguments");
+    const KeysMirror mir = mirror ? *mirror : KeysMirror();
     ProfScope prof(&ctx->prof, "topk_select", stream);
     if (counted && d_n_per_list) {
         // Lists whose lengths were produced on the device and are expected to be MUCH shorter than n_keys (K3r's compact key
@@ -1448,7 +1453,7 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
             }
             hipLaunchKernelGGL(keys_final_kernel, dim3(q), dim3(kSortThreads), 0, stream, d_tmp ? d_tmp : d_keys, (uint32_t)n1, n1,
                                d_n_per_list, k, descending, id_map, out_idx, out_ids, out_val, out_n, d_n_active,
-                               (const uint32_t*)nullptr, d_keys, stride, cap, n_per_list_stride, l2, (uint64_t)chunks2 * k);
+                               (const uint32_t*)nullptr, d_keys, stride, cap, n_per_list_stride, l2, (uint64_t)chunks2 * k, mir);
             ORAMA_HIP_TRY(hipGetLastError());
             return ORAMA_OK;
         }
@@ -1477,7 +1482,7 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
     }
     hipLaunchKernelGGL(keys_final_kernel, dim3(q), dim3(kSortThreads), 0, stream, cur, n, cur_stride, n_per_list, k,
                        descending, id_map, out_idx, out_ids, out_val, out_n, d_n_active, (const uint32_t*)nullptr,
-                       (const unsigned long long*)nullptr, (uint64_t)0, 0u, n_stride);
+                       (const unsigned long long*)nullptr, (uint64_t)0, 0u, n_stride, (const unsigned long long*)nullptr, (uint64_t)0, mir);
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -64,12 +64,20 @@ int launch_merge_candidates(orama_ctx* ctx, const uint64_t* d_ids, const float* 
 // reduction level (a chunk with at most k keys at or above the bound skips its selection).  d_n_active (optional, device):
 // only lists 0 .. *d_n_active - 1 exist — the workgroups of the others end at once and their outputs are left untouched.
 constexpr uint32_t kKeysChunk = 8192;
+// Optional side job of the final launch (round 5): workgroup i copies words [i * words, (i + 1) * words) from `src` to `dst` before
+// anything else — K3r hands its per-query result words to the pinned host block this way, and points the outputs there as well:
+// the chunk's chain ends with the final launch instead of a read-back behind it.
+struct KeysMirror {
+    const uint32_t* src = nullptr;
+    uint32_t* dst = nullptr;
+    uint32_t words = 0;
+};
 int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t n_keys, uint64_t stride,
                      uint32_t q, uint32_t k, bool descending, const uint64_t* id_map,
                      unsigned long long* d_tmp, uint32_t* out_idx, uint64_t* out_ids, float* out_val,
                      uint32_t* out_n, hipStream_t stream, const uint32_t* d_n_per_list = nullptr,
                      unsigned long long* d_tau = nullptr, uint32_t tau_stride = 0, const uint32_t* d_n_active = nullptr,
-                     bool counted = false, uint32_t n_per_list_stride = 1);
+                     bool counted = false, uint32_t n_per_list_stride = 1, const KeysMirror* mirror = nullptr);
 // Keys of scratch launch_keys_topk needs for lists of n_keys entries.
 uint64_t keys_topk_scratch_keys(uint32_t n_keys, uint32_t q, uint32_t k);
 

@@ -1,0 +1,8 @@
+# K3r: the answers written to the pinned host block by the top-k's final launch (default) against a staging launch behind it
+for M in 1 0 1 0; do
+  echo "== ORAMA_K3R_DIRECT_OUT=$M"
+  ORAMA_K3R_DIRECT_OUT=$M python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-two-stage --configs c4 --no-pmc 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['configs']['c4']; b=c['bm25_only']
+print('bm25 batch', round(b['value']), 'best', round(b['runs']['best']), 'single', round(b['single_query_calls']['value']), 'wrapper', round(b['through_python_wrapper']['value']), '| hybrid', round(c['value'],2), 'p50', round(c['latency_ms_p50'],4), 'p95', round(c['latency_ms_p95'],4))"
+done
