@@ -268,7 +268,9 @@ struct orama_ctx {
     // small host<->device blocks (the range scorer's chunk tables and answers, a lone query and its hits) move by a kernel of
     // the caller's stream instead of an SDMA copy (stage.hip); ORAMA_STAGE_COPY=dma puts the copy commands back
     bool stage_by_kernel = true;
-    bool bm25_direct_out = true;  // K3r: the top-k's final launch writes the answers to the pinned host block itself (ORAMA_K3R_DIRECT_OUT=0: a staging launch behind it)
+    // the selection's final launch writes the answers to the pinned host block itself — K3r's chunks, a lone fp32 vector search,
+    // the vector leg of a hybrid call (ORAMA_DIRECT_OUT=0: a staging launch behind it)
+    bool direct_out = true;
     // two-stream searches: the scan's completion event rides on its dispatch instead of a record packet behind it (vec_store.hip
     // scan_end; ORAMA_SCAN_DONE_EVENT=record restores the packet)
     bool scan_done_on_dispatch = true;

@@ -411,7 +411,7 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
     if (const char* e = std::getenv("ORAMA_K3R_COMPACT")) c->bm25_compact_keys = std::atoi(e) != 0;
     if (const char* e = std::getenv("ORAMA_SCAN_DONE_EVENT")) c->scan_done_on_dispatch = std::strcmp(e, "record") != 0;
     if (const char* e = std::getenv("ORAMA_SELECT_WIDE")) c->select_wide = std::atoi(e);
-    if (const char* e = std::getenv("ORAMA_K3R_DIRECT_OUT")) c->bm25_direct_out = std::atoi(e) != 0;
+    if (const char* e = std::getenv("ORAMA_DIRECT_OUT")) c->direct_out = std::atoi(e) != 0;
     if (const char* e = std::getenv("ORAMA_STAGE_COPY")) c->stage_by_kernel = std::strcmp(e, "dma") != 0;
     if (const char* e = std::getenv("ORAMA_HYBRID_DEVICE_TAIL")) c->hybrid_device_tail = std::atoi(e) != 0;
     if (const char* e = std::getenv("ORAMA_BM25_RANGES_HYBRID")) c->bm25_ranges_hybrid = std::atoi(e) != 0;

@@ -1113,7 +1113,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         // there and carries the queries' result words along (KeysMirror) — one launch fewer at the end of every chunk's chain
         // (a lone query: 6 launches -> 5, 49 -> 45 us of chain).  Not where something on the device still reads the answers (the
         // device tail of a hybrid call), and not with copy commands asked for.
-        const bool direct_out = c.kmax && !device_tail && p->ctx->stage_by_kernel && p->ctx->bm25_direct_out;
+        const bool direct_out = c.kmax && !device_tail && p->ctx->stage_by_kernel && p->ctx->direct_out;
         if (c.kmax) {
             ORAMA_TRY(sc->misc4.reserve((size_t)keys_topk_scratch_keys((uint32_t)max_total, nq, c.kmax) * 8 + 8));
             char* o = direct_out ? reinterpret_cast<char*>(h_res) : d_out;
@@ -2285,6 +2285,12 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
         if (two_stage) {  // (the read-back behind the plan, before the host looks at the proof word: one wake-up — join_vector_leg)
             ORAMA_TRY(ts.begin(v, a, a2, a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n));
             return stage_block(ctx, a->h_out.p, d_ids, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, sa);
+        }
+        if (vec_rows_are_f32(v) && ctx->stage_by_kernel && ctx->direct_out) {
+            // (fp32 rows: the selection's last launch only writes the answers — straight into the pinned block)
+            char* h = a->h_out.as<char>();
+            return vec_search_enqueue(v, a.s.get(), a->query.as<float>(), 1, limit, d_allow, bitmap_bits, reinterpret_cast<uint64_t*>(h),
+                                      reinterpret_cast<float*>(h + (size_t)kk * 8), reinterpret_cast<uint32_t*>(h + (size_t)kk * 12), sa);
         }
         ORAMA_TRY(vec_search_enqueue(v, a.s.get(), a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n, sa));
         ORAMA_TRY(stage_block(ctx, a->h_out.p, d_ids, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, sa));

@@ -22,6 +22,7 @@ class VecSharedLock {
 orama_ctx* vec_ctx(orama_vec* v);
 uint32_t vec_dim(orama_vec* v);
 uint64_t vec_rows(orama_vec* v);
+bool vec_rows_are_f32(orama_vec* v);  // plain fp32 storage (no fp16 rows: the selections behind its scans only write their outputs)
 // Enqueue scan + top-k for q queries resident at d_queries on stream s (caller holds a VecSharedLock).
 int vec_search_enqueue(orama_vec* v, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,

@@ -980,6 +980,7 @@ VecSharedLock::~VecSharedLock() { v_->mu.unlock_shared(); }
 orama_ctx* vec_ctx(orama_vec* v) { return v->ctx; }
 uint32_t vec_dim(orama_vec* v) { return v->dim; }
 uint64_t vec_rows(orama_vec* v) { return v->n_rows.load(std::memory_order_acquire); }
+bool vec_rows_are_f32(orama_vec* v) { return !v->f16(); }
 int vec_search_enqueue(orama_vec* v, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
                        uint32_t* d_out_n, hipStream_t s) {
@@ -1452,6 +1453,10 @@ int orama_vec_search(orama_vec* v, const float* queries, uint32_t q, uint32_t k,
         bool reran = false;
         ORAMA_TRY(call.finish(&reran));
         if (reran) ORAMA_TRY(stage_blocks(v->ctx, back, 3, hipMemcpyDeviceToHost, s));
+    } else if (!v->f16() && v->ctx->stage_by_kernel && v->ctx->direct_out) {
+        // fp32 rows: the selection's last launch only WRITES the answers — straight into the pinned block (no read-back launch)
+        ORAMA_TRY(search_enqueue(v, sc.s.get(), sc->query.as<float>(), q, k, d_allow, bitmap_bits, reinterpret_cast<uint64_t*>(h),
+                                 reinterpret_cast<float*>(h + nk * 8), reinterpret_cast<uint32_t*>(h + nk * 12), s));
     } else {
         ORAMA_TRY(search_enqueue(v, sc.s.get(), sc->query.as<float>(), q, k, d_allow, bitmap_bits,
                                  sc->out_ids.as<uint64_t>(), sc->out_val.as<float>(), sc->out_n.as<uint32_t>(), s));
