@@ -845,7 +845,11 @@ def hybrid_leg(oa, ctx, vec, n, dim, k, steps, warmup, n_lists=2048, tokens=12, 
                                    "note": "round 5: compact key lists — the scoring launch (2.5 VALU wave instructions per posting, bound by "
                                            "instruction issue and latency, not by HBM) appends only the keys at or above a floor, the top-k "
                                            "reads survivors only: chain traffic 0.92 x the algorithmic bytes (round 4: 2.2 x) — DESIGN K3r, "
-                                           "profiles/r05_k3r_compact_ab_final.log, r05_pmc_k3r_*.json"},
+                                           "profiles/r05_k3r_compact_ab_final.log, r05_pmc_k3r_*.json.  Since the second half of round 5 the "
+                                           "top-k's final launch also DELIVERS the answers (ids, scores, counts, the queries' result words) to "
+                                           "the pinned host block: topk_select includes that write over PCIe (~0.3 us per query), which until "
+                                           "then was a launch of its own outside every bracket — the chain's end-to-end time fell, this figure "
+                                           "rose (profiles/r05_k3r_direct_out_ab.log)"},
                       "cpu_baseline": cpu_bm25},
         "postings_fill_seconds": t_fill,
         "parity_check": "bit-exact vs oracle (last query): BM25 ids/scores/count, hybrid ids/scores/count",
