@@ -941,7 +941,7 @@ int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStr
         if (wide) hipLaunchKernelGGL((range_score_kernel<false, true>), dim3(grid), dim3(kThreads), 0, stream, b);
         else if (plain && b.compact_keys) {
             ORAMA_REQUIRE(b.score_pub, "internal: compact key lists without their published-score table");
-            ORAMA_REQUIRE(b.stripe_start[kRangeStripes * kRangeBatchMax] == grid, "internal: stripe table not filled");
+            ORAMA_REQUIRE(b.stripe_start && b.stripe_total == grid, "internal: stripe table not filled");
             hipLaunchKernelGGL(range_score_compact_kernel, dim3(grid), dim3(kThreads), 0, stream, b);
         }
         else if (plain) hipLaunchKernelGGL((range_score_kernel<false, false, true>), dim3(grid), dim3(kThreads), 0, stream, b);

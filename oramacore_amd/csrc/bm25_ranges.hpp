@@ -72,7 +72,10 @@ struct RangeBatch {
     // every query (n = its ranges), queries in order inside a stripe — so that every query's ranges are scored THROUGHOUT
     // the launch whatever the queries' sizes: stripe_start[s * kRangeBatchMax + q] = first workgroup of (stripe s, query q),
     // unused queries repeat the next entry; stripe_start[S * kRangeBatchMax] = all pairs
-    uint32_t stripe_start[kRangeStripes * kRangeBatchMax + 1] = {0};
+    // (a DEVICE table of kRangeStripes * kRangeBatchMax + 1 words, uploaded with the batch's other tables; stripe_total = its last
+    // word, for the launcher's check)
+    const uint32_t* stripe_start = nullptr;
+    uint32_t stripe_total = 0;
     uint64_t max_bound_entries = 0;      // largest references x (ranges + 1) of a query: grid.x of the bounds launch
     const uint32_t* post_doc = nullptr;
     const uint32_t* post_val = nullptr;

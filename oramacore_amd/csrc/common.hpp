@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>

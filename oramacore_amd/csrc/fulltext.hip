@@ -989,15 +989,33 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         const size_t q_bytes = ((size_t)nq * sizeof(RangeQuery) + 63) & ~(size_t)63;
         const size_t idf_bytes = (size_t)nq * kMaxTokens * 4;
         const size_t len_bytes = ((size_t)nq * 4 + 63) & ~(size_t)63;
-        ORAMA_TRY(sc->h_in.reserve(seg_bytes + q_bytes + idf_bytes + len_bytes));
+        // (compact key lists: + the stripe table of the scoring launch's walk — it travels with the tables instead of riding in
+        // every launch's kernel arguments: 1 KB that a lone query's launches carried for nothing)
+        const size_t stripe_bytes = compact ? (((size_t)kRangeStripes * kRangeBatchMax + 1) * 4 + 63) & ~(size_t)63 : 0;
+        const size_t tables_bytes = seg_bytes + q_bytes + idf_bytes + len_bytes + stripe_bytes;
+        ORAMA_TRY(sc->h_in.reserve(tables_bytes));
         char* h = sc->h_in.as<char>();
         memcpy(h, segs.data(), segs.size() * sizeof(RangeSeg));
         memcpy(h + seg_bytes, queries.data(), (size_t)nq * sizeof(RangeQuery));
         memcpy(h + seg_bytes + q_bytes, h_idf, idf_bytes);
         memcpy(h + seg_bytes + q_bytes + idf_bytes, c.lens.data(), (size_t)nq * 4);
-        ORAMA_TRY(sc->misc0.reserve(seg_bytes + q_bytes + idf_bytes + len_bytes));
+        uint32_t stripe_total = 0;
+        if (compact) {  // the scoring launch's walk over the batch: kRangeStripes passes over the queries (RangeBatch::stripe_start)
+            uint32_t* st_tab = reinterpret_cast<uint32_t*>(h + seg_bytes + q_bytes + idf_bytes + len_bytes);
+            uint32_t w = 0;
+            for (uint32_t st = 0; st < kRangeStripes; ++st)
+                for (uint32_t ci = 0; ci < kRangeBatchMax; ++ci) {
+                    st_tab[st * kRangeBatchMax + ci] = w;
+                    if (ci < nq) {
+                        const uint64_t n = queries[ci].n_ranges;
+                        w += (uint32_t)((st + 1) * n / kRangeStripes - st * n / kRangeStripes);
+                    }
+                }
+            st_tab[kRangeStripes * kRangeBatchMax] = stripe_total = w;
+        }
+        ORAMA_TRY(sc->misc0.reserve(tables_bytes));
         c.trace.mark(1);
-        ORAMA_TRY(stage_block(p->ctx, sc->misc0.p, h, seg_bytes + q_bytes + idf_bytes + len_bytes, hipMemcpyHostToDevice, s));
+        ORAMA_TRY(stage_block(p->ctx, sc->misc0.p, h, tables_bytes, hipMemcpyHostToDevice, s));
         c.trace.mark(2);
         ORAMA_TRY(sc->misc1.reserve((size_t)bounds_entries * 4));
         // device results in ONE block: [RangeResult x nq | ids | scores | n]  -> one read-back per chunk
@@ -1025,17 +1043,9 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             rb.max_refs = std::max(rb.max_refs, queries[ci].seg_end - queries[ci].seg_begin);
             rb.any_minmax |= queries[ci].track_minmax;
         }
-        if (compact) {  // the scoring launch's walk over the batch: kRangeStripes passes over the queries (RangeBatch::stripe_start)
-            uint32_t w = 0;
-            for (uint32_t st = 0; st < kRangeStripes; ++st)
-                for (uint32_t ci = 0; ci < kRangeBatchMax; ++ci) {
-                    rb.stripe_start[st * kRangeBatchMax + ci] = w;
-                    if (ci < nq) {
-                        const uint64_t n = queries[ci].n_ranges;
-                        w += (uint32_t)((st + 1) * n / kRangeStripes - st * n / kRangeStripes);
-                    }
-                }
-            rb.stripe_start[kRangeStripes * kRangeBatchMax] = w;
+        if (compact) {
+            rb.stripe_start = reinterpret_cast<const uint32_t*>(sc->misc0.as<char>() + seg_bytes + q_bytes + idf_bytes + len_bytes);
+            rb.stripe_total = stripe_total;
         }
         rb.max_bound_entries = max_bound_entries;
         rb.post_doc = p->d_post_doc.as<uint32_t>();
@@ -2264,6 +2274,7 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
     const bool have_rows = vec_rows(v) > 0 && limit > 0;
     const uint32_t kk = limit ? limit : 1;
     bool two_stage_device = false;  // the vector leg of a shadow store in the plan's device form (set with the device tail below)
+    bool hits_stay_on_device = false;  // the device tail reads the vector hits where the selection wrote them: no direct answers
     // ---- leg A: vector scan + top-`limit` rows on a's stream; the read-back lands in a->h_out
     auto vector_leg = [&](ScratchLease& a, ScratchLease& a2, VecTwoStage& ts) -> int {
         if (!have_rows) return ORAMA_OK;
@@ -2286,7 +2297,7 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
             ORAMA_TRY(ts.begin(v, a, a2, a->query.as<float>(), 1, limit, d_allow, bitmap_bits, d_ids, d_dist, d_n));
             return stage_block(ctx, a->h_out.p, d_ids, (size_t)kk * 12 + 4, hipMemcpyDeviceToHost, sa);
         }
-        if (vec_rows_are_f32(v) && ctx->stage_by_kernel && ctx->direct_out) {
+        if (vec_rows_are_f32(v) && ctx->stage_by_kernel && ctx->direct_out && !hits_stay_on_device) {
             // (fp32 rows: the selection's last launch only writes the answers — straight into the pinned block)
             char* h = a->h_out.as<char>();
             return vec_search_enqueue(v, a.s.get(), a->query.as<float>(), 1, limit, d_allow, bitmap_bits, reinterpret_cast<uint64_t*>(h),
@@ -2353,6 +2364,7 @@ int orama_hybrid_search(orama_vec* v, orama_post* p, const float* query, uint32_
                                   (uint64_t)params->top_k + 2ull * limit + 1 <= kSelectMaxK &&
                                   (!two_stage || vec_two_stage_device_usable(v, 1, limit));
             two_stage_device = dev_tail && two_stage;
+            hits_stay_on_device = dev_tail;
             ORAMA_TRY(vector_leg(a, a2, ts));
             RangeJob job{refs, n_refs, params, out_ids, out_scores, out_n, out_count};
             job.hybrid = true;
