@@ -22,6 +22,8 @@ refs = [[(t, int(l), 1.0) for t, l in enumerate(rng.choice(len(ranks), size=T, r
 for r in refs[:8]:
     post.search(r, T, float(n), k)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+if len(sys.argv) > 2:  # "always" / "never": compact key lists for every batch size / for none (default: batches of 8 and more)
+    ctx.set_bm25_ranges(True, True, compact_keys="always" if sys.argv[2] == "always" else False)
 t0 = time.perf_counter()
 for i in range(N):
     post.search(refs[i % 64], T, float(n), k)
