@@ -21,6 +21,16 @@
 //                                              scans; a list of one round is finished by the workgroup that reduces it.
 #include "select.hpp"
 
+// This file is compiled twice: as the unit "select" (ORAMA_SELECT_UNIT 1, everything but the two kernels of the second half of
+// round 5) and, included by select_wide.hip, as a unit that holds ONLY those two (select_tiny_kernel, pairs_reduce_wide_kernel)
+// and the device helpers they share with the rest.  Why: with the two kernels in THIS code object the key-list kernels of a lone
+// full-text call — same source, same instruction counts, same registers — ran 6 us longer per call (event span around
+// keys_reduce + keys_final 27.6 -> 33.8 us, 14.5 K -> 13.4 K single calls per second; linking the unit without them gave the
+// 27.6 us back: profiles/r05_select_unit_split.log).  The helpers are internal to each unit (anonymous namespace).
+#ifndef ORAMA_SELECT_UNIT
+#define ORAMA_SELECT_UNIT 1
+#endif
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -48,6 +58,7 @@ __device__ __forceinline__ unsigned long long make_key(float v, uint32_t idx, bo
     return ((unsigned long long)hi << 32) | (unsigned long long)(uint32_t)(~idx);
 }
 
+#if ORAMA_SELECT_UNIT == 1
 // ---------------------------------------------------------------- histogram pass
 __global__ __launch_bounds__(kHistThreads) void select_hist_kernel(
     const float* __restrict__ vals, const uint32_t* __restrict__ idx, uint64_t stride,
@@ -208,6 +219,7 @@ __global__ __launch_bounds__(kHistThreads) void select_collect_kernel(
     }
 }
 
+#endif
 // ---------------------------------------------------------------- LDS bitonic sort
 // Sort record: hi (ordered value key, larger first), id (64-bit, smaller first), idx (smaller first).
 struct SortLds {
@@ -269,6 +281,7 @@ __device__ void write_sorted(const SortLds& s, uint32_t count, uint32_t k, bool 
     if (threadIdx.x == 0 && out_n) *out_n = count;
 }
 
+#if ORAMA_SELECT_UNIT == 1
 // Final ordering of the k' collected keys.
 __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(
     const SelectState* __restrict__ state, const unsigned long long* __restrict__ keys,
@@ -399,6 +412,7 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(
                  out_n ? out_n + qi : nullptr);
 }
 
+#endif
 // The per-wave extremes of a workgroup's 16 waves -> the workgroup's, in every lane: lanes 0..15 read one entry each and the
 // wave reduces by shuffles (a loop over the 16 entries had the compiler fetch all of them at once: 64 registers that cost
 // pairs_reduce_kernel its second resident workgroup per CU).
@@ -520,6 +534,7 @@ __device__ __forceinline__ uint32_t rank_by_counting(const unsigned long long* s
     return above;
 }
 
+#if ORAMA_SELECT_UNIT == 1
 // ---------------------------------------------------------------- key lists (fused per-wave top-k of K1, K3r)
 // One workgroup per (chunk, list): the best k of up to 8192 u64 keys, as a SET (the final kernel orders the survivors).
 // Keys are unique (the low word is ~index), 0 = empty.  The chunk passes through registers; what reaches the floor (the
@@ -744,6 +759,7 @@ __global__ __launch_bounds__(kSortThreads, 8) void keys_reduce_kernel(const unsi
     }
 }
 
+#endif
 // ---------------------------------------------------------------- (value, index) lists in two launches
 // The candidate lists of the fp16 scans (a few thousand entries per query, length known on the device only) went
 // through the general selection: memset + 6 x (histogram + scan) + collect + sort = 15 launches of 2-15 us with a
@@ -889,6 +905,7 @@ __device__ __forceinline__ void finish_whole_list(unsigned long long* s, uint32_
                  fin.out_n ? fin.out_n + qi : nullptr);
 }
 
+#if ORAMA_SELECT_UNIT == 2
 // A list of <= 512 values (the reranked candidates of the two-stage plan: 356 for k = 100; the merged entries of a hybrid call)
 // in ONE workgroup without a sort (round 5): select_small_kernel's two bitonic sorts of 512 and 128 records are 73 barrier-
 // separated steps — 23-29 us behind a lone query (profiles/r05_lone_call_timelines.log).  The keys are unique, so the rank of a
@@ -928,6 +945,8 @@ __global__ __launch_bounds__(kSortThreads) void select_tiny_kernel(const float* 
     finish_whole_list(s, kept, true, k, descending, qi, fin);
 }
 
+#endif
+#if ORAMA_SELECT_UNIT == 1
 template <bool HAS_IDX>
 __global__ __launch_bounds__(kSortThreads, 8) void pairs_reduce_kernel(const float* __restrict__ vals,
                                                                     const uint32_t* __restrict__ idx, uint64_t stride,
@@ -1062,6 +1081,8 @@ __global__ __launch_bounds__(kSortThreads, 8) void pairs_reduce_kernel(const flo
     for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = i < kept ? s[i] : 0ull;
 }
 
+#endif
+#if ORAMA_SELECT_UNIT == 2
 // ---- a FEW LONG dense lists (a lone query's distance array: 1 M values), round 5 -------------------------------------------------
 // pairs_reduce_kernel walks such a list in rounds of 8 192 values: 40 parts of 1 M values take 3-4 rounds each, every round a
 // chain of load -> bound -> compact -> cut: 39 us behind a 230 us scan of 1 M x 384 rows (profiles/r05_c2_kernel_stats.md).
@@ -1214,6 +1235,8 @@ __global__ __launch_bounds__(kSortThreads) void pairs_reduce_wide_kernel(const f
     for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) o[i] = i < st.kept ? s[i] : 0ull;
 }
 
+#endif
+#if ORAMA_SELECT_UNIT == 1
 // Final ordering of <= 4096 keys: (value, 64-bit id asc, idx asc), empties (0) dropped.
 __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned long long* __restrict__ keys,
                                                                   uint32_t n_keys, uint64_t in_stride,
@@ -1393,8 +1416,10 @@ __global__ __launch_bounds__(kSortThreads) void keys_final_kernel(const unsigned
                  out_n ? out_n + qi : nullptr);
 }
 
+#endif
 }  // namespace
 
+#if ORAMA_SELECT_UNIT == 1
 // Keys the final kernel takes: a full sort handles 4 096 records; when the k best are cut out first (more than two sorts'
 // worth of candidates, see keys_final_kernel) the candidates only pass through the key buffer, which holds 8 192.
 static uint32_t keys_final_capacity(uint32_t k) {
@@ -1501,18 +1526,7 @@ int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
         if (p.n == 0) {
             // empty list: emit padding + zero counts through the small kernel with n = 0
         }
-        if (p.n >= 1 && p.n <= kRankCountMax && p.k <= kSortThreads && ctx->select_wide != 0) {
-            PairsFinal fin;
-            fin.id_map = p.id_map;
-            fin.out_idx = p.out_idx;
-            fin.out_ids = p.out_ids;
-            fin.out_val = p.out_val;
-            fin.out_n = p.out_n;
-            hipLaunchKernelGGL(select_tiny_kernel, dim3(p.q), dim3(kSortThreads), 0, stream, p.vals, p.idx, p.stride, p.n_dev, p.n,
-                               p.k, p.descending, fin);
-            ORAMA_HIP_TRY(hipGetLastError());
-            return ORAMA_OK;
-        }
+        if (p.n >= 1 && p.n <= kRankCountMax && p.k <= kSortThreads && ctx->select_wide != 0) return launch_select_tiny(p, stream);
         hipLaunchKernelGGL(select_small_kernel, dim3(p.q), dim3(kSortThreads), 0, stream, p.vals,
                            p.idx, p.stride, p.n_dev, p.n, p.k, p.descending, p.id_map, p.out_idx,
                            p.out_ids, p.out_val, p.out_n);
@@ -1554,19 +1568,18 @@ int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
         // a few long dense lists whose parts fit one round of 32 values per thread (1 M values in 40 parts at k = 100)
         const int wide_mode = ctx->select_wide;  // ORAMA_SELECT_WIDE: 0 = rounds of 8 192 (round 4), 2 = the fallback rounds only (tests)
         bool wide = wide_mode != 0 && !p.idx && list_chunks > 16 && p.k <= kWaveBoundMaxK &&
-                    ((uint64_t)p.n + parts - 1) / parts <= (uint64_t)kWidePer * kSortThreads;
+                    ((uint64_t)p.n + parts - 1) / parts <= (uint64_t)kSelectWidePartValues;
         // many dense lists of a known length (the dense heads of the fp16 scans: 131 072 distances for each of 64 / 256 queries)
         // as well: 4 parts of one round each per list instead of 16 parts of one round (C3) or 4 parts of four rounds (C5)
         if (!wide && wide_mode != 0 && wide_mode != 3 && !p.idx && !p.n_dev && list_chunks >= 4 && list_chunks <= 16 && p.k <= kWaveBoundMaxK) {
-            const uint32_t pw = (uint32_t)(((uint64_t)p.n + (uint64_t)kWidePer * kSortThreads - 1) / ((uint64_t)kWidePer * kSortThreads));
+            const uint32_t pw = (uint32_t)(((uint64_t)p.n + kSelectWidePartValues - 1) / kSelectWidePartValues);
             if ((uint64_t)pw * p.k <= kSelectMaxK) {
                 parts = pw;
                 wide = true;
             }
         }
         if (wide) {
-            hipLaunchKernelGGL(pairs_reduce_wide_kernel, dim3(p.q, parts), dim3(kSortThreads), 0, stream, p.vals, p.stride,
-                               p.n_dev, p.n, p.descending, p.k, p.keys, wide_mode == 2);
+            ORAMA_TRY(launch_pairs_reduce_wide(p, parts, wide_mode == 2, stream));
             fin.done = nullptr;  // (never a whole list: the final kernel always orders)
         } else if (p.idx)
             hipLaunchKernelGGL(pairs_reduce_kernel<true>, dim3(p.q, parts), dim3(kSortThreads), 0, stream, p.vals, p.idx, p.stride,
@@ -1640,4 +1653,28 @@ int launch_merge_blocks(orama_ctx* ctx, const void* d_blocks, uint64_t block_str
     return ORAMA_OK;
 }
 
+#else
+// ---- the launchers of this unit's two kernels (select.hpp; called by launch_select of the unit "select")
+static_assert((uint32_t)kWidePer * kSortThreads == kSelectWidePartValues, "select.hpp states what one part of the wide form takes");
+
+int launch_select_tiny(const SelectPlan& p, hipStream_t stream) {
+    PairsFinal fin;
+    fin.id_map = p.id_map;
+    fin.out_idx = p.out_idx;
+    fin.out_ids = p.out_ids;
+    fin.out_val = p.out_val;
+    fin.out_n = p.out_n;
+    hipLaunchKernelGGL(select_tiny_kernel, dim3(p.q), dim3(kSortThreads), 0, stream, p.vals, p.idx, p.stride, p.n_dev, p.n, p.k,
+                       p.descending, fin);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+
+int launch_pairs_reduce_wide(const SelectPlan& p, uint32_t parts, bool force_narrow, hipStream_t stream) {
+    hipLaunchKernelGGL(pairs_reduce_wide_kernel, dim3(p.q, parts), dim3(kSortThreads), 0, stream, p.vals, p.stride, p.n_dev, p.n,
+                       p.descending, p.k, p.keys, force_narrow);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
+#endif
 }  // namespace orama

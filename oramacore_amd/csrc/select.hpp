@@ -55,6 +55,13 @@ int launch_merge_candidates(orama_ctx* ctx, const uint64_t* d_ids, const float* 
                             uint32_t lists, uint32_t q, uint32_t k, uint64_t* d_out_ids,
                             float* d_out_dist, uint32_t* d_out_n, hipStream_t stream);
 
+// The launchers of select_wide.hip's two kernels (round 5; called by launch_select): <= 512 values of every list in one
+// workgroup without a sort; `parts` workgroups per dense list, each taking its <= kSelectWidePartValues values in one round and
+// writing its best k keys to p.keys (launch_select orders them with the final kernel).
+constexpr uint32_t kSelectWidePartValues = 32u * 1024u;
+int launch_select_tiny(const SelectPlan& p, hipStream_t stream);
+int launch_pairs_reduce_wide(const SelectPlan& p, uint32_t parts, bool force_narrow, hipStream_t stream);
+
 // Top-k over lists of 64-bit composite keys (value-key << 32 | ~idx, "larger wins", 0 = empty) — the output
 // of the fused per-wave top-k of K1.  List i = keys + i*stride, n_keys entries.  Reduction: workgroups sort
 // 8192-key chunks in LDS and keep their best k until <= 4096 keys remain, then one workgroup applies the
