@@ -88,3 +88,17 @@ def test_register_budgets_that_buy_a_resident_workgroup():
     for fragment in ("pairs_reduce_kernel", "keys_reduce_kernel", "keys_final_kernel"):
         for k in the(fragment):
             assert k["vgprs"] <= 64 and k["lds_bytes_per_block"] * 2 <= 160 * 1024, k
+
+
+def test_the_rounds_new_selection_kernels_keep_their_own_code_object():
+    """DESIGN §4 K4 "a code object of their own" (profiles/r05_select_unit_split.log): with select_tiny_kernel and
+    pairs_reduce_wide_kernel inside select.hip's code object the key-list kernels of that unit ran 20 % longer (same source, same
+    instruction counts).  A performance fact no parity test sees: the unit layout is asserted here."""
+    _build.build_native()
+    per_unit = _build.kernel_resources()
+    names = lambda unit: [k["name"] for k in per_unit[unit]]
+    assert not any("select_tiny_kernel" in n or "pairs_reduce_wide_kernel" in n for n in names("select"))
+    wide = names("select_wide")
+    assert len(wide) == 2 and any("select_tiny_kernel" in n for n in wide) and any("pairs_reduce_wide_kernel" in n for n in wide)
+    for k in per_unit["select_wide"]:
+        assert k["scratch_bytes_per_lane"] == 0 and k["lds_bytes_per_block"] <= 80 * 1024, k
