@@ -93,11 +93,16 @@ def parse_args():
                          "the other slot's work: +2.4 % at 256 queries per step and +4.1 % at 64 on its own, nothing inside the full bench "
                          "run — profiles/r04_f16_slots_experiment.log; default 1)")
     ap.add_argument("--no-preflight", action="store_true", help="self-launched N > 1: skip the pre-launch check of devices and RCCL")
+    ap.add_argument("--details", action="store_true",
+                    help="the long form: the CPU thread-scaling ladder with NUMA-placed rows and the GRBM_GUI_ACTIVE profiler pass "
+                         "(adds ~15 s; the default run keeps the one-thread oracle, the all-core oracle and a 4-point fast-CPU ladder)")
+    ap.add_argument("--details-file", default=str(ROOT / "bench_details.json"),
+                    help="where the full record goes (the LAST stdout line is only the compact metric line, <= 4 KB)")
     return ap.parse_args()
 
 
 # ---------------------------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(store, dim: int, n_total: int, k: int, sample_rows: int) -> dict:
+def cpu_baseline(store, dim: int, n_total: int, k: int, sample_rows: int, details: bool = False) -> dict:
     """The oracle (C restatement of the reference algorithm — NOT the reference binary) timed on this
     host: sequential-f32 cosine distances over a bounded sample of the same corpus + top-k, single
     thread (the reference runs one search synchronously on one tokio worker) and, for
@@ -123,8 +128,8 @@ def cpu_baseline(store, dim: int, n_total: int, k: int, sample_rows: int) -> dic
                 return sample_rows * passes / el
 
     cores = os.cpu_count() or 1
-    rows_per_s_1 = run(1, 8.0)
-    rows_per_s_all = run(cores, 4.0)
+    rows_per_s_1 = run(1, 8.0 if details else 6.0)
+    rows_per_s_all = run(cores, 4.0 if details else 2.0)
 
     # BASELINE.md §3's "fast CPU" leg: the same scan as a CPU implementation would write it — -O3 -march=native, 8 independent
     # FMA accumulators per row (vectorised), row-parallel — compiled on THIS host (oracle/cpu_fast.py).  Not order-exact
@@ -144,7 +149,8 @@ def cpu_baseline(store, dim: int, n_total: int, k: int, sample_rows: int) -> dic
             if el >= min_seconds and passes >= 3:
                 return sample_rows * passes / el
 
-    ladder = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, 128, cores) if t <= cores})
+    # default run: four points round the thread count that won on every host so far (16-64); --details walks the whole ladder
+    ladder = sorted({t for t in ((1, 2, 4, 8, 16, 32, 64, 128, cores) if details else (1, 16, 32, 64)) if t <= cores})
     scaling = []
     for t in ladder:
         rps = run_fast(t, 2.0 if t == 1 else 1.0)
@@ -152,7 +158,7 @@ def cpu_baseline(store, dim: int, n_total: int, k: int, sample_rows: int) -> dic
     # ... and the same scan over a copy of the sample whose pages were FIRST TOUCHED by the threads that scan them (round 4's
     # ladder fell beyond 16-32 threads: one numpy array, placed by one thread, read across the sockets — VERDICT r04 weak #9)
     placed = []
-    for t in [x for x in ladder if x >= 16][-4:]:
+    for t in ([x for x in ladder if x >= 16][-4:] if details else []):
         with cf.PlacedRows(rows, t) as pr:
             pr.distances(qs[0])
             t0, passes = time.perf_counter(), 0
@@ -169,8 +175,9 @@ def cpu_baseline(store, dim: int, n_total: int, k: int, sample_rows: int) -> dic
         "unit": "queries/s",
         "cores": 1,
         "kind": "port",
+        "sample_rows": sample_rows,
         "sample": f"oracle orc_distances_f32 (scalar, sequential f32) + top-{k} over the first {sample_rows} rows "
-                  f"of the same corpus, repeated >= 8 s; QPS = rows/s / {n_total}",
+                  f"of the same corpus, repeated >= {8 if details else 6} s; QPS = rows/s / {n_total}",
         "gbytes_per_s": rows_per_s_1 * dim * 4 / 1e9,
         "all_cores": {"value": rows_per_s_all / n_total, "cores": cores,
                       "gbytes_per_s": rows_per_s_all * dim * 4 / 1e9},
@@ -892,7 +899,7 @@ def measure_traffic(args, kernel_substr: str, alg_bytes: float) -> dict | None:
     med = {}
     clock = None
     with tempfile.TemporaryDirectory(prefix="orama_pmc_") as tmp:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE") + (("GRBM_GUI_ACTIVE",) if args.details else ()):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, str(Path(__file__).resolve()), "--pmc-child", "--workload", args.workload]
@@ -947,6 +954,104 @@ def committed_traffic(workload: str) -> dict | None:
     return {"traffic": rec.get("traffic_bytes_per_launch"), "traffic_unit": "bytes/launch",
             "traffic_source": f"NOT measured in this run — profiles/{pmc_files[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                               "passes of this command; FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
+
+
+# ---------------------------------------------------------------------------------------------- the metric line
+HEADLINE_BUDGET = 4096  # bytes: the driver keeps a bounded tail of stdout (round 5's 24.9 KB line did not parse)
+
+
+def _r(x, nd=4):
+    """Round floats for the metric line (6 significant figures at most); pass everything else through."""
+    if isinstance(x, float):
+        return float(f"{x:.6g}") if nd is None else round(x, nd)
+    return x
+
+
+def _leg_summary(leg: dict) -> dict:
+    """The five numbers of one extra configuration."""
+    rf = leg.get("roofline") or {}
+    r = {"frac": _r(rf.get("frac")), "kernel": rf.get("kernel")}
+    if rf.get("mfma_frac") is not None:
+        r["mfma_frac"] = _r(rf["mfma_frac"])
+    return {"value": _r(leg.get("value"), None), "ms_per_step": _r(leg.get("ms_per_step")),
+            "latency_ms_p50": _r(leg.get("latency_ms_p50")), "roofline": r}
+
+
+def headline_line(out: dict, details_file: str | None = None) -> dict:
+    """The compact metric line (the LAST line of stdout): the contract's keys, the NS roofline and the CPU baseline as
+    numbers, five numbers per extra configuration.  Everything else — sampler records, notes, traffic sources, the CPU
+    thread ladder, the two-stage leg — is in the details file (and on stderr)."""
+    cfg = out.get("config", {})
+    rf = out.get("roofline", {})
+    line = {k: _r(out.get(k), None) if k == "value" else _r(out.get(k)) for k in (
+        "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "latency_ms_p50", "latency_ms_p95", "latency_samples",
+        "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "rows_total", "rows_per_gpu", "dim", "k", "queries_per_step",
+                                              "parallelism", "valid", "exchange", "comm_world") if k in cfg}
+    if isinstance(cfg.get("ranks_seen"), list):
+        line["config"]["ranks_seen"] = len(cfg["ranks_seen"])
+    line["roofline"] = {k: _r(rf.get(k), None) if k in ("achieved", "traffic") else _r(rf.get(k)) for k in (
+        "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "median_scan_ms_per_step")}
+    if rf.get("traffic_over_algorithmic") is not None:
+        line["roofline"]["traffic_over_algorithmic"] = _r(rf["traffic_over_algorithmic"])
+    if rf.get("mfma_frac") is not None:
+        line["roofline"]["mfma_frac"] = _r(rf["mfma_frac"])
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"], None), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "gbytes_per_s": _r(cb.get("gbytes_per_s"), 2),
+                                "sample": f"oracle scalar cosine + top-k over {cb.get('sample_rows', '1e6')} rows of the corpus, "
+                                          "QPS scaled to the full corpus"}
+        if cb.get("fast"):
+            line["cpu_baseline"]["fast"] = {"value": _r(cb["fast"]["value"], None), "cores": cb["fast"]["cores"],
+                                            "gbytes_per_s": _r(cb["fast"].get("gbytes_per_s"), 2)}
+    legs = {name: _leg_summary(leg) for name, leg in (out.get("configs") or {}).items()}
+    c4 = (out.get("configs") or {}).get("c4") or {}
+    if c4.get("bm25_only"):
+        b = c4["bm25_only"]
+        legs["bm25_batch"] = {"value": _r(b.get("value"), None), "unit": b.get("unit"),
+                              "roofline": {"frac": _r((b.get("roofline") or {}).get("frac")),
+                                           "kernel": (b.get("roofline") or {}).get("kernel")},
+                              "us_per_query_device": _r((b.get("roofline") or {}).get("device_us_per_query"), 3),
+                              "single_calls_per_s": _r((b.get("single_query_calls") or {}).get("value"), None)}
+    if c4.get("shadow_store"):
+        legs["c4_shadow"] = {"value": _r(c4["shadow_store"].get("value"), None),
+                             "latency_ms_p50": _r(c4["shadow_store"].get("latency_ms_p50"))}
+    ts = out.get("two_stage_exact")
+    if ts:
+        legs["two_stage_exact"] = {"value": _r(ts.get("value"), None), "identical_to_fp32_scan": ts.get("identical_to_fp32_scan")}
+    if legs:
+        line["configs"] = legs
+    sb = out.get("step_breakdown_us")
+    if sb:
+        line["step_breakdown_us"] = {k: _r(sb.get(k), 1) for k in ("scan", "select", "all_gather", "merge_k6")}
+    line["parity_check"] = "ok" if out.get("parity_check") else None
+    if "error" in out:
+        line["error"] = str(out["error"])[:300]
+    if details_file:
+        line["details"] = os.path.basename(details_file)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= HEADLINE_BUDGET:
+        # shed the optional parts, largest first, until the line fits: the contract keys never go
+        for victim in ("step_breakdown_us", "configs"):
+            line.pop(victim, None)
+            if len(json.dumps(line, separators=(",", ":"))) < HEADLINE_BUDGET:
+                break
+    assert len(json.dumps(line, separators=(",", ":"))) < HEADLINE_BUDGET, "bench.py: the metric line outgrew its budget"
+    return line
+
+
+def emit(out: dict, details_file: str) -> None:
+    """Full record -> the details file and stderr; compact line -> the LAST line of stdout."""
+    try:
+        Path(details_file).write_text(json.dumps(out, indent=1) + "\n")
+    except OSError as e:  # a read-only checkout must not cost the metric line
+        print(f"bench.py: could not write {details_file}: {e}", file=sys.stderr)
+        details_file = None
+    print(json.dumps(out), file=sys.stderr, flush=True)
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    print(json.dumps(headline_line(out, details_file), separators=(",", ":")), flush=True)
 
 
 # ---------------------------------------------------------------------------------------------- main
@@ -1023,7 +1128,7 @@ def main():
     if solo:
         out.update(host_api_latency(store, queries_h, qb, k))  # adds the PCIe hop for the query and the k results
         if not args.no_cpu_baseline and not f16:
-            out["cpu_baseline"] = cpu_baseline(store, dim, n_total, k, args.cpu_sample_rows)
+            out["cpu_baseline"] = cpu_baseline(store, dim, n_total, k, args.cpu_sample_rows, details=args.details)
         want = EXTRA_CONFIGS if args.configs == "all" else () if args.configs == "none" else tuple(
             c for c in args.configs.split(",") if c)
         configs = {}
@@ -1089,12 +1194,9 @@ def main():
             out["roofline"]["traffic_reference"] = t
     if rank == 0:
         out["device"] = device_name
-        # RCCL writes its version banner through C stdio (fully buffered when stdout is a pipe): push it out first
-        # so that the JSON line is the LAST line of stdout
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        # RCCL writes its version banner through C stdio (fully buffered when stdout is a pipe): emit() pushes it out first
+        # so that the compact JSON line is the LAST line of stdout
+        emit(out, args.details_file)
 
 
 if __name__ == "__main__":

@@ -31,11 +31,16 @@ N_TOTAL = 10_000_000
 
 
 def run(cmd, env, timeout=900):
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=str(ROOT))
-    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
-    if r.returncode != 0 or not lines:
-        return {"error": f"rc {r.returncode}", "stdout": r.stdout[-1500:], "stderr": r.stderr[-1500:]}
-    return json.loads(lines[-1])
+    """One bench.py job; returns its LONG record (the details file — the last stdout line is the compact metric line)."""
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="orama_scale_") as tmp:
+        details = Path(tmp) / "details.json"
+        r = subprocess.run([*cmd, "--details-file", str(details)], env=env, capture_output=True, text=True, timeout=timeout, cwd=str(ROOT))
+        lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines or not details.exists():
+            return {"error": f"rc {r.returncode}", "stdout": r.stdout[-1500:], "stderr": r.stderr[-1500:]}
+        assert len(lines[-1]) < 4096, "bench.py's metric line outgrew its budget"
+        return json.loads(details.read_text())
 
 
 def slim(line):

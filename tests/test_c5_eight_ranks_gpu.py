@@ -41,11 +41,18 @@ def test_c5_eight_rank_job_over_the_loopback_transport(ctx, tmp_path):
         env.pop(v, None)
     dump = tmp_path / "c5"
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(G), "--workload", "c5", "--steps", "3", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-pmc", "--dump-result", str(dump)],
+                        "--no-cpu-baseline", "--no-pmc", "--dump-result", str(dump),
+                        "--details-file", str(tmp_path / "details.json")],
                        env=env, capture_output=True, text=True, timeout=1500, cwd=str(ROOT))
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
-    line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert "error" not in line, line
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096, len(last)  # the metric line of an N > 1 job obeys the same budget as the N = 1 one
+    compact = json.loads(last)
+    assert "error" not in compact, compact
+    assert compact["n_gpus"] == G and compact["config"]["ranks_seen"] == G and compact["config"]["comm_world"] == G
+    assert compact["roofline"]["frac"] > 0 and compact["value"] > 0
+    line = json.loads((tmp_path / "details.json").read_text())  # the long form: who was in the job, spans, samples
+    assert abs(line["value"] - compact["value"]) / line["value"] < 1e-5
     assert line["n_gpus"] == G and line["config"]["comm_world"] == G and line["config"]["valid"] is True
     assert line["config"]["rows_total"] == N_TOTAL and line["config"]["rows_per_gpu"] == N_TOTAL // G
     seen = line["config"]["ranks_seen"]
