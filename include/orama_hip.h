@@ -129,6 +129,13 @@ int orama_ctx_set_bm25_ranges(orama_ctx* ctx, int on);
  * least 4 GB of fp32 rows: below that the plain scan is faster than the second stage's launches), 2 = always two stages,
  * 0 = always the plain fp32 scan.  Same results in every mode. */
 int orama_ctx_set_two_stage(orama_ctx* ctx, int on);
+/* Plain fp32 stores (the reference's own dtype: Vec<f32> rows, embedding_field.rs:66,88,232-237): batches of at least
+ * `min_queries` concurrent queries share corpus passes of <= 32 queries on the matrix cores (K1m, vec_f32_mfma.hip:
+ * v_mfma_f32_32x32x2_f32 — f32 in, f32 accumulate, exact) with a per-query threshold filter instead of one dense distance
+ * array per query; smaller batches take K1 / K1b (<= 8 queries per pass, VALU).  Default 9; 0 = never.  Cosine stores whose
+ * dimension is a multiple of 32 and <= 864 (the query tile lives in LDS); everything else keeps K1 / K1b.  The distance of a
+ * (row, query) pair does not depend on the batch it was asked in (one fixed fmaf chain per pair). */
+int orama_ctx_set_f32_batch(orama_ctx* ctx, int min_queries);
 
 /* Per-kernel HIP-event timing (used by bench.py's roofline leg).  When enabled, the library
  * brackets each launch of the named hot kernels with hipEvents on the launching stream.

@@ -541,6 +541,13 @@ int orama_stream_synchronize(orama_ctx* ctx, void* stream) {
     return ORAMA_OK;
 }
 
+int orama_ctx_set_f32_batch(orama_ctx* ctx, int min_queries) {
+    ORAMA_REQUIRE(ctx, "null context");
+    ORAMA_REQUIRE(min_queries >= 0 && min_queries <= 4096, "f32 batch threshold %d outside [0, 4096]", min_queries);
+    ctx->f32_mfma_min_q = (uint32_t)min_queries;
+    return ORAMA_OK;
+}
+
 int orama_ctx_set_two_stage(orama_ctx* ctx, int on) {
     ORAMA_REQUIRE(ctx, "null context");
     ORAMA_REQUIRE(on >= 0 && on <= 2, "two-stage mode %d outside [0, 2]", on);

@@ -1,0 +1,41 @@
+// vec_f32_mfma.hpp — K1m: batched-query cosine scan over the PLAIN fp32 store on the gfx950 matrix cores
+// (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, exact — one fmaf chain per (row, query)).
+// north_star: "MFMA-backed batched-query x corpus GEMM when Q>1" for the reference's own dtype
+// (Vec<f32> rows, src/collection_manager/sides/read/index/embedding_field.rs:66,88,250-278).
+#pragma once
+
+#include "common.hpp"
+#include "vec_f16.hpp"  // F16ScanArgs: the same dense-head / threshold-filter interface as K2 (a.tiled = the f32 row-major rows)
+
+namespace orama {
+
+constexpr uint32_t kF32MfmaMaxQ = 32;       // one 32-column MFMA tile of queries per corpus pass
+constexpr uint32_t kF32MfmaChunk = 32;      // floats of every row a wave moves per chunk (32 rows x 128 B = 4 KiB)
+constexpr uint32_t kF32MfmaWaves = 8;       // waves per workgroup (one workgroup per CU: the queries take most of the LDS)
+constexpr uint32_t kF32MfmaRing = 6;        // chunks in the register ring (5 in flight while one is multiplied)
+// rows a search may read past the published count: a partial last tile is read whole (its rows beyond row_end are masked
+// in the epilogue), so the f32 arrays carry one tile of slack (vec_store.hip: matrix_bytes / norm_bytes)
+constexpr uint64_t kF32MfmaSlackRows = 32;
+
+// LDS: the queries as B fragments ((dim / 8) KiB: [k / 8][lane = (k-half, query)][4 floats]), 32 x 1/|q|, and per wave a
+// 4-KiB transposer, the ring of metadata records, a 64-bin histogram and the staging area of passing rows.
+inline size_t vec_scan_f32_mfma_lds_bytes(uint32_t dim, uint32_t stage_entries) {
+    return (size_t)(dim / 8) * 1024 + 64 * sizeof(float) +
+           kF32MfmaWaves * (4096 + (size_t)(kF32MfmaRing + 1) * kF16MetaBytes + 256 + 3 * (size_t)stage_entries * sizeof(uint32_t));
+}
+inline uint32_t vec_scan_f32_mfma_stage_entries(uint32_t dim) {
+    const size_t fixed = vec_scan_f32_mfma_lds_bytes(dim, 0);
+    if (fixed >= kF16LdsLimit) return 0;
+    const size_t e = ((kF16LdsLimit - fixed) / (kF32MfmaWaves * 3 * sizeof(uint32_t))) & ~(size_t)63;
+    return e < 128 ? 0u : (uint32_t)(e > 1024 ? 1024 : e);
+}
+// cosine, rows of whole chunks whose query tile leaves room for the staging areas (dim <= 896 in 160 KiB of LDS)
+inline bool vec_scan_f32_mfma_supports(uint32_t dim, int metric) {
+    return metric == ORAMA_METRIC_COSINE && dim >= kF32MfmaChunk && dim % kF32MfmaChunk == 0 && vec_scan_f32_mfma_stage_entries(dim) >= 128;
+}
+
+// K1m.  a.tiled = the fp32 rows (row-major, [n][dim]); a.q <= 32; dense or filter mode as launch_vec_scan_f16.
+// Algorithmic HBM traffic: (row_end - row_begin) * dim * 4 bytes per launch (serves all q queries).
+int launch_vec_scan_f32_mfma(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream);
+
+}  // namespace orama

@@ -20,6 +20,7 @@
 #include "device_utils.hpp"
 #include "select.hpp"
 #include "vec_f16.hpp"
+#include "vec_f32_mfma.hpp"
 #include "vec_internal.hpp"
 #include "stage.hpp"
 #include "vec_kernels.hpp"
@@ -257,12 +258,14 @@ struct orama_vec {
 
     bool f16() const { return dtype == ORAMA_DTYPE_F16; }
     size_t row_bytes() const { return (size_t)dim * sizeof(float); }  // f32 row (host side / f32 store)
+    // (f32: one 32-row tile of slack behind the rows and their norms — K1m reads a partial last tile whole and masks the
+    // rows beyond the published count in its epilogue, vec_f32_mfma.hpp)
     size_t matrix_bytes(uint64_t rows_) const {
-        return f16() ? (size_t)(f16_tiles(rows_) * f16_tile_bytes(dim)) : (size_t)rows_ * row_bytes();
+        return f16() ? (size_t)(f16_tiles(rows_) * f16_tile_bytes(dim)) : (size_t)(rows_ + kF32MfmaSlackRows) * row_bytes();
     }
     size_t norm_bytes(uint64_t rows_) const {
         // f16: K2c / K2d fetch the inverse norms of a block tile with one 1-KiB DMA — pad to whole block tiles
-        return (size_t)(f16() ? ((rows_ + 255) & ~255ull) + 256 : rows_) * sizeof(float);
+        return (size_t)(f16() ? ((rows_ + 255) & ~255ull) + 256 : rows_ + kF32MfmaSlackRows) * sizeof(float);
     }
 };
 
@@ -313,8 +316,9 @@ int grow(orama_vec* v, uint64_t need_rows, hipStream_t s) {
         const uint64_t nf = v->inv_norm.mapped / 4;
         c = std::min<uint64_t>(c, nf > 512 ? (nf - 256) & ~255ull : 0);
     } else {
-        c = std::min<uint64_t>(c, v->rows.mapped / v->row_bytes());
-        c = std::min<uint64_t>(c, v->inv_norm.mapped / 4);
+        const uint64_t rm = v->rows.mapped / v->row_bytes(), nm = v->inv_norm.mapped / 4;
+        c = std::min<uint64_t>(c, rm > kF32MfmaSlackRows ? rm - kF32MfmaSlackRows : 0);
+        c = std::min<uint64_t>(c, nm > kF32MfmaSlackRows ? nm - kF32MfmaSlackRows : 0);
     }
     ORAMA_REQUIRE(c >= need_rows, "internal: capacity %llu below the %llu rows asked for", (unsigned long long)c,
                   (unsigned long long)need_rows);
@@ -462,10 +466,26 @@ int tail_end(Scratch* sc, hipStream_t s_scan, hipStream_t s) {
     return ORAMA_OK;
 }
 
+int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
+                       const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
+                       uint32_t* d_out_n, hipStream_t s, uint32_t* d_out_rows = nullptr, uint32_t* d_inexact = nullptr,
+                       bool f32_rows = false);
+
+// K1m applies: a batch of at least ctx->f32_mfma_min_q queries over cosine rows of whole 32-float chunks whose query tile fits LDS
+bool f32_batch_on_mfma(const orama_vec* v, uint32_t q, uint32_t k) {
+    return v->ctx->f32_mfma_min_q && q >= v->ctx->f32_mfma_min_q && k <= kSelectMaxK && vec_scan_f32_mfma_supports(v->dim, v->metric);
+}
+
 int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
                        uint32_t* d_out_n, hipStream_t s, hipStream_t s_scan) {
     const uint64_t n = w.n_rows;
+    if (f32_batch_on_mfma(v, q, k)) {
+        // the batch shares corpus passes of <= 32 queries on the matrix cores, K2's pipeline behind them (dense head ->
+        // thresholds -> filter scan -> candidate lists): scans and selections depend on each other both ways, one stream
+        return search_enqueue_f16(v, w, sc, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, s, nullptr, nullptr,
+                                  /*f32_rows=*/true);
+    }
     // fused_topk: 1 = always, 0 = never, 2 (default) = for ONE query over a large corpus: the dense path writes and
     // re-reads 4 B per row for K4 (40 MB at 10 M rows) and K1b does not apply to a single query — measured at NS
     // 4.51 -> 4.32 ms per scan (85 -> 89 % of the HBM roofline); on a 1 M x 384 corpus the per-wave lists and their
@@ -575,12 +595,13 @@ int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_
 //   3. the last reduction also maps rows → DocumentIds and applies the final tie order.
 // Scores are never materialised for more than S1 rows; HBM traffic beyond the corpus pass is the
 // candidate appends (expected k·ln(N/S1) per query on unordered data).
+// `f32_rows`: the rows are the plain fp32 store's (row-major f32) and the scan is K1m, <= 32 queries per pass.
 int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
-                       uint32_t* d_out_n, hipStream_t s, uint32_t* d_out_rows = nullptr, uint32_t* d_inexact = nullptr) {
+                       uint32_t* d_out_n, hipStream_t s, uint32_t* d_out_rows, uint32_t* d_inexact, bool f32_rows) {
     const uint64_t n = w.n_rows;
     if (d_inexact) ORAMA_HIP_TRY(hipMemsetAsync(d_inexact, 0, (size_t)q * 4, s));
-    if (d_out_rows && q == 1 && v->ctx->f16_solo == 2 && (d_inexact || k <= kF16WaveListKeys)) {
+    if (!f32_rows && d_out_rows && q == 1 && v->ctx->f16_solo == 2 && (d_inexact || k <= kF16WaveListKeys)) {
         // candidate stage of the two-stage plan for ONE query: K1h keeps every wave's best k rows in registers — one
         // launch over the store + the key reduction, instead of dense head, selection, filter scan, selection
         F16ScanArgs fa;
@@ -619,11 +640,12 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
     const uint32_t kpad_k = f16_kpad(v->dim);
     for (uint32_t q0 = 0; q0 < q;) {
         // <= 64 queries: K2 (whole batch as LDS-resident B fragments); more: K2c (GEMM-tiled, <= 256 per pass)
-        const bool wide = v->ctx->f16_wide && (q - q0) > kF16MaxQ && (kpad_k / 16) % 2 == 0;
-        const uint32_t gq = std::min<uint32_t>(wide ? kF16WideMaxQ : vec_scan_f16_max_q(v->dim), q - q0);
+        const bool wide = !f32_rows && v->ctx->f16_wide && (q - q0) > kF16MaxQ && (kpad_k / 16) % 2 == 0;
+        const uint32_t gq = std::min<uint32_t>(f32_rows ? kF32MfmaMaxQ : wide ? kF16WideMaxQ : vec_scan_f16_max_q(v->dim), q - q0);
         if (wide) ORAMA_TRY(sc->f16_bfrag.reserve(f16_wide_query_bytes(v->dim)));
         bool wide_prepared = false;
         auto scan = [&](const F16ScanArgs& args) -> int {
+            if (f32_rows) return launch_vec_scan_f32_mfma(v->ctx, args, s);
             if (!wide) return launch_vec_scan_f16(v->ctx, args, s);
             if (!wide_prepared)
                 ORAMA_TRY(launch_f16_prepare_queries(args.queries, args.q, args.dim, args.metric, sc->f16_bfrag.p, s));
@@ -687,7 +709,7 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
         a.dead = w.dead;
         a.allow = d_allow;
         a.allow_bits = allow_bits;
-        a.solo = d_out_rows != nullptr && v->ctx->f16_solo;  // the shadow stage of the two-stage plan
+        a.solo = !f32_rows && d_out_rows != nullptr && v->ctx->f16_solo;  // the shadow stage of the two-stage plan
         // ORAMA_F16_TAU_ORACLE=1, the CEILING of any threshold exchange between shards (scripts/
         // f16_tau_ceiling_probe.py): the filter passes run under the final k-th distances the PREVIOUS call of this scratch set
         // left behind (one ulp up) — exact only when that call asked the same queries, which the probe does

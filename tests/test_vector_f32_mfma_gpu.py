@@ -1,0 +1,149 @@
+"""GPU parity of K1m: batches of >= 9 queries over the PLAIN fp32 store on the matrix cores (v_mfma_f32_32x32x2_f32,
+csrc/vec_f32_mfma.hip) — north_star's "MFMA-backed batched-query x corpus GEMM when Q>1" for the reference's own dtype
+(embedding_field.rs:66,88,250-278: Vec<f32> rows, cosine).
+
+The bar: distances within 1e-4 of the oracle evaluated on the stored rows, id sets equal under the tie-aware checker
+(util.assert_topk_sound), and — because the MFMA accumulates one fixed fmaf chain per (row, query) — answers that do not
+depend on the batch a query was asked in, bit for bit.
+"""
+import numpy as np
+import pytest
+
+import oramacore_amd as oa
+import util
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def make_store(ctx, corpus, row_doc=None):
+    n, d = corpus.shape
+    st = oa.EmbeddingFieldStorage(ctx, dimensions=d)
+    ids = np.arange(n, dtype=np.uint64) if row_doc is None else row_doc
+    assert st.insert_rows(ids, corpus) == n
+    return st
+
+
+def check(st, corpus, queries, k, allow=None, dead_rows=None, what=""):
+    ids, dist, cnt = st.storage_search(queries, k, allow)
+    for qi in range(queries.shape[0]):
+        full = orc.distances(corpus, queries[qi]).astype(np.float64)
+        if dead_rows is not None:
+            full[dead_rows] = np.nan
+        if allow is not None:
+            mask = np.array([allow.contains(int(d)) for d in range(corpus.shape[0])])
+            full[~mask] = np.nan
+        m = int(cnt[qi])
+        util.assert_topk_sound(ids[qi, :m], dist[qi, :m], full, k, TOL, f"{what} q{qi}")
+    return ids, dist, cnt
+
+
+@pytest.mark.parametrize("d", [32, 384, 768, 864])
+@pytest.mark.parametrize("nq", [9, 17, 32, 33, 70])
+def test_head_only_batches(ctx, d, nq):
+    """N below the dense head, a ragged last tile (n % 32 != 0): one and several passes of <= 32 queries, ragged query tiles."""
+    n = 3000 + d + 7
+    corpus = util.gaussian_rows(n, d, seed=d)
+    queries = util.gaussian_rows(nq, d, seed=d + nq)
+    st = make_store(ctx, corpus)
+    check(st, corpus, queries, 100, what=f"d={d} nq={nq}")
+    st.close()
+
+
+def test_filter_path_random_and_adversarial_order(ctx):
+    """N above the dense head (131072 rows): the rest goes through the threshold filter; then a corpus ordered by INCREASING
+    similarity to query 0 (every later row beats the running threshold: the candidate lists' worst case)."""
+    n, d, k = 200_003, 384, 100
+    corpus = util.gaussian_rows(n, d, seed=7)
+    queries = util.gaussian_rows(32, d, seed=8)
+    st = make_store(ctx, corpus)
+    check(st, corpus, queries, k, what="random order")
+    check(st, corpus, queries[:9], 7, what="random order small k")
+    st.close()
+    sim = corpus @ queries[0] / np.linalg.norm(corpus, axis=1)
+    order = np.argsort(sim, kind="stable")
+    corpus2 = np.ascontiguousarray(corpus[order])
+    st = make_store(ctx, corpus2)
+    check(st, corpus2, queries[:9], k, what="adversarial order")
+    st.close()
+
+
+def test_same_bits_in_every_batch(ctx):
+    """One fixed fmaf chain per (row, query): a query's answer is the same bits alone in a batch of 9 (padded by other
+    queries), in a full tile of 32, across a pass boundary (position 40 of 70) — ids, distances and counts."""
+    n, d, k = 150_000, 768, 100
+    corpus = util.gaussian_rows(n, d, seed=31)
+    queries = util.gaussian_rows(70, d, seed=32)
+    st = make_store(ctx, corpus)
+    i70, d70, c70 = st.storage_search(queries, k)
+    i32, d32, c32 = st.storage_search(queries[:32], k)
+    assert np.array_equal(i70[:32], i32) and np.array_equal(d70[:32].view(np.uint32), d32.view(np.uint32)) and np.array_equal(c70[:32], c32)
+    sel = np.array([40, 3, 69, 11, 12, 13, 14, 15, 16])
+    i9, d9, c9 = st.storage_search(queries[sel], k)
+    assert np.array_equal(i9, i70[sel]) and np.array_equal(d9.view(np.uint32), d70[sel].view(np.uint32)) and np.array_equal(c9, c70[sel])
+    # ... and within 1e-4 of what K1 / K1b answer for the same queries (another summation order), same id sets up to ties
+    st.ctx.set_f32_batch(0)
+    try:
+        ik, dk, ck = st.storage_search(queries[:16], k)
+    finally:
+        st.ctx.set_f32_batch(9)
+    assert np.array_equal(ck, c70[:16]) and np.max(np.abs(dk - d70[:16])) <= TOL
+    for j in range(16):
+        diff = set(ik[j].tolist()) ^ set(i70[j].tolist())
+        if diff:  # only rows at the k-th distance may differ
+            kth = d70[j, k - 1]
+            full = orc.distances(corpus[sorted(diff)], queries[j])
+            assert np.all(np.abs(full - kth) <= 2 * TOL), (j, diff)
+    st.close()
+
+
+def test_deletes_filter_and_compaction(ctx):
+    n, d, k = 140_000, 384, 50
+    corpus = util.gaussian_rows(n, d, seed=17)
+    queries = util.gaussian_rows(12, d, seed=18)
+    st = make_store(ctx, corpus)
+    dead = np.array([3, 64, 65, 131071, 131072, 139_999], dtype=np.int64)
+    for r in dead:
+        st.delete(int(r))
+    allow = oa.AllowBitmap.from_mask(np.arange(n) % 3 != 0)
+    check(st, corpus, queries, k, dead_rows=dead, what="dead")
+    check(st, corpus, queries, k, allow=allow, dead_rows=dead, what="dead+filter")
+    before = st.storage_search(queries, k)
+    st.compact(3)
+    assert st.info()["num_rows"] == n - len(dead) and not st.has_pending_ops()
+    after = st.storage_search(queries, k)
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1].view(np.uint32), after[1].view(np.uint32))
+    st.close()
+
+
+def test_growth_and_appends_keep_the_tail_tile_right(ctx):
+    """Rows appended in odd-sized blocks (the store grows in place; a partial last tile is read whole and masked): every prefix
+    answers like a fresh store of the same rows."""
+    d, k = 384, 20
+    corpus = util.gaussian_rows(9000, d, seed=41)
+    queries = util.gaussian_rows(10, d, seed=42)
+    st = oa.EmbeddingFieldStorage(ctx, dimensions=d)
+    at = 0
+    for step in (1, 30, 33, 1000, 4097, 3839):
+        st.insert_rows(np.arange(at, at + step, dtype=np.uint64), corpus[at:at + step])
+        at += step
+        check(st, corpus[:at], queries, k, what=f"rows={at}")
+    st.close()
+
+
+def test_unsupported_shapes_keep_the_valu_path(ctx):
+    """L2 stores, dimensions that are not whole chunks or whose query tile does not fit LDS: K1 / K1b answer as before."""
+    for d, metric in ((100, None), (1024, None), (384, "l2")):
+        n = 5000
+        corpus = util.gaussian_rows(n, d, seed=d)
+        queries = util.gaussian_rows(12, d, seed=d + 1)
+        kw = {"metric": oa.METRIC_L2SQ} if metric else {}
+        st = oa.EmbeddingFieldStorage(ctx, dimensions=d, **kw)
+        st.insert_rows(np.arange(n, dtype=np.uint64), corpus)
+        ids, dist, cnt = st.storage_search(queries, 10)
+        for j in range(12):
+            full = (orc.distances(corpus, queries[j]) if not metric else
+                    ((corpus.astype(np.float64) - queries[j].astype(np.float64)) ** 2).sum(axis=1)).astype(np.float64)
+            util.assert_topk_sound(ids[j, :cnt[j]], dist[j, :cnt[j]], full, 10, 1e-3 if metric else TOL, f"d={d} {metric} q{j}")
+        st.close()
