@@ -392,6 +392,20 @@ struct PostingList {
 // (token index, posting list, field boost) — SearchParams.boost, token_score.rs:234-238
 using TermRef = orama_term_ref;
 
+// The exact-match factor the third-party string store folds into ntf (token_score.rs:182-185, 226-228, 268-269).  Its value is
+// not in the reference checkout (oramacore_fields 0.2.0 is un-vendored); boost_integration.rs:449-491 pins only that it is > 1.
+// 1.5 is a PLACEHOLDER: the shim passes AcceleratorConfig.exact_match_boost, read from
+// oramacore_fields::string::SearchParams' implementation when the crate is available.  1.0 = no factor.
+constexpr float kDefaultExactMatchBoost = 1.5f;
+
+// The reference of one (query token, posting list) pair as the kernels take it: the field boost times the exact-match factor
+// when the list's dictionary term IS the query token (prefix / Levenshtein expansions keep 1.0) — one f32 product, as in
+// oramacore_amd/token_score.py::TokenScoreContext._refs.
+inline TermRef term_ref(uint32_t token, uint32_t list, float field_boost, bool term_is_token,
+                        float exact_match_boost = kDefaultExactMatchBoost) {
+    return TermRef{token, list, term_is_token && exact_match_boost != 1.0f ? field_boost * exact_match_boost : field_boost};
+}
+
 struct FullTextParams {            // what search_full_text derives (token_score.rs:186-302)
     uint32_t n_tokens = 1;
     float total_documents = 1.0f;  // the index's document_count (:221)

@@ -372,7 +372,11 @@ int orama_post_info(orama_post* p, uint64_t* n_docs, uint32_t* n_lists, uint64_t
 int orama_post_set_omc(orama_post* p, const uint64_t* omc_doc, const float* omc_mul, uint64_t n);
 
 /* One (token, list) reference of a query: token `token` expands to posting list `list`
- * scored with field boost `boost` (SearchParams.boost, token_score.rs:234-238). */
+ * scored with `boost` = the field boost (SearchParams.boost, token_score.rs:234-238) TIMES the exact-match factor of the
+ * third-party string store when the list's dictionary term is the query token itself (token_score.rs:182-185, 226-228: "ntf
+ * already includes boost + length normalization + exact_match_boost").  The factor's value lives in oramacore_fields 0.2.0, not in
+ * the reference checkout; boost_integration.rs:449-491 pins that it is > 1.  The library takes the product as given: the caller
+ * (the Rust shim: AcceleratorConfig.exact_match_boost; include/orama/host.hpp orama::term_ref; the Python mirror) applies it. */
 typedef struct {
     uint32_t token;
     uint32_t list;

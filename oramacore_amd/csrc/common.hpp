@@ -207,6 +207,9 @@ struct Scratch {
     DevBuf f16_tau_cap;  // ORAMA_F16_TAU_ORACLE=1 (experiment): the previous call's final k-th distances
     uint32_t f16_tau_cap_q = 0, f16_tau_cap_k = 0;
     DevBuf misc0, misc1, misc2, misc3, misc4, misc5;
+    // fp32 batches on the matrix cores (vec_store.hip search_enqueue_f32_batch): the candidate stage's answers + the exact
+    // distances of the candidates, and the list sets / answers of the device-side fallback for unproven queries
+    DevBuf mfma_cand, mfma_fb_lists, mfma_fb_tmp, mfma_fb_out;
     PinnedBuf h_in, h_out, h_misc;
     // BM25 accumulators: epoch-stamped, zeroed only when (re)allocated (see bm25_kernels.hip)
     DevBuf bm25_acc, bm25_emit;

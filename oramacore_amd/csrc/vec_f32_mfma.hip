@@ -5,24 +5,29 @@
 // Vec<Vec<f32>>) — so, unlike K2's fragment-tiled fp16 store, the HBM layout is NOT the operand layout of
 // v_mfma_f32_32x32x2_f32 (lane = row, one float per lane and k): a wave
 //   1. streams its 32-row tile in chunks of 32 floats per row with FULL-LINE loads (one global_load_dwordx4 moves 8 rows x
-//      128 B: lane l holds floats 4 (l & 7) .. +3 of row l >> 3) into a register ring — 5 chunks = 20 KiB per wave in
-//      flight, 160 KiB per CU, no LDS reserved for data that has not arrived;
+//      128 B: lane l holds floats 4 (l & 7) .. +3 of row l >> 3) into a register ring — 4 chunks of 4 KiB per wave, 3-4 in
+//      flight, no LDS reserved for data that has not arrived;
 //   2. turns a landed chunk through a 4-KiB LDS transposer of its own (ds_write_b128 / ds_read_b128, XOR-swizzled by
-//      (row >> 1) & 7 so that both directions are bank-conflict free — MI355X_MICROARCH.md §LDS lane groups) into A
-//      fragments: lane (h = l >> 5, r = l & 31) receives floats 8c + 4h .. +3 of row r for c = 0..3;
+//      (row >> 1) & 7 so that both directions are bank-conflict free — MI355X_MICROARCH.md §LDS lane groups; measured:
+//      SQ_LDS_BANK_CONFLICT 19 K cycles of 480 M active) into A fragments: lane (h = l >> 5, r = l & 31) receives floats
+//      8c + 4h .. +3 of row r for c = 0..3;
 //   3. multiplies them against the query fragments that sit in LDS in the same k order ([k / 8][lane = (h, query)][4 floats],
 //      lane-linear ds_read_b128): MFMA e of step c consumes k = 8c + e (h = 0) and k = 8c + 4 + e (h = 1) of both operands —
 //      any k order is a valid dot product as long as A and B agree, and it is FIXED, so the distance of a (row, query) pair
 //      does not depend on the batch it was asked in;
 //   4. applies K2's epilogue on the accumulator registers (1 - s / (|x||q|), tombstones, per-query threshold test, passing
 //      rows staged in LDS and appended to the candidate lists in bulk).
+// Steps 2 (for chunk g + 1) and 3 (for chunk g) are ONE straight-line block in which every matrix instruction is followed by
+// one memory operation of the other chunk (sched_group_barrier): a wave issues in order, and anything that can wait — the
+// vmcnt for a landed chunk, an LDS round trip — must not stand in front of matrix instructions that are ready.
 // No inter-wave synchronisation after the prologue: a wave's LDS operations execute in order, the transposer is private.
 //
-// Roofline: HBM — but only just.  One v_mfma_f32_32x32x2_f32 takes 64 cycles of a SIMD's matrix pipe (16 per CU) for 32 rows
-// x 2 k = 256 B of corpus: 16 B per clock per CU = 8.2 TB/s at 2.0 GHz over 256 CUs, against an HBM peak of 8.0 TB/s.  At 32
-// queries the matrix pipe must be ~85-100 % busy to keep up with the memory system; fewer queries do not make it cheaper (the
-// instruction computes all 32 columns).  Algorithmic bytes = rows x dim x 4 per launch.  mfma_frac is quoted against the
-// 157.3 TF f32-input peak (MI355X_MICROARCH.md).
+// Roofline: the f32 MATRIX PIPE at 32 queries, HBM below that only on paper.  One v_mfma_f32_32x32x2_f32 takes 64 cycles of a
+// SIMD's matrix pipe for 32 rows x 2 k = 256 B of corpus whatever the number of live query columns: 16 B per clock per CU =
+// 7.4 M cycles for 10 M x 768 — 3.1 ms at the 2.4 GHz the data sheet's 157.3 TF assumes, 4.1-4.4 ms at the 1.67-1.82 GHz the
+// package's power limit leaves this kernel (0.96-1.22 kW, PPT residency 85-100 %: profiles/r06_k1m_*.log), against 3.84 ms
+// of HBM time.  Measured 5.33-5.50 ms per pass = 76-80 % of the matrix pipe at the clock it ran at, 0.70-0.72 of the HBM peak.
+// `roofline` quotes both; algorithmic bytes = rows x dim x 4 per launch, flops = 2 x 32 x rows x dim.
 #include "vec_f32_mfma.hpp"
 
 #include <cstdlib>
@@ -47,10 +52,16 @@ using f16async::wave_or_u32;
 
 constexpr int kBlock = (int)kF32MfmaWaves * 64;
 constexpr int kWavesPerBlock = (int)kF32MfmaWaves;
-constexpr int NBUF = (int)kF32MfmaRing;
 constexpr int kLoads = 4;  // global_load_dwordx4 per chunk (8 rows x 128 B each)
 
-template <bool DENSE>
+// NBUF: chunks in the register ring.  BDBL: all four query fragments of a chunk are fetched a chunk ahead (16 more registers)
+// instead of one step ahead.  (Measured in one lease, profiles/r06_k1m_variants_ab*.log: rings of 4 / 6 / 8 chunks, either
+// fragment schedule, and loads issued as pairs of chunks — 256 contiguous bytes of a row at a time — all land within 2 % of each
+// other: the kernel is bound by the matrix pipe at the clock the package's power limit leaves, not by what is in flight.  The
+// pair form is gone; 4 chunks + fragments a chunk ahead is the default.)
+// ABL (comparison builds): timing ablations with wrong answers — 16 no matrix instructions, 128 half of them, 64 no HBM traffic
+// (every load re-reads the wave's first chunk: L2 hits).  Compile-time: a run-time test would split the ring's straight-line trips.
+template <bool DENSE, int NBUF, bool BDBL, int ABL = 0>
 __global__ __launch_bounds__(kBlock) void vec_scan_f32_mfma_kernel(F16ScanArgs a, uint32_t nc /* chunks per row = dim / 32 */,
                                                                     uint64_t tile_bytes /* 32 rows */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -103,14 +114,15 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f32_mfma_kernel(F16ScanArgs a
 
     // per-wave LDS: transposer | metadata ring | histogram | staging area
     const uint32_t wave_in_block = uniform_u32((uint32_t)tid >> 6);
-    constexpr int kMetaSlots = NBUF + 1;
-    constexpr uint32_t kWaveFixed = 4096u + (uint32_t)kMetaSlots * kF16MetaBytes + 256u;
+    constexpr int kMetaSlots = (int)f32_mfma_meta_slots(NBUF);  // records in flight: one per load group issued ahead of the epilogue
+    constexpr uint32_t kMetaBytes = kF32MfmaMetaBytes;
+    constexpr uint32_t kWaveFixed = 4096u + (uint32_t)kMetaSlots * kMetaBytes + 256u;
     const uint32_t cap = a.stage_cap;
     const uint32_t wave_off = uniform_u32(frag_total * 16u + 64u * (uint32_t)sizeof(float) + wave_in_block * (kWaveFixed + 12u * cap));
     char* tr = lds + wave_off;
     char* meta = tr + 4096;
     const uint32_t meta_addr = uniform_u32((uint32_t)(size_t)(__attribute__((address_space(3))) char*)meta);
-    uint32_t* hist = reinterpret_cast<uint32_t*>(meta + (size_t)kMetaSlots * kF16MetaBytes);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(meta + (size_t)kMetaSlots * kMetaBytes);
     uint32_t* stage = hist + 64;
     uint32_t m_w = 0, m_r = 0;  // next metadata slot to write / to read (wave-uniform)
 
@@ -130,12 +142,16 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f32_mfma_kernel(F16ScanArgs a
     const uint32_t* meta_norm = reinterpret_cast<const uint32_t*>(a.inv_norm) + (lane & 31);
     const bool meta_dead_lane = lane == 32 && a.dead != nullptr;
     auto load_meta = [&]() {
-        // the 256-byte metadata record (32 x 1/|x| + the tombstone word) of the tile of the NEXT chunk, straight into LDS
+        // the metadata record (32 x 1/|x| + the tombstone word: 132 of 144 bytes) of the tile of the NEXT chunk, straight into LDS
         // (see vec_f16.hip load_meta for why this is an asm statement and how its completion is ordered with the ring)
+        // (lanes 0..32 only: the instruction writes 4 bytes per ACTIVE lane at m0 + 4 lane — with all 64 lanes active it would
+        // write 256 bytes into a 144-byte slot and run over the record the epilogue of the oldest chunk in flight reads next.
+        // The mask is set inside the statement — an `if` around it would be a branch, and the ring's trips must stay one
+        // straight-line block; the main loop runs with every lane active, so -1 restores it.)
         const uint32_t* src = meta_dead_lane ? a.dead + ld_tile : meta_norm + ld_tile * 32;
-        asm volatile("s_nop 0\n\tglobal_load_lds_dword %0, off"
+        asm volatile("s_mov_b32 exec_hi, 1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\ts_mov_b32 exec_hi, -1"
                      :
-                     : "v"(src), "{m0}"(meta_addr + m_w * kF16MetaBytes)
+                     : "v"(src), "{m0}"(meta_addr + m_w * kMetaBytes)
                      : "memory");
         m_w = m_w + 1 == kMetaSlots ? 0 : m_w + 1;
     };
@@ -143,13 +159,13 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f32_mfma_kernel(F16ScanArgs a
         const char* p = base + ld_tile * tile_bytes + (uint64_t)ld_c * (kF32MfmaChunk * 4u) + lane_off;
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) b[i] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (size_t)i * 8u * row_pitch));
-        if (ld_more) {
-            --ld_more;
-            if (++ld_c == nc) {
-                ld_c = 0;
-                ld_tile += tile_step;
-            }
-        }
+        // advance the cursor unless it stands on the wave's last chunk (branch-free: scalar selects)
+        const uint32_t adv = (ld_more != 0 && !(ABL & 64)) ? 1u : 0u;
+        ld_more -= adv;
+        const uint32_t c1 = ld_c + adv;
+        const bool wrap = c1 == nc;
+        ld_c = wrap ? 0u : c1;
+        ld_tile += wrap ? tile_step : 0ull;
         load_meta();
     };
 
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f32_mfma_kernel(F16ScanArgs a
             // this lane's 16 accumulator rows are (r & 3) + 8 (r >> 2) + 4 (l >> 5): four 16-byte reads of the record.  The
             // statement takes an accumulator as a (never used) operand so that it stays behind the tile's last MFMA and with
             // it behind the counted wait that proves the record has landed.
-            const uint32_t rec = meta_addr + m_r * kF16MetaBytes;
+            const uint32_t rec = meta_addr + m_r * kMetaBytes;
             const uint32_t mine = rec + ((lane >> 5) ? 16u : 0u);
             asm volatile(
                 "ds_read_b128 %0, %5\n\t"
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f32_mfma_kernel(F16ScanArgs a
                 any &= any - 1u;
                 if (mine) {
                     const uint32_t i = ((r & 3u) + 8u * (r >> 2)) + hi4;
-                    const float nr = *reinterpret_cast<const float*>(meta + (size_t)m_r * kF16MetaBytes + (size_t)i * 4);
+                    const float nr = *reinterpret_cast<const float*>(meta + (size_t)m_r * kMetaBytes + (size_t)i * 4);
                     // (the accumulator row through a wave-uniform switch: a per-lane index would go through scratch memory)
                     float dot = 0.0f;
 #pragma unroll
@@ -294,29 +310,78 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f32_mfma_kernel(F16ScanArgs a
         }
     };
 
-    auto compute_chunk = [&](const f4* b) {
-        if (cp_c == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        }
-        // through the transposer: rows as they arrived (8 rows x 128 B per load) -> A fragments (lane = row)
+    // Two stages per chunk, one chunk apart: stage(g + 1) turns the landed chunk through the transposer into the A fragments and
+    // fetches the matching query fragments — all LDS traffic of chunk g + 1 is ISSUED before the 16 matrix instructions of chunk
+    // g and completes while they run (1 024 cycles of the SIMD's matrix pipe); the instructions of chunk g wait only for
+    // fragments that were requested a whole chunk earlier.  (First version: reads and MFMAs of the same chunk alternated in
+    // groups of 8 and both waves of a SIMD sat out the LDS latency twice per chunk — 5.7 ms per 32-query pass at 10 M x 768.)
+    f4 af[2][4], bf[2][BDBL ? 4 : 1];  // A fragments of two chunks; query fragments: all four steps, or step 0 only, a chunk ahead
+    uint32_t st_c = 0;                  // chunk-in-row of the NEXT stage (the query fragments' k offset)
+    auto stage_chunk = [&](const f4* b, f4* a_out, f4* b_out) {
         wave_fence();
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) *reinterpret_cast<f4*>(tr + ((i & 1) ? waddr1 : waddr0) + i * 1024) = b[i];
         wave_fence();
-        f4 af[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) af[c] = *reinterpret_cast<const f4*>(tr + raddr[c]);
+        for (int c = 0; c < 4; ++c) a_out[c] = *reinterpret_cast<const f4*>(tr + raddr[c]);
+        const char* bl = lds + ((size_t)st_c * 4 * 64 + lane) * 16;
+#pragma unroll
+        for (int c = 0; c < (BDBL ? 4 : 1); ++c) b_out[c] = *reinterpret_cast<const f4*>(bl + (size_t)c * 1024);
+        st_c = st_c + 1 == nc ? 0 : st_c + 1;
+    };
+    uint64_t tiles_left = my_tiles;
+    auto multiply = [&](const f4* a_in, const f4* b_in) {
+        // (!BDBL: query fragments of steps 1..3 are requested one step — 4 matrix instructions, 256 cycles — ahead of their use)
         const char* bl = lds + ((size_t)cp_c * 4 * 64 + lane) * 16;
+        f4 bcur = b_in[0];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const f4 bv = *reinterpret_cast<const f4*>(bl + (size_t)c * 1024);
+            f4 bnext = bcur;
+            if (c < 3) bnext = BDBL ? b_in[BDBL ? c + 1 : 0] : *reinterpret_cast<const f4*>(bl + (size_t)(c + 1) * 1024);
+            if constexpr ((ABL & 16) != 0) {  // no matrix instructions (the data is still consumed)
+                acc[c] += a_in[c][0] + a_in[c][1] + a_in[c][2] + a_in[c][3] + bcur[0];
+            } else if constexpr ((ABL & 128) != 0) {  // half of the matrix instructions
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][e], bv[e], acc, 0, 0, 0);
+                for (int e = 0; e < 2; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_in[c][e] + a_in[c][e + 2], bcur[e], acc, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_in[c][e], bcur[e], acc, 0, 0, 0);
+            }
+            bcur = bnext;
         }
-        const bool tile_done = ++cp_c == nc;
-        if (tile_done) {
-            finish_tile(cp_tile);
+    };
+    // One trip of the ring = ONE straight-line block: the matrix instructions of chunk g with the memory operations of the stage
+    // of chunk g + 1 and of the reload between them, one per matrix instruction.  A wave issues in order: written as "stage, then
+    // 16 MFMAs" (rounds 6a/6b of this kernel) the stage's waits (vmcnt for the landed chunk, the LDS round trips) sat in front
+    // of sixteen instructions that were ready, and the two waves of a SIMD — same code, same phase — waited together: 94-98
+    // cycles per matrix instruction where the pipe needs 64 (scripts/micro/mfma_f32_chain_probe.hip: a dependent chain alone
+    // runs at 64.8; 8 LDS reads whose results are waited for before the next 16 make it 74.9).  Interleaved, a non-matrix
+    // instruction issues in the shadow of the matrix instruction before it.
+    auto interleave = [] {
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 DS write
+        }
+#pragma unroll
+        for (int i = 0; i < 4 + (BDBL ? 4 : 1); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+        }
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+        }
+    };
+    auto finish_if_done = [&]() {
+        if (++cp_c == nc) {  // the tile is done (past the wave's last tile the trailing trips multiply the re-read last chunk for nobody)
+            if (tiles_left) {
+                --tiles_left;
+                finish_tile(cp_tile);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             cp_c = 0;
             cp_tile += tile_step;
         }
@@ -324,14 +389,26 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f32_mfma_kernel(F16ScanArgs a
     };
 
     const uint64_t total = my_tiles * nc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     load_meta();  // the record of the first tile (the one "group -1" would have brought)
 #pragma unroll
-    for (int b = 0; b < NBUF - 1; ++b) load_chunk(buf[b]);
+    for (int b = 0; b < NBUF; ++b) load_chunk(buf[b]);
+    stage_chunk(buf[0], af[0], bf[0]);
+    load_chunk(buf[0]);
+    // Chunk x lives in buf[x % NBUF] from its load to its stage; per trip: stage(g + 1), reload the freed buffer, multiply(g).
+    // Every trip does all of it (past the end the load cursor re-reads the wave's last chunk, see vec_f16.hip, and stage and
+    // multiply work on it for nobody): a skipped part would change the number of loads in flight on one path and the compiler's
+    // counted vmcnt waits would fall back to draining the ring at every trip — and would split the block the interleave needs.
+    static_assert(NBUF % 2 == 0, "the fragment double buffer is indexed statically inside the unrolled ring");
     for (uint64_t g = 0; g < total; g += NBUF) {
 #pragma unroll
         for (int b = 0; b < NBUF; ++b) {
-            load_chunk(buf[(b + NBUF - 1) % NBUF]);
-            if (g + b < total) compute_chunk(buf[b]);
+            stage_chunk(buf[(b + 1) % NBUF], af[(b + 1) & 1], bf[(b + 1) & 1]);
+            load_chunk(buf[(b + 1) % NBUF]);
+            multiply(af[b & 1], bf[b & 1]);
+            interleave();
+            finish_if_done();
         }
     }
     if (!DENSE && staged) {
@@ -344,6 +421,10 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f32_mfma_kernel(F16ScanArgs a
 
 int launch_vec_scan_f32_mfma(orama_ctx* ctx, const F16ScanArgs& a_in, hipStream_t stream) {
     F16ScanArgs a = a_in;
+#if ORAMA_COMPARISON_KERNELS
+    static const uint32_t k1mdbg = [] { const char* e = std::getenv("ORAMA_K1M_DBG"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+#endif
+    a.dbg = 0;
     ORAMA_REQUIRE(a.tiled && a.inv_norm && a.queries, "vec_scan_f32_mfma: bad arguments");
     ORAMA_REQUIRE(a.q >= 1 && a.q <= kF32MfmaMaxQ, "vec_scan_f32_mfma: q=%u outside [1, %u]", a.q, kF32MfmaMaxQ);
     ORAMA_REQUIRE((a.row_begin & 31) == 0 && a.row_begin <= a.row_end, "vec_scan_f32_mfma: bad row range");
@@ -351,26 +432,54 @@ int launch_vec_scan_f32_mfma(orama_ctx* ctx, const F16ScanArgs& a_in, hipStream_
     ORAMA_REQUIRE(a.out_dense || (a.tau && a.cand_dist && a.cand_row && a.cand_count), "vec_scan_f32_mfma: no output mode");
     ORAMA_REQUIRE(!a.allow || a.row_doc, "vec_scan_f32_mfma: filter needs row_doc");
     if (a.row_begin == a.row_end) return ORAMA_OK;
-    a.stage_cap = vec_scan_f32_mfma_stage_entries(a.dim);
-    const size_t lds_bytes = vec_scan_f32_mfma_lds_bytes(a.dim, a.stage_cap);
-    ORAMA_REQUIRE(a.stage_cap >= 128 && lds_bytes <= kF16LdsLimit, "vec_scan_f32_mfma: dim %u too large for the LDS query tile", a.dim);
-    static bool attr_done = false;
-    if (!attr_done) {
-        ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f32_mfma_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f32_mfma_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
     ProfScope prof(&ctx->prof, "vec_scan_f32_mfma", stream);
     const uint64_t tiles = ((a.row_end + 31) >> 5) - (a.row_begin >> 5);
     const dim3 grid(blocks_for(tiles, kWavesPerBlock, (uint32_t)ctx->compute_units));
     const uint32_t nc = a.dim / kF32MfmaChunk;
     const uint64_t tile_bytes = (uint64_t)a.dim * 4u * 32u;
-    if (a.out_dense)
-        hipLaunchKernelGGL((vec_scan_f32_mfma_kernel<true>), grid, dim3(kBlock), lds_bytes, stream, a, nc, tile_bytes);
-    else
-        hipLaunchKernelGGL((vec_scan_f32_mfma_kernel<false>), grid, dim3(kBlock), lds_bytes, stream, a, nc, tile_bytes);
+#define ORAMA_K1M_LAUNCH(NB_, BDBL_) ORAMA_K1M_LAUNCH_ABL(NB_, BDBL_, 0)
+#define ORAMA_K1M_LAUNCH_ABL(NB_, BDBL_, ABL_)                                                                                          \
+    do {                                                                                                                             \
+        a.stage_cap = vec_scan_f32_mfma_stage_entries(a.dim, NB_);                                                                   \
+        const size_t lds_bytes = vec_scan_f32_mfma_lds_bytes(a.dim, a.stage_cap, NB_);                                               \
+        ORAMA_REQUIRE(a.stage_cap >= 128 && lds_bytes <= kF16LdsLimit, "vec_scan_f32_mfma: dim %u too large for the LDS query tile", a.dim); \
+        static bool attr_done = false;                                                                                               \
+        if (!attr_done) {                                                                                                            \
+            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f32_mfma_kernel<false, NB_, BDBL_, ABL_>),    \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                              \
+            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f32_mfma_kernel<true, NB_, BDBL_, ABL_>),     \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                              \
+            attr_done = true;                                                                                                        \
+        }                                                                                                                            \
+        if (a.out_dense)                                                                                                             \
+            hipLaunchKernelGGL((vec_scan_f32_mfma_kernel<true, NB_, BDBL_, ABL_>), grid, dim3(kBlock), lds_bytes, stream, a, nc, tile_bytes);  \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((vec_scan_f32_mfma_kernel<false, NB_, BDBL_, ABL_>), grid, dim3(kBlock), lds_bytes, stream, a, nc, tile_bytes); \
+    } while (0)
+#if ORAMA_COMPARISON_KERNELS
+    // A/B builds: ORAMA_K1M_VARIANT = ring depth x 100 + 1 (query fragments a chunk ahead); ORAMA_K1M_DBG = a timing ablation
+    static const int variant = [] { const char* e = std::getenv("ORAMA_K1M_VARIANT"); return e ? std::atoi(e) : 0; }();
+    if (k1mdbg) {
+        switch (k1mdbg) {
+            case 16: ORAMA_K1M_LAUNCH_ABL(4, true, 16); break;
+            case 128: ORAMA_K1M_LAUNCH_ABL(4, true, 128); break;
+            case 64: ORAMA_K1M_LAUNCH_ABL(4, true, 64); break;
+            case 192: ORAMA_K1M_LAUNCH_ABL(4, true, 192); break;
+            default: ORAMA_K1M_LAUNCH_ABL(4, true, 80); break;
+        }
+    } else switch (variant) {
+        case 400: ORAMA_K1M_LAUNCH(4, false); break;
+        case 600: ORAMA_K1M_LAUNCH(6, false); break;
+        case 601: ORAMA_K1M_LAUNCH(6, true); break;
+        case 800: ORAMA_K1M_LAUNCH(8, false); break;
+        case 801: ORAMA_K1M_LAUNCH(8, true); break;
+        default: ORAMA_K1M_LAUNCH(4, true); break;
+    }
+#else
+    ORAMA_K1M_LAUNCH(4, true);
+#endif
+#undef ORAMA_K1M_LAUNCH
+#undef ORAMA_K1M_LAUNCH_ABL
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -250,6 +250,7 @@ struct orama_vec {
     std::mutex composite_mu;
     std::atomic<bool> shadow_ok{true};
     std::atomic<uint64_t> two_stage_queries{0}, two_stage_fallbacks{0};
+    std::atomic<uint64_t> mfma_batch_queries{0};  // queries answered through K1m + rerank (search_enqueue_f32_batch)
 
     // scratch for the device-pointer entry point, one per caller stream
     std::mutex dev_mu;
@@ -471,9 +472,110 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
                        uint32_t* d_out_n, hipStream_t s, uint32_t* d_out_rows = nullptr, uint32_t* d_inexact = nullptr,
                        bool f32_rows = false);
 
-// K1m applies: a batch of at least ctx->f32_mfma_min_q queries over cosine rows of whole 32-float chunks whose query tile fits LDS
+// ---------------------------------------------------------------- f32 batches: K1m proposes, K1 decides
+// A batch of >= ctx->f32_mfma_min_q queries over a plain fp32 store shares corpus passes of <= 32 queries on the matrix cores
+// (K1m, vec_f32_mfma.hip) — and still answers with K1's bits, whatever the batch:
+//   1. K1m + K2's filter pipeline return the k1 = k + spare best rows of every query by K1m's distance.  K1m and K1 evaluate
+//      the same f32 dot product in different orders: |d_K1m - d_K1| <= gamma_n sum|x_i q_i| / (|x||q|) <= 768 x 2^-24 = 4.6e-5
+//      for the sequential chain (K1's tree is tighter), plus a few ulp for 1/|q|: eps = 6e-5 is a bound, the typical
+//      difference is 1e-7.  Every row of K1's top-k therefore has a K1m distance <= tau + 2 eps, tau = the k-th best K1m
+//      distance: the candidate list is COMPLETE when it is not full or its last entry lies beyond tau + 2 eps
+//      (shadow_band_kernel — the proof of the fp16 two-stage plan with a band 40 x narrower);
+//   2. K1's own arithmetic on the candidates (rerank_f32_kernel: bit-identical distances), K4 with the one-stage tie rule;
+//   3. a query whose list is not proven (duplicates / ties around the k-th place) is answered again ON THE DEVICE by K1's own
+//      kernel over the flagged queries only (the two-stage plan's device form: pick -> picked scan -> key lists -> scatter);
+//      with nothing flagged those launches end at once.
+// Everything is enqueued on `s`; no host round trip.  Envelope: cosine, dim % 32 == 0 and <= 864 (the query tile lives in LDS),
+// k <= 128 (the fallback's per-wave lists).
+constexpr float kF32MfmaEps = 6.0e-5f;
+constexpr uint32_t kF32MfmaFallbackSets = 16;
 bool f32_batch_on_mfma(const orama_vec* v, uint32_t q, uint32_t k) {
-    return v->ctx->f32_mfma_min_q && q >= v->ctx->f32_mfma_min_q && k <= kSelectMaxK && vec_scan_f32_mfma_supports(v->dim, v->metric);
+    return v->ctx->f32_mfma_min_q && q >= v->ctx->f32_mfma_min_q && k >= 1 && k <= kWaveListKeys && !v->f16() &&
+           vec_scan_f32_mfma_supports(v->dim, v->metric) && vec_rerank_f32_supported(v->dim);
+}
+
+int search_enqueue_f32_batch(orama_vec* v, const View& w, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
+                             const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
+                             uint32_t* d_out_n, hipStream_t s) {
+    // spare candidates decide how often the proof fails: on the north-star rows the (k + 32)-th K1m distance lies ~2e-3 behind
+    // the k-th, 15 bands; candidates are cheap (k1 rows of 3 KiB per query against a 30 GB pass)
+    const uint32_t k1 = std::min<uint32_t>(kSelectMaxK, k + std::max<uint32_t>(32u, k / 2));
+    const size_t n1 = (size_t)q * k1;
+    // every buffer first: nothing is (re)allocated behind launches that are already enqueued (the candidate stage reserves its
+    // own — sel_state / sel_keys among them, larger than the final selection needs — before ITS launches)
+    ORAMA_TRY(sc->mfma_cand.reserve(n1 * (8 + 4 + 4 + 4) + (size_t)q * 4 * 2 + 64));
+    ORAMA_TRY(sc->sel_state.reserve(sizeof(SelectState) * (size_t)q));  // the final selection runs over all q lists at once
+    ORAMA_TRY(sc->sel_keys.reserve(sizeof(unsigned long long) * (size_t)q * kSelectMaxK));
+    uint64_t* c_ids = sc->mfma_cand.as<uint64_t>();
+    float* c_dm = reinterpret_cast<float*>(c_ids + n1);
+    uint32_t* c_rows = reinterpret_cast<uint32_t*>(c_dm + n1);
+    float* c_exact = reinterpret_cast<float*>(c_rows + n1);
+    uint32_t* d_n1 = reinterpret_cast<uint32_t*>(c_exact + n1);
+    uint32_t* d_flag = d_n1 + q;
+    ScanArgs fa;  // the fallback's scan (K1, fused mode)
+    fa.corpus = static_cast<const float*>(w.rows);
+    fa.inv_norm = w.inv_norm;
+    fa.query = d_queries;
+    fa.n = w.n_rows;
+    fa.dim = v->dim;
+    fa.metric = v->metric;
+    fa.row_doc = w.row_doc;
+    fa.dead = w.dead;
+    fa.allow = d_allow;
+    fa.allow_bits = allow_bits;
+    fa.topk = k;
+    ORAMA_REQUIRE(vec_scan_f32_picked_supported(fa), "internal: fp32 batch outside the picked scan's envelope");
+    const uint32_t fb_keys = vec_scan_f32_picked_waves(v->ctx, fa) * kWaveListKeys;
+    const uint32_t fb_sets = std::min<uint32_t>(q, kF32MfmaFallbackSets);
+    const uint32_t fb_rounds = (q + fb_sets - 1) / fb_sets;
+    ORAMA_TRY(sc->mfma_fb_lists.reserve((size_t)fb_sets * fb_keys * 8));
+    ORAMA_TRY(sc->mfma_fb_tmp.reserve((size_t)keys_topk_scratch_keys(fb_keys, fb_sets, k) * 8 + 8));
+    const size_t nk = (size_t)fb_sets * k;
+    ORAMA_TRY(sc->mfma_fb_out.reserve(nk * 12 + (size_t)fb_sets * 4 + (size_t)q * 4 + 4 + (size_t)fb_rounds * 4 + 64));
+    uint64_t* fb_ids = sc->mfma_fb_out.as<uint64_t>();
+    float* fb_dist = reinterpret_cast<float*>(fb_ids + nk);
+    uint32_t* fb_n = reinterpret_cast<uint32_t*>(fb_dist + nk);
+    uint32_t* d_pick = fb_n + fb_sets;
+    uint32_t* d_n_pick = d_pick + q;
+    uint32_t* d_round_n = d_n_pick + 1;
+    fa.wave_lists = sc->mfma_fb_lists.as<unsigned long long>();
+
+    // 1. candidates by K1m's distance (ids are not needed yet: the final selection maps rows to DocumentIds)
+    ORAMA_TRY(search_enqueue_f16(v, w, sc, d_queries, q, k1, d_allow, allow_bits, c_ids, c_dm, d_n1, s, c_rows, nullptr, /*f32_rows=*/true));
+    ORAMA_TRY(launch_shadow_band(c_dm, d_n1, q, k, k1, 2.0f * kF32MfmaEps, d_flag, s));
+    // 2. K1's distances of the candidates, then the final order
+    ORAMA_TRY(launch_rerank_f32(static_cast<const float*>(w.rows), w.inv_norm, v->dim, d_queries, q, c_rows, d_n1, k1, c_exact, s));
+    SelectPlan p;
+    p.vals = c_exact;
+    p.idx = c_rows;
+    p.stride = k1;
+    p.n_dev = d_n1;
+    p.n = k1;
+    p.q = q;
+    p.k = k;
+    p.descending = false;
+    p.id_map = w.row_doc;
+    p.state = sc->sel_state.as<SelectState>();
+    p.keys = sc->sel_keys.as<unsigned long long>();
+    p.keys_capacity = (uint64_t)q * kSelectMaxK;
+    p.out_ids = d_out_ids;
+    p.out_val = d_out_dist;
+    p.out_n = d_out_n;
+    ORAMA_TRY(launch_select(v->ctx, p, s));
+    // 3. unproven queries: K1 itself, on the device
+    hipLaunchKernelGGL(pick_flagged_kernel, dim3(1), dim3(256), 0, s, d_flag, q, d_pick, d_n_pick, fb_sets, fb_rounds, d_round_n);
+    ORAMA_HIP_TRY(hipGetLastError());
+    for (uint32_t r = 0; r < fb_rounds; ++r) {
+        const uint32_t* picks = d_pick + (size_t)r * fb_sets;
+        ORAMA_TRY(launch_vec_scan_f32_picked(v->ctx, fa, picks, d_round_n + r, fb_keys, s));
+        ORAMA_TRY(launch_keys_topk(v->ctx, fa.wave_lists, fb_keys, fb_keys, fb_sets, k, false, w.row_doc, sc->mfma_fb_tmp.as<unsigned long long>(),
+                                   nullptr, fb_ids, fb_dist, fb_n, s, nullptr, nullptr, 0, d_round_n + r));
+        hipLaunchKernelGGL(scatter_picked_kernel, dim3(fb_sets), dim3(128), 0, s, picks, d_round_n + r, k, fb_ids, fb_dist, fb_n, d_out_ids,
+                           d_out_dist, d_out_n);
+        ORAMA_HIP_TRY(hipGetLastError());
+    }
+    v->mfma_batch_queries.fetch_add(q, std::memory_order_relaxed);
+    return ORAMA_OK;
 }
 
 int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
@@ -483,8 +585,7 @@ int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_
     if (f32_batch_on_mfma(v, q, k)) {
         // the batch shares corpus passes of <= 32 queries on the matrix cores, K2's pipeline behind them (dense head ->
         // thresholds -> filter scan -> candidate lists): scans and selections depend on each other both ways, one stream
-        return search_enqueue_f16(v, w, sc, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, s, nullptr, nullptr,
-                                  /*f32_rows=*/true);
+        return search_enqueue_f32_batch(v, w, sc, d_queries, q, k, d_allow, allow_bits, d_out_ids, d_out_dist, d_out_n, s);
     }
     // fused_topk: 1 = always, 0 = never, 2 (default) = for ONE query over a large corpus: the dense path writes and
     // re-reads 4 B per row for K4 (40 MB at 10 M rows) and K1b does not apply to a single query — measured at NS

@@ -219,16 +219,26 @@ class TokenScoreParams:
     filtered_doc_ids: Optional[AllowBitmap] = None
 
 
+# The exact-match factor of the third-party string store (oramacore_fields 0.2.0, folded into ntf: token_score.rs:182-185,
+# 226-228, 268-269).  Its value is NOT in the checkout.  What the reference does pin: boost_integration.rs:449-491 asserts
+# hits[0].score > hits[1].score for "serve" against "server" — with a factor of 1.0 the two scores are bit-equal, so the
+# factor is > 1.  1.5 is a PLACEHOLDER that satisfies every relation the reference's tests hold; the Rust shim passes the real
+# one (AcceleratorConfig.exact_match_boost, "read it from oramacore_fields::string::SearchParams'
+# implementation when the crate is available").  include/orama/host.hpp carries the same constant.
+DEFAULT_EXACT_MATCH_BOOST = 1.5
+
+
 class TokenScoreContext:
     def __init__(self, index: Index, embed: Callable[[str, object], np.ndarray] | None = None, tokenizer=None,
-                 exact_match_boost: float = 1.0):
+                 exact_match_boost: float = DEFAULT_EXACT_MATCH_BOOST):
         self.index = index
         self.embed = embed
         self.text_parser = tokenizer or SimpleTokenizer()
         # The third-party store folds an exact-match boost into ntf (comments token_score.rs:182-185, 226-228); its
         # value is not visible in this checkout (SURVEY §8c assumption 3), so it is a parameter: the factor applied
         # to postings of the dictionary term that equals the query token (prefix / fuzzy expansions keep 1.0).  It
-        # reaches the device through orama_term_ref.boost (= field boost x this factor).  Default 1.0.
+        # reaches the device through orama_term_ref.boost (= field boost x this factor).  Default: the placeholder above
+        # (> 1, as the reference's test_boost_match_exact requires); 1.0 = the bit-equal variant.
         self.exact_match_boost = float(exact_match_boost)
 
     # token_score.rs:196-209

@@ -7,6 +7,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import oramacore_amd as oa  # noqa: E402
+import bench  # noqa: E402  (the clock / power sampler)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=10_000_000)
@@ -15,6 +16,10 @@ ap.add_argument("--batches", default="8,9,16,24,32,64,128")
 ap.add_argument("--reps", type=int, default=8)
 a = ap.parse_args()
 ctx = oa.Context(0)
+try:
+    bdf = ctx.pci_bus_id()
+except Exception:  # noqa: BLE001
+    bdf = None
 n, d, k = a.rows, a.dim, 100
 st = oa.EmbeddingFieldStorage(ctx, dimensions=d, reserve_rows=n)
 st.fill_synthetic(n, seed=0xC0FFEE)
@@ -24,11 +29,13 @@ for nq in [int(x) for x in a.batches.split(",")]:
     for _ in range(2):
         st.storage_search(q[:nq], k)
     ctx.prof_reset(); ctx.prof_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(a.reps):
-        st.storage_search(q[:nq], k)
-    el = (time.perf_counter() - t0) / a.reps * 1e3
+    with bench.ClockSampler(bdf) as cs:
+        t0 = time.perf_counter()
+        for _ in range(a.reps):
+            st.storage_search(q[:nq], k)
+        el = (time.perf_counter() - t0) / a.reps * 1e3
     ctx.prof_enable(False)
+    c = cs.summary()
     m = ctx.prof_get("vec_scan_f32_mfma"); b = ctx.prof_get("vec_scan_f32_multi"); k1 = ctx.prof_get("vec_scan_f32"); s = ctx.prof_get("topk_select")
     passes = -(-nq // 32)
     line = f"nq={nq:3d} call {el:8.3f} ms  QPS {nq/el*1e3:8.1f} | K1m {m[0]/a.reps:7.3f} ms in {m[1]//a.reps} launches"
@@ -36,5 +43,7 @@ for nq in [int(x) for x in a.batches.split(",")]:
         per_pass = m[0] / a.reps / passes
         line += f" = {per_pass:6.3f} ms per pass of <=32 ({alg/per_pass/1e6:7.1f} GB/s, {alg/per_pass/1e6/8000:5.3f} of HBM peak; mfma {2*32*n*d/per_pass/1e9/157.3:5.3f} of 157.3 TF)"
     line += f" | K1b {b[0]/a.reps:7.3f} ms ({b[1]//a.reps}) | K1 {k1[0]/a.reps:7.3f} ms ({k1[1]//a.reps}) | select {s[0]/a.reps:6.3f} ms"
+    if c.get("available"):
+        line += f" | {c['sclk_mhz_median']:.0f} MHz, {c['power_w_mean']:.0f} W, PPT residency {c.get('ppt_throttle_residency_pct')}"
     print(line, flush=True)
 st.close()

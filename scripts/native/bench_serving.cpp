@@ -83,8 +83,8 @@ int main(int argc, char** argv) {
             for (int nt : thread_counts) {
                 if (!batched && nt > 64) continue;  // direct calls: one corpus pass per request
                 orama_batcher* batcher = nullptr;
-                if (batched && group) CHECK(orama_batcher_create_group(group, shards.data(), dt == ORAMA_DTYPE_F32 ? 8 : 256, 0, &batcher));
-                else if (batched) CHECK(orama_batcher_create(vec, dt == ORAMA_DTYPE_F32 ? 8 : 256, 0, &batcher));
+                if (batched && group) CHECK(orama_batcher_create_group(group, shards.data(), dt == ORAMA_DTYPE_F32 ? 64 : 256, 0, &batcher));
+                else if (batched) CHECK(orama_batcher_create(vec, dt == ORAMA_DTYPE_F32 ? 64 : 256, 0, &batcher));
                 const int count = batched ? per_thread : std::max(4, per_thread / 8);
                 std::atomic<uint64_t> checksum{0};
                 auto worker = [&](int tid, int cnt) {

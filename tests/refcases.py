@@ -71,7 +71,10 @@ def levenshtein(a: bytes, b: bytes) -> int:
     return prev[-1]
 
 
-def oracle_search(idx, p, fields, exact_match_boost=1.0):
+DEFAULT_EXACT_MATCH_BOOST = 1.5  # = oramacore_amd.token_score.DEFAULT_EXACT_MATCH_BOOST (asserted in tests/test_reference_cases.py)
+
+
+def oracle_search(idx, p, fields, exact_match_boost=DEFAULT_EXACT_MATCH_BOOST):
     """One search of a case through the CPU restatement: (docs, scores) of the whole map after OMC."""
     fmap = {name: fi for fi, name in enumerate(fields)}
     exact = p.get("exact", False)
@@ -131,7 +134,8 @@ def check_expect(hits, count, ids, exp):
 def check_case(case, search):
     """Run every search of `case` through `search(spec, exact_match_boost) -> (hits [(doc, score)], count, ids)` and assert
     everything the reference's test asserts (+ the relations marked `own`)."""
-    emb = case.get("host_params", {}).get("exact_match_boost", 1.0)
+    assert "host_params" not in case, "round 6: every case runs under the declared defaults — no per-case host parameter"
+    emb = DEFAULT_EXACT_MATCH_BOOST
     saved = {}
     for spec in case["searches"]:
         hits, count, ids = search(spec, emb)
@@ -153,7 +157,13 @@ def check_case(case, search):
             assert a / b < r["bound"], (r, a / b)
     cf = case.get("closed_form")
     if cf:
-        assert abs(saved["s2"] / saved["s1"] - cf["ratio_2x"]) <= cf["tol"] and abs(saved["s5"] / saved["s1"] - cf["ratio_5x"]) <= cf["tol"]
+        for e in (emb, 1.0):  # the declared default and the factor-free variant
+            if e != emb:
+                for spec in case["searches"]:
+                    if "save_top_score_as" in spec:
+                        saved[spec["save_top_score_as"]] = float(search(spec, e)[0][0][1])
+            want = {n: n * (cf["k"] + e) / (cf["k"] + n * e) for n in (2, 5)}
+            assert abs(saved["s2"] / saved["s1"] - want[2]) <= cf["tol"] and abs(saved["s5"] / saved["s1"] - want[5]) <= cf["tol"], (e, want)
     alt = case.get("with_exact_match_boost_1")
     if alt:  # the declared default (1.0): same documents, same order by id, but the scores tie — the factor is what the reference pins
         hits, count, ids = search(alt, 1.0)

@@ -12,6 +12,11 @@ CASES = util.load_json("reference_cases.json")["cases"]
 
 
 def test_every_case_cites_the_reference_and_names_what_it_constrains():
+    from oramacore_amd.token_score import DEFAULT_EXACT_MATCH_BOOST
+
+    # the checker's default IS the mirror's default, and it is a factor > 1 (boost_integration.rs:449-491 needs that)
+    assert refcases.DEFAULT_EXACT_MATCH_BOOST == DEFAULT_EXACT_MATCH_BOOST > 1.0
+    assert not any("host_params" in c for c in CASES)
     assert len(CASES) >= 19
     for c in CASES:
         assert c["reference"].startswith("src/tests/") and ":" in c["reference"], c["name"]

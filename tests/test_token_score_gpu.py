@@ -10,8 +10,8 @@ import pytest
 import oramacore_amd as oa
 import util
 from oracle import oracle as orc
-from oramacore_amd.token_score import (FulltextMode, HybridMode, Index, StringFieldStorage, TokenScoreContext,
-                                       TokenScoreParams, VectorMode)
+from oramacore_amd.token_score import (DEFAULT_EXACT_MATCH_BOOST, FulltextMode, HybridMode, Index, StringFieldStorage,
+                                       TokenScoreContext, TokenScoreParams, VectorMode)
 
 pytestmark = pytest.mark.gpu
 F = np.float32
@@ -44,9 +44,10 @@ def oracle_fulltext(idx: Index, tokens, exact, boost=None, threshold=None, allow
                 if allow is not None:
                     pl = [(d, tf) for d, tf in pl if allow.contains(d)]
                 docs = [d for d, _ in pl]
-                ntf = [F(F((boost or {}).get(fid, 1.0)) * orc.bm25f_normalized_tf(tf, sf.field_len[d],
-                                                                                  sf.avg_field_length(), 0.75))
-                       for d, tf in pl]
+                bo = F((boost or {}).get(fid, 1.0))
+                if term == tok:  # the exact-match factor of the store (the mirror's declared default, > 1)
+                    bo = F(bo * F(DEFAULT_EXACT_MATCH_BOOST))
+                ntf = [F(bo * orc.bm25f_normalized_tf(tf, sf.field_len[d], sf.avg_field_length(), 0.75)) for d, tf in pl]
                 entries.append((ti, docs, ntf))
     return orc.search_full_text(entries, len(tokens), float(idx.document_count), 1.2, threshold)
 
