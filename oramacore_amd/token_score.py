@@ -101,9 +101,12 @@ class Index:
     bool_fields: dict = field(default_factory=dict)
     number_fields: dict = field(default_factory=dict)
     string_filter_fields: dict = field(default_factory=dict)
+    # deletes since the last commit: every search carries NOT(deleted) until then (index/mod.rs:1346-1424, filter.rs:352-390)
+    uncommitted_deleted_documents: set = field(default_factory=set)
     _post: Optional[PostingsStore] = None
-    _lists: dict = field(default_factory=dict)      # (field_id, term) -> list id
+    _lists: dict = field(default_factory=dict)      # (field_id, term) -> [list ids]: the committed list, then delta lists
     _terms: dict = field(default_factory=dict)      # field_id -> sorted term list
+    _delta_terms: dict = field(default_factory=dict)  # field_id -> terms that exist only in delta lists (not in the dictionary)
 
     @property
     def document_count(self) -> int:
@@ -113,7 +116,8 @@ class Index:
         """Export the committed postings to HBM (the GPU side of `compact`, INTEGRATION.md §3 ii)."""
         docs = np.array(sorted(self.document_ids), dtype=np.uint64)
         field_ids = sorted(self.string_fields)
-        lists, self._lists, self._terms = [], {}, {}
+        lists, self._lists, self._terms, self._delta_terms = [], {}, {}, {}
+        self.uncommitted_deleted_documents = set()  # the rebuild holds live documents only
         for fi, fid in enumerate(field_ids):
             sf = self.string_fields[fid]
             self._terms[fid] = sorted(sf.postings)
@@ -122,7 +126,7 @@ class Index:
                 if not pl:
                     continue
                 d = np.array([x[0] for x in pl], dtype=np.uint64)
-                self._lists[(fid, term)] = len(lists)
+                self._lists[(fid, term)] = [len(lists)]
                 lists.append(PostingList(field=fi, docs=d, tf=np.array([x[1] for x in pl]),
                                          field_len=np.array([sf.field_len[int(x)] for x in d])))
         if self._post is None:
@@ -137,6 +141,64 @@ class Index:
         self._dicts = {fid: TermDictionary(self.ctx, sorted(self._terms[fid], key=lambda t: t.encode("utf-8")))
                        for fid in field_ids if self._terms.get(fid)}
         self._commit_filter_fields()
+
+    # ---- live updates between commits
+    def append_documents(self, doc_ids) -> None:
+        """`StringFieldStorage::insert` between commits (string_field.rs:155-170; update_data(&self), index/mod.rs:1436): the
+        documents `doc_ids` — already inserted into this mirror's host-side fields and `document_ids`, ids greater than every
+        stored one — reach the device as DELTA posting lists (orama_post_append); a term is then its committed list plus
+        its delta lists, passed with the same token.  The field averages move with the insert."""
+        new = sorted(int(d) for d in doc_ids)
+        if not new:
+            return
+        assert self._post is not None, "append_documents needs a committed index (commit() first)"
+        field_ids = self._field_order
+        assert sorted(self.string_fields) == field_ids, "a new string field needs a commit"
+        lists, keys = [], []
+        newset = set(new)
+        for fi, fid in enumerate(field_ids):
+            sf = self.string_fields[fid]
+            for term in sorted(sf.postings):
+                pl = sorted((d, tf) for d, tf in sf.postings[term].items() if d in newset)
+                if not pl:
+                    continue
+                d = np.array([x[0] for x in pl], dtype=np.uint64)
+                keys.append((fid, term))
+                lists.append(PostingList(field=fi, docs=d, tf=np.array([x[1] for x in pl]),
+                                         field_len=np.array([sf.field_len[int(x)] for x in d])))
+        first = self._post.append(np.array(new, dtype=np.uint64), [self.string_fields[f].avg_field_length() for f in field_ids], lists)
+        for i, key in enumerate(keys):
+            if key not in self._lists:
+                self._delta_terms.setdefault(key[0], set()).add(key[1])
+            self._lists.setdefault(key, []).append(first + i)
+        if self.omc:
+            self._post.set_omc({d: m for d, m in self.omc.items() if d in self.document_ids or d in self.uncommitted_deleted_documents})
+
+    def delete_documents(self, doc_ids) -> None:
+        """IndexWriteOperation::DeleteDocuments (index/mod.rs:1346-1424): out of every field, the OMC map and the document
+        count; remembered in `uncommitted_deleted_documents`, which turns every later search's filter into ... AND NOT(deleted)
+        (filter.rs:352-390) — on the device the postings stay in their lists until the next commit and the bitmap hides them."""
+        for d in (int(x) for x in doc_ids):
+            if d not in self.document_ids:
+                continue
+            self.document_ids.discard(d)
+            self.uncommitted_deleted_documents.add(d)
+            for sf in self.string_fields.values():
+                sf.delete(d)
+            for store in (self.bool_fields, self.number_fields, self.string_filter_fields):
+                for vals in store.values():
+                    vals.pop(d, None)
+            self.omc.pop(d, None)
+        if self._post is not None:  # StringStorage::info().avg_field_length follows the live documents
+            self._post.set_avg_len([self.string_fields[f].avg_field_length() for f in self._field_order])
+
+    def calculate_filter(self, where: dict | None):
+        """Index::calculate_filter -> FilterContext::execute_filter (filter.rs:344-392): the AllowBitmap a search of this index
+        carries, or None (no `where`, no uncommitted deletes)."""
+        from .filter import FilterContext
+
+        hi = max(list(self.document_ids) + list(self.uncommitted_deleted_documents) + [0]) + 1
+        return FilterContext(self).execute_filter(where, n_bits=hi)
 
     # ---- resident images of the filter fields (orama_facet_field), rebuilt at commit like the postings
     def _commit_filter_fields(self) -> None:
@@ -193,17 +255,33 @@ class Index:
         """`lookup` with the match kind: [(list id, term == token)] — the caller folds the exact-match boost into the
         reference's `boost` of the lists whose term IS the token (SURVEY §8c assumption 3)."""
         if exact:
-            l = self._lists.get((field_id, token))
-            return [] if l is None else [(l, True)]
+            return [(l, True) for l in self._lists.get((field_id, token), [])]
         d = self._dicts.get(field_id) if hasattr(self, "_dicts") else None
-        if d is None:
-            return []
+        terms = [] if d is None else [d.terms[ti] for ti in d.expand(token, exact=False, tolerance=int(tolerance or 0))]
+        # terms that exist only in delta lists are not in the resident dictionary (it is rebuilt at commit): the same rule on the host
+        tol = int(tolerance or 0)
+        extra = [t for t in self._delta_terms.get(field_id, ()) if t.startswith(token) or (tol and _levenshtein_le(t, token, tol))]
         out = []
-        for ti in d.expand(token, exact=False, tolerance=int(tolerance or 0)):  # ascending = dictionary order
-            l = self._lists.get((field_id, d.terms[ti]))
-            if l is not None:
-                out.append((l, d.terms[ti] == token))
+        for term in sorted(set(terms) | set(extra), key=lambda t: t.encode("utf-8")):  # ascending = dictionary order
+            for l in self._lists.get((field_id, term), []):
+                out.append((l, term == token))
         return out
+
+
+def _levenshtein_le(a: str, b: str, k: int) -> bool:
+    """Levenshtein(a, b) <= k over bytes (the dictionary's unit)."""
+    a, b = a.encode("utf-8"), b.encode("utf-8")
+    if abs(len(a) - len(b)) > k:
+        return False
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i] + [0] * len(b)
+        for j, cb in enumerate(b, 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb))
+        if min(cur) > k:
+            return False
+        prev = cur
+    return prev[-1] <= k
 
 
 @dataclass
@@ -217,6 +295,9 @@ class TokenScoreParams:
     # leg is the REQUEST's limit, never limit + offset; None = `limit`
     limit_hint: Optional[int] = None
     filtered_doc_ids: Optional[AllowBitmap] = None
+    # the request's `where` (types.rs WhereFilter as JSON): search_on_indexes evaluates it PER INDEX (search.rs:304-338 ->
+    # Index::calculate_filter) into that index's filtered_doc_ids, together with its uncommitted deletes
+    where_filter: Optional[dict] = None
 
 
 # The exact-match factor of the third-party string store (oramacore_fields 0.2.0, folded into ntf: token_score.rs:182-185,
@@ -285,6 +366,10 @@ class TokenScoreContext:
         """Returns (hits [(doc_id, score)] after skip(offset).take(limit), count)."""
         from . import fulltext as ft
 
+        if params.filtered_doc_ids is None and (params.where_filter is not None or self.index.uncommitted_deleted_documents):
+            # Index::calculate_filter (filter.rs:344-392): the request's `where` and NOT(uncommitted deletes), as this index sees them
+            from dataclasses import replace
+            params = replace(params, filtered_doc_ids=self.index.calculate_filter(params.where_filter))
         m = params.mode
         top = params.limit + params.offset
         if isinstance(m, FulltextMode):
@@ -392,14 +477,24 @@ def search_on_indexes(contexts: list, params: TokenScoreParams):
     cut over those (K4 again, `orama_top_n`) is exact."""
     from . import fulltext as ft
 
+    from .filter import check_filter_fields
+
     top = params.limit + params.offset
-    # every index returns its own top-(limit + offset); the vector leg keeps the request's limit (limit_hint,
-    # search.rs:334 / token_score.rs:339-344) — with offset > 0 the two differ
-    per_index = TokenScoreParams(mode=params.mode, properties=params.properties, boost=params.boost, limit=top, offset=0,
-                                 filtered_doc_ids=params.filtered_doc_ids,
-                                 limit_hint=params.limit if params.limit_hint is None else params.limit_hint)
+    check_filter_fields([t.index for t in contexts], params.where_filter)  # ReadError::FilterFieldNotFound, search.rs:435-449
     docs, scores, count = [], [], 0
     for tsc in contexts:
+        # every index returns its own top-(limit + offset); the vector leg keeps the request's limit (limit_hint,
+        # search.rs:334 / token_score.rs:339-344) — with offset > 0 the two differ.  The filter is the index's own: its fields,
+        # its uncommitted deletes (a caller-made bitmap, if any, is AND-ed by passing it as filtered_doc_ids of a one-index call)
+        allow = params.filtered_doc_ids
+        if params.where_filter is not None or tsc.index.uncommitted_deleted_documents:
+            assert allow is None, "pass either a where filter or a ready bitmap"
+            allow = tsc.index.calculate_filter(params.where_filter)
+        per_index = TokenScoreParams(mode=params.mode, properties=params.properties, boost=params.boost, limit=top, offset=0,
+                                     filtered_doc_ids=allow,
+                                     limit_hint=params.limit if params.limit_hint is None else params.limit_hint)
+        if tsc.index.document_count == 0 or tsc.index._post is None:
+            continue  # an index without documents contributes nothing (src/tests/multi_index.rs:88-167)
         hits, c = tsc.execute(per_index)
         count += c
         docs.extend(h[0] for h in hits)

@@ -1,0 +1,187 @@
+"""Shared by tests/test_reference_filter_cases.py (CPU: oracle + the filter mirror) and tests/test_reference_filter_cases_gpu.py
+(the HIP path): tests/golden/reference_filter_cases.json — the reference's filter / multi-index / update tests as data — turned
+into a small collection model: indexes with collection-unique DocumentIds, inserts that replace, merge-updates, deletes, commits."""
+import numpy as np
+
+import refcases
+from oracle import oracle as orc
+from oramacore_amd.filter import FilterContext, FilterFieldNotFound, check_filter_fields
+from oramacore_amd.token_score import StringFieldStorage
+
+
+def gen_value(spec, i):
+    if "list" in spec:
+        return [gen_value(spec["list"], i)]
+    if "repeat" in spec:
+        return spec["repeat"] * (i + spec["times_plus"])
+    if "index" in spec:
+        return i
+    if "format_bool" in spec:
+        m, r = spec["mod_eq"]
+        return spec["format_bool"].format(b=str(i % m == r).lower())
+    if "mod_eq" in spec:
+        m, r = spec["mod_eq"]
+        return i % m == r
+    raise ValueError(spec)
+
+
+def documents_of(index_spec):
+    if "documents" in index_spec:
+        return [dict(d) for d in index_spec["documents"]]
+    g = index_spec["generate"]
+    return [{"id": g["id"].format(i=i), **{k: gen_value(v, i) for k, v in g["values"].items()}} for i in range(g["count"])]
+
+
+def _vals(v):
+    return v if isinstance(v, list) else [v]
+
+
+def _is_string_value(v):
+    return all(isinstance(x, str) for x in _vals(v)) and len(_vals(v)) > 0
+
+
+class Collection:
+    """The case's collection.  `make_index()` -> HostIndex (CPU) or the mirror's Index (GPU); `on_insert(idx, [doc ids])`,
+    `on_commit(idx)` let the GPU harness keep the device in step (delta lists / rebuild)."""
+
+    def __init__(self, case, make_index, on_insert=None, on_commit=None):
+        self.case = case
+        self.on_insert, self.on_commit = on_insert or (lambda idx, ids: None), on_commit or (lambda idx: None)
+        self.next_doc, self.auto = 1, 0
+        self.indexes, self.ids, self.docs, self.fields = [], [], [], []
+        later = {}
+        for st in case["steps"]:
+            if st.get("op") in ("insert", "update_merge"):
+                later.setdefault(st["index"], []).extend(st["documents"])
+        for ii, spec in enumerate(case["indexes"]):
+            idx = make_index()
+            docs = documents_of(spec)
+            # the scored string fields of the index: every name that holds a string anywhere in the case, in order of appearance
+            # (a field that first appears after a commit would need one more: the cases insert no such field)
+            names = []
+            for d in docs + later.get(ii, []):
+                for k, v in d.items():
+                    if k != "id" and _is_string_value(v) and k not in names:
+                        names.append(k)
+            for fi in range(len(names)):
+                idx.string_fields[fi] = StringFieldStorage()
+            self.indexes.append(idx)
+            self.ids.append({})
+            self.docs.append({})
+            self.fields.append(names)
+            new = [self._insert_host(ii, d) for d in docs]
+            self.on_commit(idx)  # the initial batch is committed: the postings are resident
+            del new
+
+    # ---- host-side state (what both harnesses share)
+    def _insert_host(self, ii, doc):
+        idx, ids = self.indexes[ii], self.ids[ii]
+        sid = doc.get("id")
+        if sid is None:
+            self.auto += 1
+            sid = f"auto-{self.auto}"
+        if sid in ids:  # replace on insert (src/tests/replace_doc_on_insert.rs): the old document goes first
+            idx.delete_documents([ids[sid]])
+        n = self.next_doc
+        self.next_doc += 1
+        ids[sid] = n
+        self.docs[ii][sid] = dict(doc)
+        idx.document_ids.add(n)
+        for k, v in doc.items():
+            if k == "id":
+                continue
+            vals = _vals(v)
+            if _is_string_value(v):
+                idx.string_fields[self.fields[ii].index(k)].insert(n, " ".join(vals))
+                idx.string_filter_fields.setdefault(k, {})[n] = v
+            elif all(isinstance(x, bool) for x in vals):
+                idx.bool_fields.setdefault(k, {})[n] = v
+            elif all(isinstance(x, (int, float)) and not isinstance(x, bool) for x in vals):
+                idx.number_fields.setdefault(k, {})[n] = v
+        return n
+
+    def apply(self, step):
+        op = step["op"]
+        if op == "commit":
+            for idx in self.indexes:
+                self.on_commit(idx)
+        elif op == "insert":
+            ii = step["index"]
+            self.on_insert(self.indexes[ii], [self._insert_host(ii, d) for d in step["documents"]])
+        elif op == "update_merge":  # UpdateDocumentRequest strategy merge (src/tests/update_docs.rs:55-75): old fields kept, given ones replaced
+            ii = step["index"]
+            merged = [{**self.docs[ii][d["id"]], **d} for d in step["documents"]]
+            self.on_insert(self.indexes[ii], [self._insert_host(ii, d) for d in merged])
+        elif op == "delete":
+            ii = step["index"]
+            self.indexes[ii].delete_documents([self.ids[ii][s] for s in step["ids"] if s in self.ids[ii]])
+        else:
+            raise ValueError(op)
+
+    def string_id(self, doc_id):
+        for m in self.ids:
+            for sid, n in m.items():
+                if n == doc_id:
+                    return sid
+        raise KeyError(doc_id)
+
+    # ---- the oracle's answer: (hits [(doc, score)], count) over all indexes
+    def oracle_search(self, p):
+        where = p.get("where")
+        check_filter_fields(self.indexes, where)
+        docs, scores = [], []
+        for ii, idx in enumerate(self.indexes):
+            if idx.document_count == 0:
+                continue
+            q = {k: v for k, v in p.items() if k != "where"}
+            if "properties" in q:
+                q["properties"] = [n for n in q["properties"] if n in self.fields[ii]]
+            allowed = FilterContext(idx).allowed_set(where)
+            d, s = refcases.oracle_search(idx, q, self.fields[ii], allowed=allowed)
+            docs.extend(int(x) for x in d)
+            scores.extend(s)
+        count = len(docs)
+        lim, off = p.get("limit", 10), p.get("offset", 0)
+        if not docs:
+            return [], 0
+        td, ts = orc.top_n(np.asarray(docs, dtype=np.uint64), np.asarray(scores, dtype=np.float32), lim + off)
+        return [(int(a), float(b)) for a, b in zip(td[off:], ts[off:])], count
+
+
+def check_expect(col, hits, count, exp):
+    if "count" in exp:
+        assert count == exp["count"], (count, exp)
+    if "n_hits" in exp:
+        assert len(hits) == exp["n_hits"], (len(hits), exp)
+    if "ids" in exp:
+        assert [col.string_id(h[0]) for h in hits] == exp["ids"]
+    if "hit_ids_mod" in exp:
+        m, r = exp["hit_ids_mod"]
+        assert all(int(col.string_id(h[0])) % m == r for h in hits), hits
+
+
+def run_case(case, make_collection, search):
+    """Every step of the case: mutations applied, searches answered by `search(col, params) -> (hits, count)` and checked against
+    the reference's expectations AND the oracle's answer (ids in order, scores bit for bit, count)."""
+    col = make_collection(case)
+    for step in case["steps"]:
+        if step["op"] != "search":
+            col.apply(step)
+            continue
+        exp = step["expect"]
+        if exp.get("error") == "FilterFieldNotFound":
+            for fn in (lambda: col.oracle_search(step["params"]), lambda: search(col, step["params"])):
+                try:
+                    fn()
+                except FilterFieldNotFound:
+                    continue
+                raise AssertionError("expected FilterFieldNotFound")
+            continue
+        o_hits, o_count = col.oracle_search(step["params"])
+        check_expect(col, o_hits, o_count, exp)
+        hits, count = search(col, step["params"])
+        check_expect(col, hits, count, exp)
+        assert count == o_count and [h[0] for h in hits] == [h[0] for h in o_hits], (step["params"], hits, o_hits)
+        assert np.array_equal(np.array([h[1] for h in hits], dtype=np.float32).view(np.uint32),
+                              np.array([h[1] for h in o_hits], dtype=np.float32).view(np.uint32)), (step["params"], hits, o_hits)
+    return col

@@ -14,6 +14,21 @@ class HostIndex:
     def __init__(self):
         self.string_fields, self.omc, self.document_ids = {}, {}, set()
         self.bool_fields, self.number_fields, self.string_filter_fields = {}, {}, {}
+        self.uncommitted_deleted_documents = set()
+
+    def delete_documents(self, doc_ids):
+        """IndexWriteOperation::DeleteDocuments (index/mod.rs:1346-1424) on the host-side state (the mirror's Index does the same
+        and keeps the device in step)."""
+        for d in doc_ids:
+            if d not in self.document_ids:
+                continue
+            self.document_ids.discard(d)
+            for sf in self.string_fields.values():
+                sf.delete(d)
+            for store in (self.bool_fields, self.number_fields, self.string_filter_fields):
+                for vals in store.values():
+                    vals.pop(d, None)
+            self.omc.pop(d, None)
 
     @property
     def document_count(self):
@@ -74,8 +89,9 @@ def levenshtein(a: bytes, b: bytes) -> int:
 DEFAULT_EXACT_MATCH_BOOST = 1.5  # = oramacore_amd.token_score.DEFAULT_EXACT_MATCH_BOOST (asserted in tests/test_reference_cases.py)
 
 
-def oracle_search(idx, p, fields, exact_match_boost=DEFAULT_EXACT_MATCH_BOOST):
-    """One search of a case through the CPU restatement: (docs, scores) of the whole map after OMC."""
+def oracle_search(idx, p, fields, exact_match_boost=DEFAULT_EXACT_MATCH_BOOST, allowed=None):
+    """One search of a case through the CPU restatement: (docs, scores) of the whole map after OMC.  `allowed`: the set of
+    documents that pass the filter (collect_contributions_with_filter: the others never reach the scorer), None = no filter."""
     fmap = {name: fi for fi, name in enumerate(fields)}
     exact = p.get("exact", False)
     tokens = tokens_of(p["term"], exact)
@@ -94,7 +110,7 @@ def oracle_search(idx, p, fields, exact_match_boost=DEFAULT_EXACT_MATCH_BOOST):
                 bo = F(boost.get(fid, 1.0))
                 if term == tok and exact_match_boost != 1.0:
                     bo = F(bo * F(exact_match_boost))
-                pl = sorted(sf.postings[term].items())
+                pl = sorted((d, tf) for d, tf in sf.postings[term].items() if allowed is None or d in allowed)
                 entries.append((ti, [d for d, _ in pl],
                                 [F(bo * orc.bm25f_normalized_tf(tf, sf.field_len[d], sf.avg_field_length(), 0.75)) for d, tf in pl]))
     thr = None if p.get("threshold") is None else int(np.floor(F(len(tokens)) * F(p["threshold"])))
