@@ -136,6 +136,16 @@ int orama_ctx_set_two_stage(orama_ctx* ctx, int on);
  * dimension is a multiple of 32 and <= 864 (the query tile lives in LDS); everything else keeps K1 / K1b.  The distance of a
  * (row, query) pair does not depend on the batch it was asked in (one fixed fmaf chain per pair). */
 int orama_ctx_set_f32_batch(orama_ctx* ctx, int min_queries);
+/* Tuning / test options of a context, by name — NOT needed by a deployment (the defaults are the measured choices of DESIGN.md) and
+ * never read from the environment by the product library (its whole environment is the deployment list of INTEGRATION.md §5b).
+ * Every option selects between code paths that return the SAME answers (the parity tests run them against each other):
+ *   "fused_topk" 0/1/2, "f32_multi" 0/1, "f16_solo" 0..2, "f16_wide" 0..5, "f16_kc" 8|12|16, "f16_nbuf" 2..4,
+ *   "f16_head_rows" (0 = 131 072), "f16_cand_mib" (0 = 6 144), "f16_chunk_grow" -1/0/1, "f16_grow_factor" 2..64,
+ *   "two_stage_spare" 1..4096, "k3r_target" 16..2048, "bm25_ranges" 0/1, "bm25_ranges_hybrid" 0/1, "select_wide" 0..3,
+ *   "select_pairs" 0/1, "hybrid_device_tail" 0/1, "direct_out" 0/1, "stage_copy" 0/1 (1 = by kernel), "scan_done_event" 0/1.
+ * ORAMA_ERR_INVALID for an unknown name or a value outside the option's range.  (Comparison builds — ORAMA_COMPARISON_KERNELS=1,
+ * liborama_hip_cmp.so — additionally accept each option as ORAMA_<NAME> in the environment, with the timing ablations and traces.) */
+int orama_ctx_set_option(orama_ctx* ctx, const char* name, long long value);
 
 /* Per-kernel HIP-event timing (used by bench.py's roofline leg).  When enabled, the library
  * brackets each launch of the named hot kernels with hipEvents on the launching stream.

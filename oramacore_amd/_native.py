@@ -132,6 +132,7 @@ def _declare(lib: C.CDLL) -> None:
         "orama_ctx_set_bm25_ranges": [vp, C.c_int],
         "orama_ctx_set_two_stage": [vp, C.c_int],
         "orama_ctx_set_f32_batch": [vp, C.c_int],
+        "orama_ctx_set_option": [vp, C.c_char_p, C.c_longlong],
         "orama_prof_enable": [vp, C.c_int],
         "orama_prof_reset": [vp],
         "orama_prof_get": [vp, C.c_char_p, C.POINTER(C.c_double), u64p],

@@ -89,6 +89,10 @@ class Context(Owner):
         mode = 4 if compact_keys == "always" else 3 if not compact_keys else 1 if hybrid else 2
         N.check(self._lib.orama_ctx_set_bm25_ranges(self.handle, mode if on else 0))
 
+    def set_option(self, name: str, value: int) -> None:
+        """A tuning / test option by name (orama_ctx_set_option): alternative code paths with the same answers — nothing a deployment sets."""
+        N.check(self._lib.orama_ctx_set_option(self.handle, name.encode(), int(value)))
+
     def set_f32_batch(self, min_queries: int = 9) -> None:
         """Plain fp32 stores: batches of >= min_queries queries take K1m (fp32 MFMA, <= 32 queries per corpus pass); 0 = never."""
         N.check(self._lib.orama_ctx_set_f32_batch(self.handle, int(min_queries)))

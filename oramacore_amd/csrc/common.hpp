@@ -23,6 +23,21 @@
 
 namespace orama {
 
+// The environment of the PRODUCT library is the deployment allow-list (ORAMA_RCCL_LIB, ORAMA_SCRATCH_POOL_MIB,
+// ORAMA_MAX_INFLIGHT, ORAMA_ACQUIRE_TIMEOUT_MS, ORAMA_SHARD_LANES, ORAMA_TWO_STAGE, ORAMA_VMM — read with std::getenv where they
+// apply; tests/test_abi.py greps for any other).  Sweeps, A/B switches, timing ablations and traces are read through dev_env:
+// nullptr unless the library was built as the comparison flavour (ORAMA_COMPARISON_KERNELS=1, liborama_hip_cmp.so) — a variable
+// that can change an answer or a code path has no business in liborama_hip.so.  What tests and tuning
+// scripts legitimately switch goes through orama_ctx_set_option.
+inline const char* dev_env(const char* name) {
+#if ORAMA_COMPARISON_KERNELS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // ---------------------------------------------------------------- errors
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 void clear_error();
@@ -292,6 +307,14 @@ struct orama_ctx {
     // of scratch the shallow ring fits three waves per SIMD (130-158 VGPRs) and that is worth more than a third chunk in
     // flight (16 queries: 2.29 vs 2.37 ms per pass, 64 queries: equal; profiles/r03_k2_ring_sweep.log)
     int f16_kc = 8, f16_nbuf = 2;
+    // fp16 filter scans (vec_store.hip search_enqueue_f16; orama_ctx_set_option "f16_head_rows" / "f16_cand_mib" / "f16_chunk_grow" /
+    // "f16_grow_factor"): rows of the dense head (0 = 131 072), candidate budget in MiB (0 = 6 GiB), super-chunk growth (-1 = the
+    // rule: on for wide passes, 0 off, 1 on) and its factor
+    uint64_t f16_head_rows = 0, f16_cand_mib = 0;
+    int f16_chunk_grow = -1, f16_grow_factor = 2;
+    uint32_t two_stage_spare = 256;  // spare candidates of the two-stage plan ("two_stage_spare")
+    uint32_t k3r_target = 1536;      // postings per document range of K3r ("k3r_target")
+    bool select_pairs = true;        // K4: (value, index) lists in two launches ("select_pairs" 0 = histogram passes)
     int compute_units = 0;
     uint64_t hbm_bytes = 0;
     char name[256] = {0};

@@ -286,6 +286,48 @@ struct orama_allow {
     uint64_t bits = 0;
 };
 
+namespace {
+// Options of orama_ctx_set_option: what tests and tuning scripts switch on a context (none is needed by a deployment).
+struct CtxOption {
+    const char* name;
+    long long lo, hi;
+    int (*set)(orama_ctx*, long long);
+};
+#define ORAMA_OPT(NAME, LO, HI, STMT) \
+    CtxOption { NAME, LO, HI, [](orama_ctx* c, long long v) -> int { STMT; return ORAMA_OK; } }
+const CtxOption kCtxOptions[] = {
+    ORAMA_OPT("fused_topk", 0, 2, c->fused_topk = (int)v),                  // K1 per-wave top-k: 0 never, 1 always, 2 = the rule
+    ORAMA_OPT("f32_multi", 0, 1, c->f32_multi = (int)v),                    // K1b for 2..8 fp32 queries
+    ORAMA_OPT("f16_solo", 0, 2, c->f16_solo = (int)v),                      // K1h for shadow scans of <= 4 queries
+    ORAMA_OPT("f16_wide", 0, 5, c->f16_wide = (int)v),                      // (orama_ctx_set_f16_wide validates against the build)
+    ORAMA_OPT("f16_kc", 8, 16, c->f16_kc = (int)v),
+    ORAMA_OPT("f16_nbuf", 2, 4, c->f16_nbuf = (int)v),
+    ORAMA_OPT("bm25_ranges", 0, 1, c->bm25_ranges = (int)v),
+    ORAMA_OPT("f16_head_rows", 0, 1ll << 24, c->f16_head_rows = (uint64_t)v),
+    ORAMA_OPT("f16_cand_mib", 0, 1ll << 20, c->f16_cand_mib = (uint64_t)v),
+    ORAMA_OPT("f16_chunk_grow", -1, 1, c->f16_chunk_grow = (int)v),
+    ORAMA_OPT("f16_grow_factor", 2, 64, c->f16_grow_factor = (int)v),
+    ORAMA_OPT("two_stage_spare", 1, 4096, c->two_stage_spare = (uint32_t)v),
+    ORAMA_OPT("k3r_target", 16, 2048, c->k3r_target = (uint32_t)v),
+    ORAMA_OPT("bm25_ranges_hybrid", 0, 1, c->bm25_ranges_hybrid = v != 0),
+    ORAMA_OPT("select_wide", 0, 3, c->select_wide = (int)v),                // K4 over a lone query's distances (select.hip)
+    ORAMA_OPT("select_pairs", 0, 1, c->select_pairs = v != 0),
+#if ORAMA_COMPARISON_KERNELS
+    ORAMA_OPT("hybrid_device_tail", 0, 1, c->hybrid_device_tail = v != 0),  // orama_hybrid_search finishes on the device (hybrid_tail.hip)
+#else
+    CtxOption{"hybrid_device_tail", 0, 1, [](orama_ctx*, long long v) -> int {  // a comparison unit: not in this library
+                  if (v == 0) return ORAMA_OK;
+                  orama::set_error("hybrid_device_tail: hybrid_tail.hip is built into liborama_hip_cmp.so only (ORAMA_COMPARISON_KERNELS=1)");
+                  return ORAMA_ERR_UNSUPPORTED;
+              }},
+#endif
+    ORAMA_OPT("direct_out", 0, 1, c->direct_out = v != 0),
+    ORAMA_OPT("stage_copy", 0, 1, c->stage_by_kernel = v != 0),             // 1 = small blocks by kernel, 0 = SDMA copies
+    ORAMA_OPT("scan_done_event", 0, 1, c->scan_done_on_dispatch = v != 0),  // 1 = the event rides on the scan's dispatch
+};
+#undef ORAMA_OPT
+}  // namespace
+
 extern "C" {
 
 int orama_allow_create(orama_ctx* ctx, const uint64_t* words, uint64_t bitmap_bits, orama_allow** out) {
@@ -401,29 +443,30 @@ int orama_ctx_create(int device_ordinal, orama_ctx** out) {
         return ORAMA_ERR_OOM;
     }
     c->scan_tuning = orama::default_scan_tuning();
-    if (const char* e = std::getenv("ORAMA_FUSED_TOPK")) c->fused_topk = std::atoi(e);
-    if (const char* e = std::getenv("ORAMA_F32_MULTI")) c->f32_multi = std::atoi(e);
-    if (const char* e = std::getenv("ORAMA_F16_WIDE")) c->f16_wide = std::atoi(e);
-#if !ORAMA_COMPARISON_KERNELS
-    if (c->f16_wide == 1 || c->f16_wide == 5) c->f16_wide = 4;  // K2c / K2h are not in this build
-#endif
-    if (const char* e = std::getenv("ORAMA_BM25_RANGES")) c->bm25_ranges = std::atoi(e) != 0;
-    if (const char* e = std::getenv("ORAMA_K3R_COMPACT")) c->bm25_compact_keys = std::atoi(e) != 0;
-    if (const char* e = std::getenv("ORAMA_SCAN_DONE_EVENT")) c->scan_done_on_dispatch = std::strcmp(e, "record") != 0;
-    if (const char* e = std::getenv("ORAMA_SELECT_WIDE")) c->select_wide = std::atoi(e);
-    if (const char* e = std::getenv("ORAMA_DIRECT_OUT")) c->direct_out = std::atoi(e) != 0;
-    if (const char* e = std::getenv("ORAMA_STAGE_COPY")) c->stage_by_kernel = std::strcmp(e, "dma") != 0;
-    if (const char* e = std::getenv("ORAMA_HYBRID_DEVICE_TAIL")) c->hybrid_device_tail = std::atoi(e) != 0;
-    if (const char* e = std::getenv("ORAMA_BM25_RANGES_HYBRID")) c->bm25_ranges_hybrid = std::atoi(e) != 0;
-#if ORAMA_COMPARISON_KERNELS
-    if (const char* e = std::getenv("ORAMA_K3R_MERGE")) c->k3r_merge = std::atoi(e) != 0;
-#endif
+    // deployment knobs (the product library's whole environment, with ORAMA_RCCL_LIB / ORAMA_SHARD_LANES in shard_group.hip,
+    // ORAMA_SCRATCH_POOL_MIB above and ORAMA_VMM in vec_store.hip)
     if (const char* e = std::getenv("ORAMA_TWO_STAGE")) c->two_stage = std::max(0, std::min(2, std::atoi(e)));
-    if (const char* e = std::getenv("ORAMA_F16_SOLO")) c->f16_solo = std::atoi(e);
-    if (const char* e = std::getenv("ORAMA_F16_KC")) c->f16_kc = std::atoi(e);
-    if (const char* e = std::getenv("ORAMA_F16_NBUF")) c->f16_nbuf = std::atoi(e);
     if (const char* e = std::getenv("ORAMA_MAX_INFLIGHT")) c->max_inflight = (uint32_t)std::max(2, std::atoi(e));
     if (const char* e = std::getenv("ORAMA_ACQUIRE_TIMEOUT_MS")) c->acquire_timeout_ms = (uint32_t)std::max(1, std::atoi(e));
+#if ORAMA_COMPARISON_KERNELS
+    // comparison builds: every option of orama_ctx_set_option can also come from the environment as ORAMA_<NAME> (the A/B
+    // scripts of rounds 1-5 keep working against liborama_hip_cmp.so)
+    for (const CtxOption& o : kCtxOptions) {
+        std::string env = "ORAMA_";
+        for (const char* p = o.name; *p; ++p) env.push_back((char)std::toupper((unsigned char)*p));
+        if (const char* e = orama::dev_env(env.c_str())) {
+            long long v = 0;
+            if (std::strcmp(o.name, "scan_done_event") == 0) v = std::strcmp(e, "record") != 0;
+            else if (std::strcmp(o.name, "stage_copy") == 0) v = std::strcmp(e, "dma") != 0;
+            else v = std::atoll(e);
+            (void)o.set(c, v);
+        }
+    }
+    if (const char* e = orama::dev_env("ORAMA_K3R_COMPACT")) c->bm25_compact_keys = std::atoi(e) != 0;
+    if (const char* e = orama::dev_env("ORAMA_K3R_MERGE")) c->k3r_merge = std::atoi(e) != 0;
+#else
+    if (c->f16_wide == 1 || c->f16_wide == 5) c->f16_wide = 4;  // K2c / K2h are not in this build
+#endif
     c->device = device_ordinal;
     c->compute_units = prop.multiProcessorCount;
     c->hbm_bytes = (uint64_t)prop.totalGlobalMem;
@@ -539,6 +582,17 @@ int orama_stream_synchronize(orama_ctx* ctx, void* stream) {
     ORAMA_ON_DEVICE(ctx->device);
     ORAMA_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return ORAMA_OK;
+}
+
+int orama_ctx_set_option(orama_ctx* ctx, const char* name, long long value) {
+    ORAMA_REQUIRE(ctx && name, "null argument");
+    for (const CtxOption& o : kCtxOptions) {
+        if (std::strcmp(o.name, name) != 0) continue;
+        ORAMA_REQUIRE(value >= o.lo && value <= o.hi, "option %s: %lld outside [%lld, %lld]", name, value, o.lo, o.hi);
+        return o.set(ctx, value);
+    }
+    orama::set_error("unknown option %s", name);
+    return ORAMA_ERR_INVALID;
 }
 
 int orama_ctx_set_f32_batch(orama_ctx* ctx, int min_queries) {

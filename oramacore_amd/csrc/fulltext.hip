@@ -623,12 +623,8 @@ bool ranges_eligible(const orama_post* p, const orama_term_ref* refs, uint32_t n
 // went 8 x narrower whatever the excess: lists over the same documents (a term in two fields) ran at a third of the rate of
 // independent lists ever after (scripts/bench_overlap_lists.py).  The factor that held is remembered per list set
 // (orama_post::shrink_hint).
-uint32_t choose_width(uint64_t n_docs, uint64_t total_postings, uint32_t narrow16) {
-    static const uint64_t target = [] {
-        const char* e = std::getenv("ORAMA_K3R_TARGET");
-        const long v = e ? std::atol(e) : 0;
-        return (uint64_t)(v >= 16 && v <= (long)kRangeCap ? v : 1536);
-    }();
+uint32_t choose_width(uint64_t n_docs, uint64_t total_postings, uint32_t narrow16, uint32_t target_opt) {
+    const uint64_t target = target_opt >= 16 && target_opt <= kRangeCap ? target_opt : 1536;  // option "k3r_target"
     uint64_t w = total_postings ? n_docs * target / total_postings : n_docs;
     if (narrow16 > 16u) w = w * 16u / narrow16;
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(w, 1), kRangeMaxWidth);
@@ -742,7 +738,7 @@ int hybrid_from_candidates(const RangeJob& jb, const RangeResult& res, const uin
 struct CallTrace {
     static constexpr int kMarks = 8;
     static bool on() {
-        static const bool v = std::getenv("ORAMA_POST_CALL_TRACE") != nullptr;
+        static const bool v = orama::dev_env("ORAMA_POST_CALL_TRACE") != nullptr;
         return v;
     }
     std::chrono::steady_clock::time_point t[kMarks];
@@ -766,7 +762,7 @@ struct CallTrace {
 
 // ORAMA_K3R_STATS=1: one stderr line per query scored with compact key lists (keys appended against postings).
 static bool k3r_stats_enabled() {
-    static const bool on = [] { const char* e = std::getenv("ORAMA_K3R_STATS"); return e && std::atoi(e) != 0; }();
+    static const bool on = [] { const char* e = orama::dev_env("ORAMA_K3R_STATS"); return e && std::atoi(e) != 0; }();
     return on;
 }
 
@@ -922,7 +918,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             q.key_off = (uint64_t)ci * max_total;
             q.bounds_base = bounds_entries;
             q.seg_begin = (uint32_t)segs.size();
-            q.width = choose_width(p->n_docs, pd.total, pd.shrink);
+            q.width = choose_width(p->n_docs, pd.total, pd.shrink, p->ctx->k3r_target);
             q.n_ranges = (uint32_t)((p->n_docs - 1) / q.width + 1);
             q.n_tokens = jb.params->n_tokens;
             q.use_threshold = jb.params->use_threshold != 0;
@@ -1085,7 +1081,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             m->epoch = rb.map_epoch;
             *jobs[0].map_list_len = (uint32_t)c.members[0].total;  // (the stride may be one slot longer: that slot is never written)
         }
-        if (const char* e = std::getenv("ORAMA_K3R_DBG")) rb.debug = (uint32_t)std::atoi(e);
+        if (const char* e = orama::dev_env("ORAMA_K3R_DBG")) rb.debug = (uint32_t)std::atoi(e);
         ORAMA_TRY(launch_range_bounds(p->ctx, rb, s));
         c.trace.mark(3);
         ORAMA_TRY(sc->h_out.reserve(out_bytes + 64));
@@ -1183,9 +1179,15 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             ta.out_flag = reinterpret_cast<uint32_t*>(d_tail);
             ta.out_count = reinterpret_cast<unsigned long long*>(d_tail + 8);
             ORAMA_HIP_TRY(hipStreamWaitEvent(s, jb.vec_ready, 0));
+#if ORAMA_COMPARISON_KERNELS
+            // (hybrid_tail.hip is a comparison unit since round 6: built, bit-identical, 40-70 us slower than the host tail —
+            // profiles/r05_hybrid_device_tail_ab.log; the product library cannot switch it on: orama_ctx_set_option refuses)
             ORAMA_TRY(launch_hybrid_vec_epilogue(ta, s));
             ORAMA_TRY(launch_range_score_docs(p->ctx, rb, 0, ta.vlocal, L, ta.vft, ta.vpresent, s, ta.state));
             ORAMA_TRY(launch_hybrid_merge(ta, s));
+#else
+            ORAMA_REQUIRE(false, "internal: the device hybrid tail is not in this build");
+#endif
             if (top_k) {
                 SelectPlan sp;  // top_n: score desc, DocumentId asc, NaN already left out (sort.rs:260-279)
                 sp.vals = ta.e_score;
@@ -1302,7 +1304,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
 
     uint32_t head = 0, inflight = 0;
     int rc = ORAMA_OK;
-    static const bool trace_flow = [] { const char* e = std::getenv("ORAMA_K3R_FLOW"); return e && std::atoi(e) != 0; }();
+    static const bool trace_flow = [] { const char* e = orama::dev_env("ORAMA_K3R_FLOW"); return e && std::atoi(e) != 0; }();
     const auto t_flow = std::chrono::steady_clock::now();
     auto us_flow = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_flow).count(); };
     while (rc == ORAMA_OK && (!pending.empty() || inflight)) {
@@ -2911,7 +2913,7 @@ int orama_shard_post_search_batch(orama_shard_group* g, orama_post* const* shard
     for (uint32_t i = 0; i < nl; ++i) ORAMA_REQUIRE(shards[i], "null shard %u", i);
     ShardCall call(g);  // one lane of the group from the first collective to the last
     ORAMA_TRY(call.init());
-    static const bool trace = std::getenv("ORAMA_SHARD_BATCH_TRACE") != nullptr;  // phase times of every block on stderr
+    static const bool trace = orama::dev_env("ORAMA_SHARD_BATCH_TRACE") != nullptr;  // phase times of every block on stderr
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     std::vector<int> status(n_queries, ORAMA_OK);

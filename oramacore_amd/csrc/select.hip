@@ -1512,10 +1512,6 @@ int launch_keys_topk(orama_ctx* ctx, const unsigned long long* d_keys, uint32_t 
     return ORAMA_OK;
 }
 
-static bool select_pairs_enabled() {
-    static const bool on = [] { const char* e = std::getenv("ORAMA_SELECT_PAIRS"); return !e || std::atoi(e) != 0; }();
-    return on;
-}
 
 int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
     ORAMA_REQUIRE(p.k >= 1, "top-k: k is 0");
@@ -1542,7 +1538,7 @@ int launch_select(orama_ctx* ctx, const SelectPlan& p, hipStream_t stream) {
     // (profiles/r04_c2_kernel_stats.md), the two launches ~30.
     const uint32_t parts_cap = p.q <= 4 ? std::max<uint32_t>(16u, kSelectMaxK / p.k) : 16u;
     const bool few_long = p.q <= 4 && list_chunks <= 8ull * std::min<uint32_t>(parts_cap, std::max<uint32_t>(1u, kSelectMaxK / p.k));
-    if (p.keys_capacity >= (uint64_t)p.q * kSelectMaxK && (list_chunks <= 16 || few_long) && select_pairs_enabled()) {
+    if (p.keys_capacity >= (uint64_t)p.q * kSelectMaxK && (list_chunks <= 16 || few_long) && ctx->select_pairs) {
         // (value, index) lists in two launches: `parts` workgroups per list keep their best k, one orders parts * k keys
         // (lists expected to be longer than 16 chunks keep the histogram passes, which spread one list over the chip).
         // Lists of a length known here (the dense heads of the fp16 scans: 131 072 distances per query) take it too since

@@ -909,7 +909,7 @@ __global__ void f16_remember_kth_kernel(const float* __restrict__ out_dist, cons
 uint64_t f16_tile_pad() {
     static const uint64_t pad = [] {
         uint64_t v = 0;  // measured: no effect on MI355X (profiles/r01_f16_tile_pad_sweep.md), so no padding
-        if (const char* e = std::getenv("ORAMA_F16_TILE_PAD")) v = (uint64_t)std::strtoull(e, nullptr, 10);
+        if (const char* e = orama::dev_env("ORAMA_F16_TILE_PAD")) v = (uint64_t)std::strtoull(e, nullptr, 10);
         return (v + 15) & ~15ull;
     }();
     return pad;
@@ -972,7 +972,7 @@ int launch_shadow_wave_check(const unsigned long long* d_wave_thr, uint32_t wave
 }
 
 int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a_in, hipStream_t stream) {
-    static const uint32_t k2dbg = [] { const char* e = std::getenv("ORAMA_K2_DBG"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    static const uint32_t k2dbg = [] { const char* e = orama::dev_env("ORAMA_K2_DBG"); return e ? (uint32_t)std::atoi(e) : 0u; }();
     F16ScanArgs a = a_in;
     if (!a.out_dense && !a.wave_lists) a.dbg = k2dbg;  // timing ablation of the filter-mode launches
     ORAMA_REQUIRE(a.tiled && a.inv_norm && a.queries, "vec_scan_f16: bad arguments");
@@ -985,7 +985,7 @@ int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a_in, hipStream_t str
         ProfScope prof(&ctx->prof, "vec_scan_f16", stream);
         const uint32_t ksteps = f16_kpad(a.dim) / 16;
         const size_t lds_bytes = (size_t)ksteps * 2 * 16 + 16 * sizeof(float);
-        static const int dbg = [] { const char* e = std::getenv("ORAMA_K1H_DBG"); return e ? std::atoi(e) : 0; }();
+        static const int dbg = [] { const char* e = orama::dev_env("ORAMA_K1H_DBG"); return e ? std::atoi(e) : 0; }();
         if (dbg == 1) hipLaunchKernelGGL((vec_scan_f16_solo_fused_kernel<12, 1>), dim3(waves / 4), dim3(256), lds_bytes, stream, a, ksteps, f16_tile_bytes(a.dim));
         else if (dbg == 2) hipLaunchKernelGGL((vec_scan_f16_solo_fused_kernel<12, 2>), dim3(waves / 4), dim3(256), lds_bytes, stream, a, ksteps, f16_tile_bytes(a.dim));
         else if (dbg == 3) hipLaunchKernelGGL((vec_scan_f16_solo_fused_kernel<12, 3>), dim3(waves / 4), dim3(256), lds_bytes, stream, a, ksteps, f16_tile_bytes(a.dim));
@@ -1007,7 +1007,7 @@ int launch_vec_scan_f16(orama_ctx* ctx, const F16ScanArgs& a_in, hipStream_t str
         const int nq = a.q == 1 ? 1 : (a.q == 2 ? 2 : 4);
         const size_t lds_bytes = (size_t)ksteps * 2 * nq * 16 + 16 * sizeof(float);
         if (ctx->f16_solo == 2 && ksteps % 12 == 0 && nq <= 2) {  // K1's loop shape: 256-thread blocks, a few per CU
-            static const int bpc = [] { const char* e = std::getenv("ORAMA_F16_SOLO_BPC"); return e ? std::atoi(e) : 2; }();
+            static const int bpc = [] { const char* e = orama::dev_env("ORAMA_F16_SOLO_BPC"); return e ? std::atoi(e) : 2; }();
             const dim3 g2(blocks_for((tiles + 1) / 2, 4, (uint32_t)ctx->compute_units * (uint32_t)bpc));
             if (nq == 1) hipLaunchKernelGGL((vec_scan_f16_solo2_kernel<1, 12>), g2, dim3(256), lds_bytes, stream, a, ksteps, f16_tile_bytes(a.dim));
             else hipLaunchKernelGGL((vec_scan_f16_solo2_kernel<2, 12>), g2, dim3(256), lds_bytes, stream, a, ksteps, f16_tile_bytes(a.dim));

@@ -498,7 +498,7 @@ bool vec_scan_f16_kh_supports(uint32_t dim, uint32_t q) {
 }
 
 int launch_vec_scan_f16_kh(orama_ctx* ctx, const F16ScanArgs& a_in, void* d_query_frags, hipStream_t stream) {
-    static const uint32_t k2dbg = [] { const char* e = std::getenv("ORAMA_K2_DBG"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    static const uint32_t k2dbg = [] { const char* e = orama::dev_env("ORAMA_K2_DBG"); return e ? (uint32_t)std::atoi(e) : 0u; }();
     F16ScanArgs a = a_in;
     if (!a.out_dense) a.dbg = k2dbg & 2u;  // timing ablation: no candidate appends
     ORAMA_REQUIRE(a.tiled && a.inv_norm && a.queries && d_query_frags, "vec_scan_f16_kh: bad arguments");
@@ -512,7 +512,7 @@ int launch_vec_scan_f16_kh(orama_ctx* ctx, const F16ScanArgs& a_in, void* d_quer
     const float* qinv = reinterpret_cast<const float*>(bfrag + (size_t)8 * ksteps * 1024);
     ProfScope prof(&ctx->prof, "vec_scan_f16", stream);
     int dbg = 0;
-    if (const char* e = std::getenv("ORAMA_K2C_DBG")) dbg = std::atoi(e);
+    if (const char* e = orama::dev_env("ORAMA_K2C_DBG")) dbg = std::atoi(e);
     switch (ksteps) {
         case 16: return kh_dispatch<16>(ctx, a, bfrag, qinv, stream, dbg);
         case 32: return kh_dispatch<32>(ctx, a, bfrag, qinv, stream, dbg);

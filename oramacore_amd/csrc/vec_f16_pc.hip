@@ -499,7 +499,7 @@ int pc_launch(orama_ctx* ctx, const F16ScanArgs& a, const char* bfrag, const flo
     if (blocks > (uint64_t)ctx->compute_units) blocks = (uint64_t)ctx->compute_units;
     unsigned long long* trace = nullptr;
     if (DBG & 16) {
-        const char* e = std::getenv("ORAMA_K2D_TRACE");  // device pointer of >= 64 KiB (hex), set by the probe script
+        const char* e = orama::dev_env("ORAMA_K2D_TRACE");  // device pointer of >= 64 KiB (hex), set by the probe script
         if (e) trace = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 16));
         ORAMA_REQUIRE(trace, "trace build needs ORAMA_K2D_TRACE");
     }
@@ -532,7 +532,7 @@ using PcD = PcCfg<3, 2, 2, 4, 4, 2, 5, 1>;
 using PcA2 = PcCfg<2, 2, 4, 2, 4, 2, 5, 1>;
 
 int launch_vec_scan_f16_pc(orama_ctx* ctx, const F16ScanArgs& a_in, void* d_query_frags, hipStream_t stream, int geometry) {
-    static const uint32_t k2dbg = [] { const char* e = std::getenv("ORAMA_K2_DBG"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    static const uint32_t k2dbg = [] { const char* e = orama::dev_env("ORAMA_K2_DBG"); return e ? (uint32_t)std::atoi(e) : 0u; }();
     F16ScanArgs a = a_in;
     if (!a.out_dense) a.dbg = k2dbg & 2u;  // timing ablation: no candidate appends
     ORAMA_REQUIRE(a.tiled && a.inv_norm && a.queries && d_query_frags, "vec_scan_f16_pc: bad arguments");
@@ -547,7 +547,7 @@ int launch_vec_scan_f16_pc(orama_ctx* ctx, const F16ScanArgs& a_in, void* d_quer
     const float* qinv = reinterpret_cast<const float*>(bfrag + (size_t)8 * ksteps * 1024);
     ProfScope prof(&ctx->prof, "vec_scan_f16", stream);
     int dbg = 0;
-    if (const char* e = std::getenv("ORAMA_K2C_DBG")) dbg = std::atoi(e);
+    if (const char* e = orama::dev_env("ORAMA_K2C_DBG")) dbg = std::atoi(e);
     if (dbg && !a.out_dense && geometry == 1 && a.q > 128) {  // ablation builds of the default geometry (timing only)
         switch (dbg) {
             case 9: return pc_launch<PcB, 9>(ctx, a, bfrag, qinv, ksteps, stream);    // DMA only

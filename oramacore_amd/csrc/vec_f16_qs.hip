@@ -523,7 +523,7 @@ int qs_launch_one(const F16ScanArgs& a, const char* bfrag, const float* qinv, ui
     }
     unsigned long long* trace = nullptr;
     if (DBG & 16) {
-        const char* e = std::getenv("ORAMA_K2D_TRACE");  // device pointer of >= 128 KiB (hex), set by the probe script
+        const char* e = orama::dev_env("ORAMA_K2D_TRACE");  // device pointer of >= 128 KiB (hex), set by the probe script
         if (e) trace = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 16));
         ORAMA_REQUIRE(trace, "trace build needs ORAMA_K2D_TRACE");
     }
@@ -579,7 +579,7 @@ int qs_dispatch(orama_ctx* ctx, const F16ScanArgs& a, const char* bfrag, const f
             }
         }
     }
-    static const bool lag = [] { const char* e = std::getenv("ORAMA_QS_LAG"); return !e || std::atoi(e) != 0; }();
+    static const bool lag = [] { const char* e = orama::dev_env("ORAMA_QS_LAG"); return !e || std::atoi(e) != 0; }();
     if constexpr (KSTEPS == 48) {
         if (!lag) {
             if (dbg == 32 && !a.out_dense) return qs_launch<QsLock<KSTEPS>, 32>(ctx, a, bfrag, qinv, stream);
@@ -596,7 +596,7 @@ int qs_dispatch(orama_ctx* ctx, const F16ScanArgs& a, const char* bfrag, const f
 bool vec_scan_f16_qs_supports(uint32_t dim, uint32_t q) { return f16_kpad(dim) <= 768 && q > 128 && q <= kF16WideMaxQ; }
 
 int launch_vec_scan_f16_qs(orama_ctx* ctx, const F16ScanArgs& a_in, void* d_query_frags, hipStream_t stream) {
-    static const uint32_t k2dbg = [] { const char* e = std::getenv("ORAMA_K2_DBG"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    static const uint32_t k2dbg = [] { const char* e = orama::dev_env("ORAMA_K2_DBG"); return e ? (uint32_t)std::atoi(e) : 0u; }();
     F16ScanArgs a = a_in;
     if (!a.out_dense) a.dbg = k2dbg & 2u;  // timing ablation: no candidate appends
     ORAMA_REQUIRE(a.tiled && a.inv_norm && a.queries && d_query_frags, "vec_scan_f16_qs: bad arguments");
@@ -611,7 +611,7 @@ int launch_vec_scan_f16_qs(orama_ctx* ctx, const F16ScanArgs& a_in, void* d_quer
     const float* qinv = reinterpret_cast<const float*>(bfrag + (size_t)8 * ksteps * 1024);
     ProfScope prof(&ctx->prof, "vec_scan_f16", stream);
     int dbg = 0;
-    if (const char* e = std::getenv("ORAMA_K2C_DBG")) dbg = std::atoi(e);
+    if (const char* e = orama::dev_env("ORAMA_K2C_DBG")) dbg = std::atoi(e);
     switch (ksteps) {
         case 8: return qs_dispatch<8>(ctx, a, bfrag, qinv, stream, dbg);
         case 16: return qs_dispatch<16>(ctx, a, bfrag, qinv, stream, dbg);

@@ -365,7 +365,7 @@ int launch_vec_scan_f16_wide(orama_ctx* ctx, const F16ScanArgs& a, void* d_query
     } while (0)
     const bool ks3 = ksteps % 3 == 0;
     int dbg = 0;
-    if (const char* e = std::getenv("ORAMA_K2C_DBG")) dbg = std::atoi(e);
+    if (const char* e = orama::dev_env("ORAMA_K2C_DBG")) dbg = std::atoi(e);
     if (dbg && ks3 && a.q > 128 && !a.out_dense) {  // ablation builds of the Q = 256, 768-dim shape (timing only)
         switch (dbg) {
             case 1: ORAMA_WIDE_LAUNCH(4, 3, 1); break;    // DMA + fragment reads, no MFMA

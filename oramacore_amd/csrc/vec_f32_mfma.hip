@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f32_mfma_kernel(F16ScanArgs a
 int launch_vec_scan_f32_mfma(orama_ctx* ctx, const F16ScanArgs& a_in, hipStream_t stream) {
     F16ScanArgs a = a_in;
 #if ORAMA_COMPARISON_KERNELS
-    static const uint32_t k1mdbg = [] { const char* e = std::getenv("ORAMA_K1M_DBG"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    static const uint32_t k1mdbg = [] { const char* e = orama::dev_env("ORAMA_K1M_DBG"); return e ? (uint32_t)std::atoi(e) : 0u; }();
 #endif
     a.dbg = 0;
     ORAMA_REQUIRE(a.tiled && a.inv_norm && a.queries, "vec_scan_f32_mfma: bad arguments");
@@ -458,7 +458,7 @@ int launch_vec_scan_f32_mfma(orama_ctx* ctx, const F16ScanArgs& a_in, hipStream_
     } while (0)
 #if ORAMA_COMPARISON_KERNELS
     // A/B builds: ORAMA_K1M_VARIANT = ring depth x 100 + 1 (query fragments a chunk ahead); ORAMA_K1M_DBG = a timing ablation
-    static const int variant = [] { const char* e = std::getenv("ORAMA_K1M_VARIANT"); return e ? std::atoi(e) : 0; }();
+    static const int variant = [] { const char* e = orama::dev_env("ORAMA_K1M_VARIANT"); return e ? std::atoi(e) : 0; }();
     if (k1mdbg) {
         switch (k1mdbg) {
             case 16: ORAMA_K1M_LAUNCH_ABL(4, true, 16); break;

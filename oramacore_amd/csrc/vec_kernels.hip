@@ -28,9 +28,9 @@ bool scan_tuning_valid(const ScanTuning& t) {
 
 ScanTuning default_scan_tuning() {
     ScanTuning x;
-    if (const char* e = std::getenv("ORAMA_SCAN_ROWS")) x.rows_per_wave = std::atoi(e);
-    if (const char* e = std::getenv("ORAMA_SCAN_BLOCKS_PER_CU")) x.blocks_per_cu = std::atoi(e);
-    if (const char* e = std::getenv("ORAMA_SCAN_NT")) x.nontemporal = std::atoi(e);
+    if (const char* e = orama::dev_env("ORAMA_SCAN_ROWS")) x.rows_per_wave = std::atoi(e);
+    if (const char* e = orama::dev_env("ORAMA_SCAN_BLOCKS_PER_CU")) x.blocks_per_cu = std::atoi(e);
+    if (const char* e = orama::dev_env("ORAMA_SCAN_NT")) x.nontemporal = std::atoi(e);
     if (!scan_tuning_valid(x)) x = ScanTuning();
     return x;
 }
@@ -515,7 +515,7 @@ int launch_row_inv_norm_f32(const float* corpus, uint64_t first, uint64_t n, uin
 int launch_synth_fill_f32(float* corpus, uint64_t first, uint64_t n, uint32_t dim, uint64_t seed,
                           hipStream_t stream) {
     if (n == 0) return ORAMA_OK;
-    static const bool unit_norm = [] { const char* e = std::getenv("ORAMA_SYNTH_UNIT_NORM"); return e && std::atoi(e) != 0; }();
+    static const bool unit_norm = [] { const char* e = orama::dev_env("ORAMA_SYNTH_UNIT_NORM"); return e && std::atoi(e) != 0; }();
     hipLaunchKernelGGL(synth_fill_kernel, dim3(grid_for_rows(n, 8192)), dim3(kScanThreads), 0, stream,
                        corpus, first, n, dim, seed, unit_norm);
     ORAMA_HIP_TRY(hipGetLastError());

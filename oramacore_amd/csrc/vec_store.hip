@@ -765,17 +765,12 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
             if (fw >= 4 && vec_scan_f16_qs_supports(args.dim, args.q)) return launch_vec_scan_f16_qs(v->ctx, args, sc->f16_bfrag.p, s);
             return launch_vec_scan_f16_pc(v->ctx, args, sc->f16_bfrag.p, s, fw == 3 ? 2 : 1);
         };
-        static const uint64_t head_rows = [] {  // ORAMA_F16_HEAD_ROWS: the dense head (sweeps; a multiple of 256)
-            const char* e = std::getenv("ORAMA_F16_HEAD_ROWS");
-            const uint64_t v = e ? std::strtoull(e, nullptr, 10) : 0;
-            return v >= 4096 && v % 256 == 0 ? v : kS1;
-        }();
+        // (option "f16_head_rows": the dense head — sweeps; a multiple of 256)
+        const uint64_t hr = v->ctx->f16_head_rows;
+        const uint64_t head_rows = hr >= 4096 && hr % 256 == 0 ? hr : kS1;
         const uint64_t s1 = std::min<uint64_t>(n, head_rows);
-        // super-chunk size: gq * (rows + k) * 8 B <= budget
-        static const uint64_t budget = [] {
-            const char* e = std::getenv("ORAMA_F16_CAND_MIB");
-            return e ? (uint64_t)std::strtoull(e, nullptr, 10) << 20 : kCandBudget;
-        }();
+        // super-chunk size: gq * (rows + k) * 8 B <= budget (option "f16_cand_mib")
+        const uint64_t budget = v->ctx->f16_cand_mib ? v->ctx->f16_cand_mib << 20 : kCandBudget;
         uint64_t chunk_rows = budget / ((uint64_t)gq * 8);
         chunk_rows = std::max<uint64_t>(chunk_rows & ~255ull, 1u << 20);  // whole K2c block tiles (256 rows)
         const uint64_t rest = n > s1 ? n - s1 : 0;
@@ -814,7 +809,7 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
         // ORAMA_F16_TAU_ORACLE=1, the CEILING of any threshold exchange between shards (scripts/
         // f16_tau_ceiling_probe.py): the filter passes run under the final k-th distances the PREVIOUS call of this scratch set
         // left behind (one ulp up) — exact only when that call asked the same queries, which the probe does
-        static const bool tau_oracle = [] { const char* e = std::getenv("ORAMA_F16_TAU_ORACLE"); return e && std::atoi(e) != 0; }();
+        static const bool tau_oracle = [] { const char* e = orama::dev_env("ORAMA_F16_TAU_ORACLE"); return e && std::atoi(e) != 0; }();
         const float* tau_cap = nullptr;
         if (tau_oracle && q0 == 0 && gq == q) {
             const bool have = sc->f16_tau_cap_q == gq && sc->f16_tau_cap_k == k;
@@ -860,14 +855,8 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
         // candidates each: 5.4 -> 3.2 ms of scan).  Since K2 and K2d stage passing rows in LDS and append them in bulk it
         // costs more than it saves at every batch size measured (two-stage: 100 queries 4.87 -> 3.88 ms without growth,
         // 128: 4.41 -> 3.94, 200: 6.10 -> 5.67, 64: 3.35 -> 2.97) and was OFF by default through round 3.
-        static const int grow_env = [] {
-            const char* e = std::getenv("ORAMA_F16_CHUNK_GROW");
-            return e ? std::atoi(e) : -1;
-        }();
-        static const uint64_t grow_factor_env = [] {
-            const char* e = std::getenv("ORAMA_F16_GROW_FACTOR");
-            return e ? (uint64_t)std::max(2, std::atoi(e)) : 2ull;
-        }();
+        const int grow_env = v->ctx->f16_chunk_grow;  // options "f16_chunk_grow" / "f16_grow_factor"
+        const uint64_t grow_factor_env = (uint64_t)std::max(2, v->ctx->f16_grow_factor);
         // Round 4: ON for the wide passes (more than 64 queries: K2q / K2d) with factor 8 — there the candidate budget cuts the rest
         // into ~3 M-row super-chunks anyway, and ONE extra small chunk behind the head (7 x 131 072 rows) hands the first big
         // one a threshold from 1 M rows instead of 131 072: 2 400 -> ~1 000 candidates per query, C5 shard 4.80 -> 4.69 ms per
@@ -984,10 +973,7 @@ int two_stage_search(orama_vec* v, Scratch* sc, Scratch* sc2, const float* d_que
     // k1 - k spare candidates decide how often the completeness proof fails: on the north-star corpus the 228th best
     // shadow distance lies ~7e-3 behind the 100th, barely more than 2 eps, and 0.1 % of the queries fell back to the
     // fp32 scan (4.3 ms each: 0.8 ms per batch of 256 on average); the 356th lies ~1e-2 behind.  Candidates are cheap.
-    static const uint64_t spare = [] {
-        const char* e = std::getenv("ORAMA_TWO_STAGE_SPARE");
-        return e ? (uint64_t)std::max(1, std::atoi(e)) : 256ull;
-    }();
+    const uint64_t spare = std::max<uint32_t>(1u, v->ctx->two_stage_spare);  // option "two_stage_spare"
     const uint32_t k1 = (uint32_t)std::min<uint64_t>(kSelectMaxK, std::max<uint64_t>(2ull * k, (uint64_t)k + spare));
     // stage 1 works in the second scratch set (the fp16 pipeline uses most buffers of one)
     const size_t n1 = (size_t)q * k1;

@@ -1,4 +1,6 @@
 # the answers written to the pinned host block by the selection's final launch (default) against a staging launch behind it: C4 (K3r batch, single calls, hybrid) and C2 (lone vector query)
+# (round 6: sweep / A-B variables are read by the COMPARISON flavour only — liborama_hip_cmp.so, built and loaded with this set)
+export ORAMA_COMPARISON_KERNELS=1
 for M in 1 0 1 0; do
   echo "== ORAMA_DIRECT_OUT=$M"
   ORAMA_DIRECT_OUT=$M python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-two-stage --configs c4 --no-pmc 2>/dev/null | python -c "

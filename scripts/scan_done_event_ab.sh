@@ -1,4 +1,6 @@
 # the scan's completion event on its dispatch (default) against a record packet behind it (ORAMA_SCAN_DONE_EVENT=record)
+# (round 6: sweep / A-B variables are read by the COMPARISON flavour only — liborama_hip_cmp.so, built and loaded with this set)
+export ORAMA_COMPARISON_KERNELS=1
 for M in dispatch record dispatch record; do
   echo "== ORAMA_SCAN_DONE_EVENT=$M"
   for W in c2 ns; do

@@ -1,4 +1,6 @@
 export ORAMA_K3R_STATS=0
+# (round 6: sweep / A-B variables are read by the COMPARISON flavour only — liborama_hip_cmp.so, built and loaded with this set)
+export ORAMA_COMPARISON_KERNELS=1
 mkdir -p gpurun_out
 (
 for M in kernel dma; do

@@ -70,3 +70,31 @@ def test_integration_doc_mentions_every_entry_point():
     doc = (_build.ROOT / "INTEGRATION.md").read_text()
     missing = [s for s in _native.declared_symbols() if s not in doc]
     assert not missing, missing
+
+
+def test_product_library_reads_only_the_deployment_environment():
+    """46 ORAMA_* switches — debug hooks, ablations, one that could make answers wrong — were read by
+    liborama_hip.so.  The product library's environment is the deployment allow-list; everything else goes through
+    orama::dev_env (nullptr unless built as the comparison flavour) or orama_ctx_set_option."""
+    allow = {"ORAMA_RCCL_LIB", "ORAMA_SCRATCH_POOL_MIB", "ORAMA_MAX_INFLIGHT", "ORAMA_ACQUIRE_TIMEOUT_MS", "ORAMA_SHARD_LANES",
+             "ORAMA_TWO_STAGE", "ORAMA_VMM"}
+    seen, offenders = set(), []
+    for p in sorted(list(_build.CSRC.glob("*.hip")) + list(_build.CSRC.glob("*.hpp")) + list(_build.CSRC.glob("*.inc"))):
+        text = p.read_text(errors="replace")
+        for m in re.finditer(r"(?<![A-Za-z_:])(?:std::)?getenv\(([^)]*)\)", text):
+            arg = m.group(1).strip()
+            line = text[: m.start()].count("\n") + 1
+            ctx_line = text.splitlines()[line - 1]
+            if p.name == "common.hpp" and "dev_env" in text[max(0, m.start() - 300): m.start()]:
+                continue  # dev_env itself
+            name = arg.strip('"')
+            if arg.startswith('"') and name in allow:
+                seen.add(name)
+                continue
+            offenders.append(f"{p.name}:{line}: {ctx_line.strip()}")
+    assert not offenders, offenders
+    assert seen == allow, (seen ^ allow)
+    # and INTEGRATION.md documents exactly that list as the deployment environment
+    doc = (_build.ROOT / "INTEGRATION.md").read_text()
+    for name in allow:
+        assert f"`{name}`" in doc, name

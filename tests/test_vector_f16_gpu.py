@@ -251,6 +251,9 @@ import numpy as np
 sys.path.insert(0, sys.argv[1])
 import oramacore_amd as oa
 ctx = oa.Context(0)
+for opt in sys.argv[2:]:
+    name, value = opt.split("=")
+    ctx.set_option(name, int(value))
 n, d, k = 1_300_000, 64, 50
 st = oa.EmbeddingFieldStorage(ctx, dimensions=d, dtype=oa.DTYPE_F16, reserve_rows=n)
 st.fill_synthetic(n, seed=0xABCD)
@@ -267,8 +270,8 @@ print(json.dumps(out))
 
 
 def test_super_chunks_and_growing_chunks_give_the_same_answer(tmp_path):
-    """The filter scan runs in super-chunks (candidate budget) that may grow geometrically; both are decided by
-    environment variables read once per process, so each variant runs in its own process: one chunk (default budget),
+    """The filter scan runs in super-chunks (candidate budget) that may grow geometrically; both are context options
+    (orama_ctx_set_option "f16_cand_mib" / "f16_chunk_grow"); each variant runs in its own process: one chunk (default budget),
     two chunks of >= 1 M rows (1 MiB budget), and growing chunks (131 072, 262 144, ... rows) — for K2 (3 and 64
     queries) and the wide kernel (70).  Ids, distance bits and counts must be identical."""
     import json, os, subprocess, sys
@@ -277,10 +280,8 @@ def test_super_chunks_and_growing_chunks_give_the_same_answer(tmp_path):
     script = tmp_path / "chunks.py"
     script.write_text(_CHUNK_SCRIPT)
     outs = []
-    for extra in ({}, {"ORAMA_F16_CAND_MIB": "1"}, {"ORAMA_F16_CAND_MIB": "1", "ORAMA_F16_CHUNK_GROW": "1"}):
-        env = dict(os.environ)
-        env.update(extra)
-        r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=300)
+    for extra in ([], ["f16_cand_mib=1"], ["f16_cand_mib=1", "f16_chunk_grow=1"]):
+        r = subprocess.run([sys.executable, str(script), root, *extra], env=dict(os.environ), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1] == outs[2], outs

@@ -292,8 +292,8 @@ def test_concurrent_searches_with_inserts_and_deletes(ctx):
     st.close()
 
 
-def test_experimental_fused_topk_path_is_exact(monkeypatch):
-    """ORAMA_FUSED_TOPK=1 (per-wave register top-k inside K1; by default only for one query over a large corpus) must
+def test_experimental_fused_topk_path_is_exact():
+    """Option "fused_topk" = 1 (per-wave register top-k inside K1; by default only for one query over a large corpus) must
     return exactly what the default dense path returns."""
     n, d = 30_000, 768
     corpus = util.gaussian_rows(n, d, seed=301)
@@ -304,8 +304,8 @@ def test_experimental_fused_topk_path_is_exact(monkeypatch):
     want = [st.storage_search(queries, k) for k in (1, 10, 100, 128)]
     st.close()
     base_ctx.close()
-    monkeypatch.setenv("ORAMA_FUSED_TOPK", "1")
     fctx = oa.Context(0)
+    fctx.set_option("fused_topk", 1)
     st = make_store(fctx, corpus)
     for k, w in zip((1, 10, 100, 128), want):
         got = st.storage_search(queries, k)
@@ -438,14 +438,14 @@ def test_ties_at_the_cut_are_decided_by_row_index_whatever_the_list_length(ctx):
 
 
 @pytest.mark.parametrize("mode", ["1", "2", "0"])
-def test_a_lone_query_over_a_long_dense_list_takes_one_round_per_part(monkeypatch, mode):
+def test_a_lone_query_over_a_long_dense_list_takes_one_round_per_part(mode):
     """Round 5: the distance array of a lone query (> 16 chunks of 8 192 values) is cut by
-    pairs_reduce_wide_kernel — a part's <= 32 768 values in registers, one bound, one cut.  ORAMA_SELECT_WIDE=2 forces the
+    pairs_reduce_wide_kernel — a part's <= 32 768 values in registers, one bound, one cut.  Option "select_wide" = 2 forces the
     rounds it falls back to when more keys reach the bound than LDS holds, 0 the rounds of round 4: three forms, one answer —
     checked against a host selection over the distances the device reports for every row (limit = n is not offered: the
     distances come from the rows read back), with exact ties across the cut and NaN-free inputs of three lengths."""
-    monkeypatch.setenv("ORAMA_SELECT_WIDE", mode)
     c = oa.Context(0)
+    c.set_option("select_wide", int(mode))
     d = 16
     rng = np.random.default_rng(5150)
     for n, ks in ((140_000, (1, 100)), (300_000, (10, 100, 256)), (1_000_003, (100, 128))):
