@@ -204,7 +204,11 @@ class GsSummary(ctypes.Structure):
                 ("xcd_spread_mhz_max", _C.c_double), ("socket_power_w_mean", _C.c_double), ("socket_power_w_max", _C.c_double),
                 ("energy_j", _C.c_double), ("energy_power_w", _C.c_double), ("ppt_residency_pct", _C.c_double),
                 ("thm_residency_pct", _C.c_double), ("gfx_activity_pct_median", _C.c_double), ("xcds_reporting", _C.c_uint32),
-                ("rsmi_index", _C.c_uint32), ("bdfid", _C.c_uint64)]
+                ("rsmi_index", _C.c_uint32), ("bdfid", _C.c_uint64),
+                # round 6: the memory side (uclk, fabric clock, HBM temperature, memory-controller activity, per-XCD busy spread)
+                ("uclk_mhz_median", _C.c_double), ("uclk_mhz_min", _C.c_double), ("socclk_mhz_median", _C.c_double),
+                ("temp_hbm_c_max", _C.c_double), ("temp_mem_c_max", _C.c_double), ("temp_hotspot_c_max", _C.c_double),
+                ("umc_activity_pct_median", _C.c_double), ("xcd_busy_spread_pct", _C.c_double)]
 
 
 _SAMPLER_LIB = None
@@ -318,7 +322,13 @@ class ClockSampler:
                        energy_j=g.energy_j or None, power_w_from_energy_counter=g.energy_power_w or None,
                        ppt_throttle_residency_pct=None if g.ppt_residency_pct < 0 else g.ppt_residency_pct,
                        thermal_throttle_residency_pct=None if g.thm_residency_pct < 0 else g.thm_residency_pct,
-                       gfx_activity_pct_median=None if g.gfx_activity_pct_median < 0 else g.gfx_activity_pct_median)
+                       gfx_activity_pct_median=None if g.gfx_activity_pct_median < 0 else g.gfx_activity_pct_median,
+                       uclk_mhz_median=g.uclk_mhz_median or None, uclk_mhz_min=g.uclk_mhz_min or None,
+                       socclk_mhz_median=g.socclk_mhz_median or None,
+                       temp_hbm_c_max=g.temp_hbm_c_max or None, temp_mem_c_max=g.temp_mem_c_max or None,
+                       temp_hotspot_c_max=g.temp_hotspot_c_max or None,
+                       umc_activity_pct_median=None if g.umc_activity_pct_median < 0 else g.umc_activity_pct_median,
+                       xcd_busy_spread_pct=None if g.xcd_busy_spread_pct < 0 else g.xcd_busy_spread_pct)
             if g.gfxclk_mhz_median < self.BUSY_MIN_MHZ:
                 out.update(available=False, reason=f"median clock {g.gfxclk_mhz_median:.0f} MHz during a busy region: not this GPU's "
                                                    "clock domain (or the table is stale) — record kept for inspection, not evidence")

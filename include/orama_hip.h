@@ -121,9 +121,9 @@ int orama_ctx_set_f16_wide(orama_ctx* ctx, int mode);
 /* Scorer of the BM25 searches over a resident store: 1 (default) = K3r, the document-range partitioned scorer that takes
  * whole query batches per launch (bm25_ranges.hip) — for the plain top-k search and, where no OMC applies, for
  * orama_post_search_hybrid; 2 = K3r for the plain search only; 0 = K3, per-document records in HBM (bm25_kernels.hip),
- * which the score-map / precomputed-ntf / fused-hybrid entry points always use; 3 = as 1 with round 4's key lists (one key
- * slot per posting; the default appends only the keys that can still reach the answer, for batches of 8 queries or more —
- * A/B runs), 4 = as 1 with the compact lists for every batch size (parity tests).  Same results bit for bit. */
+ * which the score-map / precomputed-ntf / fused-hybrid entry points always use.  Modes 0-2 leave the key-list form alone (option
+ * "k3r_compact" of orama_ctx_set_option); 3 / 4 are kept as shorthands: mode 1 + "k3r_compact" 0 (round 4's lists, one key slot
+ * per posting) / 2 (compact lists for every batch size).  Same results bit for bit. */
 int orama_ctx_set_bm25_ranges(orama_ctx* ctx, int on);
 /* ORAMA_DTYPE_F32_SHADOW16 stores: 1 (default) = two-stage search where it pays (batches of more than 8 queries, or at
  * least 4 GB of fp32 rows: below that the plain scan is faster than the second stage's launches), 2 = always two stages,
@@ -141,7 +141,8 @@ int orama_ctx_set_f32_batch(orama_ctx* ctx, int min_queries);
  * Every option selects between code paths that return the SAME answers (the parity tests run them against each other):
  *   "fused_topk" 0/1/2, "f32_multi" 0/1, "f16_solo" 0..2, "f16_wide" 0..5, "f16_kc" 8|12|16, "f16_nbuf" 2..4,
  *   "f16_head_rows" (0 = 131 072), "f16_cand_mib" (0 = 6 144), "f16_chunk_grow" -1/0/1, "f16_grow_factor" 2..64,
- *   "two_stage_spare" 1..4096, "k3r_target" 16..2048, "bm25_ranges" 0/1, "bm25_ranges_hybrid" 0/1, "select_wide" 0..3,
+ *   "two_stage_spare" 1..4096, "k3r_target" 16..2048, "k3r_compact" 0/1/2 (key lists: one slot per posting / compact for batches
+ *   of >= 8 queries / always compact), "bm25_ranges" 0/1, "bm25_ranges_hybrid" 0/1, "select_wide" 0..3,
  *   "select_pairs" 0/1, "hybrid_device_tail" 0/1, "direct_out" 0/1, "stage_copy" 0/1 (1 = by kernel), "scan_done_event" 0/1.
  * ORAMA_ERR_INVALID for an unknown name or a value outside the option's range.  (Comparison builds — ORAMA_COMPARISON_KERNELS=1,
  * liborama_hip_cmp.so — additionally accept each option as ORAMA_<NAME> in the environment, with the timing ablations and traces.) */

@@ -82,12 +82,14 @@ class Context(Owner):
         scan; always=True takes the two stages for small stores too."""
         N.check(self._lib.orama_ctx_set_two_stage(self.handle, (2 if always else 1) if on else 0))
 
-    def set_bm25_ranges(self, on: bool, hybrid: bool = True, compact_keys: bool | str = True) -> None:
-        """BM25 searches: True = K3r range-partitioned batch scorer (default; hybrid=False keeps it to the plain top-k
-        search; compact_keys=False = round 4's key lists, one slot per posting; "always" = compact lists for every batch
-        size, not only for 8 queries and more), False = K3 per-document records."""
-        mode = 4 if compact_keys == "always" else 3 if not compact_keys else 1 if hybrid else 2
-        N.check(self._lib.orama_ctx_set_bm25_ranges(self.handle, mode if on else 0))
+    def set_bm25_ranges(self, on: bool, hybrid: bool = True, compact_keys: bool | str | None = None) -> None:
+        """BM25 searches: True = K3r range-partitioned batch scorer (default; hybrid=False keeps it to the plain top-k search),
+        False = K3 per-document records.  `compact_keys` (None = leave as it is): False = round 4's key lists, one slot per
+        posting; True = compact lists for batches of 8 queries and more (the default); "always" = for every batch size — the
+        option "k3r_compact", independent of the scorer choice."""
+        N.check(self._lib.orama_ctx_set_bm25_ranges(self.handle, (1 if hybrid else 2) if on else 0))
+        if compact_keys is not None:
+            self.set_option("k3r_compact", 2 if compact_keys == "always" else 1 if compact_keys else 0)
 
     def set_option(self, name: str, value: int) -> None:
         """A tuning / test option by name (orama_ctx_set_option): alternative code paths with the same answers — nothing a deployment sets."""

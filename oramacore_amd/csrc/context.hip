@@ -310,6 +310,8 @@ const CtxOption kCtxOptions[] = {
     ORAMA_OPT("two_stage_spare", 1, 4096, c->two_stage_spare = (uint32_t)v),
     ORAMA_OPT("k3r_target", 16, 2048, c->k3r_target = (uint32_t)v),
     ORAMA_OPT("bm25_ranges_hybrid", 0, 1, c->bm25_ranges_hybrid = v != 0),
+    // K3r key lists: 0 = one slot per posting (round 4), 1 = compact lists for batches of >= 8 queries (default), 2 = always
+    ORAMA_OPT("k3r_compact", 0, 2, (c->bm25_compact_keys = v != 0, c->bm25_compact_min = v == 2 ? 1u : 8u)),
     ORAMA_OPT("select_wide", 0, 3, c->select_wide = (int)v),                // K4 over a lone query's distances (select.hip)
     ORAMA_OPT("select_pairs", 0, 1, c->select_pairs = v != 0),
 #if ORAMA_COMPARISON_KERNELS
@@ -612,10 +614,12 @@ int orama_ctx_set_two_stage(orama_ctx* ctx, int on) {
 int orama_ctx_set_bm25_ranges(orama_ctx* ctx, int on) {
     ORAMA_REQUIRE(ctx, "null context");
     ORAMA_REQUIRE(on >= 0 && on <= 4, "bm25 ranges mode %d outside [0, 4]", on);
+    // 0 / 1 / 2 choose the scorer and nothing else: the key-list form is its own option ("k3r_compact") and survives this call —
+    // a test's restoring set_bm25_ranges(1) used to switch compact lists back on behind an A/B run's back
     ctx->bm25_ranges = on != 0;
     ctx->bm25_ranges_hybrid = on == 1 || on >= 3;
-    ctx->bm25_compact_keys = on != 3;
-    ctx->bm25_compact_min = on == 4 ? 1u : 8u;
+    if (on == 3) ctx->bm25_compact_keys = false;                          // (kept: = mode 1 + option k3r_compact 0)
+    if (on == 4) ctx->bm25_compact_keys = true, ctx->bm25_compact_min = 1u;  // (kept: = mode 1 + option k3r_compact 2)
     return ORAMA_OK;
 }
 

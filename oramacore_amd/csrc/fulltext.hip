@@ -289,6 +289,9 @@ uint32_t shrink_recall(orama_post* p, const orama_term_ref* refs, uint32_t n_ref
     auto it = p->shrink_hint.find(shrink_key(p, refs, n_refs));
     return it == p->shrink_hint.end() ? 0u : it->second;
 }
+// The hint is the SMALLEST narrowing that held for the lists: a filtered query that needed 8x narrower ranges must not narrow the
+// unfiltered queries over the same lists for good — a run that completes at a wider width overwrites a narrower hint (the hint is
+// only where the retry loop STARTS: a width that overflows is narrowed again by the loop itself).
 void shrink_remember(orama_post* p, const orama_term_ref* refs, uint32_t n_refs, uint32_t shrink) {
     std::lock_guard<std::mutex> g(p->df_union_mu);
     if (p->shrink_hint.size() >= orama_post::kDfUnionMax) p->shrink_hint.clear();
@@ -327,12 +330,19 @@ int refresh_post_ntf_try(orama_post* p) {
     return ORAMA_OK;
 }
 int refresh_post_ntf(orama_post* p) {
-    if (refresh_post_ntf_try(p) != ORAMA_OK) {
-        p->ntf_valid = false;
-        (void)hipGetLastError();  // (a failed allocation leaves a sticky-looking error code behind: the store itself is intact)
+    const int st = refresh_post_ntf_try(p);
+    if (st == ORAMA_OK) return ORAMA_OK;
+    p->ntf_valid = false;
+    const hipError_t last = hipGetLastError();  // (read AND cleared: a failed allocation leaves its code behind, the store is intact)
+    if (st == ORAMA_ERR_OOM || last == hipErrorOutOfMemory) {
+        // only the +4 B per posting are missing: the kernels divide themselves — same operations, same bits — and the build /
+        // append that called this has committed its lists (a caller that retried it would append twice)
         clear_error();
+        return ORAMA_OK;
     }
-    return ORAMA_OK;
+    // anything else — a launch failure, an illegal address — is a real fault of the device: it would surface on some later,
+    // unrelated call with a misleading context.  The lists ARE committed; the status says what happened.
+    return st;
 }
 
 // State of one resident-postings query between its two stages.
@@ -778,6 +788,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         uint32_t job;
         uint32_t shrink;
         uint64_t total;
+        uint32_t recalled = 0;  // the hint the store held for these lists when the query was queued (0 = none)
     };
     // hybrid (a batch of one): the vector map as local document indices; a hit that is not a document of this index is the
     // per-record scorer's business (it reports the error)
@@ -842,7 +853,10 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                           bitmap_bits, jb.df_out))
                 continue;
         }
-        if (total) pending.push_back({j, shrink_recall(p, jb.refs, jb.n_refs), total});  // (shrink = narrow16: 0 / 16 = the target's width)
+        if (total) {
+            const uint32_t hint = shrink_recall(p, jb.refs, jb.n_refs);
+            pending.push_back({j, hint, total, hint});  // (shrink = narrow16: 0 / 16 = the target's width)
+        }
     }
     ORAMA_REQUIRE(p->n_docs > 0 || pending.empty(), "postings store is empty (orama_post_build not called)");
     // Queries of similar length share a set of launches: the launches of a chunk are sized by its longest query (grid of the
@@ -1275,7 +1289,10 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                 pending.push_back(pd);
                 continue;
             }
-            if (pd.shrink > 16u && !df_pass) shrink_remember(p, jb.refs, jb.n_refs, pd.shrink);  // (the width the next query over these lists starts at)
+            // the width the next query over these lists starts at — written only when it DIFFERS from what the store recalled for
+            // this query (every narrowed query of a batch took df_union_mu and built a key string here, thousands of
+            // times over the same lists)
+            if (pd.shrink > 16u && !df_pass && pd.shrink != pd.recalled) shrink_remember(p, jb.refs, jb.n_refs, pd.shrink);
             if (df_pass) {
                 memcpy(jb.df_out, h_res[ci].df, sizeof(uint32_t) * kMaxTokens);
                 df_remember(p, jb.refs, jb.n_refs, jb.params->n_tokens, c.d_allow != nullptr, c.allow_version, bitmap_bits, h_res[ci].df);

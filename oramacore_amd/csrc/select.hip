@@ -1223,12 +1223,16 @@ __global__ __launch_bounds__(kSortThreads) void pairs_reduce_wide_kernel(const f
 #define ORAMA_WIDE_ROUND(T0, TN) \
     wide_round<T0, TN>(x, pos, cnt_in, descending, k, s, hist, red_max, red_min, red_nz, sel, &cursor, &cursor2, &kth_s, st)
     if (force_narrow || !ORAMA_WIDE_ROUND(0, kWidePer)) {
-        // (uniform) rounds that always fit: 7 x 1 024 + kept <= 8 192 (k <= 256 here)
-        ORAMA_WIDE_ROUND(0, 7);
-        ORAMA_WIDE_ROUND(7, 7);
-        ORAMA_WIDE_ROUND(14, 7);
-        ORAMA_WIDE_ROUND(21, 7);
-        ORAMA_WIDE_ROUND(28, 4);
+        // (uniform) rounds that always fit: 7 x 1 024 values + the kept keys <= 8 192 — the wide path is gated on
+        // k <= kWaveBoundMaxK (launch_select), so the invariant is the constants': asserted, and a round that does not fit
+        // (it cannot) stops the kernel loudly instead of dropping keys
+        static_assert(7 * kSortThreads + kWaveBoundMaxK <= kKeysChunk, "the narrow fallback rounds of pairs_reduce_wide_kernel must fit the key chunk");
+        bool fits = ORAMA_WIDE_ROUND(0, 7);
+        fits = ORAMA_WIDE_ROUND(7, 7) && fits;
+        fits = ORAMA_WIDE_ROUND(14, 7) && fits;
+        fits = ORAMA_WIDE_ROUND(21, 7) && fits;
+        fits = ORAMA_WIDE_ROUND(28, 4) && fits;
+        if (!fits) __builtin_trap();
     }
 #undef ORAMA_WIDE_ROUND
     unsigned long long* o = out + ((uint64_t)qi * parts + part) * k;

@@ -51,9 +51,27 @@ __global__ __launch_bounds__(256) void stage_blocks_kernel(StageArgs a) {
 
 }  // namespace
 
+// CONTRACT: the host side of every part is PINNED, MAPPED memory (PinnedBuf: hipHostMallocPortable | hipHostMallocMapped) — the
+// kernel form dereferences the host pointer on the device; `kind` only tells the copy form (hipMemcpyAsync) the direction.
+// Every caller passes PinnedBuf memory (Scratch::h_in / h_out / h_misc).  Comparison builds CHECK it — a host pointer the runtime does
+// not know as host memory takes the copy form instead of faulting on the GPU; the product build does not pay the
+// runtime's pointer lookup on the lone-call path (a lone full-text call crosses this function three times).
 int stage_blocks(orama_ctx* ctx, const StagePart* parts, int n_parts, hipMemcpyKind kind, hipStream_t s) {
     ORAMA_REQUIRE(n_parts >= 1 && n_parts <= 4, "stage_blocks: 1..4 parts");
     bool by_kernel = ctx->stage_by_kernel;
+#if ORAMA_COMPARISON_KERNELS
+    if (by_kernel) {
+        for (int i = 0; i < n_parts && by_kernel; ++i) {
+            if (!parts[i].bytes) continue;
+            const void* host = kind == hipMemcpyDeviceToHost ? parts[i].dst : parts[i].src;
+            hipPointerAttribute_t at{};
+            if (hipPointerGetAttributes(&at, host) != hipSuccess || at.type != hipMemoryTypeHost) {
+                (void)hipGetLastError();
+                by_kernel = false;  // pageable (or unknown) host memory: the runtime's copy handles it
+            }
+        }
+    }
+#endif
     for (int i = 0; i < n_parts; ++i) {
         const StagePart& p = parts[i];
         if (p.bytes > kStageKernelMaxBytes || (p.bytes & 3u) ||

@@ -38,6 +38,13 @@ typedef struct {
     uint32_t xcds_reporting;
     uint32_t rsmi_index;
     uint64_t bdfid;
+    /* round 6: the memory side — is a slow run a lower memory clock, a hotter stack, or the shader clock eating
+     * the socket budget?  0 / -1 = the table does not report the field on this firmware. */
+    double uclk_mhz_median, uclk_mhz_min;     /* current_uclk: the HBM / memory-controller clock */
+    double socclk_mhz_median;                 /* mean of current_socclks[] (data fabric side of the XCDs) */
+    double temp_hbm_c_max, temp_mem_c_max, temp_hotspot_c_max; /* hottest HBM stack / memory / hotspot sample */
+    double umc_activity_pct_median;           /* average_umc_activity */
+    double xcd_busy_spread_pct;               /* per-XCD gfx_busy_acc deltas over the region: (max - min) / max * 100, -1 = not reported */
 } gs_summary_t;
 
 static struct {
@@ -50,6 +57,8 @@ static struct {
     uint32_t n;
     double t[GS_MAX_SAMPLES];
     float clk_mean[GS_MAX_SAMPLES], clk_spread[GS_MAX_SAMPLES], power[GS_MAX_SAMPLES], activity[GS_MAX_SAMPLES];
+    float uclk[GS_MAX_SAMPLES], socclk[GS_MAX_SAMPLES], umc[GS_MAX_SAMPLES];
+    float t_hbm_max, t_mem_max, t_hot_max;
     uint32_t xcds;
     rsmi_gpu_metrics_t first, last;
     int have_first;
@@ -139,6 +148,24 @@ static void take_sample(void) {
     if (p == 0 || p == 0xFFFF) p = m.average_socket_power;
     G.power[i] = (p == 0xFFFF) ? 0.f : (float)p;
     G.activity[i] = (m.average_gfx_activity == 0xFFFF) ? -1.f : (float)m.average_gfx_activity;
+    G.uclk[i] = (m.current_uclk == 0xFFFF) ? 0.f : (float)m.current_uclk;
+    {
+        double ss = 0.0;
+        uint32_t sc = 0;
+        for (int x = 0; x < RSMI_MAX_NUM_CLKS; ++x) {
+            uint16_t c = m.current_socclks[x];
+            if (c == 0 || c == 0xFFFF) continue;
+            ss += c;
+            ++sc;
+        }
+        if (sc == 0 && m.current_socclk != 0 && m.current_socclk != 0xFFFF) ss = m.current_socclk, sc = 1;
+        G.socclk[i] = sc ? (float)(ss / sc) : 0.f;
+    }
+    G.umc[i] = (m.average_umc_activity == 0xFFFF) ? -1.f : (float)m.average_umc_activity;
+    for (int x = 0; x < RSMI_NUM_HBM_INSTANCES; ++x)
+        if (m.temperature_hbm[x] != 0xFFFF && (float)m.temperature_hbm[x] > G.t_hbm_max) G.t_hbm_max = (float)m.temperature_hbm[x];
+    if (m.temperature_mem != 0xFFFF && (float)m.temperature_mem > G.t_mem_max) G.t_mem_max = (float)m.temperature_mem;
+    if (m.temperature_hotspot != 0xFFFF && (float)m.temperature_hotspot > G.t_hot_max) G.t_hot_max = (float)m.temperature_hotspot;
     G.n = i + 1;
 }
 
@@ -158,6 +185,7 @@ static void* loop(void* arg) {
 int gs_start(double period_s) {
     if (!G.opened || G.running) return -1;
     G.n = 0;
+    G.t_hbm_max = G.t_mem_max = G.t_hot_max = 0.f;
     G.xcds = 0;
     G.have_first = 0;
     G.stop = 0;
@@ -217,6 +245,32 @@ int gs_stop(gs_summary_t* out) {
         G.last.energy_accumulator != UINT64_MAX) {
         out->energy_j = (double)(G.last.energy_accumulator - G.first.energy_accumulator) * 15.259e-6;
         if (out->seconds > 0) out->energy_power_w = out->energy_j / out->seconds;
+    }
+    out->uclk_mhz_median = median_f(G.uclk, G.n);
+    out->socclk_mhz_median = median_f(G.socclk, G.n);
+    out->umc_activity_pct_median = median_f(G.umc, G.n);
+    {
+        double ulo = 1e9;
+        for (uint32_t i = 0; i < G.n; ++i)
+            if (G.uclk[i] > 0.f && G.uclk[i] < ulo) ulo = G.uclk[i];
+        out->uclk_mhz_min = ulo < 1e9 ? ulo : 0.0;
+    }
+    out->temp_hbm_c_max = G.t_hbm_max;
+    out->temp_mem_c_max = G.t_mem_max;
+    out->temp_hotspot_c_max = G.t_hot_max;
+    out->xcd_busy_spread_pct = -1.0;
+    {   /* per-XCD busy accumulators of partition 0 (the whole GPU in SPX mode): how evenly the launch kept the XCDs busy */
+        double bmax = 0.0, bmin = 1e30;
+        uint32_t bc = 0;
+        for (int x = 0; x < RSMI_MAX_NUM_XCC; ++x) {
+            uint64_t b0 = G.first.xcp_stats[0].gfx_busy_acc[x], b1 = G.last.xcp_stats[0].gfx_busy_acc[x];
+            if (b0 == UINT64_MAX || b1 == UINT64_MAX || b1 <= b0) continue;
+            double d = (double)(b1 - b0);
+            if (d > bmax) bmax = d;
+            if (d < bmin) bmin = d;
+            ++bc;
+        }
+        if (bc >= 2 && bmax > 0.0) out->xcd_busy_spread_pct = 100.0 * (bmax - bmin) / bmax;
     }
     uint64_t a0 = G.first.accumulation_counter, a1 = G.last.accumulation_counter;
     if (a1 > a0 && a1 != UINT64_MAX && a0 != UINT64_MAX) {

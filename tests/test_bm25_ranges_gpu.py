@@ -703,7 +703,8 @@ def test_compact_key_lists_equal_one_slot_per_posting(ctx):
         batch = [(refs, nt, thr) for c, refs, nt, k, thr, allow, mask in cases if c is corpus and allow is None]
         got.append(corpus.store.search_batch(batch, float(n_docs), 100))
         answers[compact] = got
-    ctx.set_bm25_ranges(True)
+    ctx.set_bm25_ranges(True)  # (the scorer setter leaves the key-list form alone since round 6: ADVICE r05)
+    ctx.set_bm25_ranges(True, compact_keys=True)  # ... back to the default explicitly
     for a, b_ in zip(answers["always"][:-1], answers[False][:-1]):
         assert a[2] == b_[2] and a[0].tolist() == b_[0].tolist() and np.array_equal(bits(a[1]), bits(b_[1]))
     for a, b_ in zip(answers["always"][-1], answers[False][-1]):
