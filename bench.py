@@ -53,8 +53,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA (v_mfma_f32_32x32x2_f32): MI355X_
 WORKLOADS = {
     # name: (rows, dim, k, queries per step, storage dtype, description)
     "ns": (10_000_000, 768, 100, 1, "f32", "10M x 768 fp32 embeddings, single-query cosine top-100 (north-star)"),
-    "nsb": (10_000_000, 768, 100, 32, "f32", "10M x 768 fp32 embeddings (the north-star rows, plain fp32 store), 32 concurrent queries per corpus pass: "
-                                             "K1m fp32-MFMA scan proposes, K1 decides — answers bit-identical to single queries"),
+    "nsb": (10_000_000, 768, 100, 64, "f32", "10M x 768 fp32 embeddings (the north-star rows, plain fp32 store), 64 concurrent queries per corpus pass: "
+                                             "K1x (rows rounded to fp16 in registers, fp16 MFMA) proposes, K1 decides — answers bit-identical to single queries"),
     "c2": (1_000_000, 384, 100, 1, "f32", "1M x 384 fp32 embeddings, single-query cosine top-100 (BASELINE configs[1])"),
     "c3": (10_000_000, 768, 100, 64, "f16", "10M x 768 fp16 embeddings, batch-64 queries, MFMA scan + top-100 "
                                             "(BASELINE configs[2])"),
@@ -525,7 +525,7 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
                  lo=lo, hi=hi, world=world)
 
     f32_mfma = not f16 and qb >= 9  # the library's default threshold (orama_ctx_set_f32_batch): batches take K1m
-    kern = "vec_scan_f16" if f16 else "vec_scan_f32_mfma" if f32_mfma else "vec_scan_f32"
+    kern = "vec_scan_f16" if f16 else "vec_scan_f32_cvt" if f32_mfma else "vec_scan_f32"  # (K1x where every row has a sound fp16 image: synthetic rows do)
     prof_steps, prof_note = steps, "HIP events on the launching stream over the timed region"
     if f16 and n_streams > 1:
         # Two steps in flight: a launch of one slot queues behind the other slot's scan (every scan kernel fills all CUs), and an
@@ -648,14 +648,13 @@ def vector_leg(oa, group, name, n_total, steps, warmup, streams, force_exchange=
         out["roofline"]["mfma_peak_tflops_dense_f16"] = MFMA_F16_PEAK_TFLOPS
         out["roofline"]["mfma_frac"] = out["roofline"]["mfma_tflops"] / MFMA_F16_PEAK_TFLOPS
     if f32_mfma:
-        # the instruction computes 32 query columns whatever the batch holds: the pipe's work is 2 x 32 x rows x dim per pass
-        flops = 2.0 * 32 * ((qb + 31) // 32) * n_local * dim * prof_steps
+        flops = 2.0 * 32 * ((qb + 31) // 32) * n_local * dim * prof_steps  # (the instruction computes whole 32-column tiles)
         out["roofline"]["mfma_tflops"] = flops / (scan_ms / 1e3) / 1e12 if scan_ms else 0.0
-        out["roofline"]["mfma_peak_tflops_f32"] = MFMA_F32_PEAK_TFLOPS
-        out["roofline"]["mfma_frac"] = out["roofline"]["mfma_tflops"] / MFMA_F32_PEAK_TFLOPS
-        out["roofline"]["note"] = ("K1m: 16 B of corpus per clock and CU is all the f32 matrix pipe takes (7.4 M cycles per 10 M x 768 pass): at the "
-                                   "clock the package's power limit leaves, that — not HBM — bounds the pass; mfma_frac is against the 2.4 GHz "
-                                   "data-sheet peak, clocks_during_timed_region says what the pass ran at")
+        out["roofline"]["mfma_peak_tflops_dense_f16"] = MFMA_F16_PEAK_TFLOPS
+        out["roofline"]["mfma_frac"] = out["roofline"]["mfma_tflops"] / MFMA_F16_PEAK_TFLOPS
+        out["roofline"]["note"] = ("K1x: the fp32 rows cross HBM once per 64 queries and are rounded to fp16 in registers (v_mfma_f32_32x32x16_f16); "
+                                   "the candidates are re-scored by K1's arithmetic — the answers are the single-query scan's bits.  "
+                                   "K1m (f32 x f32, <= 32 per pass, 5.3-5.5 ms) is scripts/k1m_probe.py --plan mfma")
     sess.close()
     return out, store, queries_h
 
@@ -1166,9 +1165,9 @@ def main():
         if shadow is not None:
             out["two_stage_exact"] = two_stage_leg(oa, ctx, store, shadow, dim, k, qb, queries_h, group=group)
         if args.workload == "ns" and not args.rows and "f32_batch" in want:
-            # the SAME plain fp32 store asked 32 queries at a time (what the request batcher does under load)
+            # the SAME plain fp32 store asked 64 queries at a time (what the request batcher does under load)
             configs["f32_batch"], _, qhb = vector_leg(oa, group, "nsb", n_total, 20, 3, 1, store=store, bdf=bdf, latency_steps=20)
-            configs["f32_batch"].update(host_api_latency(store, qhb, 32, k, n=10))
+            configs["f32_batch"].update(host_api_latency(store, qhb, 64, k, n=10))
         store.close()
         store = None
         if args.workload == "ns" and not args.rows:

@@ -133,13 +133,16 @@ int orama_ctx_set_two_stage(orama_ctx* ctx, int on);
  * `min_queries` concurrent queries share corpus passes of <= 32 queries on the matrix cores (K1m, vec_f32_mfma.hip:
  * v_mfma_f32_32x32x2_f32 — f32 in, f32 accumulate, exact) with a per-query threshold filter instead of one dense distance
  * array per query; smaller batches take K1 / K1b (<= 8 queries per pass, VALU).  Default 9; 0 = never.  Cosine stores whose
- * dimension is a multiple of 32 and <= 864 (the query tile lives in LDS); everything else keeps K1 / K1b.  The distance of a
- * (row, query) pair does not depend on the batch it was asked in (one fixed fmaf chain per pair). */
+ * dimension is a multiple of 32 and <= 1024 (the query tile lives in LDS), k <= 128; everything else keeps K1 / K1b.  The matrix
+ * scan only PROPOSES candidates — K1x (the rows rounded to fp16 in registers, <= 64 queries per pass, HBM-bound) where every row
+ * has a sound fp16 image, else K1m (f32 x f32, <= 32 per pass) — K1's own arithmetic decides, and a candidate list that is not
+ * proven complete is re-answered by K1 on the device: a query's answer is the single-query scan's, bit for bit, in any batch. */
 int orama_ctx_set_f32_batch(orama_ctx* ctx, int min_queries);
 /* Tuning / test options of a context, by name — NOT needed by a deployment (the defaults are the measured choices of DESIGN.md) and
  * never read from the environment by the product library (its whole environment is the deployment list of INTEGRATION.md §5b).
  * Every option selects between code paths that return the SAME answers (the parity tests run them against each other):
- *   "fused_topk" 0/1/2, "f32_multi" 0/1, "f16_solo" 0..2, "f16_wide" 0..5, "f16_kc" 8|12|16, "f16_nbuf" 2..4,
+ *   "fused_topk" 0/1/2, "f32_multi" 0/1, "f32_batch_cvt" 0/1 (fp32 batches: the candidate scan rounds the rows to fp16 in registers — K1x,
+ *   <= 64 queries per pass, HBM-bound — or multiplies f32 by f32 — K1m, <= 32 per pass; the answer is K1's either way), "f16_solo" 0..2, "f16_wide" 0..5, "f16_kc" 8|12|16, "f16_nbuf" 2..4,
  *   "f16_head_rows" (0 = 131 072), "f16_cand_mib" (0 = 6 144), "f16_chunk_grow" -1/0/1, "f16_grow_factor" 2..64,
  *   "two_stage_spare" 1..4096, "k3r_target" 16..2048, "k3r_compact" 0/1/2 (key lists: one slot per posting / compact for batches
  *   of >= 8 queries / always compact), "bm25_ranges" 0/1, "bm25_ranges_hybrid" 0/1, "select_wide" 0..3,

@@ -266,6 +266,9 @@ struct orama_ctx {
     // K1m (vec_f32_mfma.hip): fp32 batches of at least this many queries share corpus passes of <= 32 queries on the matrix
     // cores (v_mfma_f32_32x32x2_f32) with K2's threshold filter behind them; 0 = never (orama_ctx_set_f32_batch)
     uint32_t f32_mfma_min_q = 9;
+    // ... and the candidate scan of such a batch is K1x (vec_f32_cvt.hip: the fp32 rows rounded to fp16 in registers, fp16 MFMA,
+    // <= 64 queries per pass, HBM-bound) where every row has a sound fp16 image; false = always K1m (option "f32_batch_cvt")
+    bool f32_batch_cvt = true;
     // fp16 batches of 65..256 queries share one corpus pass: 4 = K2q (queries stationary in registers, default; batches of
     // <= 128 and rows wider than 768 dimensions take K2d), 5 = K2h (K loop split over a wave pair), 2 = K2d (dedicated
     // loader waves), 3 = K2d second geometry, 1 = K2c (round 1: MFMA waves issue the DMA), 0 = K2 in passes of 64

@@ -298,6 +298,7 @@ struct CtxOption {
 const CtxOption kCtxOptions[] = {
     ORAMA_OPT("fused_topk", 0, 2, c->fused_topk = (int)v),                  // K1 per-wave top-k: 0 never, 1 always, 2 = the rule
     ORAMA_OPT("f32_multi", 0, 1, c->f32_multi = (int)v),                    // K1b for 2..8 fp32 queries
+    ORAMA_OPT("f32_batch_cvt", 0, 1, c->f32_batch_cvt = v != 0),            // fp32 batches: K1x proposes (1) or K1m (0)
     ORAMA_OPT("f16_solo", 0, 2, c->f16_solo = (int)v),                      // K1h for shadow scans of <= 4 queries
     ORAMA_OPT("f16_wide", 0, 5, c->f16_wide = (int)v),                      // (orama_ctx_set_f16_wide validates against the build)
     ORAMA_OPT("f16_kc", 8, 16, c->f16_kc = (int)v),

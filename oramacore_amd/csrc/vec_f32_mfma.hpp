@@ -38,6 +38,31 @@ inline bool vec_scan_f32_mfma_supports(uint32_t dim, int metric) {
     return metric == ORAMA_METRIC_COSINE && dim >= kF32MfmaChunk && dim % kF32MfmaChunk == 0 && vec_scan_f32_mfma_stage_entries(dim, 8) >= 128;
 }
 
+// ---- K1x (vec_f32_cvt.hip): the same scan with the rows rounded to fp16 in registers and v_mfma_f32_32x32x16_f16 — an APPROXIMATE
+// candidate scan (|d - d_K1| <= kShadowEps) over the plain fp32 store, HBM-bound, <= 64 queries per pass.
+constexpr uint32_t kF32CvtMaxQ = 64;
+constexpr uint32_t kF32CvtRing = 6;
+constexpr uint32_t kF32CvtTransposerBytes = 2048;  // 32 rows x 32 halves per wave
+inline size_t vec_scan_f32_cvt_lds_bytes(uint32_t dim, int nqt, uint32_t stage_entries) {
+    return (size_t)(dim / 16) * (size_t)nqt * 1024 + 64 * sizeof(float) +
+           kF32MfmaWaves * (kF32CvtTransposerBytes + (size_t)f32_mfma_meta_slots(kF32CvtRing) * kF32MfmaMetaBytes + 256 +
+                            3 * (size_t)stage_entries * sizeof(uint32_t));
+}
+inline uint32_t vec_scan_f32_cvt_stage_entries(uint32_t dim, int nqt) {
+    const size_t fixed = vec_scan_f32_cvt_lds_bytes(dim, nqt, 0);
+    if (fixed >= kF16LdsLimit) return 0;
+    const size_t e = ((kF16LdsLimit - fixed) / (kF32MfmaWaves * 3 * sizeof(uint32_t))) & ~(size_t)63;
+    return e < 128 ? 0u : (uint32_t)(e > 1024 ? 1024 : e);
+}
+// queries one K1x pass takes at this dimension: 64 while two column tiles of fp16 fragments fit the LDS, else 32, else none
+inline uint32_t vec_scan_f32_cvt_max_q(uint32_t dim) {
+    return vec_scan_f32_cvt_stage_entries(dim, 2) >= 128 ? 64u : vec_scan_f32_cvt_stage_entries(dim, 1) >= 128 ? 32u : 0u;
+}
+inline bool vec_scan_f32_cvt_supports(uint32_t dim, int metric) {
+    return metric == ORAMA_METRIC_COSINE && dim >= kF32MfmaChunk && dim % kF32MfmaChunk == 0 && vec_scan_f32_cvt_max_q(dim) > 0;
+}
+int launch_vec_scan_f32_cvt(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream);
+
 // K1m.  a.tiled = the fp32 rows (row-major, [n][dim]); a.q <= 32; dense or filter mode as launch_vec_scan_f16.
 // Algorithmic HBM traffic: (row_end - row_begin) * dim * 4 bytes per launch (serves all q queries).
 int launch_vec_scan_f32_mfma(orama_ctx* ctx, const F16ScanArgs& a, hipStream_t stream);

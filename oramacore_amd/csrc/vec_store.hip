@@ -250,7 +250,11 @@ struct orama_vec {
     std::mutex composite_mu;
     std::atomic<bool> shadow_ok{true};
     std::atomic<uint64_t> two_stage_queries{0}, two_stage_fallbacks{0};
-    std::atomic<uint64_t> mfma_batch_queries{0};  // queries answered through K1m + rerank (search_enqueue_f32_batch)
+    std::atomic<uint64_t> mfma_batch_queries{0};  // queries answered through K1m / K1x + rerank (search_enqueue_f32_batch)
+    // plain fp32 stores: every row accepted so far has an fp16 image with a usable error bound (row_shadow_safe: |x_i| < 6e4,
+    // |x|^2 >= 1e-4) — what K1x, the convert-in-registers candidate scan, needs; drops to false for good at the first row that
+    // does not (batches then take K1m, f32 on the matrix cores)
+    std::atomic<bool> f16_safe{true};
 
     // scratch for the device-pointer entry point, one per caller stream
     std::mutex dev_mu;
@@ -470,7 +474,7 @@ int tail_end(Scratch* sc, hipStream_t s_scan, hipStream_t s) {
 int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
                        uint32_t* d_out_n, hipStream_t s, uint32_t* d_out_rows = nullptr, uint32_t* d_inexact = nullptr,
-                       bool f32_rows = false);
+                       int f32_rows = 0);
 
 // ---------------------------------------------------------------- f32 batches: K1m proposes, K1 decides
 // A batch of >= ctx->f32_mfma_min_q queries over a plain fp32 store shares corpus passes of <= 32 queries on the matrix cores
@@ -487,19 +491,37 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
 //      with nothing flagged those launches end at once.
 // Everything is enqueued on `s`; no host round trip.  Envelope: cosine, dim % 32 == 0 and <= 864 (the query tile lives in LDS),
 // k <= 128 (the fallback's per-wave lists).
+// Round 6, second half — K1x (vec_f32_cvt.hip): when every row of the store has a sound fp16 image (orama_vec::f16_safe) the
+// PROPOSAL is the fp16 two-stage plan's, computed from the fp32 rows themselves: rows rounded to fp16 in registers,
+// v_mfma_f32_32x32x16_f16, <= 64 queries per pass, HBM-bound instead of bound by the f32 matrix pipe; eps = kShadowEps (2.5e-3,
+// the plan's proven bound), k1 = max(2k, k + 256) candidates, a query without a sound fp16 image flags itself
+// (query_shadow_unsafe_kernel) and takes the fallback.  The answer is K1's either way.
 constexpr float kF32MfmaEps = 6.0e-5f;
+constexpr float kF32CvtEps = 2.5e-3f;  // = kShadowEps (defined with the two-stage plan below)
 constexpr uint32_t kF32MfmaFallbackSets = 16;
-bool f32_batch_on_mfma(const orama_vec* v, uint32_t q, uint32_t k) {
-    return v->ctx->f32_mfma_min_q && q >= v->ctx->f32_mfma_min_q && k >= 1 && k <= kWaveListKeys && !v->f16() &&
-           vec_scan_f32_mfma_supports(v->dim, v->metric) && vec_rerank_f32_supported(v->dim);
+// 0 = K1 / K1b, 1 = K1m proposes, 2 = K1x proposes
+int f32_batch_plan(const orama_vec* v, uint32_t q, uint32_t k) {
+    if (!(v->ctx->f32_mfma_min_q && q >= v->ctx->f32_mfma_min_q && k >= 1 && k <= kWaveListKeys && !v->f16() &&
+          vec_rerank_f32_supported(v->dim)))
+        return 0;
+    if (v->ctx->f32_batch_cvt && v->f16_safe.load(std::memory_order_acquire) && vec_scan_f32_cvt_supports(v->dim, v->metric) &&
+        2ull * k <= kSelectMaxK)
+        return 2;
+    return vec_scan_f32_mfma_supports(v->dim, v->metric) ? 1 : 0;
 }
+bool f32_batch_on_mfma(const orama_vec* v, uint32_t q, uint32_t k) { return f32_batch_plan(v, q, k) != 0; }
 
 int search_enqueue_f32_batch(orama_vec* v, const View& w, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                              const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
                              uint32_t* d_out_n, hipStream_t s) {
-    // spare candidates decide how often the proof fails: on the north-star rows the (k + 32)-th K1m distance lies ~2e-3 behind
-    // the k-th, 15 bands; candidates are cheap (k1 rows of 3 KiB per query against a 30 GB pass)
-    const uint32_t k1 = std::min<uint32_t>(kSelectMaxK, k + std::max<uint32_t>(32u, k / 2));
+    const int plan = f32_batch_plan(v, q, k);
+    ORAMA_REQUIRE(plan != 0, "internal: fp32 batch outside its envelope");
+    // spare candidates decide how often the proof fails.  K1m: on the north-star rows the (k + 32)-th distance lies ~2e-3 behind
+    // the k-th, 15 bands of 1.2e-4.  K1x: the two-stage plan's max(2k, k + 256) against its band of 5e-3 (0.1 % of the
+    // north-star queries fall back).  Candidates are cheap (k1 rows of 3 KiB per query against a 30 GB pass).
+    const float eps = plan == 2 ? kF32CvtEps : kF32MfmaEps;
+    const uint32_t k1 = plan == 2 ? (uint32_t)std::min<uint64_t>(kSelectMaxK, std::max<uint64_t>(2ull * k, (uint64_t)k + std::max<uint32_t>(1u, v->ctx->two_stage_spare)))
+                                  : std::min<uint32_t>(kSelectMaxK, k + std::max<uint32_t>(32u, k / 2));
     const size_t n1 = (size_t)q * k1;
     // every buffer first: nothing is (re)allocated behind launches that are already enqueued (the candidate stage reserves its
     // own — sel_state / sel_keys among them, larger than the final selection needs — before ITS launches)
@@ -541,8 +563,12 @@ int search_enqueue_f32_batch(orama_vec* v, const View& w, Scratch* sc, const flo
     fa.wave_lists = sc->mfma_fb_lists.as<unsigned long long>();
 
     // 1. candidates by K1m's distance (ids are not needed yet: the final selection maps rows to DocumentIds)
-    ORAMA_TRY(search_enqueue_f16(v, w, sc, d_queries, q, k1, d_allow, allow_bits, c_ids, c_dm, d_n1, s, c_rows, nullptr, /*f32_rows=*/true));
-    ORAMA_TRY(launch_shadow_band(c_dm, d_n1, q, k, k1, 2.0f * kF32MfmaEps, d_flag, s));
+    ORAMA_TRY(search_enqueue_f16(v, w, sc, d_queries, q, k1, d_allow, allow_bits, c_ids, c_dm, d_n1, s, c_rows, nullptr, /*f32_rows=*/plan));
+    ORAMA_TRY(launch_shadow_band(c_dm, d_n1, q, k, k1, 2.0f * eps, d_flag, s));
+    if (plan == 2) {  // a query the fp16 image cannot serve (tiny norm, an element beyond the fp16 range, NaN) flags itself
+        hipLaunchKernelGGL(query_shadow_unsafe_kernel, dim3((q + 3) / 4), dim3(256), 0, s, d_queries, q, v->dim, d_flag);
+        ORAMA_HIP_TRY(hipGetLastError());
+    }
     // 2. K1's distances of the candidates, then the final order
     ORAMA_TRY(launch_rerank_f32(static_cast<const float*>(w.rows), w.inv_norm, v->dim, d_queries, q, c_rows, d_n1, k1, c_exact, s));
     SelectPlan p;
@@ -696,10 +722,11 @@ int search_enqueue_f32(orama_vec* v, const View& w, Scratch* sc, const float* d_
 //   3. the last reduction also maps rows → DocumentIds and applies the final tie order.
 // Scores are never materialised for more than S1 rows; HBM traffic beyond the corpus pass is the
 // candidate appends (expected k·ln(N/S1) per query on unordered data).
-// `f32_rows`: the rows are the plain fp32 store's (row-major f32) and the scan is K1m, <= 32 queries per pass.
+// `f32_rows` != 0: the rows are the plain fp32 store's (row-major f32) and the scan is K1m (1: f32 on the matrix cores, <= 32
+// queries per pass) or K1x (2: rows rounded to fp16 in registers, <= 64 queries per pass).
 int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_queries, uint32_t q, uint32_t k,
                        const uint64_t* d_allow, uint64_t allow_bits, uint64_t* d_out_ids, float* d_out_dist,
-                       uint32_t* d_out_n, hipStream_t s, uint32_t* d_out_rows, uint32_t* d_inexact, bool f32_rows) {
+                       uint32_t* d_out_n, hipStream_t s, uint32_t* d_out_rows, uint32_t* d_inexact, int f32_rows) {
     const uint64_t n = w.n_rows;
     if (d_inexact) ORAMA_HIP_TRY(hipMemsetAsync(d_inexact, 0, (size_t)q * 4, s));
     if (!f32_rows && d_out_rows && q == 1 && v->ctx->f16_solo == 2 && (d_inexact || k <= kF16WaveListKeys)) {
@@ -742,10 +769,12 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
     for (uint32_t q0 = 0; q0 < q;) {
         // <= 64 queries: K2 (whole batch as LDS-resident B fragments); more: K2c (GEMM-tiled, <= 256 per pass)
         const bool wide = !f32_rows && v->ctx->f16_wide && (q - q0) > kF16MaxQ && (kpad_k / 16) % 2 == 0;
-        const uint32_t gq = std::min<uint32_t>(f32_rows ? kF32MfmaMaxQ : wide ? kF16WideMaxQ : vec_scan_f16_max_q(v->dim), q - q0);
+        const uint32_t gq = std::min<uint32_t>(f32_rows == 2 ? vec_scan_f32_cvt_max_q(v->dim) : f32_rows ? kF32MfmaMaxQ
+                                               : wide     ? kF16WideMaxQ : vec_scan_f16_max_q(v->dim), q - q0);
         if (wide) ORAMA_TRY(sc->f16_bfrag.reserve(f16_wide_query_bytes(v->dim)));
         bool wide_prepared = false;
         auto scan = [&](const F16ScanArgs& args) -> int {
+            if (f32_rows == 2) return launch_vec_scan_f32_cvt(v->ctx, args, s);
             if (f32_rows) return launch_vec_scan_f32_mfma(v->ctx, args, s);
             if (!wide) return launch_vec_scan_f16(v->ctx, args, s);
             if (!wide_prepared)
@@ -1348,6 +1377,8 @@ static int vec_insert_one(orama_vec* v, const uint64_t* doc_ids, const float* ro
         for (uint64_t i = 0; i < cnt; ++i) {
             const float* x = rows + (r0 + i) * (uint64_t)v->dim;
             if (!row_valid(x, v->dim)) continue;
+            if (!v->f16() && v->f16_safe.load(std::memory_order_relaxed) && !row_shadow_safe(x, v->dim))
+                v->f16_safe.store(false, std::memory_order_release);
             memcpy(stage + ok * (uint64_t)v->dim, x, rb);
             stage_doc[ok] = doc_ids[r0 + i];
             ++ok;

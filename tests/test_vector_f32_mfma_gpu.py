@@ -18,6 +18,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+@pytest.fixture(params=["K1x", "K1m"], autouse=True)
+def plan(request, ctx):
+    """Every case runs under both candidate scans: K1x (default where every row has a sound fp16 image: the fp32 rows rounded to
+    fp16 in registers, <= 64 queries per pass) and K1m (f32 x f32 on the matrix cores, <= 32 per pass)."""
+    ctx.set_option("f32_batch_cvt", 1 if request.param == "K1x" else 0)
+    yield request.param
+    ctx.set_option("f32_batch_cvt", 1)
+
+
 def make_store(ctx, corpus, row_doc=None):
     n, d = corpus.shape
     st = oa.EmbeddingFieldStorage(ctx, dimensions=d)
@@ -40,10 +49,11 @@ def check(st, corpus, queries, k, allow=None, dead_rows=None, what=""):
     return ids, dist, cnt
 
 
-@pytest.mark.parametrize("d", [32, 384, 768, 864])
-@pytest.mark.parametrize("nq", [9, 17, 32, 33, 70])
+@pytest.mark.parametrize("d", [32, 384, 768, 864, 1024])
+@pytest.mark.parametrize("nq", [9, 17, 32, 33, 70, 130])
 def test_head_only_batches(ctx, d, nq):
-    """N below the dense head, a ragged last tile (n % 32 != 0): one and several passes of <= 32 queries, ragged query tiles."""
+    """N below the dense head, a ragged last tile (n % 32 != 0): one and several passes, ragged query tiles.  (1 024 dimensions:
+    K1x takes 32 queries per pass there, K1m's query tile does not fit LDS — K1 / K1b answer under that plan.)"""
     n = 3000 + d + 7
     corpus = util.gaussian_rows(n, d, seed=d)
     queries = util.gaussian_rows(nq, d, seed=d + nq)
@@ -169,4 +179,43 @@ def test_duplicates_around_the_kth_place_take_the_fallback_and_stay_exact(ctx):
     z = np.zeros((9, d), dtype=np.float32)
     iz, dz, cz = st.storage_search(z, k)
     assert np.all(dz == 1.0) and iz[0].tolist() == list(range(k)) and np.all(cz == k)
+    st.close()
+
+
+def test_the_plan_follows_the_rows_and_the_queries(ctx, plan):
+    """K1x needs a sound fp16 image of every row (|x_i| < 6e4, |x|^2 >= 1e-4): a store that ever accepted another row proposes with
+    K1m from then on; a QUERY without one (tiny norm, an element beyond the fp16 range) flags itself on the device and is answered
+    by K1.  Answers equal the solo scan's bits in every case."""
+    n, d, k = 30_000, 384, 10
+    corpus = util.gaussian_rows(n, d, seed=61)
+    queries = util.gaussian_rows(12, d, seed=62)
+    queries[2] *= np.float32(1e-4)      # |q|^2 ~ 4e-6: no usable fp16 image
+    queries[5][7] = np.float32(7.0e4)   # beyond the fp16 range
+    st = make_store(ctx, corpus)
+
+    def launches():
+        ctx.prof_reset(); ctx.prof_enable(True)
+        out = st.storage_search(queries, k)
+        ctx.prof_enable(False)
+        return out, ctx.prof_get("vec_scan_f32_cvt")[1], ctx.prof_get("vec_scan_f32_mfma")[1]
+
+    (ib, db, cb), n_cvt, n_mfma = launches()
+    assert (n_cvt > 0 and n_mfma == 0) if plan == "K1x" else (n_cvt == 0 and n_mfma > 0)
+    ctx.set_f32_batch(0)
+    try:
+        for j in range(12):
+            i1, d1, c1 = st.storage_search(queries[j], k)
+            assert np.array_equal(i1[0], ib[j]) and np.array_equal(d1[0].view(np.uint32), db[j].view(np.uint32)) and c1[0] == cb[j], j
+    finally:
+        ctx.set_f32_batch(9)
+    # one row beyond the fp16 range: the store leaves K1x for good
+    big = util.gaussian_rows(1, d, seed=63)
+    big[0][3] = np.float32(1.0e5)
+    st.insert_rows(np.array([n], dtype=np.uint64), big)
+    corpus2 = np.concatenate([corpus, big])
+    (ib, db, cb), n_cvt, n_mfma = launches()
+    assert n_cvt == 0 and n_mfma > 0
+    for j in (0, 1, 3, 4):
+        full = orc.distances(corpus2, queries[j]).astype(np.float64)
+        util.assert_topk_sound(ib[j, :cb[j]], db[j, :cb[j]], full, k, TOL, f"after the unsafe row q{j}")
     st.close()
