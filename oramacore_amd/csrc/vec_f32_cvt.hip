@@ -22,6 +22,8 @@
 // |x|^2 >= 1e-4: tracked per store at insert, per query on the device) — otherwise K1m.
 #include "vec_f32_mfma.hpp"
 
+#include <cstdlib>
+
 #include "device_utils.hpp"
 #include "vec_f16_async.hpp"
 
@@ -384,32 +386,43 @@ int launch_vec_scan_f32_cvt(orama_ctx* ctx, const F16ScanArgs& a_in, hipStream_t
     ORAMA_REQUIRE(!a.allow || a.row_doc, "vec_scan_f32_cvt: filter needs row_doc");
     if (a.row_begin == a.row_end) return ORAMA_OK;
     const int nqt = a.q <= 32 ? 1 : 2;
-    a.stage_cap = vec_scan_f32_cvt_stage_entries(a.dim, nqt);
-    const size_t lds_bytes = vec_scan_f32_cvt_lds_bytes(a.dim, nqt, a.stage_cap);
-    ORAMA_REQUIRE(a.stage_cap >= 128 && lds_bytes <= kF16LdsLimit, "vec_scan_f32_cvt: dim %u too large for the LDS query tile", a.dim);
     ProfScope prof(&ctx->prof, "vec_scan_f32_cvt", stream);
     const uint64_t tiles = ((a.row_end + 31) >> 5) - (a.row_begin >> 5);
     const dim3 grid(blocks_for(tiles, kWavesPerBlock, (uint32_t)ctx->compute_units));
     const uint32_t nc = a.dim / kF32MfmaChunk;
     const uint64_t tile_bytes = (uint64_t)a.dim * 4u * 32u;
-#define ORAMA_K1X_LAUNCH(NQT_)                                                                                                        \
+#define ORAMA_K1X_LAUNCH(NQT_) ORAMA_K1X_LAUNCH_RING(NQT_, (int)kF32CvtRing)
+#define ORAMA_K1X_LAUNCH_RING(NQT_, RING_)                                                                                            \
     do {                                                                                                                             \
+        a.stage_cap = vec_scan_f32_cvt_stage_entries(a.dim, NQT_, RING_);                                                            \
+        const size_t lds_bytes = vec_scan_f32_cvt_lds_bytes(a.dim, NQT_, a.stage_cap, RING_);                                        \
+        ORAMA_REQUIRE(a.stage_cap >= 128 && lds_bytes <= kF16LdsLimit, "vec_scan_f32_cvt: dim %u too large for the LDS query tile", a.dim); \
         static bool attr_done = false;                                                                                               \
         if (!attr_done) {                                                                                                            \
-            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f32_cvt_kernel<false, NQT_, (int)kF32CvtRing>), \
+            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f32_cvt_kernel<false, NQT_, RING_>), \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                              \
-            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f32_cvt_kernel<true, NQT_, (int)kF32CvtRing>),  \
+            ORAMA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vec_scan_f32_cvt_kernel<true, NQT_, RING_>),  \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                              \
             attr_done = true;                                                                                                        \
         }                                                                                                                            \
         if (a.out_dense)                                                                                                             \
-            hipLaunchKernelGGL((vec_scan_f32_cvt_kernel<true, NQT_, (int)kF32CvtRing>), grid, dim3(kBlock), lds_bytes, stream, a, nc, tile_bytes); \
+            hipLaunchKernelGGL((vec_scan_f32_cvt_kernel<true, NQT_, RING_>), grid, dim3(kBlock), lds_bytes, stream, a, nc, tile_bytes); \
         else                                                                                                                         \
-            hipLaunchKernelGGL((vec_scan_f32_cvt_kernel<false, NQT_, (int)kF32CvtRing>), grid, dim3(kBlock), lds_bytes, stream, a, nc, tile_bytes); \
+            hipLaunchKernelGGL((vec_scan_f32_cvt_kernel<false, NQT_, RING_>), grid, dim3(kBlock), lds_bytes, stream, a, nc, tile_bytes); \
     } while (0)
+#if ORAMA_COMPARISON_KERNELS
+    static const int ring = [] { const char* e = orama::dev_env("ORAMA_K1X_RING"); return e ? std::atoi(e) : 0; }();  // A/B: 4 / 8
+    if (ring == 4) {
+        if (nqt == 1) ORAMA_K1X_LAUNCH_RING(1, 4);
+        else ORAMA_K1X_LAUNCH_RING(2, 4);
+    } else if (ring == 8 && nqt == 1) {
+        ORAMA_K1X_LAUNCH_RING(1, 8);
+    } else
+#endif
     if (nqt == 1) ORAMA_K1X_LAUNCH(1);
     else ORAMA_K1X_LAUNCH(2);
 #undef ORAMA_K1X_LAUNCH
+#undef ORAMA_K1X_LAUNCH_RING
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }

@@ -43,13 +43,13 @@ inline bool vec_scan_f32_mfma_supports(uint32_t dim, int metric) {
 constexpr uint32_t kF32CvtMaxQ = 64;
 constexpr uint32_t kF32CvtRing = 6;
 constexpr uint32_t kF32CvtTransposerBytes = 2048;  // 32 rows x 32 halves per wave
-inline size_t vec_scan_f32_cvt_lds_bytes(uint32_t dim, int nqt, uint32_t stage_entries) {
+inline size_t vec_scan_f32_cvt_lds_bytes(uint32_t dim, int nqt, uint32_t stage_entries, uint32_t ring = kF32CvtRing) {
     return (size_t)(dim / 16) * (size_t)nqt * 1024 + 64 * sizeof(float) +
-           kF32MfmaWaves * (kF32CvtTransposerBytes + (size_t)f32_mfma_meta_slots(kF32CvtRing) * kF32MfmaMetaBytes + 256 +
+           kF32MfmaWaves * (kF32CvtTransposerBytes + (size_t)f32_mfma_meta_slots(ring) * kF32MfmaMetaBytes + 256 +
                             3 * (size_t)stage_entries * sizeof(uint32_t));
 }
-inline uint32_t vec_scan_f32_cvt_stage_entries(uint32_t dim, int nqt) {
-    const size_t fixed = vec_scan_f32_cvt_lds_bytes(dim, nqt, 0);
+inline uint32_t vec_scan_f32_cvt_stage_entries(uint32_t dim, int nqt, uint32_t ring = kF32CvtRing) {
+    const size_t fixed = vec_scan_f32_cvt_lds_bytes(dim, nqt, 0, ring);
     if (fixed >= kF16LdsLimit) return 0;
     const size_t e = ((kF16LdsLimit - fixed) / (kF32MfmaWaves * 3 * sizeof(uint32_t))) & ~(size_t)63;
     return e < 128 ? 0u : (uint32_t)(e > 1024 ? 1024 : e);

@@ -23,6 +23,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 import oramacore_amd as oa  # noqa: E402
 from oracle import oracle as orc  # noqa: E402  (checker + CPU baseline leg only)
+from oramacore_amd.token_score import DEFAULT_EXACT_MATCH_BOOST  # noqa: E402
 from oramacore_amd.token_score import (FulltextMode, Index, StringFieldStorage, TokenScoreContext,  # noqa: E402
                                        TokenScoreParams)
 
@@ -37,7 +38,9 @@ def oracle_entries(idx, tokens):
             for term in [t for t in sorted(sf.postings) if t.startswith(tok)]:
                 pl = sorted(sf.postings[term].items())
                 docs = np.array([d for d, _ in pl], dtype=np.uint64)
-                ntf = np.array([orc.bm25f_normalized_tf(tf, sf.field_len[d], sf.avg_field_length(), 0.75)
+                # (the exact-match factor of the store — the mirror's declared default — on the term that IS the token)
+                bo = F(DEFAULT_EXACT_MATCH_BOOST) if term == tok else F(1.0)
+                ntf = np.array([F(bo * orc.bm25f_normalized_tf(tf, sf.field_len[d], sf.avg_field_length(), 0.75))
                                 for d, tf in pl], dtype=np.float32)
                 entries.append((ti, docs, ntf))
     return entries
