@@ -35,6 +35,15 @@ for STEP in "$@"; do
       timeout 600 scripts/native/bench_serving hybrid 10000000 20 1,8,32 2>&1 | tee $O/serving_hybrid.log
       timeout 600 scripts/native/bench_serving vec 10000000 60 8,64,256 f32 2>&1 | tee $O/serving_vec_f32.log ;;
     profall) prof driver_command python $R/bench.py --steps 20 --warmup 5 --no-pmc ;;
+    pmc)  # FETCH_SIZE / WRITE_SIZE passes (separate, kernel trace only) over the scan kernels: total traffic per step / algorithmic
+      for W in nsb:vec_scan_f32_cvt nsb_mfma:vec_scan_f32_mfma ns:vec_scan_f32_kernel; do
+        N=${W%%:*}; KERN=${W#*:}
+        for C in FETCH_SIZE WRITE_SIZE; do
+          echo "== pmc $N $C"; (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$N/$C -o p -- python $R/scripts/pmc_scan_probe.py $N 6 > $O/pmc_${N}_$C.log 2>&1); echo rc=$?
+        done
+        python scripts/pmc_total.py $O/pmc_$N $KERN 30720000000 6 > $O/pmc_${N}_vec_scan.json 2>$O/pmc_$N.err; grep -E "traffic_over|launches" $O/pmc_${N}_vec_scan.json
+        find $O/pmc_$N -name "*.csv" -size +1M -delete
+      done ;;
     py:*) A=${STEP#py:}; P=${A%%:*}; ARGS=""; [ "$A" != "$P" ] && ARGS=$(echo "${A#*:}" | tr ',' ' '); echo "== python $P $ARGS"; timeout 900 python $P $ARGS 2>&1 | tee $O/$(basename $P .py).log | tail -40 ;;
     *) echo "unknown step $STEP" ;;
   esac

@@ -15,12 +15,16 @@ import oramacore_amd as oa  # noqa: E402
 from oramacore_amd.shard_group import ShardGroup  # noqa: E402
 
 SHAPES = {"ns": (10_000_000, 768, 1, "f32"), "c2": (1_000_000, 384, 1, "f32"), "c3": (10_000_000, 768, 64, "f16"),
-          "c5": (10_000_000, 768, 256, "f16")}
+          "c5": (10_000_000, 768, 256, "f16"),
+          # round 6: the plain fp32 store asked 64 queries per pass (K1x proposes; `nsb_mfma`: 32 per pass, K1m proposes)
+          "nsb": (10_000_000, 768, 64, "f32"), "nsb_mfma": (10_000_000, 768, 32, "f32")}
 name = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 n, d, qb, dt = SHAPES[name]
 group = ShardGroup([0])
 ctx = group.ctx(0)
+if name == "nsb_mfma":
+    ctx.set_option("f32_batch_cvt", 0)
 st = oa.EmbeddingFieldStorage(ctx, dimensions=d, reserve_rows=n, dtype=oa.DTYPE_F16 if dt == "f16" else oa.DTYPE_F32)
 st.fill_synthetic(n, seed=0xC0FFEE)
 q = np.random.default_rng(0xBEEF).standard_normal((steps * qb, d)).astype(np.float32)
