@@ -71,15 +71,17 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f32_cvt_kernel(F16ScanArgs a,
         for (int e = 0; e < 8; ++e) v[e] = (_Float16)((j < a.q) ? a.queries[(size_t)j * a.dim + k0 + e] : 0.0f);
         *reinterpret_cast<h8*>(lds + (size_t)idx * 16) = v;
     }
-    if (tid < NQT * 32) {
-        const uint32_t j = tid;
+    // 1 / |q| from the f32 values: one wave per query at a time, lanes strided over the dimensions (a serial loop per query — 768
+    // dependent steps — cost 40-100 us per launch: more than the whole dense head's corpus traffic, profiles/r06_driver_command_*)
+    for (uint32_t j = (uint32_t)tid >> 6; j < NQT * 32u; j += kWavesPerBlock) {
         float ss = 0.0f;
         if (j < a.q)
-            for (uint32_t k = 0; k < a.dim; ++k) {
+            for (uint32_t k = lane; k < a.dim; k += 64) {
                 const float x = a.queries[(size_t)j * a.dim + k];
                 ss = fmaf(x, x, ss);
             }
-        qinv[j] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+        ss = wave_sum(ss);
+        if (lane == 0) qinv[j] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
     }
     __syncthreads();
 

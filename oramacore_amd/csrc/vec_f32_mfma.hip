@@ -78,16 +78,17 @@ __global__ __launch_bounds__(kBlock) void vec_scan_f32_mfma_kernel(F16ScanArgs a
         if (j < a.q) v = *reinterpret_cast<const f4*>(a.queries + (size_t)j * a.dim + k0);
         *reinterpret_cast<f4*>(lds + (size_t)idx * 16) = v;
     }
-    __syncthreads();
-    if (tid < 32) {  // |q|: f32, one fmaf chain in k order
-        const uint32_t j = tid;
+    // 1 / |q|: one wave per query at a time, lanes strided over the dimensions (the answer is K1's whatever the last ulp here: a
+    // serial chain per query cost ~40 us per launch)
+    for (uint32_t j = (uint32_t)tid >> 6; j < 32u; j += kWavesPerBlock) {
         float ss = 0.0f;
-        for (uint32_t k = 0; k < nc * 32; ++k) {
-            const uint32_t cc = k >> 3, h = (k >> 2) & 1, e = k & 3;
-            const float x = reinterpret_cast<const float*>(lds + (size_t)(cc * 64 + h * 32 + j) * 16)[e];
-            ss = fmaf(x, x, ss);
-        }
-        qinv[j] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+        if (j < a.q)
+            for (uint32_t k = lane; k < a.dim; k += 64) {
+                const float x = a.queries[(size_t)j * a.dim + k];
+                ss = fmaf(x, x, ss);
+            }
+        ss = wave_sum(ss);
+        if (lane == 0) qinv[j] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
     }
     __syncthreads();
 

@@ -498,7 +498,7 @@ int search_enqueue_f16(orama_vec* v, const View& w, Scratch* sc, const float* d_
 // (query_shadow_unsafe_kernel) and takes the fallback.  The answer is K1's either way.
 constexpr float kF32MfmaEps = 6.0e-5f;
 constexpr float kF32CvtEps = 2.5e-3f;  // = kShadowEps (defined with the two-stage plan below)
-constexpr uint32_t kF32MfmaFallbackSets = 16;
+constexpr uint32_t kF32MfmaFallbackSets = 32;  // list sets of the device-side K1 fallback (4 MB each at the north-star shape; more flagged queries take further rounds)
 // 0 = K1 / K1b, 1 = K1m proposes, 2 = K1x proposes
 int f32_batch_plan(const orama_vec* v, uint32_t q, uint32_t k) {
     if (!(v->ctx->f32_mfma_min_q && q >= v->ctx->f32_mfma_min_q && k >= 1 && k <= kWaveListKeys && !v->f16() &&
