@@ -501,13 +501,16 @@ constexpr float kF32CvtEps = 2.5e-3f;  // = kShadowEps (defined with the two-sta
 constexpr uint32_t kF32MfmaFallbackSets = 32;  // list sets of the device-side K1 fallback (4 MB each at the north-star shape; more flagged queries take further rounds)
 // 0 = K1 / K1b, 1 = K1m proposes, 2 = K1x proposes
 int f32_batch_plan(const orama_vec* v, uint32_t q, uint32_t k) {
-    if (!(v->ctx->f32_mfma_min_q && q >= v->ctx->f32_mfma_min_q && k >= 1 && k <= kWaveListKeys && !v->f16() &&
-          vec_rerank_f32_supported(v->dim)))
-        return 0;
-    if (v->ctx->f32_batch_cvt && v->f16_safe.load(std::memory_order_acquire) && vec_scan_f32_cvt_supports(v->dim, v->metric) &&
-        2ull * k <= kSelectMaxK)
-        return 2;
-    return vec_scan_f32_mfma_supports(v->dim, v->metric) ? 1 : 0;
+    if (!(v->ctx->f32_mfma_min_q && q >= 2 && k >= 1 && k <= kWaveListKeys && !v->f16() && vec_rerank_f32_supported(v->dim))) return 0;
+    const bool cvt = v->ctx->f32_batch_cvt && v->f16_safe.load(std::memory_order_acquire) && vec_scan_f32_cvt_supports(v->dim, v->metric) &&
+                     2ull * k <= kSelectMaxK;
+    // K1x serves 2..8 queries too where the pass, not the launches, is the cost: one 4.5 ms pass + ~0.25 ms of candidate stage
+    // against K1b's 5.6 ms + dense selection at 10 M x 768; under 4 GB of rows K1b's single launch wins (the two-stage plan's rule)
+    const uint64_t bytes = v->n_rows.load(std::memory_order_relaxed) * (uint64_t)v->row_bytes();
+    const uint32_t min_q = cvt && bytes >= (4ull << 30) ? 2u : v->ctx->f32_mfma_min_q;
+    if (q < min_q) return 0;
+    if (cvt) return 2;
+    return q >= v->ctx->f32_mfma_min_q && vec_scan_f32_mfma_supports(v->dim, v->metric) ? 1 : 0;
 }
 bool f32_batch_on_mfma(const orama_vec* v, uint32_t q, uint32_t k) { return f32_batch_plan(v, q, k) != 0; }
 

@@ -57,12 +57,43 @@ def test_ns_full_size_fp32(ctx):
         bm.close()
     md, ms = orc.top_n(np.concatenate(parts_i), -np.concatenate(parts_d), k)
     assert np.array_equal(md, ids[0]) and np.array_equal(-ms, dist[0])
-    # a batch of 5 (K1b) equals the solo answers
+    # a batch of 5 equals the solo answers — through K1x (round 6: 2..8 queries over >= 4 GB of rows take the convert-in-registers
+    # candidate scan too) and through K1b (the matrix path off)
     qs = util.gaussian_rows(5, d, seed=77)
     bi, bd, bc = st.storage_search(qs, k)
-    for j in (0, 4):
-        si, sd, sc = st.storage_search(qs[j], k)
+    ctx.set_f32_batch(0)
+    try:
+        ki, kd, kc = st.storage_search(qs, k)
+        solo = {j: st.storage_search(qs[j], k) for j in (0, 4)}
+    finally:
+        ctx.set_f32_batch(9)
+    assert np.array_equal(bi, ki) and np.array_equal(bd.view(np.uint32), kd.view(np.uint32)) and np.array_equal(bc, kc)
+    for j, (si, sd, sc) in solo.items():
         assert np.array_equal(bi[j], si[0]) and np.array_equal(bd[j], sd[0])
+    # the north-star rows asked 64 + 6 queries at a time (K1x: two passes; K1m with the option): the single-query scan's bits
+    # for every query looked at, under a filter as well, and the plan really ran on the matrix cores
+    qb = util.gaussian_rows(70, d, seed=78)
+    bm = oa.AllowBitmap.from_mask(np.arange(n + 3) % 3 != 0).to_device(ctx)
+    for option in (1, 0):
+        ctx.set_option("f32_batch_cvt", option)
+        ctx.prof_reset(); ctx.prof_enable(True)
+        bi, bd, bc = st.storage_search(qb, k)
+        fi, fd, fc = st.storage_search(qb[:12], k, bm)
+        ctx.prof_enable(False)
+        assert ctx.prof_get("vec_scan_f32_cvt" if option else "vec_scan_f32_mfma")[1] >= 4
+        assert ctx.prof_get("vec_scan_f32")[1] == 0, "a query fell back to the plain scan: the candidate lists were not proven"
+        ctx.set_f32_batch(0)
+        try:
+            for j in (0, 31, 32, 63, 64, 69):
+                si, sd, sc = st.storage_search(qb[j], k)
+                assert np.array_equal(bi[j], si[0]) and np.array_equal(bd[j].view(np.uint32), sd[0].view(np.uint32)) and bc[j] == sc[0], (option, j)
+            for j in (0, 11):
+                si, sd, sc = st.storage_search(qb[j], k, bm)
+                assert np.array_equal(fi[j], si[0]) and np.array_equal(fd[j].view(np.uint32), sd[0].view(np.uint32)) and fc[j] == sc[0], (option, j)
+        finally:
+            ctx.set_f32_batch(9)
+    ctx.set_option("f32_batch_cvt", 1)
+    bm.close()
     st.close()
 
 
