@@ -2,7 +2,8 @@
 """Regenerate the machine-derived part of profiles/README.md FROM THE FILES (the hand-written index quoted
 figures the files no longer held).  For every round it lists the kernel-stats tables with the dominant kernel's average
 duration and call count as the file states them, the pytest logs with their pass counts, and the bench JSON lines with
-their values; hand-written descriptions of the other records are kept in profiles/README.notes.md and appended verbatim.
+their values; hand-written descriptions of the other records (and, since round 6, the kernel design histories moved out of
+DESIGN.md) are kept in profiles/README.notes.md, which the index LINKS to (round 5 appended it verbatim: 150 KB by now).
 
     python scripts/profiles_index.py > profiles/README.md
 """
@@ -44,10 +45,15 @@ def pytest_line(path: Path) -> str:
 
 def bench_line(path: Path) -> str:
     try:
-        txt = path.read_text().strip().splitlines()[-1]
-        d = json.loads(txt)
+        whole = path.read_text().strip()
+        try:
+            d = json.loads(whole)  # (round 6: bench_details.json is an indented document)
+        except Exception:  # noqa: BLE001
+            d = json.loads(whole.splitlines()[-1])
     except Exception:  # noqa: BLE001
         return "(not a JSON line)"
+    if not isinstance(d, dict):
+        return "(not a bench line: see the notes)"
     if "value" not in d:
         return "(not a bench line: see the notes below)"
     out = f"value {d.get('value', 0):.1f} {d.get('unit', '')}, ms_per_step {d.get('ms_per_step', 0):.3f}, n_gpus {d.get('n_gpus')}"
@@ -65,10 +71,11 @@ def bench_line(path: Path) -> str:
 
 
 def main() -> None:
-    print("# profiles/ — measurement evidence (one MI355X, ROCm 7.x, `gpurun`); files are named per round: `r01_*` … `r05_*`\n")
+    print("# profiles/ — measurement evidence (one MI355X, ROCm 7.x, `gpurun`); files are named per round: `r01_*` … `r06_*`\n")
     print("The tables below are GENERATED from the files by `scripts/profiles_index.py` (figures are read out of each file, not "
-          "typed); the notes on the other records follow them.\n")
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+          "typed).  Hand-written notes on every other record, and the kernel design histories of rounds 1-5, are in "
+          "[`README.notes.md`](README.notes.md).\n")
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         files = sorted(P.glob(f"{rnd}_*"))
         if not files:
             continue
@@ -83,9 +90,8 @@ def main() -> None:
             elif f.suffix == ".json" and "bench" in f.name:
                 print(f"| `{f.name}` | {bench_line(f)} |")
         print()
-    notes = P / "README.notes.md"
-    if notes.exists():
-        print(notes.read_text())
+    print("## Round 6 — the other records\n")
+    print((P / "README.r06.md").read_text() if (P / "README.r06.md").exists() else "(see README.notes.md)")
 
 
 if __name__ == "__main__":
