@@ -316,7 +316,10 @@ struct orama_ctx {
     uint64_t f16_head_rows = 0, f16_cand_mib = 0;
     int f16_chunk_grow = -1, f16_grow_factor = 2;
     uint32_t two_stage_spare = 256;  // spare candidates of the two-stage plan ("two_stage_spare")
-    uint32_t k3r_target = 1536;      // postings per document range of K3r ("k3r_target")
+    // postings per document range of K3r ("k3r_target").  1 792 since round 6 (1 536 before): the scoring launch's cost is mostly
+    // per-WORKGROUP fixed work, so fuller ranges are cheaper per posting — 231 K -> 239 K queries/s in one lease, 242 K at 1 920
+    // (profiles/r06_k3r_target_sweep.log); 1 920 leaves the 2 048-posting cap ~3 sigma of a Poisson range away, 1 792 six
+    uint32_t k3r_target = 1792;
     bool select_pairs = true;        // K4: (value, index) lists in two launches ("select_pairs" 0 = histogram passes)
     int compute_units = 0;
     uint64_t hbm_bytes = 0;

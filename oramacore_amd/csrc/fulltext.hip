@@ -620,12 +620,14 @@ bool ranges_eligible(const orama_post* p, const orama_term_ref* refs, uint32_t n
     return nonempty <= kRangeMaxRefs && total < 0x7fffffffull;
 }
 
-// Documents per range: `target` postings per range on average (ORAMA_K3R_TARGET; a workgroup holds at most kRangeCap = 2 048).
+// Documents per range: `target` postings per range on average (option "k3r_target"; a workgroup holds at most kRangeCap = 2 048).
 // The cost per posting falls with the postings per workgroup — per-workgroup work (tables, scans, barriers) is amortised over
 // more of them: round 4's sort-free kernel takes 5.03 us per C4-shaped query at 1 280, 4.78 at 1 536, 4.57 at 1 792 and 4.36 at
 // 2 000 (profiles/r04_k3r_target_sweep_v3.log) — but a range that exceeds the 2 048 reruns its whole query with 8x narrower
-// ranges, so the default keeps 25 % of headroom: 1 536 (a Poisson count of that mean is 13 standard deviations below the
-// cap; documents of a term clustered in id space overflow at any target).  Any width — a power of two would leave the average
+// ranges, so rounds 3-5 kept 25 % of headroom: 1 536 (a Poisson count of that mean is 13 standard deviations below the
+// cap; documents of a term clustered in id space overflow at any target).  Round 6: 1 792 (6 sigma) — since round 5 an overflow
+// costs a rerun "that much narrower plus a quarter" whose factor is remembered per list set, not 8 x for good; compact-list kernel,
+// one lease: 231 K queries/s at 1 536, 239 K at 1 792, 242 K at 1 920 (profiles/r06_k3r_target_sweep.log).  Any width — a power of two would leave the average
 // anywhere between target / 2 and target — `shrink` times 8x smaller after an overflow.
 // `narrow16`: by how much the ranges are narrower than the target asks, in 1/16 (16 = not at all).  After an overflow the scoring
 // launch says by how much its worst range was too large (RangeResult::pad1[0]: postings, documents with several postings or
@@ -634,7 +636,7 @@ bool ranges_eligible(const orama_post* p, const orama_term_ref* refs, uint32_t n
 // independent lists ever after (scripts/bench_overlap_lists.py).  The factor that held is remembered per list set
 // (orama_post::shrink_hint).
 uint32_t choose_width(uint64_t n_docs, uint64_t total_postings, uint32_t narrow16, uint32_t target_opt) {
-    const uint64_t target = target_opt >= 16 && target_opt <= kRangeCap ? target_opt : 1536;  // option "k3r_target"
+    const uint64_t target = target_opt >= 16 && target_opt <= kRangeCap ? target_opt : 1792;  // option "k3r_target"
     uint64_t w = total_postings ? n_docs * target / total_postings : n_docs;
     if (narrow16 > 16u) w = w * 16u / narrow16;
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(w, 1), kRangeMaxWidth);

@@ -14,10 +14,13 @@ ap.add_argument("--rows", type=int, default=10_000_000)
 ap.add_argument("--dim", type=int, default=768)
 ap.add_argument("--batches", default="8,9,16,24,32,64,128")
 ap.add_argument("--reps", type=int, default=8)
+ap.add_argument("--head-rows", type=int, default=0, help="dense head of the filter pipeline (option f16_head_rows; 0 = 131 072)")
 ap.add_argument("--plan", choices=["cvt", "mfma"], default="cvt", help="candidate scan of the batches: K1x (rows rounded to fp16 in registers) or K1m (f32 x f32)")
 a = ap.parse_args()
 ctx = oa.Context(0)
 ctx.set_option("f32_batch_cvt", 1 if a.plan == "cvt" else 0)
+if a.head_rows:
+    ctx.set_option("f16_head_rows", a.head_rows)
 try:
     bdf = ctx.pci_bus_id()
 except Exception:  # noqa: BLE001
