@@ -219,3 +219,41 @@ def test_the_plan_follows_the_rows_and_the_queries(ctx, plan):
         full = orc.distances(corpus2, queries[j]).astype(np.float64)
         util.assert_topk_sound(ib[j, :cb[j]], db[j, :cb[j]], full, k, TOL, f"after the unsafe row q{j}")
     st.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shapes_equal_the_plain_path(ctx, seed):
+    """Random dimensions, row counts (down to fewer rows than k, than a tile), batch sizes, k, tombstones and filters: the matrix
+    path's answers are the plain path's (K1 / K1b, the matrix path switched off) bit for bit — ids, distances, counts."""
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.choice([32, 64, 96, 128, 256, 384, 512, 768, 1024]))
+    n = [1, 7, 31, 33, 100, 5000, 40_000, 140_000, 270_001, 200_000][seed]  # (every size class once: a random draw clusters)
+    nq = int(rng.choice([9, 10, 31, 32, 33, 64, 65, 100, 129]))
+    k = int(rng.choice([1, 5, 10, 100, 128]))
+    corpus = util.gaussian_rows(n, d, seed=2000 + seed)
+    if n > 50 and seed % 3 == 0:
+        corpus[rng.choice(n, size=min(n // 2, 300), replace=False)] = corpus[0]  # a crowd of duplicates
+    queries = util.gaussian_rows(nq, d, seed=3000 + seed)
+    if seed % 4 == 1:
+        queries[0] = 0.0  # a zero query
+    row_doc = (np.arange(n, dtype=np.uint64) * 3 + 5) if seed % 2 else None
+    st = make_store(ctx, corpus, row_doc)
+    docs = np.arange(n, dtype=np.uint64) if row_doc is None else row_doc
+    if n > 40:
+        for r in rng.choice(n, size=5, replace=False):
+            st.delete(int(docs[r]))
+    allow = None
+    if seed % 3 == 1:
+        allow = oa.AllowBitmap(int(docs.max()) + 1, docs[rng.random(n) < 0.7])
+    got = st.storage_search(queries, k, allow)
+    ctx.set_f32_batch(0)
+    try:
+        want = st.storage_search(queries, k, allow)
+    finally:
+        ctx.set_f32_batch(9)
+    assert np.array_equal(got[2], want[2]), (d, n, nq, k)
+    for j in range(nq):
+        m = int(want[2][j])
+        assert np.array_equal(got[0][j, :m], want[0][j, :m]), (d, n, nq, k, j)
+        assert np.array_equal(got[1][j, :m].view(np.uint32), want[1][j, :m].view(np.uint32)), (d, n, nq, k, j)
+    st.close()
