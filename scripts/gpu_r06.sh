@@ -32,7 +32,7 @@ for STEP in "$@"; do
     serving-f32) serving_build; echo "== serving vec f32"; timeout 600 scripts/native/bench_serving vec 10000000 60 8,64,256 f32 2>&1 | tee $O/serving_vec_f32.log ;;
     serving) serving_build
       timeout 600 scripts/native/bench_serving bm25 10000000 300 1,8,32,128 2>&1 | tee $O/serving_bm25.log
-      timeout 600 scripts/native/bench_serving hybrid 10000000 20 1,8,32 2>&1 | tee $O/serving_hybrid.log
+      timeout 600 scripts/native/bench_serving hybrid 10000000 20 1,8,32,128 2>&1 | tee $O/serving_hybrid.log
       timeout 600 scripts/native/bench_serving vec 10000000 60 8,64,256 f32 2>&1 | tee $O/serving_vec_f32.log ;;
     profall) prof driver_command python $R/bench.py --steps 20 --warmup 5 --no-pmc ;;
     pmc)  # FETCH_SIZE / WRITE_SIZE passes (separate, kernel trace only) over the scan kernels: total traffic per step / algorithmic

@@ -183,8 +183,8 @@ int main(int argc, char** argv) {
         for (int batched = 0; batched < 2; ++batched) {
             for (int nt : thread_counts) {
                 orama_batcher* vb = nullptr;
-                // plain fp32: K1b shares a corpus pass among <= 8 queries; with a shadow the fp16 scan takes 256
-                if (batched) CHECK(orama_batcher_create(vec, shadow ? 256 : 8, 0, &vb));
+                // plain fp32: a corpus pass proposes for <= 64 queries (K1x); with a shadow the fp16 scan takes 256
+                if (batched) CHECK(orama_batcher_create(vec, shadow ? 256 : 64, 0, &vb));
                 std::atomic<uint64_t> checksum{0};
                 auto worker = [&](int tid, int cnt) {
                     std::vector<uint64_t> ids(K), vid(K);
