@@ -43,13 +43,15 @@ COMMON_FLAGS = [
 ]
 # Translation units whose f32 arithmetic must round exactly like the scalar reference
 # (BM25F scores must be bit-identical to the scalar f32 evaluation): no FMA contraction.
-EXACT_FP = {"fulltext.hip", "bm25_kernels.hip", "bm25_ranges.hip", "bm25_ranges_merge.hip", "hybrid_tail.hip"}
+EXACT_FP = {"fulltext.hip", "bm25_kernels.hip", "bm25_ranges.hip", "bm25_ranges_fast.hip", "bm25_ranges_merge.hip", "hybrid_tail.hip"}
 # Superseded kernels kept for A/B measurements only — K2c (round-1 wide fp16 scan), K2h (K-split wave pairs, 6 % slower than
 # K2q) and the round-3 merge-tree form of K3r's scoring launch.  They are compiled and linked only when the environment says
 # ORAMA_COMPARISON_KERNELS=1 at build time; the product library does not contain them.
 # Round 6: + hybrid_tail.hip, the device form of the one-call hybrid search's tail — built, bit-identical and 40-70 us slower than
 # the host tail (profiles/r05_hybrid_device_tail_ab.log): it left the product library instead of shipping as a dead path.
-COMPARISON_UNITS = {"vec_f16_wide.hip", "vec_f16_kh.hip", "bm25_ranges_merge.hip", "hybrid_tail.hip"}
+#          + bm25_ranges_fast.hip, K3r's scoring launch with rank-free singletons and lists under the published floor left unscored —
+# bit-identical, 14 % fewer vector instructions, 66-80 % of the wave iterations unscored, and 3 % SLOWER (profiles/r06_k3r_fast_body.md).
+COMPARISON_UNITS = {"vec_f16_wide.hip", "vec_f16_kh.hip", "bm25_ranges_merge.hip", "hybrid_tail.hip", "bm25_ranges_fast.hip"}
 
 
 def comparison_build() -> bool:

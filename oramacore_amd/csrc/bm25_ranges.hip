@@ -939,6 +939,9 @@ int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStr
         const bool plain = !b.map_idx && !b.omc_dense && !b.any_minmax && b.post_ntf;
         ORAMA_REQUIRE(!b.compact_keys || (plain && !wide), "internal: compact key lists need the plain scoring launch");
         if (wide) hipLaunchKernelGGL((range_score_kernel<false, true>), dim3(grid), dim3(kThreads), 0, stream, b);
+#if ORAMA_COMPARISON_KERNELS
+        else if (plain && b.compact_keys && ctx->k3r_fast) return launch_range_score_fast(ctx, b, stream);
+#endif
         else if (plain && b.compact_keys) {
             ORAMA_REQUIRE(b.score_pub, "internal: compact key lists without their published-score table");
             ORAMA_REQUIRE(b.stripe_start && b.stripe_total == grid, "internal: stripe table not filled");

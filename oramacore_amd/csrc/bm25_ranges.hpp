@@ -121,6 +121,10 @@ int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream)
 // df_only: count distinct (token, document) pairs into results[q].df for the queries that want it.
 int launch_range_score(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStream_t stream);
 #if ORAMA_COMPARISON_KERNELS
+// The plain top-k batch with compact key lists, round-6 experiment (bm25_ranges_fast.hip): singletons need no ranks, lists whose
+// singletons cannot reach the published floor are not scored.  Same answers, bit for bit, fewer instructions — and not faster
+// (profiles/r06_k3r_fast_body.md): comparison builds only, option "k3r_fast" (default 0).
+int launch_range_score_fast(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream);
 // The round-2/3 scoring launch (bm25_ranges_merge.hip: 64-bit keys merged by a merge tree in LDS), kept for A/B runs only.
 int launch_range_score_merge(orama_ctx* ctx, const RangeBatch& b, bool df_only, hipStream_t stream);
 #endif

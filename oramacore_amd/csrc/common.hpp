@@ -320,6 +320,8 @@ struct orama_ctx {
     // per-WORKGROUP fixed work, so fuller ranges are cheaper per posting — 231 K -> 239 K queries/s in one lease, 242 K at 1 920
     // (profiles/r06_k3r_target_sweep.log); 1 920 leaves the 2 048-posting cap ~3 sigma of a Poisson range away, 1 792 six
     uint32_t k3r_target = 1792;
+    // comparison builds: the plain top-k batch's scoring launch by bm25_ranges_fast.hip (1) instead of bm25_ranges.hip's body (0)
+    bool k3r_fast = false;
     bool select_pairs = true;        // K4: (value, index) lists in two launches ("select_pairs" 0 = histogram passes)
     int compute_units = 0;
     uint64_t hbm_bytes = 0;

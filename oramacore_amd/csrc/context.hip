@@ -316,6 +316,7 @@ const CtxOption kCtxOptions[] = {
     ORAMA_OPT("select_wide", 0, 3, c->select_wide = (int)v),                // K4 over a lone query's distances (select.hip)
     ORAMA_OPT("select_pairs", 0, 1, c->select_pairs = v != 0),
 #if ORAMA_COMPARISON_KERNELS
+    ORAMA_OPT("k3r_fast", 0, 1, c->k3r_fast = v != 0),                      // plain top-k batches scored by bm25_ranges_fast.hip (the r06 experiment)
     ORAMA_OPT("hybrid_device_tail", 0, 1, c->hybrid_device_tail = v != 0),  // orama_hybrid_search finishes on the device (hybrid_tail.hip)
 #else
     CtxOption{"hybrid_device_tail", 0, 1, [](orama_ctx*, long long v) -> int {  // a comparison unit: not in this library

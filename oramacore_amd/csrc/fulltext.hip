@@ -1308,9 +1308,11 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
             if (jb.out_count) *jb.out_count = h_res[ci].count;
             if (c.rb.compact_keys && k3r_stats_enabled() && k3r_stats_lines.fetch_add(1) < 24)
                 fprintf(stderr, "[k3r] query of %llu postings, %u ranges: %u keys appended (%.2f %%), top_k %u | dbg16: %u workgroups found a "
-                        "published floor, %u above their own; largest published %08x, largest local %08x\n",
+                        "published floor, %u above their own (fast body: wave iterations not scored); largest published %08x, largest local %08x | "
+                        "fast body: %u wave iterations, %u kept postings of which %u of lists under the floor\n",
                         (unsigned long long)pd.total, c.queries[ci].n_ranges, h_res[ci].n_keys, 100.0 * h_res[ci].n_keys / (double)pd.total,
-                        jb.params->top_k, h_res[ci].pad0[0], h_res[ci].pad0[1], h_res[ci].score_floor, h_res[ci].pad0[2]);
+                        jb.params->top_k, h_res[ci].pad0[0], h_res[ci].pad0[1], h_res[ci].score_floor, h_res[ci].pad0[2], h_res[ci].pad0[3],
+                        h_res[ci].pad0[5], h_res[ci].pad0[4]);
             if (jb.params->top_k) {
                 const uint32_t n = std::min(reinterpret_cast<const uint32_t*>(h_n)[ci], jb.params->top_k);
                 memcpy(jb.out_ids, h_ids + (size_t)ci * kk * 8, (size_t)n * 8);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """C4-shaped BM25 batch of 32 queries (one set of launches): wall time and device time per query by kernel."""
-import sys, time
+import os, sys, time
 from pathlib import Path
 import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
@@ -9,6 +9,8 @@ import oramacore_amd as oa
 from oramacore_amd import fulltext as ft
 n, T, k = 10_000_000, 12, 100
 ctx = oa.Context(0)
+if os.environ.get("K3R_FAST") is not None:  # (comparison flavour: run with ORAMA_COMPARISON_KERNELS=1)  # the plain batch's scoring body: 1 = bm25_ranges_fast.hip, 0 = the round-5 body
+    ctx.set_option("k3r_fast", int(os.environ["K3R_FAST"]))
 rng = np.random.default_rng(0xB26)
 ranks = np.unique(np.exp(rng.uniform(np.log(100), np.log(100000), size=2048)).astype(np.uint32))
 post = ft.PostingsStore(ctx)

@@ -1,8 +1,10 @@
 #!/bin/bash
 # SQ counters of K3r's scoring launch (one set of launches over 32 C4-shaped queries): where do the wave cycles go?
+#   comparison flavour (ORAMA_COMPARISON_KERNELS=1), both bodies of the plain batch:
+#   KERNEL=range_score_fast_kernel K3R_FAST=1 OUT=k3r_sq_fast scripts/k3r_sq_pmc.sh ; KERNEL=range_score_compact_kernel K3R_FAST=0 OUT=k3r_sq_r05 scripts/k3r_sq_pmc.sh
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$PWD
-O=$R/gpurun_out/k3r_sq
+O=$R/gpurun_out/${OUT:-k3r_sq}
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
@@ -18,7 +20,7 @@ python - <<'PY'
 import csv, glob, statistics, collections, os
 KERNEL = os.environ.get("KERNEL", "range_score_kernel")
 vals = collections.defaultdict(list)
-for path in glob.glob("gpurun_out/k3r_sq/*/*counter_collection.csv"):
+for path in glob.glob("gpurun_out/" + os.environ.get("OUT", "k3r_sq") + "/*/*counter_collection.csv"):
     for row in csv.DictReader(open(path, newline="")):
         if KERNEL in row["Kernel_Name"]:
             vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
