@@ -67,7 +67,8 @@ def obj_dir() -> Path:
 
 
 def _flags() -> list[str]:
-    return [*COMMON_FLAGS, f"-DORAMA_COMPARISON_KERNELS={1 if comparison_build() else 0}"]
+    extra = [f"-DORAMA_K3R_WG={os.environ['ORAMA_K3R_WG']}"] if os.environ.get("ORAMA_K3R_WG") else []  # (experiments: 512-thread scoring workgroups)
+    return [*COMMON_FLAGS, f"-DORAMA_COMPARISON_KERNELS={1 if comparison_build() else 0}", *extra]
 
 
 def _hipcc() -> str:

@@ -129,14 +129,14 @@ __global__ __launch_bounds__(kBoundsThreads) void range_bounds_kernel(RangeBatch
 //     per-posting code: a multi-posting document's postings only park their value in a cell; the documents themselves are
 //     listed densely and folded + reported by as many lanes as there are such documents;
 //   * reductions through LDS atomics without return (one instruction) instead of cross-lane shuffles (~30).
-constexpr int kThreads = 256;
+constexpr int kThreads = (int)kRangeThreads;
 constexpr int kWaves = kThreads / 64;
 static_assert(kRangeCap / kThreads == 8, "a lane carries at most 8 postings through the phases (score_body<.., 8>)");
 constexpr uint32_t kBitWords = kRangeMaxWidth / 32;        // bitmap words of the widest range
 constexpr int kWordsPerThread = kBitWords / kThreads;
-constexpr uint32_t kBlkShift = 5, kBlocks = kRangeCap >> kBlkShift;  // run lookup table: one entry per 32 gathered postings
-constexpr uint32_t kCells = 1024;                          // cells of the multi-posting documents of one range ...
-constexpr uint32_t kMultiMax = 512;                        // ... and how many such documents: more raise `overflow` (narrower ranges)
+constexpr uint32_t kBlkShift = kThreads == 256 ? 5 : 6, kBlocks = kRangeCap >> kBlkShift;  // run lookup table: one entry per 32 (64) gathered postings
+constexpr uint32_t kCells = 4 * kThreads;                  // cells of the multi-posting documents of one range ...
+constexpr uint32_t kMultiMax = 2 * kThreads;               // ... and how many such documents: more raise `overflow` (narrower ranges)
 static_assert(kRangeCap % kThreads == 0 && kBitWords % kThreads == 0, "phase loops are unrolled over whole threads");
 static_assert(kRangeCap <= 0x8000u && kRangeMaxWidth <= 0x10000u, "posting slot and local document share one 32-bit word");
 static_assert(kBlocks <= 64, "the block table is built by one wave");

@@ -7,8 +7,14 @@
 
 namespace orama {
 
-constexpr uint32_t kRangeCap = 2048;     // postings one workgroup scores in LDS
-constexpr uint32_t kRangeMaxWidth = 32768;  // documents per range (one bit each in the workgroup's LDS bitmap)
+// Threads of a scoring workgroup (256 or 512): a lane carries up to 8 postings, so a range holds at most 8 x that many.
+#ifndef ORAMA_K3R_WG
+#define ORAMA_K3R_WG 256
+#endif
+constexpr uint32_t kRangeThreads = ORAMA_K3R_WG;
+static_assert(kRangeThreads == 256 || kRangeThreads == 512, "scoring workgroups of four or eight waves");
+constexpr uint32_t kRangeCap = 8 * kRangeThreads;         // postings one workgroup scores in LDS
+constexpr uint32_t kRangeMaxWidth = 128 * kRangeThreads;  // documents per range (one bit each in the workgroup's LDS bitmap)
 constexpr uint32_t kRangeMaxRefs = 64;   // non-empty posting lists per query: one bit each in the scoring launch's presence masks
 constexpr uint32_t kRangeBatchMax = 32;  // queries scored by one set of launches
 constexpr uint32_t kRangeStripes = 8;     // compact key lists: the scoring launch walks the batch in this many passes over its queries

@@ -31,17 +31,17 @@ namespace orama {
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = (int)kRangeThreads;
 constexpr int kWaves = kThreads / 64;
 static_assert(kRangeCap / kThreads == 8, "a lane carries at most 8 postings through the phases");
 constexpr uint32_t kBitWords = kRangeMaxWidth / 32;
 constexpr int kWordsPerThread = kBitWords / kThreads;
-constexpr uint32_t kBlkShift = 5, kBlocks = kRangeCap >> kBlkShift;
-constexpr uint32_t kCells = 1024;    // postings of multi-posting documents one range may hold ...
-constexpr uint32_t kMultiMax = 512;  // ... and how many such documents: more raise `overflow` (narrower ranges), as in the round-5 body
+constexpr uint32_t kBlkShift = kThreads == 256 ? 5 : 6, kBlocks = kRangeCap >> kBlkShift;
+constexpr uint32_t kCells = 4 * kThreads;    // postings of multi-posting documents one range may hold ...
+constexpr uint32_t kMultiMax = 2 * kThreads;  // ... and how many such documents: more raise `overflow` (narrower ranges), as in the round-5 body
 constexpr int kCellRounds = kCells / kThreads, kMultiRounds = kMultiMax / kThreads;
 static_assert(kRangeCap % kThreads == 0 && kBitWords % kThreads == 0 && kCells % kThreads == 0 && kMultiMax % kThreads == 0, "whole threads");
-static_assert(kRangeMaxWidth <= 0x8000u && kRangeMaxRefs <= 64, "local document: 15 bits, reference: 6 bits of a posting's word");
+static_assert(kRangeMaxWidth <= 0x10000u && kRangeMaxRefs <= 64 && kMultiMax <= 1024, "local document: 16 bits, reference: 6 bits, multi rank: 10 bits of a word");
 static_assert(kBlocks <= 64, "the block table is built by one wave");
 static_assert(kCells == kBitWords && kMultiMax * 2 == kBitWords, "cells take the multi bitmap's place, cell bases + documents the rank table's");
 
@@ -94,7 +94,7 @@ __device__ __forceinline__ void fast_body(const RangeBatch& b, const RangeQuery&
     const uint32_t pub_floor = L.pub_floor;
 
     // ---- A. gather; mark the document; a posting of a list whose singletons cannot reach the published floor is flagged
-    uint32_t pk[NITER];  // [kept:1 | token:6 | pad:2 | reference:6 | below-floor list:1 | pad:1 | local document:15]
+    uint32_t pk[NITER];  // [kept:1 | token:6 | below-floor list:1 | pad:1 | reference:6 | pad:1 | local document:16]
     float pv[NITER];     // normalised tf (boost included)
 #pragma unroll
     for (int g = 0; g < NITER; g += 4) {
@@ -134,7 +134,7 @@ __device__ __forceinline__ void fast_body(const RangeBatch& b, const RangeQuery&
             // [0, idf (k+1) (1 + 3 ulp)] (seg_ub's conditions on idf and k), i.e. `applied` holds and the list's bound applies
             const bool tame = (__builtin_bit_cast(uint32_t, val) - 0x00800000u) < 0x71000000u;
             const bool under = tame && L.seg_ub[run[j]] < pub_floor;
-            pk[n] = kept ? (L.seg_pkb[run[j]] | (under ? 0x10000u : 0u) | dl) : 0u;
+            pk[n] = kept ? (L.seg_pkb[run[j]] | (under ? 0x1000000u : 0u) | dl) : 0u;
             pv[n] = val;
             // (both atomics by every lane, a dropped posting ORs nothing: the launch is bound by the SCALAR unit — exec masks and
             // branches — and a skipped LDS atomic saves nothing there, profiles/r06_k3r_fast_sq_counters.md)
@@ -156,10 +156,10 @@ __device__ __forceinline__ void fast_body(const RangeBatch& b, const RangeQuery&
 #endif
 #pragma unroll
     for (int n = 0; n < NITER; ++n) {
-        const uint32_t dl = pk[n] & 0x7fffu;
+        const uint32_t dl = pk[n] & 0xffffu;
         const bool kept = (pk[n] >> 31) != 0u;
         const bool is_multi = kept && ((L.multi[dl >> 5] >> (dl & 31u)) & 1u);
-        const bool under = ((pk[n] >> 16) & 1u) != 0u;
+        const bool under = ((pk[n] >> 24) & 1u) != 0u;
         ko[n] = 0u;
 #if ORAMA_COMPARISON_KERNELS
         if (__ballot(kept) != 0ull) {
@@ -363,7 +363,7 @@ __device__ __forceinline__ void fast_body(const RangeBatch& b, const RangeQuery&
 #pragma unroll
     for (int n = 0; n < NITER; ++n) {
         if (ko[n] >= floor_w)
-            lst[at + (uint32_t)__popcll(sm[n] & below_me)] = ((unsigned long long)ko[n] << 32) | (unsigned long long)(~(doc0 + (pk[n] & 0x7fffu)));
+            lst[at + (uint32_t)__popcll(sm[n] & below_me)] = ((unsigned long long)ko[n] << 32) | (unsigned long long)(~(doc0 + (pk[n] & 0xffffu)));
         at += (uint32_t)__popcll(sm[n]);
     }
 #pragma unroll

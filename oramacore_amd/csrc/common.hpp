@@ -319,7 +319,7 @@ struct orama_ctx {
     // postings per document range of K3r ("k3r_target").  1 792 since round 6 (1 536 before): the scoring launch's cost is mostly
     // per-WORKGROUP fixed work, so fuller ranges are cheaper per posting — 231 K -> 239 K queries/s in one lease, 242 K at 1 920
     // (profiles/r06_k3r_target_sweep.log); 1 920 leaves the 2 048-posting cap ~3 sigma of a Poisson range away, 1 792 six
-    uint32_t k3r_target = 1792;
+    uint32_t k3r_target = 0;  // (0: 7/8 of what a scoring workgroup holds — 1 792 with 256 threads)
     // comparison builds: the plain top-k batch's scoring launch by bm25_ranges_fast.hip (1) instead of bm25_ranges.hip's body (0)
     bool k3r_fast = false;
     bool select_pairs = true;        // K4: (value, index) lists in two launches ("select_pairs" 0 = histogram passes)

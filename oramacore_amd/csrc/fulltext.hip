@@ -636,7 +636,7 @@ bool ranges_eligible(const orama_post* p, const orama_term_ref* refs, uint32_t n
 // independent lists ever after (scripts/bench_overlap_lists.py).  The factor that held is remembered per list set
 // (orama_post::shrink_hint).
 uint32_t choose_width(uint64_t n_docs, uint64_t total_postings, uint32_t narrow16, uint32_t target_opt) {
-    const uint64_t target = target_opt >= 16 && target_opt <= kRangeCap ? target_opt : 1792;  // option "k3r_target"
+    const uint64_t target = target_opt >= 16 && target_opt <= kRangeCap ? target_opt : 7 * kRangeThreads;  // option "k3r_target" (0: 7/8 of what a workgroup holds)
     uint64_t w = total_postings ? n_docs * target / total_postings : n_docs;
     if (narrow16 > 16u) w = w * 16u / narrow16;
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(w, 1), kRangeMaxWidth);
