@@ -733,6 +733,99 @@ def test_the_range_width_that_held_is_remembered(ctx):
     corpus.store.close()
 
 
+def test_postings_per_range_never_change_an_answer(ctx):
+    """Option `k3r_target` (postings per document range; 0 = the default, 7/8 of what a scoring workgroup holds): from ranges of a
+    few dozen postings to ranges AT the workgroup's capacity (where many overflow and their queries rerun with narrower ranges),
+    single calls and batches return the oracle's ids, score bits and counts.  The round-6 experiment `k3r_fast` is a comparison
+    unit: the product library refuses the option instead of ignoring it."""
+    rng = np.random.default_rng(91)
+    n_docs = 300_000
+    lists = random_lists(rng, n_docs, 10, 2, 500, 60_000)
+    corpus = Corpus(ctx, n_docs, lists, [50.0, 8.0], seed=92)
+    queries = []
+    for _ in range(12):
+        nt = int(rng.integers(1, 7))
+        queries.append(([(t, int(l), float(F(rng.choice([1.0, 2.0])))) for t, l in enumerate(rng.choice(10, size=nt, replace=False))], nt, None))
+    expect = [corpus.oracle(refs, nt, 100) for refs, nt, _ in queries]
+    try:
+        for target in (0, 16, 300, 1792, 2048, 4096):  # (4096: above what a 256-thread workgroup holds -> the default)
+            ctx.set_option("k3r_target", target)
+            got = corpus.store.search_batch(queries, float(n_docs), 100)
+            got += [corpus.store.search(refs, nt, float(n_docs), 100) for refs, nt, _ in queries[:4]]
+            for (ids, sc, count), (od, os_, ocount) in zip(got, expect + expect[:4]):
+                assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_)), target
+    finally:
+        ctx.set_option("k3r_target", 0)
+    from oramacore_amd import _build
+
+    if not _build.comparison_build():
+        with pytest.raises(oa.OramaError):
+            ctx.set_option("k3r_fast", 1)
+    corpus.store.close()
+
+
+_FAST_BODY_SCRIPT = r"""
+import sys
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, root + "/tests")
+import numpy as np
+import oramacore_amd as oa
+from test_bm25_ranges_gpu import Corpus, random_lists, bits, F
+
+rng = np.random.default_rng(123)
+n_docs = 600_000
+lists = random_lists(rng, n_docs, 12, 2, 2_000, 120_000)
+allow_mask = rng.random(n_docs) < 0.7
+queries = []
+for i in range(96):
+    nt = int(rng.integers(2, 9))
+    refs = [(t, int(l), float(F(rng.choice([1.0, 1.5])))) for t, l in enumerate(rng.choice(12, size=nt, replace=False))]
+    if i % 8 == 0:  # the same token in two lists (two fields): multi-posting documents whose postings share a token
+        refs.append((refs[-1][0], int((refs[-1][1] + 1) % 12), 1.0))
+    queries.append((refs, nt, 2 if i % 11 == 0 else None))  # (threshold: at least 2 of the query's tokens)
+answers = {}
+for fast in (0, 1):
+    ctx = oa.Context(0)
+    ctx.set_option("k3r_fast", fast)
+    corpus = Corpus(ctx, n_docs, lists, [50.0, 8.0], seed=124)
+    bm = oa.AllowBitmap(n_docs, np.arange(n_docs, dtype=np.uint64)[allow_mask])
+    got = {}
+    for k in (1, 100, 300):
+        got[("plain", k)] = corpus.store.search_batch(queries, float(n_docs), k)
+    got[("filtered", 100)] = corpus.store.search_batch(queries[:48], float(n_docs), 100, allow=bm)
+    if fast:
+        for (refs, nt, thr), (ids, sc, count) in zip(queries[:6], got[("plain", 100)][:6]):
+            od, os_, ocount = corpus.oracle(refs, nt, 100, thr)
+            assert count == ocount and ids.tolist() == od.tolist() and np.array_equal(bits(sc), bits(os_))
+    answers[fast] = got
+    corpus.store.close(); ctx.close()
+for key in answers[0]:
+    for a, b in zip(answers[0][key], answers[1][key]):
+        assert a[2] == b[2] and a[0].tolist() == b[0].tolist() and np.array_equal(bits(a[1]), bits(b[1])), key
+print("identical", sum(len(v) for v in answers[0].values()))
+"""
+
+
+def test_comparison_scoring_body_equals_the_product_body(tmp_path):
+    """bm25_ranges_fast.hip (round 6: singletons without ranks, lists under the published floor left unscored) is a comparison
+    unit — not faster, kept with its record (profiles/r06_k3r_fast_body.md).  Where liborama_hip_cmp.so is present it must return
+    the product body's answers bit for bit: batches of 96 queries (floors get published: hundreds of ranges per query), k = 1 /
+    100 / 300, thresholds, a token with two lists, a filter; the first queries against the oracle as well."""
+    import os, subprocess, sys
+    from pathlib import Path
+
+    from oramacore_amd import _build
+
+    if not _build.LIB_CMP.exists():
+        pytest.skip("liborama_hip_cmp.so is not built (ORAMA_COMPARISON_KERNELS=1 python -c 'import __graft_entry__ as g; g.build()')")
+    root = str(Path(__file__).resolve().parent.parent)
+    script = tmp_path / "fast_body.py"
+    script.write_text(_FAST_BODY_SCRIPT)
+    r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, ORAMA_COMPARISON_KERNELS="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.strip().splitlines()[-1].startswith("identical"), r.stdout[-500:]
+
+
 def test_hybrid_tail_on_the_device_equals_the_host_tail():
     """Round 5: orama_hybrid_search finishes ON THE DEVICE (hybrid_tail.hip: a2 epilogue, per-document scoring of the hits,
     normalize_and_combine, K4 — one read-back, one host wake-up).  Same corpus on two contexts, one of them with option
