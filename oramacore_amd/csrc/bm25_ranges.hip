@@ -901,7 +901,81 @@ __global__ __launch_bounds__(256) void ntf_precompute_kernel(const uint32_t* __r
     }
 }
 
+// Dense-list accelerators (orama_post::d_acc, RangeSeg::acc_off).  acc_bits_kernel: every posting of an accelerated list sets its
+// document's bit (grid.y = the list).  acc_scan_kernel: one workgroup per list — the exclusive popcount prefix of the bitmap's
+// words (a posting's position in its list = prefix of its word + set bits below it in the word) and the smallest / largest
+// normalised tf of the list (NaN if any posting's is).
+__global__ __launch_bounds__(256) void acc_bits_kernel(const uint32_t* __restrict__ post_doc, const uint64_t* __restrict__ list_off,
+                                                       const uint32_t* __restrict__ acc_list, uint32_t acc_words, uint32_t* __restrict__ acc) {
+    const uint32_t i = blockIdx.y, l = acc_list[i];
+    const uint64_t begin = list_off[l], end = list_off[l + 1];
+    uint32_t* bits = acc + (size_t)i * 2 * acc_words;
+    for (uint64_t j = begin + (uint64_t)blockIdx.x * 256 + threadIdx.x; j < end; j += (uint64_t)gridDim.x * 256) {
+        const uint32_t d = post_doc[j];
+        if ((d >> 5) < acc_words) atomicOr(&bits[d >> 5], 1u << (d & 31u));
+    }
+}
+constexpr int kAccScanThreads = 1024;
+__global__ __launch_bounds__(kAccScanThreads) void acc_scan_kernel(const float* __restrict__ post_ntf, const uint64_t* __restrict__ list_off,
+                                                                  const uint32_t* __restrict__ acc_list, uint32_t acc_words,
+                                                                  uint32_t* __restrict__ acc, float* __restrict__ minmax) {
+    __shared__ uint32_t part[kAccScanThreads];
+    __shared__ float red_lo[kAccScanThreads / 64], red_hi[kAccScanThreads / 64];
+    __shared__ uint32_t red_nan;
+    const uint32_t i = blockIdx.x, l = acc_list[i], t = threadIdx.x;
+    const uint32_t* bits = acc + (size_t)i * 2 * acc_words;
+    uint32_t* wrank = acc + (size_t)i * 2 * acc_words + acc_words;
+    const uint32_t per = (acc_words + kAccScanThreads - 1) / kAccScanThreads;
+    const uint32_t w0 = min(t * per, acc_words), w1 = min(w0 + per, acc_words);
+    uint32_t sum = 0;
+    for (uint32_t w = w0; w < w1; ++w) sum += (uint32_t)__popc(bits[w]);
+    part[t] = sum;
+    if (t == 0) red_nan = 0u;
+    __syncthreads();
+    for (int off = 1; off < kAccScanThreads; off <<= 1) {  // (Hillis-Steele over 1 024 partial sums: the launch runs once per build)
+        const uint32_t v = t >= (uint32_t)off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t w = w0; w < w1; ++w) {
+        wrank[w] = run;
+        run += (uint32_t)__popc(bits[w]);
+    }
+    float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+    bool nan = false;
+    for (uint64_t j = list_off[l] + t; j < list_off[l + 1]; j += kAccScanThreads) {
+        const float v = post_ntf[j];
+        nan |= v != v;
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    }
+    if (nan) atomicOr(&red_nan, 1u);
+    if ((t & 63u) == 0) red_lo[t >> 6] = lo, red_hi[t >> 6] = hi;
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < kAccScanThreads / 64; ++w) lo = fminf(lo, red_lo[w]), hi = fmaxf(hi, red_hi[w]);
+        minmax[2 * i] = red_nan ? __builtin_nanf("") : lo;
+        minmax[2 * i + 1] = red_nan ? __builtin_nanf("") : hi;
+    }
+}
+
 }  // namespace
+
+int launch_acc_build(const uint32_t* post_doc, const float* post_ntf, const uint64_t* d_list_off, const uint32_t* d_acc_list, uint32_t n_acc,
+                     uint32_t acc_words, uint32_t* d_acc, float* d_minmax, hipStream_t stream) {
+    if (n_acc == 0) return ORAMA_OK;
+    ORAMA_HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)n_acc * 2 * acc_words * 4, stream));
+    hipLaunchKernelGGL(acc_bits_kernel, dim3(512, n_acc), dim3(256), 0, stream, post_doc, d_list_off, d_acc_list, acc_words, d_acc);
+    hipLaunchKernelGGL(acc_scan_kernel, dim3(n_acc), dim3(kAccScanThreads), 0, stream, post_ntf, d_list_off, d_acc_list, acc_words, d_acc, d_minmax);
+    ORAMA_HIP_TRY(hipGetLastError());
+    return ORAMA_OK;
+}
 
 int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream) {
     if (b.total_postings == 0 || b.n_queries == 0 || b.max_bound_entries == 0) {

@@ -27,6 +27,10 @@ struct RangeSeg {
     uint32_t tok_rank;    // token << 10 | rank (position of the list among the token's lists)
     float boost;
     float avg_len;
+    // Dense-list accelerator (round 6, orama_post::d_acc): 1 + the offset, in 32-bit words, of this list's
+    // [bitmap over the index's documents | exclusive popcount prefix of the bitmap's words] inside RangeBatch::post_acc; 0 = none
+    // (a list under n_docs / 128 postings or beyond the store's budget, a posting whose normalised tf is not a tame number)
+    uint64_t acc_off;
 };
 
 struct RangeQuery {
@@ -88,6 +92,9 @@ struct RangeBatch {
     // tf / ((1 - b) + b * len / avg_len) per posting, stored by the store for ITS b and average lengths (nullptr when the
     // query's b differs: the kernels then divide themselves — same operations, same bits)
     const float* post_ntf = nullptr;
+    // dense-list accelerators (RangeSeg::acc_off): per list acc_words bitmap words, then acc_words word ranks; nullptr = none
+    const uint32_t* post_acc = nullptr;
+    uint32_t acc_words = 0;              // ceil(n_docs / 32)
     uint32_t* bounds = nullptr;
     const uint64_t* docs = nullptr;      // local idx -> DocumentId (filter); nullptr when the ids are dense_base + idx
     uint64_t dense_base = 0;
@@ -136,6 +143,11 @@ int launch_range_score_merge(orama_ctx* ctx, const RangeBatch& b, bool df_only, 
 #endif
 // post_ntf[i] = tf_i / ((1 - b) + b * len_i / avg_len[list of i]) for every posting of the store (list_off: n_lists + 1
 // offsets, list_avg: the average length of each list's field; both on the device).
+// Dense-list accelerators: for each of the n_acc lists (acc_list: list index, its postings at list_off), the bitmap of its
+// documents and the exclusive popcount prefix of the bitmap's words at d_acc + i * 2 * acc_words (zeroed by the call), and the
+// smallest / largest post_ntf of the list at d_minmax[2 i], [2 i + 1] (a NaN anywhere yields NaN).
+int launch_acc_build(const uint32_t* post_doc, const float* post_ntf, const uint64_t* d_list_off, const uint32_t* d_acc_list, uint32_t n_acc,
+                     uint32_t acc_words, uint32_t* d_acc, float* d_minmax, hipStream_t stream);
 int launch_ntf_precompute(const uint32_t* post_val, float* post_ntf, const uint64_t* d_list_off, const float* d_list_avg,
                           uint32_t n_lists, uint64_t n_postings, float b, hipStream_t stream);
 // Hybrid: the full-text score of `n` given documents (local indices) of query `qi`, by the same fold as the range kernel

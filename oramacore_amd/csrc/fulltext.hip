@@ -198,6 +198,14 @@ struct orama_post {
     // query (same f32 operations in the same order as the kernels' own division: same bits).  A search with another b
     // divides in the kernel.  +4 B per posting.
     DevBuf d_post_ntf;
+    // Dense-list accelerators (round 6): for the longest lists (at least n_docs / 128 postings, as many as fit 6 bytes per posting
+    // of the store) whose normalised tfs are all tame numbers, a bitmap of its documents + the exclusive popcount prefix of the
+    // bitmap's words (n_docs / 4 bytes per list).  Derived data, rebuilt with post_ntf whenever the postings change; the range scorer reads a
+    // frequent term's documents as WORDS where the query's published floor says none of them can reach the answer alone
+    // (bm25_ranges_fast.hip).  acc_off_of_list[l] = RangeSeg::acc_off (0: none).
+    DevBuf d_acc;
+    std::vector<uint64_t> acc_off_of_list;
+    uint32_t acc_words = 0;
     float ntf_b = 0.75f;  // Bm25Params::default().b
     bool ntf_valid = false;
     bool has_omc = false;
@@ -303,6 +311,56 @@ void shrink_remember(orama_post* p, const orama_term_ref* refs, uint32_t n_refs,
 // committed before this runs, so a failure here — out of memory for the +4 B per posting, a HIP error — must not fail the
 // build / append that called it (a caller that retried the append would append twice: ADVICE r04).  It leaves ntf_valid
 // false — the kernels then divide themselves, same operations, same bits — and reports OK.
+// orama_post::d_acc.  Best effort: without memory for them (or on any failure) the store simply has no accelerators.
+void build_dense_accelerators(orama_post* p, const uint64_t* d_list_off) {
+    p->acc_off_of_list.assign(p->n_lists, 0);
+    p->acc_words = 0;
+    if (!p->ctx->bm25_dense_acc || p->n_docs < 32768 || p->n_docs > 0xffffffffull) return;
+    // the longest lists first, as many as fit a budget of 6 bytes per posting of the store (+50 % at most), none under
+    // n_docs / 128 postings (a word of such a list holds a posting every fourth time: reading it costs what gathering does)
+    std::vector<uint32_t> lists;
+    for (uint32_t l = 0; l < p->n_lists; ++l)
+        if ((p->list_off[l + 1] - p->list_off[l]) * 128 >= p->n_docs) lists.push_back(l);
+    if (lists.empty()) return;
+    const uint32_t words = (uint32_t)((p->n_docs + 31) / 32);
+    std::sort(lists.begin(), lists.end(), [&](uint32_t a, uint32_t b2) {
+        const uint64_t la = p->list_off[a + 1] - p->list_off[a], lb = p->list_off[b2 + 1] - p->list_off[b2];
+        return la != lb ? la > lb : a < b2;
+    });
+    const uint64_t fit = p->n_postings * 6 / ((uint64_t)words * 8);
+    if (fit == 0) return;
+    if (lists.size() > fit) lists.resize((size_t)fit);
+    const uint32_t n = (uint32_t)lists.size();
+    const size_t acc_bytes = (size_t)n * 2 * words * 4;
+    DevBuf aux;  // [list indices u32 x n | min, max f32 x n]
+    std::vector<float> minmax((size_t)n * 2);
+    bool ok = p->d_acc.reserve(acc_bytes) == ORAMA_OK && aux.reserve((size_t)n * 12) == ORAMA_OK &&
+              hipMemcpy(aux.p, lists.data(), (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              launch_acc_build(p->d_post_doc.as<uint32_t>(), p->d_post_ntf.as<float>(), d_list_off, aux.as<uint32_t>(), n, words,
+                               p->d_acc.as<uint32_t>(), reinterpret_cast<float*>(aux.as<char>() + (size_t)n * 4), nullptr) == ORAMA_OK &&
+              hipDeviceSynchronize() == hipSuccess &&
+              hipMemcpy(minmax.data(), aux.as<char>() + (size_t)n * 4, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) {
+        if (const char* e = orama::dev_env("ORAMA_K3R_STATS"); e && std::atoi(e) != 0)
+            fprintf(stderr, "[k3r] dense-list accelerators: build failed (%u lists, %.1f MB): %s\n", n, acc_bytes / 1e6, hipGetErrorString(hipGetLastError()));
+        (void)hipGetLastError();
+        clear_error();
+        p->d_acc.release();
+        return;
+    }
+    p->acc_words = words;
+    if (const char* e = orama::dev_env("ORAMA_K3R_STATS"); e && std::atoi(e) != 0)  // (comparison flavour)
+        fprintf(stderr, "[k3r] dense-list accelerators: %u of %u lists, %.1f MB; first list ntf in [%g, %g]\n", n, p->n_lists, acc_bytes / 1e6,
+                minmax[0], minmax[1]);
+    for (uint32_t i = 0; i < n; ++i) {
+        // every normalised tf of the list within [2^-60, 2^60]: with a field boost within [2^-40, 2^39] (checked per query by
+        // the kernel) every contribution S is a positive normal number under 2^100 — `applied` holds for every posting of the
+        // list without looking at it (bm25.rs: S normal, the term a number)
+        const float lo = minmax[2 * i], hi = minmax[2 * i + 1];
+        if (lo >= 0x1p-60f && hi <= 0x1p60f) p->acc_off_of_list[lists[i]] = 1 + (uint64_t)i * 2 * words;
+    }
+}
+
 int refresh_post_ntf_try(orama_post* p) {
     ++p->mutations;
     {  // (every change of the postings comes through here: what was counted over the old lists is forgotten)
@@ -311,6 +369,7 @@ int refresh_post_ntf_try(orama_post* p) {
         p->shrink_hint.clear();
     }
     p->ntf_valid = false;
+    p->acc_off_of_list.assign(p->n_lists, 0);
     if (p->n_postings == 0 || p->n_lists == 0) return ORAMA_OK;
     const size_t need = (size_t)p->n_postings * 4;
     if (need > p->d_post_ntf.cap) ORAMA_TRY(p->d_post_ntf.reserve(need + need / 4));  // (appends grow the arrays with the same slack)
@@ -327,6 +386,7 @@ int refresh_post_ntf_try(orama_post* p) {
                                     nullptr));
     ORAMA_HIP_TRY(hipDeviceSynchronize());
     p->ntf_valid = true;
+    build_dense_accelerators(p, table.as<uint64_t>());
     return ORAMA_OK;
 }
 int refresh_post_ntf(orama_post* p) {
@@ -639,6 +699,7 @@ uint32_t choose_width(uint64_t n_docs, uint64_t total_postings, uint32_t narrow1
     const uint64_t target = target_opt >= 16 && target_opt <= kRangeCap ? target_opt : 7 * kRangeThreads;  // option "k3r_target" (0: 7/8 of what a workgroup holds)
     uint64_t w = total_postings ? n_docs * target / total_postings : n_docs;
     if (narrow16 > 16u) w = w * 16u / narrow16;
+    if (w >= 64) w &= ~31ull;  // whole bitmap words per range: a dense list's documents are read as words (RangeSeg::acc_off)
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(w, 1), kRangeMaxWidth);
 }
 uint32_t narrower_after_overflow(uint32_t narrow16, uint32_t excess16) {
@@ -959,6 +1020,7 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
                     g.tok_rank = (t << 10) | per_token[t];
                     g.boost = jb.refs[i].boost;
                     g.avg_len = p->avg_len[p->field_of_list[l]];
+                    g.acc_off = l < p->acc_off_of_list.size() ? p->acc_off_of_list[l] : 0;
                     virt += len;
                     segs.push_back(g);
                     if (++per_token[t] > 1) {
@@ -1063,6 +1125,8 @@ int post_search_ranges(orama_post* p, Scratch* sc, const RangeJob* jobs, uint32_
         rb.post_doc = p->d_post_doc.as<uint32_t>();
         rb.post_val = p->d_post_val.as<uint32_t>();
         rb.post_ntf = (p->ntf_valid && b == p->ntf_b) ? p->d_post_ntf.as<float>() : nullptr;
+        rb.post_acc = (rb.post_ntf && p->acc_words) ? p->d_acc.as<uint32_t>() : nullptr;
+        rb.acc_words = p->acc_words;
         rb.bounds = sc->misc1.as<uint32_t>();
         rb.docs = p->dense ? nullptr : p->d_docs.as<uint64_t>();
         rb.dense_base = p->dense_base;

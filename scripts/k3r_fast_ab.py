@@ -23,6 +23,7 @@ ranks = np.unique(np.exp(rng.uniform(np.log(100), np.log(100000), size=2048)).as
 ctx_new, ctx_old = oa.Context(0), oa.Context(0)
 ctx_old.set_option("k3r_fast", 0)
 ctx_new.set_option("k3r_fast", 1)
+ctx_new.set_option("bm25_dense_acc", 1)  # the store of this context keeps bitmaps of its longest lists (background lists)
 if len(sys.argv) > 1:  # compact lists for every batch size (single calls included) on both
     ctx_old.set_option("k3r_compact", 2)
     ctx_new.set_option("k3r_compact", 2)

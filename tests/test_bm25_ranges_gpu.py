@@ -787,6 +787,7 @@ answers = {}
 for fast in (0, 1):
     ctx = oa.Context(0)
     ctx.set_option("k3r_fast", fast)
+    ctx.set_option("bm25_dense_acc", fast)  # (bitmaps of the longest lists: what the fast body's background lists read)
     corpus = Corpus(ctx, n_docs, lists, [50.0, 8.0], seed=124)
     bm = oa.AllowBitmap(n_docs, np.arange(n_docs, dtype=np.uint64)[allow_mask])
     got = {}
