@@ -901,7 +901,8 @@ __global__ __launch_bounds__(256) void ntf_precompute_kernel(const uint32_t* __r
     }
 }
 
-// Dense-list accelerators (orama_post::d_acc, RangeSeg::acc_off).  acc_bits_kernel: every posting of an accelerated list sets its
+#if ORAMA_COMPARISON_KERNELS
+// Dense-list accelerators (orama_post::d_acc, RangeSeg::acc_off; read by bm25_ranges_fast.hip only).  acc_bits_kernel: every posting of an accelerated list sets its
 // document's bit (grid.y = the list).  acc_scan_kernel: one workgroup per list — the exclusive popcount prefix of the bitmap's
 // words (a posting's position in its list = prefix of its word + set bits below it in the word) and the smallest / largest
 // normalised tf of the list (NaN if any posting's is).
@@ -964,9 +965,11 @@ __global__ __launch_bounds__(kAccScanThreads) void acc_scan_kernel(const float* 
         minmax[2 * i + 1] = red_nan ? __builtin_nanf("") : hi;
     }
 }
+#endif
 
 }  // namespace
 
+#if ORAMA_COMPARISON_KERNELS
 int launch_acc_build(const uint32_t* post_doc, const float* post_ntf, const uint64_t* d_list_off, const uint32_t* d_acc_list, uint32_t n_acc,
                      uint32_t acc_words, uint32_t* d_acc, float* d_minmax, hipStream_t stream) {
     if (n_acc == 0) return ORAMA_OK;
@@ -976,6 +979,7 @@ int launch_acc_build(const uint32_t* post_doc, const float* post_ntf, const uint
     ORAMA_HIP_TRY(hipGetLastError());
     return ORAMA_OK;
 }
+#endif
 
 int launch_range_bounds(orama_ctx* ctx, const RangeBatch& b, hipStream_t stream) {
     if (b.total_postings == 0 || b.n_queries == 0 || b.max_bound_entries == 0) {

@@ -143,11 +143,13 @@ int launch_range_score_merge(orama_ctx* ctx, const RangeBatch& b, bool df_only, 
 #endif
 // post_ntf[i] = tf_i / ((1 - b) + b * len_i / avg_len[list of i]) for every posting of the store (list_off: n_lists + 1
 // offsets, list_avg: the average length of each list's field; both on the device).
+#if ORAMA_COMPARISON_KERNELS
 // Dense-list accelerators: for each of the n_acc lists (acc_list: list index, its postings at list_off), the bitmap of its
 // documents and the exclusive popcount prefix of the bitmap's words at d_acc + i * 2 * acc_words (zeroed by the call), and the
 // smallest / largest post_ntf of the list at d_minmax[2 i], [2 i + 1] (a NaN anywhere yields NaN).
 int launch_acc_build(const uint32_t* post_doc, const float* post_ntf, const uint64_t* d_list_off, const uint32_t* d_acc_list, uint32_t n_acc,
                      uint32_t acc_words, uint32_t* d_acc, float* d_minmax, hipStream_t stream);
+#endif
 int launch_ntf_precompute(const uint32_t* post_val, float* post_ntf, const uint64_t* d_list_off, const float* d_list_avg,
                           uint32_t n_lists, uint64_t n_postings, float b, hipStream_t stream);
 // Hybrid: the full-text score of `n` given documents (local indices) of query `qi`, by the same fold as the range kernel

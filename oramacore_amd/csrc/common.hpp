@@ -322,7 +322,7 @@ struct orama_ctx {
     uint32_t k3r_target = 0;  // (0: 7/8 of what a scoring workgroup holds — 1 792 with 256 threads)
     // comparison builds: the plain top-k batch's scoring launch by bm25_ranges_fast.hip (1) instead of bm25_ranges.hip's body (0)
     bool k3r_fast = false;
-    // dense-list accelerators of the postings store (orama_post::d_acc): built at build / append time when set.  Their only reader is
+    // comparison builds: dense-list accelerators of the postings store (orama_post::d_acc), built at build / append time when set.  Their only reader is
     // the comparison unit bm25_ranges_fast.hip (not faster: profiles/r06_k3r_fast_body.md), so the default is off
     bool bm25_dense_acc = false;
     bool select_pairs = true;        // K4: (value, index) lists in two launches ("select_pairs" 0 = histogram passes)

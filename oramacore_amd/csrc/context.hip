@@ -309,7 +309,6 @@ const CtxOption kCtxOptions[] = {
     ORAMA_OPT("f16_chunk_grow", -1, 1, c->f16_chunk_grow = (int)v),
     ORAMA_OPT("f16_grow_factor", 2, 64, c->f16_grow_factor = (int)v),
     ORAMA_OPT("two_stage_spare", 1, 4096, c->two_stage_spare = (uint32_t)v),
-    ORAMA_OPT("bm25_dense_acc", 0, 1, c->bm25_dense_acc = v != 0),           // dense-list bitmaps for postings stores built from now on (<= +6 B / posting; read by the comparison unit only)
     ORAMA_OPT("k3r_target", 0, 4096, c->k3r_target = (uint32_t)v),  // (0 = default; above what a workgroup holds: the default)
     ORAMA_OPT("bm25_ranges_hybrid", 0, 1, c->bm25_ranges_hybrid = v != 0),
     // K3r key lists: 0 = one slot per posting (round 4), 1 = compact lists for batches of >= 8 queries (default), 2 = always
@@ -317,6 +316,7 @@ const CtxOption kCtxOptions[] = {
     ORAMA_OPT("select_wide", 0, 3, c->select_wide = (int)v),                // K4 over a lone query's distances (select.hip)
     ORAMA_OPT("select_pairs", 0, 1, c->select_pairs = v != 0),
 #if ORAMA_COMPARISON_KERNELS
+    ORAMA_OPT("bm25_dense_acc", 0, 1, c->bm25_dense_acc = v != 0),           // dense-list bitmaps for postings stores built from now on (<= +6 B / posting; read by the comparison unit only)
     ORAMA_OPT("k3r_fast", 0, 1, c->k3r_fast = v != 0),                      // plain top-k batches scored by bm25_ranges_fast.hip (the r06 experiment)
     ORAMA_OPT("hybrid_device_tail", 0, 1, c->hybrid_device_tail = v != 0),  // orama_hybrid_search finishes on the device (hybrid_tail.hip)
 #else

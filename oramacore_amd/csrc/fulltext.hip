@@ -312,9 +312,13 @@ void shrink_remember(orama_post* p, const orama_term_ref* refs, uint32_t n_refs,
 // build / append that called it (a caller that retried the append would append twice: ADVICE r04).  It leaves ntf_valid
 // false — the kernels then divide themselves, same operations, same bits — and reports OK.
 // orama_post::d_acc.  Best effort: without memory for them (or on any failure) the store simply has no accelerators.
+// (Their only reader is the comparison unit bm25_ranges_fast.hip: built in the comparison flavour only.)
 void build_dense_accelerators(orama_post* p, const uint64_t* d_list_off) {
     p->acc_off_of_list.assign(p->n_lists, 0);
     p->acc_words = 0;
+#if !ORAMA_COMPARISON_KERNELS
+    (void)d_list_off;
+#else
     if (!p->ctx->bm25_dense_acc || p->n_docs < 32768 || p->n_docs > 0xffffffffull) return;
     // the longest lists first, as many as fit a budget of 6 bytes per posting of the store (+50 % at most), none under
     // n_docs / 128 postings (a word of such a list holds a posting every fourth time: reading it costs what gathering does)
@@ -359,6 +363,7 @@ void build_dense_accelerators(orama_post* p, const uint64_t* d_list_off) {
         const float lo = minmax[2 * i], hi = minmax[2 * i + 1];
         if (lo >= 0x1p-60f && hi <= 0x1p60f) p->acc_off_of_list[lists[i]] = 1 + (uint64_t)i * 2 * words;
     }
+#endif
 }
 
 int refresh_post_ntf_try(orama_post* p) {
