@@ -306,11 +306,6 @@ void shrink_remember(orama_post* p, const orama_term_ref* refs, uint32_t n_refs,
     p->shrink_hint[shrink_key(p, refs, n_refs)] = shrink;
 }
 
-// (Re)compute p->d_post_ntf for the store's current postings and average lengths.  Caller holds p->mu exclusively.
-// The table is an OPTIMISATION (two IEEE divisions less per posting and query): the postings, documents and averages are
-// committed before this runs, so a failure here — out of memory for the +4 B per posting, a HIP error — must not fail the
-// build / append that called it (a caller that retried the append would append twice: ADVICE r04).  It leaves ntf_valid
-// false — the kernels then divide themselves, same operations, same bits — and reports OK.
 // orama_post::d_acc.  Best effort: without memory for them (or on any failure) the store simply has no accelerators.
 // (Their only reader is the comparison unit bm25_ranges_fast.hip: built in the comparison flavour only.)
 void build_dense_accelerators(orama_post* p, const uint64_t* d_list_off) {
@@ -366,6 +361,11 @@ void build_dense_accelerators(orama_post* p, const uint64_t* d_list_off) {
 #endif
 }
 
+// (Re)compute p->d_post_ntf for the store's current postings and average lengths.  Caller holds p->mu exclusively.
+// The table is an OPTIMISATION (two IEEE divisions less per posting and query): the postings, documents and averages are
+// committed before this runs, so a failure here — out of memory for the +4 B per posting, a HIP error — must not fail the
+// build / append that called it (a caller that retried the append would append twice: ADVICE r04).  It leaves ntf_valid
+// false — the kernels then divide themselves, same operations, same bits — and reports OK.
 int refresh_post_ntf_try(orama_post* p) {
     ++p->mutations;
     {  // (every change of the postings comes through here: what was counted over the old lists is forgotten)
