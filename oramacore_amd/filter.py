@@ -19,7 +19,10 @@ Semantics restated from the reference, with the line that pins each:
     (tests/filter.rs:427-495);
   * string filters: equality with one of the document's values; only strings of 1..=25 bytes are indexed as filter values
     (EnumStrategy::StringLength(25), write/index/fields.rs:364-388; tests/filter.rs:913-986);
-  * bool filters: equality with one of the document's values.
+  * bool filters: equality with one of the document's values;
+  * date filters (types.rs DateFilter; tests/filter.rs:576-817): the number operators over timestamps; a string value that parses
+    as a date makes its field a DATE filter field instead of a string filter one (write/index/mod.rs:811-818).  The reference
+    parses with the `dateparser` crate (many formats); this mirror takes RFC 3339 only — what the reference's tests use.
 Across the indexes of a collection a key must be a filter field of AT LEAST ONE index, else the search fails with
 FilterFieldNotFound (search.rs:435-449): `check_filter_fields`.
 """
@@ -55,13 +58,30 @@ def _number_matches(x, flt: dict) -> bool:
     raise ValueError(f"unknown number filter {op!r}")
 
 
+def parse_date(s) -> int | None:
+    """OramaDate::try_from (types.rs:2122-2130) for RFC 3339 strings: milliseconds since the epoch, None when `s` is no date."""
+    if not isinstance(s, str) or len(s) < 10 or not (s[4:5] == "-" and s[7:8] == "-"):
+        return None
+    from datetime import datetime, timezone
+    try:
+        t = datetime.fromisoformat(s[:-1] + "+00:00" if s.endswith(("Z", "z")) else s)
+    except ValueError:
+        return None
+    if t.tzinfo is None:
+        t = t.replace(tzinfo=timezone.utc)
+    return int(round(t.timestamp() * 1000))
+
+
 def filter_kind(flt) -> str:
-    """Filter::{Bool, Number, String} as serde's untagged enum reads the JSON value (types.rs)."""
+    """Filter::{Date, Number, Bool, String} as serde's untagged enum reads the JSON value (types.rs)."""
     if isinstance(flt, bool):
         return "bool"
     if isinstance(flt, str):
         return "string"
     if isinstance(flt, dict) and len(flt) == 1 and next(iter(flt)) in ("eq", "gt", "gte", "lt", "lte", "between"):
+        arg = next(iter(flt.values()))
+        if all(isinstance(x, str) for x in _values(arg)):
+            return "date"
         return "number"
     raise ValueError(f"unsupported filter value {flt!r}")
 
@@ -84,7 +104,7 @@ def all_keys(where: dict | None) -> list[str]:
 
 class FilterContext:
     """FilterContext (filter.rs:296-392) over the mirror's `Index` (or the tests' HostIndex): bool_fields / number_fields /
-    string_filter_fields are {field name: {DocumentId: value | [values]}}, `document_ids` the live documents,
+    string_filter_fields / date_fields (timestamps) are {field name: {DocumentId: value | [values]}}, `document_ids` the live documents,
     `uncommitted_deleted_documents` the deletes since the last commit."""
 
     def __init__(self, index):
@@ -94,7 +114,7 @@ class FilterContext:
     def field_type(self, key: str) -> str | None:
         """path_to_index_id_map.get_filter_field: the type the index holds `key` as, None when it is no filter field."""
         for kind, store in (("bool", self.index.bool_fields), ("number", self.index.number_fields),
-                            ("string", self.index.string_filter_fields)):
+                            ("string", self.index.string_filter_fields), ("date", getattr(self.index, "date_fields", {}))):
             if key in store:
                 return kind
         return None
@@ -107,7 +127,15 @@ class FilterContext:
         kind = self.field_type(key)
         if kind != filter_kind(flt):
             return set()  # "Wrong filter type for ... field - return empty set"
-        store = getattr(self.index, {"bool": "bool_fields", "number": "number_fields", "string": "string_filter_fields"}[kind])[key]
+        store = getattr(self.index, {"bool": "bool_fields", "number": "number_fields", "string": "string_filter_fields",
+                                     "date": "date_fields"}[kind])[key]
+        if kind == "date":  # (values are stored as timestamps; a bound that is no date matches nothing)
+            (op, arg), = flt.items()
+            bounds = [parse_date(x) for x in _values(arg)]
+            if any(b is None for b in bounds):
+                return set()
+            ts = {op: bounds if op == "between" else bounds[0]}
+            return {d for d, v in store.items() if any(_number_matches(x, ts) for x in _values(v)) and d in self.universe}
         if kind == "bool":
             return {d for d, v in store.items() if any(x is flt for x in _values(v)) and d in self.universe}
         if kind == "number":

@@ -96,11 +96,15 @@ class Index:
     embedding_fields: dict[int, EmbeddingFieldStorage] = field(default_factory=dict)
     omc: dict[int, float] = field(default_factory=dict)
     document_ids: set = field(default_factory=set)
+    # field path -> (FieldId, type name) — path_to_field_id_map (token_score.rs:140-176): a request names its properties, every
+    # index resolves them against its OWN fields and ignores the names it does not hold as string fields
+    path_to_field_id_map: dict = field(default_factory=dict)
     # filter fields (index/{bool,number,string_filter}_field.rs) as the facet / group code reads them:
     # field name -> {doc id: value | [values]}
     bool_fields: dict = field(default_factory=dict)
     number_fields: dict = field(default_factory=dict)
     string_filter_fields: dict = field(default_factory=dict)
+    date_fields: dict = field(default_factory=dict)  # timestamps (ms): a string value that parses as a date (filter.py::parse_date)
     # deletes since the last commit: every search carries NOT(deleted) until then (index/mod.rs:1346-1424, filter.rs:352-390)
     uncommitted_deleted_documents: set = field(default_factory=set)
     _post: Optional[PostingsStore] = None
@@ -185,7 +189,7 @@ class Index:
             self.uncommitted_deleted_documents.add(d)
             for sf in self.string_fields.values():
                 sf.delete(d)
-            for store in (self.bool_fields, self.number_fields, self.string_filter_fields):
+            for store in (self.bool_fields, self.number_fields, self.string_filter_fields, self.date_fields):
                 for vals in store.values():
                     vals.pop(d, None)
             self.omc.pop(d, None)
@@ -287,7 +291,7 @@ def _levenshtein_le(a: str, b: str, k: int) -> bool:
 @dataclass
 class TokenScoreParams:
     mode: object
-    properties: Optional[list[int]] = None       # string field ids; None = all (Properties::None | Star)
+    properties: Optional[list] = None            # string field ids or NAMES (resolved per index); None = all (Properties::None | Star)
     boost: dict = field(default_factory=dict)    # field_id -> boost
     limit: int = 10                              # Limit default 10, types.rs:748-754
     offset: int = 0
@@ -328,9 +332,25 @@ class TokenScoreContext:
         out = [t for t, _ in toks] if exact else [x for t, s in toks for x in ((t,) if s is None else (t, s))]
         return out or [""]
 
+    def calculate_string_properties(self, properties) -> list[int]:
+        """token_score.rs:154-177: Properties::None | Star = every string field of the index; Specified = the given fields this
+        index holds as STRING fields (names through path_to_field_id_map; unknown names and other types are skipped — an index that
+        holds none of them searches nothing, src/tests/fulltext_search.rs:1021-1105).  Canonical order: ascending FieldId."""
+        if properties is None:
+            return sorted(self.index.string_fields)
+        out = set()
+        for f in properties:
+            if isinstance(f, str):
+                hit = self.index.path_to_field_id_map.get(f)
+                if hit is None or hit[1] != "string":
+                    continue
+                f = hit[0]
+            if f in self.index.string_fields:
+                out.add(f)
+        return sorted(out)
+
     def _refs(self, tokens, properties, boost, exact, tolerance=None):
-        fields = sorted(self.index.string_fields) if properties is None else sorted(
-            f for f in properties if f in self.index.string_fields)  # canonical order: ascending FieldId
+        fields = self.calculate_string_properties(properties)
         refs = []
         for ti, tok in enumerate(tokens):
             for fid in fields:

@@ -5,7 +5,7 @@ import numpy as np
 
 import refcases
 from oracle import oracle as orc
-from oramacore_amd.filter import FilterContext, FilterFieldNotFound, check_filter_fields
+from oramacore_amd.filter import FilterContext, FilterFieldNotFound, check_filter_fields, parse_date
 from oramacore_amd.token_score import StringFieldStorage
 
 
@@ -40,6 +40,10 @@ def _is_string_value(v):
     return all(isinstance(x, str) for x in _vals(v)) and len(_vals(v)) > 0
 
 
+class UnknownIndex(Exception):
+    """ReadError::UnknownIndex: a request names an index the collection does not hold (src/tests/fulltext_search.rs:459-473)."""
+
+
 class Collection:
     """The case's collection.  `make_index()` -> HostIndex (CPU) or the mirror's Index (GPU); `on_insert(idx, [doc ids])`,
     `on_commit(idx)` let the GPU harness keep the device in step (delta lists / rebuild)."""
@@ -65,6 +69,8 @@ class Collection:
                         names.append(k)
             for fi in range(len(names)):
                 idx.string_fields[fi] = StringFieldStorage()
+            if hasattr(idx, "path_to_field_id_map"):  # (the mirror's Index resolves property NAMES itself)
+                idx.path_to_field_id_map.update({n: (fi, "string") for fi, n in enumerate(names)})
             self.indexes.append(idx)
             self.ids.append({})
             self.docs.append({})
@@ -87,13 +93,23 @@ class Collection:
         ids[sid] = n
         self.docs[ii][sid] = dict(doc)
         idx.document_ids.add(n)
+        omc = doc.get("_omc")  # write/index/mod.rs:451-458: only positive numbers are multipliers
+        if isinstance(omc, (int, float)) and not isinstance(omc, bool) and omc > 0:
+            idx.omc[n] = float(omc)
         for k, v in doc.items():
-            if k == "id":
+            if k in ("id", "_omc"):
                 continue
             vals = _vals(v)
             if _is_string_value(v):
                 idx.string_fields[self.fields[ii].index(k)].insert(n, " ".join(vals))
-                idx.string_filter_fields.setdefault(k, {})[n] = v
+                # the FILTER field of a string value: a date field when the value parses as a date, else a string filter field
+                # (write/index/mod.rs:811-818; the field's type is that of its first value)
+                dates = [parse_date(x) for x in vals]
+                if k in idx.date_fields or (k not in idx.string_filter_fields and all(t is not None for t in dates)):
+                    if all(t is not None for t in dates):
+                        idx.date_fields.setdefault(k, {})[n] = dates if isinstance(v, list) else dates[0]
+                else:
+                    idx.string_filter_fields.setdefault(k, {})[n] = v
             elif all(isinstance(x, bool) for x in vals):
                 idx.bool_fields.setdefault(k, {})[n] = v
             elif all(isinstance(x, (int, float)) and not isinstance(x, bool) for x in vals):
@@ -125,15 +141,26 @@ class Collection:
                     return sid
         raise KeyError(doc_id)
 
+    def searched_indexes(self, p):
+        """`indexes` of a request: absent or empty = every index of the collection; an ordinal the collection does not hold is
+        ReadError::UnknownIndex (collection level, before any index is asked)."""
+        want = p.get("indexes") or list(range(len(self.indexes)))
+        for ii in want:
+            if not (isinstance(ii, int) and 0 <= ii < len(self.indexes)):
+                raise UnknownIndex(ii)
+        return want
+
     # ---- the oracle's answer: (hits [(doc, score)], count) over all indexes
     def oracle_search(self, p):
         where = p.get("where")
-        check_filter_fields(self.indexes, where)
+        want = self.searched_indexes(p)
+        check_filter_fields([self.indexes[ii] for ii in want], where)
         docs, scores = [], []
-        for ii, idx in enumerate(self.indexes):
+        for ii in want:
+            idx = self.indexes[ii]
             if idx.document_count == 0:
                 continue
-            q = {k: v for k, v in p.items() if k != "where"}
+            q = {k: v for k, v in p.items() if k not in ("where", "indexes")}
             if "properties" in q:
                 q["properties"] = [n for n in q["properties"] if n in self.fields[ii]]
             allowed = FilterContext(idx).allowed_set(where)
@@ -158,6 +185,12 @@ def check_expect(col, hits, count, exp):
     if "hit_ids_mod" in exp:
         m, r = exp["hit_ids_mod"]
         assert all(int(col.string_id(h[0])) % m == r for h in hits), hits
+    if "min_score_gt" in exp:
+        assert all(h[1] > exp["min_score_gt"] for h in hits), hits
+    if "score_ratio" in exp:  # assert_approx_eq!(a.score, b.score * value, tol)
+        r = exp["score_ratio"]
+        by_id = {col.string_id(h[0]): h[1] for h in hits}
+        assert abs(by_id[r["num"]] - by_id[r["den"]] * r["value"]) < r["tol"], (by_id, r)
 
 
 def run_case(case, make_collection, search):
@@ -169,13 +202,14 @@ def run_case(case, make_collection, search):
             col.apply(step)
             continue
         exp = step["expect"]
-        if exp.get("error") == "FilterFieldNotFound":
+        if exp.get("error") in ("FilterFieldNotFound", "UnknownIndex"):
+            kind = FilterFieldNotFound if exp["error"] == "FilterFieldNotFound" else UnknownIndex
             for fn in (lambda: col.oracle_search(step["params"]), lambda: search(col, step["params"])):
                 try:
                     fn()
-                except FilterFieldNotFound:
+                except kind:
                     continue
-                raise AssertionError("expected FilterFieldNotFound")
+                raise AssertionError("expected " + exp["error"])
             continue
         o_hits, o_count = col.oracle_search(step["params"])
         check_expect(col, o_hits, o_count, exp)

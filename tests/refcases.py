@@ -13,7 +13,7 @@ class HostIndex:
 
     def __init__(self):
         self.string_fields, self.omc, self.document_ids = {}, {}, set()
-        self.bool_fields, self.number_fields, self.string_filter_fields = {}, {}, {}
+        self.bool_fields, self.number_fields, self.string_filter_fields, self.date_fields = {}, {}, {}, {}
         self.uncommitted_deleted_documents = set()
 
     def delete_documents(self, doc_ids):
@@ -25,7 +25,7 @@ class HostIndex:
             self.document_ids.discard(d)
             for sf in self.string_fields.values():
                 sf.delete(d)
-            for store in (self.bool_fields, self.number_fields, self.string_filter_fields):
+            for store in (self.bool_fields, self.number_fields, self.string_filter_fields, self.date_fields):
                 for vals in store.values():
                     vals.pop(d, None)
             self.omc.pop(d, None)

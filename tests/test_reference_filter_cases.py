@@ -1,5 +1,7 @@
 """The reference's filter / multi-index / update tests as data (tests/golden/reference_filter_cases.json: src/tests/filter.rs,
-multi_index.rs, update_docs.rs, replace_doc_on_insert.rs, bugs.rs, commit.rs) through the CPU restatement: the host-side filter
+multi_index.rs, update_docs.rs, replace_doc_on_insert.rs, bugs.rs, commit.rs, and — second half of round 6 — fulltext_search.rs
+(`indexes`, property names per index, commit / reload), omc_test.rs (multipliers under commit / delete / replace), delete_doc.rs)
+through the CPU restatement: the host-side filter
 materialiser (oramacore_amd/filter.py <-> index/filter.rs:33-392) produces the document set, the oracle scores what passes.
 tests/test_reference_filter_cases_gpu.py runs the same cases through the kernels."""
 import pytest
@@ -14,10 +16,11 @@ CASES = DOC["cases"]
 
 
 def test_every_case_cites_the_reference():
-    assert len(CASES) >= 17 and sum(1 for c in CASES for s in c["steps"] if s["op"] == "search") >= 40
+    assert len(CASES) >= 26 and sum(1 for c in CASES for s in c["steps"] if s["op"] == "search") >= 74
     files = {c["reference"].split(":")[0] for c in CASES}
     assert {"src/tests/filter.rs", "src/tests/multi_index.rs", "src/tests/update_docs.rs", "src/tests/replace_doc_on_insert.rs",
-            "src/tests/bugs.rs", "src/tests/commit.rs"} <= files
+            "src/tests/bugs.rs", "src/tests/commit.rs", "src/tests/fulltext_search.rs", "src/tests/omc_test.rs",
+            "src/tests/delete_doc.rs"} <= files
     for c in CASES:
         assert c["constrains"] and c["indexes"] and c["steps"], c["name"]
 
@@ -43,6 +46,13 @@ def test_filter_tree_rules():
     assert fc.allowed_set({"n": {"between": [2.5, 4]}}) == {2, 3, 4} and fc.allowed_set({"n": {"gt": 4}}) == {3}
     assert fc.allowed_set({"s": "a"}) == {1, 3} and fc.allowed_set({"s": "x" * 26}) == set()   # over 25 bytes: not a filter value
     assert fc.allowed_set({"b": {"eq": 1}}) == set() and fc.allowed_set({"n": True}) == set()  # wrong filter type: empty
+    idx.date_fields["d"] = {1: flt.parse_date("2024-02-29T12:00:00Z"), 2: flt.parse_date("2024-03-01T00:00:00+01:00"), 3: [0, 10**13]}
+    fc = flt.FilterContext(idx)
+    assert fc.allowed_set({"d": {"gte": "2024-02-29T23:00:00Z"}}) == {2, 3} and fc.allowed_set({"d": {"eq": "2024-02-29T12:00:00Z"}}) == {1}
+    assert fc.allowed_set({"d": {"gt": 5}}) == set() and fc.allowed_set({"n": {"gt": "2024-01-01T00:00:00Z"}}) == set()  # number <-> date: empty
+    assert fc.allowed_set({"d": {"lt": "not a date"}}) == set() and flt.parse_date("machine learning") is None
+    del idx.date_fields["d"]
+    fc = flt.FilterContext(idx)
     assert fc.allowed_set({"nope": True}) == set()                                # unknown key: the whole level is empty
     assert fc.allowed_set({"or": []}) == set() and fc.allowed_set({"and": []}) == set()
     assert fc.allowed_set({"b": True, "n": {"lt": 4}}) == {1, 3}                  # entries of a level are AND-ed

@@ -40,12 +40,10 @@ def test_reference_filter_case_through_the_hip_path(case, live):
             return col
 
         def search(col, p):
-            tscs = [TokenScoreContext(idx) for idx in col.indexes]
-            names = p.get("properties")
-            # (`properties` by name: the cases that use it hold one index; field ids are per index)
-            props = None if names is None else [col.fields[0].index(n) for n in names if n in col.fields[0]]
+            tscs = [TokenScoreContext(col.indexes[ii]) for ii in col.searched_indexes(p)]
+            # (`properties` by NAME: every index resolves them against its own fields — token_score.rs:154-177)
             params = TokenScoreParams(mode=FulltextMode(p["term"]), limit=p.get("limit", 10), offset=p.get("offset", 0),
-                                      properties=props, where_filter=p.get("where"))
+                                      properties=p.get("properties"), where_filter=p.get("where"))
             return search_on_indexes(tscs, params)
 
         col = filtercases.run_case(case, make, search)
