@@ -122,6 +122,11 @@ class Index:
         field_ids = sorted(self.string_fields)
         lists, self._lists, self._terms, self._delta_terms = [], {}, {}, {}
         self.uncommitted_deleted_documents = set()  # the rebuild holds live documents only
+        if len(docs) == 0:  # an index without documents holds nothing resident (searches skip it: document_count == 0)
+            if self._post is not None:
+                self._post.close()
+                self._post = None
+            return
         for fi, fid in enumerate(field_ids):
             sf = self.string_fields[fid]
             self._terms[fid] = sorted(sf.postings)
@@ -426,6 +431,10 @@ def facets_and_groups(tsc: "TokenScoreContext", params: TokenScoreParams, facets
     if not isinstance(m, FulltextMode):
         raise TypeError("facets_and_groups mirrors the full-text path (the vector map is <= limit entries on the host)")
     idx = tsc.index
+    if idx.document_count == 0:
+        # an index without documents scores nothing, holds no filter field and forms no group (src/tests/groupby.rs:950-982,
+        # multi_index.rs:88-167): nothing to launch
+        return [], 0, {}, {}
     tokens = tsc._tokens(m.term, m.exact)
     thr = None if m.threshold is None else threshold_tokens(len(tokens), m.threshold)
     refs = tsc._refs(tokens, params.properties, params.boost, m.exact, m.tolerance)
@@ -483,6 +492,18 @@ def facets_and_groups(tsc: "TokenScoreContext", params: TokenScoreParams, facets
     finally:
         sm.close()
     return hits, count, facet_results, group_results
+
+
+class FacetFieldNotFound(KeyError):
+    """ReadError::FacetFieldNotFound (read/mod.rs:148)."""
+
+
+def check_facet_results(requested, facets_results: dict) -> None:
+    """search.rs:452-463: after the facets of every searched index were added up, a requested facet that NO index produced (each
+    index skips the names it does not hold, facet.rs:159-163) fails the search with the missing names."""
+    missing = [name for name in requested if name not in facets_results]
+    if missing:
+        raise FacetFieldNotFound(missing)
 
 
 def search_on_indexes(contexts: list, params: TokenScoreParams):

@@ -252,6 +252,16 @@ def add_facets(total, part):
 
 
 def check_facets(case, got):
+    if case["expect"].get("error") == "FacetFieldNotFound":  # search.rs:452-463, over the collection's summed facets
+        from oramacore_amd.token_score import FacetFieldNotFound, check_facet_results
+        try:
+            check_facet_results(case["facets"], got)
+        except FacetFieldNotFound as e:
+            assert list(e.args[0]) == case["expect"]["missing"]
+            return
+        raise AssertionError("expected FacetFieldNotFound")
+    from oramacore_amd.token_score import check_facet_results
+    check_facet_results(case["facets"], got)
     for name, exp in case["expect"].items():
         assert name in got, (case["name"], name)
         assert got[name]["values"] == exp["values"], (case["name"], name, got[name]["values"])
@@ -293,9 +303,13 @@ def oracle_groups(idx, map_docs, map_scores, properties, max_results):
     return {c: list(zip(i_[: int(n_)].tolist(), s_[: int(n_)].tolist())) for c, i_, s_, n_ in zip(combos, g_ids, g_sc, g_n)}
 
 
-def check_groups(spec, groups, ids, hits=None):
+def check_groups(spec, groups, ids, hits=None, count=None):
     """`groups`: {tuple(values): [(doc, score)]}; the reference lists only groups... of every combination (empty ones included)."""
     exp = spec["expect"]
+    if "n_groups" in exp:
+        assert len(groups) == exp["n_groups"], sorted(groups, key=str)
+    if "count" in exp and count is not None:
+        assert count == exp["count"]
     back = {v: k for k, v in ids.items()}
     norm = lambda v: tuple(float(x) if isinstance(x, (int, float)) and not isinstance(x, bool) else x for x in v)
     if "group_values" in exp:

@@ -93,4 +93,4 @@ def test_oracle_forms_the_groups_the_reference_asserts(case):
         mr = 1 if g["max_results"] is None else g["max_results"]  # default_group_by_max_results, types.rs:1473-1475
         groups = refcases.oracle_groups(idx, docs, scores, g["properties"], mr)
         td, ts = orc.top_n(docs, scores, 10)
-        refcases.check_groups(spec, groups, ids, hits=list(zip(td.tolist(), ts.tolist())))
+        refcases.check_groups(spec, groups, ids, hits=list(zip(td.tolist(), ts.tolist())), count=len(docs))

@@ -100,7 +100,7 @@ def test_reference_group_case_through_the_hip_path(case):
             mr = 1 if g["max_results"] is None else g["max_results"]  # default_group_by_max_results, types.rs:1473-1475
             params = TokenScoreParams(mode=FulltextMode(spec["term"]), limit=10)
             hits, count, _, groups = facets_and_groups(tsc, params, group_by=(g["properties"], mr))
-            refcases.check_groups(spec, groups, ids, hits=hits)
+            refcases.check_groups(spec, groups, ids, hits=hits, count=count)
             od, os_ = refcases.oracle_search(idx, {"term": spec["term"]}, case["fields"])
             mine = refcases.oracle_groups(idx, od, os_, g["properties"], mr)
             assert set(groups) == set(mine)
