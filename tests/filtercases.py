@@ -53,6 +53,7 @@ class Collection:
         self.on_insert, self.on_commit = on_insert or (lambda idx, ids: None), on_commit or (lambda idx: None)
         self.next_doc, self.auto = 1, 0
         self.indexes, self.ids, self.docs, self.fields = [], [], [], []
+        self.deleted_indexes = set()
         later = {}
         for st in case["steps"]:
             if st.get("op") in ("insert", "update_merge"):
@@ -128,6 +129,8 @@ class Collection:
             ii = step["index"]
             merged = [{**self.docs[ii][d["id"]], **d} for d in step["documents"]]
             self.on_insert(self.indexes[ii], [self._insert_host(ii, d) for d in merged])
+        elif op == "delete_index":
+            self.deleted_indexes.add(step["index"])
         elif op == "delete":
             ii = step["index"]
             self.indexes[ii].delete_documents([self.ids[ii][s] for s in step["ids"] if s in self.ids[ii]])
@@ -148,7 +151,9 @@ class Collection:
         for ii in want:
             if not (isinstance(ii, int) and 0 <= ii < len(self.indexes)):
                 raise UnknownIndex(ii)
-        return want
+        # a DELETED index named by the request passes the validation and is skipped by the search loop
+        # (src/tests/multi_index.rs:278-348: the reference accepts that outcome)
+        return [ii for ii in want if ii not in self.deleted_indexes]
 
     # ---- the oracle's answer: (hits [(doc, score)], count) over all indexes
     def oracle_search(self, p):

@@ -16,7 +16,7 @@ CASES = DOC["cases"]
 
 
 def test_every_case_cites_the_reference():
-    assert len(CASES) >= 26 and sum(1 for c in CASES for s in c["steps"] if s["op"] == "search") >= 74
+    assert len(CASES) >= 27 and sum(1 for c in CASES for s in c["steps"] if s["op"] == "search") >= 75
     files = {c["reference"].split(":")[0] for c in CASES}
     assert {"src/tests/filter.rs", "src/tests/multi_index.rs", "src/tests/update_docs.rs", "src/tests/replace_doc_on_insert.rs",
             "src/tests/bugs.rs", "src/tests/commit.rs", "src/tests/fulltext_search.rs", "src/tests/omc_test.rs",
