@@ -106,8 +106,12 @@ def parse_resource_remarks(stderr: str) -> tuple[list[dict], str]:
     kernels: list[dict] = []
     rest = []
     in_remark = False
-    for line in stderr.splitlines():
+    lines = stderr.splitlines()
+    for li, line in enumerate(lines):
         m = _REMARK.search(line)
+        if not m and line.startswith("In file included from") and li + 1 < len(lines) and (
+                _REMARK.search(lines[li + 1]) or lines[li + 1].startswith("In file included from")):
+            continue  # the include chain printed in front of a remark about a kernel of an included file (select_wide.hip)
         if not m:
             if "[-Rpass-analysis=kernel-resource-usage]" in line:
                 in_remark = True
