@@ -67,3 +67,24 @@ def test_filter_tree_rules():
     assert flt.all_keys({"a": 1, "and": [{"b": 2}, {"or": [{"c": 3}]}], "not": {"d": 4}}) == ["a", "b", "c", "d"]
     with pytest.raises(flt.FilterFieldNotFound):
         flt.check_filter_fields([idx], {"and": [{"b": True}, {"zzz": True}]})
+
+
+def test_property_names_resolve_per_index_and_missing_facets_fail():
+    """Host logic of the mirror that needs no device: calculate_string_properties (token_score.rs:154-177) and the collection-level
+    facet check (search.rs:452-463)."""
+    from types import SimpleNamespace
+
+    from oramacore_amd.token_score import FacetFieldNotFound, StringFieldStorage, TokenScoreContext, check_facet_results
+
+    idx = SimpleNamespace(string_fields={0: StringFieldStorage(), 2: StringFieldStorage()},
+                          path_to_field_id_map={"title": (0, "string"), "body": (2, "string"), "price": (1, "number")})
+    tsc = TokenScoreContext(idx)
+    assert tsc.calculate_string_properties(None) == [0, 2]                       # Properties::None | Star
+    assert tsc.calculate_string_properties(["body", "title"]) == [0, 2]          # canonical order: ascending FieldId
+    assert tsc.calculate_string_properties(["body", "nope", "price"]) == [2]     # unknown names and non-string fields are skipped
+    assert tsc.calculate_string_properties(["nope"]) == []                       # nothing left: the index searches nothing
+    assert tsc.calculate_string_properties([2, 7, "title"]) == [0, 2]            # field ids still work (7: not a field of this index)
+    check_facet_results({"a": "bool"}, {"a": {"count": 0, "values": {}}})
+    with pytest.raises(FacetFieldNotFound) as e:
+        check_facet_results({"a": "bool", "b": "string", "c": "string"}, {"b": {}})
+    assert list(e.value.args[0]) == ["a", "c"]
